@@ -1,0 +1,282 @@
+/*
+ * svo.h — C-ABI drop-in boundary of the MI355X-native stereo-VO hot path.
+ *
+ * Every entry point replaces one call the reference's ImageProcessor /
+ * FeatureTracker / BundleAdjuster make into OpenCV / Ceres (reference
+ * file:line is cited on each declaration; paths are relative to the
+ * reference repository root).  Plain pointers and sizes only: no C++ types,
+ * no torch types.  All functions return 0 (SVO_OK) on success and a negative
+ * svo_status otherwise; nothing ever throws across this boundary.  The
+ * reference's own error convention is "void + early return" (SURVEY §8b), so a
+ * C++ adapter maps a non-zero status to "skip this frame".
+ *
+ * Memory spaces: functions without a suffix take caller-owned HOST pointers
+ * (the boundary the reference classes would bind); functions ending in `_dev`
+ * take DEVICE pointers (HBM resident; what the in-library pipeline and
+ * bench.py use) and are asynchronous on svo_stream(ctx) unless stated.
+ *
+ * Threading: one caller thread per context (the reference's vo_node is
+ * single-threaded, src/vo_node.cpp:139-227).
+ */
+#ifndef SVO_H_
+#define SVO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum svo_status {
+  SVO_OK = 0,
+  SVO_ERR_INVALID = -1,   /* bad argument / shape */
+  SVO_ERR_HIP = -2,       /* a HIP runtime call failed (see svo_last_error) */
+  SVO_ERR_CAPACITY = -3,  /* a workspace bound given at svo_create was exceeded */
+  SVO_ERR_NO_DEVICE = -4, /* no gfx950 device visible */
+  SVO_ERR_NUMERIC = -5    /* singular system / non-finite value */
+} svo_status;
+
+/* Mirrors struct CameraInfo, src/camera_info.hpp:4-18 (same field order, so a
+ * reference CameraInfo can be reinterpret_cast). k1..p2 are never read. */
+typedef struct svo_camera_info {
+  double focal, cx, cy;
+  double k1, k2, p1, p2;
+  double baseline;
+} svo_camera_info;
+
+typedef struct svo_ctx svo_ctx;
+
+/* Limits fixed at context creation (workspace is allocated once; no
+ * allocation happens on the hot path). */
+typedef struct svo_limits {
+  int max_width, max_height; /* largest image */
+  int max_batch;             /* frames per batched front-end call */
+  int max_corners;           /* corners returned per image (ref: 300, src/image_processor.cpp:22) */
+  int max_candidates;        /* NMS survivors per image before min-distance selection */
+  int max_features;          /* tracked features per frame (ref: 400, src/bundle_adjuster.hpp:75) */
+} svo_limits;
+
+int svo_create(svo_ctx** out, int device, const svo_limits* limits);
+void svo_destroy(svo_ctx* ctx);
+const char* svo_last_error(const svo_ctx* ctx);
+/* hipStream_t the context launches on (as void*). */
+void* svo_stream(svo_ctx* ctx);
+int svo_sync(svo_ctx* ctx);
+/* library build tag; "gfx950" must appear in it. */
+const char* svo_version(void);
+
+/* ------------------------------------------------------------------ a11 --
+ * Batched ReprojectionFactor::Evaluate (src/reprojection_factor.cpp:10-88).
+ * pose7 = [qw qx qy qz tx ty tz] (src/bundle_adjuster.hpp:50), n of them;
+ * point3, obs2 likewise.  r2: n x 2.  jpose14: n x (2x7 row-major) or NULL;
+ * jpoint6: n x (2x3 row-major) or NULL (Ceres' null conventions,
+ * src/reprojection_factor.cpp:58-59,77).  Entries 5 and 11 of each 2x7 are 0
+ * (src/reprojection_factor.cpp:61). */
+int svo_reproj_eval(svo_ctx* ctx, int n, const double* pose7, const double* point3,
+                    const double* obs2, double focal, double cx, double cy,
+                    double* r2, double* jpose14, double* jpoint6);
+int svo_reproj_eval_dev(svo_ctx* ctx, int n, const double* pose7, const double* point3,
+                        const double* obs2, double focal, double cx, double cy,
+                        double* r2, double* jpose14, double* jpoint6);
+
+/* ------------------------------------------------------------------- a1 --
+ * cv::goodFeaturesToTrack(img, out, max_corners, quality, min_distance)
+ * with defaults blockSize=3, useHarris=false, no mask
+ * (call site src/image_processor.cpp:22; semantics SURVEY Appendix A.1).
+ * xy: max_corners x 2 floats (integer-valued pixel coords, strongest first);
+ * *n receives the count.  Batched form: images are `image_stride` bytes
+ * apart, rows `row_stride` bytes apart; xy is batch x max_corners x 2,
+ * n is batch ints. */
+int svo_corner_detect(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride,
+                      int max_corners, double quality, double min_distance,
+                      float* xy, int* n);
+int svo_corner_detect_batch_dev(svo_ctx* ctx, const uint8_t* imgs, int batch, int width, int height,
+                                int row_stride, size_t image_stride, int max_corners,
+                                double quality, double min_distance, float* xy, int* n);
+/* Debug/parity taps of the same path: the min-eigenvalue map (float, width*height)
+ * produced by the response kernel. Host pointers. */
+int svo_corner_response(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride,
+                        float* eig);
+
+/* ------------------------------------------------------------------- a7 --
+ * cv::StereoBM::create(num_disp, block)->compute(L,R) + convertTo(CV_32F,1/16)
+ * (src/image_processor.cpp:173-176; defaults XSOBEL cap 31,
+ * minDisparity 0, textureThreshold 10, uniquenessRatio 15).
+ * Dense form writes the CV_16S map (4 fractional bits, FILTERED = -16).
+ * Sparse form evaluates exactly the same function only at (int)y,(int)x of
+ * each point (what src/image_processor.cpp:193 samples) and returns the
+ * float disparity (-1.0 = filtered). */
+int svo_stereo_bm(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width, int height,
+                  int row_stride, int num_disparities, int block_size, int16_t* disp16);
+int svo_stereo_disparity_at(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width,
+                            int height, int row_stride, int num_disparities, int block_size,
+                            const float* xy, int n, float* disp);
+int svo_stereo_disparity_at_dev(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width,
+                                int height, int row_stride, int num_disparities, int block_size,
+                                const float* xy, const int* n_dev, int n_max, float* disp);
+
+/* ------------------------------------------------------------------- a8 --
+ * ImageProcessor::triangulate_stereo's reprojection loop
+ * (src/image_processor.cpp:178-207): keep i iff disp[i] > 0; X = pose * Q * [x y d 1]^T,
+ * de-homogenised.  pose16: row-major 4x4 float camera->world.  Output order =
+ * input order (stable).  kept_xy: n x 2, xyz: n x 3, kept_index: n (index into the
+ * input list) or NULL. */
+int svo_triangulate(svo_ctx* ctx, const float* xy, const float* disp, int n, const float* pose16,
+                    float focal, float cx, float cy, float baseline,
+                    float* kept_xy, float* xyz, int* kept_index, int* n_kept);
+
+/* ------------------------------------------------------------------- a3 --
+ * cv::calcOpticalFlowPyrLK(prev, next, pts, out, status, err, Size(21,21), 3,
+ * TermCriteria(COUNT+EPS,30,0.01), 0, 1e-2)
+ * (src/feature_tracker.cpp:23-26).  out: n x 2, status: n bytes. */
+int svo_lk_track(svo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height,
+                 int row_stride, const float* xy, int n, float* out_xy, uint8_t* status);
+/* The 4-level pyramid the tracker uses (pyrDown chain), for parity taps.
+ * levels: concatenated level images, level l has size ((w+2^l-1)>>l) x ((h+2^l-1)>>l), tight rows. */
+int svo_build_pyramid(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride,
+                      uint8_t* levels, size_t levels_bytes);
+
+/* FeatureTracker::track_features (src/feature_tracker.cpp:18-67) as one call:
+ * forward + backward LK and the survivor / parallax filter.
+ * initial_xy[i] is the keyframe position of feature i (initial_features.at(id)).
+ * Outputs: kept_xy (n x 2), kept_index (n; index into the input list, ascending),
+ * *n_kept, *av_parallax (sum over kept / n, src/feature_tracker.cpp:59,63),
+ * *percent_lost is left to the caller (needs |initial_features|, :64). */
+int svo_track_features(svo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width,
+                       int height, int row_stride, const float* xy, const float* initial_xy, int n,
+                       float* kept_xy, int* kept_index, int* n_kept, float* av_parallax);
+
+/* ------------------------------------------------------------------- a6 --
+ * new-vs-tracked dedup loop (src/image_processor.cpp:113-128): keep detected[i]
+ * iff no tracked[j] has sqrt(dx^2+dy^2) < min_distance. Stable order. */
+int svo_dedup(svo_ctx* ctx, const float* detected_xy, int n_detected, const float* tracked_xy,
+              int n_tracked, float min_distance, float* kept_xy, int* n_kept);
+
+/* ------------------------------------------------------------------- a5 --
+ * cv::solvePnPRansac(obj, img, K, 0, rvec, tvec, true, iters, reproj_err, conf, inliers)
+ * (src/image_processor.cpp:76-80).  Deterministic restatement:
+ * fixed-seed hypothesis sampling, Gauss-Newton minimal solves from the extrinsic
+ * guess, inlier test err^2 <= reproj_err^2, refinement on the inliers.
+ * rvec3/tvec3 are in/out doubles; inliers: n ints (ascending), *n_inliers. */
+int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, int n, float focal, float cx,
+                   float cy, double* rvec3, double* tvec3, int iterations, float reproj_err,
+                   double confidence, int* inliers, int* n_inliers);
+
+/* ------------------------------------------------------------ a9,a10,a12,a13 --
+ * Sliding-window bundle adjustment (src/bundle_adjuster.cpp:5-163).
+ * The graph lives on the device; ids are assigned exactly as the reference does
+ * (sequential in creation order, SURVEY C-3). */
+typedef struct svo_ba svo_ba;
+
+typedef struct svo_ba_options {
+  int max_iterations;      /* Ceres default 50 */
+  double max_time_s;       /* reference: 0.1 (src/bundle_adjuster.cpp:11); <=0 disables (parity runs) */
+  double function_tolerance, gradient_tolerance, parameter_tolerance; /* 1e-6, 1e-10, 1e-8 */
+  double initial_radius;   /* 1e4 */
+  int max_features;        /* per keyframe; reference 400 (src/bundle_adjuster.hpp:75) */
+} svo_ba_options;
+
+typedef struct svo_ba_summary {
+  int iterations, successful_steps, termination; /* 0 conv, 1 no-conv(iter/time), 2 failure */
+  double initial_cost, final_cost;
+  double solve_ms;
+} svo_ba_summary;
+
+typedef int (*svo_allreduce_fn)(void* dev_ptr, size_t n_doubles, void* user);
+
+void svo_ba_default_options(svo_ba_options* o);
+int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const svo_camera_info* cam,
+                  const svo_ba_options* opt, int max_landmarks, int max_observations);
+void svo_ba_destroy(svo_ba* ba);
+/* BundleAdjuster::add_keyframe (src/bundle_adjuster.cpp:60-135). pose7 from the
+ * keyframe's (orientation, position) floats widened to double (:63-70).
+ * tracked_ids/tracked_xy: n_tracked observations of existing landmarks;
+ * new_xy/new_xyz: n_new fresh landmarks, truncated to max_features-n_tracked
+ * (:85-90); new_ids receives the ids assigned, *n_new_out the surviving count. */
+int svo_ba_add_keyframe(svo_ba* ba, const double* pose7, const int64_t* tracked_ids,
+                        const float* tracked_xy, int n_tracked, const float* new_xy,
+                        const float* new_xyz, int n_new, int64_t* new_ids, int* n_new_out);
+/* BundleAdjuster::bundle_adjust (src/bundle_adjuster.cpp:137-157): no-op unless a
+ * keyframe was added since the last solve. */
+int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary);
+/* pose of window slot k (0 = oldest, -1 = newest). */
+int svo_ba_get_pose(svo_ba* ba, int k, double* pose7);
+int svo_ba_window_count(svo_ba* ba);
+/* BundleAdjuster::get_world_points (src/bundle_adjuster.cpp:159-163): double->float gather. */
+int svo_ba_get_points(svo_ba* ba, const int64_t* ids, int n, float* xyz);
+
+/* Bulk problem interface (synthetic BA of BASELINE config 4; also what a
+ * sharded rank loads): poses K x 7 (pose 0 constant), points N x 3, observations
+ * sorted by landmark: obs_pose/obs_point/obs_uv.  In a sharded run every rank
+ * loads all poses and only its own landmarks; `allreduce` (may be NULL for one
+ * rank) is called on a device buffer of doubles once or twice per LM iteration
+ * and must sum it in place over all ranks (RCCL all-reduce). */
+int svo_ba_load_problem(svo_ba* ba, int n_poses, const double* poses7, int n_points,
+                        const double* points3, int n_obs, const int32_t* obs_pose,
+                        const int32_t* obs_point, const double* obs_uv);
+int svo_ba_set_allreduce(svo_ba* ba, svo_allreduce_fn fn, void* user);
+int svo_ba_solve_problem(svo_ba* ba, svo_ba_summary* summary);
+int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3);
+
+/* ---------------------------------------------------------------- pipeline --
+ * ImageProcessor::process + BundleAdjuster::bundle_adjust for a batch of
+ * consecutive frames already resident in HBM (src/image_processor.cpp:18-163,
+ * driver loop src/vo_node.cpp:141-148).  Stateless stages (a1, pyramids) are
+ * batched over the frames; the sequential chain runs per frame.  Results are
+ * identical to frame-by-frame processing. */
+typedef struct svo_pipeline svo_pipeline;
+typedef struct svo_pipeline_params {
+  svo_camera_info cam;
+  int width, height;
+  int max_corners;            /* 300 */
+  double quality;             /* 0.1 */
+  float min_feature_distance; /* 30 (src/vo_node.cpp:34) */
+  float parallax_thresh;      /* 20 (src/vo_node.cpp:33) */
+  int window_size;            /* 5  (src/vo_node.cpp:36) */
+  int max_features;           /* 400 */
+  int ba_max_iterations;      /* 50 */
+  double ba_max_time_s;       /* 0.1; <=0 disables */
+} svo_pipeline_params;
+
+typedef struct svo_frame_result {
+  int n_detected, n_tracked, n_inliers, n_new;
+  int is_keyframe;       /* 1 if this frame became a keyframe */
+  float av_parallax, percent_lost;
+  double pose7[7];       /* last keyframe pose (world wrt camera) after bundle_adjust */
+  int ba_iterations;
+} svo_frame_result;
+
+void svo_pipeline_default_params(svo_pipeline_params* p);
+int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_pipeline_params* p);
+void svo_pipeline_destroy(svo_pipeline* p);
+int svo_pipeline_reset(svo_pipeline* p);
+/* left/right: batch images, tight rows (row stride = width), image stride = width*height. */
+int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* left, const uint8_t* right,
+                                   int batch, svo_frame_result* results);
+int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, const uint8_t* right,
+                               int batch, svo_frame_result* results);
+/* Feature-set taps for parity tests: ids + positions the tracker holds after the last frame. */
+int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n);
+
+/* ------------------------------------------------------------- synthetic data --
+ * Deterministic KITTI-shaped stereo stream: integer PRNG, ray-cast
+ * textured billboards; host buffers; bit-identical on every host. Not part of the
+ * reference; test/bench input only. */
+typedef struct svo_synth_params {
+  uint64_t seed;
+  int width, height;
+  double focal, cx, cy, baseline;
+  double step_z, step_x, yaw_per_frame; /* camera motion per frame */
+  int n_billboards;
+} svo_synth_params;
+void svo_synth_default_params(svo_synth_params* p, int width, int height);
+int svo_synth_render(const svo_synth_params* p, int frame, uint8_t* left, uint8_t* right);
+/* ground-truth camera-in-world pose of `frame` as 3x4 row-major [R|t] (KITTI poses row format,
+ * src/kitti_node.cpp:47-50). */
+int svo_synth_pose(const svo_synth_params* p, int frame, double* rt12);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVO_H_ */

@@ -1,0 +1,383 @@
+// oracle: BundleAdjuster::bundle_adjust -> ceres::Solve with DENSE_SCHUR
+// (src/bundle_adjuster.cpp:9-12,137-157) over ReprojectionFactor residuals
+// (src/reprojection_factor.cpp:10-88) with the quaternion (x) identity local parameterization
+// (src/bundle_adjuster.cpp:19-20,123), oldest pose constant (:130), squared loss (:79,118).
+// TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED vs Ceres (not available here); restates SURVEY.md
+// Appendix B: trust-region Levenberg-Marquardt, Jacobi column scaling fixed at the first Jacobian,
+// LM diagonal clamp(diag(J'^T J'),1e-6,1e32)/radius, Schur elimination of the 3x3 landmark blocks,
+// dense Cholesky on the reduced camera system, Ceres' step acceptance / radius update / tolerances.
+// Stated differences: (1) the model cost change is evaluated in its algebraically equal closed form
+// 1/2 y^T (D^2 y - g'); (2) the gradient test uses the 2-norm (an upper bound of Ceres' max-norm) so
+// that every quantity a sharded run decides on is a sum; (3) no wall-clock limit (SURVEY C-10).
+//
+// Sharded form: a rank holds all poses and a subset of landmarks.  Per LM iteration it sums
+//   payload1 = [ U - sum_j W_j Vd_j^-1 W_j^T  (n x n) | g_c - sum_j W_j Vd_j^-1 g_pj (n) | g_c (n) |
+//                diag U (n) | cost | sum g_p^2 ]              (pose block unscaled, n = 6 (K-1))
+//   payload2 = [ candidate cost | point part of the model change | sum dp^2 | sum p^2 ]
+// through `allreduce`, so every rank takes identical decisions.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "svo_oracle.h"
+
+namespace {
+struct Problem {
+  int K, N, M, n;
+  double* poses;
+  double* points;
+  const int32_t *op, *oj;
+  const double* uv;
+  double f, cx, cy;
+  std::vector<int> lm_start;  // CSR over landmarks that have observations
+  std::vector<int> lm_id;
+};
+
+// residual + tangent Jacobians for one observation. Jc: 2x6 (pose tangent), Jp: 2x3.
+inline void eval_obs(const Problem& P, const double* poses, const double* points, int o, double* r,
+                     double* Jc, double* Jp) {
+  double jp14[14], jx6[6];
+  const double* pose = poses + 7 * P.op[o];
+  ora_reproj_eval(1, pose, points + 3 * P.oj[o], P.uv + 2 * o, P.f, P.cx, P.cy, r,
+                  Jc ? jp14 : nullptr, Jp ? jx6 : nullptr);
+  if (Jc) {
+    const double w = pose[0], x = pose[1], y = pose[2], z = pose[3];
+    // d q / d delta for q+ = [cos|d|, sin|d|/|d| d] (x) q at d=0 : rows (w,x,y,z)
+    const double T[4][3] = {{-x, -y, -z}, {w, z, -y}, {-z, w, x}, {y, -x, w}};
+    for (int row = 0; row < 2; ++row) {
+      for (int c = 0; c < 3; ++c) {
+        double s = 0;
+        for (int k = 0; k < 4; ++k) s += jp14[7 * row + k] * T[k][c];
+        Jc[6 * row + c] = s;
+      }
+      for (int c = 0; c < 3; ++c) Jc[6 * row + 3 + c] = jp14[7 * row + 4 + c];
+    }
+  }
+  if (Jp) std::memcpy(Jp, jx6, sizeof(jx6));
+}
+
+inline bool inv3_sym(const double* V, double* Vi) {
+  const double a = V[0], b = V[1], c = V[2], d = V[4], e = V[5], f = V[8];
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double det = a * c00 + b * c01 + c * c02;
+  if (!(std::fabs(det) > 0)) return false;
+  const double id = 1.0 / det;
+  Vi[0] = c00 * id; Vi[1] = c01 * id; Vi[2] = c02 * id;
+  Vi[3] = Vi[1]; Vi[4] = (a * f - c * c) * id; Vi[5] = (b * c - a * e) * id;
+  Vi[6] = Vi[2]; Vi[7] = Vi[5]; Vi[8] = (a * d - b * b) * id;
+  return true;
+}
+
+bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) {
+  for (int j = 0; j < n; ++j) {
+    double s = A[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+    if (!(s > 0)) return false;
+    const double l = std::sqrt(s);
+    A[(size_t)j * n + j] = l;
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+      A[(size_t)i * n + j] = v / l;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double v = b[i];
+    for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
+    b[i] = v / A[(size_t)i * n + i];
+  }
+  for (int i = n - 1; i >= 0; --i) {
+    double v = b[i];
+    for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * b[k];
+    b[i] = v / A[(size_t)i * n + i];
+  }
+  return true;
+}
+
+void plus_pose(const double* p, const double* d, double* out) {
+  const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double qd[4];
+  if (nd > 0) {
+    const double s = std::sin(nd) / nd;
+    qd[0] = std::cos(nd); qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
+  } else { qd[0] = 1; qd[1] = qd[2] = qd[3] = 0; }
+  const double* q = p;
+  out[0] = qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2] - qd[3] * q[3];
+  out[1] = qd[0] * q[1] + qd[1] * q[0] + qd[2] * q[3] - qd[3] * q[2];
+  out[2] = qd[0] * q[2] - qd[1] * q[3] + qd[2] * q[0] + qd[3] * q[1];
+  out[3] = qd[0] * q[3] + qd[1] * q[2] - qd[2] * q[1] + qd[3] * q[0];
+  out[4] = p[4] + d[3]; out[5] = p[5] + d[4]; out[6] = p[6] + d[5];
+}
+}  // namespace
+
+extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* points3, int n_obs,
+                            const int32_t* obs_pose, const int32_t* obs_point, const double* obs_uv,
+                            double focal, double cx, double cy, int max_iterations,
+                            double function_tol, double gradient_tol, double parameter_tol,
+                            double initial_radius, int num_threads, ora_allreduce_fn allreduce,
+                            void* user, double* summary5) {
+  Problem P{n_poses, n_points, n_obs, 6 * (n_poses - 1), poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, {}, {}};
+  for (int o = 0; o < n_obs; ++o) {
+    if (o == 0 || obs_point[o] != obs_point[o - 1]) { P.lm_start.push_back(o); P.lm_id.push_back(obs_point[o]); }
+  }
+  P.lm_start.push_back(n_obs);
+  const int L = (int)P.lm_id.size();
+  const int n = P.n;
+  const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  if (num_threads < 1) num_threads = 1;
+  (void)num_threads;
+
+  std::vector<double> sp((size_t)L * 3, 0.0), sc(n, 0.0);   // Jacobi scales
+  bool have_scale = false;
+  std::vector<double> pay(pay1), Sm((size_t)n * n), rhs(n), dc(n);
+  std::vector<double> cand_poses((size_t)7 * n_poses), cand_points((size_t)3 * n_points);
+  double radius = initial_radius, decrease_factor = 2.0;
+  const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
+  const double min_rel_decrease = 1e-3;
+
+  // pass A: linearise at (poses, points) and build payload1 for the current radius.
+  auto linearize = [&](double rad) {
+    std::fill(pay.begin(), pay.end(), 0.0);
+    double* S = pay.data();
+    double* gred = S + (size_t)n * n;
+    double* gc = gred + n;
+    double* dU = gc + n;
+    double cost = 0, gp2 = 0;
+#pragma omp parallel num_threads(num_threads)
+    {
+      std::vector<double> lp(pay1, 0.0);
+      double* lS = lp.data();
+      double* lgred = lS + (size_t)n * n;
+      double* lgc = lgred + n;
+      double* ldU = lgc + n;
+      double lcost = 0, lgp2 = 0;
+      std::vector<double> W;   // per obs 6x3
+      std::vector<int> Wk;
+#pragma omp for schedule(static)
+      for (int l = 0; l < L; ++l) {
+        const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
+        double V[9] = {0}, gp[3] = {0};
+        W.assign((size_t)(o1 - o0) * 18, 0.0);
+        Wk.assign(o1 - o0, -1);
+        for (int o = o0; o < o1; ++o) {
+          double r[2], Jc[12], Jp[6];
+          const int k = P.op[o];
+          eval_obs(P, P.poses, P.points, o, r, k > 0 ? Jc : nullptr, Jp);
+          lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+          for (int a = 0; a < 3; ++a) {
+            gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+            for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+          }
+          if (k > 0) {
+            const int base = 6 * (k - 1);
+            Wk[o - o0] = base;
+            double* Wo = &W[(size_t)(o - o0) * 18];
+            for (int a = 0; a < 6; ++a) {
+              lgc[base + a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+              for (int b = 0; b < 3; ++b) Wo[3 * a + b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b];
+              for (int b = 0; b < 6; ++b)
+                lS[(size_t)(base + a) * n + base + b] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+              ldU[base + a] += Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+            }
+          }
+        }
+        for (int a = 0; a < 3; ++a) lgp2 += gp[a] * gp[a];
+        double* s = &sp[(size_t)l * 3];
+        if (!have_scale) for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + std::sqrt(V[4 * a]));
+        // scale the point block
+        double Vd[9], gps[3];
+        for (int a = 0; a < 3; ++a) {
+          gps[a] = gp[a] * s[a];
+          for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+        }
+        for (int a = 0; a < 3; ++a) Vd[4 * a] += std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad;
+        double Vi[9] = {0};
+        inv3_sym(Vd, Vi);
+        // Y_k = W_k s Vi ; S -= Y_k (W_k' s)^T ; gred -= Y_k gps
+        for (int oa = 0; oa < o1 - o0; ++oa) {
+          if (Wk[oa] < 0) continue;
+          double Y[18];
+          const double* Wa = &W[(size_t)oa * 18];
+          for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 3; ++b) {
+              double v = 0;
+              for (int c = 0; c < 3; ++c) v += Wa[3 * a + c] * s[c] * Vi[3 * c + b];
+              Y[3 * a + b] = v;
+            }
+          for (int a = 0; a < 6; ++a) {
+            double v = 0;
+            for (int b = 0; b < 3; ++b) v += Y[3 * a + b] * gps[b];
+            lgred[Wk[oa] + a] -= v;
+          }
+          for (int ob = 0; ob < o1 - o0; ++ob) {
+            if (Wk[ob] < 0) continue;
+            const double* Wb = &W[(size_t)ob * 18];
+            for (int a = 0; a < 6; ++a)
+              for (int b = 0; b < 6; ++b) {
+                double v = 0;
+                for (int c = 0; c < 3; ++c) v += Y[3 * a + c] * Wb[3 * b + c] * s[c];
+                lS[(size_t)(Wk[oa] + a) * n + Wk[ob] + b] -= v;
+              }
+          }
+        }
+      }
+#pragma omp critical
+      {
+        for (size_t i = 0; i < pay1; ++i) pay[i] += lp[i];
+        cost += lcost;
+        gp2 += lgp2;
+      }
+    }
+    for (int a = 0; a < n; ++a) gred[a] += gc[a];
+    pay[pay1 - 2] = cost;
+    pay[pay1 - 1] = gp2;
+    if (allreduce) allreduce(pay.data(), pay1, user);
+  };
+
+  // pass B: back-substitute with the pose step dc (unscaled tangent), build candidate, payload2.
+  double pay2[4];
+  auto backsub = [&](double rad) {
+    for (int k = 0; k < n_poses; ++k) {
+      if (k == 0) std::memcpy(&cand_poses[0], P.poses, 7 * sizeof(double));
+      else plus_pose(P.poses + 7 * k, &dc[6 * (k - 1)], &cand_poses[7 * k]);
+    }
+    std::memcpy(cand_points.data(), P.points, sizeof(double) * 3 * n_points);
+    double mc = 0, dp2 = 0, p2 = 0;
+#pragma omp parallel for schedule(static) reduction(+ : mc, dp2, p2) num_threads(num_threads)
+    for (int l = 0; l < L; ++l) {
+      const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
+      double V[9] = {0}, gp[3] = {0}, wd[3] = {0};
+      for (int o = o0; o < o1; ++o) {
+        double r[2], Jc[12], Jp[6];
+        const int k = P.op[o];
+        eval_obs(P, P.poses, P.points, o, r, k > 0 ? Jc : nullptr, Jp);
+        double jd[2] = {0, 0};
+        if (k > 0)
+          for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * dc[6 * (k - 1) + a]; jd[1] += Jc[6 + a] * dc[6 * (k - 1) + a]; }
+        for (int a = 0; a < 3; ++a) {
+          gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+          wd[a] += Jp[a] * jd[0] + Jp[3 + a] * jd[1];  // W^T dc
+          for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+        }
+      }
+      const double* s = &sp[(size_t)l * 3];
+      double Vd[9], De[3], rh[3];
+      for (int a = 0; a < 3; ++a) {
+        rh[a] = -(gp[a] + wd[a]) * s[a];
+        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+      }
+      for (int a = 0; a < 3; ++a) { De[a] = std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad; Vd[4 * a] += De[a]; }
+      double Vi[9] = {0};
+      inv3_sym(Vd, Vi);
+      double* pt = &cand_points[3 * (size_t)P.lm_id[l]];
+      for (int a = 0; a < 3; ++a) {
+        const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
+        mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
+        const double d = y * s[a];
+        dp2 += d * d;
+        p2 += pt[a] * pt[a];
+        pt[a] += d;
+      }
+    }
+    double cn = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cn) num_threads(num_threads)
+    for (int o = 0; o < n_obs; ++o) {
+      double r[2];
+      eval_obs(P, cand_poses.data(), cand_points.data(), o, r, nullptr, nullptr);
+      cn += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    }
+    pay2[0] = cn; pay2[1] = mc; pay2[2] = dp2; pay2[3] = p2;
+    if (allreduce) allreduce(pay2, 4, user);
+  };
+
+  int iterations = 0, successful = 0, termination = 1;
+  linearize(radius);
+  double cost = pay[pay1 - 2];
+  const double initial_cost = cost;
+  bool need_linearize = false;
+  {
+    const double* gc = pay.data() + (size_t)n * n + n;
+    const double* dU = gc + n;
+    for (int a = 0; a < n; ++a) sc[a] = 1.0 / (1.0 + std::sqrt(dU[a]));
+    have_scale = true;
+    double g2 = pay[pay1 - 1];
+    for (int a = 0; a < n; ++a) g2 += gc[a] * gc[a];
+    if (std::sqrt(g2) <= gradient_tol) { termination = 0; goto done; }
+  }
+  while (true) {
+    if (iterations >= max_iterations) { termination = 1; break; }
+    if (radius <= min_radius) { termination = 0; break; }
+    ++iterations;
+    if (need_linearize) { linearize(radius); need_linearize = false; }
+    const double* S = pay.data();
+    const double* gred = S + (size_t)n * n;
+    const double* gc = gred + n;
+    const double* dU = gc + n;
+    std::vector<double> Df(n);
+    for (int a = 0; a < n; ++a) {
+      Df[a] = std::min(std::max(dU[a] * sc[a] * sc[a], min_diag), max_diag) / radius;
+      for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = S[(size_t)a * n + b] * sc[a] * sc[b];
+      Sm[(size_t)a * n + a] += Df[a];
+      rhs[a] = -gred[a] * sc[a];
+    }
+    bool ok = n == 0 || cholesky_solve(Sm, rhs, n);
+    bool step_ok = false;
+    double cost_new = 0, model_change = 0, step2 = 0, x2 = 0;
+    if (ok) {
+      double mcc = 0;
+      for (int a = 0; a < n; ++a) {
+        mcc += 0.5 * rhs[a] * (Df[a] * rhs[a] - gc[a] * sc[a]);
+        dc[a] = rhs[a] * sc[a];
+      }
+      backsub(radius);
+      cost_new = pay2[0];
+      model_change = mcc + pay2[1];
+      step2 = pay2[2]; x2 = pay2[3];
+      for (int k = 1; k < n_poses; ++k)
+        for (int a = 0; a < 7; ++a) {
+          const double d = cand_poses[7 * k + a] - P.poses[7 * k + a];
+          step2 += d * d;
+          x2 += P.poses[7 * k + a] * P.poses[7 * k + a];
+        }
+      step_ok = model_change > 0;
+    }
+    if (!step_ok) {  // invalid step
+      radius /= decrease_factor; decrease_factor *= 2; need_linearize = true;
+      continue;
+    }
+    if (std::sqrt(step2) <= parameter_tol * (std::sqrt(x2) + parameter_tol)) { termination = 0; break; }
+    const double cost_change = cost - cost_new;
+    if (std::fabs(cost_change) <= function_tol * cost) {
+      if (cost_change > 0) {  // Ceres stops here without taking the step; keep the better point
+        std::memcpy(P.poses, cand_poses.data(), sizeof(double) * 7 * n_poses);
+        std::memcpy(P.points, cand_points.data(), sizeof(double) * 3 * n_points);
+        cost = cost_new;
+      }
+      termination = 0;
+      break;
+    }
+    const double rho = cost_change / model_change;
+    if (rho > min_rel_decrease) {
+      std::memcpy(P.poses, cand_poses.data(), sizeof(double) * 7 * n_poses);
+      std::memcpy(P.points, cand_points.data(), sizeof(double) * 3 * n_points);
+      cost = cost_new;
+      ++successful;
+      const double t = 2.0 * rho - 1.0;
+      radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+      radius = std::min(max_radius, radius);
+      decrease_factor = 2.0;
+      linearize(radius);
+      const double* gc2 = pay.data() + (size_t)n * n + n;
+      double g2 = pay[pay1 - 1];
+      for (int a = 0; a < n; ++a) g2 += gc2[a] * gc2[a];
+      if (std::sqrt(g2) <= gradient_tol) { termination = 0; break; }
+    } else {
+      radius /= decrease_factor; decrease_factor *= 2; need_linearize = true;
+    }
+  }
+done:
+  summary5[0] = iterations; summary5[1] = successful; summary5[2] = termination;
+  summary5[3] = initial_cost; summary5[4] = cost;
+  return 0;
+}

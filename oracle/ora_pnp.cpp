@@ -1,0 +1,246 @@
+// oracle: cv::solvePnPRansac(obj, img, K, dist=0, rvec, tvec, useExtrinsicGuess=true, 100, 8.0,
+// 0.99, inliers) — call site src/image_processor.cpp:76-80.
+// TEST INFRASTRUCTURE ONLY.  PARITY UNPINNED vs OpenCV: OpenCV's sample sequence and minimal
+// solver (EPnP on 5 points) are version specific.  This file DEFINES the
+// deterministic RANSAC both this oracle and the HIP path implement:
+//   * model size 5; hypothesis h draws its 5 distinct indices from splitmix64 seeded with
+//     kSeed + h*kStride (so hypotheses are independent and can run in parallel);
+//   * minimal solve = damped Gauss-Newton (LM, <=12 iterations) on the 5 points starting from the
+//     extrinsic guess, pose = unit quaternion + translation, left-multiplicative update
+//     q <- normalize([1, dw/2]) (x) q  (no trigonometry => bit-reproducible on CPU and GPU);
+//   * inlier iff z>0 and squared reprojection error <= reproj_err^2 (OpenCV compares squared
+//     error with the squared threshold);
+//   * hypotheses are consumed in order h=0,1,..; a hypothesis replaces the best only with strictly
+//     more inliers; the iteration cap is updated with OpenCV's RANSACUpdateNumIters formula;
+//   * the returned pose is an LM refinement of the best model over its inliers; the returned
+//     inlier list is the best hypothesis' inlier set (ascending), as OpenCV returns the RANSAC mask.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "svo_oracle.h"
+
+namespace {
+const uint64_t kSeed = 0x5EED0A5ull, kStride = 0xD1B54A32D192ED03ull;
+inline uint64_t splitmix(uint64_t& s) {
+  uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+struct Pose { double q[4]; double t[3]; };
+
+inline void quat_to_R(const double* q, double R[9]) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// cost + normal equations over a subset. Returns cost (sum of squared errors), fills H(21 upper), g(6).
+double accumulate(const Pose& P, const float* xyz, const float* xy, const int* idx, int m, double f,
+                  double cx, double cy, double* H, double* g) {
+  double R[9];
+  quat_to_R(P.q, R);
+  double cost = 0;
+  if (H) { std::memset(H, 0, 36 * sizeof(double)); std::memset(g, 0, 6 * sizeof(double)); }
+  for (int k = 0; k < m; ++k) {
+    const int i = idx[k];
+    const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+    const double rx = R[0] * X + R[1] * Y + R[2] * Z;
+    const double ry = R[3] * X + R[4] * Y + R[5] * Z;
+    const double rz = R[6] * X + R[7] * Y + R[8] * Z;
+    const double px = rx + P.t[0], py = ry + P.t[1], pz = rz + P.t[2];
+    const double iz = 1.0 / pz;
+    const double ex = f * px * iz + cx - (double)xy[2 * i];
+    const double ey = f * py * iz + cy - (double)xy[2 * i + 1];
+    cost += ex * ex + ey * ey;
+    if (!H) continue;
+    const double a = f * iz, bx = -f * px * iz * iz, by = -f * py * iz * iz;
+    // d Xc / d w = -[RX]x ; d Xc / d t = I
+    double J[2][6];
+    J[0][0] = bx * ry;            J[0][1] = a * rz - bx * rx;  J[0][2] = -a * ry;
+    J[1][0] = -a * rz + by * ry;  J[1][1] = -by * rx;          J[1][2] = a * rx;
+    J[0][3] = a; J[0][4] = 0; J[0][5] = bx;
+    J[1][3] = 0; J[1][4] = a; J[1][5] = by;
+    for (int r = 0; r < 6; ++r) {
+      g[r] += J[0][r] * ex + J[1][r] * ey;
+      for (int c = r; c < 6; ++c) H[6 * r + c] += J[0][r] * J[0][c] + J[1][r] * J[1][c];
+    }
+  }
+  return cost;
+}
+
+bool solve6(const double* Hin, const double* g, double lambda, double* d) {
+  double L[36];
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) L[6 * c + r] = Hin[6 * r + c];
+  for (int r = 0; r < 6; ++r) L[6 * r + r] += lambda * Hin[6 * r + r] + 1e-12;
+  for (int j = 0; j < 6; ++j) {
+    double s = L[6 * j + j];
+    for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k];
+    if (!(s > 0)) return false;
+    const double ljj = std::sqrt(s);
+    L[6 * j + j] = ljj;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = L[6 * i + j];
+      for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = v / ljj;
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double v = -g[i];
+    for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+    y[i] = v / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+    for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * d[k];
+    d[i] = v / L[6 * i + i];
+  }
+  return true;
+}
+
+inline Pose retract(const Pose& P, const double* d) {
+  Pose N;
+  double dq[4] = {1.0, 0.5 * d[0], 0.5 * d[1], 0.5 * d[2]};
+  const double nn = std::sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+  for (double& v : dq) v /= nn;
+  const double* q = P.q;
+  N.q[0] = dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2] - dq[3] * q[3];
+  N.q[1] = dq[0] * q[1] + dq[1] * q[0] + dq[2] * q[3] - dq[3] * q[2];
+  N.q[2] = dq[0] * q[2] - dq[1] * q[3] + dq[2] * q[0] + dq[3] * q[1];
+  N.q[3] = dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1] + dq[3] * q[0];
+  const double n2 = std::sqrt(N.q[0] * N.q[0] + N.q[1] * N.q[1] + N.q[2] * N.q[2] + N.q[3] * N.q[3]);
+  for (double& v : N.q) v /= n2;
+  // rotation perturbation acts on R X, translation is additive
+  for (int k = 0; k < 3; ++k) N.t[k] = P.t[k] + d[3 + k];
+  return N;
+}
+
+Pose lm_solve(Pose P, const float* xyz, const float* xy, const int* idx, int m, double f, double cx,
+              double cy, int max_it) {
+  double lambda = 1e-3;
+  double H[36], g[6], d[6];
+  double cost = accumulate(P, xyz, xy, idx, m, f, cx, cy, H, g);
+  for (int it = 0; it < max_it; ++it) {
+    if (!solve6(H, g, lambda, d)) { lambda *= 10; continue; }
+    const Pose N = retract(P, d);
+    const double c2 = accumulate(N, xyz, xy, idx, m, f, cx, cy, nullptr, nullptr);
+    if (c2 < cost) {
+      P = N;
+      lambda *= 0.1;
+      if (lambda < 1e-9) lambda = 1e-9;
+      const double step2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+      cost = accumulate(P, xyz, xy, idx, m, f, cx, cy, H, g);
+      if (step2 < 1e-20) break;
+    } else {
+      lambda *= 10;
+      if (lambda > 1e6) break;
+    }
+  }
+  return P;
+}
+
+int update_num_iters(double p, double ep, int model_points, int max_iters) {
+  p = std::max(p, 0.0); p = std::min(p, 1.0);
+  ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
+  double num = std::max(1.0 - p, DBL_MIN);
+  double denom = 1.0 - std::pow(1.0 - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num);
+  denom = std::log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+}  // namespace
+
+extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float focal, float cxf,
+                              float cyf, double* rvec3, double* tvec3, int iterations,
+                              float reproj_err, double confidence, int* inliers) {
+  const int kModel = 5;
+  if (n < kModel) return 0;
+  const double f = focal, cx = cxf, cy = cyf;
+  // Rodrigues(rvec) -> quaternion (host libm)
+  Pose P0;
+  {
+    const double th = std::sqrt(rvec3[0] * rvec3[0] + rvec3[1] * rvec3[1] + rvec3[2] * rvec3[2]);
+    if (th < 1e-12) { P0.q[0] = 1; P0.q[1] = 0.5 * rvec3[0]; P0.q[2] = 0.5 * rvec3[1]; P0.q[3] = 0.5 * rvec3[2]; }
+    else {
+      const double s = std::sin(0.5 * th) / th;
+      P0.q[0] = std::cos(0.5 * th); P0.q[1] = s * rvec3[0]; P0.q[2] = s * rvec3[1]; P0.q[3] = s * rvec3[2];
+    }
+    for (int k = 0; k < 3; ++k) P0.t[k] = tvec3[k];
+  }
+  const double thr2 = (double)reproj_err * (double)reproj_err;
+  std::vector<Pose> hyp(iterations);
+  std::vector<int> count(iterations);
+  for (int h = 0; h < iterations; ++h) {
+    uint64_t s = kSeed + (uint64_t)h * kStride;
+    int idx[kModel];
+    for (int k = 0; k < kModel; ++k) {
+      for (;;) {
+        const int c = (int)(splitmix(s) % (uint64_t)n);
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup |= idx[j] == c;
+        if (!dup) { idx[k] = c; break; }
+      }
+    }
+    const Pose P = lm_solve(P0, xyz, xy, idx, kModel, f, cx, cy, 12);
+    double R[9];
+    quat_to_R(P.q, R);
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+      const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+      const double px = R[0] * X + R[1] * Y + R[2] * Z + P.t[0];
+      const double py = R[3] * X + R[4] * Y + R[5] * Z + P.t[1];
+      const double pz = R[6] * X + R[7] * Y + R[8] * Z + P.t[2];
+      if (!(pz > 0)) continue;
+      const double iz = 1.0 / pz;
+      const double ex = f * px * iz + cx - (double)xy[2 * i];
+      const double ey = f * py * iz + cy - (double)xy[2 * i + 1];
+      if (ex * ex + ey * ey <= thr2) ++cnt;
+    }
+    hyp[h] = P;
+    count[h] = cnt;
+  }
+  int best = -1, best_cnt = 0, niters = iterations;
+  for (int h = 0; h < niters; ++h) {
+    if (count[h] > std::max(best_cnt, kModel - 1)) {
+      best = h; best_cnt = count[h];
+      niters = update_num_iters(confidence, (double)(n - best_cnt) / n, kModel, niters);
+    }
+  }
+  if (best < 0) return 0;
+  // inlier list of the best hypothesis
+  const Pose B = hyp[best];
+  double R[9];
+  quat_to_R(B.q, R);
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+    const double px = R[0] * X + R[1] * Y + R[2] * Z + B.t[0];
+    const double py = R[3] * X + R[4] * Y + R[5] * Z + B.t[1];
+    const double pz = R[6] * X + R[7] * Y + R[8] * Z + B.t[2];
+    if (!(pz > 0)) continue;
+    const double iz = 1.0 / pz;
+    const double ex = f * px * iz + cx - (double)xy[2 * i];
+    const double ey = f * py * iz + cy - (double)xy[2 * i + 1];
+    if (ex * ex + ey * ey <= thr2) inliers[m++] = i;
+  }
+  const Pose F = lm_solve(B, xyz, xy, inliers, m, f, cx, cy, 20);
+  // quaternion -> rvec (host libm)
+  double q[4] = {F.q[0], F.q[1], F.q[2], F.q[3]};
+  if (q[0] < 0) for (double& v : q) v = -v;
+  const double vn = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (vn < 1e-12) { rvec3[0] = 2 * q[1]; rvec3[1] = 2 * q[2]; rvec3[2] = 2 * q[3]; }
+  else {
+    const double th = 2.0 * std::atan2(vn, q[0]);
+    rvec3[0] = q[1] / vn * th; rvec3[1] = q[2] / vn * th; rvec3[2] = q[3] / vn * th;
+  }
+  for (int k = 0; k < 3; ++k) tvec3[k] = F.t[k];
+  return m;
+}

@@ -1,0 +1,295 @@
+"""ctypes binding of include/svo.h.  Mirrors the C-ABI one to one; numpy arrays in, numpy arrays out."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SvoError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsvo_hip.so")
+
+
+class Limits(C.Structure):
+    _fields_ = [("max_width", C.c_int), ("max_height", C.c_int), ("max_batch", C.c_int),
+                ("max_corners", C.c_int), ("max_candidates", C.c_int), ("max_features", C.c_int)]
+
+
+class CameraInfo(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("focal", "cx", "cy", "k1", "k2", "p1", "p2", "baseline")]
+
+
+class BAOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("max_time_s", C.c_double),
+                ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+                ("parameter_tolerance", C.c_double), ("initial_radius", C.c_double),
+                ("max_features", C.c_int)]
+
+
+class BASummary(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("successful_steps", C.c_int), ("termination", C.c_int),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double), ("solve_ms", C.c_double)]
+
+
+class PipelineParams(C.Structure):
+    _fields_ = [("cam", CameraInfo), ("width", C.c_int), ("height", C.c_int), ("max_corners", C.c_int),
+                ("quality", C.c_double), ("min_feature_distance", C.c_float),
+                ("parallax_thresh", C.c_float), ("window_size", C.c_int), ("max_features", C.c_int),
+                ("ba_max_iterations", C.c_int), ("ba_max_time_s", C.c_double)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("n_detected", C.c_int), ("n_tracked", C.c_int), ("n_inliers", C.c_int),
+                ("n_new", C.c_int), ("is_keyframe", C.c_int), ("av_parallax", C.c_float),
+                ("percent_lost", C.c_float), ("pose7", C.c_double * 7), ("ba_iterations", C.c_int)]
+
+
+class SynthParams(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("width", C.c_int), ("height", C.c_int), ("focal", C.c_double),
+                ("cx", C.c_double), ("cy", C.c_double), ("baseline", C.c_double), ("step_z", C.c_double),
+                ("step_x", C.c_double), ("yaw_per_frame", C.c_double), ("n_billboards", C.c_int)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/svo.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "svo_create", "svo_destroy", "svo_last_error", "svo_stream", "svo_sync", "svo_version",
+    "svo_reproj_eval", "svo_reproj_eval_dev",
+    "svo_corner_detect", "svo_corner_detect_batch_dev", "svo_corner_response",
+    "svo_stereo_bm", "svo_stereo_disparity_at", "svo_stereo_disparity_at_dev",
+    "svo_triangulate", "svo_lk_track", "svo_build_pyramid", "svo_track_features", "svo_dedup",
+    "svo_pnp_ransac",
+    "svo_ba_default_options", "svo_ba_create", "svo_ba_destroy", "svo_ba_add_keyframe", "svo_ba_solve",
+    "svo_ba_get_pose", "svo_ba_window_count", "svo_ba_get_points", "svo_ba_load_problem",
+    "svo_ba_set_allreduce", "svo_ba_solve_problem", "svo_ba_read_problem",
+    "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
+    "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
+    "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
+]
+
+
+def lib():
+    """Load libsvo_hip.so (raises if it has not been built: there is no fallback)."""
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise SvoError(f"{p} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(p)
+        L.svo_version.restype = C.c_char_p
+        L.svo_last_error.restype = C.c_char_p
+        L.svo_last_error.argtypes = [C.c_void_p]
+        L.svo_stream.restype = C.c_void_p
+        L.svo_stream.argtypes = [C.c_void_p]
+        L.svo_destroy.argtypes = [C.c_void_p]
+        L.svo_destroy.restype = None
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t=None):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def synth_default(width, height):
+    p = SynthParams()
+    lib().svo_synth_default_params(C.byref(p), width, height)
+    return p
+
+
+def synth_render(params, frame):
+    L = lib()
+    left = np.empty((params.height, params.width), np.uint8)
+    right = np.empty_like(left)
+    rc = L.svo_synth_render(C.byref(params), frame, _p(left), _p(right))
+    if rc:
+        raise SvoError(f"svo_synth_render rc={rc}")
+    return left, right
+
+
+def synth_pose(params, frame):
+    rt = np.empty(12, np.float64)
+    rc = lib().svo_synth_pose(C.byref(params), frame, _p(rt))
+    if rc:
+        raise SvoError(f"svo_synth_pose rc={rc}")
+    return rt.reshape(3, 4)
+
+
+class Context:
+    """svo_ctx wrapper.  Host-pointer entry points (numpy in/out)."""
+
+    def __init__(self, max_width, max_height, device=0, max_batch=1, max_corners=2048,
+                 max_candidates=65536, max_features=2048):
+        self.L = lib()
+        self.lim = Limits(max_width, max_height, max_batch, max_corners, max_candidates, max_features)
+        self.h = C.c_void_p()
+        rc = self.L.svo_create(C.byref(self.h), device, C.byref(self.lim))
+        if rc:
+            raise SvoError(f"svo_create failed rc={rc} (no GPU / HIP error); the HIP path has no fallback")
+
+    def close(self):
+        if self.h:
+            self.L.svo_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc:
+            raise SvoError(f"{what} rc={rc}: {self.L.svo_last_error(self.h).decode()}")
+
+    def sync(self):
+        self._chk(self.L.svo_sync(self.h), "svo_sync")
+
+    @property
+    def stream(self):
+        return self.L.svo_stream(self.h)
+
+    # ---- a11
+    def reproj_eval(self, pose7, point3, obs2, focal, cx, cy, want_jpose=True, want_jpoint=True):
+        pose7, point3, obs2 = _f64(pose7), _f64(point3), _f64(obs2)
+        n = pose7.shape[0]
+        r = np.empty((n, 2))
+        jq = np.empty((n, 14)) if want_jpose else None
+        jx = np.empty((n, 6)) if want_jpoint else None
+        self._chk(self.L.svo_reproj_eval(self.h, n, _p(pose7), _p(point3), _p(obs2), C.c_double(focal),
+                                         C.c_double(cx), C.c_double(cy), _p(r), _p(jq), _p(jx)),
+                  "svo_reproj_eval")
+        return r, jq, jx
+
+    # ---- a1
+    def corner_response(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        eig = np.empty((h, w), np.float32)
+        self._chk(self.L.svo_corner_response(self.h, _p(img), w, h, w, _p(eig)), "svo_corner_response")
+        return eig
+
+    def corner_detect(self, img, max_corners=300, quality=0.1, min_distance=30.0):
+        img = _u8(img)
+        h, w = img.shape
+        xy = np.empty((max_corners, 2), np.float32)
+        n = C.c_int(0)
+        self._chk(self.L.svo_corner_detect(self.h, _p(img), w, h, w, max_corners, C.c_double(quality),
+                                           C.c_double(min_distance), _p(xy), C.byref(n)),
+                  "svo_corner_detect")
+        return xy[:n.value].copy()
+
+    # ---- a7
+    def stereo_bm(self, left, right, ndisp=48, block=21):
+        left, right = _u8(left), _u8(right)
+        h, w = left.shape
+        d = np.empty((h, w), np.int16)
+        self._chk(self.L.svo_stereo_bm(self.h, _p(left), _p(right), w, h, w, ndisp, block, _p(d)),
+                  "svo_stereo_bm")
+        return d
+
+    def stereo_disparity_at(self, left, right, xy, ndisp=48, block=21):
+        left, right, xy = _u8(left), _u8(right), _f32(xy)
+        h, w = left.shape
+        n = xy.shape[0]
+        d = np.empty(n, np.float32)
+        self._chk(self.L.svo_stereo_disparity_at(self.h, _p(left), _p(right), w, h, w, ndisp, block,
+                                                 _p(xy), n, _p(d)), "svo_stereo_disparity_at")
+        return d
+
+    # ---- a8
+    def triangulate(self, xy, disp, pose16, focal, cx, cy, baseline):
+        xy, disp, pose16 = _f32(xy), _f32(disp), _f32(pose16)
+        n = xy.shape[0]
+        kxy = np.empty((n, 2), np.float32)
+        xyz = np.empty((n, 3), np.float32)
+        kidx = np.empty(n, np.int32)
+        m = C.c_int(0)
+        self._chk(self.L.svo_triangulate(self.h, _p(xy), _p(disp), n, _p(pose16), C.c_float(focal),
+                                         C.c_float(cx), C.c_float(cy), C.c_float(baseline), _p(kxy),
+                                         _p(xyz), _p(kidx), C.byref(m)), "svo_triangulate")
+        return kxy[:m.value].copy(), xyz[:m.value].copy(), kidx[:m.value].copy()
+
+    # ---- a3
+    def build_pyramid(self, img):
+        img = _u8(img)
+        h, w = img.shape
+        sizes = []
+        lw, lh = w, h
+        for _ in range(4):
+            sizes.append((lh, lw))
+            lw, lh = (lw + 1) // 2, (lh + 1) // 2
+        total = sum(a * b for a, b in sizes)
+        buf = np.empty(total, np.uint8)
+        self._chk(self.L.svo_build_pyramid(self.h, _p(img), w, h, w, _p(buf), C.c_size_t(total)),
+                  "svo_build_pyramid")
+        out, off = [], 0
+        for (a, b) in sizes:
+            out.append(buf[off:off + a * b].reshape(a, b).copy())
+            off += a * b
+        return out
+
+    def lk_track(self, prev, nxt, xy):
+        prev, nxt, xy = _u8(prev), _u8(nxt), _f32(xy)
+        h, w = prev.shape
+        n = xy.shape[0]
+        out = np.empty((n, 2), np.float32)
+        st = np.empty(n, np.uint8)
+        self._chk(self.L.svo_lk_track(self.h, _p(prev), _p(nxt), w, h, w, _p(xy), n, _p(out), _p(st)),
+                  "svo_lk_track")
+        return out, st
+
+    def track_features(self, prev, nxt, xy, initial_xy):
+        prev, nxt, xy, initial_xy = _u8(prev), _u8(nxt), _f32(xy), _f32(initial_xy)
+        h, w = prev.shape
+        n = xy.shape[0]
+        kxy = np.empty((n, 2), np.float32)
+        kidx = np.empty(n, np.int32)
+        m = C.c_int(0)
+        av = C.c_float(0)
+        self._chk(self.L.svo_track_features(self.h, _p(prev), _p(nxt), w, h, w, _p(xy), _p(initial_xy), n,
+                                            _p(kxy), _p(kidx), C.byref(m), C.byref(av)),
+                  "svo_track_features")
+        return kxy[:m.value].copy(), kidx[:m.value].copy(), av.value
+
+    # ---- a6
+    def dedup(self, det, trk, min_distance):
+        det, trk = _f32(det), _f32(trk)
+        out = np.empty_like(det)
+        m = C.c_int(0)
+        self._chk(self.L.svo_dedup(self.h, _p(det), det.shape[0], _p(trk), trk.shape[0],
+                                   C.c_float(min_distance), _p(out), C.byref(m)), "svo_dedup")
+        return out[:m.value].copy()
+
+    # ---- a5
+    def pnp_ransac(self, xyz, xy, focal, cx, cy, rvec, tvec, iterations=100, reproj_err=8.0, confidence=0.99):
+        xyz, xy = _f32(xyz), _f32(xy)
+        n = xyz.shape[0]
+        rv, tv = _f64(rvec).copy(), _f64(tvec).copy()
+        inl = np.empty(max(n, 1), np.int32)
+        m = C.c_int(0)
+        self._chk(self.L.svo_pnp_ransac(self.h, _p(xyz), _p(xy), n, C.c_float(focal), C.c_float(cx),
+                                        C.c_float(cy), _p(rv), _p(tv), iterations, C.c_float(reproj_err),
+                                        C.c_double(confidence), _p(inl), C.byref(m)), "svo_pnp_ransac")
+        return rv, tv, inl[:m.value].copy()

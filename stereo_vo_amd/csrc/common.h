@@ -1,0 +1,80 @@
+// Shared internals of libsvo_hip.so (gfx950 only).
+#ifndef SVO_COMMON_H_
+#define SVO_COMMON_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "svo.h"
+
+struct svo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  svo_limits lim{};
+  std::string err;
+  // persistent device workspace (allocated once in svo_create)
+  uint8_t* d_ws = nullptr;   // generic scratch for host-pointer entry points
+  size_t ws_bytes = 0;
+  // front-end buffers, sized for max_batch frames
+  float* d_eig = nullptr;              // batch * W*H
+  unsigned* d_maxkey = nullptr;        // batch
+  unsigned long long* d_cand = nullptr;  // batch * max_candidates  (key<<32 | raster idx)
+  int* d_ncand = nullptr;              // batch
+  int* d_cell_count = nullptr;         // batch * max_cells
+  int* d_cell_start = nullptr;         // batch * (max_cells + 1)
+  unsigned long long* d_sorted = nullptr;  // batch * max_candidates (cell-ordered keys)
+  uint8_t* d_state = nullptr;          // batch * max_candidates
+  int max_cells = 0;
+  int* d_status = nullptr;             // device status word (capacity overflow etc.)
+  // pinned host mirror for small readbacks
+  void* h_pinned = nullptr;
+  size_t pinned_bytes = 0;
+};
+
+#define SVO_HIP_CHECK(ctx, expr)                                                        \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess) {                                                            \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                  \
+      return SVO_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+#define SVO_REQUIRE(ctx, cond, msg)          \
+  do {                                       \
+    if (!(cond)) {                           \
+      if (ctx) (ctx)->err = (msg);           \
+      return SVO_ERR_INVALID;                \
+    }                                        \
+  } while (0)
+
+inline int svo_div_up(int a, int b) { return (a + b - 1) / b; }
+
+// Scratch carve-out from ctx->d_ws for host-pointer wrappers.
+struct SvoScratch {
+  svo_ctx* ctx;
+  size_t off = 0;
+  explicit SvoScratch(svo_ctx* c) : ctx(c) {}
+  template <typename T>
+  T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    if (off + n * sizeof(T) > ctx->ws_bytes) return nullptr;
+    T* p = reinterpret_cast<T*>(ctx->d_ws + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+  return i;
+}
+#endif
+
+#endif  // SVO_COMMON_H_

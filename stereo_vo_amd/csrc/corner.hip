@@ -1,0 +1,407 @@
+// a1 — Shi-Tomasi corner detection, the cv::goodFeaturesToTrack call at
+// reference src/image_processor.cpp:22 (semantics: SURVEY.md Appendix A.1; the exact float
+// operation order is the one declared in oracle/ora_corner.cpp and repeated here bit for bit).
+//
+// Three launches per batch of frames (grid.z / blockIdx.x = frame):
+//   corner_response_kernel : u8 tile (+2 halo) staged in LDS -> Sobel -> products -> 3x3 box (double)
+//                            -> min eigenvalue map (f32) + per-image max (order-preserving uint atomicMax).
+//                            HBM: reads A bytes, writes 4A.
+//   corner_nms_kernel      : threshold at quality*max, 3x3 non-max suppression, wave-aggregated
+//                            append of (value key << 32 | raster index) candidates.  Reads 4A.
+//   corner_select_kernel   : one 1024-thread workgroup per image.  The reference's greedy
+//                            "strongest first, reject within minDistance" scan is the lexicographically
+//                            first maximal independent set under the total order (value desc, raster
+//                            index desc); it is computed in parallel by monotone fixed-point rounds
+//                            (a candidate is accepted once every stronger neighbour is rejected, rejected
+//                            once any stronger neighbour is accepted) over a cell-binned candidate list,
+//                            then the accepted set is bitonic-sorted in LDS and truncated to maxCorners.
+//                            The result is identical to the sequential scan, including the truncation,
+//                            because acceptance of a candidate depends only on stronger candidates.
+#include "common.h"
+
+namespace {
+constexpr int TX = 64, TY = 16;          // output tile of the response kernel
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAX_ACCEPT = 16384;    // accepted corners held in LDS for the final sort
+constexpr int SEL_LDS_BYTES = SEL_MAX_ACCEPT * 8;
+
+__device__ __forceinline__ unsigned f32_key(float v) {
+  const unsigned b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+template <typename T>
+__device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void st_l2(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}  // namespace
+
+__global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t* __restrict__ imgs, int W, int H,
+                                                              int row_stride, size_t image_stride,
+                                                              float* __restrict__ eig,
+                                                              unsigned* __restrict__ maxkey) {
+  __shared__ uint8_t sI[(TY + 4)][(TX + 4)];
+  __shared__ float sXX[(TY + 2)][(TX + 2)], sXY[(TY + 2)][(TX + 2)], sYY[(TY + 2)][(TX + 2)];
+  __shared__ unsigned sMax;
+  const int b = blockIdx.z;
+  const uint8_t* img = imgs + (size_t)b * image_stride;
+  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
+  const int tid = threadIdx.x;
+  if (tid == 0) sMax = 0u;
+  // stage the u8 tile, image coordinates reflected (BORDER_REFLECT_101)
+  for (int i = tid; i < (TY + 4) * (TX + 4); i += 256) {
+    const int ty = i / (TX + 4), tx = i % (TX + 4);
+    const int gx = reflect101(x0 + tx - 2, W), gy = reflect101(y0 + ty - 2, H);
+    sI[ty][tx] = img[(size_t)gy * row_stride + gx];
+  }
+  __syncthreads();
+  const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+  const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
+  // covariance terms on the (TX+2)x(TY+2) extended tile; the box filter reflects COVARIANCE
+  // coordinates, so an out-of-image position takes the value computed at its reflection.
+  for (int i = tid; i < (TY + 2) * (TX + 2); i += 256) {
+    const int ey = i / (TX + 2), ex = i % (TX + 2);
+    const int gx = x0 + ex - 1, gy = y0 + ey - 1;
+    float xx = 0.f, xy = 0.f, yy = 0.f;
+    if (gx >= -1 && gx <= W && gy >= -1 && gy <= H) {
+      const int cx = reflect101(gx, W) - x0 + 2, cy = reflect101(gy, H) - y0 + 2;  // tile coords of the centre
+      float rdx[3], rdy[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int l = sI[cy + j - 1][cx - 1], m = sI[cy + j - 1][cx], r = sI[cy + j - 1][cx + 1];
+        rdx[j] = (float)(r - l);
+        rdy[j] = (float)m * k0 + (float)(l + r) * k1;
+      }
+      const float dx = (rdx[0] + rdx[2]) * k1 + rdx[1] * k0;
+      const float dy = rdy[2] - rdy[0];
+      xx = dx * dx; xy = dx * dy; yy = dy * dy;
+    }
+    sXX[ey][ex] = xx; sXY[ey][ex] = xy; sYY[ey][ex] = yy;
+  }
+  __syncthreads();
+  unsigned lmax = 0u;
+  for (int i = tid; i < TY * TX; i += 256) {
+    const int oy = i / TX, ox = i % TX;
+    const int gx = x0 + ox, gy = y0 + oy;
+    if (gx >= W || gy >= H) continue;
+    double s[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      s[0][j] = ((double)sXX[oy + j][ox] + (double)sXX[oy + j][ox + 1]) + (double)sXX[oy + j][ox + 2];
+      s[1][j] = ((double)sXY[oy + j][ox] + (double)sXY[oy + j][ox + 1]) + (double)sXY[oy + j][ox + 2];
+      s[2][j] = ((double)sYY[oy + j][ox] + (double)sYY[oy + j][ox + 1]) + (double)sYY[oy + j][ox + 2];
+    }
+    const float a = (float)((s[0][0] + s[0][1]) + s[0][2]) * 0.5f;
+    const float bq = (float)((s[1][0] + s[1][1]) + s[1][2]);
+    const float c = (float)((s[2][0] + s[2][1]) + s[2][2]) * 0.5f;
+    const float d = a - c;
+    const float e = (a + c) - __fsqrt_rn(d * d + bq * bq);
+    eig[(size_t)b * W * H + (size_t)gy * W + gx] = e;
+    const unsigned k = f32_key(e);
+    lmax = k > lmax ? k : lmax;
+  }
+  // wave max then one LDS atomic per wave, one global atomic per block
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_xor(lmax, off);
+    lmax = o > lmax ? o : lmax;
+  }
+  if ((tid & 63) == 0) atomicMax(&sMax, lmax);
+  __syncthreads();
+  if (tid == 0) atomicMax(&maxkey[b], sMax);
+}
+
+__global__ __launch_bounds__(256) void corner_nms_kernel(const float* __restrict__ eig, int W, int H,
+                                                         const unsigned* __restrict__ maxkey, double quality,
+                                                         unsigned long long* __restrict__ cand,
+                                                         int* __restrict__ ncand, int cap, int* __restrict__ status) {
+  const int b = blockIdx.z;
+  const float* E = eig + (size_t)b * W * H;
+  const float maxv = key_f32(maxkey[b]);
+  const float thr = (float)((double)maxv * quality);
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x < 1 || x > W - 2 || y < 1 || y > H - 2) return;
+  const float c = E[(size_t)y * W + x];
+  const float v = c > thr ? c : 0.0f;
+  if (v == 0.0f) return;
+  float m = v;
+#pragma unroll
+  for (int j = -1; j <= 1; ++j)
+#pragma unroll
+    for (int i = -1; i <= 1; ++i) {
+      const float nv = E[(size_t)(y + j) * W + (x + i)];
+      const float t = nv > thr ? nv : 0.0f;
+      m = t > m ? t : m;
+    }
+  if (v != m) return;
+  const int pos = atomicAdd(&ncand[b], 1);
+  if (pos < cap)
+    cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(v) << 32) | (unsigned)(y * W + x);
+  else
+    atomicOr(status, 1);
+}
+
+// One workgroup per image.  All cross-wave global traffic uses L2-scope (sc1) loads/stores.
+__global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
+    const unsigned long long* __restrict__ cand, const int* __restrict__ ncand, int cap, int W, int H,
+    float min_distance, int max_corners, int* __restrict__ cell_count, int* __restrict__ cell_start, int max_cells,
+    unsigned long long* __restrict__ sorted, uint8_t* __restrict__ state_g, float* __restrict__ out_xy,
+    int* __restrict__ out_n, int* __restrict__ status) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  unsigned long long* sKeys = reinterpret_cast<unsigned long long*>(lds_raw);
+  __shared__ int sPart[SEL_THREADS];
+  __shared__ int sFlag, sCount;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const unsigned long long* C = cand + (size_t)b * cap;
+  int n = ncand[b];
+  if (n > cap) n = cap;
+  float* oxy = out_xy + (size_t)b * max_corners * 2;
+  if (min_distance < 1.0f) {
+    // no distance constraint: plain top-K by key
+    if (n > SEL_MAX_ACCEPT) { if (tid == 0) { atomicOr(status, 2); out_n[b] = 0; } return; }
+    int np2 = 1; while (np2 < n) np2 <<= 1;
+    for (int i = tid; i < np2; i += SEL_THREADS) sKeys[i] = i < n ? C[i] : 0ull;
+    __syncthreads();
+    for (int k = 2; k <= np2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < np2; i += SEL_THREADS) {
+          const int l = i ^ j;
+          if (l > i) {
+            const unsigned long long a = sKeys[i], c = sKeys[l];
+            const bool desc = (i & k) == 0;
+            if (desc ? a < c : a > c) { sKeys[i] = c; sKeys[l] = a; }
+          }
+        }
+        __syncthreads();
+      }
+    const int m = n < max_corners ? n : max_corners;
+    for (int i = tid; i < m; i += SEL_THREADS) {
+      const unsigned idx = (unsigned)(sKeys[i] & 0xffffffffu);
+      oxy[2 * i] = (float)(idx % W); oxy[2 * i + 1] = (float)(idx / W);
+    }
+    if (tid == 0) out_n[b] = m;
+    return;
+  }
+  const int cell = (int)rintf(min_distance);
+  const int gw = (W + cell - 1) / cell, gh = (H + cell - 1) / cell;
+  const int ncell = gw * gh;
+  int* cc = cell_count + (size_t)b * max_cells;
+  int* cs = cell_start + (size_t)b * (max_cells + 1);
+  unsigned long long* S = sorted + (size_t)b * cap;
+  uint8_t* st = state_g + (size_t)b * cap;
+  if (ncell > max_cells) { if (tid == 0) { atomicOr(status, 4); out_n[b] = 0; } return; }
+  // (a) histogram of candidates per cell
+  for (int i = tid; i < ncell; i += SEL_THREADS) st_l2(&cc[i], 0);
+  __syncthreads();
+  for (int i = tid; i < n; i += SEL_THREADS) {
+    const unsigned idx = (unsigned)(C[i] & 0xffffffffu);
+    const int cx = (int)(idx % W) / cell, cy = (int)(idx / W) / cell;
+    atomicAdd(&cc[cy * gw + cx], 1);
+  }
+  __syncthreads();
+  // (b) exclusive scan -> cell_start
+  {
+    const int chunk = (ncell + SEL_THREADS - 1) / SEL_THREADS;
+    const int lo = tid * chunk, hi = (lo + chunk < ncell) ? lo + chunk : ncell;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += ld_l2(&cc[i]);
+    sPart[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < SEL_THREADS; off <<= 1) {
+      int v = tid >= off ? sPart[tid - off] : 0;
+      __syncthreads();
+      sPart[tid] += v;
+      __syncthreads();
+    }
+    int run = sPart[tid] - s;
+    for (int i = lo; i < hi; ++i) { const int c = ld_l2(&cc[i]); st_l2(&cs[i], run); run += c; }
+    if (tid == 0) st_l2(&cs[ncell], n);
+  }
+  __syncthreads();
+  // (c) scatter into cell order (order inside a cell is irrelevant: every decision below uses the key)
+  for (int i = tid; i < n; i += SEL_THREADS) {
+    const unsigned long long k = C[i];
+    const unsigned idx = (unsigned)(k & 0xffffffffu);
+    const int cid = ((int)(idx / W) / cell) * gw + (int)(idx % W) / cell;
+    const int slot = atomicSub(&cc[cid], 1) - 1;
+    const int pos = ld_l2(&cs[cid]) + slot;
+    st_l2(&S[pos], k);
+    st_l2(&st[pos], (uint8_t)0);
+  }
+  __syncthreads();
+  // (d) monotone fixed-point rounds.  state: 0 undecided, 1 accepted, 2 rejected.
+  const float md2 = min_distance * min_distance;
+  for (int round = 0; round < 4096; ++round) {
+    if (tid == 0) sFlag = 0;
+    __syncthreads();
+    int pending = 0;
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      if (ld_l2(&st[i]) != 0) continue;
+      const unsigned long long k = ld_l2(&S[i]);
+      const unsigned idx = (unsigned)(k & 0xffffffffu);
+      const int x = (int)(idx % W), y = (int)(idx / W);
+      const int cx = x / cell, cy = y / cell;
+      const int x1 = cx > 0 ? cx - 1 : 0, x2 = cx < gw - 1 ? cx + 1 : gw - 1;
+      const int y1 = cy > 0 ? cy - 1 : 0, y2 = cy < gh - 1 ? cy + 1 : gh - 1;
+      bool rejected = false, blocked = false;
+      for (int yy = y1; yy <= y2 && !rejected; ++yy) {
+        const int p0 = ld_l2(&cs[yy * gw + x1]), p1 = ld_l2(&cs[yy * gw + x2 + 1]);  // cells x1..x2 of a row are contiguous
+        for (int p = p0; p < p1; ++p) {
+          const unsigned long long km = ld_l2(&S[p]);
+          if (km <= k) continue;  // only stronger candidates matter (keys are unique)
+          const unsigned im = (unsigned)(km & 0xffffffffu);
+          const float dx = (float)(x - (int)(im % W)), dy = (float)(y - (int)(im / W));
+          if (!(dx * dx + dy * dy < md2)) continue;
+          const uint8_t sm = ld_l2(&st[p]);
+          if (sm == 1) { rejected = true; break; }
+          if (sm == 0) blocked = true;
+        }
+      }
+      if (rejected) st_l2(&st[i], (uint8_t)2);
+      else if (!blocked) st_l2(&st[i], (uint8_t)1);
+      else pending = 1;
+    }
+    if (pending) sFlag = 1;
+    __syncthreads();
+    const int again = sFlag;
+    __syncthreads();
+    if (!again) break;
+  }
+  // (e) gather accepted keys into LDS, sort descending, truncate
+  if (tid == 0) sCount = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += SEL_THREADS) {
+    if (ld_l2(&st[i]) == 1) {
+      const int p = atomicAdd(&sCount, 1);
+      if (p < SEL_MAX_ACCEPT) sKeys[p] = ld_l2(&S[i]);
+    }
+  }
+  __syncthreads();
+  int A = sCount;
+  if (A > SEL_MAX_ACCEPT) { if (tid == 0) { atomicOr(status, 2); out_n[b] = 0; } return; }
+  int np2 = 1; while (np2 < A) np2 <<= 1;
+  for (int i = A + tid; i < np2; i += SEL_THREADS) sKeys[i] = 0ull;
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += SEL_THREADS) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = sKeys[i], c = sKeys[l];
+          const bool desc = (i & k) == 0;
+          if (desc ? a < c : a > c) { sKeys[i] = c; sKeys[l] = a; }
+        }
+      }
+      __syncthreads();
+    }
+  const int m = A < max_corners ? A : max_corners;
+  for (int i = tid; i < m; i += SEL_THREADS) {
+    const unsigned idx = (unsigned)(sKeys[i] & 0xffffffffu);
+    oxy[2 * i] = (float)(idx % W); oxy[2 * i + 1] = (float)(idx / W);
+  }
+  if (tid == 0) out_n[b] = m;
+}
+
+// ----------------------------------------------------------------------------- host side
+static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, int H, int row_stride,
+                         size_t image_stride, int max_corners, double quality, double min_distance,
+                         float* xy, int* n) {
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned) * batch, st));
+  SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * batch, st));
+  hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(W, TX), svo_div_up(H, TY), batch), dim3(256), 0, st,
+                     imgs, W, H, row_stride, image_stride, ctx->d_eig, ctx->d_maxkey);
+  hipLaunchKernelGGL(corner_nms_kernel, dim3(svo_div_up(W, 64), svo_div_up(H, 4), batch), dim3(256), 0, st,
+                     ctx->d_eig, W, H, ctx->d_maxkey, quality, ctx->d_cand, ctx->d_ncand, ctx->lim.max_candidates,
+                     ctx->d_status);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)corner_select_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(corner_select_kernel, dim3(batch), dim3(SEL_THREADS), SEL_LDS_BYTES, st, ctx->d_cand,
+                     ctx->d_ncand, ctx->lim.max_candidates, W, H, (float)min_distance, max_corners,
+                     ctx->d_cell_count, ctx->d_cell_start, ctx->max_cells, ctx->d_sorted, ctx->d_state, xy, n,
+                     ctx->d_status);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+static int corner_check_args(svo_ctx* ctx, const void* img, int batch, int W, int H, int row_stride,
+                             int max_corners, const void* xy, const void* n) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, img && xy && n, "corner_detect: null buffer");
+  SVO_REQUIRE(ctx, W >= 3 && H >= 3 && W <= ctx->lim.max_width && H <= ctx->lim.max_height && row_stride >= W,
+              "corner_detect: image size outside the limits given to svo_create");
+  SVO_REQUIRE(ctx, batch >= 1 && batch <= ctx->lim.max_batch, "corner_detect: batch outside limits");
+  SVO_REQUIRE(ctx, max_corners >= 1, "corner_detect: max_corners must be >= 1");
+  return SVO_OK;
+}
+
+static int corner_status(svo_ctx* ctx) {
+  int* h = (int*)ctx->h_pinned;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (*h) {
+    const int s = *h;
+    (void)hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream);
+    ctx->err = (s & 1)   ? "corner_detect: more NMS candidates than svo_limits.max_candidates"
+               : (s & 2) ? "corner_detect: more accepted corners than the select kernel holds (16384)"
+                         : "corner_detect: min-distance grid larger than the workspace";
+    return SVO_ERR_CAPACITY;
+  }
+  return SVO_OK;
+}
+
+extern "C" int svo_corner_detect_batch_dev(svo_ctx* ctx, const uint8_t* imgs, int batch, int width, int height,
+                                           int row_stride, size_t image_stride, int max_corners, double quality,
+                                           double min_distance, float* xy, int* n) {
+  int rc = corner_check_args(ctx, imgs, batch, width, height, row_stride, max_corners, xy, n);
+  if (rc) return rc;
+  return corner_launch(ctx, imgs, batch, width, height, row_stride, image_stride, max_corners, quality,
+                       min_distance, xy, n);
+}
+
+extern "C" int svo_corner_detect(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride,
+                                 int max_corners, double quality, double min_distance, float* xy, int* n) {
+  int rc = corner_check_args(ctx, img, 1, width, height, row_stride, max_corners, xy, n);
+  if (rc) return rc;
+  SvoScratch s(ctx);
+  uint8_t* d_img = s.take<uint8_t>((size_t)width * height);
+  float* d_xy = s.take<float>(2 * (size_t)max_corners);
+  int* d_n = s.take<int>(1);
+  if (!d_img || !d_xy || !d_n) { ctx->err = "corner_detect: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_img, width, img, row_stride, width, height, hipMemcpyHostToDevice, st));
+  rc = corner_launch(ctx, d_img, 1, width, height, width, (size_t)width * height, max_corners, quality,
+                     min_distance, d_xy, d_n);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(n, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
+  rc = corner_status(ctx);
+  if (rc) return rc;
+  if (*n > 0) SVO_HIP_CHECK(ctx, hipMemcpy(xy, d_xy, sizeof(float) * 2 * (size_t)*n, hipMemcpyDeviceToHost));
+  return SVO_OK;
+}
+
+extern "C" int svo_corner_response(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride,
+                                   float* eig) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, img && eig, "corner_response: null buffer");
+  SVO_REQUIRE(ctx, width >= 3 && height >= 3 && width <= ctx->lim.max_width && height <= ctx->lim.max_height,
+              "corner_response: image size outside limits");
+  SvoScratch s(ctx);
+  uint8_t* d_img = s.take<uint8_t>((size_t)width * height);
+  if (!d_img) { ctx->err = "corner_response: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_img, width, img, row_stride, width, height, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned), st));
+  hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(width, TX), svo_div_up(height, TY), 1), dim3(256), 0,
+                     st, d_img, width, height, width, (size_t)width * height, ctx->d_eig, ctx->d_maxkey);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(eig, ctx->d_eig, sizeof(float) * (size_t)width * height, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  return SVO_OK;
+}

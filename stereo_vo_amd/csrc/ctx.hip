@@ -1,0 +1,73 @@
+// Context lifetime and workspace (svo.h: svo_create / svo_destroy / svo_stream / svo_sync).
+#include "common.h"
+
+extern "C" const char* svo_version(void) { return "stereo_vo_amd 0.1 (gfx950, HIP, wave64)"; }
+
+extern "C" const char* svo_last_error(const svo_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" void* svo_stream(svo_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int svo_sync(svo_ctx* ctx) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return SVO_OK;
+}
+
+extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
+  if (!out || !lim) return SVO_ERR_INVALID;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return SVO_ERR_NO_DEVICE;
+  svo_ctx* c = new svo_ctx();
+  c->device = device;
+  c->lim = *lim;
+  if (c->lim.max_batch < 1) c->lim.max_batch = 1;
+  if (c->lim.max_corners < 1) c->lim.max_corners = 300;
+  if (c->lim.max_candidates < 1024) c->lim.max_candidates = 1024;
+  if (c->lim.max_features < 1) c->lim.max_features = 400;
+  auto fail = [&](const char* what, hipError_t e) {
+    fprintf(stderr, "svo_create: %s: %s\n", what, hipGetErrorString(e));
+    svo_destroy(c);
+    return SVO_ERR_HIP;
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+  const size_t px = (size_t)c->lim.max_width * c->lim.max_height;
+  const size_t B = (size_t)c->lim.max_batch;
+  // generic scratch: enough for two images + pyramids + dense outputs of the host-pointer wrappers
+  c->ws_bytes = 24 * px + (size_t)(64 << 20);
+  c->max_cells = (int)(px / 4 + 64);  // min_distance >= 2 px cells
+  c->pinned_bytes = 1 << 20;
+#define ALLOC(ptr, bytes) \
+  if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return fail(#ptr, e)
+  ALLOC(c->d_ws, c->ws_bytes);
+  ALLOC(c->d_eig, B * px * sizeof(float));
+  ALLOC(c->d_maxkey, B * sizeof(unsigned));
+  ALLOC(c->d_cand, B * c->lim.max_candidates * sizeof(unsigned long long));
+  ALLOC(c->d_sorted, B * c->lim.max_candidates * sizeof(unsigned long long));
+  ALLOC(c->d_state, B * c->lim.max_candidates);
+  ALLOC(c->d_ncand, B * sizeof(int));
+  ALLOC(c->d_cell_count, B * (size_t)c->max_cells * sizeof(int));
+  ALLOC(c->d_cell_start, B * ((size_t)c->max_cells + 1) * sizeof(int));
+  ALLOC(c->d_status, 64);
+#undef ALLOC
+  if ((e = hipHostMalloc(&c->h_pinned, c->pinned_bytes, hipHostMallocDefault)) != hipSuccess) return fail("pinned", e);
+  if ((e = hipMemsetAsync(c->d_status, 0, 64, c->stream)) != hipSuccess) return fail("memset", e);
+  if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("sync", e);
+  *out = c;
+  return SVO_OK;
+}
+
+extern "C" void svo_destroy(svo_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->d_ws, c->d_eig, c->d_maxkey, c->d_cand, c->d_sorted, c->d_state, c->d_ncand,
+                  c->d_cell_count, c->d_cell_start, c->d_status};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}

@@ -1,0 +1,168 @@
+// Deterministic KITTI-shaped synthetic stereo stream (not part of the reference).
+// An infinite procedural street: textured ground plane, two side walls and axis-aligned
+// billboards, ray-cast per pixel (2x2 supersampling) from a camera that drives forward with a
+// small constant yaw rate.  Left/right/temporal views are geometrically consistent by
+// construction (same world, different camera centre), including occlusions.
+// Only + - * / floor and integer hashing are used (no libm transcendental), and the file is built
+// with -ffp-contract=off, so the images are bit-identical on every host.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "svo.h"
+
+namespace {
+inline uint64_t mix(uint64_t z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+inline uint64_t hash3(uint64_t seed, int64_t a, int64_t b, int64_t c) {
+  return mix(mix(mix(seed ^ (uint64_t)a * 0x9E3779B97F4A7C15ull) ^ (uint64_t)b * 0xC2B2AE3D27D4EB4Full) ^
+             (uint64_t)c * 0x165667B19E3779F9ull);
+}
+inline double unit(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740992.0); }
+
+struct Cam { double R[9]; double C[3]; };
+
+void cam_at(const svo_synth_params* p, int frame, Cam* cam) {
+  const double a = 0.5 * p->yaw_per_frame;  // half-tangent of the per-frame yaw
+  const double c = (1.0 - a * a) / (1.0 + a * a), s = 2.0 * a / (1.0 + a * a);
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, C[3] = {0, 0, 0};
+  for (int i = 0; i < frame; ++i) {
+    // C += R * (step_x, 0, step_z)
+    C[0] += R[0] * p->step_x + R[2] * p->step_z;
+    C[1] += R[3] * p->step_x + R[5] * p->step_z;
+    C[2] += R[6] * p->step_x + R[8] * p->step_z;
+    // R = R * Ry(c, s),  Ry = [c 0 s; 0 1 0; -s 0 c]
+    double N[9];
+    for (int r = 0; r < 3; ++r) {
+      N[3 * r + 0] = R[3 * r + 0] * c - R[3 * r + 2] * s;
+      N[3 * r + 1] = R[3 * r + 1];
+      N[3 * r + 2] = R[3 * r + 0] * s + R[3 * r + 2] * c;
+    }
+    std::memcpy(R, N, sizeof(R));
+  }
+  std::memcpy(cam->R, R, sizeof(R));
+  std::memcpy(cam->C, C, sizeof(C));
+}
+
+const double kCamHeight = 1.65, kWallX = 7.5, kSpacing = 2.5, kFirstZ = 12.0;
+
+// two-octave blocky texture + soft variation, in [0,255]
+inline double texture(uint64_t seed, int plane, double a, double b) {
+  const double c1 = unit(hash3(seed, plane, (int64_t)std::floor(a / 0.55), (int64_t)std::floor(b / 0.55)));
+  const double c2 = unit(hash3(seed, plane + 7777, (int64_t)std::floor(a / 0.14), (int64_t)std::floor(b / 0.14)));
+  const double c3 = unit(hash3(seed, plane + 5555, (int64_t)std::floor(a / 2.3), (int64_t)std::floor(b / 2.3)));
+  return 30.0 + 120.0 * c1 + 55.0 * c2 + 35.0 * c3;
+}
+
+inline double shade(const svo_synth_params* p, const double* O, const double* d) {
+  double best = 1e30, val = 205.0 - 40.0 * (d[1] < 0 ? -d[1] : 0);  // sky
+  if (d[1] > 1e-9) {  // ground Y = kCamHeight
+    const double l = (kCamHeight - O[1]) / d[1];
+    if (l > 0 && l < best) { best = l; val = texture(p->seed, 1, O[0] + l * d[0], O[2] + l * d[2]); }
+  }
+  if (d[0] > 1e-9) {
+    const double l = (kWallX - O[0]) / d[0];
+    if (l > 0 && l < best && O[1] + l * d[1] > -6.0) { best = l; val = texture(p->seed, 2, O[1] + l * d[1], O[2] + l * d[2]); }
+  } else if (d[0] < -1e-9) {
+    const double l = (-kWallX - O[0]) / d[0];
+    if (l > 0 && l < best && O[1] + l * d[1] > -6.0) { best = l; val = texture(p->seed, 3, O[1] + l * d[1], O[2] + l * d[2]); }
+  }
+  if (d[2] > 1e-9 && p->n_billboards > 0) {
+    int64_t i0 = (int64_t)std::floor((O[2] - kFirstZ) / kSpacing);
+    if (i0 < 0) i0 = 0;
+    for (int64_t i = i0; i < i0 + p->n_billboards; ++i) {
+      const double z = kFirstZ + (double)i * kSpacing + 0.85 * kSpacing * unit(hash3(p->seed, 11, i, 0));
+      const double l = (z - O[2]) / d[2];
+      if (l <= 0) continue;
+      if (l >= best) break;
+      const double xc = -6.0 + 12.0 * unit(hash3(p->seed, 12, i, 0));
+      const double hw = 0.7 + 1.6 * unit(hash3(p->seed, 13, i, 0));
+      const double top = kCamHeight - (1.2 + 2.8 * unit(hash3(p->seed, 14, i, 0)));
+      const double X = O[0] + l * d[0], Y = O[1] + l * d[1];
+      if (X > xc - hw && X < xc + hw && Y > top && Y < kCamHeight) {
+        best = l;
+        val = texture(p->seed, 100 + (int)(i % 1000), X, Y);
+        break;
+      }
+    }
+  }
+  if (best < 1e29) {  // distance fog towards a flat grey (limits far-field aliasing)
+    double t = (best - 45.0) / 75.0;
+    t = t < 0 ? 0 : (t > 1 ? 1 : t);
+    val = val * (1.0 - t) + 150.0 * t;
+  }
+  return val;
+}
+
+void render_one(const svo_synth_params* p, const Cam& cam, double ox, uint8_t* img) {
+  const int W = p->width, H = p->height;
+  const double O[3] = {cam.C[0] + cam.R[0] * ox, cam.C[1] + cam.R[3] * ox, cam.C[2] + cam.R[6] * ox};
+  const double inv_f = 1.0 / p->focal;
+  auto rows = [&](int v0, int v1) {
+  for (int v = v0; v < v1; ++v)
+    for (int u = 0; u < W; ++u) {
+      double acc = 0;
+      for (int sy = 0; sy < 2; ++sy)
+        for (int sx = 0; sx < 2; ++sx) {
+          const double dc[3] = {((double)u - 0.25 + 0.5 * sx - p->cx) * inv_f,
+                                ((double)v - 0.25 + 0.5 * sy - p->cy) * inv_f, 1.0};
+          const double d[3] = {cam.R[0] * dc[0] + cam.R[1] * dc[1] + cam.R[2] * dc[2],
+                               cam.R[3] * dc[0] + cam.R[4] * dc[1] + cam.R[5] * dc[2],
+                               cam.R[6] * dc[0] + cam.R[7] * dc[1] + cam.R[8] * dc[2]};
+          acc += shade(p, O, d);
+        }
+      const double m = acc * 0.25;
+      const int q = (int)std::floor(m + 0.5);
+      img[(size_t)v * W + u] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+    }
+  };
+  unsigned nt = std::thread::hardware_concurrency();
+  if (nt == 0) nt = 1;
+  if (nt > 16) nt = 16;
+  std::vector<std::thread> pool;
+  for (unsigned t = 0; t < nt; ++t) pool.emplace_back(rows, (int)((long)H * t / nt), (int)((long)H * (t + 1) / nt));
+  for (auto& th : pool) th.join();
+}
+}  // namespace
+
+extern "C" void svo_synth_default_params(svo_synth_params* p, int width, int height) {
+  std::memset(p, 0, sizeof(*p));
+  p->seed = 0x5EED0001ull;
+  p->width = width;
+  p->height = height;
+  // config/kitti00.yaml:1-4
+  p->focal = 718.856;
+  p->cx = 607.1928 * (double)width / 1241.0;
+  p->cy = 185.2157 * (double)height / 376.0;
+  p->baseline = 0.537165718864418;
+  p->step_z = 0.8;
+  p->step_x = 0.0;
+  p->yaw_per_frame = 0.004;
+  p->n_billboards = 40;
+}
+
+extern "C" int svo_synth_render(const svo_synth_params* p, int frame, uint8_t* left, uint8_t* right) {
+  if (!p || frame < 0 || p->width <= 0 || p->height <= 0) return SVO_ERR_INVALID;
+  Cam cam;
+  cam_at(p, frame, &cam);
+  if (left) render_one(p, cam, 0.0, left);
+  if (right) render_one(p, cam, p->baseline, right);
+  return SVO_OK;
+}
+
+extern "C" int svo_synth_pose(const svo_synth_params* p, int frame, double* rt12) {
+  if (!p || frame < 0) return SVO_ERR_INVALID;
+  Cam cam;
+  cam_at(p, frame, &cam);
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) rt12[4 * r + c] = cam.R[3 * r + c];
+    rt12[4 * r + 3] = cam.C[r];
+  }
+  return SVO_OK;
+}
