@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t* __r
     const float bq = (float)((s[1][0] + s[1][1]) + s[1][2]);
     const float c = (float)((s[2][0] + s[2][1]) + s[2][2]) * 0.5f;
     const float d = a - c;
-    const float e = (a + c) - __fsqrt_rn(d * d + bq * bq);
+    const float e = (a + c) - sqrtf(d * d + bq * bq);
     eig[(size_t)b * W * H + (size_t)gy * W + gx] = e;
     const unsigned k = f32_key(e);
     lmax = k > lmax ? k : lmax;

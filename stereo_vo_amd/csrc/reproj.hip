@@ -51,27 +51,31 @@ extern "C" int svo_reproj_eval(svo_ctx* ctx, int n, const double* pose7, const d
                                double* jpose14, double* jpoint6) {
   if (!ctx) return SVO_ERR_INVALID;
   SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (pose7 && point3 && obs2 && r2)), "reproj_eval: null buffer");
-  if (n == 0) return SVO_OK;
-  SvoScratch s(ctx);
-  double* d_pose = s.take<double>(7 * (size_t)n);
-  double* d_pt = s.take<double>(3 * (size_t)n);
-  double* d_obs = s.take<double>(2 * (size_t)n);
-  double* d_r = s.take<double>(2 * (size_t)n);
-  double* d_jq = jpose14 ? s.take<double>(14 * (size_t)n) : nullptr;
-  double* d_jx = jpoint6 ? s.take<double>(6 * (size_t)n) : nullptr;
-  if (!d_pose || !d_pt || !d_obs || !d_r || (jpose14 && !d_jq) || (jpoint6 && !d_jx)) {
-    ctx->err = "reproj_eval: batch exceeds workspace";
-    return SVO_ERR_CAPACITY;
-  }
   hipStream_t st = ctx->stream;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d_pose, pose7, sizeof(double) * 7 * n, hipMemcpyHostToDevice, st));
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d_pt, point3, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d_obs, obs2, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
-  int rc = svo_reproj_eval_dev(ctx, n, d_pose, d_pt, d_obs, focal, cx, cy, d_r, d_jq, d_jx);
-  if (rc) return rc;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(r2, d_r, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, st));
-  if (jpose14) SVO_HIP_CHECK(ctx, hipMemcpyAsync(jpose14, d_jq, sizeof(double) * 14 * n, hipMemcpyDeviceToHost, st));
-  if (jpoint6) SVO_HIP_CHECK(ctx, hipMemcpyAsync(jpoint6, d_jx, sizeof(double) * 6 * n, hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  // host batches are streamed through the fixed workspace in chunks (34 doubles per observation)
+  const int chunk_max = (int)((ctx->ws_bytes - 4096) / (34 * sizeof(double)));
+  for (int base = 0; base < n; base += chunk_max) {
+    const int m = n - base < chunk_max ? n - base : chunk_max;
+    SvoScratch s(ctx);
+    double* d_pose = s.take<double>(7 * (size_t)m);
+    double* d_pt = s.take<double>(3 * (size_t)m);
+    double* d_obs = s.take<double>(2 * (size_t)m);
+    double* d_r = s.take<double>(2 * (size_t)m);
+    double* d_jq = jpose14 ? s.take<double>(14 * (size_t)m) : nullptr;
+    double* d_jx = jpoint6 ? s.take<double>(6 * (size_t)m) : nullptr;
+    if (!d_pose || !d_pt || !d_obs || !d_r || (jpose14 && !d_jq) || (jpoint6 && !d_jx)) {
+      ctx->err = "reproj_eval: workspace too small";
+      return SVO_ERR_CAPACITY;
+    }
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(d_pose, pose7 + 7 * (size_t)base, sizeof(double) * 7 * m, hipMemcpyHostToDevice, st));
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(d_pt, point3 + 3 * (size_t)base, sizeof(double) * 3 * m, hipMemcpyHostToDevice, st));
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(d_obs, obs2 + 2 * (size_t)base, sizeof(double) * 2 * m, hipMemcpyHostToDevice, st));
+    int rc = svo_reproj_eval_dev(ctx, m, d_pose, d_pt, d_obs, focal, cx, cy, d_r, d_jq, d_jx);
+    if (rc) return rc;
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(r2 + 2 * (size_t)base, d_r, sizeof(double) * 2 * m, hipMemcpyDeviceToHost, st));
+    if (jpose14) SVO_HIP_CHECK(ctx, hipMemcpyAsync(jpose14 + 14 * (size_t)base, d_jq, sizeof(double) * 14 * m, hipMemcpyDeviceToHost, st));
+    if (jpoint6) SVO_HIP_CHECK(ctx, hipMemcpyAsync(jpoint6 + 6 * (size_t)base, d_jx, sizeof(double) * 6 * m, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
   return SVO_OK;
 }
