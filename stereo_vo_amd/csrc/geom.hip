@@ -1,0 +1,183 @@
+// a8 — per-feature stereo reprojection (reference src/image_processor.cpp:178-207) and
+// a6 — new-vs-tracked dedup (reference src/image_processor.cpp:113-128).
+// Both are "predicate + stable compaction" over at most a few thousand features: one 1024-thread
+// workgroup, ballot/popcount prefix inside each wave, LDS prefix across the 16 waves.  Output order is
+// the input order, as the reference's push_back loops produce.
+#include "kernels.h"
+
+namespace {
+constexpr int CT = 1024;
+
+// Stable compaction step for one chunk of CT items; returns this thread's output slot or -1.
+__device__ __forceinline__ int compact_slot(bool keep, int& base, int* sWave) {
+  const unsigned long long mask = __ballot(keep);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int before = __popcll(mask & ((1ull << lane) - 1ull));
+  if (lane == 0) sWave[wave] = __popcll(mask);
+  __syncthreads();
+  int off = 0, total = 0;
+  for (int w = 0; w < CT / 64; ++w) {
+    const int c = sWave[w];
+    if (w < wave) off += c;
+    total += c;
+  }
+  const int slot = keep ? base + off + before : -1;
+  base += total;
+  __syncthreads();
+  return slot;
+}
+}  // namespace
+
+__global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict__ xy, const float* __restrict__ disp,
+                                                         const int* __restrict__ n_dev, int n_host, SvoMat4 M,
+                                                         float* __restrict__ kept_xy, float* __restrict__ xyz,
+                                                         int* __restrict__ kept_index, int* __restrict__ n_kept) {
+  __shared__ int sWave[CT / 64];
+  const int n = n_dev ? *n_dev : n_host;
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += CT) {
+    const int i = c0 + threadIdx.x;
+    float x = 0.f, y = 0.f, d = 0.f;
+    bool keep = false;
+    if (i < n) {
+      x = xy[2 * i]; y = xy[2 * i + 1]; d = disp[i];
+      keep = d > 0.0f;  // src/image_processor.cpp:194
+    }
+    const int slot = compact_slot(keep, base, sWave);
+    if (slot >= 0) {
+      const float v[4] = {x, y, d, 1.0f};
+      float wv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += (double)M.m[4 * r + k] * (double)v[k];
+        wv[r] = (float)s;
+      }
+      kept_xy[2 * slot] = x; kept_xy[2 * slot + 1] = y;
+      xyz[3 * slot] = wv[0] / wv[3]; xyz[3 * slot + 1] = wv[1] / wv[3]; xyz[3 * slot + 2] = wv[2] / wv[3];
+      if (kept_index) kept_index[slot] = i;
+    }
+  }
+  if (threadIdx.x == 0) *n_kept = base;
+}
+
+__global__ __launch_bounds__(CT) void dedup_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
+                                                   int n_det_host, const float* __restrict__ trk,
+                                                   const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
+                                                   float* __restrict__ kept_xy, int* __restrict__ n_kept) {
+  __shared__ int sWave[CT / 64];
+  const int nd = n_det_dev ? *n_det_dev : n_det_host;
+  const int nt = n_trk_dev ? *n_trk_dev : n_trk_host;
+  int base = 0;
+  for (int c0 = 0; c0 < nd; c0 += CT) {
+    const int i = c0 + threadIdx.x;
+    bool keep = false;
+    float x = 0.f, y = 0.f;
+    if (i < nd) {
+      x = det[2 * i]; y = det[2 * i + 1];
+      keep = true;
+      for (int j = 0; j < nt; ++j) {
+        const float dx = x - trk[2 * j], dy = y - trk[2 * j + 1];
+        if (sqrtf(dx * dx + dy * dy) < min_d) { keep = false; break; }  // src/image_processor.cpp:118-123
+      }
+    }
+    const int slot = compact_slot(keep, base, sWave);
+    if (slot >= 0) { kept_xy[2 * slot] = x; kept_xy[2 * slot + 1] = y; }
+  }
+  if (threadIdx.x == 0) *n_kept = base;
+}
+
+SvoMat4 svo_k_reprojection_matrix(const float* pose16, float focal, float cx, float cy, float baseline) {
+  float Q[16] = {0};
+  Q[0] = (float)(1.0 / (double)focal);
+  Q[5] = (float)(1.0 / (double)focal);
+  Q[3] = -cx / focal;
+  Q[7] = -cy / focal;
+  Q[11] = 1.0f;
+  Q[14] = (float)(1.0 / (double)(baseline * focal));
+  SvoMat4 M;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      double s = 0.0;
+      for (int k = 0; k < 4; ++k) s += (double)pose16[4 * i + k] * (double)Q[4 * k + j];
+      M.m[4 * i + j] = (float)s;
+    }
+  return M;
+}
+
+int svo_k_triangulate(svo_ctx* ctx, const float* xy, const float* disp, const int* n_dev, int n_max,
+                      const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept) {
+  hipLaunchKernelGGL(triangulate_kernel, dim3(1), dim3(CT), 0, ctx->stream, xy, disp, n_dev, n_max, M, kept_xy, xyz,
+                     kept_index, n_kept);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_k_dedup(svo_ctx* ctx, const float* det_xy, const int* n_det_dev, int n_det_max, const float* trk_xy,
+                const int* n_trk_dev, int n_trk_max, float min_distance, float* kept_xy, int* n_kept) {
+  hipLaunchKernelGGL(dedup_kernel, dim3(1), dim3(CT), 0, ctx->stream, det_xy, n_det_dev, n_det_max, trk_xy, n_trk_dev,
+                     n_trk_max, min_distance, kept_xy, n_kept);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+extern "C" int svo_triangulate(svo_ctx* ctx, const float* xy, const float* disp, int n, const float* pose16,
+                               float focal, float cx, float cy, float baseline, float* kept_xy, float* xyz,
+                               int* kept_index, int* n_kept) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && pose16 && n_kept && (n == 0 || (xy && disp && kept_xy && xyz)), "triangulate: null buffer");
+  *n_kept = 0;
+  if (n == 0) return SVO_OK;
+  SvoScratch s(ctx);
+  float* dxy = s.take<float>(2 * (size_t)n);
+  float* dd = s.take<float>(n);
+  float* dk = s.take<float>(2 * (size_t)n);
+  float* d3 = s.take<float>(3 * (size_t)n);
+  int* di = s.take<int>(n);
+  int* dn = s.take<int>(1);
+  if (!dxy || !dd || !dk || !d3 || !di || !dn) { ctx->err = "triangulate: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dd, disp, sizeof(float) * n, hipMemcpyHostToDevice, st));
+  const SvoMat4 M = svo_k_reprojection_matrix(pose16, focal, cx, cy, baseline);
+  int rc = svo_k_triangulate(ctx, dxy, dd, nullptr, n, M, dk, d3, di, dn);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(n_kept, dn, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const int m = *n_kept;
+  if (m > 0) {
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(kept_xy, dk, sizeof(float) * 2 * m, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(xyz, d3, sizeof(float) * 3 * m, hipMemcpyDeviceToHost, st));
+    if (kept_index) SVO_HIP_CHECK(ctx, hipMemcpyAsync(kept_index, di, sizeof(int) * m, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
+  return SVO_OK;
+}
+
+extern "C" int svo_dedup(svo_ctx* ctx, const float* detected_xy, int n_detected, const float* tracked_xy,
+                         int n_tracked, float min_distance, float* kept_xy, int* n_kept) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, n_detected >= 0 && n_tracked >= 0 && n_kept, "dedup: bad sizes");
+  SVO_REQUIRE(ctx, (n_detected == 0 || (detected_xy && kept_xy)) && (n_tracked == 0 || tracked_xy), "dedup: null buffer");
+  *n_kept = 0;
+  if (n_detected == 0) return SVO_OK;
+  SvoScratch s(ctx);
+  float* dd = s.take<float>(2 * (size_t)n_detected);
+  float* dt = s.take<float>(2 * (size_t)(n_tracked > 0 ? n_tracked : 1));
+  float* dk = s.take<float>(2 * (size_t)n_detected);
+  int* dn = s.take<int>(1);
+  if (!dd || !dt || !dk || !dn) { ctx->err = "dedup: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dd, detected_xy, sizeof(float) * 2 * n_detected, hipMemcpyHostToDevice, st));
+  if (n_tracked > 0) SVO_HIP_CHECK(ctx, hipMemcpyAsync(dt, tracked_xy, sizeof(float) * 2 * n_tracked, hipMemcpyHostToDevice, st));
+  int rc = svo_k_dedup(ctx, dd, nullptr, n_detected, dt, nullptr, n_tracked, min_distance, dk, dn);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(n_kept, dn, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (*n_kept > 0) {
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(kept_xy, dk, sizeof(float) * 2 * (size_t)*n_kept, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
+  return SVO_OK;
+}

@@ -1,0 +1,28 @@
+// Internal device-pointer entry points shared between the C-ABI wrappers and the in-library
+// pipeline (host/pipeline.cpp).  All asynchronous on ctx->stream.  Counts that are produced on the
+// device stay on the device (`const int* n_dev`) so stages chain without host round trips;
+// `n_max` bounds the launch.
+#ifndef SVO_KERNELS_H_
+#define SVO_KERNELS_H_
+#include "common.h"
+
+struct SvoMat4 { float m[16]; };
+
+// a8: M = float(pose * Q) formed on the host in the reference's order (src/image_processor.cpp:183-189,202).
+SvoMat4 svo_k_reprojection_matrix(const float* pose16, float focal, float cx, float cy, float baseline);
+int svo_k_triangulate(svo_ctx* ctx, const float* xy, const float* disp, const int* n_dev, int n_max,
+                      const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept);
+// a6
+int svo_k_dedup(svo_ctx* ctx, const float* det_xy, const int* n_det_dev, int n_det_max, const float* trk_xy,
+                const int* n_trk_dev, int n_trk_max, float min_distance, float* kept_xy, int* n_kept);
+// a3: pyramid of `batch` images. levels buffer: per image svo_k_pyramid_bytes(w,h) bytes, level 0 first.
+size_t svo_k_pyramid_bytes(int w, int h);
+int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride,
+                        size_t image_stride, uint8_t* pyr, size_t pyr_stride);
+// forward+backward LK and the survivor filter of FeatureTracker::track_features.
+int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
+                const float* initial_xy, const int* n_dev, int n_max, float* fwd_xy, uint8_t* keep_flag,
+                float* parallax, float* kept_xy, int* kept_index, int* n_kept, float* av_parallax);
+int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
+             int n, float* out_xy, uint8_t* status);
+#endif

@@ -1,0 +1,437 @@
+// a3 — pyramidal Lucas-Kanade: cv::calcOpticalFlowPyrLK(prev, next, pts, out, status, err, Size(21,21), 3,
+// TermCriteria(COUNT+EPS,30,0.01), 0, 1e-2) at reference src/feature_tracker.cpp:23-26,32-35, and the
+// survivor / parallax filter of FeatureTracker::track_features, src/feature_tracker.cpp:38-64.
+// Semantics: SURVEY.md Appendix A.3 with the arithmetic declared in oracle/ora_lk.cpp (14-bit bilinear
+// weights, int16 patches, EXACT int64 window sums => the wave reduction order cannot change a bit,
+// f32 2x2 solve without FMA contraction).
+//
+//   pyr_copy_kernel / pyr_down_kernel : 4-level pyramid, [1 4 6 4 1]^2, REFLECT_101, (s+128)>>8.
+//   lk_fb_kernel  : one wavefront (64 lanes) per feature.  Per level the 24x24 source patch is staged in
+//                   LDS, Scharr derivatives are formed on the fly (no derivative image ever hits HBM),
+//                   the 21x21 int16 template/gradient patches live in LDS, the 2x2 normal matrix and the
+//                   per-iteration mismatch vector are wave-reduced with DPP shuffles.  Forward and
+//                   backward tracking and the reference's keep/drop predicate are fused in one launch.
+//   track_compact_kernel : stable compaction + the sequential f32 parallax sum (order matters).
+#include "kernels.h"
+
+namespace {
+constexpr int WIN = 21, HALF = 10, LEVELS = 4, MAX_ITER = 30;
+constexpr int G = WIN + 1;      // 22: bilinear needs one extra row/col
+constexpr int RP = WIN + 3;     // 24: Scharr needs one more on each side
+constexpr float MIN_EIG = 1e-2f;
+constexpr float FLT_SCALE = 1.0f / (float)(1 << 20);
+constexpr float FLT_EPS = 1.1920928955078125e-7f;
+
+struct Pyr {
+  const uint8_t* p[LEVELS];
+  int w[LEVELS], h[LEVELS];
+};
+
+__device__ __forceinline__ Pyr make_pyr(const uint8_t* base, int w, int h) {
+  Pyr P;
+  size_t off = 0;
+  for (int l = 0; l < LEVELS; ++l) {
+    P.p[l] = base + off; P.w[l] = w; P.h[l] = h;
+    off += (size_t)w * h;
+    w = (w + 1) / 2; h = (h + 1) / 2;
+  }
+  return P;
+}
+
+__device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+struct LkShared {
+  uint8_t raw[RP * RP];      // source patch of the template image (reflect-101 staged)
+  uint8_t jraw[G * G + 4];   // per-iteration patch of the target image
+  short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
+  short gx[G * G], gy[G * G];
+};
+
+// One feature through all pyramid levels; every lane of the wave returns the same values.
+__device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, float* ox, float* oy, LkShared& S) {
+  const int lane = threadIdx.x & 63;
+  uint8_t status = 1;
+  float nx = 0.f, ny = 0.f;
+  for (int level = LEVELS - 1; level >= 0; --level) {
+    const uint8_t* Ip = A.p[level];
+    const uint8_t* Jp = B.p[level];
+    const int Iw_ = A.w[level], Ih_ = A.h[level], Jw_ = B.w[level], Jh_ = B.h[level];
+    const float sc = (float)(1.0 / (double)(1 << level));
+    float pxl = px0 * sc, pyl = py0 * sc;
+    if (level == LEVELS - 1) { nx = pxl; ny = pyl; } else { nx = nx * 2.0f; ny = ny * 2.0f; }
+    pxl -= (float)HALF; pyl -= (float)HALF;
+    const int ipx = (int)floorf(pxl), ipy = (int)floorf(pyl);
+    if (ipx < -WIN || ipx >= Iw_ || ipy < -WIN || ipy >= Ih_) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    float a = pxl - (float)ipx, b = pyl - (float)ipy;
+    int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << 14));
+    int iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
+    int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
+    int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    __syncthreads();
+    // stage the (WIN+3)^2 raw patch: tile (r,c) <-> image (ipy-1+r, ipx-1+c), reflect-101
+    for (int i = lane; i < RP * RP; i += 64) {
+      const int r = i / RP, c = i % RP;
+      S.raw[i] = Ip[(size_t)reflect101(ipy - 1 + r, Ih_) * Iw_ + reflect101(ipx - 1 + c, Iw_)];
+    }
+    __syncthreads();
+    // Scharr at the (WIN+1)^2 grid; zero outside the image (BORDER_CONSTANT derivative padding)
+    for (int i = lane; i < G * G; i += 64) {
+      const int r = i / G, c = i % G;
+      const int X = ipx + c, Y = ipy + r;
+      int vx = 0, vy = 0;
+      if (X >= 0 && X < Iw_ && Y >= 0 && Y < Ih_) {
+        const uint8_t* t = &S.raw[r * RP + c];  // top-left of the 3x3 neighbourhood (centre at r+1,c+1)
+        const int t00 = t[0], t01 = t[1], t02 = t[2];
+        const int t10 = t[RP], t11 = t[RP + 1], t12 = t[RP + 2];
+        const int t20 = t[2 * RP], t21 = t[2 * RP + 1], t22 = t[2 * RP + 2];
+        const int s0 = (t00 + t20) * 3 + t10 * 10, s2 = (t02 + t22) * 3 + t12 * 10;
+        const int d0 = t20 - t00, d1 = t21 - t01, d2 = t22 - t02;
+        vx = (short)(s2 - s0);
+        vy = (short)((d2 + d0) * 3 + d1 * 10);
+        (void)t11;
+      }
+      S.gx[i] = (short)vx; S.gy[i] = (short)vy;
+    }
+    __syncthreads();
+    long long sA11 = 0, sA12 = 0, sA22 = 0;
+    for (int i = lane; i < WIN * WIN; i += 64) {
+      const int r = i / WIN, c = i % WIN;
+      const int o = r * G + c, o1 = o + G;
+      const int rr = (r + 1) * RP + (c + 1);
+      const int ival = descale(S.raw[rr] * iw00 + S.raw[rr + 1] * iw01 + S.raw[rr + RP] * iw10 + S.raw[rr + RP + 1] * iw11, 9);
+      const int ixv = descale(S.gx[o] * iw00 + S.gx[o + 1] * iw01 + S.gx[o1] * iw10 + S.gx[o1 + 1] * iw11, 14);
+      const int iyv = descale(S.gy[o] * iw00 + S.gy[o + 1] * iw01 + S.gy[o1] * iw10 + S.gy[o1 + 1] * iw11, 14);
+      S.Iw[i] = (short)ival; S.dIx[i] = (short)ixv; S.dIy[i] = (short)iyv;
+      sA11 += (long long)(ixv * ixv);
+      sA12 += (long long)(ixv * iyv);
+      sA22 += (long long)(iyv * iyv);
+    }
+    sA11 = wave_sum_i64(sA11); sA12 = wave_sum_i64(sA12); sA22 = wave_sum_i64(sA22);
+    const float A11 = (float)(double)sA11 * FLT_SCALE;
+    const float A12 = (float)(double)sA12 * FLT_SCALE;
+    const float A22 = (float)(double)sA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float dif = A11 - A22;
+    const float minEig = (A22 + A11 - sqrtf(dif * dif + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+    if (minEig < MIN_EIG || D < FLT_EPS) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    D = 1.f / D;
+    float outx = nx, outy = ny;
+    nx -= (float)HALF; ny -= (float)HALF;
+    float pdx = 0.f, pdy = 0.f;
+    for (int j = 0; j < MAX_ITER; ++j) {
+      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+      if (inx < -WIN || inx >= Jw_ || iny < -WIN || iny >= Jh_) {
+        if (level == 0) status = 0;
+        break;
+      }
+      a = nx - (float)inx; b = ny - (float)iny;
+      iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << 14));
+      iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
+      iw10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
+      iw11 = (1 << 14) - iw00 - iw01 - iw10;
+      __syncthreads();
+      for (int i = lane; i < G * G; i += 64) {
+        const int r = i / G, c = i % G;
+        S.jraw[i] = Jp[(size_t)reflect101(iny + r, Jh_) * Jw_ + reflect101(inx + c, Jw_)];
+      }
+      __syncthreads();
+      long long sb1 = 0, sb2 = 0;
+      for (int i = lane; i < WIN * WIN; i += 64) {
+        const int r = i / WIN, c = i % WIN;
+        const int o = r * G + c;
+        const int diff = descale(S.jraw[o] * iw00 + S.jraw[o + 1] * iw01 + S.jraw[o + G] * iw10 + S.jraw[o + G + 1] * iw11, 9) - S.Iw[i];
+        sb1 += (long long)(diff * S.dIx[i]);
+        sb2 += (long long)(diff * S.dIy[i]);
+      }
+      sb1 = wave_sum_i64(sb1); sb2 = wave_sum_i64(sb2);
+      const float b1 = (float)(double)sb1 * FLT_SCALE;
+      const float b2 = (float)(double)sb2 * FLT_SCALE;
+      const float dx = (A12 * b2 - A22 * b1) * D;
+      const float dy = (A12 * b1 - A11 * b2) * D;
+      nx += dx; ny += dy;
+      outx = nx + (float)HALF; outy = ny + (float)HALF;
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= 0.01 * 0.01) break;
+      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+        outx -= dx * 0.5f; outy -= dy * 0.5f;
+        break;
+      }
+      pdx = dx; pdy = dy;
+    }
+    nx = outx; ny = outy;
+    if (status && level == 0) {
+      const float fx = nx - (float)HALF, fy = ny - (float)HALF;
+      const int ix = (int)floorf(fx), iy = (int)floorf(fy);
+      if (ix < -WIN || ix >= Jw_ || iy < -WIN || iy >= Jh_) status = 0;
+    }
+  }
+  *ox = nx; *oy = ny;
+  return status;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void pyr_copy_kernel(const uint8_t* __restrict__ imgs, int w, int h, int row_stride,
+                                                       size_t image_stride, uint8_t* __restrict__ pyr, size_t pyr_stride) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  pyr[(size_t)blockIdx.z * pyr_stride + (size_t)y * w + x] = imgs[(size_t)blockIdx.z * image_stride + (size_t)y * row_stride + x];
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(uint8_t* __restrict__ pyr, size_t pyr_stride, size_t src_off, int sw,
+                                                       int sh, size_t dst_off, int dw, int dh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= dw || y >= dh) return;
+  const uint8_t* src = pyr + (size_t)blockIdx.z * pyr_stride + src_off;
+  const int k[5] = {1, 4, 6, 4, 1};
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) {
+    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, sh) * sw;
+    int r = 0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r += k[i] * row[reflect101(2 * x + i - 2, sw)];
+    s += k[j] * r;
+  }
+  pyr[(size_t)blockIdx.z * pyr_stride + dst_off + (size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
+}
+
+__global__ __launch_bounds__(64) void lk_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
+                                                int h, const float* __restrict__ xy, int n, float* __restrict__ out,
+                                                uint8_t* __restrict__ status) {
+  __shared__ LkShared S;
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const Pyr A = make_pyr(pyrA, w, h), B = make_pyr(pyrB, w, h);
+  float ox, oy;
+  const uint8_t s = lk_point(A, B, xy[2 * f], xy[2 * f + 1], &ox, &oy, S);
+  if (threadIdx.x == 0) { out[2 * f] = ox; out[2 * f + 1] = oy; status[f] = s; }
+}
+
+// forward + backward + keep predicate (src/feature_tracker.cpp:44-55)
+__global__ __launch_bounds__(64) void lk_fb_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
+                                                   int h, const float* __restrict__ xy, const float* __restrict__ init_xy,
+                                                   const int* __restrict__ n_dev, int n_host, float* __restrict__ fwd,
+                                                   uint8_t* __restrict__ keep, float* __restrict__ parallax) {
+  __shared__ LkShared S;
+  const int n = n_dev ? *n_dev : n_host;
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const Pyr A = make_pyr(pyrA, w, h), B = make_pyr(pyrB, w, h);
+  const float x0 = xy[2 * f], y0 = xy[2 * f + 1];
+  float fx, fy, bx = 0.f, by = 0.f;
+  const uint8_t s1 = lk_point(A, B, x0, y0, &fx, &fy, S);
+  uint8_t s2 = 0;
+  if (s1) s2 = lk_point(B, A, fx, fy, &bx, &by, S);
+  if (threadIdx.x == 0) {
+    uint8_t k = 0;
+    float par = 0.f;
+    if (s1 && s2) {
+      const float ex = x0 - bx, ey = y0 - by;
+      if ((double)ex * (double)ex + (double)ey * (double)ey < 4.0) {  // norm(old - back) < 2
+        const float dx = fx - init_xy[2 * f], dy = fy - init_xy[2 * f + 1];
+        par = sqrtf(dx * dx + dy * dy);
+        k = !(par > 200.f);
+      }
+    }
+    fwd[2 * f] = fx; fwd[2 * f + 1] = fy; keep[f] = k; parallax[f] = par;
+  }
+}
+
+// Stable compaction of the kept features; av_parallax = (sequential float sum over kept)/n (SURVEY C-2).
+__global__ __launch_bounds__(1024) void track_compact_kernel(const float* __restrict__ fwd, const uint8_t* __restrict__ keep,
+                                                             const float* __restrict__ parallax, const int* __restrict__ n_dev,
+                                                             int n_host, float* __restrict__ kept_xy, int* __restrict__ kept_index,
+                                                             int* __restrict__ n_kept, float* __restrict__ av_parallax) {
+  __shared__ int sWave[16];
+  const int n = n_dev ? *n_dev : n_host;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int base = 0;
+  for (int c0 = 0; c0 < n; c0 += 1024) {
+    const int i = c0 + threadIdx.x;
+    const bool k = i < n && keep[i];
+    const unsigned long long mask = __ballot(k);
+    if (lane == 0) sWave[wave] = __popcll(mask);
+    __syncthreads();
+    int off = 0, total = 0;
+    for (int w = 0; w < 16; ++w) { const int c = sWave[w]; if (w < wave) off += c; total += c; }
+    if (k) {
+      const int slot = base + off + __popcll(mask & ((1ull << lane) - 1ull));
+      kept_xy[2 * slot] = fwd[2 * i]; kept_xy[2 * slot + 1] = fwd[2 * i + 1];
+      kept_index[slot] = i;
+    }
+    base += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float sum = 0.f;
+    for (int i = 0; i < n; ++i)
+      if (keep[i]) sum += parallax[i];
+    *n_kept = base;
+    *av_parallax = n > 0 ? sum / (float)n : 0.f;
+  }
+}
+
+// ----------------------------------------------------------------------------- host side
+size_t svo_k_pyramid_bytes(int w, int h) {
+  size_t s = 0;
+  for (int l = 0; l < LEVELS; ++l) { s += (size_t)w * h; w = (w + 1) / 2; h = (h + 1) / 2; }
+  return s;
+}
+
+int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride, size_t image_stride,
+                        uint8_t* pyr, size_t pyr_stride) {
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(pyr_copy_kernel, dim3(svo_div_up(w, 64), svo_div_up(h, 4), batch), dim3(256), 0, st, imgs, w, h,
+                     row_stride, image_stride, pyr, pyr_stride);
+  size_t src_off = 0;
+  int sw = w, sh = h;
+  for (int l = 1; l < LEVELS; ++l) {
+    const size_t dst_off = src_off + (size_t)sw * sh;
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    hipLaunchKernelGGL(pyr_down_kernel, dim3(svo_div_up(dw, 64), svo_div_up(dh, 4), batch), dim3(256), 0, st, pyr, pyr_stride,
+                       src_off, sw, sh, dst_off, dw, dh);
+    src_off = dst_off; sw = dw; sh = dh;
+  }
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy, int n,
+             float* out_xy, uint8_t* status) {
+  if (n <= 0) return SVO_OK;
+  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, n, out_xy, status);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
+                const float* initial_xy, const int* n_dev, int n_max, float* fwd_xy, uint8_t* keep_flag, float* parallax,
+                float* kept_xy, int* kept_index, int* n_kept, float* av_parallax) {
+  if (n_max > 0)
+    hipLaunchKernelGGL(lk_fb_kernel, dim3(n_max), dim3(64), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
+                       n_max, fwd_xy, keep_flag, parallax);
+  hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, fwd_xy, keep_flag, parallax, n_dev, n_max,
+                     kept_xy, kept_index, n_kept, av_parallax);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+static int lk_check(svo_ctx* ctx, const void* a, const void* b, int w, int h, int stride) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, a && b, "lk: null image");
+  SVO_REQUIRE(ctx, w >= 8 && h >= 8 && w <= ctx->lim.max_width && h <= ctx->lim.max_height && stride >= w,
+              "lk: image size outside limits");
+  return SVO_OK;
+}
+
+extern "C" int svo_build_pyramid(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride, uint8_t* levels,
+                                 size_t levels_bytes) {
+  int rc = lk_check(ctx, img, levels, width, height, row_stride);
+  if (rc) return rc;
+  const size_t pb = svo_k_pyramid_bytes(width, height);
+  SVO_REQUIRE(ctx, levels_bytes >= pb, "build_pyramid: output buffer too small");
+  SvoScratch s(ctx);
+  uint8_t* dI = s.take<uint8_t>((size_t)width * height);
+  uint8_t* dP = s.take<uint8_t>(pb);
+  if (!dI || !dP) { ctx->err = "build_pyramid: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dI, width, img, row_stride, width, height, hipMemcpyHostToDevice, st));
+  rc = svo_k_build_pyramid(ctx, dI, 1, width, height, width, (size_t)width * height, dP, pb);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(levels, dP, pb, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  return SVO_OK;
+}
+
+// uploads both images and builds both pyramids in the workspace
+static int lk_upload(svo_ctx* ctx, SvoScratch& s, const uint8_t* prev, const uint8_t* next, int w, int h, int stride,
+                     uint8_t** pA, uint8_t** pB) {
+  const size_t pb = svo_k_pyramid_bytes(w, h);
+  uint8_t* dI = s.take<uint8_t>(2 * (size_t)w * h);
+  uint8_t* dP = s.take<uint8_t>(2 * pb);
+  if (!dI || !dP) { ctx->err = "lk: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dI, w, prev, stride, w, h, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dI + (size_t)w * h, w, next, stride, w, h, hipMemcpyHostToDevice, st));
+  int rc = svo_k_build_pyramid(ctx, dI, 2, w, h, w, (size_t)w * h, dP, pb);
+  if (rc) return rc;
+  *pA = dP; *pB = dP + pb;
+  return SVO_OK;
+}
+
+extern "C" int svo_lk_track(svo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int row_stride,
+                            const float* xy, int n, float* out_xy, uint8_t* status) {
+  int rc = lk_check(ctx, prev, next, width, height, row_stride);
+  if (rc) return rc;
+  SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (xy && out_xy && status)), "lk_track: null buffer");
+  if (n == 0) return SVO_OK;
+  SvoScratch s(ctx);
+  uint8_t *pA, *pB;
+  rc = lk_upload(ctx, s, prev, next, width, height, row_stride, &pA, &pB);
+  if (rc) return rc;
+  float* dxy = s.take<float>(2 * (size_t)n);
+  float* dout = s.take<float>(2 * (size_t)n);
+  uint8_t* dst = s.take<uint8_t>(n);
+  if (!dxy || !dout || !dst) { ctx->err = "lk_track: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  rc = svo_k_lk(ctx, pA, pB, width, height, dxy, n, dout, dst);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(out_xy, dout, sizeof(float) * 2 * n, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  return SVO_OK;
+}
+
+extern "C" int svo_track_features(svo_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height,
+                                  int row_stride, const float* xy, const float* initial_xy, int n, float* kept_xy,
+                                  int* kept_index, int* n_kept, float* av_parallax) {
+  int rc = lk_check(ctx, prev, next, width, height, row_stride);
+  if (rc) return rc;
+  SVO_REQUIRE(ctx, n >= 0 && n_kept && av_parallax && (n == 0 || (xy && initial_xy && kept_xy && kept_index)),
+              "track_features: null buffer");
+  *n_kept = 0; *av_parallax = 0.f;
+  if (n == 0) return SVO_OK;
+  SvoScratch s(ctx);
+  uint8_t *pA, *pB;
+  rc = lk_upload(ctx, s, prev, next, width, height, row_stride, &pA, &pB);
+  if (rc) return rc;
+  float* dxy = s.take<float>(2 * (size_t)n);
+  float* dinit = s.take<float>(2 * (size_t)n);
+  float* dfwd = s.take<float>(2 * (size_t)n);
+  float* dpar = s.take<float>(n);
+  float* dkept = s.take<float>(2 * (size_t)n);
+  int* dkidx = s.take<int>(n);
+  uint8_t* dkeep = s.take<uint8_t>(n);
+  int* dn = s.take<int>(1);
+  float* dav = s.take<float>(1);
+  if (!dxy || !dinit || !dfwd || !dpar || !dkept || !dkidx || !dkeep || !dn || !dav) {
+    ctx->err = "track_features: workspace too small";
+    return SVO_ERR_CAPACITY;
+  }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dinit, initial_xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  rc = svo_k_track(ctx, pA, pB, width, height, dxy, dinit, nullptr, n, dfwd, dkeep, dpar, dkept, dkidx, dn, dav);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(n_kept, dn, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(av_parallax, dav, sizeof(float), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (*n_kept > 0) {
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(kept_xy, dkept, sizeof(float) * 2 * (size_t)*n_kept, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(kept_index, dkidx, sizeof(int) * (size_t)*n_kept, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
+  return SVO_OK;
+}

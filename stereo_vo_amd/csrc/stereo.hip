@@ -1,0 +1,259 @@
+// a7 — SAD block-matching disparity: cv::StereoBM::create(48, 21)->compute(L, R) + convertTo(CV_32F, 1/16)
+// at reference src/image_processor.cpp:173-176 (semantics: SURVEY.md Appendix A.2; XSOBEL prefilter
+// cap 31, minDisparity 0, textureThreshold 10, uniquenessRatio 15, no speckle / L-R check).
+// All integer arithmetic => bit-exact by construction, any summation order.
+//
+//   stereo_at_kernel     : what the pipeline uses.  The reference samples the dense map only at the
+//                          <=300 feature pixels (src/image_processor.cpp:193) and every step of the block
+//                          matcher is local, so evaluating it at those pixels alone is exactly
+//                          equivalent (SURVEY C-8).  One 256-thread workgroup per feature: the raw
+//                          23x23 (left) and 23x70 (right) patches are staged in LDS, prefiltered in LDS,
+//                          and the 48 SADs are accumulated by 4 waves (lane = disparity, wave = row
+//                          group) with LDS integer atomics.  No intermediate image touches HBM.
+//   stereo_prefilter_kernel + stereo_dense_kernel : the drop-in for StereoBM::compute (full CV_16S map).
+#include "common.h"
+
+namespace {
+constexpr int CAP = 31, TEXTURE_THRESHOLD = 10, UNIQUENESS_RATIO = 15;
+constexpr int MAX_NDISP = 64, MAX_BLOCK = 21;
+
+__device__ __forceinline__ int pf_row(int y, int H) {
+  if (y < 0) return H > 1 ? 1 : 0;
+  if (y >= H) return H > 1 ? H - 2 : 0;
+  return y;
+}
+
+// XSOBEL prefilter value at (x,y) from a raw image (global or LDS accessor).
+template <typename Load>
+__device__ __forceinline__ int prefilter_at(Load I, int x, int y, int W, int H) {
+  if (x <= 0 || x >= W - 1) return CAP;
+  if ((H & 1) && y == H - 1) return CAP;  // leftover odd row
+  const int y0 = pf_row(y - 1, H), y2 = pf_row(y + 1, H);
+  const int v = (I(x + 1, y0) - I(x - 1, y0)) + 2 * (I(x + 1, y) - I(x - 1, y)) + (I(x + 1, y2) - I(x - 1, y2));
+  return min(max(v, -CAP), CAP) + CAP;
+}
+
+// Winner selection + uniqueness + sub-pixel from sad[-1..ndisp] (index i = ndisp-1-d). Returns CV_16S value.
+__device__ __forceinline__ int bm_select(int* s /* points at index 0, s[-1] and s[ndisp] writable */, int ndisp,
+                                         int tsum) {
+  if (tsum < TEXTURE_THRESHOLD) return -16;
+  int minsad = 0x7fffffff, mind = -1;
+  for (int i = 0; i < ndisp; ++i)
+    if (s[i] < minsad) { minsad = s[i]; mind = i; }
+  const int thresh = minsad + (minsad * UNIQUENESS_RATIO / 100);
+  for (int i = 0; i < ndisp; ++i)
+    if ((i < mind - 1 || i > mind + 1) && s[i] <= thresh) return -16;
+  s[-1] = s[1];
+  s[ndisp] = s[ndisp - 2];
+  const int p = s[mind + 1], n = s[mind - 1];
+  const int dd = p + n - 2 * s[mind] + abs(p - n);
+  return (short)(((ndisp - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                        int W, int H, int stride, int ndisp, int block,
+                                                        const float* __restrict__ xy, const int* __restrict__ n_dev,
+                                                        int n_host, float* __restrict__ disp) {
+  const int n = n_dev ? *n_dev : n_host;
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const int half = block / 2;
+  const int x = (int)xy[2 * f], y = (int)xy[2 * f + 1];  // at<float>(it->y, it->x): truncation (SURVEY C-13)
+  const int tid = threadIdx.x;
+  if (!(x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half)) {
+    if (tid == 0) disp[f] = -1.0f;
+    return;
+  }
+  constexpr int PR = MAX_BLOCK + 2;              // raw rows
+  constexpr int LC = MAX_BLOCK + 2;              // raw left cols
+  constexpr int RC = MAX_BLOCK + 2 + MAX_NDISP;  // raw right cols
+  __shared__ uint8_t sLr[PR][LC + 1], sRr[PR][RC + 1];
+  __shared__ uint8_t sLp[MAX_BLOCK][MAX_BLOCK + 3], sRp[MAX_BLOCK][MAX_BLOCK + MAX_NDISP + 3];
+  __shared__ int sSad[MAX_NDISP + 2];
+  __shared__ int sT;
+  const int rows = block + 2, lcols = block + 2, rcols = block + 1 + ndisp;
+  const int ly0 = y - half - 1, lx0 = x - half - 1, rx0 = x - half - (ndisp - 1) - 1;
+  for (int i = tid; i < rows * lcols; i += 256) {
+    const int r = i / lcols, c = i % lcols;
+    const int gx = min(max(lx0 + c, 0), W - 1);
+    sLr[r][c] = L[(size_t)pf_row(ly0 + r, H) * stride + gx];
+  }
+  for (int i = tid; i < rows * rcols; i += 256) {
+    const int r = i / rcols, c = i % rcols;
+    const int gx = min(max(rx0 + c, 0), W - 1);
+    sRr[r][c] = R[(size_t)pf_row(ly0 + r, H) * stride + gx];
+  }
+  if (tid < MAX_NDISP + 2) sSad[tid] = 0;
+  if (tid == 0) sT = 0;
+  __syncthreads();
+  // prefilter in LDS: the staged rows are already row-reflected, so the vertical taps are r-1, r, r+1
+  const int pcols_r = block + ndisp - 1;
+  for (int i = tid; i < block * block; i += 256) {
+    const int r = i / block, c = i % block;
+    const int gx = x - half + c, gy = y - half + r;
+    int v = CAP;
+    if (gx > 0 && gx < W - 1 && !((H & 1) && gy == H - 1)) {
+      const int t = (sLr[r][c + 2] - sLr[r][c]) + 2 * (sLr[r + 1][c + 2] - sLr[r + 1][c]) + (sLr[r + 2][c + 2] - sLr[r + 2][c]);
+      v = min(max(t, -CAP), CAP) + CAP;
+    }
+    sLp[r][c] = (uint8_t)v;
+  }
+  for (int i = tid; i < block * pcols_r; i += 256) {
+    const int r = i / pcols_r, c = i % pcols_r;
+    const int gx = x - half - (ndisp - 1) + c, gy = y - half + r;
+    int v = CAP;
+    if (gx > 0 && gx < W - 1 && !((H & 1) && gy == H - 1)) {
+      const int t = (sRr[r][c + 2] - sRr[r][c]) + 2 * (sRr[r + 1][c + 2] - sRr[r + 1][c]) + (sRr[r + 2][c + 2] - sRr[r + 2][c]);
+      v = min(max(t, -CAP), CAP) + CAP;
+    }
+    sRp[r][c] = (uint8_t)v;
+  }
+  __syncthreads();
+  // lane = index i (disparity d = ndisp-1-i), wave = row group
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane < ndisp) {
+    int acc = 0;
+    for (int r = wave; r < block; r += 4)
+      for (int c = 0; c < block; ++c) acc += abs((int)sLp[r][c] - (int)sRp[r][c + lane]);  // R col = x-half+c-d
+    atomicAdd(&sSad[lane + 1], acc);
+  }
+  if (wave == 0) {  // texture sum by one wave
+    int t = 0;
+    for (int i = lane; i < block * block; i += 64) t += abs((int)sLp[i / block][i % block] - CAP);
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) sT = t;
+  }
+  __syncthreads();
+  if (tid == 0) disp[f] = (float)bm_select(sSad + 1, ndisp, sT) * (1.0f / 16.0f);
+}
+
+__global__ __launch_bounds__(256) void stereo_prefilter_kernel(const uint8_t* __restrict__ img, int W, int H, int stride,
+                                                               uint8_t* __restrict__ out) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= W || y >= H) return;
+  auto I = [&](int xx, int yy) -> int { return img[(size_t)yy * stride + xx]; };
+  out[(size_t)y * W + x] = (uint8_t)prefilter_at(I, x, y, W, H);
+}
+
+// Dense map.  Workgroup = 64 columns x 4 rows of output; lane = column, each lane keeps the running
+// 21-column window of absolute differences for one disparity at a time.  Prefiltered tiles in LDS.
+namespace {
+constexpr int DT_W = 64, DT_H = 4;
+}
+__global__ __launch_bounds__(256) void stereo_dense_kernel(const uint8_t* __restrict__ Lp, const uint8_t* __restrict__ Rp,
+                                                           int W, int H, int ndisp, int block,
+                                                           int16_t* __restrict__ out) {
+  constexpr int TH = DT_H + MAX_BLOCK - 1;
+  constexpr int TWL = DT_W + MAX_BLOCK - 1;
+  constexpr int TWR = TWL + MAX_NDISP;
+  __shared__ uint8_t sL[TH][TWL + 1], sR[TH][TWR + 1];
+  const int half = block / 2;
+  const int x0 = blockIdx.x * DT_W, y0 = blockIdx.y * DT_H;
+  const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+  const int th = DT_H + block - 1, twl = DT_W + block - 1, twr = twl + ndisp - 1;
+  for (int i = tid; i < th * twl; i += 256) {
+    const int r = i / twl, c = i % twl;
+    const int gx = x0 - half + c, gy = y0 - half + r;
+    sL[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? Lp[(size_t)gy * W + gx] : 0;
+  }
+  for (int i = tid; i < th * twr; i += 256) {
+    const int r = i / twr, c = i % twr;
+    const int gx = x0 - half - (ndisp - 1) + c, gy = y0 - half + r;
+    sR[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? Rp[(size_t)gy * W + gx] : 0;
+  }
+  __syncthreads();
+  const int x = x0 + lane, y = y0 + row;
+  if (x >= W || y >= H) return;
+  int16_t res = -16;
+  if (x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half) {
+    int sad[MAX_NDISP + 2];
+    int tsum = 0;
+    for (int r = 0; r < block; ++r)
+      for (int c = 0; c < block; ++c) tsum += abs((int)sL[row + r][lane + c] - CAP);
+    for (int i = 0; i < ndisp; ++i) {
+      int acc = 0;
+      for (int r = 0; r < block; ++r)
+        for (int c = 0; c < block; ++c) acc += abs((int)sL[row + r][lane + c] - (int)sR[row + r][lane + c + i]);
+      sad[i + 1] = acc;
+    }
+    res = (int16_t)bm_select(sad + 1, ndisp, tsum);
+  }
+  out[(size_t)y * W + x] = res;
+}
+
+// ----------------------------------------------------------------------------- host side
+static int stereo_check(svo_ctx* ctx, const void* l, const void* r, int W, int H, int stride, int ndisp, int block) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, l && r, "stereo: null image");
+  SVO_REQUIRE(ctx, W >= 3 && H >= 3 && W <= ctx->lim.max_width && H <= ctx->lim.max_height && stride >= W,
+              "stereo: image size outside limits");
+  SVO_REQUIRE(ctx, ndisp >= 16 && ndisp <= MAX_NDISP && ndisp % 16 == 0, "stereo: numDisparities must be 16..64, multiple of 16");
+  SVO_REQUIRE(ctx, block >= 5 && block <= MAX_BLOCK && (block & 1), "stereo: blockSize must be odd, 5..21");
+  return SVO_OK;
+}
+
+extern "C" int svo_stereo_disparity_at_dev(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width,
+                                           int height, int row_stride, int num_disparities, int block_size,
+                                           const float* xy, const int* n_dev, int n_max, float* disp) {
+  int rc = stereo_check(ctx, left, right, width, height, row_stride, num_disparities, block_size);
+  if (rc) return rc;
+  SVO_REQUIRE(ctx, n_max >= 0 && (n_max == 0 || (xy && disp)), "stereo_disparity_at: null buffer");
+  if (n_max == 0) return SVO_OK;
+  hipLaunchKernelGGL(stereo_at_kernel, dim3(n_max), dim3(256), 0, ctx->stream, left, right, width, height, row_stride,
+                     num_disparities, block_size, xy, n_dev, n_max, disp);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+extern "C" int svo_stereo_disparity_at(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width, int height,
+                                       int row_stride, int num_disparities, int block_size, const float* xy, int n,
+                                       float* disp) {
+  int rc = stereo_check(ctx, left, right, width, height, row_stride, num_disparities, block_size);
+  if (rc) return rc;
+  SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (xy && disp)), "stereo_disparity_at: null buffer");
+  if (n == 0) return SVO_OK;
+  SvoScratch s(ctx);
+  const size_t px = (size_t)width * height;
+  uint8_t* dL = s.take<uint8_t>(px);
+  uint8_t* dR = s.take<uint8_t>(px);
+  float* dxy = s.take<float>(2 * (size_t)n);
+  float* dd = s.take<float>(n);
+  if (!dL || !dR || !dxy || !dd) { ctx->err = "stereo_disparity_at: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dL, width, left, row_stride, width, height, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dR, width, right, row_stride, width, height, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  rc = svo_stereo_disparity_at_dev(ctx, dL, dR, width, height, width, num_disparities, block_size, dxy, nullptr, n, dd);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(disp, dd, sizeof(float) * n, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  return SVO_OK;
+}
+
+extern "C" int svo_stereo_bm(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width, int height,
+                             int row_stride, int num_disparities, int block_size, int16_t* disp16) {
+  int rc = stereo_check(ctx, left, right, width, height, row_stride, num_disparities, block_size);
+  if (rc) return rc;
+  SVO_REQUIRE(ctx, disp16, "stereo_bm: null output");
+  SvoScratch s(ctx);
+  const size_t px = (size_t)width * height;
+  uint8_t* dL = s.take<uint8_t>(px);
+  uint8_t* dR = s.take<uint8_t>(px);
+  uint8_t* dLp = s.take<uint8_t>(px);
+  uint8_t* dRp = s.take<uint8_t>(px);
+  int16_t* dD = s.take<int16_t>(px);
+  if (!dL || !dR || !dLp || !dRp || !dD) { ctx->err = "stereo_bm: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dL, width, left, row_stride, width, height, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(dR, width, right, row_stride, width, height, hipMemcpyHostToDevice, st));
+  const dim3 g1(svo_div_up(width, 64), svo_div_up(height, 4));
+  hipLaunchKernelGGL(stereo_prefilter_kernel, g1, dim3(256), 0, st, dL, width, height, width, dLp);
+  hipLaunchKernelGGL(stereo_prefilter_kernel, g1, dim3(256), 0, st, dR, width, height, width, dRp);
+  hipLaunchKernelGGL(stereo_dense_kernel, dim3(svo_div_up(width, DT_W), svo_div_up(height, DT_H)), dim3(256), 0, st, dLp,
+                     dRp, width, height, num_disparities, block_size, dD);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(disp16, dD, sizeof(int16_t) * px, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  return SVO_OK;
+}
