@@ -41,13 +41,13 @@ inline void quat_to_R(const double* q, double R[9]) {
 }
 
 // cost + normal equations over a subset. Returns cost (sum of squared errors), fills H(21 upper), g(6).
-double accumulate(const Pose& P, const float* xyz, const float* xy, const int* idx, int m, double f,
-                  double cx, double cy, double* H, double* g) {
+double accumulate_range(const Pose& P, const float* xyz, const float* xy, const int* idx, int m, double f,
+                        double cx, double cy, double* H, double* g, int first, int step) {
   double R[9];
   quat_to_R(P.q, R);
   double cost = 0;
   if (H) { std::memset(H, 0, 36 * sizeof(double)); std::memset(g, 0, 6 * sizeof(double)); }
-  for (int k = 0; k < m; ++k) {
+  for (int k = first; k < m; k += step) {
     const int i = idx[k];
     const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
     const double rx = R[0] * X + R[1] * Y + R[2] * Z;
@@ -72,6 +72,31 @@ double accumulate(const Pose& P, const float* xyz, const float* xy, const int* i
     }
   }
   return cost;
+}
+
+// sequential order (minimal 5-point sets)
+double accumulate(const Pose& P, const float* xyz, const float* xy, const int* idx, int m, double f,
+                  double cx, double cy, double* H, double* g) {
+  return accumulate_range(P, xyz, xy, idx, m, f, cx, cy, H, g, 0, 1);
+}
+
+// Declared reduction order for the refinement over all inliers (what the 256-thread HIP workgroup
+// does): partial[t] = sequential sum over k = t, t+256, ...; then partial[t] += partial[t+s] for
+// s = 128, 64, ..., 1.
+double accumulate_tree(const Pose& P, const float* xyz, const float* xy, const int* idx, int m, double f,
+                       double cx, double cy, double* H, double* g) {
+  const int T = 256;
+  static thread_local double part[256][43];
+  for (int t = 0; t < T; ++t) {
+    double* h = part[t];
+    part[t][42] = accumulate_range(P, xyz, xy, idx, m, f, cx, cy, H ? h : nullptr, H ? h + 36 : nullptr, t, T);
+    if (!H) std::memset(h, 0, 42 * sizeof(double));
+  }
+  for (int sft = T / 2; sft > 0; sft >>= 1)
+    for (int t = 0; t < sft; ++t)
+      for (int e = 0; e < 43; ++e) part[t][e] += part[t + sft][e];
+  if (H) { std::memcpy(H, part[0], 36 * sizeof(double)); std::memcpy(g, part[0] + 36, 6 * sizeof(double)); }
+  return part[0][42];
 }
 
 bool solve6(const double* Hin, const double* g, double lambda, double* d) {
@@ -123,7 +148,12 @@ inline Pose retract(const Pose& P, const double* d) {
 }
 
 Pose lm_solve(Pose P, const float* xyz, const float* xy, const int* idx, int m, double f, double cx,
-              double cy, int max_it) {
+              double cy, int max_it, bool tree) {
+  auto accumulate = [&](const Pose& Q, const float* a, const float* b, const int* c, int mm, double ff,
+                        double ccx, double ccy, double* HH, double* gg) {
+    return tree ? accumulate_tree(Q, a, b, c, mm, ff, ccx, ccy, HH, gg)
+                : accumulate_range(Q, a, b, c, mm, ff, ccx, ccy, HH, gg, 0, 1);
+  };
   double lambda = 1e-3;
   double H[36], g[6], d[6];
   double cost = accumulate(P, xyz, xy, idx, m, f, cx, cy, H, g);
@@ -189,7 +219,7 @@ extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float fo
         if (!dup) { idx[k] = c; break; }
       }
     }
-    const Pose P = lm_solve(P0, xyz, xy, idx, kModel, f, cx, cy, 12);
+    const Pose P = lm_solve(P0, xyz, xy, idx, kModel, f, cx, cy, 12, false);
     double R[9];
     quat_to_R(P.q, R);
     int cnt = 0;
@@ -231,7 +261,7 @@ extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float fo
     const double ey = f * py * iz + cy - (double)xy[2 * i + 1];
     if (ex * ex + ey * ey <= thr2) inliers[m++] = i;
   }
-  const Pose F = lm_solve(B, xyz, xy, inliers, m, f, cx, cy, 20);
+  const Pose F = lm_solve(B, xyz, xy, inliers, m, f, cx, cy, 20, true);
   // quaternion -> rvec (host libm)
   double q[4] = {F.q[0], F.q[1], F.q[2], F.q[3]};
   if (q[0] < 0) for (double& v : q) v = -v;

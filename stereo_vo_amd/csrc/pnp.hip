@@ -1,0 +1,396 @@
+// a5 — cv::solvePnPRansac(obj, img, K, 0, rvec, tvec, true, 100, 8.0, 0.99, inliers), reference call site
+// src/image_processor.cpp:76-80.  OpenCV's sample sequence / EPnP are version specific;
+// the deterministic RANSAC implemented here is the one DEFINED in oracle/ora_pnp.cpp and DESIGN.md §PnP:
+//   pnp_hypotheses_kernel : one wavefront per hypothesis (all `iterations` hypotheses in one launch).
+//       splitmix64 sampling of 5 distinct points, LM minimal solve from the extrinsic guess with a
+//       trig-free quaternion retraction, then every lane tests its share of the n points and the inlier
+//       set is emitted as a 64-bit ballot mask per 64 points.  The 5-term normal-equation sums are
+//       evaluated entry-per-lane in the oracle's k = 0..4 order => bit-identical to the CPU.
+//   (host)                : consumes the counts in order h = 0,1,.. with OpenCV's adaptive iteration cap.
+//   pnp_refine_kernel     : LM over the best model's inliers; reductions use the declared order
+//       "per-thread strided partials (stride 256), then binary tree" so the refined pose is bit-identical
+//       to the oracle as well.
+#include <math.h>
+
+#include <algorithm>
+#include <cfloat>
+
+#include "kernels.h"
+
+namespace {
+constexpr int MODEL = 5;
+constexpr unsigned long long SEED = 0x5EED0A5ull, STRIDE = 0xD1B54A32D192ED03ull;
+
+struct PnpPose { double q[4]; double t[3]; };
+
+__host__ __device__ inline unsigned long long splitmix(unsigned long long& s) {
+  unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ void quat_to_R(const double* q, double* R) {
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - w * z); R[2] = 2 * (x * z + w * y);
+  R[3] = 2 * (x * y + w * z); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - w * x);
+  R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+// residual (and 2x6 Jacobian) of one point; returns ex^2+ey^2
+__device__ __forceinline__ double pnp_term(const double* R, const double* t, const float* xyz, const float* xy, int i,
+                                           double f, double cx, double cy, double* e, double* J /*12 or null*/) {
+  const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+  const double rx = R[0] * X + R[1] * Y + R[2] * Z;
+  const double ry = R[3] * X + R[4] * Y + R[5] * Z;
+  const double rz = R[6] * X + R[7] * Y + R[8] * Z;
+  const double px = rx + t[0], py = ry + t[1], pz = rz + t[2];
+  const double iz = 1.0 / pz;
+  const double ex = f * px * iz + cx - (double)xy[2 * i];
+  const double ey = f * py * iz + cy - (double)xy[2 * i + 1];
+  e[0] = ex; e[1] = ey;
+  if (J) {
+    const double a = f * iz, bx = -f * px * iz * iz, by = -f * py * iz * iz;
+    J[0] = bx * ry;           J[1] = a * rz - bx * rx; J[2] = -a * ry;
+    J[6] = -a * rz + by * ry; J[7] = -by * rx;         J[8] = a * rx;
+    J[3] = a; J[4] = 0; J[5] = bx;
+    J[9] = 0; J[10] = a; J[11] = by;
+  }
+  return ex * ex + ey * ey;
+}
+
+__device__ bool solve6(const double* Hin, const double* g, double lambda, double* d) {
+  double L[36];
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) L[6 * c + r] = Hin[6 * r + c];
+  for (int r = 0; r < 6; ++r) L[6 * r + r] += lambda * Hin[6 * r + r] + 1e-12;
+  for (int j = 0; j < 6; ++j) {
+    double s = L[6 * j + j];
+    for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k];
+    if (!(s > 0)) return false;
+    const double ljj = sqrt(s);
+    L[6 * j + j] = ljj;
+    for (int i = j + 1; i < 6; ++i) {
+      double v = L[6 * i + j];
+      for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
+      L[6 * i + j] = v / ljj;
+    }
+  }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double v = -g[i];
+    for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
+    y[i] = v / L[6 * i + i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double v = y[i];
+    for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * d[k];
+    d[i] = v / L[6 * i + i];
+  }
+  return true;
+}
+
+__device__ void retract(const PnpPose& P, const double* d, PnpPose& N) {
+  double dq[4] = {1.0, 0.5 * d[0], 0.5 * d[1], 0.5 * d[2]};
+  const double nn = sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
+  for (int k = 0; k < 4; ++k) dq[k] /= nn;
+  const double* q = P.q;
+  N.q[0] = dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2] - dq[3] * q[3];
+  N.q[1] = dq[0] * q[1] + dq[1] * q[0] + dq[2] * q[3] - dq[3] * q[2];
+  N.q[2] = dq[0] * q[2] - dq[1] * q[3] + dq[2] * q[0] + dq[3] * q[1];
+  N.q[3] = dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1] + dq[3] * q[0];
+  const double n2 = sqrt(N.q[0] * N.q[0] + N.q[1] * N.q[1] + N.q[2] * N.q[2] + N.q[3] * N.q[3]);
+  for (int k = 0; k < 4; ++k) N.q[k] /= n2;
+  for (int k = 0; k < 3; ++k) N.t[k] = P.t[k] + d[3 + k];
+}
+
+// Shared LM driver.  `Acc` evaluates cost (+ H,g into LDS when with_jac) at the pose in S.cur/S.cand for
+// the whole workgroup and returns the cost (uniform).
+struct LmShared {
+  PnpPose cur, cand;
+  double H[36], g[6], d[6];
+  double cost;
+  int ok;
+};
+
+template <typename Acc>
+__device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
+  double lambda = 1e-3;
+  double cost = acc(S.cur, true);
+  for (int it = 0; it < max_it; ++it) {
+    if (threadIdx.x == 0) {
+      S.ok = solve6(S.H, S.g, lambda, S.d) ? 1 : 0;
+      if (S.ok) retract(S.cur, S.d, S.cand);
+    }
+    __syncthreads();
+    const int ok = S.ok;
+    if (!ok) { lambda *= 10; __syncthreads(); continue; }
+    const double c2 = acc(S.cand, false);
+    if (c2 < cost) {
+      const double* d = S.d;
+      const double step2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+      __syncthreads();
+      if (threadIdx.x == 0) S.cur = S.cand;
+      __syncthreads();
+      lambda *= 0.1;
+      if (lambda < 1e-9) lambda = 1e-9;
+      cost = acc(S.cur, true);
+      if (step2 < 1e-20) break;
+    } else {
+      lambda *= 10;
+      if (lambda > 1e6) break;
+    }
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__ xy,
+                                                            int n, double f, double cx, double cy, PnpPose P0,
+                                                            double thr2, double* __restrict__ hyp_pose,
+                                                            int* __restrict__ hyp_count,
+                                                            unsigned long long* __restrict__ hyp_mask, int mask_words) {
+  __shared__ LmShared S;
+  __shared__ int sIdx[MODEL];
+  __shared__ double sJ[MODEL][12], sE[MODEL][2];
+  const int h = blockIdx.x, lane = threadIdx.x;
+  if (lane == 0) {
+    unsigned long long s = SEED + (unsigned long long)h * STRIDE;
+    for (int k = 0; k < MODEL; ++k) {
+      for (;;) {
+        const int c = (int)(splitmix(s) % (unsigned long long)n);
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup |= sIdx[j] == c;
+        if (!dup) { sIdx[k] = c; break; }
+      }
+    }
+    S.cur = P0;
+  }
+  __syncthreads();
+  auto acc = [&](const PnpPose& P, bool with_jac) -> double {
+    double R[9];
+    quat_to_R(P.q, R);
+    if (lane < MODEL) pnp_term(R, P.t, xyz, xy, sIdx[lane], f, cx, cy, sE[lane], with_jac ? sJ[lane] : nullptr);
+    __syncthreads();
+    if (with_jac && lane < 27) {
+      if (lane < 21) {  // upper-triangular entry (r,c)
+        int r = 0, e = lane;
+        while (e >= 6 - r) { e -= 6 - r; ++r; }
+        const int c = r + e;
+        double s = 0.0;
+        for (int k = 0; k < MODEL; ++k) s += sJ[k][r] * sJ[k][c] + sJ[k][6 + r] * sJ[k][6 + c];
+        S.H[6 * r + c] = s;
+      } else {
+        const int r = lane - 21;
+        double s = 0.0;
+        for (int k = 0; k < MODEL; ++k) s += sJ[k][r] * sE[k][0] + sJ[k][6 + r] * sE[k][1];
+        S.g[r] = s;
+      }
+    }
+    double cost = 0.0;
+    for (int k = 0; k < MODEL; ++k) cost += sE[k][0] * sE[k][0] + sE[k][1] * sE[k][1];
+    __syncthreads();
+    return cost;
+  };
+  lm_solve(S, 12, acc);
+  __syncthreads();
+  const PnpPose P = S.cur;
+  double R[9];
+  quat_to_R(P.q, R);
+  int cnt = 0;
+  for (int w = 0; w < mask_words; ++w) {
+    const int i = w * 64 + lane;
+    bool in = false;
+    if (i < n) {
+      const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+      const double px = R[0] * X + R[1] * Y + R[2] * Z + P.t[0];
+      const double py = R[3] * X + R[4] * Y + R[5] * Z + P.t[1];
+      const double pz = R[6] * X + R[7] * Y + R[8] * Z + P.t[2];
+      if (pz > 0) {
+        const double iz = 1.0 / pz;
+        const double ex = f * px * iz + cx - (double)xy[2 * i];
+        const double ey = f * py * iz + cy - (double)xy[2 * i + 1];
+        in = ex * ex + ey * ey <= thr2;
+      }
+    }
+    const unsigned long long m = __ballot(in);
+    cnt += __popcll(m);
+    if (lane == 0) hyp_mask[(size_t)h * mask_words + w] = m;
+  }
+  if (lane == 0) {
+    hyp_count[h] = cnt;
+    for (int k = 0; k < 4; ++k) hyp_pose[7 * h + k] = P.q[k];
+    for (int k = 0; k < 3; ++k) hyp_pose[7 * h + 4 + k] = P.t[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
+                                                         double f, double cx, double cy, const double* __restrict__ hyp_pose,
+                                                         const unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                         int best, double* __restrict__ out_pose, int* __restrict__ inliers,
+                                                         int* __restrict__ n_inliers) {
+  __shared__ LmShared S;
+  __shared__ double sPart[256][28];
+  __shared__ int sBase;
+  const int tid = threadIdx.x;
+  // inlier list of the best hypothesis, ascending (one wave builds it)
+  if (tid < 64) {
+    int base = 0;
+    for (int w = 0; w < mask_words; ++w) {
+      const unsigned long long m = hyp_mask[(size_t)best * mask_words + w];
+      if ((m >> tid) & 1ull) inliers[base + __popcll(m & ((1ull << tid) - 1ull))] = w * 64 + tid;
+      base += __popcll(m);
+    }
+    if (tid == 0) {
+      sBase = base;
+      for (int k = 0; k < 4; ++k) S.cur.q[k] = hyp_pose[7 * best + k];
+      for (int k = 0; k < 3; ++k) S.cur.t[k] = hyp_pose[7 * best + 4 + k];
+    }
+  }
+  __syncthreads();
+  const int m = sBase;
+  auto acc = [&](const PnpPose& P, bool with_jac) -> double {
+    double R[9];
+    quat_to_R(P.q, R);
+    double v[28];
+#pragma unroll
+    for (int e = 0; e < 28; ++e) v[e] = 0.0;
+    for (int k = tid; k < m; k += 256) {
+      double e2[2], J[12];
+      const int pi = __hip_atomic_load(&inliers[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by wave 0 above
+      v[27] += pnp_term(R, P.t, xyz, xy, pi, f, cx, cy, e2, with_jac ? J : nullptr);
+      if (with_jac) {
+        int o = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+          v[21 + r] += J[r] * e2[0] + J[6 + r] * e2[1];
+#pragma unroll
+          for (int c = r; c < 6; ++c) { v[o] += J[r] * J[c] + J[6 + r] * J[6 + c]; ++o; }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 28; ++e) sPart[tid][e] = v[e];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s)
+        for (int e = 0; e < 28; ++e) sPart[tid][e] += sPart[tid + s][e];
+      __syncthreads();
+    }
+    if (with_jac && tid == 0) {
+      int o = 0;
+      for (int r = 0; r < 6; ++r) {
+        S.g[r] = sPart[0][21 + r];
+        for (int c = r; c < 6; ++c) S.H[6 * r + c] = sPart[0][o++];
+      }
+    }
+    const double cost = sPart[0][27];
+    __syncthreads();
+    return cost;
+  };
+  lm_solve(S, 20, acc);
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 4; ++k) out_pose[k] = S.cur.q[k];
+    for (int k = 0; k < 3; ++k) out_pose[4 + k] = S.cur.t[k];
+    *n_inliers = m;
+  }
+}
+
+// ----------------------------------------------------------------------------- host side
+static int update_num_iters(double p, double ep, int model_points, int max_iters) {
+  p = std::max(p, 0.0); p = std::min(p, 1.0);
+  ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
+  double num = std::max(1.0 - p, DBL_MIN);
+  double denom = 1.0 - pow(1.0 - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = log(num);
+  denom = log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+}
+
+// Device-pointer form used by the pipeline: xyz/xy on the device, n known on the host.
+// Work buffers come from `s`.  On return rvec3/tvec3 are updated (host), d_inliers holds the list.
+int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy, int n, float focal, float cxf, float cyf,
+              double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence, int* d_inliers,
+              int* n_inliers) {
+  *n_inliers = 0;
+  if (n < MODEL || iterations < 1) return SVO_OK;
+  PnpPose P0;
+  {
+    const double th = sqrt(rvec3[0] * rvec3[0] + rvec3[1] * rvec3[1] + rvec3[2] * rvec3[2]);
+    if (th < 1e-12) { P0.q[0] = 1; P0.q[1] = 0.5 * rvec3[0]; P0.q[2] = 0.5 * rvec3[1]; P0.q[3] = 0.5 * rvec3[2]; }
+    else {
+      const double sn = sin(0.5 * th) / th;
+      P0.q[0] = cos(0.5 * th); P0.q[1] = sn * rvec3[0]; P0.q[2] = sn * rvec3[1]; P0.q[3] = sn * rvec3[2];
+    }
+    for (int k = 0; k < 3; ++k) P0.t[k] = tvec3[k];
+  }
+  const int words = svo_div_up(n, 64);
+  double* d_pose = s.take<double>(7 * (size_t)iterations);
+  int* d_count = s.take<int>(iterations);
+  unsigned long long* d_mask = s.take<unsigned long long>((size_t)iterations * words);
+  double* d_out = s.take<double>(7);
+  int* d_nin = s.take<int>(1);
+  if (!d_pose || !d_count || !d_mask || !d_out || !d_nin) { ctx->err = "pnp: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  const double thr2 = (double)reproj_err * (double)reproj_err;
+  hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3(iterations), dim3(64), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf,
+                     (double)cyf, P0, thr2, d_pose, d_count, d_mask, words);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  int* h_count = (int*)ctx->h_pinned;
+  if ((size_t)iterations * sizeof(int) + 64 > ctx->pinned_bytes) { ctx->err = "pnp: too many iterations"; return SVO_ERR_CAPACITY; }
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_count, d_count, sizeof(int) * iterations, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  int best = -1, best_cnt = 0, niters = iterations;
+  for (int h = 0; h < niters; ++h) {
+    if (h_count[h] > std::max(best_cnt, MODEL - 1)) {
+      best = h; best_cnt = h_count[h];
+      niters = update_num_iters(confidence, (double)(n - best_cnt) / n, MODEL, niters);
+    }
+  }
+  if (best < 0) return SVO_OK;
+  hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf, (double)cyf,
+                     d_pose, d_mask, words, best, d_out, d_inliers, d_nin);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  double* h_out = (double*)((char*)ctx->h_pinned + 4096);
+  int* h_nin = (int*)((char*)ctx->h_pinned + 4096 + 64);
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * 7, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_nin, d_nin, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  double q[4] = {h_out[0], h_out[1], h_out[2], h_out[3]};
+  if (q[0] < 0) for (double& v : q) v = -v;
+  const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (vn < 1e-12) { rvec3[0] = 2 * q[1]; rvec3[1] = 2 * q[2]; rvec3[2] = 2 * q[3]; }
+  else {
+    const double th = 2.0 * atan2(vn, q[0]);
+    rvec3[0] = q[1] / vn * th; rvec3[1] = q[2] / vn * th; rvec3[2] = q[3] / vn * th;
+  }
+  for (int k = 0; k < 3; ++k) tvec3[k] = h_out[4 + k];
+  *n_inliers = *h_nin;
+  return SVO_OK;
+}
+
+extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, int n, float focal, float cx, float cy,
+                              double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence,
+                              int* inliers, int* n_inliers) {
+  if (!ctx) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, n >= 0 && rvec3 && tvec3 && n_inliers && (n == 0 || (xyz && xy && inliers)), "pnp_ransac: null buffer");
+  SVO_REQUIRE(ctx, iterations >= 1 && iterations <= 1024, "pnp_ransac: iterations must be 1..1024");
+  *n_inliers = 0;
+  if (n < MODEL) return SVO_OK;
+  SvoScratch s(ctx);
+  float* dxyz = s.take<float>(3 * (size_t)n);
+  float* dxy = s.take<float>(2 * (size_t)n);
+  int* din = s.take<int>(n);
+  if (!dxyz || !dxy || !din) { ctx->err = "pnp_ransac: workspace too small"; return SVO_ERR_CAPACITY; }
+  hipStream_t st = ctx->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+  int rc = svo_k_pnp(ctx, s, dxyz, dxy, n, focal, cx, cy, rvec3, tvec3, iterations, reproj_err, confidence, din, n_inliers);
+  if (rc) return rc;
+  if (*n_inliers > 0) {
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(inliers, din, sizeof(int) * (size_t)*n_inliers, hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  }
+  return SVO_OK;
+}

@@ -1,0 +1,63 @@
+"""a5 PnP-RANSAC — cv::solvePnPRansac call at reference src/image_processor.cpp:76-80, restated
+deterministically (oracle/ora_pnp.cpp).  Inlier index sets bit-exact; pose bit-exact as well because
+every reduction uses the declared order."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+F, CX, CY = 718.856, 607.1928, 185.2157
+
+
+def _scene(seed, n, outlier_frac=0.2, noise=0.3):
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-8, 8, n), rng.uniform(-2, 2, n), rng.uniform(6, 40, n)], 1)
+    rv = np.array([0.01, -0.03, 0.005]) * rng.uniform(0.5, 1.5)
+    tv = np.array([0.05, -0.02, -0.8]) * rng.uniform(0.5, 1.5)
+    th = np.linalg.norm(rv); k = rv / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+    Xc = X @ R.T + tv
+    uv = np.stack([F * Xc[:, 0] / Xc[:, 2] + CX, F * Xc[:, 1] / Xc[:, 2] + CY], 1)
+    uv += rng.normal(0, noise, uv.shape)
+    out = rng.random(n) < outlier_frac
+    uv[out] += rng.uniform(20, 80, (out.sum(), 2)) * rng.choice([-1, 1], (out.sum(), 2))
+    return X.astype(np.float32), uv.astype(np.float32), rv, tv, ~out
+
+
+def test_oracle_recovers_pose_and_inliers():
+    X, uv, rv, tv, good = _scene(1, 300)
+    r, t, inl = O.pnp_ransac(X, uv, F, CX, CY, np.zeros(3), np.zeros(3))
+    assert np.linalg.norm(r - rv) < 2e-3 and np.linalg.norm(t - tv) < 2e-2
+    mask = np.zeros(len(X), bool); mask[inl] = True
+    assert (mask & good).sum() >= 0.97 * good.sum() and (mask & ~good).sum() <= 2
+    assert np.all(np.diff(inl) > 0)
+
+
+def test_oracle_degenerate_inputs():
+    X, uv, *_ = _scene(2, 4)
+    r, t, inl = O.pnp_ransac(X, uv, F, CX, CY, np.ones(3) * 0.01, np.ones(3))
+    assert len(inl) == 0 and np.allclose(r, 0.01) and np.allclose(t, 1.0)  # < 5 points: unchanged
+    X, uv, *_ = _scene(3, 50, outlier_frac=1.0)
+    r, t, inl = O.pnp_ransac(X, uv, F, CX, CY, np.zeros(3), np.zeros(3))
+    assert len(inl) < 12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,n,of", [(1, 300, 0.2), (4, 1500, 0.35), (5, 64, 0.0), (6, 7, 0.1), (7, 2000, 0.6)])
+def test_hip_pnp_bit_exact(ctx, seed, n, of):
+    X, uv, rv, tv, good = _scene(seed, n, of)
+    r0, t0 = np.array([0.002, 0.001, -0.003]), np.array([0.01, 0.0, -0.1])
+    rg, tg, ig = ctx.pnp_ransac(X, uv, F, CX, CY, r0, t0)
+    ro, to, io = O.pnp_ransac(X, uv, F, CX, CY, r0, t0)
+    assert np.array_equal(ig, io)
+    assert np.allclose(rg, ro, rtol=0, atol=1e-12) and np.allclose(tg, to, rtol=0, atol=1e-12)
+    if len(io) > 20:
+        assert np.linalg.norm(rg - rv) < 5e-3
+
+
+@pytest.mark.gpu
+def test_hip_pnp_too_few_points(ctx):
+    X, uv, *_ = _scene(2, 4)
+    r, t, inl = ctx.pnp_ransac(X, uv, F, CX, CY, np.ones(3) * 0.01, np.ones(3))
+    assert len(inl) == 0 and np.allclose(r, 0.01) and np.allclose(t, 1.0)
