@@ -293,3 +293,91 @@ class Context:
                                         C.c_float(cy), _p(rv), _p(tv), iterations, C.c_float(reproj_err),
                                         C.c_double(confidence), _p(inl), C.byref(m)), "svo_pnp_ransac")
         return rv, tv, inl[:m.value].copy()
+
+
+class BA:
+    """svo_ba wrapper: sliding-window graph (add_keyframe / solve) and the bulk-problem interface."""
+
+    def __init__(self, ctx, window_size, focal, cx, cy, baseline=0.0, max_landmarks=1 << 16,
+                 max_observations=1 << 18, max_iterations=50, max_time_s=0.0, max_features=400):
+        self.ctx = ctx
+        self.L = ctx.L
+        cam = CameraInfo(focal, cx, cy, 0, 0, 0, 0, baseline)
+        opt = BAOptions()
+        self.L.svo_ba_default_options(C.byref(opt))
+        opt.max_iterations = max_iterations
+        opt.max_time_s = max_time_s
+        opt.max_features = max_features
+        self.h = C.c_void_p()
+        ctx._chk(self.L.svo_ba_create(ctx.h, C.byref(self.h), window_size, C.byref(cam), C.byref(opt),
+                                      max_landmarks, max_observations), "svo_ba_create")
+        self.L.svo_ba_destroy.argtypes = [C.c_void_p]
+        self._cb = None
+
+    def close(self):
+        if self.h:
+            self.L.svo_ba_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_problem(self, poses7, points3, obs_pose, obs_point, obs_uv):
+        poses7, points3, obs_uv = _f64(poses7), _f64(points3), _f64(obs_uv)
+        op = np.ascontiguousarray(obs_pose, np.int32)
+        oj = np.ascontiguousarray(obs_point, np.int32)
+        self._shape = (poses7.shape[0], points3.shape[0])
+        self.ctx._chk(self.L.svo_ba_load_problem(self.h, poses7.shape[0], _p(poses7), points3.shape[0],
+                                                 _p(points3), op.shape[0], _p(op), _p(oj), _p(obs_uv)),
+                      "svo_ba_load_problem")
+
+    def set_allreduce(self, fn):
+        """fn(dev_ptr:int, n_doubles:int) -> 0; must sum the device buffer in place over all ranks."""
+        self._cb = ALLREDUCE_FN(lambda ptr, n, user: int(fn(ptr, n) or 0)) if fn else None
+        self.ctx._chk(self.L.svo_ba_set_allreduce(self.h, self._cb if self._cb else C.cast(None, ALLREDUCE_FN), None),
+                      "svo_ba_set_allreduce")
+
+    def solve_problem(self):
+        s = BASummary()
+        self.ctx._chk(self.L.svo_ba_solve_problem(self.h, C.byref(s)), "svo_ba_solve_problem")
+        return s
+
+    def read_problem(self):
+        K, N = self._shape
+        poses = np.empty((K, 7))
+        pts = np.empty((N, 3))
+        self.ctx._chk(self.L.svo_ba_read_problem(self.h, _p(poses), _p(pts)), "svo_ba_read_problem")
+        return poses, pts
+
+    def add_keyframe(self, pose7, tracked_ids, tracked_xy, new_xy, new_xyz):
+        pose7 = _f64(pose7)
+        tid = np.ascontiguousarray(tracked_ids, np.int64)
+        txy, nxy, nxyz = _f32(tracked_xy), _f32(new_xy), _f32(new_xyz)
+        nn = nxy.shape[0] if nxy.ndim == 2 else 0
+        ids = np.empty(max(nn, 1), np.int64)
+        m = C.c_int(0)
+        self.ctx._chk(self.L.svo_ba_add_keyframe(self.h, _p(pose7), _p(tid), _p(txy), tid.shape[0], _p(nxy),
+                                                 _p(nxyz), nn, _p(ids), C.byref(m)), "svo_ba_add_keyframe")
+        return ids[:m.value].copy()
+
+    def solve(self):
+        s = BASummary()
+        self.ctx._chk(self.L.svo_ba_solve(self.h, C.byref(s)), "svo_ba_solve")
+        return s
+
+    def get_pose(self, k=-1):
+        p = np.empty(7)
+        self.ctx._chk(self.L.svo_ba_get_pose(self.h, k, _p(p)), "svo_ba_get_pose")
+        return p
+
+    def window_count(self):
+        return self.L.svo_ba_window_count(self.h)
+
+    def get_points(self, ids):
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.empty((ids.shape[0], 3), np.float32)
+        self.ctx._chk(self.L.svo_ba_get_points(self.h, _p(ids), ids.shape[0], _p(out)), "svo_ba_get_points")
+        return out

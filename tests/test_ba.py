@@ -1,0 +1,121 @@
+"""a12 bundle adjustment — BundleAdjuster::bundle_adjust -> ceres::Solve (reference
+src/bundle_adjuster.cpp:137-157) restated as LM + Schur (oracle/ora_ba.cpp).
+Floating point: converged poses must agree to 1e-6 m / 1e-6 rad, costs to 1e-9 rel."""
+import numpy as np
+import pytest
+
+import ba_problem as BP
+import oracle_lib as O
+
+T_TOL, R_TOL = 1e-6, 1e-6
+
+
+def test_oracle_converges_to_ground_truth():
+    p = BP.make_problem(1, 5, 400, noise=0.0, pt_sigma=0.05)
+    poses, pts, s = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=2)
+    assert s["termination"] == 0 and s["final_cost"] < 1e-10 * max(1.0, s["initial_cost"])
+    # only reprojection factors + one fixed pose: global scale is a gauge freedom (as in the reference),
+    # so compare rotations directly and translations up to one common scale
+    t_est, t_gt = poses[1:, 4:].ravel(), p["poses_gt"][1:, 4:].ravel()
+    scale = (t_est @ t_gt) / (t_est @ t_est)
+    aligned = poses.copy(); aligned[:, 4:] *= scale
+    dt, ang = BP.pose_error(aligned, p["poses_gt"])
+    assert abs(scale - 1) < 0.05 and dt < 1e-5 and ang < 1e-6
+    assert np.array_equal(poses[0], p["poses0"][0])  # oldest pose constant (src/bundle_adjuster.cpp:130)
+
+
+def test_oracle_noisy_problem_decreases_cost_and_is_thread_invariant():
+    p = BP.make_problem(2, 6, 600)
+    a = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=1)
+    b = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=4)
+    assert a[2]["final_cost"] < 0.05 * a[2]["initial_cost"] and a[2]["iterations"] <= 50
+    dt, ang = BP.pose_error(a[0], b[0])
+    assert dt < T_TOL and ang < R_TOL
+
+
+def test_oracle_sharded_equals_single():
+    """Two landmark shards + an in-process 'allreduce' == the unsharded solve (Schur is per-landmark local)."""
+    import threading
+    p = BP.make_problem(3, 5, 300)
+    ref = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY)
+    n_pts = len(p["points0"])
+    shards = [np.arange(n_pts) % 2 == r for r in range(2)]
+    bar = threading.Barrier(2)
+    bufs, res = [None, None], [None, None]
+
+    def run(rank):
+        def allreduce(buf, n, user):
+            a = np.ctypeslib.as_array(buf, shape=(n,))
+            bufs[rank] = a
+            bar.wait()
+            tot = bufs[0] + bufs[1]
+            bar.wait()
+            a[:] = tot
+            bar.wait()
+            return 0
+        m = shards[rank][p["oj"]]
+        remap = -np.ones(n_pts, np.int64); idx = np.nonzero(shards[rank])[0]; remap[idx] = np.arange(len(idx))
+        res[rank] = (idx, O.ba_solve(p["poses0"], p["points0"][idx], p["op"][m], remap[p["oj"][m]], p["uv"][m],
+                                     BP.F, BP.CX, BP.CY, allreduce=allreduce))
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for rank in range(2):
+        idx, (poses, pts, s) = res[rank]
+        dt, ang = BP.pose_error(poses, ref[0])
+        assert dt < T_TOL and ang < R_TOL and s["iterations"] == ref[2]["iterations"]
+        assert np.allclose(pts, ref[1][idx], rtol=1e-7, atol=1e-6)  # low-parallax points are ill-conditioned: relative
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,K,N,dense", [(1, 5, 400, False), (2, 6, 1500, False), (4, 10, 3000, False),
+                                            (5, 20, 2000, True), (6, 2, 50, False)])
+def test_hip_ba_matches_oracle(ctx, seed, K, N, dense):
+    import stereo_vo_amd as S
+    p = BP.make_problem(seed, K, N, dense=dense)
+    ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8,
+                  max_observations=len(p["op"]) + 8, max_time_s=0.0)
+    ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s = ba.solve_problem()
+    poses, pts = ba.read_problem()
+    po, pto, so = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=4)
+    assert s.termination == so["termination"] == 0
+    assert abs(s.initial_cost - so["initial_cost"]) <= 1e-9 * so["initial_cost"]
+    assert abs(s.final_cost - so["final_cost"]) <= 1e-7 * so["final_cost"]
+    assert s.iterations == so["iterations"]
+    dt, ang = BP.pose_error(poses, po)
+    assert dt < T_TOL and ang < R_TOL
+    assert np.allclose(pts, pto, rtol=1e-6, atol=1e-5)
+    assert np.array_equal(poses[0], p["poses0"][0])
+    ba.close()
+
+
+@pytest.mark.gpu
+def test_hip_ba_sliding_window_graph(ctx):
+    """add_keyframe / solve / get_points follow src/bundle_adjuster.cpp:60-163: sequential ids (C-3),
+    truncation to max_features (:85-90), window pop (:126-128), solve is a no-op without a new keyframe."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(7, 4, 300, dense=True)
+    ba = S.api.BA(ctx, 3, BP.F, BP.CX, BP.CY, max_features=250)
+    n_pts = len(p["points0"])
+    ids0 = None
+    for k in range(4):
+        m = p["op"] == k
+        lm = p["oj"][m]
+        if k == 0:
+            ids0 = ba.add_keyframe(p["poses0"][0], [], np.zeros((0, 2)), p["uv"][m], p["points0"][lm])
+            assert list(ids0) == list(range(250))  # truncated at max_features, ids sequential from 0
+            lm_to_id = {int(l): int(i) for l, i in zip(lm[:250], ids0)}
+        else:
+            sel = [i for i, l in enumerate(lm) if int(l) in lm_to_id]
+            tid = [lm_to_id[int(lm[i])] for i in sel]
+            new = ba.add_keyframe(p["poses0"][k], tid, p["uv"][m][sel], np.zeros((0, 2)), np.zeros((0, 3)))
+            assert len(new) == 0
+        assert ba.window_count() == min(k + 1, 3)
+        s = ba.solve()
+        assert s.iterations >= (1 if k > 0 else 0)
+        s2 = ba.solve()
+        assert s2.iterations == 0 and s2.initial_cost == 0  # no new keyframe -> no-op (:138)
+    pts = ba.get_points(ids0[:10])
+    assert pts.dtype == np.float32 and np.isfinite(pts).all() and (pts[:, 2] > 1.0).all()  # double -> float gather (:159-163)
+    assert np.allclose(ba.get_pose(0), ba.get_pose(-3))
+    ba.close()
