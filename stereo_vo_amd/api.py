@@ -381,3 +381,55 @@ class BA:
         out = np.empty((ids.shape[0], 3), np.float32)
         self.ctx._chk(self.L.svo_ba_get_points(self.h, _p(ids), ids.shape[0], _p(out)), "svo_ba_get_points")
         return out
+
+
+def pipeline_default_params():
+    p = PipelineParams()
+    lib().svo_pipeline_default_params(C.byref(p))
+    return p
+
+
+class Pipeline:
+    """svo_pipeline wrapper: ImageProcessor::process + BundleAdjuster::bundle_adjust per frame."""
+
+    def __init__(self, ctx, params):
+        self.ctx, self.L, self.prm = ctx, ctx.L, params
+        self.h = C.c_void_p()
+        ctx._chk(self.L.svo_pipeline_create(ctx.h, C.byref(self.h), C.byref(params)), "svo_pipeline_create")
+        self.L.svo_pipeline_destroy.argtypes = [C.c_void_p]
+
+    def close(self):
+        if self.h:
+            self.L.svo_pipeline_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._chk(self.L.svo_pipeline_reset(self.h), "svo_pipeline_reset")
+
+    def process_batch(self, left, right):
+        """left/right: (B, H, W) uint8 host arrays."""
+        left, right = _u8(left), _u8(right)
+        b = left.shape[0]
+        res = (FrameResult * b)()
+        self.ctx._chk(self.L.svo_pipeline_process_batch(self.h, _p(left), _p(right), b, res), "svo_pipeline_process_batch")
+        return list(res)
+
+    def process_batch_dev(self, left_ptr, right_ptr, batch):
+        """left_ptr/right_ptr: raw device pointers (ints) to (B, H, W) uint8 images resident in HBM."""
+        res = (FrameResult * batch)()
+        self.ctx._chk(self.L.svo_pipeline_process_batch_dev(self.h, C.c_void_p(left_ptr), C.c_void_p(right_ptr), batch, res),
+                      "svo_pipeline_process_batch_dev")
+        return list(res)
+
+    def tracked(self, capacity=8192):
+        ids = np.empty(capacity, np.int64)
+        xy = np.empty((capacity, 2), np.float32)
+        n = C.c_int(0)
+        self.ctx._chk(self.L.svo_pipeline_get_tracked(self.h, _p(ids), _p(xy), capacity, C.byref(n)), "svo_pipeline_get_tracked")
+        return ids[:n.value].copy(), xy[:n.value].copy()

@@ -1,7 +1,6 @@
-"""Build recipes: the gfx950 C-ABI library (hipcc) and, for tests/bench only, the CPU oracle (g++).
-
-Everything is built in-tree (the .so files travel to the GPU box with the snapshot; they are
-git-ignored).  No CMake: a handful of translation units compiled directly.
+"""Build recipe of the gfx950 C-ABI library (hipcc), in-tree: the .so travels to the GPU box with the
+snapshot and is git-ignored.  No CMake: a handful of translation units compiled directly.
+(The CPU checker has its own recipe under oracle/build.py; the product never builds or loads it.)
 """
 import glob
 import os
@@ -12,8 +11,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "stereo_vo_amd", "csrc")
 HOST = os.path.join(ROOT, "stereo_vo_amd", "host")
 LIB = os.path.join(ROOT, "stereo_vo_amd", "libsvo_hip.so")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "_build", "libsvo_oracle.so")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
@@ -57,19 +54,5 @@ def build_hip(force=False):
     return LIB
 
 
-def build_oracle(force=False):
-    srcs = sorted(glob.glob(os.path.join(ORACLE_DIR, "*.cpp")))
-    deps = srcs + [os.path.join(ORACLE_DIR, "svo_oracle.h")]
-    os.makedirs(os.path.dirname(ORACLE_LIB), exist_ok=True)
-    if force or _newer(ORACLE_LIB, deps):
-        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fopenmp",
-              "-Wall", "-o", ORACLE_LIB] + srcs)
-    return ORACLE_LIB
-
-
 if __name__ == "__main__":
-    force = "--force" in sys.argv
-    if "--oracle" in sys.argv or "--all" in sys.argv or len(sys.argv) == 1:
-        build_oracle(force)
-    if "--hip" in sys.argv or "--all" in sys.argv or len(sys.argv) == 1:
-        build_hip(force)
+    build_hip("--force" in sys.argv)

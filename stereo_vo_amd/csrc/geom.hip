@@ -88,6 +88,31 @@ __global__ __launch_bounds__(CT) void dedup_kernel(const float* __restrict__ det
   if (threadIdx.x == 0) *n_kept = base;
 }
 
+__global__ void gather_track_kernel(const int* __restrict__ idx, const int* __restrict__ n_dev, int n_host,
+                                    const float* __restrict__ init_src, const long long* __restrict__ ids_src,
+                                    float* __restrict__ init_dst, long long* __restrict__ ids_dst) {
+  const int n = n_dev ? *n_dev : n_host;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int s = idx[i];
+    init_dst[2 * i] = init_src[2 * s]; init_dst[2 * i + 1] = init_src[2 * s + 1];
+    ids_dst[i] = ids_src[s];
+  }
+}
+
+int svo_k_gather_track(svo_ctx* ctx, const int* idx, const int* n_dev, int n_max, const float* init_src,
+                       const long long* ids_src, float* init_dst, long long* ids_dst) {
+  if (n_max <= 0) return SVO_OK;
+  hipLaunchKernelGGL(gather_track_kernel, dim3(svo_div_up(n_max, 256)), dim3(256), 0, ctx->stream, idx, n_dev, n_max,
+                     init_src, ids_src, init_dst, ids_dst);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_k_gather_xy_ids(svo_ctx* ctx, const int* idx, int n, const float* xy_src, const long long* ids_src,
+                        float* xy_dst, long long* ids_dst) {
+  return svo_k_gather_track(ctx, idx, nullptr, n, xy_src, ids_src, xy_dst, ids_dst);
+}
+
 SvoMat4 svo_k_reprojection_matrix(const float* pose16, float focal, float cx, float cy, float baseline) {
   float Q[16] = {0};
   Q[0] = (float)(1.0 / (double)focal);

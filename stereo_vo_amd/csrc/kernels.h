@@ -25,4 +25,13 @@ int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, 
                 float* parallax, float* kept_xy, int* kept_index, int* n_kept, float* av_parallax);
 int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
              int n, float* out_xy, uint8_t* status);
+// gathers used by the tracker / pipeline: dst[i] = src[idx[i]] for i < n (n on the device or host)
+int svo_k_gather_track(svo_ctx* ctx, const int* idx, const int* n_dev, int n_max, const float* init_src,
+                       const long long* ids_src, float* init_dst, long long* ids_dst);
+int svo_k_gather_xy_ids(svo_ctx* ctx, const int* idx, int n, const float* xy_src, const long long* ids_src,
+                        float* xy_dst, long long* ids_dst);
+// a5 (device-pointer form)
+int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy, int n, float focal, float cx, float cy,
+              double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence, int* d_inliers,
+              int* n_inliers);
 #endif

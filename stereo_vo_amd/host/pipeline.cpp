@@ -1,0 +1,519 @@
+// Host side of the hot path: the reference's ImageProcessor / FeatureTracker / BundleAdjuster control flow
+// re-hosted over the HIP kernels (everything heavy stays in HBM; the host only sees the handful of
+// scalars the reference's own branches test) and the svo_pipeline_* C-ABI on top.
+// Reference: src/image_processor.cpp:18-208, src/feature_tracker.cpp:3-72, src/bundle_adjuster.cpp:60-163,
+// driver rule src/vo_node.cpp:141-148.
+#include <math.h>
+#include <string.h>
+
+#include "kernels.h"
+#include "stereo_vo.hpp"
+
+namespace svo {
+
+#define SVO_TRY(expr)            \
+  do {                           \
+    hipError_t e__ = (expr);     \
+    if (e__ != hipSuccess) {     \
+      ctx_->err = std::string(#expr) + ": " + hipGetErrorString(e__); \
+      return;                    \
+    }                            \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------ ReprojectionFactor
+bool ReprojectionFactor::Evaluate(double const* const* parameters, double* residuals, double** jacobians) const {
+  double obs[2] = {ox_, oy_};
+  return svo_reproj_eval(ctx_, 1, parameters[0], parameters[1], obs, info_.focal, info_.cx, info_.cy, residuals,
+                         jacobians ? jacobians[0] : nullptr, jacobians ? jacobians[1] : nullptr) == SVO_OK;
+}
+
+// ------------------------------------------------------------------------------------------ BundleAdjuster
+BundleAdjuster::BundleAdjuster(svo_ctx* ctx, size_t window_size, svo_camera_info info, int max_features, int max_iterations,
+                               double max_time_s)
+    : ctx_(ctx), window_size_(window_size), info_(info), max_features_(max_features), max_iterations_(max_iterations),
+      max_time_s_(max_time_s) {
+  reset();
+}
+
+void BundleAdjuster::reset() {
+  if (ba_) svo_ba_destroy(ba_);
+  ba_ = nullptr;
+  svo_ba_options opt;
+  svo_ba_default_options(&opt);
+  opt.max_features = max_features_;       // src/bundle_adjuster.hpp:75
+  opt.max_iterations = max_iterations_;
+  opt.max_time_s = max_time_s_;           // src/bundle_adjuster.cpp:11
+  const int max_lm = 1 << 20;             // landmark store grows monotonically (SURVEY C-3)
+  const int max_obs = (int)(window_size_ + 1) * max_features_ + 64;
+  svo_ba_create(ctx_, &ba_, (int)window_size_, &info_, &opt, max_lm > max_obs ? max_obs : max_lm, max_obs);
+  last_keyframe_.reset();
+  last_iterations_ = 0;
+}
+
+BundleAdjuster::~BundleAdjuster() { if (ba_) svo_ba_destroy(ba_); }
+
+void BundleAdjuster::add_keyframe(std::shared_ptr<Keyframe> kf) {  // src/bundle_adjuster.cpp:60-135
+  if (!ba_) return;
+  double pose7[7] = {kf->orientation.w_, kf->orientation.x_, kf->orientation.y_, kf->orientation.z_,
+                     kf->position(0), kf->position(1), kf->position(2)};
+  const int nt = (int)kf->tracked_ids.size(), nn = (int)kf->new_features_2d.size();
+  std::vector<int64_t> tid(nt), nid(nn > 0 ? nn : 1);
+  for (int i = 0; i < nt; ++i) tid[i] = (int64_t)kf->tracked_ids[i];
+  int kept = 0;
+  const int rc = svo_ba_add_keyframe(ba_, pose7, tid.data(), (const float*)kf->tracked_features_2d.data(), nt,
+                                     (const float*)kf->new_features_2d.data(), (const float*)kf->new_features_3d.data(), nn,
+                                     nid.data(), &kept);
+  if (rc) return;
+  kf->new_features_2d.resize(kept);  // :86-90
+  kf->new_features_3d.resize(kept);
+  kf->new_ids.clear();               // real ids only (SURVEY C-4)
+  for (int i = 0; i < kept; ++i) kf->new_ids.push_back((size_t)nid[i]);
+  last_keyframe_ = kf;               // :132
+}
+
+void BundleAdjuster::bundle_adjust() {  // src/bundle_adjuster.cpp:137-157
+  last_iterations_ = 0;
+  if (!ba_ || !last_keyframe_) return;
+  svo_ba_summary s;
+  if (svo_ba_solve(ba_, &s)) return;
+  last_iterations_ = s.iterations;
+  double p[7];
+  if (svo_ba_get_pose(ba_, -1, p)) return;
+  // :146-153 (copying an unchanged pose back when no solve ran is the identity on float values already stored)
+  if (s.iterations > 0 || s.initial_cost != 0.0) {
+    last_keyframe_->orientation = Quaternionf{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+    last_keyframe_->position = Vector3f{{(float)p[4], (float)p[5], (float)p[6]}};
+  }
+}
+
+void BundleAdjuster::get_world_points(std::vector<Point3f>& world_points, const std::vector<size_t>& ids) {
+  const size_t n = ids.size();
+  if (!n || !ba_) return;
+  std::vector<int64_t> id64(n);
+  for (size_t i = 0; i < n; ++i) id64[i] = (int64_t)ids[i];
+  const size_t base = world_points.size();
+  world_points.resize(base + n);
+  svo_ba_get_points(ba_, id64.data(), (int)n, (float*)(world_points.data() + base));  // :159-163
+}
+
+// ------------------------------------------------------------------------------------------ FeatureTracker
+FeatureTracker::FeatureTracker(svo_ctx* ctx, int max_features, int max_width, int max_height) : ctx_(ctx), cap_(max_features) {
+  pyr_cap_ = svo_k_pyramid_bytes(max_width, max_height);
+  for (int b = 0; b < 2; ++b) {
+    (void)hipMalloc((void**)&d_xy_[b], sizeof(float) * 2 * cap_);
+    (void)hipMalloc((void**)&d_init_[b], sizeof(float) * 2 * cap_);
+    (void)hipMalloc((void**)&d_ids_[b], sizeof(long long) * cap_);
+  }
+  (void)hipMalloc((void**)&d_fwd_, sizeof(float) * 2 * cap_);
+  (void)hipMalloc((void**)&d_par_, sizeof(float) * cap_);
+  (void)hipMalloc((void**)&d_keep_, cap_);
+  (void)hipMalloc((void**)&d_kidx_, sizeof(int) * cap_);
+  (void)hipMalloc((void**)&d_n_, sizeof(int));
+  (void)hipMalloc((void**)&d_av_, sizeof(float));
+  (void)hipMalloc((void**)&d_last_pyr_, pyr_cap_);
+}
+
+FeatureTracker::~FeatureTracker() {
+  void* ptrs[] = {d_xy_[0], d_xy_[1], d_init_[0], d_init_[1], d_ids_[0], d_ids_[1], d_fwd_, d_par_, d_keep_, d_kidx_, d_n_, d_av_, d_last_pyr_};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+}
+
+void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const std::vector<Point2f>& features,
+                          const std::vector<size_t>& ids) {  // src/feature_tracker.cpp:3-16
+  hipStream_t st = ctx_->stream;
+  int n = (int)ids.size();
+  if (n > cap_) n = cap_;
+  std::vector<long long> id64(n);
+  for (int i = 0; i < n; ++i) id64[i] = (long long)ids[i];
+  if (n) {
+    SVO_TRY(hipMemcpyAsync(d_xy_[cur_], features.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    SVO_TRY(hipMemcpyAsync(d_init_[cur_], features.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+    SVO_TRY(hipMemcpyAsync(d_ids_[cur_], id64.data(), sizeof(long long) * n, hipMemcpyHostToDevice, st));
+  }
+  SVO_TRY(hipMemcpyAsync(d_last_pyr_, pyramid, svo_k_pyramid_bytes(width, height), hipMemcpyDeviceToDevice, st));  // clone, :14
+  SVO_TRY(hipStreamSynchronize(st));  // id64 / features are host temporaries
+  n_ = n_initial_ = n;
+  has_image_ = true;
+}
+
+void FeatureTracker::track_features(float& av_parallax, float& percent_lost, const uint8_t* pyramid, int width, int height,
+                                    bool /*flow_back: the reference always passes true*/) {  // src/feature_tracker.cpp:18-67
+  hipStream_t st = ctx_->stream;
+  const int nxt = 1 - cur_;
+  if (svo_k_track(ctx_, d_last_pyr_, pyramid, width, height, d_xy_[cur_], d_init_[cur_], nullptr, n_, d_fwd_, d_keep_, d_par_,
+                  d_xy_[nxt], d_kidx_, d_n_, d_av_)) return;
+  if (svo_k_gather_track(ctx_, d_kidx_, d_n_, n_, d_init_[cur_], d_ids_[cur_], d_init_[nxt], d_ids_[nxt])) return;  // C-1: old ids
+  int* h_n = (int*)ctx_->h_pinned;
+  float* h_av = (float*)ctx_->h_pinned + 1;
+  SVO_TRY(hipMemcpyAsync(h_n, d_n_, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipMemcpyAsync(h_av, d_av_, sizeof(float), hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipMemcpyAsync(d_last_pyr_, pyramid, svo_k_pyramid_bytes(width, height), hipMemcpyDeviceToDevice, st));  // :66
+  SVO_TRY(hipStreamSynchronize(st));
+  cur_ = nxt;
+  n_ = *h_n;
+  av_parallax = *h_av;                                                                    // :63
+  percent_lost = (float)(1.0 - (double)((float)n_ / (float)n_initial_));                   // :64
+}
+
+void FeatureTracker::get_tracked_features(std::vector<Point2f>& features, std::vector<size_t>& ids) {  // :69-72
+  features.resize(n_);
+  ids.resize(n_);
+  if (!n_) return;
+  std::vector<long long> id64(n_);
+  hipStream_t st = ctx_->stream;
+  SVO_TRY(hipMemcpyAsync(features.data(), d_xy_[cur_], sizeof(float) * 2 * n_, hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipMemcpyAsync(id64.data(), d_ids_[cur_], sizeof(long long) * n_, hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipStreamSynchronize(st));
+  for (int i = 0; i < n_; ++i) ids[i] = (size_t)id64[i];
+}
+
+// ------------------------------------------------------------------------------------------ ImageProcessor
+namespace {
+// cv::Rodrigues on a CV_32F rvec: evaluated in double, stored as float.
+void rodrigues_f(const float* rv, float* R9) {
+  const double rx = rv[0], ry = rv[1], rz = rv[2];
+  const double th = sqrt(rx * rx + ry * ry + rz * rz);
+  double R[9];
+  if (th < 2.220446049250313e-16) {
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+  } else {
+    const double c = cos(th), s = sin(th), c1 = 1.0 - c, it = 1.0 / th;
+    const double x = rx * it, y = ry * it, z = rz * it;
+    R[0] = c + c1 * x * x; R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y; R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+  }
+  for (int i = 0; i < 9; ++i) R9[i] = (float)R[i];
+}
+
+// Eigen::Quaternionf(Matrix3f) (src/image_processor.cpp:92), float arithmetic, row-major m.
+void quat_from_R(const float* m, float* q /*wxyz*/) {
+  float t = m[0] + m[4] + m[8];
+  if (t > 0.f) {
+    t = sqrtf(t + 1.0f);
+    q[0] = 0.5f * t;
+    t = 0.5f / t;
+    q[1] = (m[7] - m[5]) * t; q[2] = (m[2] - m[6]) * t; q[3] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrtf(m[4 * i] - m[4 * j] - m[4 * k] + 1.0f);
+    q[1 + i] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (m[3 * k + j] - m[3 * j + k]) * t;
+    q[1 + j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    q[1 + k] = (m[3 * k + i] + m[3 * i + k]) * t;
+  }
+}
+}  // namespace
+
+ImageProcessor::ImageProcessor(svo_ctx* ctx, const float K[9], std::shared_ptr<FeatureTracker> tracker,
+                               std::shared_ptr<BundleAdjuster> adjuster, float bline, float min_dist, float par_thresh,
+                               int max_corners, double quality, int max_batch)
+    : ctx_(ctx), feature_tracker(std::move(tracker)), bundle_adjuster(std::move(adjuster)), baseline(bline),
+      min_feature_distance(min_dist), parallax_thresh(par_thresh), max_corners_(max_corners), quality_(quality),
+      max_batch_(max_batch < 1 ? 1 : max_batch) {
+  memcpy(K_, K, sizeof(K_));
+  pyr_stride_ = svo_k_pyramid_bytes(ctx->lim.max_width, ctx->lim.max_height);
+  const size_t mc = (size_t)max_corners_, mf = (size_t)ctx->lim.max_features;
+  (void)hipMalloc((void**)&d_corners_, sizeof(float) * 2 * mc * max_batch_);
+  (void)hipMalloc((void**)&d_ncorners_, sizeof(int) * max_batch_);
+  (void)hipMalloc((void**)&d_pyr_, pyr_stride_ * max_batch_);
+  (void)hipMalloc((void**)&d_xyz_, sizeof(float) * 3 * mf);
+  (void)hipMalloc((void**)&d_trk_xy_, sizeof(float) * 2 * mf);
+  (void)hipMalloc((void**)&d_trk_ids_, sizeof(long long) * mf);
+  (void)hipMalloc((void**)&d_inl_, sizeof(int) * mf);
+  (void)hipMalloc((void**)&d_new_xy_, sizeof(float) * 2 * mc);
+  (void)hipMalloc((void**)&d_disp_, sizeof(float) * mc);
+  (void)hipMalloc((void**)&d_kxy_, sizeof(float) * 5 * mc + 64);  // kept xy (2) + xyz (3) contiguous for one copy
+  d_kxyz_ = d_kxy_ + 2 * mc;
+  (void)hipMalloc((void**)&d_cnt_, sizeof(int) * 4);
+  h_ncorners_.assign(max_batch_, 0);
+}
+
+ImageProcessor::~ImageProcessor() {
+  void* ptrs[] = {d_corners_, d_ncorners_, d_pyr_, d_xyz_, d_trk_xy_, d_trk_ids_, d_inl_, d_new_xy_, d_disp_, d_kxy_, d_cnt_};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+}
+
+void ImageProcessor::reset() {
+  rvec[0] = rvec[1] = rvec[2] = tvec[0] = tvec[1] = tvec[2] = 0.f;
+  batch_ = 0;
+  feature_tracker->reset();
+  bundle_adjuster->reset();
+}
+
+int ImageProcessor::prepare_batch(const uint8_t* left, int batch, int width, int height) {
+  if (batch < 1 || batch > max_batch_ || batch > ctx_->lim.max_batch) { ctx_->err = "prepare_batch: batch outside limits"; return SVO_ERR_INVALID; }
+  width_ = width; height_ = height; batch_ = batch;
+  const size_t istride = (size_t)width * height;
+  // a1 on every frame (the reference detects on every frame, src/image_processor.cpp:22, SURVEY C-7)
+  int rc = svo_corner_detect_batch_dev(ctx_, left, batch, width, height, width, istride, max_corners_, quality_,
+                                       (double)min_feature_distance, d_corners_, d_ncorners_);
+  if (rc) return rc;
+  pyr_stride_ = svo_k_pyramid_bytes(width, height);
+  rc = svo_k_build_pyramid(ctx_, left, batch, width, height, width, istride, d_pyr_, pyr_stride_);
+  if (rc) return rc;
+  int* h = (int*)((char*)ctx_->h_pinned + 8192);
+  if (hipMemcpyAsync(h, d_ncorners_, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx_->stream) != hipSuccess ||
+      hipMemcpyAsync(h + batch, ctx_->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx_->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx_->stream) != hipSuccess) {
+    ctx_->err = "prepare_batch: readback failed";
+    return SVO_ERR_HIP;
+  }
+  if (h[batch]) {
+    (void)hipMemsetAsync(ctx_->d_status, 0, sizeof(int), ctx_->stream);
+    ctx_->err = "corner detection exceeded a workspace bound (svo_limits.max_candidates)";
+    return SVO_ERR_CAPACITY;
+  }
+  for (int i = 0; i < batch; ++i) h_ncorners_[i] = h[i];
+  return SVO_OK;
+}
+
+// src/image_processor.cpp:165-208.  StereoBM evaluated only at the feature pixels (exactly equivalent, SURVEY C-8).
+void ImageProcessor::triangulate_stereo(std::vector<Point3f>& features_3d, std::vector<Point2f>& valid_features_2d,
+                                        const float* d_features, const int* d_n, int n_max, const DeviceImage& left,
+                                        const DeviceImage& right, const float camera_pose[16]) {
+  if (n_max <= 0) return;
+  hipStream_t st = ctx_->stream;
+  if (svo_stereo_disparity_at_dev(ctx_, left.data, right.data, left.width, left.height, left.stride, 16 * 3, 21, d_features,
+                                  d_n, n_max, d_disp_)) return;  // :173-176
+  const SvoMat4 M = svo_k_reprojection_matrix(camera_pose, K_[0], K_[2], K_[5], baseline);  // :178-189
+  if (svo_k_triangulate(ctx_, d_features, d_disp_, d_n, n_max, M, d_kxy_, d_kxyz_, nullptr, d_cnt_ + 1)) return;
+  // one readback: count + kept 2-D + 3-D (n_max entries each; only the first `count` are meaningful)
+  int* h_cnt = (int*)((char*)ctx_->h_pinned + 16384);
+  float* h_buf = (float*)((char*)ctx_->h_pinned + 16384 + 64);
+  SVO_TRY(hipMemcpyAsync(h_cnt, d_cnt_ + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipMemcpyAsync(h_buf, d_kxy_, sizeof(float) * 2 * n_max, hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipMemcpyAsync(h_buf + 2 * n_max, d_kxyz_, sizeof(float) * 3 * n_max, hipMemcpyDeviceToHost, st));
+  SVO_TRY(hipStreamSynchronize(st));
+  const int m = *h_cnt;
+  valid_features_2d.resize(m);
+  features_3d.resize(m);
+  memcpy(valid_features_2d.data(), h_buf, sizeof(float) * 2 * m);
+  memcpy(features_3d.data(), h_buf + 2 * n_max, sizeof(float) * 3 * m);
+}
+
+void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp:18-163
+  stats_ = Stats();
+  int slot = sp.batch_slot;
+  if (slot < 0 || slot >= batch_) {
+    if (prepare_batch(sp.left.data, 1, sp.left.width, sp.left.height)) return;
+    slot = 0;
+  }
+  hipStream_t st = ctx_->stream;
+  const float* d_det = d_corners_ + (size_t)slot * 2 * max_corners_;
+  const uint8_t* pyr = d_pyr_ + (size_t)slot * pyr_stride_;
+  const int n_det = h_ncorners_[slot];
+  stats_.n_detected = n_det;
+  if (n_det < 4) return;  // :23-25
+
+  std::shared_ptr<Keyframe> last_keyframe = bundle_adjuster->get_last_keyframe();  // :27
+  if (last_keyframe == nullptr) {  // :30-58
+    std::vector<Point3f> features_3d;
+    std::vector<Point2f> valid_features_2d;
+    const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    triangulate_stereo(features_3d, valid_features_2d, d_det, nullptr, n_det, sp.left, sp.right, eye);
+    auto kf = std::make_shared<Keyframe>(Vector3f{{0, 0, 0}}, Quaternionf{1, 0, 0, 0}, sp.left, std::vector<Point2f>(),
+                                         std::vector<size_t>(), valid_features_2d, features_3d);
+    bundle_adjuster->add_keyframe(kf);
+    feature_tracker->init(pyr, width_, height_, kf->new_features_2d, kf->new_ids);
+    tvec[0] = tvec[1] = tvec[2] = 0.f;
+    rvec[0] = rvec[1] = rvec[2] = 0.f;
+    stats_.is_keyframe = 1;
+    stats_.n_new = (int)kf->new_ids.size();
+    return;
+  }
+
+  float av_parallax = 0, percent_lost = 0;
+  feature_tracker->track_features(av_parallax, percent_lost, pyr, width_, height_, true);  // :62
+  stats_.n_tracked = feature_tracker->count();
+  stats_.av_parallax = av_parallax;
+  stats_.percent_lost = percent_lost;
+  if (av_parallax <= parallax_thresh && (double)percent_lost < 0.4) return;  // :63-65
+
+  std::vector<Point2f> tracked_features;
+  std::vector<Point3f> tracked_world_points;
+  std::vector<size_t> tracked_ids;
+  feature_tracker->get_tracked_features(tracked_features, tracked_ids);   // :71
+  bundle_adjuster->get_world_points(tracked_world_points, tracked_ids);   // :72
+  const int m = (int)tracked_ids.size();
+
+  // PnP :74-82 (rvec/tvec are CV_32F in/out; the solver works in double)
+  double rv[3] = {rvec[0], rvec[1], rvec[2]}, tv[3] = {tvec[0], tvec[1], tvec[2]};
+  int num_inliers = 0;
+  std::vector<int> inlier_indices(m > 0 ? m : 1);
+  if (m > 0) {
+    SVO_TRY(hipMemcpyAsync(d_xyz_, tracked_world_points.data(), sizeof(float) * 3 * m, hipMemcpyHostToDevice, st));
+    SvoScratch scratch(ctx_);
+    if (svo_k_pnp(ctx_, scratch, d_xyz_, feature_tracker->device_features(), m, K_[0], K_[2], K_[5], rv, tv, 100, 8.0f, 0.99,
+                  d_inl_, &num_inliers)) return;
+    if (num_inliers > 0) {
+      SVO_TRY(hipMemcpyAsync(inlier_indices.data(), d_inl_, sizeof(int) * num_inliers, hipMemcpyDeviceToHost, st));
+      SVO_TRY(hipStreamSynchronize(st));
+    }
+  }
+  for (int i = 0; i < 3; ++i) { rvec[i] = (float)rv[i]; tvec[i] = (float)tv[i]; }
+  stats_.n_inliers = num_inliers;
+
+  float rmat[9], q[4];
+  rodrigues_f(rvec, rmat);   // :84-85
+  quat_from_R(rmat, q);      // :87-92
+  auto kf = std::make_shared<Keyframe>(Vector3f{{tvec[0], tvec[1], tvec[2]}}, Quaternionf{q[0], q[1], q[2], q[3]}, sp.left,
+                                       std::vector<Point2f>(num_inliers), std::vector<size_t>(num_inliers),
+                                       std::vector<Point2f>(), std::vector<Point3f>());
+  for (int i = 0; i < num_inliers; ++i) {  // :104-108
+    const int idx = inlier_indices[i];
+    kf->tracked_ids[i] = tracked_ids[idx];
+    kf->tracked_features_2d[i] = tracked_features[idx];
+  }
+
+  // dedup :113-128 on the device; the surviving corners stay in HBM for the stereo stage
+  if (num_inliers > 0)
+    SVO_TRY(hipMemcpyAsync(d_trk_xy_, kf->tracked_features_2d.data(), sizeof(float) * 2 * num_inliers, hipMemcpyHostToDevice, st));
+  if (svo_k_dedup(ctx_, d_det, nullptr, n_det, d_trk_xy_, nullptr, num_inliers, min_feature_distance, d_new_xy_, d_cnt_)) return;
+
+  // hmat = [R^T | -R^T t]  :130-134 (float Mats; the product accumulates in double)
+  float hmat[16] = {0};
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) hmat[4 * i + j] = rmat[3 * j + i];
+    double s = 0.0;
+    for (int k = 0; k < 3; ++k) s += (double)(-rmat[3 * k + i]) * (double)tvec[k];
+    hmat[4 * i + 3] = (float)s;
+  }
+  hmat[15] = 1.f;
+  triangulate_stereo(kf->new_features_3d, kf->new_features_2d, d_new_xy_, d_cnt_, n_det, sp.left, sp.right, hmat);  // :137-142
+
+  bundle_adjuster->add_keyframe(kf);  // :144
+
+  std::vector<Point2f> features_2d_for_tracker(kf->tracked_features_2d);  // :148-162
+  features_2d_for_tracker.insert(features_2d_for_tracker.end(), kf->new_features_2d.begin(), kf->new_features_2d.end());
+  std::vector<size_t> ids_for_tracker(kf->tracked_ids);
+  ids_for_tracker.insert(ids_for_tracker.end(), kf->new_ids.begin(), kf->new_ids.end());
+  feature_tracker->init(pyr, width_, height_, features_2d_for_tracker, ids_for_tracker);
+  stats_.is_keyframe = 1;
+  stats_.n_new = (int)kf->new_ids.size();
+}
+
+}  // namespace svo
+
+// ------------------------------------------------------------------------------------------------- C-ABI
+struct svo_pipeline {
+  svo_ctx* ctx;
+  svo_pipeline_params prm;
+  std::shared_ptr<svo::FeatureTracker> tracker;
+  std::shared_ptr<svo::BundleAdjuster> adjuster;
+  std::unique_ptr<svo::ImageProcessor> proc;
+  uint8_t* d_imgs = nullptr;  // staging for the host-pointer entry point (left batch | right batch)
+  size_t d_imgs_bytes = 0;
+};
+
+extern "C" void svo_pipeline_default_params(svo_pipeline_params* p) {
+  if (!p) return;
+  memset(p, 0, sizeof(*p));
+  p->cam.focal = 718.856; p->cam.cx = 607.1928; p->cam.cy = 185.2157; p->cam.baseline = 0.537165718864418;  // config/kitti00.yaml:1-4
+  p->width = 1241; p->height = 376;
+  p->max_corners = 300;            // src/image_processor.cpp:22
+  p->quality = 0.1;
+  p->min_feature_distance = 30.f;  // src/vo_node.cpp:34
+  p->parallax_thresh = 20.f;       // src/vo_node.cpp:33
+  p->window_size = 5;              // src/vo_node.cpp:36
+  p->max_features = 400;           // src/bundle_adjuster.hpp:75
+  p->ba_max_iterations = 50;
+  p->ba_max_time_s = 0.1;          // src/bundle_adjuster.cpp:11
+}
+
+extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_pipeline_params* p) {
+  if (!ctx || !out || !p) return SVO_ERR_INVALID;
+  SVO_REQUIRE(ctx, p->width >= 32 && p->height >= 32 && p->width <= ctx->lim.max_width && p->height <= ctx->lim.max_height,
+              "pipeline_create: image size outside the context limits");
+  SVO_REQUIRE(ctx, p->max_corners >= 4 && p->max_corners <= ctx->lim.max_corners && p->max_features >= 4 &&
+                       p->max_features <= ctx->lim.max_features, "pipeline_create: feature counts outside the context limits");
+  SVO_REQUIRE(ctx, p->window_size >= 1 && p->window_size <= 63, "pipeline_create: window size must be 1..63");
+  svo_pipeline* pl = new svo_pipeline();
+  pl->ctx = ctx;
+  pl->prm = *p;
+  pl->tracker = std::make_shared<svo::FeatureTracker>(ctx, ctx->lim.max_features, ctx->lim.max_width, ctx->lim.max_height);
+  pl->adjuster = std::make_shared<svo::BundleAdjuster>(ctx, (size_t)p->window_size, p->cam, p->max_features,
+                                                       p->ba_max_iterations, p->ba_max_time_s);
+  // K as the reference builds it (CV_32F 3x3, src/vo_node.cpp:104-108)
+  const float K[9] = {(float)p->cam.focal, 0.f, (float)p->cam.cx, 0.f, (float)p->cam.focal, (float)p->cam.cy, 0.f, 0.f, 1.f};
+  pl->proc.reset(new svo::ImageProcessor(ctx, K, pl->tracker, pl->adjuster, (float)p->cam.baseline, p->min_feature_distance,
+                                         p->parallax_thresh, p->max_corners, p->quality, ctx->lim.max_batch));
+  *out = pl;
+  return SVO_OK;
+}
+
+extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
+  if (!p) return;
+  if (p->d_imgs) (void)hipFree(p->d_imgs);
+  delete p;
+}
+
+extern "C" int svo_pipeline_reset(svo_pipeline* p) {
+  if (!p) return SVO_ERR_INVALID;
+  p->proc->reset();
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* left, const uint8_t* right, int batch,
+                                              svo_frame_result* results) {
+  if (!p) return SVO_ERR_INVALID;
+  svo_ctx* ctx = p->ctx;
+  SVO_REQUIRE(ctx, left && right && results && batch >= 1, "pipeline_process_batch: bad arguments");
+  const int W = p->prm.width, H = p->prm.height;
+  const size_t istride = (size_t)W * H;
+  ctx->err.clear();
+  int rc = p->proc->prepare_batch(left, batch, W, H);
+  if (rc) return rc;
+  for (int i = 0; i < batch; ++i) {
+    svo::DeviceImage L{left + i * istride, W, H, W}, R{right + i * istride, W, H, W};
+    p->proc->process(svo::StereoPair(L, R, (double)i, i));  // src/vo_node.cpp:141-144
+    svo_frame_result& r = results[i];
+    memset(&r, 0, sizeof(r));
+    const auto& s = p->proc->stats();
+    r.n_detected = s.n_detected; r.n_tracked = s.n_tracked; r.n_inliers = s.n_inliers; r.n_new = s.n_new;
+    r.is_keyframe = s.is_keyframe; r.av_parallax = s.av_parallax; r.percent_lost = s.percent_lost;
+    if (p->adjuster->get_last_keyframe() != nullptr) {  // src/vo_node.cpp:146-148
+      p->adjuster->bundle_adjust();
+      r.ba_iterations = p->adjuster->last_iterations();
+      auto kf = p->adjuster->get_last_keyframe();
+      r.pose7[0] = kf->orientation.w_; r.pose7[1] = kf->orientation.x_; r.pose7[2] = kf->orientation.y_; r.pose7[3] = kf->orientation.z_;
+      r.pose7[4] = kf->position(0); r.pose7[5] = kf->position(1); r.pose7[6] = kf->position(2);
+    }
+    if (!ctx->err.empty()) return SVO_ERR_HIP;
+  }
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, const uint8_t* right, int batch,
+                                          svo_frame_result* results) {
+  if (!p) return SVO_ERR_INVALID;
+  svo_ctx* ctx = p->ctx;
+  SVO_REQUIRE(ctx, left && right && results && batch >= 1 && batch <= ctx->lim.max_batch, "pipeline_process_batch: bad arguments");
+  const size_t bytes = (size_t)p->prm.width * p->prm.height * batch;
+  if (p->d_imgs_bytes < 2 * bytes) {
+    if (p->d_imgs) (void)hipFree(p->d_imgs);
+    p->d_imgs = nullptr; p->d_imgs_bytes = 0;
+    SVO_HIP_CHECK(ctx, hipMalloc((void**)&p->d_imgs, 2 * bytes));
+    p->d_imgs_bytes = 2 * bytes;
+  }
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(p->d_imgs, left, bytes, hipMemcpyHostToDevice, ctx->stream));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(p->d_imgs + bytes, right, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return svo_pipeline_process_batch_dev(p, p->d_imgs, p->d_imgs + bytes, batch, results);
+}
+
+extern "C" int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n) {
+  if (!p || !n) return SVO_ERR_INVALID;
+  std::vector<svo::Point2f> f;
+  std::vector<size_t> id;
+  p->tracker->get_tracked_features(f, id);
+  *n = (int)id.size();
+  for (int i = 0; i < *n && i < capacity; ++i) {
+    if (ids) ids[i] = (int64_t)id[i];
+    if (xy) { xy[2 * i] = f[i].x; xy[2 * i + 1] = f[i].y; }
+  }
+  return SVO_OK;
+}

@@ -1,0 +1,158 @@
+// Host-side mirror of the reference's class surfaces, device resident.
+//
+//   reference (OpenCV/Eigen/Ceres types)                    this header (plain types, HBM-resident images)
+//   --------------------------------------------------------------------------------------------------------
+//   struct CameraInfo              src/camera_info.hpp:4-18  ->  svo_camera_info (same fields, same order)
+//   struct StereoPair              src/image_processor.hpp:9-17 -> svo::StereoPair {left, right, t}
+//   struct Keyframe                src/bundle_adjuster.hpp:22-46 -> svo::Keyframe (same 8 fields)
+//   class  FeatureTracker          src/feature_tracker.hpp:20-54 -> svo::FeatureTracker (init / track_features /
+//                                                                   get_tracked_features)
+//   class  BundleAdjuster          src/bundle_adjuster.hpp:86-126 -> svo::BundleAdjuster (get_last_keyframe /
+//                                                                   add_keyframe / bundle_adjust / get_world_points)
+//   class  ImageProcessor          src/image_processor.hpp:31-46 -> svo::ImageProcessor (ctor, process)
+//   class  ReprojectionFactor      src/reprojection_factor.hpp:7-18 -> svo::ReprojectionFactor (Evaluate, Ceres' null
+//                                                                   conventions) — host entry to the a11 kernel
+// Same method names, argument meaning and error behaviour (void + silent early return).  cv::Mat / Eigen
+// types do not exist in this environment; INTEGRATION.md shows the few-line adapters a maintainer with
+// OpenCV/Eigen installed adds so that vo_node.cpp compiles unchanged against these classes.
+#ifndef SVO_STEREO_VO_HPP_
+#define SVO_STEREO_VO_HPP_
+#include <cstddef>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#include "svo.h"
+
+struct svo_ba;
+
+namespace svo {
+
+struct Point2f { float x, y; };
+struct Point3f { float x, y, z; };
+struct Vector3f { float v[3]; float& operator()(int i) { return v[i]; } float operator()(int i) const { return v[i]; } };
+struct Quaternionf { float w_, x_, y_, z_; float& w() { return w_; } float& x() { return x_; } float& y() { return y_; } float& z() { return z_; } };
+
+// mono8 image resident in HBM (what cv::Mat holds on the host in the reference)
+struct DeviceImage { const uint8_t* data = nullptr; int width = 0, height = 0, stride = 0; };
+
+struct StereoPair {  // src/image_processor.hpp:9-17
+  DeviceImage left, right;
+  double t;
+  int batch_slot;  // index into the batch prepared with ImageProcessor::prepare_batch (-1: none)
+  StereoPair(const DeviceImage& l, const DeviceImage& r, double t_, int slot = -1) : left(l), right(r), t(t_), batch_slot(slot) {}
+};
+
+struct Keyframe {  // src/bundle_adjuster.hpp:22-46
+  Vector3f position;
+  Quaternionf orientation;
+  DeviceImage image;
+  std::vector<Point2f> tracked_features_2d;
+  std::vector<size_t> tracked_ids;
+  std::vector<Point2f> new_features_2d;
+  std::vector<Point3f> new_features_3d;
+  std::vector<size_t> new_ids;
+  Keyframe(Vector3f p, Quaternionf q, DeviceImage img, std::vector<Point2f> t2d, std::vector<size_t> tid,
+           std::vector<Point2f> n2d, std::vector<Point3f> n3d)
+      : position(p), orientation(q), image(img), tracked_features_2d(std::move(t2d)), tracked_ids(std::move(tid)),
+        new_features_2d(std::move(n2d)), new_features_3d(std::move(n3d)) {}
+};
+
+class ReprojectionFactor {  // src/reprojection_factor.hpp:7-18
+ public:
+  ReprojectionFactor(svo_ctx* ctx, double ox, double oy, svo_camera_info info) : ctx_(ctx), ox_(ox), oy_(oy), info_(info) {}
+  bool Evaluate(double const* const* parameters, double* residuals, double** jacobians) const;
+ private:
+  svo_ctx* ctx_;
+  double ox_, oy_;
+  svo_camera_info info_;
+};
+
+class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
+ public:
+  BundleAdjuster(svo_ctx* ctx, size_t window_size, svo_camera_info info, int max_features = 400,
+                 int max_iterations = 50, double max_time_s = 0.1);
+  ~BundleAdjuster();
+  std::shared_ptr<Keyframe> get_last_keyframe() { return last_keyframe_; }
+  void add_keyframe(std::shared_ptr<Keyframe> keyframe);
+  void bundle_adjust();
+  void get_world_points(std::vector<Point3f>& world_points, const std::vector<size_t>& ids);
+  int last_iterations() const { return last_iterations_; }
+  svo_ba* handle() { return ba_; }
+  void reset();
+ private:
+  svo_ctx* ctx_;
+  svo_ba* ba_ = nullptr;
+  size_t window_size_;
+  svo_camera_info info_;
+  int max_features_, max_iterations_;
+  double max_time_s_;
+  std::shared_ptr<Keyframe> last_keyframe_;
+  int last_iterations_ = 0;
+};
+
+class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing are visualisation: out of scope)
+ public:
+  FeatureTracker(svo_ctx* ctx, int max_features, int max_width, int max_height);
+  ~FeatureTracker();
+  // `pyramid` is the device pyramid of `image` (built by ImageProcessor::prepare_batch); it is copied, as the
+  // reference clones the image (src/feature_tracker.cpp:14).
+  void init(const uint8_t* pyramid, int width, int height, const std::vector<Point2f>& features, const std::vector<size_t>& ids);
+  void track_features(float& av_parallax, float& percent_lost, const uint8_t* pyramid, int width, int height, bool flow_back);
+  void get_tracked_features(std::vector<Point2f>& features, std::vector<size_t>& ids);
+  // device views of the current feature set (for the in-library pipeline)
+  const float* device_features() const { return d_xy_[cur_]; }
+  const long long* device_ids() const { return d_ids_[cur_]; }
+  int count() const { return n_; }
+  void reset() { n_ = 0; n_initial_ = 0; has_image_ = false; }
+ private:
+  svo_ctx* ctx_;
+  int cap_;
+  size_t pyr_cap_;
+  float* d_xy_[2] = {nullptr, nullptr};
+  float* d_init_[2] = {nullptr, nullptr};
+  long long* d_ids_[2] = {nullptr, nullptr};
+  float* d_fwd_ = nullptr; float* d_par_ = nullptr; uint8_t* d_keep_ = nullptr; int* d_kidx_ = nullptr;
+  int* d_n_ = nullptr; float* d_av_ = nullptr;
+  uint8_t* d_last_pyr_ = nullptr;
+  int cur_ = 0, n_ = 0, n_initial_ = 0;
+  bool has_image_ = false;
+};
+
+class ImageProcessor {  // src/image_processor.hpp:31-46
+ public:
+  ImageProcessor(svo_ctx* ctx, const float K[9], std::shared_ptr<FeatureTracker> tracker,
+                 std::shared_ptr<BundleAdjuster> adjuster, float bline, float min_feature_distance, float parallax_thresh,
+                 int max_corners = 300, double quality = 0.1, int max_batch = 1);
+  ~ImageProcessor();
+  // Batch the stateless per-frame stages (corner detection on every left image, pyramids) for `batch`
+  // consecutive frames resident in HBM.  process() on those frames then only runs the sequential chain.
+  int prepare_batch(const uint8_t* left, int batch, int width, int height);
+  void process(const StereoPair& stereo_pair);
+  // per-frame diagnostics of the last process() call
+  struct Stats { int n_detected = 0, n_tracked = 0, n_inliers = 0, n_new = 0, is_keyframe = 0; float av_parallax = 0, percent_lost = 0; };
+  const Stats& stats() const { return stats_; }
+  void reset();
+ private:
+  void triangulate_stereo(std::vector<Point3f>& features_3d, std::vector<Point2f>& valid_features_2d,
+                          const float* d_features, const int* d_n, int n_max, const DeviceImage& left,
+                          const DeviceImage& right, const float camera_pose[16]);
+  svo_ctx* ctx_;
+  float K_[9];
+  std::shared_ptr<FeatureTracker> feature_tracker;
+  std::shared_ptr<BundleAdjuster> bundle_adjuster;
+  float baseline, min_feature_distance, parallax_thresh;
+  int max_corners_; double quality_; int max_batch_;
+  float rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};  // CV_32F in the reference (src/image_processor.cpp:54-55)
+  // batch state
+  float* d_corners_ = nullptr; int* d_ncorners_ = nullptr; uint8_t* d_pyr_ = nullptr; size_t pyr_stride_ = 0;
+  std::vector<int> h_ncorners_;
+  int batch_ = 0, width_ = 0, height_ = 0;
+  // scratch
+  float *d_xyz_ = nullptr, *d_trk_xy_ = nullptr, *d_new_xy_ = nullptr, *d_disp_ = nullptr, *d_kxy_ = nullptr, *d_kxyz_ = nullptr;
+  long long* d_trk_ids_ = nullptr; int *d_inl_ = nullptr, *d_cnt_ = nullptr;
+  Stats stats_;
+};
+
+}  // namespace svo
+#endif

@@ -32,10 +32,11 @@ def oracle():
     if _LIB is None:
         path = os.path.join(ROOT, "oracle", "_build", "libsvo_oracle.so")
         if not os.path.exists(path):
-            import sys
-            sys.path.insert(0, ROOT)
-            from stereo_vo_amd import build
-            build.build_oracle()
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("oracle_build", os.path.join(ROOT, "oracle", "build.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            mod.build_oracle()
         L = C.CDLL(path)
         L.ora_pyramid_bytes.restype = C.c_size_t
         L.ora_pipeline_create.restype = C.c_void_p
