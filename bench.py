@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — stereo frames/s of the MI355X-native stereo-VO hot path (BASELINE.json metric).
+
+A "step" = one pass of the whole hot path (ImageProcessor::process + BundleAdjuster::bundle_adjust per
+frame: corner detection, pyramids, forward/backward LK + survivor filter, PnP-RANSAC, dedup, stereo
+disparity at the features, triangulation, sliding-window bundle adjustment) over one batch of B
+consecutive synthetic KITTI-shaped stereo pairs that are already resident in HBM, starting from a reset
+pipeline (so every step does identical work).  Workload = BASELINE.json configs[1]:
+1241x376, ~1.5k corners per frame (max_corners 1500, quality 0.02, minDistance 10), 5-keyframe BA window.
+
+N GPUs: the frame stream shards across ranks (rank r processes its own sequence chunk; weak scaling, no
+data-path collective — SURVEY §8e "front end / frames").  value = frames all ranks processed / max-over-
+ranks time.  The BA all-reduce path (config 4) is benchmarked with --workload ba50k.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP
+events on the library's stream) and `cpu_baseline` (oracle pipeline on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+W, H = 1241, 376
+MAXC, QUALITY, MIN_DIST, MAX_FEAT, WINDOW = 1500, 0.02, 10.0, 2000, 5
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 measured copy)
+FP64_VEC_PEAK_TFLOPS = 78.6  # public MI355X FP64 vector spec (not in the local guide)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per GPU)")
+    ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "ba50k"])
+    ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=16)
+    return ap.parse_args()
+
+
+def dist_setup(n):
+    """One process per GPU; RCCL via torch.distributed when n > 1."""
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        return torch, dist, rank, local, world
+    return torch, None, rank, local, world
+
+
+def barrier_sync(torch, dist, ctx):
+    ctx.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def render_batch(S, seed, batch):
+    p = S.synth_default(W, H)
+    p.seed = seed
+    fr = [S.synth_render(p, i) for i in range(batch)]
+    return p, np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+
+
+def cpu_baseline(p, L, R, frames):
+    """Oracle pipeline (CPU restatement of the reference path) on the same frames, host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    pipe = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=MAXC,
+                      quality=QUALITY, min_feature_distance=MIN_DIST, parallax_thresh=20.0, window_size=WINDOW,
+                      max_features=MAX_FEAT, ba_max_iterations=50, num_threads=cores)
+    n = min(frames, L.shape[0])
+    t0 = time.perf_counter()
+    res = [pipe.process(L[i], R[i]) for i in range(n)]
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="frames/s", cores=cores, kind="port",
+                sample=f"first {n} frames of the same batch, whole oracle pipeline, {dt:.1f} s"), res
+
+
+def run_kitti(args):
+    import stereo_vo_amd as S
+    torch, dist, rank, local, world = dist_setup(args.gpus)
+    B = args.batch
+    ctx = S.Context(W, H, device=local, max_batch=B, max_corners=MAXC, max_candidates=1 << 16, max_features=MAX_FEAT)
+    p, L, R = render_batch(S, 0x5EED0001 + rank, B)
+    dev = torch.device("cuda", local)
+    dL = torch.from_numpy(L).to(dev)
+    dR = torch.from_numpy(R).to(dev)
+    torch.cuda.synchronize()
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = W, H
+    pp.max_corners, pp.quality, pp.min_feature_distance = MAXC, QUALITY, MIN_DIST
+    pp.max_features, pp.window_size = MAX_FEAT, WINDOW
+    pp.ba_max_iterations, pp.ba_max_time_s = 50, 0.0
+    pipe = S.Pipeline(ctx, pp)
+
+    def step():
+        pipe.reset()
+        return pipe.process_batch_dev(dL.data_ptr(), dR.data_ptr(), B)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+    ctx.profile_select(args.profile_kernel)
+    barrier_sync(torch, dist, ctx)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier_sync(torch, dist, ctx)
+    dt = time.perf_counter() - t0
+    k_ms, k_n = ctx.profile_read()
+    ctx.profile_select(None)
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    frames = world * B * args.steps
+    n_kf = sum(r.is_keyframe for r in res)
+    n_trk = [r.n_tracked for r in res if r.n_tracked]
+    ba_it = sum(r.ba_iterations for r in res)
+    out = {
+        "metric": "stereo frames/sec on 1241x376 KITTI pairs", "value": frames / dt, "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
+        "data": "synthetic",
+        "config": {"workload": "kitti_1241x376_1500corners_5kf_window (BASELINE configs[1])", "batch_per_gpu": B,
+                   "max_corners": MAXC, "quality": QUALITY, "min_distance": MIN_DIST, "window": WINDOW,
+                   "keyframes_per_step": n_kf, "mean_tracked": float(np.mean(n_trk)) if n_trk else 0.0,
+                   "ba_lm_iterations_per_step": ba_it, "sharding": "frames across ranks, no collective"},
+    }
+    # roofline of the profiled kernel (HIP events on the library stream, over the timed region)
+    if k_n > 0:
+        avg_us = 1e3 * k_ms / k_n
+        out["roofline"] = roofline_for(args.profile_kernel, avg_us, res, k_n, args.steps)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cb, ores = cpu_baseline(p, L, R, args.cpu_frames)
+        out["cpu_baseline"] = cb
+        m = min(len(ores), len(res))
+        same = all((a.n_detected, a.n_tracked, a.n_inliers, a.n_new, a.is_keyframe) ==
+                   (b.n_detected, b.n_tracked, b.n_inliers, b.n_new, b.is_keyframe) for a, b in zip(res[:m], ores[:m]))
+        out["parity_vs_cpu"] = {"frames": m, "index_sets_identical": bool(same)}
+    pipe.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def roofline_for(kernel, avg_us, res, launches, steps):
+    """Algorithmic work per launch / measured average launch duration."""
+    A = W * H
+    if kernel == "lk_fb":
+        # one launch per tracked frame: n features x (fwd + bwd) x 4 levels; bytes actually needed from
+        # HBM/L2: both pyramids once (2 x 1.33 A); the binding resource is integer VALU/LDS, reported as
+        # achieved GB/s against HBM for the contract plus the op rate in `note`.
+        n = np.mean([r.n_tracked for r in res if r.n_tracked]) if any(r.n_tracked for r in res) else 0
+        byts = 2 * 1.33 * A
+        gbs = byts / (avg_us * 1e-6) / 1e9
+        return {"kernel": "lk_fb_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us, "launches": launches,
+                "note": f"{n:.0f} features/launch; per feature 2 directions x 4 levels x <=30 iterations x 441-px window"}
+    if kernel == "corner_response":
+        B = launches and (len(res))
+        byts = 5.0 * A * B  # read u8, write f32 response per frame, B frames per launch
+        gbs = byts / (avg_us * 1e-6) / 1e9
+        return {"kernel": "corner_response_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us, "launches": launches}
+    if kernel in ("ba_linearize", "ba_backsub"):
+        return {"kernel": kernel + "_kernel", "bound": "mfma", "achieved": None, "peak": FP64_VEC_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": None, "traffic": None, "avg_launch_us": avg_us, "launches": launches}
+    return {"kernel": kernel, "avg_launch_us": avg_us, "launches": launches}
+
+
+def main():
+    args = parse()
+    if args.workload == "kitti_cfg1":
+        out = run_kitti(args)
+    else:
+        from tools import bench_ba
+        out = bench_ba.run(args)
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

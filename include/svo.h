@@ -66,6 +66,14 @@ int svo_sync(svo_ctx* ctx);
 /* library build tag; "gfx950" must appear in it. */
 const char* svo_version(void);
 
+/* Measurement aid (not a reference interface): time every launch of ONE named kernel with HIP events
+ * recorded on the context stream.  kernel: "corner_response", "corner_nms", "corner_select", "pyr_down",
+ * "lk_fb", "stereo_at", "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub";
+ * NULL/"" disables.  svo_profile_read synchronises the stream and returns the summed duration and the
+ * launch count since the last svo_profile_select. */
+int svo_profile_select(svo_ctx* ctx, const char* kernel);
+int svo_profile_read(svo_ctx* ctx, double* total_ms, int* launches);
+
 /* ------------------------------------------------------------------ a11 --
  * Batched ReprojectionFactor::Evaluate (src/reprojection_factor.cpp:10-88).
  * pose7 = [qw qx qy qz tx ty tz] (src/bundle_adjuster.hpp:50), n of them;

@@ -10,6 +10,14 @@
 // 1/2 y^T (D^2 y - g'); (2) the gradient test uses the 2-norm (an upper bound of Ceres' max-norm) so
 // that every quantity a sharded run decides on is a sum; (3) no wall-clock limit (SURVEY C-10).
 //
+// Declared summation order (what makes the HIP solver bit-identical to this one, and this one independent
+// of its thread count): every sum over observations of ONE landmark runs sequentially in observation
+// order; every sum ACROSS landmarks / observations / pose pairs is R(list) = "256 strided partials
+// (partial[t] = sequential sum of entries t, t+256, ...), then partial[t] += partial[t+s] for
+// s = 128..1" over the contribution list in landmark order.  Per pose pair the 6x6 Schur contribution of
+// observations i <= t of a landmark is B = -(Y_i (W_t s)^T) (+ J_c^T J_c when i == t); it enters block
+// (k_i,k_t) as B and, when i != t, block (k_t,k_i) as B^T.
+//
 // Sharded form: a rank holds all poses and a subset of landmarks.  Per LM iteration it sums
 //   payload1 = [ U - sum_j W_j Vd_j^-1 W_j^T  (n x n) | g_c - sum_j W_j Vd_j^-1 g_pj (n) | g_c (n) |
 //                diag U (n) | cost | sum g_p^2 ]              (pose block unscaled, n = 6 (K-1))
@@ -17,6 +25,8 @@
 // through `allreduce`, so every rank takes identical decisions.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -111,6 +121,24 @@ void plus_pose(const double* p, const double* d, double* out) {
 }
 }  // namespace
 
+namespace {
+// R(list): the declared reduction. get(e, out) yields `width` doubles of list entry e.
+template <typename Get>
+void reduce_list(int count, int width, Get get, double* out) {
+  const int T = 256;
+  std::vector<double> part((size_t)T * width, 0.0), v(width);
+  for (int t = 0; t < T; ++t)
+    for (int e = t; e < count; e += T) {
+      get(e, v.data());
+      for (int w = 0; w < width; ++w) part[(size_t)t * width + w] += v[w];
+    }
+  for (int sft = T / 2; sft > 0; sft >>= 1)
+    for (int t = 0; t < sft; ++t)
+      for (int w = 0; w < width; ++w) part[(size_t)t * width + w] += part[(size_t)(t + sft) * width + w];
+  for (int w = 0; w < width; ++w) out[w] = part[w];
+}
+}  // namespace
+
 extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* points3, int n_obs,
                             const int32_t* obs_pose, const int32_t* obs_point, const double* obs_uv,
                             double focal, double cx, double cy, int max_iterations,
@@ -123,10 +151,30 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
   }
   P.lm_start.push_back(n_obs);
   const int L = (int)P.lm_id.size();
-  const int n = P.n;
+  const int n = P.n, F = n_poses - 1;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   if (num_threads < 1) num_threads = 1;
-  (void)num_threads;
+
+  // contribution slots and destination lists (landmark order)
+  std::vector<int> pair_base(n_obs + 1, 0);
+  for (int l = 0; l < L; ++l)
+    for (int o = P.lm_start[l]; o < P.lm_start[l + 1]; ++o) pair_base[o + 1] = pair_base[o] + (P.lm_start[l + 1] - o);
+  const int n_pairs = pair_base[n_obs];
+  std::vector<std::vector<int>> blk_list((size_t)F * F), pose_list(F);  // entry = slot*2 + transposed
+  for (int l = 0; l < L; ++l)
+    for (int i = P.lm_start[l]; i < P.lm_start[l + 1]; ++i) {
+      const int ki = obs_pose[i] - 1;
+      if (ki < 0) continue;
+      pose_list[ki].push_back(i);
+      for (int t = i; t < P.lm_start[l + 1]; ++t) {
+        const int kt = obs_pose[t] - 1;
+        if (kt < 0) continue;
+        const int slot = pair_base[i] + (t - i);
+        blk_list[(size_t)ki * F + kt].push_back(slot * 2);
+        if (t != i) blk_list[(size_t)kt * F + ki].push_back(slot * 2 + 1);
+      }
+    }
+  std::vector<double> pairB((size_t)n_pairs * 36), obsV((size_t)n_obs * 18), lmV((size_t)L * 4);
 
   std::vector<double> sp((size_t)L * 3, 0.0), sc(n, 0.0);   // Jacobi scales
   bool have_scale = false;
@@ -136,102 +184,100 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
   const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
   const double min_rel_decrease = 1e-3;
 
-  // pass A: linearise at (poses, points) and build payload1 for the current radius.
+  // pass A: linearise at (poses, points), fill the slots, reduce into payload1 for the current radius.
   auto linearize = [&](double rad) {
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+    for (int l = 0; l < L; ++l) {
+      const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1], len = o1 - o0;
+      std::vector<double> R((size_t)len * 2), JC((size_t)len * 12, 0.0), JP((size_t)len * 6), WS((size_t)len * 18), YY((size_t)len * 18);
+      double V[9] = {0}, gp[3] = {0}, cost_l = 0.0;
+      for (int o = o0; o < o1; ++o) {
+        double* r = &R[2 * (o - o0)];
+        double* Jc = &JC[12 * (o - o0)];
+        double* Jp = &JP[6 * (o - o0)];
+        eval_obs(P, P.poses, P.points, o, r, P.op[o] > 0 ? Jc : nullptr, Jp);
+        cost_l += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+        for (int a = 0; a < 3; ++a) {
+          gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+          for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+        }
+      }
+      double* s = &sp[(size_t)l * 3];
+      if (!have_scale) for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + std::sqrt(V[4 * a]));
+      double Vd[9], gps[3], Vi[9] = {0};
+      for (int a = 0; a < 3; ++a) {
+        gps[a] = gp[a] * s[a];
+        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+      }
+      for (int a = 0; a < 3; ++a) Vd[4 * a] += std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad;
+      inv3_sym(Vd, Vi);
+      lmV[4 * (size_t)l] = cost_l;
+      lmV[4 * (size_t)l + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+      for (int o = o0; o < o1; ++o) {
+        if (P.op[o] <= 0) continue;
+        const double* r = &R[2 * (o - o0)];
+        const double* Jc = &JC[12 * (o - o0)];
+        const double* Jp = &JP[6 * (o - o0)];
+        double* Ws = &WS[18 * (o - o0)];
+        double* Y = &YY[18 * (o - o0)];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 3; ++b) Ws[3 * a + b] = (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
+        double* ov = &obsV[(size_t)o * 18];
+        for (int a = 0; a < 6; ++a) {
+          ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+          ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+          ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+        }
+      }
+      for (int i = o0; i < o1; ++i) {
+        if (P.op[i] <= 0) continue;
+        const double* Y = &YY[18 * (i - o0)];
+        const double* Jc = &JC[12 * (i - o0)];
+        for (int t = i; t < o1; ++t) {
+          if (P.op[t] <= 0) continue;
+          const double* Wt = &WS[18 * (t - o0)];
+          double* B = &pairB[(size_t)(pair_base[i] + (t - i)) * 36];
+          for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) {
+              const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+              B[6 * a + b] = t == i ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+            }
+        }
+      }
+    }
     std::fill(pay.begin(), pay.end(), 0.0);
     double* S = pay.data();
     double* gred = S + (size_t)n * n;
     double* gc = gred + n;
     double* dU = gc + n;
-    double cost = 0, gp2 = 0;
-#pragma omp parallel num_threads(num_threads)
-    {
-      std::vector<double> lp(pay1, 0.0);
-      double* lS = lp.data();
-      double* lgred = lS + (size_t)n * n;
-      double* lgc = lgred + n;
-      double* ldU = lgc + n;
-      double lcost = 0, lgp2 = 0;
-      std::vector<double> W;   // per obs 6x3
-      std::vector<int> Wk;
-#pragma omp for schedule(static)
-      for (int l = 0; l < L; ++l) {
-        const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
-        double V[9] = {0}, gp[3] = {0};
-        W.assign((size_t)(o1 - o0) * 18, 0.0);
-        Wk.assign(o1 - o0, -1);
-        for (int o = o0; o < o1; ++o) {
-          double r[2], Jc[12], Jp[6];
-          const int k = P.op[o];
-          eval_obs(P, P.poses, P.points, o, r, k > 0 ? Jc : nullptr, Jp);
-          lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-          for (int a = 0; a < 3; ++a) {
-            gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
-            for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
-          }
-          if (k > 0) {
-            const int base = 6 * (k - 1);
-            Wk[o - o0] = base;
-            double* Wo = &W[(size_t)(o - o0) * 18];
-            for (int a = 0; a < 6; ++a) {
-              lgc[base + a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
-              for (int b = 0; b < 3; ++b) Wo[3 * a + b] = Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b];
-              for (int b = 0; b < 6; ++b)
-                lS[(size_t)(base + a) * n + base + b] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
-              ldU[base + a] += Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
-            }
-          }
-        }
-        for (int a = 0; a < 3; ++a) lgp2 += gp[a] * gp[a];
-        double* s = &sp[(size_t)l * 3];
-        if (!have_scale) for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + std::sqrt(V[4 * a]));
-        // scale the point block
-        double Vd[9], gps[3];
-        for (int a = 0; a < 3; ++a) {
-          gps[a] = gp[a] * s[a];
-          for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
-        }
-        for (int a = 0; a < 3; ++a) Vd[4 * a] += std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad;
-        double Vi[9] = {0};
-        inv3_sym(Vd, Vi);
-        // Y_k = W_k s Vi ; S -= Y_k (W_k' s)^T ; gred -= Y_k gps
-        for (int oa = 0; oa < o1 - o0; ++oa) {
-          if (Wk[oa] < 0) continue;
-          double Y[18];
-          const double* Wa = &W[(size_t)oa * 18];
-          for (int a = 0; a < 6; ++a)
-            for (int b = 0; b < 3; ++b) {
-              double v = 0;
-              for (int c = 0; c < 3; ++c) v += Wa[3 * a + c] * s[c] * Vi[3 * c + b];
-              Y[3 * a + b] = v;
-            }
-          for (int a = 0; a < 6; ++a) {
-            double v = 0;
-            for (int b = 0; b < 3; ++b) v += Y[3 * a + b] * gps[b];
-            lgred[Wk[oa] + a] -= v;
-          }
-          for (int ob = 0; ob < o1 - o0; ++ob) {
-            if (Wk[ob] < 0) continue;
-            const double* Wb = &W[(size_t)ob * 18];
-            for (int a = 0; a < 6; ++a)
-              for (int b = 0; b < 6; ++b) {
-                double v = 0;
-                for (int c = 0; c < 3; ++c) v += Y[3 * a + c] * Wb[3 * b + c] * s[c];
-                lS[(size_t)(Wk[oa] + a) * n + Wk[ob] + b] -= v;
-              }
-          }
-        }
-      }
-#pragma omp critical
-      {
-        for (size_t i = 0; i < pay1; ++i) pay[i] += lp[i];
-        cost += lcost;
-        gp2 += lgp2;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+    for (int d = 0; d < F * F + F + 1; ++d) {
+      if (d < F * F) {
+        const std::vector<int>& lst = blk_list[d];
+        double B[36];
+        reduce_list((int)lst.size(), 36, [&](int e, double* out) {
+          const double* src = &pairB[(size_t)(lst[e] >> 1) * 36];
+          if (lst[e] & 1) { for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[6 * a + b] = src[6 * b + a]; }
+          else std::memcpy(out, src, 36 * sizeof(double));
+        }, B);
+        const int ka = d / F, kb = d % F;
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 6; ++b) S[(size_t)(6 * ka + a) * n + 6 * kb + b] = B[6 * a + b];
+      } else if (d < F * F + F) {
+        const int k = d - F * F;
+        const std::vector<int>& lst = pose_list[k];
+        double v[18];
+        reduce_list((int)lst.size(), 18, [&](int e, double* out) { std::memcpy(out, &obsV[(size_t)lst[e] * 18], 18 * sizeof(double)); }, v);
+        for (int a = 0; a < 6; ++a) { gc[6 * k + a] = v[a]; gred[6 * k + a] = v[6 + a]; dU[6 * k + a] = v[12 + a]; }
+      } else {
+        double v[2];
+        reduce_list(L, 2, [&](int e, double* out) { out[0] = lmV[4 * (size_t)e]; out[1] = lmV[4 * (size_t)e + 1]; }, v);
+        pay[pay1 - 2] = v[0];
+        pay[pay1 - 1] = v[1];
       }
     }
-    for (int a = 0; a < n; ++a) gred[a] += gc[a];
-    pay[pay1 - 2] = cost;
-    pay[pay1 - 1] = gp2;
     if (allreduce) allreduce(pay.data(), pay1, user);
   };
 
@@ -243,8 +289,7 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
       else plus_pose(P.poses + 7 * k, &dc[6 * (k - 1)], &cand_poses[7 * k]);
     }
     std::memcpy(cand_points.data(), P.points, sizeof(double) * 3 * n_points);
-    double mc = 0, dp2 = 0, p2 = 0;
-#pragma omp parallel for schedule(static) reduction(+ : mc, dp2, p2) num_threads(num_threads)
+#pragma omp parallel for schedule(static) num_threads(num_threads)
     for (int l = 0; l < L; ++l) {
       const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
       double V[9] = {0}, gp[3] = {0}, wd[3] = {0};
@@ -257,37 +302,38 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
           for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * dc[6 * (k - 1) + a]; jd[1] += Jc[6 + a] * dc[6 * (k - 1) + a]; }
         for (int a = 0; a < 3; ++a) {
           gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
-          wd[a] += Jp[a] * jd[0] + Jp[3 + a] * jd[1];  // W^T dc
+          wd[a] += Jp[a] * jd[0] + Jp[3 + a] * jd[1];
           for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
         }
       }
       const double* s = &sp[(size_t)l * 3];
-      double Vd[9], De[3], rh[3];
+      double Vd[9], De[3], rh[3], Vi[9] = {0};
       for (int a = 0; a < 3; ++a) {
         rh[a] = -(gp[a] + wd[a]) * s[a];
         for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
       }
       for (int a = 0; a < 3; ++a) { De[a] = std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad; Vd[4 * a] += De[a]; }
-      double Vi[9] = {0};
       inv3_sym(Vd, Vi);
+      const double* p0 = &P.points[3 * (size_t)P.lm_id[l]];
       double* pt = &cand_points[3 * (size_t)P.lm_id[l]];
+      double mc = 0, dp2 = 0, p2 = 0;
       for (int a = 0; a < 3; ++a) {
         const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
         mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
         const double d = y * s[a];
         dp2 += d * d;
-        p2 += pt[a] * pt[a];
-        pt[a] += d;
+        p2 += p0[a] * p0[a];
+        pt[a] = p0[a] + d;
       }
+      double cn = 0;
+      for (int o = o0; o < o1; ++o) {
+        double r[2];
+        eval_obs(P, cand_poses.data(), cand_points.data(), o, r, nullptr, nullptr);
+        cn += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+      }
+      lmV[4 * (size_t)l] = cn; lmV[4 * (size_t)l + 1] = mc; lmV[4 * (size_t)l + 2] = dp2; lmV[4 * (size_t)l + 3] = p2;
     }
-    double cn = 0;
-#pragma omp parallel for schedule(static) reduction(+ : cn) num_threads(num_threads)
-    for (int o = 0; o < n_obs; ++o) {
-      double r[2];
-      eval_obs(P, cand_poses.data(), cand_points.data(), o, r, nullptr, nullptr);
-      cn += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-    }
-    pay2[0] = cn; pay2[1] = mc; pay2[2] = dp2; pay2[3] = p2;
+    reduce_list(L, 4, [&](int e, double* out) { std::memcpy(out, &lmV[4 * (size_t)e], 4 * sizeof(double)); }, pay2);
     if (allreduce) allreduce(pay2, 4, user);
   };
 
@@ -319,7 +365,7 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
       Df[a] = std::min(std::max(dU[a] * sc[a] * sc[a], min_diag), max_diag) / radius;
       for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = S[(size_t)a * n + b] * sc[a] * sc[b];
       Sm[(size_t)a * n + a] += Df[a];
-      rhs[a] = -gred[a] * sc[a];
+      rhs[a] = -(gred[a] + gc[a]) * sc[a];
     }
     bool ok = n == 0 || cholesky_solve(Sm, rhs, n);
     bool step_ok = false;
@@ -358,6 +404,8 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
       break;
     }
     const double rho = cost_change / model_change;
+    if (std::getenv("SVO_BA_TRACE"))
+      std::fprintf(stderr, "[ora] it %d cost %.17g new %.17g model %.17g rho %.6g radius %.6g\n", iterations, cost, cost_new, model_change, rho, radius);
     if (rho > min_rel_decrease) {
       std::memcpy(P.poses, cand_poses.data(), sizeof(double) * 7 * n_poses);
       std::memcpy(P.points, cand_points.data(), sizeof(double) * 3 * n_points);

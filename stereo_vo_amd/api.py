@@ -61,6 +61,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 # every symbol include/svo.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_stream", "svo_sync", "svo_version",
+    "svo_profile_select", "svo_profile_read",
     "svo_reproj_eval", "svo_reproj_eval_dev",
     "svo_corner_detect", "svo_corner_detect_batch_dev", "svo_corner_response",
     "svo_stereo_bm", "svo_stereo_disparity_at", "svo_stereo_disparity_at_dev",
@@ -165,6 +166,14 @@ class Context:
 
     def sync(self):
         self._chk(self.L.svo_sync(self.h), "svo_sync")
+
+    def profile_select(self, kernel):
+        self._chk(self.L.svo_profile_select(self.h, kernel.encode() if kernel else None), "svo_profile_select")
+
+    def profile_read(self):
+        ms, n = C.c_double(0), C.c_int(0)
+        self._chk(self.L.svo_profile_read(self.h, C.byref(ms), C.byref(n)), "svo_profile_read")
+        return ms.value, n.value
 
     @property
     def stream(self):

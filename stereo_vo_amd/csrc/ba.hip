@@ -12,11 +12,21 @@
 //   ba_backsub_kernel   : recomputes the landmark blocks (cheaper than 144 B/observation of W traffic),
 //       back-substitutes the camera step, writes candidate points and evaluates the candidate cost in
 //       the same pass -> payload2 = [cost_new | model-change(points) | sum dp^2 | sum p^2].
+// Deterministic mode (window-sized problems, i.e. everything the pipeline solves): instead of LDS/global
+// atomics the kernels write per-pair 6x6 blocks, per-observation vectors and per-landmark scalars to
+// contribution slots, and ba_reduce1/2_kernel sum every destination with the DECLARED order
+// "256 strided partials, then binary tree" over its slot list in landmark order.  The oracle performs the
+// same sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is
+// bit-identical between CPU and GPU and independent of grid size.  (Needed because the reference's
+// problem has a scale gauge: with one fixed pose and only reprojection factors the iterates slide along
+// a flat direction and amplify any summation-order difference; measured 3e-2 pose drift otherwise.)
+// Problems whose pair slots would not fit (config 4) keep the atomic path and a tolerance-level result.
 // The n x n (n = 6 (K-1) <= 114) Cholesky, step control and termination run on the host from the
 // (all-reduced) payloads, so every rank of a sharded run takes identical decisions.
 // A rank of a sharded run holds all poses and its own landmarks; `allreduce` sums payload1/2 in place
 // on the device (RCCL all-reduce over xGMI) — the only exchange of the path.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <chrono>
@@ -46,6 +56,14 @@ struct BaDev {
   double* pay1 = nullptr;
   double* pay2 = nullptr;
   double f = 0, cx = 0, cy = 0;
+  // deterministic mode: contribution slots + destination lists
+  int det = 0;
+  int32_t* pair_base = nullptr;   // per observation: first pair slot (pairs (o, t>=o) of its landmark)
+  double* pairB = nullptr;        // n_pairs x 36
+  double* obsV = nullptr;         // M x 18  (g_c | g_red part | diag U)
+  double* lmV = nullptr;          // Npts x 4
+  int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1)
+  int32_t* list_entries = nullptr;
 };
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
@@ -94,7 +112,9 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
   double* sGred = sS + n * n;
   double* sGc = sGred + n;
   double* sDU = sGc + n;
-  for (int i = threadIdx.x; i < pay1; i += 256) lds[i] = 0.0;
+  if (!P.det) {
+    for (int i = threadIdx.x; i < pay1; i += 256) lds[i] = 0.0;
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double lcost = 0.0, lgp2 = 0.0;
@@ -115,6 +135,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
       eval_obs(P.poses + 7 * k, p, P.obs_uv[2 * o], P.obs_uv[2 * o + 1], P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
       lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
     }
+    const double my_cost = active ? 0.5 * (r[0] * r[0] + r[1] * r[1]) : 0.0;
+    double cost_l = 0.0;  // landmark cost, summed in observation order (deterministic mode)
     int maxlen = len;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
@@ -126,7 +148,9 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 #pragma unroll
       for (int i = 0; i < 6; ++i) q[i] = shfl_d(Jp[i], src);
       rr[0] = shfl_d(r[0], src); rr[1] = shfl_d(r[1], src);
+      const double ct = shfl_d(my_cost, src);
       if (t < len) {
+        cost_l += ct;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           gp[a] += q[a] * rr[0] + q[3 + a] * rr[1];
@@ -144,7 +168,10 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
       } else {
         s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
       }
-      if (lane == first) lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+      if (lane == first) {
+        lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+        if (P.det) { P.lmV[4 * (size_t)j] = cost_l; P.lmV[4 * (size_t)j + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
+      }
     }
     double Vd[9], Vi[9], gps[3];
 #pragma unroll
@@ -168,7 +195,16 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
-    if (freep) {
+    if (freep && P.det) {
+      double* ov = P.obsV + (size_t)o * 18;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+        ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+        ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+      }
+    }
+    if (freep && !P.det) {
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
@@ -186,16 +222,28 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 #pragma unroll
       for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
       if (freep && t < len && kt > 0 && src >= lane) {
-        const int bt = 6 * (kt - 1);
+        if (P.det) {
+          double* B = P.pairB + (size_t)(P.pair_base[o] + (src - lane)) * 36;
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+          for (int a = 0; a < 6; ++a)
 #pragma unroll
-          for (int b = 0; b < 6; ++b)
-            atomicAdd(&sS[(base + a) * n + bt + b],
-                      -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]));
+            for (int b = 0; b < 6; ++b) {
+              const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+              B[6 * a + b] = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+            }
+        } else {
+          const int bt = 6 * (kt - 1);
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = 0; b < 6; ++b)
+              atomicAdd(&sS[(base + a) * n + bt + b],
+                        -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]));
+        }
       }
     }
   }
+  if (P.det) return;  // sums are formed by ba_reduce1_kernel in the declared order
   // block totals of cost / gp2
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { lcost += __shfl_xor(lcost, off); lgp2 += __shfl_xor(lgp2, off); }
@@ -219,6 +267,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
     const bool active = o < c1;
     int k = 0, j = 0, first = lane, len = 0;
     double r[2] = {0, 0}, Jc[12], Jp[6], jd[2] = {0, 0}, u = 0, v = 0;
+    double det_c = 0.0, det_mc = 0.0, det_dp2 = 0.0, det_p2 = 0.0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
     D3 p{0, 0, 1};
@@ -284,8 +333,30 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
       double r0, r1;
       reproj_residual(P.cand_poses + 7 * k, D3{np[0], np[1], np[2]}, u, v, P.f, P.cx, P.cy, r0, r1);
       a_cost += 0.5 * (r0 * r0 + r1 * r1);
+      det_c = 0.5 * (r0 * r0 + r1 * r1);
+      det_mc = 0.0; det_dp2 = 0.0; det_p2 = 0.0;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
+        const double d = y * s[a];
+        det_mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
+        det_dp2 += d * d;
+        det_p2 += pv[a] * pv[a];
+      }
+    }
+    if (P.det) {  // candidate cost of the landmark in observation order, then the landmark's slot
+      double cn = 0.0;
+      for (int t = 0; t < maxlen; ++t) {
+        const double ct = shfl_d(det_c, (first + t) & 63);
+        if (t < len) cn += ct;
+      }
+      if (active && lane == first) {
+        double* lv = P.lmV + 4 * (size_t)j;
+        lv[0] = cn; lv[1] = det_mc; lv[2] = det_dp2; lv[3] = det_p2;
+      }
     }
   }
+  if (P.det) return;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     a_cost += __shfl_xor(a_cost, off); a_mc += __shfl_xor(a_mc, off);
@@ -294,6 +365,90 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
   if (lane == 0) { atomicAdd(&sAcc[0], a_cost); atomicAdd(&sAcc[1], a_mc); atomicAdd(&sAcc[2], a_dp2); atomicAdd(&sAcc[3], a_p2); }
   __syncthreads();
   if (threadIdx.x < 4) atomicAdd(&P.pay2[threadIdx.x], sAcc[threadIdx.x]);
+}
+
+// R(list) = 256 strided partials + binary tree (the declared order; see oracle/ora_ba.cpp).
+// One workgroup per destination: F*F pose-pair blocks (36 values), F pose vectors (18), 1 scalar pair.
+__global__ __launch_bounds__(256) void ba_reduce1_kernel(BaDev P) {
+  __shared__ double sP[256][37];
+  const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
+  double acc[36];
+#pragma unroll
+  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
+  int width;
+  if (d < F * F) {
+    width = 36;
+    const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
+    for (int e = e0 + tid; e < e1; e += 256) {
+      const int ent = P.list_entries[e];
+      const double* src = P.pairB + (size_t)(ent >> 1) * 36;
+      if (ent & 1) {
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) acc[6 * a + b] += src[6 * b + a];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 36; ++i) acc[i] += src[i];
+      }
+    }
+  } else if (d < F * F + F) {
+    width = 18;
+    const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
+    for (int e = e0 + tid; e < e1; e += 256) {
+      const double* src = P.obsV + (size_t)P.list_entries[e] * 18;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) acc[i] += src[i];
+    }
+  } else {
+    width = 2;
+    const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
+    for (int e = e0 + tid; e < e1; e += 256) {
+      const double* src = P.lmV + 4 * (size_t)P.list_entries[e];
+      acc[0] += src[0]; acc[1] += src[1];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 36; ++e) sP[tid][e] = acc[e];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s)
+      for (int e = 0; e < width; ++e) sP[tid][e] += sP[tid + s][e];
+    __syncthreads();
+  }
+  if (d < F * F) {
+    const int ka = d / F, kb = d % F;
+    if (tid < 36) P.pay1[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = sP[0][tid];
+  } else if (d < F * F + F) {
+    const int k = d - F * F;
+    if (tid < 6) {
+      P.pay1[(size_t)n * n + n + 6 * k + tid] = sP[0][tid];           // g_c
+      P.pay1[(size_t)n * n + 6 * k + tid] = sP[0][6 + tid];           // g_red (the -Y g_p part)
+      P.pay1[(size_t)n * n + 2 * n + 6 * k + tid] = sP[0][12 + tid];  // diag U
+    }
+  } else if (tid < 2) {
+    P.pay1[(size_t)n * n + 3 * n + tid] = sP[0][tid];
+  }
+}
+
+__global__ __launch_bounds__(256) void ba_reduce2_kernel(BaDev P) {
+  __shared__ double sP[256][4];
+  const int F = P.K - 1, tid = threadIdx.x;
+  const int d = F * F + F;  // the landmark list
+  double acc[4] = {0, 0, 0, 0};
+  const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
+  for (int e = e0 + tid; e < e1; e += 256) {
+    const double* src = P.lmV + 4 * (size_t)P.list_entries[e];
+    acc[0] += src[0]; acc[1] += src[1]; acc[2] += src[2]; acc[3] += src[3];
+  }
+  for (int e = 0; e < 4; ++e) sP[tid][e] = acc[e];
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s)
+      for (int e = 0; e < 4; ++e) sP[tid][e] += sP[tid + s][e];
+    __syncthreads();
+  }
+  if (tid < 4) P.pay2[tid] = sP[0][tid];
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -349,7 +504,7 @@ struct svo_ba {
   void* allreduce_user = nullptr;
   // device problem
   BaDev d;
-  size_t cap_points = 0, cap_obs = 0, cap_chunks = 0, cap_pay1 = 0;
+  size_t cap_points = 0, cap_obs = 0, cap_chunks = 0, cap_pay1 = 0, cap_pairs = 0, cap_list = 0;
   // host mirrors of the loaded problem
   std::vector<double> h_poses, h_cand_poses;
   int n_points = 0;
@@ -377,6 +532,7 @@ static int ba_alloc(svo_ba* ba) {
   A(d.obs_pose, int32_t, ba->cap_obs); A(d.obs_point, int32_t, ba->cap_obs); A(d.obs_uv, double, 2 * ba->cap_obs);
   A(d.lm_start, int32_t, ba->cap_points + 1); A(d.chunk_start, int32_t, ba->cap_chunks + 1);
   A(d.pay1, double, ba->cap_pay1); A(d.pay2, double, 4);
+  A(d.pair_base, int32_t, ba->cap_obs + 1); A(d.obsV, double, 18 * ba->cap_obs); A(d.lmV, double, 4 * ba->cap_points);
 #undef A
   ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 64 + 16 * (size_t)Kmax);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
@@ -418,7 +574,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (!ba) return;
   BaDev& d = ba->d;
   void* ptrs[] = {d.poses, d.cand_poses, d.dc, d.points, d.cand_points, d.sp, d.obs_pose, d.obs_point, d.obs_uv,
-                  d.lm_start, d.chunk_start, d.pay1, d.pay2};
+                  d.lm_start, d.chunk_start, d.pay1, d.pay2, d.pair_base, d.pairB, d.obsV, d.lmV, d.list_start, d.list_entries};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
@@ -464,6 +620,54 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   d.C = (int)chunks.size() - 1;
   d.L = npts;
   hipStream_t st = ctx->stream;
+  // deterministic mode: pair slots + destination lists (landmark order) if they fit
+  {
+    const int F = K - 1;
+    std::vector<int32_t> pair_base((size_t)M + 1, 0);
+    for (int j = 0; j < npts; ++j)
+      for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) pair_base[o + 1] = pair_base[o] + (lm_start[j + 1] - o);
+    const size_t n_pairs = (size_t)pair_base[M];
+    d.det = n_pairs <= ((size_t)1 << 21) ? 1 : 0;  // <= 604 MB of pair blocks
+    if (d.det) {
+      const int nd = F * F + F + 1;
+      std::vector<std::vector<int32_t>> lists(nd);
+      for (int j = 0; j < npts; ++j) {
+        if (lm_start[j + 1] > lm_start[j]) lists[F * F + F].push_back(j);
+        for (int i = lm_start[j]; i < lm_start[j + 1]; ++i) {
+          const int ki = op[i] - 1;
+          if (ki < 0) continue;
+          lists[F * F + ki].push_back(i);
+          for (int t = i; t < lm_start[j + 1]; ++t) {
+            const int kt = op[t] - 1;
+            if (kt < 0) continue;
+            const int slot = pair_base[i] + (t - i);
+            lists[ki * F + kt].push_back(slot * 2);
+            if (t != i) lists[kt * F + ki].push_back(slot * 2 + 1);
+          }
+        }
+      }
+      std::vector<int32_t> lstart(nd + 1, 0), lent;
+      for (int q = 0; q < nd; ++q) { lstart[q + 1] = lstart[q] + (int32_t)lists[q].size(); lent.insert(lent.end(), lists[q].begin(), lists[q].end()); }
+      if (n_pairs > ba->cap_pairs) {
+        if (d.pairB) (void)hipFree(d.pairB);
+        d.pairB = nullptr;
+        ba->cap_pairs = n_pairs + n_pairs / 4 + 1024;
+        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
+      }
+      if (lent.size() + nd + 2 > ba->cap_list) {
+        if (d.list_entries) (void)hipFree(d.list_entries);
+        if (d.list_start) (void)hipFree(d.list_start);
+        d.list_entries = d.list_start = nullptr;
+        ba->cap_list = lent.size() + lent.size() / 4 + 4096;
+        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.list_entries, sizeof(int32_t) * ba->cap_list));
+        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.list_start, sizeof(int32_t) * (64 * 64 + 64 + 8)));
+      }
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.pair_base, pair_base.data(), sizeof(int32_t) * (M + 1), hipMemcpyHostToDevice, st));
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.list_start, lstart.data(), sizeof(int32_t) * (nd + 1), hipMemcpyHostToDevice, st));
+      if (!lent.empty()) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.list_entries, lent.data(), sizeof(int32_t) * lent.size(), hipMemcpyHostToDevice, st));
+      SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
+  }
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
   ba->h_cand_poses = ba->h_poses;
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, poses7, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
@@ -494,7 +698,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   double* h_cp = h_dc + (n > 0 ? n : 1);
   const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
   const size_t lds_bytes = pay1 * sizeof(double);
-  if (lds_bytes > 64 * 1024) {
+  if (!d.det && lds_bytes > 64 * 1024) {
     SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
   std::vector<double> sc(n, 0.0), Sm((size_t)n * n), rhs(n), Df(n), Sfull((size_t)n * n);
@@ -506,8 +710,11 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   auto linearize = [&](double rad) -> int {
     d.points = cur_points; d.cand_points = cand_points;
     SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
-    if (d.C > 0)
-      hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, st, d, rad, have_scale ? 0 : 1);
+    if (d.C > 0) {
+      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE);
+      hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), d.det ? 64 : lds_bytes, st, d, rad, have_scale ? 0 : 1);
+    }
+    if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3((K - 1) * (K - 1) + (K - 1) + 1), dim3(256), 0, st, d);
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (ba->allreduce) {
       SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -522,7 +729,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         for (int i = 0; i < 6; ++i)
           for (int j = 0; j < 6; ++j) {
             const size_t ij = (size_t)(6 * a + i) * n + 6 * b + j, ji = (size_t)(6 * b + j) * n + 6 * a + i;
-            Sfull[ij] = a == b ? S[ij] : S[ij] + S[ji];
+            Sfull[ij] = (a == b || d.det) ? S[ij] : S[ij] + S[ji];
           }
     return SVO_OK;
   };
@@ -582,7 +789,11 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.cand_poses, h_cp, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
         SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay2, 0, sizeof(double) * 4, st));
         d.points = cur_points; d.cand_points = cand_points;
-        if (d.C > 0) hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
+        if (d.C > 0) {
+          SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB);
+          hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
+        }
+        if (d.det) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(256), 0, st, d);
         SVO_HIP_CHECK(ctx, hipGetLastError());
         if (ba->allreduce) {
           SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -615,6 +826,8 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         break;
       }
       const double rho = cost_change / model_change;
+      if (getenv("SVO_BA_TRACE"))
+        fprintf(stderr, "[hip] it %d cost %.17g new %.17g model %.17g rho %.6g radius %.6g\n", iterations, cost, cost_new, model_change, rho, radius);
       if (rho > MIN_REL_DECREASE) {
         accept();
         ++successful;

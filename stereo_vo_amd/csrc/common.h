@@ -33,6 +33,29 @@ struct svo_ctx {
   // pinned host mirror for small readbacks
   void* h_pinned = nullptr;
   size_t pinned_bytes = 0;
+  // per-kernel HIP-event timing (svo_profile_select / svo_profile_read)
+  int prof_tag = 0;
+  std::vector<hipEvent_t> prof_ev;  // start/stop pairs
+  int prof_used = 0;                // pairs recorded
+};
+
+enum SvoProfTag { SVO_PROF_NONE = 0, SVO_PROF_CORNER_RESPONSE, SVO_PROF_CORNER_NMS, SVO_PROF_CORNER_SELECT,
+                  SVO_PROF_PYR_DOWN, SVO_PROF_LK_FB, SVO_PROF_STEREO_AT, SVO_PROF_TRIANGULATE, SVO_PROF_PNP_HYP,
+                  SVO_PROF_PNP_REFINE, SVO_PROF_BA_LINEARIZE, SVO_PROF_BA_BACKSUB };
+
+// RAII event pair around one launch of the selected kernel (no-op for every other kernel).
+struct SvoProfScope {
+  svo_ctx* c;
+  int slot = -1;
+  SvoProfScope(svo_ctx* ctx, int tag) : c(ctx) {
+    if (ctx->prof_tag == tag && 2 * (ctx->prof_used + 1) <= (int)ctx->prof_ev.size()) {
+      slot = ctx->prof_used++;
+      (void)hipEventRecord(ctx->prof_ev[2 * slot], ctx->stream);
+    }
+  }
+  ~SvoProfScope() {
+    if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], c->stream);
+  }
 };
 
 #define SVO_HIP_CHECK(ctx, expr)                                                        \

@@ -311,17 +311,24 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned) * batch, st));
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * batch, st));
-  hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(W, TX), svo_div_up(H, TY), batch), dim3(256), 0, st,
-                     imgs, W, H, row_stride, image_stride, ctx->d_eig, ctx->d_maxkey);
+  {
+    SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
+    hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(W, TX), svo_div_up(H, TY), batch), dim3(256), 0, st,
+                       imgs, W, H, row_stride, image_stride, ctx->d_eig, ctx->d_maxkey);
+  }
+  {
+  SvoProfScope prof(ctx, SVO_PROF_CORNER_NMS);
   hipLaunchKernelGGL(corner_nms_kernel, dim3(svo_div_up(W, 64), svo_div_up(H, 4), batch), dim3(256), 0, st,
                      ctx->d_eig, W, H, ctx->d_maxkey, quality, ctx->d_cand, ctx->d_ncand, ctx->lim.max_candidates,
                      ctx->d_status);
+  }
   static bool attr_set = false;
   if (!attr_set) {
     SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)corner_select_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_BYTES));
     attr_set = true;
   }
+  SvoProfScope ps(ctx, SVO_PROF_CORNER_SELECT);
   hipLaunchKernelGGL(corner_select_kernel, dim3(batch), dim3(SEL_THREADS), SEL_LDS_BYTES, st, ctx->d_cand,
                      ctx->d_ncand, ctx->lim.max_candidates, W, H, (float)min_distance, max_corners,
                      ctx->d_cell_count, ctx->d_cell_start, ctx->max_cells, ctx->d_sorted, ctx->d_state, xy, n,

@@ -13,6 +13,41 @@ extern "C" int svo_sync(svo_ctx* ctx) {
   return SVO_OK;
 }
 
+extern "C" int svo_profile_select(svo_ctx* ctx, const char* kernel) {
+  if (!ctx) return SVO_ERR_INVALID;
+  static const char* names[] = {"", "corner_response", "corner_nms", "corner_select", "pyr_down", "lk_fb", "stereo_at",
+                                "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub"};
+  int tag = 0;
+  if (kernel && kernel[0]) {
+    tag = -1;
+    for (int i = 1; i < (int)(sizeof(names) / sizeof(names[0])); ++i)
+      if (!strcmp(kernel, names[i])) tag = i;
+    SVO_REQUIRE(ctx, tag > 0, "profile_select: unknown kernel name");
+  }
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (tag && ctx->prof_ev.empty()) {
+    ctx->prof_ev.resize(2 * 16384);
+    for (auto& e : ctx->prof_ev) SVO_HIP_CHECK(ctx, hipEventCreate(&e));
+  }
+  ctx->prof_tag = tag;
+  ctx->prof_used = 0;
+  return SVO_OK;
+}
+
+extern "C" int svo_profile_read(svo_ctx* ctx, double* total_ms, int* launches) {
+  if (!ctx || !total_ms || !launches) return SVO_ERR_INVALID;
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  for (int i = 0; i < ctx->prof_used; ++i) {
+    float ms = 0.f;
+    SVO_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[2 * i], ctx->prof_ev[2 * i + 1]));
+    tot += ms;
+  }
+  *total_ms = tot;
+  *launches = ctx->prof_used;
+  return SVO_OK;
+}
+
 extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
   if (!out || !lim) return SVO_ERR_INVALID;
   *out = nullptr;
@@ -67,6 +102,7 @@ extern "C" void svo_destroy(svo_ctx* c) {
                   c->d_cell_count, c->d_cell_start, c->d_status};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto& e : c->prof_ev) (void)hipEventDestroy(e);
   if (c->h_pinned) (void)hipHostFree(c->h_pinned);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;

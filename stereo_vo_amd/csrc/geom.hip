@@ -133,6 +133,7 @@ SvoMat4 svo_k_reprojection_matrix(const float* pose16, float focal, float cx, fl
 
 int svo_k_triangulate(svo_ctx* ctx, const float* xy, const float* disp, const int* n_dev, int n_max,
                       const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept) {
+  SvoProfScope prof(ctx, SVO_PROF_TRIANGULATE);
   hipLaunchKernelGGL(triangulate_kernel, dim3(1), dim3(CT), 0, ctx->stream, xy, disp, n_dev, n_max, M, kept_xy, xyz,
                      kept_index, n_kept);
   SVO_HIP_CHECK(ctx, hipGetLastError());

@@ -299,6 +299,7 @@ int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int
   for (int l = 1; l < LEVELS; ++l) {
     const size_t dst_off = src_off + (size_t)sw * sh;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    SvoProfScope prof(ctx, SVO_PROF_PYR_DOWN);
     hipLaunchKernelGGL(pyr_down_kernel, dim3(svo_div_up(dw, 64), svo_div_up(dh, 4), batch), dim3(256), 0, st, pyr, pyr_stride,
                        src_off, sw, sh, dst_off, dw, dh);
     src_off = dst_off; sw = dw; sh = dh;
@@ -318,9 +319,11 @@ int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int
 int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
                 const float* initial_xy, const int* n_dev, int n_max, float* fwd_xy, uint8_t* keep_flag, float* parallax,
                 float* kept_xy, int* kept_index, int* n_kept, float* av_parallax) {
-  if (n_max > 0)
+  if (n_max > 0) {
+    SvoProfScope prof(ctx, SVO_PROF_LK_FB);
     hipLaunchKernelGGL(lk_fb_kernel, dim3(n_max), dim3(64), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
                        n_max, fwd_xy, keep_flag, parallax);
+  }
   hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, fwd_xy, keep_flag, parallax, n_dev, n_max,
                      kept_xy, kept_index, n_kept, av_parallax);
   SVO_HIP_CHECK(ctx, hipGetLastError());

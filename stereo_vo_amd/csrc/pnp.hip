@@ -334,8 +334,11 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   if (!d_pose || !d_count || !d_mask || !d_out || !d_nin) { ctx->err = "pnp: workspace too small"; return SVO_ERR_CAPACITY; }
   hipStream_t st = ctx->stream;
   const double thr2 = (double)reproj_err * (double)reproj_err;
+  {
+  SvoProfScope prof(ctx, SVO_PROF_PNP_HYP);
   hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3(iterations), dim3(64), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf,
                      (double)cyf, P0, thr2, d_pose, d_count, d_mask, words);
+  }
   SVO_HIP_CHECK(ctx, hipGetLastError());
   int* h_count = (int*)ctx->h_pinned;
   if ((size_t)iterations * sizeof(int) + 64 > ctx->pinned_bytes) { ctx->err = "pnp: too many iterations"; return SVO_ERR_CAPACITY; }
@@ -349,8 +352,11 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
     }
   }
   if (best < 0) return SVO_OK;
+  {
+  SvoProfScope prof(ctx, SVO_PROF_PNP_REFINE);
   hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf, (double)cyf,
                      d_pose, d_mask, words, best, d_out, d_inliers, d_nin);
+  }
   SVO_HIP_CHECK(ctx, hipGetLastError());
   double* h_out = (double*)((char*)ctx->h_pinned + 4096);
   int* h_nin = (int*)((char*)ctx->h_pinned + 4096 + 64);

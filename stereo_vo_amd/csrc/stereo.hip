@@ -200,6 +200,7 @@ extern "C" int svo_stereo_disparity_at_dev(svo_ctx* ctx, const uint8_t* left, co
   if (rc) return rc;
   SVO_REQUIRE(ctx, n_max >= 0 && (n_max == 0 || (xy && disp)), "stereo_disparity_at: null buffer");
   if (n_max == 0) return SVO_OK;
+  SvoProfScope prof(ctx, SVO_PROF_STEREO_AT);
   hipLaunchKernelGGL(stereo_at_kernel, dim3(n_max), dim3(256), 0, ctx->stream, left, right, width, height, row_stride,
                      num_disparities, block_size, xy, n_dev, n_max, disp);
   SVO_HIP_CHECK(ctx, hipGetLastError());
