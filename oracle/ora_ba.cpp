@@ -12,9 +12,9 @@
 //
 // Declared summation order (what makes the HIP solver bit-identical to this one, and this one independent
 // of its thread count): every sum over observations of ONE landmark runs sequentially in observation
-// order; every sum ACROSS landmarks / observations / pose pairs is R(list) = "256 strided partials
-// (partial[t] = sequential sum of entries t, t+256, ...), then partial[t] += partial[t+s] for
-// s = 128..1" over the contribution list in landmark order.  Per pose pair the 6x6 Schur contribution of
+// order; every sum ACROSS landmarks / observations / pose pairs is R(list) = "28 consecutive
+// segments of ceil(len/28) entries, each summed sequentially, then the 28 segment sums added
+// sequentially" over the contribution list in landmark order.  Per pose pair the 6x6 Schur contribution of
 // observations i <= t of a landmark is B = -(Y_i (W_t s)^T) (+ J_c^T J_c when i == t); it enters block
 // (k_i,k_t) as B and, when i != t, block (k_t,k_i) as B^T.
 //
@@ -122,20 +122,26 @@ void plus_pose(const double* p, const double* d, double* out) {
 }  // namespace
 
 namespace {
-// R(list): the declared reduction. get(e, out) yields `width` doubles of list entry e.
+// R(list): the declared reduction.  The list is cut into 28 consecutive segments of ceil(len/28) entries;
+// each segment is summed sequentially, then the 28 segment sums are summed sequentially.
+// get(e, out) yields `width` doubles of list entry e.
 template <typename Get>
 void reduce_list(int count, int width, Get get, double* out) {
-  const int T = 256;
-  std::vector<double> part((size_t)T * width, 0.0), v(width);
-  for (int t = 0; t < T; ++t)
-    for (int e = t; e < count; e += T) {
+  const int S = 28;
+  const int seglen = (count + S - 1) / S;
+  std::vector<double> part((size_t)S * width, 0.0), v(width);
+  for (int sg = 0; sg < S; ++sg) {
+    const int e1 = std::min(count, (sg + 1) * seglen);
+    for (int e = sg * seglen; e < e1; ++e) {
       get(e, v.data());
-      for (int w = 0; w < width; ++w) part[(size_t)t * width + w] += v[w];
+      for (int w = 0; w < width; ++w) part[(size_t)sg * width + w] += v[w];
     }
-  for (int sft = T / 2; sft > 0; sft >>= 1)
-    for (int t = 0; t < sft; ++t)
-      for (int w = 0; w < width; ++w) part[(size_t)t * width + w] += part[(size_t)(t + sft) * width + w];
-  for (int w = 0; w < width; ++w) out[w] = part[w];
+  }
+  for (int w = 0; w < width; ++w) {
+    double acc = 0.0;
+    for (int sg = 0; sg < S; ++sg) acc += part[(size_t)sg * width + w];
+    out[w] = acc;
+  }
 }
 }  // namespace
 

@@ -74,12 +74,6 @@ double accumulate_range(const Pose& P, const float* xyz, const float* xy, const 
   return cost;
 }
 
-// sequential order (minimal 5-point sets)
-double accumulate(const Pose& P, const float* xyz, const float* xy, const int* idx, int m, double f,
-                  double cx, double cy, double* H, double* g) {
-  return accumulate_range(P, xyz, xy, idx, m, f, cx, cy, H, g, 0, 1);
-}
-
 // Declared reduction order for the refinement over all inliers (what the 256-thread HIP workgroup
 // does): partial[t] = sequential sum over k = t, t+256, ...; then partial[t] += partial[t+s] for
 // s = 128, 64, ..., 1.

@@ -15,7 +15,8 @@
 // Deterministic mode (window-sized problems, i.e. everything the pipeline solves): instead of LDS/global
 // atomics the kernels write per-pair 6x6 blocks, per-observation vectors and per-landmark scalars to
 // contribution slots, and ba_reduce1/2_kernel sum every destination with the DECLARED order
-// "256 strided partials, then binary tree" over its slot list in landmark order.  The oracle performs the
+// "28 consecutive segments of ceil(len/28) entries summed sequentially, then the 28 segment sums added
+// sequentially" over its slot list in landmark order (one lane per (segment, element)).  The oracle performs the
 // same sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is
 // bit-identical between CPU and GPU and independent of grid size.  (Needed because the reference's
 // problem has a scale gauge: with one fixed pose and only reprojection factors the iterates slide along
@@ -113,12 +114,13 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
   double* sGc = sGred + n;
   double* sDU = sGc + n;
   if (!P.det) {
-    for (int i = threadIdx.x; i < pay1; i += 256) lds[i] = 0.0;
+    for (int i = threadIdx.x; i < pay1; i += blockDim.x) lds[i] = 0.0;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double lcost = 0.0, lgp2 = 0.0;
-  for (int chunk = blockIdx.x * 4 + wave; chunk < P.C; chunk += gridDim.x * 4) {
+  const int wpb = blockDim.x >> 6;
+  for (int chunk = blockIdx.x * wpb + wave; chunk < P.C; chunk += gridDim.x * wpb) {
     const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
     const int o = c0 + lane;
     const bool active = o < c1;
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
   for (int off = 32; off > 0; off >>= 1) { lcost += __shfl_xor(lcost, off); lgp2 += __shfl_xor(lgp2, off); }
   if (lane == 0) { atomicAdd(&lds[pay1 - 2], lcost); atomicAdd(&lds[pay1 - 1], lgp2); }
   __syncthreads();
-  for (int i = threadIdx.x; i < pay1; i += 256) {
+  for (int i = threadIdx.x; i < pay1; i += blockDim.x) {
     const double v = lds[i];
     if (v != 0.0) atomicAdd(&P.pay1[i], v);
   }
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double a_cost = 0, a_mc = 0, a_dp2 = 0, a_p2 = 0;
-  for (int chunk = blockIdx.x * 4 + wave; chunk < P.C; chunk += gridDim.x * 4) {
+  const int wpb = blockDim.x >> 6;
+  for (int chunk = blockIdx.x * wpb + wave; chunk < P.C; chunk += gridDim.x * wpb) {
     const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
     const int o = c0 + lane;
     const bool active = o < c1;
@@ -367,88 +370,86 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
   if (threadIdx.x < 4) atomicAdd(&P.pay2[threadIdx.x], sAcc[threadIdx.x]);
 }
 
-// R(list) = 256 strided partials + binary tree (the declared order; see oracle/ora_ba.cpp).
-// One workgroup per destination: F*F pose-pair blocks (36 values), F pose vectors (18), 1 scalar pair.
-__global__ __launch_bounds__(256) void ba_reduce1_kernel(BaDev P) {
-  __shared__ double sP[256][37];
+// R(list): 28 consecutive segments summed sequentially, then the segment sums added sequentially
+// (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: F*F pose-pair blocks
+// (36 values), F pose vectors (18 values), 1 scalar pair; lane = (segment, element).
+constexpr int RSEG = 28;
+__global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) {
+  __shared__ double sP[RSEG][36];
   const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
-  double acc[36];
+  const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
+  const int seg = tid / width, e = tid % width;
+  const int e0 = P.list_start[d], len = P.list_start[d + 1] - e0;
+  const int seglen = (len + RSEG - 1) / RSEG;
+  if (seg < RSEG) {
+    double acc = 0.0;
+    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+    // 8 entries' loads are issued before their (strictly ordered) adds: the loop is latency-bound otherwise
+    const int et = (e % 6) * 6 + e / 6;  // transposed element (pair blocks)
+    for (int q0 = b0; q0 < b1; q0 += 8) {
+      double v[8];
 #pragma unroll
-  for (int e = 0; e < 36; ++e) acc[e] = 0.0;
-  int width;
-  if (d < F * F) {
-    width = 36;
-    const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
-    for (int e = e0 + tid; e < e1; e += 256) {
-      const int ent = P.list_entries[e];
-      const double* src = P.pairB + (size_t)(ent >> 1) * 36;
-      if (ent & 1) {
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < 6; ++b) acc[6 * a + b] += src[6 * b + a];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) acc[i] += src[i];
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u;
+        double val = 0.0;
+        if (q < b1) {
+          const int ent = P.list_entries[e0 + q];
+          if (d < F * F) val = P.pairB[(size_t)(ent >> 1) * 36 + ((ent & 1) ? et : e)];
+          else if (d < F * F + F) val = P.obsV[(size_t)ent * 18 + e];
+          else val = P.lmV[4 * (size_t)ent + e];
+        }
+        v[u] = val;
       }
-    }
-  } else if (d < F * F + F) {
-    width = 18;
-    const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
-    for (int e = e0 + tid; e < e1; e += 256) {
-      const double* src = P.obsV + (size_t)P.list_entries[e] * 18;
 #pragma unroll
-      for (int i = 0; i < 18; ++i) acc[i] += src[i];
+      for (int u = 0; u < 8; ++u)
+        if (q0 + u < b1) acc += v[u];
     }
-  } else {
-    width = 2;
-    const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
-    for (int e = e0 + tid; e < e1; e += 256) {
-      const double* src = P.lmV + 4 * (size_t)P.list_entries[e];
-      acc[0] += src[0]; acc[1] += src[1];
-    }
+    sP[seg][e] = acc;
   }
-#pragma unroll
-  for (int e = 0; e < 36; ++e) sP[tid][e] = acc[e];
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s)
-      for (int e = 0; e < width; ++e) sP[tid][e] += sP[tid + s][e];
-    __syncthreads();
-  }
-  if (d < F * F) {
-    const int ka = d / F, kb = d % F;
-    if (tid < 36) P.pay1[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = sP[0][tid];
-  } else if (d < F * F + F) {
-    const int k = d - F * F;
-    if (tid < 6) {
-      P.pay1[(size_t)n * n + n + 6 * k + tid] = sP[0][tid];           // g_c
-      P.pay1[(size_t)n * n + 6 * k + tid] = sP[0][6 + tid];           // g_red (the -Y g_p part)
-      P.pay1[(size_t)n * n + 2 * n + 6 * k + tid] = sP[0][12 + tid];  // diag U
+  if (tid < width) {
+    double acc = 0.0;
+    for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
+    if (d < F * F) {
+      const int ka = d / F, kb = d % F;
+      P.pay1[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
+    } else if (d < F * F + F) {
+      const int k = d - F * F;
+      if (tid < 6) P.pay1[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
+      else if (tid < 12) P.pay1[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
+      else P.pay1[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
+    } else {
+      P.pay1[(size_t)n * n + 3 * n + tid] = acc;
     }
-  } else if (tid < 2) {
-    P.pay1[(size_t)n * n + 3 * n + tid] = sP[0][tid];
   }
 }
 
-__global__ __launch_bounds__(256) void ba_reduce2_kernel(BaDev P) {
-  __shared__ double sP[256][4];
+__global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) {
+  __shared__ double sP[RSEG][4];
   const int F = P.K - 1, tid = threadIdx.x;
   const int d = F * F + F;  // the landmark list
-  double acc[4] = {0, 0, 0, 0};
-  const int e0 = P.list_start[d], e1 = P.list_start[d + 1];
-  for (int e = e0 + tid; e < e1; e += 256) {
-    const double* src = P.lmV + 4 * (size_t)P.list_entries[e];
-    acc[0] += src[0]; acc[1] += src[1]; acc[2] += src[2]; acc[3] += src[3];
+  const int seg = tid / 4, e = tid % 4;
+  const int e0 = P.list_start[d], len = P.list_start[d + 1] - e0;
+  const int seglen = (len + RSEG - 1) / RSEG;
+  if (seg < RSEG) {
+    double acc = 0.0;
+    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+    for (int q0 = b0; q0 < b1; q0 += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? P.lmV[4 * (size_t)P.list_entries[e0 + q0 + u] + e] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (q0 + u < b1) acc += v[u];
+    }
+    sP[seg][e] = acc;
   }
-  for (int e = 0; e < 4; ++e) sP[tid][e] = acc[e];
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s)
-      for (int e = 0; e < 4; ++e) sP[tid][e] += sP[tid + s][e];
-    __syncthreads();
+  if (tid < 4) {
+    double acc = 0.0;
+    for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
+    P.pay2[tid] = acc;
   }
-  if (tid < 4) P.pay2[tid] = sP[0][tid];
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -508,6 +509,7 @@ struct svo_ba {
   // host mirrors of the loaded problem
   std::vector<double> h_poses, h_cand_poses;
   int n_points = 0;
+  double* step_buf[2] = {nullptr, nullptr};
   double* h_pin = nullptr;  // pinned staging: payload1 / payload2 / dc / poses
   size_t pin_bytes = 0;
   // sliding-window graph (BundleAdjuster state, host side; ids sequential — SURVEY C-3)
@@ -526,7 +528,8 @@ static int ba_alloc(svo_ba* ba) {
   ba->cap_points = ba->max_landmarks; ba->cap_obs = ba->max_obs; ba->cap_chunks = ba->max_obs + 1;
   ba->cap_pay1 = (size_t)nmax * nmax + 3 * (size_t)nmax + 2;
 #define A(ptr, T, cnt) SVO_HIP_CHECK(ctx, hipMalloc((void**)&(ptr), sizeof(T) * (size_t)(cnt)))
-  A(d.poses, double, 7 * Kmax); A(d.cand_poses, double, 7 * Kmax); A(d.dc, double, nmax > 0 ? nmax : 1);
+  // two [dc | poses] step buffers: the candidate of an accepted step becomes the linearisation point by a pointer swap
+  A(ba->step_buf[0], double, (nmax > 0 ? nmax : 1) + 7 * Kmax); A(ba->step_buf[1], double, (nmax > 0 ? nmax : 1) + 7 * Kmax);
   A(d.points, double, 3 * ba->cap_points); A(d.cand_points, double, 3 * ba->cap_points);
   A(d.sp, double, 3 * ba->cap_points);
   A(d.obs_pose, int32_t, ba->cap_obs); A(d.obs_point, int32_t, ba->cap_obs); A(d.obs_uv, double, 2 * ba->cap_obs);
@@ -573,7 +576,7 @@ extern "C" int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const 
 extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (!ba) return;
   BaDev& d = ba->d;
-  void* ptrs[] = {d.poses, d.cand_poses, d.dc, d.points, d.cand_points, d.sp, d.obs_pose, d.obs_point, d.obs_uv,
+  void* ptrs[] = {ba->step_buf[0], ba->step_buf[1], d.points, d.cand_points, d.sp, d.obs_pose, d.obs_point, d.obs_uv,
                   d.lm_start, d.chunk_start, d.pay1, d.pay2, d.pair_base, d.pairB, d.obsV, d.lmV, d.list_start, d.list_entries};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -670,6 +673,9 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   }
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
   ba->h_cand_poses = ba->h_poses;
+  d.poses = ba->step_buf[0] + (d.n > 0 ? d.n : 1);
+  d.cand_poses = ba->step_buf[1] + (d.n > 0 ? d.n : 1);
+  d.dc = ba->step_buf[1];
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, poses7, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
   if (npts) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.points, points3, sizeof(double) * 3 * npts, hipMemcpyHostToDevice, st));
   if (npts) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.cand_points, points3, sizeof(double) * 3 * npts, hipMemcpyHostToDevice, st));
@@ -695,7 +701,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   double* h_pay1 = ba->h_pin;
   double* h_pay2 = h_pay1 + pay1;
   double* h_dc = h_pay2 + 8;
-  double* h_cp = h_dc + (n > 0 ? n : 1);
+  double* h_cp = h_dc + (n > 0 ? n : 1);  // contiguous with h_dc: one H2D per iteration
   const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
   const size_t lds_bytes = pay1 * sizeof(double);
   if (!d.det && lds_bytes > 64 * 1024) {
@@ -706,15 +712,18 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   double radius = ba->opt.initial_radius, decrease_factor = 2.0;
   double* cur_points = d.points;
   double* cand_points = d.cand_points;
+  double* cur_poses = d.poses;
+  double* cand_poses = d.cand_poses;
 
   auto linearize = [&](double rad) -> int {
-    d.points = cur_points; d.cand_points = cand_points;
-    SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
+    d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
+    if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE);
-      hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), d.det ? 64 : lds_bytes, st, d, rad, have_scale ? 0 : 1);
+      if (d.det) hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, rad, have_scale ? 0 : 1);  // one wave per workgroup: spreads the chunks over the CUs
+      else hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, st, d, rad, have_scale ? 0 : 1);
     }
-    if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3((K - 1) * (K - 1) + (K - 1) + 1), dim3(256), 0, st, d);
+    if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3((K - 1) * (K - 1) + (K - 1) + 1), dim3(1024), 0, st, d);
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (ba->allreduce) {
       SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -785,15 +794,17 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
           else plus_pose(&ba->h_poses[7 * k], &h_dc[6 * (k - 1)], &ba->h_cand_poses[7 * k]);
         }
         memcpy(h_cp, ba->h_cand_poses.data(), sizeof(double) * 7 * K);
-        if (n) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.dc, h_dc, sizeof(double) * n, hipMemcpyHostToDevice, st));
-        SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.cand_poses, h_cp, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
-        SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay2, 0, sizeof(double) * 4, st));
+        // one H2D: [dc (n) | candidate poses (7K)] are adjacent both in the pinned buffer and on the device
+        d.poses = cur_poses; d.cand_poses = cand_poses; d.dc = cand_poses - (n > 0 ? n : 1);
+        SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.dc, h_dc, sizeof(double) * ((n > 0 ? n : 1) + 7 * K), hipMemcpyHostToDevice, st));
+        if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay2, 0, sizeof(double) * 4, st));
         d.points = cur_points; d.cand_points = cand_points;
         if (d.C > 0) {
           SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB);
-          hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
+          if (d.det) hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.C), dim3(64), 0, st, d, radius);
+          else hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
         }
-        if (d.det) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(256), 0, st, d);
+        if (d.det) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(128), 0, st, d);
         SVO_HIP_CHECK(ctx, hipGetLastError());
         if (ba->allreduce) {
           SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -816,6 +827,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
       auto accept = [&]() {
         ba->h_poses = ba->h_cand_poses;
         std::swap(cur_points, cand_points);
+        std::swap(cur_poses, cand_poses);  // the candidate poses are already on the device
         cost = cost_new;
       };
       if (sqrt(step2) <= ba->opt.parameter_tolerance * (sqrt(x2) + ba->opt.parameter_tolerance)) { termination = 0; break; }
@@ -835,8 +847,6 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
         radius = std::min(MAX_RADIUS, radius);
         decrease_factor = 2.0;
-        // the accepted points must also seed the next candidate buffer for landmarks the kernel skips
-        SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, ba->h_poses.data(), sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
         rc = linearize(radius);
         if (rc) return rc;
         if (gradient_norm() <= ba->opt.gradient_tolerance) { termination = 0; break; }
@@ -845,12 +855,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
       }
     }
   // leave the result in d.points / d.poses
-  if (cur_points != d.points || true) {
-    d.points = cur_points; d.cand_points = cand_points;
-    // keep canonical buffer order: copy into the first buffer if the result sits in the second
-  }
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, ba->h_poses.data(), sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
   if (sum) {
     sum->iterations = iterations; sum->successful_steps = successful; sum->termination = termination;
     sum->initial_cost = initial_cost; sum->final_cost = cost;

@@ -24,6 +24,7 @@ constexpr int TX = 64, TY = 16;          // output tile of the response kernel
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAX_ACCEPT = 16384;    // accepted corners held in LDS for the final sort
 constexpr int SEL_LDS_BYTES = SEL_MAX_ACCEPT * 8;
+constexpr int NC_STRIDE = 32;            // per-image candidate counters live on separate 128-B lines
 
 __device__ __forceinline__ unsigned f32_key(float v) {
   const unsigned b = __float_as_uint(v);
@@ -122,25 +123,41 @@ __global__ __launch_bounds__(256) void corner_nms_kernel(const float* __restrict
   const float thr = (float)((double)maxv * quality);
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
   const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (x < 1 || x > W - 2 || y < 1 || y > H - 2) return;
-  const float c = E[(size_t)y * W + x];
-  const float v = c > thr ? c : 0.0f;
-  if (v == 0.0f) return;
-  float m = v;
+  __shared__ int sCount, sBase;
+  if (threadIdx.x == 0) sCount = 0;
+  __syncthreads();
+  bool is_cand = false;
+  float v = 0.f;
+  if (!(x < 1 || x > W - 2 || y < 1 || y > H - 2)) {
+    const float c = E[(size_t)y * W + x];
+    v = c > thr ? c : 0.0f;
+    if (v != 0.0f) {
+      float m = v;
 #pragma unroll
-  for (int j = -1; j <= 1; ++j)
+      for (int j = -1; j <= 1; ++j)
 #pragma unroll
-    for (int i = -1; i <= 1; ++i) {
-      const float nv = E[(size_t)(y + j) * W + (x + i)];
-      const float t = nv > thr ? nv : 0.0f;
-      m = t > m ? t : m;
+        for (int i = -1; i <= 1; ++i) {
+          const float nv = E[(size_t)(y + j) * W + (x + i)];
+          const float t = nv > thr ? nv : 0.0f;
+          m = t > m ? t : m;
+        }
+      is_cand = v == m;
     }
-  if (v != m) return;
-  const int pos = atomicAdd(&ncand[b], 1);
-  if (pos < cap)
-    cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(v) << 32) | (unsigned)(y * W + x);
-  else
-    atomicOr(status, 1);
+  }
+  // one global atomic per workgroup that has candidates (a per-thread returning atomic on one word
+  // serialises at ~88/us: measured 550 us for 16 frames before this change)
+  int local = 0;
+  if (is_cand) local = atomicAdd(&sCount, 1);
+  __syncthreads();
+  if (threadIdx.x == 0 && sCount > 0) sBase = atomicAdd(&ncand[b * NC_STRIDE], sCount);
+  __syncthreads();
+  if (is_cand) {
+    const int pos = sBase + local;
+    if (pos < cap)
+      cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(v) << 32) | (unsigned)(y * W + x);
+    else
+      atomicOr(status, 1);
+  }
 }
 
 // One workgroup per image.  All cross-wave global traffic uses L2-scope (sc1) loads/stores.
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   __shared__ int sFlag, sCount;
   const int b = blockIdx.x, tid = threadIdx.x;
   const unsigned long long* C = cand + (size_t)b * cap;
-  int n = ncand[b];
+  int n = ncand[b * NC_STRIDE];
   if (n > cap) n = cap;
   float* oxy = out_xy + (size_t)b * max_corners * 2;
   if (min_distance < 1.0f) {
@@ -310,7 +327,7 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
                          float* xy, int* n) {
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned) * batch, st));
-  SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * batch, st));
+  SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * NC_STRIDE * batch, st));
   {
     SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
     hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(W, TX), svo_div_up(H, TY), batch), dim3(256), 0, st,

@@ -82,7 +82,7 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
   ALLOC(c->d_cand, B * c->lim.max_candidates * sizeof(unsigned long long));
   ALLOC(c->d_sorted, B * c->lim.max_candidates * sizeof(unsigned long long));
   ALLOC(c->d_state, B * c->lim.max_candidates);
-  ALLOC(c->d_ncand, B * sizeof(int));
+  ALLOC(c->d_ncand, B * 32 * sizeof(int));  // one 128-B line per image (corner.hip NC_STRIDE)
   ALLOC(c->d_cell_count, B * (size_t)c->max_cells * sizeof(int));
   ALLOC(c->d_cell_start, B * ((size_t)c->max_cells + 1) * sizeof(int));
   ALLOC(c->d_status, 64);

@@ -62,28 +62,41 @@ __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict
   if (threadIdx.x == 0) *n_kept = base;
 }
 
-__global__ __launch_bounds__(CT) void dedup_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
-                                                   int n_det_host, const float* __restrict__ trk,
-                                                   const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
-                                                   float* __restrict__ kept_xy, int* __restrict__ n_kept) {
-  __shared__ int sWave[CT / 64];
+// one wavefront per detected corner: 64 tracked features are tested per step, any hit drops the corner
+__global__ __launch_bounds__(256) void dedup_flag_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
+                                                         int n_det_host, const float* __restrict__ trk,
+                                                         const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
+                                                         uint8_t* __restrict__ keep) {
   const int nd = n_det_dev ? *n_det_dev : n_det_host;
   const int nt = n_trk_dev ? *n_trk_dev : n_trk_host;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= nd) return;
+  const float x = det[2 * i], y = det[2 * i + 1];
+  bool hit = false;
+  for (int j0 = 0; j0 < nt && !hit; j0 += 64) {
+    const int j = j0 + lane;
+    bool h = false;
+    if (j < nt) {
+      const float dx = x - trk[2 * j], dy = y - trk[2 * j + 1];
+      h = sqrtf(dx * dx + dy * dy) < min_d;  // src/image_processor.cpp:118-123
+    }
+    hit = __any(h);
+  }
+  if (lane == 0) keep[i] = hit ? 0 : 1;
+}
+
+__global__ __launch_bounds__(CT) void dedup_compact_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
+                                                           int n_det_host, const uint8_t* __restrict__ keepf,
+                                                           float* __restrict__ kept_xy, int* __restrict__ n_kept) {
+  __shared__ int sWave[CT / 64];
+  const int nd = n_det_dev ? *n_det_dev : n_det_host;
   int base = 0;
   for (int c0 = 0; c0 < nd; c0 += CT) {
     const int i = c0 + threadIdx.x;
-    bool keep = false;
-    float x = 0.f, y = 0.f;
-    if (i < nd) {
-      x = det[2 * i]; y = det[2 * i + 1];
-      keep = true;
-      for (int j = 0; j < nt; ++j) {
-        const float dx = x - trk[2 * j], dy = y - trk[2 * j + 1];
-        if (sqrtf(dx * dx + dy * dy) < min_d) { keep = false; break; }  // src/image_processor.cpp:118-123
-      }
-    }
+    const bool keep = i < nd && keepf[i];
     const int slot = compact_slot(keep, base, sWave);
-    if (slot >= 0) { kept_xy[2 * slot] = x; kept_xy[2 * slot + 1] = y; }
+    if (slot >= 0) { kept_xy[2 * slot] = det[2 * i]; kept_xy[2 * slot + 1] = det[2 * i + 1]; }
   }
   if (threadIdx.x == 0) *n_kept = base;
 }
@@ -142,8 +155,13 @@ int svo_k_triangulate(svo_ctx* ctx, const float* xy, const float* disp, const in
 
 int svo_k_dedup(svo_ctx* ctx, const float* det_xy, const int* n_det_dev, int n_det_max, const float* trk_xy,
                 const int* n_trk_dev, int n_trk_max, float min_distance, float* kept_xy, int* n_kept) {
-  hipLaunchKernelGGL(dedup_kernel, dim3(1), dim3(CT), 0, ctx->stream, det_xy, n_det_dev, n_det_max, trk_xy, n_trk_dev,
-                     n_trk_max, min_distance, kept_xy, n_kept);
+  if (n_det_max > ctx->lim.max_batch * ctx->lim.max_candidates) { ctx->err = "dedup: too many detected corners"; return SVO_ERR_CAPACITY; }
+  uint8_t* flags = ctx->d_state;  // scratch (the corner-select state array is idle here)
+  if (n_det_max > 0)
+    hipLaunchKernelGGL(dedup_flag_kernel, dim3(svo_div_up(n_det_max, 4)), dim3(256), 0, ctx->stream, det_xy, n_det_dev,
+                       n_det_max, trk_xy, n_trk_dev, n_trk_max, min_distance, flags);
+  hipLaunchKernelGGL(dedup_compact_kernel, dim3(1), dim3(CT), 0, ctx->stream, det_xy, n_det_dev, n_det_max, flags, kept_xy,
+                     n_kept);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -6,7 +6,9 @@
 // f32 2x2 solve without FMA contraction).
 //
 //   pyr_copy_kernel / pyr_down_kernel : 4-level pyramid, [1 4 6 4 1]^2, REFLECT_101, (s+128)>>8.
-//   lk_fb_kernel  : one wavefront (64 lanes) per feature.  Per level the 24x24 source patch is staged in
+//   lk_fb_kernel  : one wavefront (64 lanes) per feature.  Per level the 24x24 source patch and a 32x32
+//                   region of the target image are staged in LDS once (the region is restaged only if the
+//                   window walks out of it, so iterations run barrier-free out of LDS); source patch in
 //                   LDS, Scharr derivatives are formed on the fly (no derivative image ever hits HBM),
 //                   the 21x21 int16 template/gradient patches live in LDS, the 2x2 normal matrix and the
 //                   per-iteration mismatch vector are wave-reduced with DPP shuffles.  Forward and
@@ -40,15 +42,30 @@ __device__ __forceinline__ Pyr make_pyr(const uint8_t* base, int w, int h) {
 
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+// Exact wave-wide integer sum without LDS traffic: DPP quad/row permutes inside each 16-lane row, then
+// the four row totals are read with v_readlane.  Integer addition is associative, so the result does not
+// depend on the order (this is what lets the oracle use a plain sequential int64 sum).
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);  // row_mirror
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
 }
+// per-lane partial (|v| < 2^31) -> exact 64-bit wave total via a 16-bit split (both halves stay in int32)
+__device__ __forceinline__ long long wave_sum_split(int v) {
+  const int lo = wave_sum_i32(v & 0xFFFF);
+  const int hi = wave_sum_i32(v >> 16);
+  return (long long)hi * 65536 + (long long)lo;
+}
+
+constexpr int RM = 5;            // margin of the staged target region around the 22x22 window
+constexpr int RS = G + 2 * RM;   // 32
 
 struct LkShared {
   uint8_t raw[RP * RP];      // source patch of the template image (reflect-101 staged)
-  uint8_t jraw[G * G + 4];   // per-iteration patch of the target image
+  uint8_t jreg[RS * RS];     // target-image region; restaged only when the window leaves it
   short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
   short gx[G * G], gy[G * G];
 };
@@ -102,7 +119,7 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       S.gx[i] = (short)vx; S.gy[i] = (short)vy;
     }
     __syncthreads();
-    long long sA11 = 0, sA12 = 0, sA22 = 0;
+    int pA11 = 0, pA12 = 0, pA22 = 0;  // <= 7 pixels per lane, each product < 2^24.1: fits int32
     for (int i = lane; i < WIN * WIN; i += 64) {
       const int r = i / WIN, c = i % WIN;
       const int o = r * G + c, o1 = o + G;
@@ -111,11 +128,11 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       const int ixv = descale(S.gx[o] * iw00 + S.gx[o + 1] * iw01 + S.gx[o1] * iw10 + S.gx[o1 + 1] * iw11, 14);
       const int iyv = descale(S.gy[o] * iw00 + S.gy[o + 1] * iw01 + S.gy[o1] * iw10 + S.gy[o1 + 1] * iw11, 14);
       S.Iw[i] = (short)ival; S.dIx[i] = (short)ixv; S.dIy[i] = (short)iyv;
-      sA11 += (long long)(ixv * ixv);
-      sA12 += (long long)(ixv * iyv);
-      sA22 += (long long)(iyv * iyv);
+      pA11 += ixv * ixv;
+      pA12 += ixv * iyv;
+      pA22 += iyv * iyv;
     }
-    sA11 = wave_sum_i64(sA11); sA12 = wave_sum_i64(sA12); sA22 = wave_sum_i64(sA22);
+    const long long sA11 = wave_sum_split(pA11), sA12 = wave_sum_split(pA12), sA22 = wave_sum_split(pA22);
     const float A11 = (float)(double)sA11 * FLT_SCALE;
     const float A12 = (float)(double)sA12 * FLT_SCALE;
     const float A22 = (float)(double)sA22 * FLT_SCALE;
@@ -130,6 +147,17 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
     float outx = nx, outy = ny;
     nx -= (float)HALF; ny -= (float)HALF;
     float pdx = 0.f, pdy = 0.f;
+    // window-pixel offsets of this lane inside the staged region (7 pixels per lane, fixed for the level)
+    int woff[7], wi[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int i = lane + 64 * u;
+      wi[u] = i < WIN * WIN ? i : -1;
+      woff[u] = i < WIN * WIN ? (i / WIN) * RS + (i % WIN) : 0;
+    }
+    int rx0 = 0, ry0 = 0;
+    bool staged = false;
+    __syncthreads();  // Iw/dIx/dIy visible to every lane
     for (int j = 0; j < MAX_ITER; ++j) {
       const int inx = (int)floorf(nx), iny = (int)floorf(ny);
       if (inx < -WIN || inx >= Jw_ || iny < -WIN || iny >= Jh_) {
@@ -141,21 +169,30 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
       iw10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
       iw11 = (1 << 14) - iw00 - iw01 - iw10;
-      __syncthreads();
-      for (int i = lane; i < G * G; i += 64) {
-        const int r = i / G, c = i % G;
-        S.jraw[i] = Jp[(size_t)reflect101(iny + r, Jh_) * Jw_ + reflect101(inx + c, Jw_)];
+      if (!staged || inx < rx0 || inx > rx0 + 2 * RM || iny < ry0 || iny > ry0 + 2 * RM) {  // wave-uniform
+        rx0 = inx - RM; ry0 = iny - RM;
+        __syncthreads();
+        if (rx0 >= 0 && ry0 >= 0 && rx0 + RS <= Jw_ && ry0 + RS <= Jh_) {
+          for (int i = lane; i < RS * RS; i += 64) S.jreg[i] = Jp[(size_t)(ry0 + i / RS) * Jw_ + rx0 + i % RS];
+        } else {
+          for (int i = lane; i < RS * RS; i += 64)
+            S.jreg[i] = Jp[(size_t)reflect101(ry0 + i / RS, Jh_) * Jw_ + reflect101(rx0 + i % RS, Jw_)];
+        }
+        __syncthreads();
+        staged = true;
       }
-      __syncthreads();
-      long long sb1 = 0, sb2 = 0;
-      for (int i = lane; i < WIN * WIN; i += 64) {
-        const int r = i / WIN, c = i % WIN;
-        const int o = r * G + c;
-        const int diff = descale(S.jraw[o] * iw00 + S.jraw[o + 1] * iw01 + S.jraw[o + G] * iw10 + S.jraw[o + G + 1] * iw11, 9) - S.Iw[i];
-        sb1 += (long long)(diff * S.dIx[i]);
-        sb2 += (long long)(diff * S.dIy[i]);
+      const int ob = (iny - ry0) * RS + (inx - rx0);
+      int pb1 = 0, pb2 = 0;
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        if (wi[u] >= 0) {
+          const int o = ob + woff[u];
+          const int diff = descale(S.jreg[o] * iw00 + S.jreg[o + 1] * iw01 + S.jreg[o + RS] * iw10 + S.jreg[o + RS + 1] * iw11, 9) - S.Iw[wi[u]];
+          pb1 += diff * S.dIx[wi[u]];
+          pb2 += diff * S.dIy[wi[u]];
+        }
       }
-      sb1 = wave_sum_i64(sb1); sb2 = wave_sum_i64(sb2);
+      const long long sb1 = wave_sum_split(pb1), sb2 = wave_sum_split(pb2);
       const float b1 = (float)(double)sb1 * FLT_SCALE;
       const float b2 = (float)(double)sb2 * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;
@@ -273,10 +310,20 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
     base += total;
     __syncthreads();
   }
+  // sequential f32 sum in feature order (the reference's loop order decides the rounding, SURVEY C-2):
+  // values are staged in LDS by all threads so the single summing lane never waits on global memory
+  __shared__ float sPar[4096];
+  float sum = 0.f;
+  for (int c0 = 0; c0 < n; c0 += 4096) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4096 && c0 + i < n; i += 1024) sPar[i] = keep[c0 + i] ? parallax[c0 + i] : -1.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int m = n - c0 < 4096 ? n - c0 : 4096;
+      for (int i = 0; i < m; ++i) { const float v = sPar[i]; if (v >= 0.f) sum += v; }
+    }
+  }
   if (threadIdx.x == 0) {
-    float sum = 0.f;
-    for (int i = 0; i < n; ++i)
-      if (keep[i]) sum += parallax[i];
     *n_kept = base;
     *av_parallax = n > 0 ? sum / (float)n : 0.f;
   }
