@@ -59,12 +59,16 @@ struct BaDev {
   double f = 0, cx = 0, cy = 0;
   // deterministic mode: contribution slots + destination lists
   int det = 0;
+  // Contributions are stored DESTINATION-ORDERED so the reduce kernels stream contiguous memory:
   int32_t* pair_base = nullptr;   // per observation: first pair slot (pairs (o, t>=o) of its landmark)
-  double* pairB = nullptr;        // n_pairs x 36
-  double* obsV = nullptr;         // M x 18  (g_c | g_red part | diag U)
-  double* lmV = nullptr;          // Npts x 4
-  int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1)
-  int32_t* list_entries = nullptr;
+  int32_t* pair_pos = nullptr;    // per pair slot: [position in its block list, position in the mirrored list or -1]
+  int32_t* obs_pos = nullptr;     // per observation: position in its pose list or -1
+  double* pairB = nullptr;        // (sum of block-list lengths) x 36, block lists back to back
+  double* obsV = nullptr;         // (free observations) x 18  (g_c | g_red part | diag U), pose lists back to back
+  double* lmV = nullptr;          // Npts x 4, by landmark index (zero for landmarks without observations)
+  int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1): offsets into pairB / obsV / lmV rows
+  double* pay1_out = nullptr;     // where the reduce kernels write (pinned host memory when single-rank)
+  double* pay2_out = nullptr;
 };
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 #pragma unroll
       for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
     if (freep && P.det) {
-      double* ov = P.obsV + (size_t)o * 18;
+      double* ov = P.obsV + (size_t)P.obs_pos[o] * 18;
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
         ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
@@ -225,13 +229,18 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
       for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
       if (freep && t < len && kt > 0 && src >= lane) {
         if (P.det) {
-          double* B = P.pairB + (size_t)(P.pair_base[o] + (src - lane)) * 36;
+          const int slot = P.pair_base[o] + (src - lane);
+          const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
+          double* B = P.pairB + (size_t)posA * 36;
+          double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
 #pragma unroll
           for (int a = 0; a < 6; ++a)
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
               const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-              B[6 * a + b] = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+              const double w = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+              B[6 * a + b] = w;
+              if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
             }
         } else {
           const int bt = 6 * (kt - 1);
@@ -378,28 +387,21 @@ __global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) {
   __shared__ double sP[RSEG][36];
   const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
   const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
+  const int stride = d < F * F ? 36 : (d < F * F + F ? 18 : 4);
+  const double* base = d < F * F ? P.pairB : (d < F * F + F ? P.obsV : P.lmV);
   const int seg = tid / width, e = tid % width;
-  const int e0 = P.list_start[d], len = P.list_start[d + 1] - e0;
+  const int nd = F * F + F + 1;
+  const int e0 = P.list_start[d], len = P.list_start[nd + 1 + d] - e0;
   const int seglen = (len + RSEG - 1) / RSEG;
   if (seg < RSEG) {
     double acc = 0.0;
     const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-    // 8 entries' loads are issued before their (strictly ordered) adds: the loop is latency-bound otherwise
-    const int et = (e % 6) * 6 + e / 6;  // transposed element (pair blocks)
+    const double* src = base + (size_t)e0 * stride + e;
+    // 8 independent loads in flight, adds strictly in list order
     for (int q0 = b0; q0 < b1; q0 += 8) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int q = q0 + u;
-        double val = 0.0;
-        if (q < b1) {
-          const int ent = P.list_entries[e0 + q];
-          if (d < F * F) val = P.pairB[(size_t)(ent >> 1) * 36 + ((ent & 1) ? et : e)];
-          else if (d < F * F + F) val = P.obsV[(size_t)ent * 18 + e];
-          else val = P.lmV[4 * (size_t)ent + e];
-        }
-        v[u] = val;
-      }
+      for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[(size_t)(q0 + u) * stride] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (q0 + u < b1) acc += v[u];
@@ -410,16 +412,17 @@ __global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) {
   if (tid < width) {
     double acc = 0.0;
     for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
+    double* out = P.pay1_out;
     if (d < F * F) {
       const int ka = d / F, kb = d % F;
-      P.pay1[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
+      out[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
     } else if (d < F * F + F) {
       const int k = d - F * F;
-      if (tid < 6) P.pay1[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
-      else if (tid < 12) P.pay1[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
-      else P.pay1[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
+      if (tid < 6) out[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
+      else if (tid < 12) out[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
+      else out[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
     } else {
-      P.pay1[(size_t)n * n + 3 * n + tid] = acc;
+      out[(size_t)n * n + 3 * n + tid] = acc;
     }
   }
 }
@@ -429,15 +432,16 @@ __global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) {
   const int F = P.K - 1, tid = threadIdx.x;
   const int d = F * F + F;  // the landmark list
   const int seg = tid / 4, e = tid % 4;
-  const int e0 = P.list_start[d], len = P.list_start[d + 1] - e0;
+  const int e0 = P.list_start[d], len = P.list_start[F * F + F + 1 + 1 + d] - e0;
   const int seglen = (len + RSEG - 1) / RSEG;
   if (seg < RSEG) {
     double acc = 0.0;
     const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+    const double* src = P.lmV + 4 * (size_t)e0 + e;
     for (int q0 = b0; q0 < b1; q0 += 8) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? P.lmV[4 * (size_t)P.list_entries[e0 + q0 + u] + e] : 0.0;
+      for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[4 * (size_t)(q0 + u)] : 0.0;
 #pragma unroll
       for (int u = 0; u < 8; ++u)
         if (q0 + u < b1) acc += v[u];
@@ -448,7 +452,7 @@ __global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) {
   if (tid < 4) {
     double acc = 0.0;
     for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-    P.pay2[tid] = acc;
+    P.pay2_out[tid] = acc;
   }
 }
 
@@ -519,6 +523,8 @@ struct svo_ba {
   std::vector<double> feat_pos;  // 3 per feature id
   bool new_frame_added = false;
   std::vector<int64_t> solve_lm_ids;
+  std::vector<int32_t> h_list_begin, h_list_end;
+  size_t n_pair_rows = 0;
 };
 
 static int ba_alloc(svo_ba* ba) {
@@ -535,7 +541,8 @@ static int ba_alloc(svo_ba* ba) {
   A(d.obs_pose, int32_t, ba->cap_obs); A(d.obs_point, int32_t, ba->cap_obs); A(d.obs_uv, double, 2 * ba->cap_obs);
   A(d.lm_start, int32_t, ba->cap_points + 1); A(d.chunk_start, int32_t, ba->cap_chunks + 1);
   A(d.pay1, double, ba->cap_pay1); A(d.pay2, double, 4);
-  A(d.pair_base, int32_t, ba->cap_obs + 1); A(d.obsV, double, 18 * ba->cap_obs); A(d.lmV, double, 4 * ba->cap_points);
+  A(d.pair_base, int32_t, ba->cap_obs + 1); A(d.obs_pos, int32_t, ba->cap_obs + 1); A(d.obsV, double, 18 * ba->cap_obs);
+  A(d.lmV, double, 4 * ba->cap_points); A(d.list_start, int32_t, 2 * (64 * 64 + 64 + 1) + 8);
 #undef A
   ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 64 + 16 * (size_t)Kmax);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
@@ -577,7 +584,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (!ba) return;
   BaDev& d = ba->d;
   void* ptrs[] = {ba->step_buf[0], ba->step_buf[1], d.points, d.cand_points, d.sp, d.obs_pose, d.obs_point, d.obs_uv,
-                  d.lm_start, d.chunk_start, d.pay1, d.pay2, d.pair_base, d.pairB, d.obsV, d.lmV, d.list_start, d.list_entries};
+                  d.lm_start, d.chunk_start, d.pay1, d.pay2, d.pair_base, d.pair_pos, d.obs_pos, d.pairB, d.obsV, d.lmV, d.list_start};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
@@ -632,42 +639,59 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
     const size_t n_pairs = (size_t)pair_base[M];
     d.det = n_pairs <= ((size_t)1 << 21) ? 1 : 0;  // <= 604 MB of pair blocks
     if (d.det) {
+      // destination lists in landmark order; the landmark list is the identity over [0, npts)
       const int nd = F * F + F + 1;
-      std::vector<std::vector<int32_t>> lists(nd);
-      for (int j = 0; j < npts; ++j) {
-        if (lm_start[j + 1] > lm_start[j]) lists[F * F + F].push_back(j);
-        for (int i = lm_start[j]; i < lm_start[j + 1]; ++i) {
-          const int ki = op[i] - 1;
-          if (ki < 0) continue;
-          lists[F * F + ki].push_back(i);
-          for (int t = i; t < lm_start[j + 1]; ++t) {
-            const int kt = op[t] - 1;
-            if (kt < 0) continue;
-            const int slot = pair_base[i] + (t - i);
-            lists[ki * F + kt].push_back(slot * 2);
-            if (t != i) lists[kt * F + ki].push_back(slot * 2 + 1);
-          }
+      std::vector<int32_t> cnt(nd, 0), pair_pos(2 * n_pairs + 2, -1), obs_pos((size_t)M + 1, -1);
+      for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+          // block lists are back to back in pairB, pose lists back to back in obsV, the landmark list is
+          // rows [0, npts) of lmV
+          ba->h_list_begin.assign(nd, 0); ba->h_list_end.assign(nd, 0);
+          int32_t acc = 0;
+          for (int q = 0; q < F * F; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
+          ba->n_pair_rows = (size_t)acc;
+          acc = 0;
+          for (int q = F * F; q < F * F + F; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
+          ba->h_list_begin[F * F + F] = 0; ba->h_list_end[F * F + F] = npts;
         }
+        std::vector<int32_t> fill(nd, 0);
+        for (int j = 0; j < npts; ++j)
+          for (int i = lm_start[j]; i < lm_start[j + 1]; ++i) {
+            const int ki = op[i] - 1;
+            if (ki < 0) continue;
+            if (pass == 0) cnt[F * F + ki]++;
+            else obs_pos[i] = ba->h_list_begin[F * F + ki] + fill[F * F + ki]++;
+            for (int t = i; t < lm_start[j + 1]; ++t) {
+              const int kt = op[t] - 1;
+              if (kt < 0) continue;
+              const int slot = pair_base[i] + (t - i);
+              const int da = ki * F + kt, db = kt * F + ki;
+              if (pass == 0) { cnt[da]++; if (t != i) cnt[db]++; }
+              else {
+                pair_pos[2 * slot] = ba->h_list_begin[da] + fill[da]++;
+                if (t != i) pair_pos[2 * slot + 1] = ba->h_list_begin[db] + fill[db]++;
+              }
+            }
+          }
       }
-      std::vector<int32_t> lstart(nd + 1, 0), lent;
-      for (int q = 0; q < nd; ++q) { lstart[q + 1] = lstart[q] + (int32_t)lists[q].size(); lent.insert(lent.end(), lists[q].begin(), lists[q].end()); }
-      if (n_pairs > ba->cap_pairs) {
+      const size_t rows = ba->n_pair_rows;
+      if (rows > ba->cap_pairs || 2 * n_pairs + 2 > ba->cap_list) {
         if (d.pairB) (void)hipFree(d.pairB);
-        d.pairB = nullptr;
-        ba->cap_pairs = n_pairs + n_pairs / 4 + 1024;
+        if (d.pair_pos) (void)hipFree(d.pair_pos);
+        d.pairB = nullptr; d.pair_pos = nullptr;
+        ba->cap_pairs = rows + rows / 4 + 1024;
+        ba->cap_list = 2 * n_pairs + n_pairs / 2 + 4096;
         SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
-      }
-      if (lent.size() + nd + 2 > ba->cap_list) {
-        if (d.list_entries) (void)hipFree(d.list_entries);
-        if (d.list_start) (void)hipFree(d.list_start);
-        d.list_entries = d.list_start = nullptr;
-        ba->cap_list = lent.size() + lent.size() / 4 + 4096;
-        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.list_entries, sizeof(int32_t) * ba->cap_list));
-        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.list_start, sizeof(int32_t) * (64 * 64 + 64 + 8)));
+        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pair_pos, sizeof(int32_t) * ba->cap_list));
       }
       SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.pair_base, pair_base.data(), sizeof(int32_t) * (M + 1), hipMemcpyHostToDevice, st));
-      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.list_start, lstart.data(), sizeof(int32_t) * (nd + 1), hipMemcpyHostToDevice, st));
-      if (!lent.empty()) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.list_entries, lent.data(), sizeof(int32_t) * lent.size(), hipMemcpyHostToDevice, st));
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.pair_pos, pair_pos.data(), sizeof(int32_t) * (2 * n_pairs + 2), hipMemcpyHostToDevice, st));
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.obs_pos, obs_pos.data(), sizeof(int32_t) * (M + 1), hipMemcpyHostToDevice, st));
+      // list_start[q] = begin(q), list_start[nd + 1 + q] = end(q)
+      std::vector<int32_t> ls(2 * (size_t)nd + 2, 0);
+      for (int q = 0; q < nd; ++q) { ls[q] = ba->h_list_begin[q]; ls[nd + 1 + q] = ba->h_list_end[q]; }
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.list_start, ls.data(), sizeof(int32_t) * ls.size(), hipMemcpyHostToDevice, st));
+      if (npts) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
       SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
     }
   }
@@ -723,13 +747,18 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
       if (d.det) hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, rad, have_scale ? 0 : 1);  // one wave per workgroup: spreads the chunks over the CUs
       else hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, st, d, rad, have_scale ? 0 : 1);
     }
+    // single rank + deterministic mode: the reduce kernel writes the payload straight into pinned host
+    // memory (no copy kernel); a sharded run keeps it on the device for the all-reduce
+    const bool zero_copy = d.det && !ba->allreduce;
+    d.pay1_out = zero_copy ? h_pay1 : d.pay1;
+    d.pay2_out = zero_copy ? h_pay2 : d.pay2;
     if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3((K - 1) * (K - 1) + (K - 1) + 1), dim3(1024), 0, st, d);
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (ba->allreduce) {
       SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
       if (ba->allreduce(d.pay1, pay1, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
     }
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay1, d.pay1, sizeof(double) * pay1, hipMemcpyDeviceToHost, st));
+    if (!zero_copy) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay1, d.pay1, sizeof(double) * pay1, hipMemcpyDeviceToHost, st));
     SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
     // mirror the upper pair blocks (kernel writes each unordered pose pair once)
     const double* S = h_pay1;
@@ -810,7 +839,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
           SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
           if (ba->allreduce(d.pay2, 4, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
         }
-        SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay2, d.pay2, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
+        if (!(d.det && !ba->allreduce)) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay2, d.pay2, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
         SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
         cost_new = h_pay2[0];
         model_change = mcc + h_pay2[1];
