@@ -6,7 +6,7 @@
 // f32 2x2 solve without FMA contraction).
 //
 //   pyr_copy_kernel / pyr_down_kernel : 4-level pyramid, [1 4 6 4 1]^2, REFLECT_101, (s+128)>>8.
-//   lk_fb_kernel  : one wavefront (64 lanes) per feature.  Per level the 24x24 source patch and a 32x32
+//   lk_fb_kernel  : one 256-thread workgroup (4 wavefronts) per feature.  Per level the 24x24 source patch and a 32x32
 //                   region of the target image are staged in LDS once (the region is restaged only if the
 //                   window walks out of it, so iterations run barrier-free out of LDS); source patch in
 //                   LDS, Scharr derivatives are formed on the fly (no derivative image ever hits HBM),
@@ -60,6 +60,7 @@ __device__ __forceinline__ long long wave_sum_split(int v) {
   return (long long)hi * 65536 + (long long)lo;
 }
 
+constexpr int LKT = 256;         // threads (4 wavefronts) per feature
 constexpr int RM = 5;            // margin of the staged target region around the 22x22 window
 constexpr int RS = G + 2 * RM;   // 32
 
@@ -68,11 +69,32 @@ struct LkShared {
   uint8_t jreg[RS * RS];     // target-image region; restaged only when the window leaves it
   short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
   short gx[G * G], gy[G * G];
+  int red[2][6][4];          // cross-wave partials (double-buffered: one barrier per reduction point)
 };
+
+// Exact 64-bit sums of NV per-thread int32 partials over the 4 wavefronts of the workgroup.
+template <int NV>
+__device__ __forceinline__ void block_sum_split(const int* v, long long* out, LkShared& S, int& phase) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int lo = wave_sum_i32(v[k] & 0xFFFF), hi = wave_sum_i32(v[k] >> 16);
+    if (lane == 0) { S.red[phase][2 * k][wave] = lo; S.red[phase][2 * k + 1][wave] = hi; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int lo = S.red[phase][2 * k][0] + S.red[phase][2 * k][1] + S.red[phase][2 * k][2] + S.red[phase][2 * k][3];
+    const int hi = S.red[phase][2 * k + 1][0] + S.red[phase][2 * k + 1][1] + S.red[phase][2 * k + 1][2] + S.red[phase][2 * k + 1][3];
+    out[k] = (long long)hi * 65536 + (long long)lo;
+  }
+  phase ^= 1;
+}
 
 // One feature through all pyramid levels; every lane of the wave returns the same values.
 __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, float* ox, float* oy, LkShared& S) {
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x;  // 0..LKT-1: index over the workgroup (4 wavefronts share one feature)
+  int phase = 0;
   uint8_t status = 1;
   float nx = 0.f, ny = 0.f;
   for (int level = LEVELS - 1; level >= 0; --level) {
@@ -95,13 +117,13 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
     int iw11 = (1 << 14) - iw00 - iw01 - iw10;
     __syncthreads();
     // stage the (WIN+3)^2 raw patch: tile (r,c) <-> image (ipy-1+r, ipx-1+c), reflect-101
-    for (int i = lane; i < RP * RP; i += 64) {
+    for (int i = lane; i < RP * RP; i += LKT) {
       const int r = i / RP, c = i % RP;
       S.raw[i] = Ip[(size_t)reflect101(ipy - 1 + r, Ih_) * Iw_ + reflect101(ipx - 1 + c, Iw_)];
     }
     __syncthreads();
     // Scharr at the (WIN+1)^2 grid; zero outside the image (BORDER_CONSTANT derivative padding)
-    for (int i = lane; i < G * G; i += 64) {
+    for (int i = lane; i < G * G; i += LKT) {
       const int r = i / G, c = i % G;
       const int X = ipx + c, Y = ipy + r;
       int vx = 0, vy = 0;
@@ -119,8 +141,8 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       S.gx[i] = (short)vx; S.gy[i] = (short)vy;
     }
     __syncthreads();
-    int pA11 = 0, pA12 = 0, pA22 = 0;  // <= 7 pixels per lane, each product < 2^24.1: fits int32
-    for (int i = lane; i < WIN * WIN; i += 64) {
+    int pA[3] = {0, 0, 0};  // <= 2 pixels per thread, each product < 2^24.1: fits int32
+    for (int i = lane; i < WIN * WIN; i += LKT) {
       const int r = i / WIN, c = i % WIN;
       const int o = r * G + c, o1 = o + G;
       const int rr = (r + 1) * RP + (c + 1);
@@ -128,11 +150,13 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       const int ixv = descale(S.gx[o] * iw00 + S.gx[o + 1] * iw01 + S.gx[o1] * iw10 + S.gx[o1 + 1] * iw11, 14);
       const int iyv = descale(S.gy[o] * iw00 + S.gy[o + 1] * iw01 + S.gy[o1] * iw10 + S.gy[o1 + 1] * iw11, 14);
       S.Iw[i] = (short)ival; S.dIx[i] = (short)ixv; S.dIy[i] = (short)iyv;
-      pA11 += ixv * ixv;
-      pA12 += ixv * iyv;
-      pA22 += iyv * iyv;
+      pA[0] += ixv * ixv;
+      pA[1] += ixv * iyv;
+      pA[2] += iyv * iyv;
     }
-    const long long sA11 = wave_sum_split(pA11), sA12 = wave_sum_split(pA12), sA22 = wave_sum_split(pA22);
+    long long sA[3];
+    block_sum_split<3>(pA, sA, S, phase);  // the barrier inside also publishes Iw/dIx/dIy
+    const long long sA11 = sA[0], sA12 = sA[1], sA22 = sA[2];
     const float A11 = (float)(double)sA11 * FLT_SCALE;
     const float A12 = (float)(double)sA12 * FLT_SCALE;
     const float A22 = (float)(double)sA22 * FLT_SCALE;
@@ -147,17 +171,16 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
     float outx = nx, outy = ny;
     nx -= (float)HALF; ny -= (float)HALF;
     float pdx = 0.f, pdy = 0.f;
-    // window-pixel offsets of this lane inside the staged region (7 pixels per lane, fixed for the level)
-    int woff[7], wi[7];
+    // window-pixel offsets of this thread inside the staged region (<= 2 pixels per thread)
+    int woff[2], wi[2];
 #pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int i = lane + 64 * u;
+    for (int u = 0; u < 2; ++u) {
+      const int i = lane + LKT * u;
       wi[u] = i < WIN * WIN ? i : -1;
       woff[u] = i < WIN * WIN ? (i / WIN) * RS + (i % WIN) : 0;
     }
     int rx0 = 0, ry0 = 0;
     bool staged = false;
-    __syncthreads();  // Iw/dIx/dIy visible to every lane
     for (int j = 0; j < MAX_ITER; ++j) {
       const int inx = (int)floorf(nx), iny = (int)floorf(ny);
       if (inx < -WIN || inx >= Jw_ || iny < -WIN || iny >= Jh_) {
@@ -173,26 +196,28 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
         rx0 = inx - RM; ry0 = iny - RM;
         __syncthreads();
         if (rx0 >= 0 && ry0 >= 0 && rx0 + RS <= Jw_ && ry0 + RS <= Jh_) {
-          for (int i = lane; i < RS * RS; i += 64) S.jreg[i] = Jp[(size_t)(ry0 + i / RS) * Jw_ + rx0 + i % RS];
+          for (int i = lane; i < RS * RS; i += LKT) S.jreg[i] = Jp[(size_t)(ry0 + i / RS) * Jw_ + rx0 + i % RS];
         } else {
-          for (int i = lane; i < RS * RS; i += 64)
+          for (int i = lane; i < RS * RS; i += LKT)
             S.jreg[i] = Jp[(size_t)reflect101(ry0 + i / RS, Jh_) * Jw_ + reflect101(rx0 + i % RS, Jw_)];
         }
         __syncthreads();
         staged = true;
       }
       const int ob = (iny - ry0) * RS + (inx - rx0);
-      int pb1 = 0, pb2 = 0;
+      int pb[2] = {0, 0};
 #pragma unroll
-      for (int u = 0; u < 7; ++u) {
+      for (int u = 0; u < 2; ++u) {
         if (wi[u] >= 0) {
           const int o = ob + woff[u];
           const int diff = descale(S.jreg[o] * iw00 + S.jreg[o + 1] * iw01 + S.jreg[o + RS] * iw10 + S.jreg[o + RS + 1] * iw11, 9) - S.Iw[wi[u]];
-          pb1 += diff * S.dIx[wi[u]];
-          pb2 += diff * S.dIy[wi[u]];
+          pb[0] += diff * S.dIx[wi[u]];
+          pb[1] += diff * S.dIy[wi[u]];
         }
       }
-      const long long sb1 = wave_sum_split(pb1), sb2 = wave_sum_split(pb2);
+      long long sb[2];
+      block_sum_split<2>(pb, sb, S, phase);
+      const long long sb1 = sb[0], sb2 = sb[1];
       const float b1 = (float)(double)sb1 * FLT_SCALE;
       const float b2 = (float)(double)sb2 * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;
@@ -243,7 +268,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(uint8_t* __restrict__ pyr
   pyr[(size_t)blockIdx.z * pyr_stride + dst_off + (size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
 }
 
-__global__ __launch_bounds__(64) void lk_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
+__global__ __launch_bounds__(LKT) void lk_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
                                                 int h, const float* __restrict__ xy, int n, float* __restrict__ out,
                                                 uint8_t* __restrict__ status) {
   __shared__ LkShared S;
@@ -256,7 +281,7 @@ __global__ __launch_bounds__(64) void lk_kernel(const uint8_t* __restrict__ pyrA
 }
 
 // forward + backward + keep predicate (src/feature_tracker.cpp:44-55)
-__global__ __launch_bounds__(64) void lk_fb_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
+__global__ __launch_bounds__(LKT) void lk_fb_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
                                                    int h, const float* __restrict__ xy, const float* __restrict__ init_xy,
                                                    const int* __restrict__ n_dev, int n_host, float* __restrict__ fwd,
                                                    uint8_t* __restrict__ keep, float* __restrict__ parallax) {
@@ -358,7 +383,7 @@ int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int
 int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy, int n,
              float* out_xy, uint8_t* status) {
   if (n <= 0) return SVO_OK;
-  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(64), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, n, out_xy, status);
+  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(LKT), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, n, out_xy, status);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -368,7 +393,7 @@ int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, 
                 float* kept_xy, int* kept_index, int* n_kept, float* av_parallax) {
   if (n_max > 0) {
     SvoProfScope prof(ctx, SVO_PROF_LK_FB);
-    hipLaunchKernelGGL(lk_fb_kernel, dim3(n_max), dim3(64), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
+    hipLaunchKernelGGL(lk_fb_kernel, dim3(n_max), dim3(LKT), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
                        n_max, fwd_xy, keep_flag, parallax);
   }
   hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, fwd_xy, keep_flag, parallax, n_dev, n_max,

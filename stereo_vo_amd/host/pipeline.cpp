@@ -4,12 +4,30 @@
 // Reference: src/image_processor.cpp:18-208, src/feature_tracker.cpp:3-72, src/bundle_adjuster.cpp:60-163,
 // driver rule src/vo_node.cpp:141-148.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include "kernels.h"
 #include "stereo_vo.hpp"
 
 namespace svo {
+
+// SVO_TIMING=1: wall-clock per phase of the host-side chain, printed when the pipeline is destroyed.
+struct PhaseTimer {
+  static double acc[8];
+  static const char* name(int i) {
+    static const char* n[8] = {"prepare_batch", "track", "pnp", "dedup+stereo+triangulate", "add_keyframe+init", "bundle_adjust", "first_keyframe", "other"};
+    return n[i];
+  }
+  int id;
+  std::chrono::steady_clock::time_point t0;
+  explicit PhaseTimer(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
+  ~PhaseTimer() { acc[id] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
+double PhaseTimer::acc[8] = {0};
 
 #define SVO_TRY(expr)            \
   do {                           \
@@ -246,6 +264,7 @@ void ImageProcessor::reset() {
 }
 
 int ImageProcessor::prepare_batch(const uint8_t* left, int batch, int width, int height) {
+  PhaseTimer pt(0);
   if (batch < 1 || batch > max_batch_ || batch > ctx_->lim.max_batch) { ctx_->err = "prepare_batch: batch outside limits"; return SVO_ERR_INVALID; }
   width_ = width; height_ = height; batch_ = batch;
   const size_t istride = (size_t)width * height;
@@ -328,12 +347,16 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   }
 
   float av_parallax = 0, percent_lost = 0;
-  feature_tracker->track_features(av_parallax, percent_lost, pyr, width_, height_, true);  // :62
+  {
+    PhaseTimer pt(1);
+    feature_tracker->track_features(av_parallax, percent_lost, pyr, width_, height_, true);  // :62
+  }
   stats_.n_tracked = feature_tracker->count();
   stats_.av_parallax = av_parallax;
   stats_.percent_lost = percent_lost;
   if (av_parallax <= parallax_thresh && (double)percent_lost < 0.4) return;  // :63-65
 
+  PhaseTimer* ptp = new PhaseTimer(2);
   std::vector<Point2f> tracked_features;
   std::vector<Point3f> tracked_world_points;
   std::vector<size_t> tracked_ids;
@@ -370,6 +393,8 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
     kf->tracked_features_2d[i] = tracked_features[idx];
   }
 
+  delete ptp;
+  ptp = new PhaseTimer(3);
   // dedup :113-128 on the device; the surviving corners stay in HBM for the stereo stage
   if (num_inliers > 0)
     SVO_TRY(hipMemcpyAsync(d_trk_xy_, kf->tracked_features_2d.data(), sizeof(float) * 2 * num_inliers, hipMemcpyHostToDevice, st));
@@ -386,6 +411,8 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   hmat[15] = 1.f;
   triangulate_stereo(kf->new_features_3d, kf->new_features_2d, d_new_xy_, d_cnt_, n_det, sp.left, sp.right, hmat);  // :137-142
 
+  delete ptp;
+  PhaseTimer pt4(4);
   bundle_adjuster->add_keyframe(kf);  // :144
 
   std::vector<Point2f> features_2d_for_tracker(kf->tracked_features_2d);  // :148-162
@@ -448,6 +475,10 @@ extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_p
 
 extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
   if (!p) return;
+  if (getenv("SVO_TIMING")) {
+    for (int i = 0; i < 8; ++i)
+      if (svo::PhaseTimer::acc[i] > 0) fprintf(stderr, "[svo timing] %-28s %10.3f ms\n", svo::PhaseTimer::name(i), svo::PhaseTimer::acc[i]);
+  }
   if (p->d_imgs) (void)hipFree(p->d_imgs);
   delete p;
 }
@@ -477,7 +508,10 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
     r.n_detected = s.n_detected; r.n_tracked = s.n_tracked; r.n_inliers = s.n_inliers; r.n_new = s.n_new;
     r.is_keyframe = s.is_keyframe; r.av_parallax = s.av_parallax; r.percent_lost = s.percent_lost;
     if (p->adjuster->get_last_keyframe() != nullptr) {  // src/vo_node.cpp:146-148
-      p->adjuster->bundle_adjust();
+      {
+        svo::PhaseTimer pt(5);
+        p->adjuster->bundle_adjust();
+      }
       r.ba_iterations = p->adjuster->last_iterations();
       auto kf = p->adjuster->get_last_keyframe();
       r.pose7[0] = kf->orientation.w_; r.pose7[1] = kf->orientation.x_; r.pose7[2] = kf->orientation.y_; r.pose7[3] = kf->orientation.z_;
