@@ -513,6 +513,7 @@ struct svo_ba {
   // host mirrors of the loaded problem
   std::vector<double> h_poses, h_cand_poses;
   int n_points = 0;
+  hipStream_t stream = nullptr;  // BA has its own stream so a solve can overlap the tracker's kernels
   double* step_buf[2] = {nullptr, nullptr};
   double* h_pin = nullptr;  // pinned staging: payload1 / payload2 / dc / poses
   size_t pin_bytes = 0;
@@ -544,6 +545,7 @@ static int ba_alloc(svo_ba* ba) {
   A(d.pair_base, int32_t, ba->cap_obs + 1); A(d.obs_pos, int32_t, ba->cap_obs + 1); A(d.obsV, double, 18 * ba->cap_obs);
   A(d.lmV, double, 4 * ba->cap_points); A(d.list_start, int32_t, 2 * (64 * 64 + 64 + 1) + 8);
 #undef A
+  SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
   ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 64 + 16 * (size_t)Kmax);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
   return SVO_OK;
@@ -588,6 +590,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
+  if (ba->stream) { (void)hipStreamSynchronize(ba->stream); (void)hipStreamDestroy(ba->stream); }
   delete ba;
 }
 
@@ -629,7 +632,7 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   chunks.push_back(M);
   d.C = (int)chunks.size() - 1;
   d.L = npts;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ba->stream;
   // deterministic mode: pair slots + destination lists (landmark order) if they fit
   {
     const int F = K - 1;
@@ -718,7 +721,7 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
 static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = ba->stream;
   const int n = d.n, K = d.K;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -743,7 +746,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
     d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
     if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
     if (d.C > 0) {
-      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE);
+      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       if (d.det) hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, rad, have_scale ? 0 : 1);  // one wave per workgroup: spreads the chunks over the CUs
       else hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, st, d, rad, have_scale ? 0 : 1);
     }
@@ -829,7 +832,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay2, 0, sizeof(double) * 4, st));
         d.points = cur_points; d.cand_points = cand_points;
         if (d.C > 0) {
-          SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB);
+          SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB, st);
           if (d.det) hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.C), dim3(64), 0, st, d, radius);
           else hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
         }
@@ -912,8 +915,8 @@ extern "C" int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3) 
   svo_ctx* ctx = ba->ctx;
   if (poses7) memcpy(poses7, ba->h_poses.data(), sizeof(double) * 7 * (size_t)ba->d.K);
   if (points3 && ba->n_points) {
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(points3, ba->d.points, sizeof(double) * 3 * (size_t)ba->n_points, hipMemcpyDeviceToHost, ctx->stream));
-    SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(points3, ba->d.points, sizeof(double) * 3 * (size_t)ba->n_points, hipMemcpyDeviceToHost, ba->stream));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
   }
   return SVO_OK;
 }

@@ -46,15 +46,16 @@ enum SvoProfTag { SVO_PROF_NONE = 0, SVO_PROF_CORNER_RESPONSE, SVO_PROF_CORNER_N
 // RAII event pair around one launch of the selected kernel (no-op for every other kernel).
 struct SvoProfScope {
   svo_ctx* c;
+  hipStream_t st;
   int slot = -1;
-  SvoProfScope(svo_ctx* ctx, int tag) : c(ctx) {
+  SvoProfScope(svo_ctx* ctx, int tag, hipStream_t stream = nullptr) : c(ctx), st(stream ? stream : ctx->stream) {
     if (ctx->prof_tag == tag && 2 * (ctx->prof_used + 1) <= (int)ctx->prof_ev.size()) {
       slot = ctx->prof_used++;
-      (void)hipEventRecord(ctx->prof_ev[2 * slot], ctx->stream);
+      (void)hipEventRecord(ctx->prof_ev[2 * slot], st);
     }
   }
   ~SvoProfScope() {
-    if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], c->stream);
+    if (slot >= 0) (void)hipEventRecord(c->prof_ev[2 * slot + 1], st);
   }
 };
 

@@ -36,7 +36,7 @@ extern "C" int svo_profile_select(svo_ctx* ctx, const char* kernel) {
 
 extern "C" int svo_profile_read(svo_ctx* ctx, double* total_ms, int* launches) {
   if (!ctx || !total_ms || !launches) return SVO_ERR_INVALID;
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  SVO_HIP_CHECK(ctx, hipDeviceSynchronize());  // profiled kernels may run on the BA stream
   double tot = 0.0;
   for (int i = 0; i < ctx->prof_used; ++i) {
     float ms = 0.f;

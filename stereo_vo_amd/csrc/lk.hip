@@ -17,7 +17,10 @@
 #include "kernels.h"
 
 namespace {
-constexpr int WIN = 21, HALF = 10, LEVELS = 4, MAX_ITER = 30;
+#ifndef SVO_LK_MAX_ITER
+#define SVO_LK_MAX_ITER 30
+#endif
+constexpr int WIN = 21, HALF = 10, LEVELS = 4, MAX_ITER = SVO_LK_MAX_ITER;
 constexpr int G = WIN + 1;      // 22: bilinear needs one extra row/col
 constexpr int RP = WIN + 3;     // 24: Scharr needs one more on each side
 constexpr float MIN_EIG = 1e-2f;

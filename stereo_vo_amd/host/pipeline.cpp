@@ -53,7 +53,23 @@ BundleAdjuster::BundleAdjuster(svo_ctx* ctx, size_t window_size, svo_camera_info
   reset();
 }
 
+void BundleAdjuster::wait() {
+  if (worker_.joinable()) worker_.join();
+}
+
+void BundleAdjuster::bundle_adjust_async() {
+  wait();
+  if (!launch_needed_) return;
+  launch_needed_ = false;
+  svo_ctx* c = ctx_;
+  worker_ = std::thread([this, c]() {
+    (void)hipSetDevice(c->device);
+    this->bundle_adjust();
+  });
+}
+
 void BundleAdjuster::reset() {
+  wait();
   if (ba_) svo_ba_destroy(ba_);
   ba_ = nullptr;
   svo_ba_options opt;
@@ -68,9 +84,10 @@ void BundleAdjuster::reset() {
   last_iterations_ = 0;
 }
 
-BundleAdjuster::~BundleAdjuster() { if (ba_) svo_ba_destroy(ba_); }
+BundleAdjuster::~BundleAdjuster() { wait(); if (ba_) svo_ba_destroy(ba_); }
 
 void BundleAdjuster::add_keyframe(std::shared_ptr<Keyframe> kf) {  // src/bundle_adjuster.cpp:60-135
+  wait();
   if (!ba_) return;
   double pose7[7] = {kf->orientation.w_, kf->orientation.x_, kf->orientation.y_, kf->orientation.z_,
                      kf->position(0), kf->position(1), kf->position(2)};
@@ -87,24 +104,32 @@ void BundleAdjuster::add_keyframe(std::shared_ptr<Keyframe> kf) {  // src/bundle
   kf->new_ids.clear();               // real ids only (SURVEY C-4)
   for (int i = 0; i < kept; ++i) kf->new_ids.push_back((size_t)nid[i]);
   last_keyframe_ = kf;               // :132
+  new_frame_added_ = true;           // :134
+  launch_needed_ = true;
 }
 
 void BundleAdjuster::bundle_adjust() {  // src/bundle_adjuster.cpp:137-157
   last_iterations_ = 0;
+  if (!worker_.joinable() || std::this_thread::get_id() != worker_.get_id()) launch_needed_ = false;  // synchronous use
   if (!ba_ || !last_keyframe_) return;
-  svo_ba_summary s;
-  if (svo_ba_solve(ba_, &s)) return;
-  last_iterations_ = s.iterations;
-  double p[7];
-  if (svo_ba_get_pose(ba_, -1, p)) return;
-  // :146-153 (copying an unchanged pose back when no solve ran is the identity on float values already stored)
-  if (s.iterations > 0 || s.initial_cost != 0.0) {
-    last_keyframe_->orientation = Quaternionf{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};
+  if (new_frame_added_) {  // :138
+    PhaseTimer pt(5);
+    svo_ba_summary s;
+    if (svo_ba_solve(ba_, &s)) return;
+    last_iterations_ = s.iterations;
+    double p[7];
+    if (svo_ba_get_pose(ba_, -1, p)) return;
+    last_keyframe_->orientation = Quaternionf{(float)p[0], (float)p[1], (float)p[2], (float)p[3]};  // :146-153
     last_keyframe_->position = Vector3f{{(float)p[4], (float)p[5], (float)p[6]}};
+    new_frame_added_ = false;  // :155
   }
+  solved_pose_[0] = last_keyframe_->orientation.w_; solved_pose_[1] = last_keyframe_->orientation.x_;
+  solved_pose_[2] = last_keyframe_->orientation.y_; solved_pose_[3] = last_keyframe_->orientation.z_;
+  for (int i = 0; i < 3; ++i) solved_pose_[4 + i] = last_keyframe_->position(i);
 }
 
 void BundleAdjuster::get_world_points(std::vector<Point3f>& world_points, const std::vector<size_t>& ids) {
+  wait();  // the landmarks must be the bundle-adjusted ones (src/bundle_adjuster.cpp:159-163)
   const size_t n = ids.size();
   if (!n || !ba_) return;
   std::vector<int64_t> id64(n);
@@ -485,6 +510,7 @@ extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
 
 extern "C" int svo_pipeline_reset(svo_pipeline* p) {
   if (!p) return SVO_ERR_INVALID;
+  p->adjuster->wait();
   p->proc->reset();
   return SVO_OK;
 }
@@ -499,6 +525,19 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
   ctx->err.clear();
   int rc = p->proc->prepare_batch(left, batch, W, H);
   if (rc) return rc;
+  // The reference runs process() then bundle_adjust() per frame (src/vo_node.cpp:141-148).  Here the solve of
+  // keyframe k runs asynchronously (own stream + worker thread) while frames k+1.. are tracked; it is joined
+  // before anything reads the graph again (next keyframe's get_world_points / add_keyframe), so every number
+  // is the same as in the synchronous order.  Poses of frames [k, next keyframe) are filled at that join.
+  int pending_from = -1;
+  auto fill_pending = [&](int upto) {
+    if (pending_from < 0) return;
+    for (int j = pending_from; j < upto; ++j) {
+      memcpy(results[j].pose7, p->adjuster->solved_pose(), sizeof(results[j].pose7));
+      if (j == pending_from && results[j].is_keyframe) results[j].ba_iterations = p->adjuster->last_iterations();
+    }
+    pending_from = -1;
+  };
   for (int i = 0; i < batch; ++i) {
     svo::DeviceImage L{left + i * istride, W, H, W}, R{right + i * istride, W, H, W};
     p->proc->process(svo::StereoPair(L, R, (double)i, i));  // src/vo_node.cpp:141-144
@@ -507,18 +546,21 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
     const auto& s = p->proc->stats();
     r.n_detected = s.n_detected; r.n_tracked = s.n_tracked; r.n_inliers = s.n_inliers; r.n_new = s.n_new;
     r.is_keyframe = s.is_keyframe; r.av_parallax = s.av_parallax; r.percent_lost = s.percent_lost;
-    if (p->adjuster->get_last_keyframe() != nullptr) {  // src/vo_node.cpp:146-148
-      {
-        svo::PhaseTimer pt(5);
-        p->adjuster->bundle_adjust();
-      }
-      r.ba_iterations = p->adjuster->last_iterations();
-      auto kf = p->adjuster->get_last_keyframe();
-      r.pose7[0] = kf->orientation.w_; r.pose7[1] = kf->orientation.x_; r.pose7[2] = kf->orientation.y_; r.pose7[3] = kf->orientation.z_;
-      r.pose7[4] = kf->position(0); r.pose7[5] = kf->position(1); r.pose7[6] = kf->position(2);
+    if (!ctx->err.empty()) { p->adjuster->wait(); return SVO_ERR_HIP; }
+    if (p->adjuster->get_last_keyframe() == nullptr) continue;  // src/vo_node.cpp:146
+    if (p->adjuster->new_keyframe_pending()) {
+      // process() joined the previous solve before editing the graph: its poses are final now
+      fill_pending(i);
+      pending_from = i;
+      p->adjuster->bundle_adjust_async();  // src/vo_node.cpp:147
+    } else if (pending_from < 0) {
+      pending_from = i;  // no solve in flight: the pose is the last solved one
     }
-    if (!ctx->err.empty()) return SVO_ERR_HIP;
   }
+  p->adjuster->wait();
+  if (pending_from < 0) pending_from = batch;
+  fill_pending(batch);
+  if (!ctx->err.empty()) return SVO_ERR_HIP;
   return SVO_OK;
 }
 
@@ -541,6 +583,7 @@ extern "C" int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, 
 
 extern "C" int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n) {
   if (!p || !n) return SVO_ERR_INVALID;
+  p->adjuster->wait();
   std::vector<svo::Point2f> f;
   std::vector<size_t> id;
   p->tracker->get_tracked_features(f, id);

@@ -20,6 +20,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "svo.h"
@@ -76,8 +77,16 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   std::shared_ptr<Keyframe> get_last_keyframe() { return last_keyframe_; }
   void add_keyframe(std::shared_ptr<Keyframe> keyframe);
   void bundle_adjust();
+  // Same solve, started on the adjuster's own HIP stream and a worker thread so that it overlaps the
+  // tracker's kernels of the following frames; every method that reads or edits the graph joins it first,
+  // so results are identical to the synchronous call.
+  void bundle_adjust_async();
+  void wait();
+  bool pending() const { return worker_.joinable(); }
+  bool new_keyframe_pending() const { return launch_needed_; }  // caller-thread flag (the worker never touches it)
   void get_world_points(std::vector<Point3f>& world_points, const std::vector<size_t>& ids);
   int last_iterations() const { return last_iterations_; }
+  const double* solved_pose() const { return solved_pose_; }
   svo_ba* handle() { return ba_; }
   void reset();
  private:
@@ -89,6 +98,10 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   double max_time_s_;
   std::shared_ptr<Keyframe> last_keyframe_;
   int last_iterations_ = 0;
+  bool new_frame_added_ = false;   // owned by whoever runs bundle_adjust()
+  bool launch_needed_ = false;     // owned by the caller thread
+  double solved_pose_[7] = {1, 0, 0, 0, 0, 0, 0};
+  std::thread worker_;
 };
 
 class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing are visualisation: out of scope)
