@@ -66,9 +66,6 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
     return SVO_ERR_HIP;
   };
   hipError_t e;
-  // the LM loop and the per-frame gates wait on the stream hundreds of times per batch: spin, don't sleep
-  (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
-  (void)hipGetLastError();
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
   const size_t px = (size_t)c->lim.max_width * c->lim.max_height;

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+# torch bundles its own libamdhip64; load it BEFORE libsvo_hip.so so that the process holds exactly one HIP
+# runtime (same soname => the loader reuses the first one).  Tests that hand torch tensors / RCCL buffers to
+# the library need that; the library itself does not depend on torch.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

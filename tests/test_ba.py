@@ -119,3 +119,53 @@ def test_hip_ba_sliding_window_graph(ctx):
     assert pts.dtype == np.float32 and np.isfinite(pts).all() and (pts[:, 2] > 1.0).all()  # double -> float gather (:159-163)
     assert np.allclose(ba.get_pose(0), ba.get_pose(-3))
     ba.close()
+
+
+@pytest.mark.gpu
+def test_hip_sharded_callback_equals_unsharded(ctx):
+    """The all-reduce contract on the GPU: two landmark shards solved in lock-step inside one process, the
+    callback summing their device payloads (what RCCL does across ranks), must equal the unsharded solve."""
+    import threading
+    import torch
+    import stereo_vo_amd as S
+    from stereo_vo_amd import sharding
+    p = BP.make_problem(21, 5, 600)
+    ref = S.api.BA(ctx, 5, BP.F, BP.CX, BP.CY, max_time_s=0.0)
+    ref.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s_ref = ref.solve_problem()
+    poses_ref, pts_ref = ref.read_problem()
+    bar = threading.Barrier(2)
+    bufs, res = [None, None], [None, None]
+    ctxs = [S.Context(64, 64), S.Context(64, 64)]
+
+    def run(rank):
+        torch.cuda.set_device(0)
+
+        def cb(ptr, n):
+            t = torch.as_tensor(sharding._DevBuf(ptr, n), device="cuda:0")
+            bufs[rank] = t
+            bar.wait()
+            tot = bufs[0] + bufs[1]
+            torch.cuda.synchronize()
+            bar.wait()
+            t.copy_(tot)
+            torch.cuda.synchronize()
+            bar.wait()
+            return 0
+        pts, op, oj, uv, mine = sharding.shard_problem(p["points0"], p["op"], p["oj"], p["uv"], rank, 2)
+        ba = S.api.BA(ctxs[rank], 5, BP.F, BP.CX, BP.CY, max_time_s=0.0)
+        ba.set_allreduce(cb)
+        ba.load_problem(p["poses0"], pts, op, oj, uv)
+        s = ba.solve_problem()
+        res[rank] = (mine, ba.read_problem(), s.iterations, s.final_cost)
+        ba.close()
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for rank in range(2):
+        mine, (poses, pts), it, fc = res[rank]
+        dt, ang = BP.pose_error(poses, poses_ref)
+        assert dt < T_TOL and ang < R_TOL and it == s_ref.iterations
+        assert np.allclose(pts, pts_ref[mine], rtol=1e-6, atol=1e-5)
+    assert np.array_equal(res[0][1][0], res[1][1][0])  # identical poses on both "ranks"
+    ref.close()
+    [c.close() for c in ctxs]
