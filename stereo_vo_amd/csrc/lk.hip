@@ -27,20 +27,23 @@ constexpr float MIN_EIG = 1e-2f;
 constexpr float FLT_SCALE = 1.0f / (float)(1 << 20);
 constexpr float FLT_EPS = 1.1920928955078125e-7f;
 
+// A pyramid is addressed arithmetically (base pointer + level-0 size); runtime-indexed arrays of level
+// pointers would live in scratch memory (measured: 136 B/lane of scratch, 30 MB of spill writes per launch).
 struct Pyr {
-  const uint8_t* p[LEVELS];
-  int w[LEVELS], h[LEVELS];
+  const uint8_t* base;
+  int w0, h0;
 };
 
-__device__ __forceinline__ Pyr make_pyr(const uint8_t* base, int w, int h) {
-  Pyr P;
+__device__ __forceinline__ Pyr make_pyr(const uint8_t* base, int w, int h) { return Pyr{base, w, h}; }
+
+__device__ __forceinline__ void pyr_level(const Pyr& P, int level, const uint8_t*& p, int& w, int& h) {
   size_t off = 0;
-  for (int l = 0; l < LEVELS; ++l) {
-    P.p[l] = base + off; P.w[l] = w; P.h[l] = h;
+  w = P.w0; h = P.h0;
+  for (int l = 0; l < level; ++l) {
     off += (size_t)w * h;
     w = (w + 1) / 2; h = (h + 1) / 2;
   }
-  return P;
+  p = P.base + off;
 }
 
 __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
@@ -101,9 +104,10 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
   uint8_t status = 1;
   float nx = 0.f, ny = 0.f;
   for (int level = LEVELS - 1; level >= 0; --level) {
-    const uint8_t* Ip = A.p[level];
-    const uint8_t* Jp = B.p[level];
-    const int Iw_ = A.w[level], Ih_ = A.h[level], Jw_ = B.w[level], Jh_ = B.h[level];
+    const uint8_t *Ip, *Jp;
+    int Iw_, Ih_, Jw_, Jh_;
+    pyr_level(A, level, Ip, Iw_, Ih_);
+    pyr_level(B, level, Jp, Jw_, Jh_);
     const float sc = (float)(1.0 / (double)(1 << level));
     float pxl = px0 * sc, pyl = py0 * sc;
     if (level == LEVELS - 1) { nx = pxl; ny = pyl; } else { nx = nx * 2.0f; ny = ny * 2.0f; }
