@@ -197,6 +197,8 @@ void svo_ba_default_options(svo_ba_options* o);
 int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const svo_camera_info* cam,
                   const svo_ba_options* opt, int max_landmarks, int max_observations);
 void svo_ba_destroy(svo_ba* ba);
+/* forget all keyframes and landmarks, keep every buffer (a fresh BundleAdjuster without re-allocation). */
+int svo_ba_reset(svo_ba* ba);
 /* BundleAdjuster::add_keyframe (src/bundle_adjuster.cpp:60-135). pose7 from the
  * keyframe's (orientation, position) floats widened to double (:63-70).
  * tracked_ids/tracked_xy: n_tracked observations of existing landmarks;

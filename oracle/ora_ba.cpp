@@ -97,20 +97,40 @@ bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) {
     for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
     b[i] = v / A[(size_t)i * n + i];
   }
-  for (int i = n - 1; i >= 0; --i) {
+  for (int i = n - 1; i >= 0; --i) {  // inner index DESCENDING: the order a parallel column sweep produces
     double v = b[i];
-    for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * b[k];
+    for (int k = n - 1; k > i; --k) v -= A[(size_t)k * n + i] * b[k];
     b[i] = v / A[(size_t)i * n + i];
   }
   return true;
+}
+
+// sin/cos with a declared operation sequence (no libm): halve until <= 0.5, 8-term Taylor polynomials in
+// Horner form, then double-angle steps.  Bit-identical on CPU and GPU (no FMA contraction).
+void det_sincos(double x, double* sn, double* cs) {
+  int k = 0;
+  while (x > 0.5) { x *= 0.5; ++k; }
+  const double x2 = x * x;
+  double s = x * (1.0 + x2 * (-1.0 / 6.0 + x2 * (1.0 / 120.0 + x2 * (-1.0 / 5040.0 + x2 * (1.0 / 362880.0 + x2 * (-1.0 / 39916800.0 +
+             x2 * (1.0 / 6227020800.0 + x2 * (-1.0 / 1307674368000.0))))))));
+  double c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24.0 + x2 * (-1.0 / 720.0 + x2 * (1.0 / 40320.0 + x2 * (-1.0 / 3628800.0 +
+             x2 * (1.0 / 479001600.0 + x2 * (-1.0 / 87178291200.0)))))));
+  for (int i = 0; i < k; ++i) {
+    const double s2 = 2.0 * s * c;
+    c = 1.0 - 2.0 * s * s;
+    s = s2;
+  }
+  *sn = s; *cs = c;
 }
 
 void plus_pose(const double* p, const double* d, double* out) {
   const double nd = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
   double qd[4];
   if (nd > 0) {
-    const double s = std::sin(nd) / nd;
-    qd[0] = std::cos(nd); qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
+    double sn, cs;
+    det_sincos(nd, &sn, &cs);
+    const double s = sn / nd;
+    qd[0] = cs; qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
   } else { qd[0] = 1; qd[1] = qd[2] = qd[3] = 0; }
   const double* q = p;
   out[0] = qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2] - qd[3] * q[3];

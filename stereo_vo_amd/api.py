@@ -67,7 +67,7 @@ SYMBOLS = [
     "svo_stereo_bm", "svo_stereo_disparity_at", "svo_stereo_disparity_at_dev",
     "svo_triangulate", "svo_lk_track", "svo_build_pyramid", "svo_track_features", "svo_dedup",
     "svo_pnp_ransac",
-    "svo_ba_default_options", "svo_ba_create", "svo_ba_destroy", "svo_ba_add_keyframe", "svo_ba_solve",
+    "svo_ba_default_options", "svo_ba_create", "svo_ba_destroy", "svo_ba_reset", "svo_ba_add_keyframe", "svo_ba_solve",
     "svo_ba_get_pose", "svo_ba_window_count", "svo_ba_get_points", "svo_ba_load_problem",
     "svo_ba_set_allreduce", "svo_ba_solve_problem", "svo_ba_read_problem",
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",

@@ -41,8 +41,26 @@
 namespace {
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, MAX_RADIUS = 1e16, MIN_RADIUS = 1e-32, MIN_REL_DECREASE = 1e-3;
 
+// LM state of the device-resident loop (deterministic, single-rank solves): the host never sees an
+// iteration, it enqueues chunks of [linearize, reduce1, solve, backsub, reduce2+decide] and polls `done`.
+struct LmDev {
+  double radius, decrease_factor, cost, initial_cost, mcc;
+  double function_tol, gradient_tol, parameter_tol;
+  int max_iterations;
+  int iterations, successful, termination, done;
+  int cur;          // which (points, step) buffer pair holds the linearisation point
+  int have_scale;   // Jacobi scales fixed (first linearisation done)
+  int step_valid;   // the solve kernel produced a step for this iteration
+  int grad_check;   // previous step accepted: test the gradient of the new linearisation
+  double sc[6 * 63], Df[6 * 63];
+};
+
 struct BaDev {
   int K = 0, n = 0, M = 0, L = 0, C = 0;
+  LmDev* lm = nullptr;           // non-null: buffers/radius come from the device state
+  double* pts[2] = {nullptr, nullptr};
+  double* step[2] = {nullptr, nullptr};  // [dc (max(n,1)) | poses (7K)] x 2
+  int* done_host = nullptr;      // pinned: ints [done, iterations, successful, termination, cur, pad], then doubles [initial_cost, cost]
   double* poses = nullptr;       // K x 7 (linearisation point)
   double* cand_poses = nullptr;  // K x 7
   double* dc = nullptr;          // n
@@ -109,7 +127,49 @@ __device__ __forceinline__ void eval_obs(const double* __restrict__ pose, D3 p, 
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass) {
+// sin/cos with a declared operation sequence (see oracle/ora_ba.cpp): bit-identical on host and device.
+__host__ __device__ inline void det_sincos(double x, double* sn, double* cs) {
+  int k = 0;
+  while (x > 0.5) { x *= 0.5; ++k; }
+  const double x2 = x * x;
+  double s = x * (1.0 + x2 * (-1.0 / 6.0 + x2 * (1.0 / 120.0 + x2 * (-1.0 / 5040.0 + x2 * (1.0 / 362880.0 + x2 * (-1.0 / 39916800.0 +
+             x2 * (1.0 / 6227020800.0 + x2 * (-1.0 / 1307674368000.0))))))));
+  double c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24.0 + x2 * (-1.0 / 720.0 + x2 * (1.0 / 40320.0 + x2 * (-1.0 / 3628800.0 +
+             x2 * (1.0 / 479001600.0 + x2 * (-1.0 / 87178291200.0)))))));
+  for (int i = 0; i < k; ++i) {
+    const double s2 = 2.0 * s * c;
+    c = 1.0 - 2.0 * s * s;
+    s = s2;
+  }
+  *sn = s; *cs = c;
+}
+
+__host__ __device__ inline void plus_pose(const double* p, const double* d, double* out) {
+  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+  double qd[4];
+  if (nd > 0) {
+    double sn, cs;
+    det_sincos(nd, &sn, &cs);
+    const double s = sn / nd;
+    qd[0] = cs; qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
+  } else { qd[0] = 1; qd[1] = qd[2] = qd[3] = 0; }
+  const double* q = p;
+  out[0] = qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2] - qd[3] * q[3];
+  out[1] = qd[0] * q[1] + qd[1] * q[0] + qd[2] * q[3] - qd[3] * q[2];
+  out[2] = qd[0] * q[2] - qd[1] * q[3] + qd[2] * q[0] + qd[3] * q[1];
+  out[3] = qd[0] * q[3] + qd[1] * q[2] - qd[2] * q[1] + qd[3] * q[0];
+  out[4] = p[4] + d[3]; out[5] = p[5] + d[4]; out[6] = p[6] + d[5];
+}
+
+__device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius, int first_pass) {
+  const double* poses_ = P.poses;
+  const double* points_ = P.points;
+  if (P.lm) {
+    if (P.lm->done) return;
+    const int c = P.lm->cur;
+    poses_ = P.step[c] + (P.n > 0 ? P.n : 1); points_ = P.pts[c];
+    radius = P.lm->radius; first_pass = !P.lm->have_scale;
+  }
   extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2
   const int n = P.n;
   const int pay1 = n * n + 3 * n + 2;
@@ -137,8 +197,8 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
     if (active) {
       k = P.obs_pose[o]; j = P.obs_point[o];
       first = P.lm_start[j] - c0; len = P.lm_start[j + 1] - P.lm_start[j];
-      const D3 p{P.points[3 * j], P.points[3 * j + 1], P.points[3 * j + 2]};
-      eval_obs(P.poses + 7 * k, p, P.obs_uv[2 * o], P.obs_uv[2 * o + 1], P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+      const D3 p{points_[3 * j], points_[3 * j + 1], points_[3 * j + 2]};
+      eval_obs(poses_ + 7 * k, p, P.obs_uv[2 * o], P.obs_uv[2 * o + 1], P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
       lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
     }
     const double my_cost = active ? 0.5 * (r[0] * r[0] + r[1] * r[1]) : 0.0;
@@ -266,7 +326,19 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
   }
 }
 
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius) {
+__device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
+  const double* poses_ = P.poses;
+  const double* points_ = P.points;
+  const double* cand_poses_ = P.cand_poses;
+  double* cand_points_ = P.cand_points;
+  const double* dc_ = P.dc;
+  if (P.lm) {
+    if (P.lm->done || !P.lm->step_valid) return;
+    const int c = P.lm->cur, nn = P.n > 0 ? P.n : 1;
+    poses_ = P.step[c] + nn; points_ = P.pts[c];
+    dc_ = P.step[1 - c]; cand_poses_ = P.step[1 - c] + nn; cand_points_ = P.pts[1 - c];
+    radius = P.lm->radius;
+  }
   __shared__ double sAcc[4];
   if (threadIdx.x < 4) sAcc[threadIdx.x] = 0.0;
   __syncthreads();
@@ -286,11 +358,11 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
     if (active) {
       k = P.obs_pose[o]; j = P.obs_point[o];
       first = P.lm_start[j] - c0; len = P.lm_start[j + 1] - P.lm_start[j];
-      p = D3{P.points[3 * j], P.points[3 * j + 1], P.points[3 * j + 2]};
+      p = D3{points_[3 * j], points_[3 * j + 1], points_[3 * j + 2]};
       u = P.obs_uv[2 * o]; v = P.obs_uv[2 * o + 1];
-      eval_obs(P.poses + 7 * k, p, u, v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+      eval_obs(poses_ + 7 * k, p, u, v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
       if (k > 0) {
-        const double* d = P.dc + 6 * (k - 1);
+        const double* d = dc_ + 6 * (k - 1);
 #pragma unroll
         for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * d[a]; jd[1] += Jc[6 + a] * d[a]; }
       }
@@ -341,9 +413,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
           a_p2 += pv[a] * pv[a];
         }
       }
-      if (lane == first) { P.cand_points[3 * j] = np[0]; P.cand_points[3 * j + 1] = np[1]; P.cand_points[3 * j + 2] = np[2]; }
+      if (lane == first) { cand_points_[3 * j] = np[0]; cand_points_[3 * j + 1] = np[1]; cand_points_[3 * j + 2] = np[2]; }
       double r0, r1;
-      reproj_residual(P.cand_poses + 7 * k, D3{np[0], np[1], np[2]}, u, v, P.f, P.cx, P.cy, r0, r1);
+      reproj_residual(cand_poses_ + 7 * k, D3{np[0], np[1], np[2]}, u, v, P.f, P.cx, P.cy, r0, r1);
       a_cost += 0.5 * (r0 * r0 + r1 * r1);
       det_c = 0.5 * (r0 * r0 + r1 * r1);
       det_mc = 0.0; det_dp2 = 0.0; det_p2 = 0.0;
@@ -383,7 +455,9 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
 // (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: F*F pose-pair blocks
 // (36 values), F pose vectors (18 values), 1 scalar pair; lane = (segment, element).
 constexpr int RSEG = 28;
-__global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) {
+__device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
+  if (P.lm && P.lm->done) return;
+  if ((int)blockIdx.x >= (P.K - 1) * (P.K - 1) + (P.K - 1) + 1) return;
   __shared__ double sP[RSEG][36];
   const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
   const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
@@ -427,8 +501,10 @@ __global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) {
   }
 }
 
-__global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) {
+__device__ __forceinline__ void ba_reduce2_body(const BaDev& P) {
+  if (P.lm && (P.lm->done || !P.lm->step_valid)) return;
   __shared__ double sP[RSEG][4];
+  __shared__ double sOut[4];
   const int F = P.K - 1, tid = threadIdx.x;
   const int d = F * F + F;  // the landmark list
   const int seg = tid / 4, e = tid % 4;
@@ -452,9 +528,184 @@ __global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) {
   if (tid < 4) {
     double acc = 0.0;
     for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-    P.pay2_out[tid] = acc;
+    sOut[tid] = acc;
+    if (!P.lm) P.pay2_out[tid] = acc;
+  }
+  if (!P.lm) return;
+  __syncthreads();
+  if (tid != 0) return;
+  // ---- step control (same statements, same order as the host loop in ba_lm / oracle/ora_ba.cpp)
+  LmDev& S = *P.lm;
+  const int K = P.K, nn = P.n > 0 ? P.n : 1;
+  const double* poses = P.step[S.cur] + nn;
+  const double* cand = P.step[1 - S.cur] + nn;
+  const double cost_new = sOut[0];
+  const double model_change = S.mcc + sOut[1];
+  double step2 = sOut[2], x2 = sOut[3];
+  for (int k = 1; k < K; ++k)
+    for (int a = 0; a < 7; ++a) {
+      const double dd = cand[7 * k + a] - poses[7 * k + a];
+      step2 += dd * dd;
+      x2 += poses[7 * k + a] * poses[7 * k + a];
+    }
+  auto publish = [&]() {
+    P.done_host[1] = S.iterations; P.done_host[2] = S.successful; P.done_host[3] = S.termination; P.done_host[4] = S.cur;
+    double* dh = reinterpret_cast<double*>(P.done_host + 6);
+    dh[0] = S.initial_cost; dh[1] = S.cost;
+    __threadfence_system();
+    P.done_host[0] = 1;
+  };
+  if (!(model_change > 0)) { S.radius /= S.decrease_factor; S.decrease_factor *= 2; return; }
+  if (sqrt(step2) <= S.parameter_tol * (sqrt(x2) + S.parameter_tol)) { S.termination = 0; S.done = 1; publish(); return; }
+  const double cost_change = S.cost - cost_new;
+  if (fabs(cost_change) <= S.function_tol * S.cost) {
+    if (cost_change > 0) { S.cur = 1 - S.cur; S.cost = cost_new; }
+    S.termination = 0; S.done = 1; publish();
+    return;
+  }
+  const double rho = cost_change / model_change;
+  if (rho > MIN_REL_DECREASE) {
+    S.cur = 1 - S.cur; S.cost = cost_new; ++S.successful;
+    const double t = 2.0 * rho - 1.0;
+    S.radius = S.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    S.radius = fmin(MAX_RADIUS, S.radius);
+    S.decrease_factor = 2.0;
+    S.grad_check = 1;
+  } else {
+    S.radius /= S.decrease_factor; S.decrease_factor *= 2;
   }
 }
+
+// Reduced camera system: scaling, LM diagonal, Cholesky (column sweep, same operation order as the host
+// cholesky_solve), pose step and candidate poses.  One workgroup; n <= 6*63.
+__device__ __forceinline__ void ba_solve_body(const BaDev& P) {
+  LmDev& S = *P.lm;
+  if (S.done) return;
+  extern __shared__ double sm[];  // Sm (n*n) | b (n)
+  const int n = P.n, K = P.K, tid = threadIdx.x, nn = n > 0 ? n : 1;
+  double* Sm = sm;
+  double* sB = sm + (size_t)n * n;
+  __shared__ int sFail;
+  const double* pay = P.pay1;
+  const double* gred = pay + (size_t)n * n;
+  const double* gc = gred + n;
+  const double* dU = gc + n;
+  auto publish = [&]() {
+    P.done_host[1] = S.iterations; P.done_host[2] = S.successful; P.done_host[3] = S.termination; P.done_host[4] = S.cur;
+    double* dh = reinterpret_cast<double*>(P.done_host + 6);
+    dh[0] = S.initial_cost; dh[1] = S.cost;
+    __threadfence_system();
+    P.done_host[0] = 1;
+  };
+  if (tid == 0) {
+    sFail = 0;
+    S.step_valid = 0;
+    bool check = false;
+    if (!S.have_scale) {
+      for (int a = 0; a < n; ++a) S.sc[a] = 1.0 / (1.0 + sqrt(dU[a]));
+      S.have_scale = 1;
+      S.cost = pay[(size_t)n * n + 3 * n];
+      S.initial_cost = S.cost;
+      check = true;
+    } else if (S.grad_check) {
+      check = true;
+    }
+    S.grad_check = 0;
+    if (check) {
+      double g2 = pay[(size_t)n * n + 3 * n + 1];
+      for (int a = 0; a < n; ++a) g2 += gc[a] * gc[a];
+      if (sqrt(g2) <= S.gradient_tol) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
+    }
+    if (!sFail) {
+      if (S.iterations >= S.max_iterations) { S.termination = 1; S.done = 1; publish(); sFail = 2; }
+      else if (S.radius <= MIN_RADIUS) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
+      else ++S.iterations;
+    }
+  }
+  __syncthreads();
+  if (sFail) return;
+  const int T = blockDim.x;  // 64 (one wavefront, n < 64) or 128
+  const double radius = S.radius;
+  for (int a = tid; a < n; a += T) S.Df[a] = fmin(fmax(dU[a] * S.sc[a] * S.sc[a], MIN_DIAG), MAX_DIAG) / radius;
+  __syncthreads();
+  for (int i = tid; i < n * n; i += T) {
+    const int a = i / n, b = i % n;
+    double v = pay[i] * S.sc[a] * S.sc[b];
+    if (a == b) v += S.Df[a];
+    Sm[i] = v;
+  }
+  for (int a = tid; a < n; a += T) sB[a] = -(gred[a] + gc[a]) * S.sc[a];
+  __syncthreads();
+  // Cholesky, column by column (row i's dot products run sequentially in k, as on the host).  The right-hand
+  // side rides along as an extra row: y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj is exactly the forward
+  // substitution, product for product.
+  for (int j = 0; j < n; ++j) {
+    if (tid == 0) {
+      double s = Sm[(size_t)j * n + j];
+      for (int k = 0; k < j; ++k) s -= Sm[(size_t)j * n + k] * Sm[(size_t)j * n + k];
+      if (!(s > 0)) sFail = 1; else Sm[(size_t)j * n + j] = sqrt(s);
+    }
+    __syncthreads();
+    if (sFail) break;
+    const double l = Sm[(size_t)j * n + j];
+    for (int i = j + 1 + tid; i <= n; i += T) {
+      if (i < n) {
+        double v = Sm[(size_t)i * n + j];
+        for (int k = 0; k < j; ++k) v -= Sm[(size_t)i * n + k] * Sm[(size_t)j * n + k];
+        Sm[(size_t)i * n + j] = v / l;
+      } else {  // the augmented row: forward substitution of column j
+        double v = sB[j];
+        for (int k = 0; k < j; ++k) v -= Sm[(size_t)j * n + k] * sB[k];
+        sB[j] = v / l;
+      }
+    }
+    __syncthreads();
+  }
+  if (sFail) {  // not positive definite: an invalid step
+    if (tid == 0) { S.radius /= S.decrease_factor; S.decrease_factor *= 2; }
+    return;
+  }
+  // backward substitution (k descending) as a column sweep
+  for (int k = n - 1; k >= 0; --k) {
+    if (tid == 0) sB[k] = sB[k] / Sm[(size_t)k * n + k];
+    __syncthreads();
+    const double bk = sB[k];
+    for (int i = tid; i < k; i += T) sB[i] -= Sm[(size_t)k * n + i] * bk;
+    __syncthreads();
+  }
+  // step, model change (pose part), candidate poses
+  const int c = S.cur;
+  double* dc = P.step[1 - c];
+  const double* poses = P.step[c] + nn;
+  double* cand = P.step[1 - c] + nn;
+  if (tid == 0) {
+    double mcc = 0;
+    for (int a = 0; a < n; ++a) {
+      mcc += 0.5 * sB[a] * (S.Df[a] * sB[a] - gc[a] * S.sc[a]);
+      dc[a] = sB[a] * S.sc[a];
+    }
+    S.mcc = mcc;
+    S.step_valid = 1;
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += T) {
+    if (k == 0) { for (int a = 0; a < 7; ++a) cand[a] = poses[a]; }
+    else plus_pose(poses + 7 * k, dc + 6 * (k - 1), cand + 7 * k);
+  }
+}
+
+// By-value wrappers (host-driven loop) and by-pointer wrappers (hipGraph replay: the parameters live in
+// device memory so the instantiated graph never has to be updated between solves).
+__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass) { ba_linearize_body(P, radius, first_pass); }
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius) { ba_backsub_body(P, radius); }
+__global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) { ba_reduce1_body(P); }
+__global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) { ba_reduce2_body(P); }
+__global__ __launch_bounds__(128) void ba_solve_kernel(BaDev P) { ba_solve_body(P); }
+__global__ __launch_bounds__(64) void ba_linearize_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_linearize_body(P, 0.0, 0); }
+__global__ __launch_bounds__(64) void ba_backsub_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_backsub_body(P, 0.0); }
+__global__ __launch_bounds__(1024) void ba_reduce1_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_reduce1_body(P); }
+__global__ __launch_bounds__(128) void ba_reduce2_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_reduce2_body(P); }
+__global__ __launch_bounds__(128) void ba_solve_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_solve_body(P); }
 
 // ----------------------------------------------------------------------------- host side
 namespace {
@@ -476,29 +727,16 @@ bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) {
     for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
     b[i] = v / A[(size_t)i * n + i];
   }
-  for (int i = n - 1; i >= 0; --i) {
+  for (int i = n - 1; i >= 0; --i) {  // inner index DESCENDING: the order the device column sweep produces
     double v = b[i];
-    for (int k = i + 1; k < n; ++k) v -= A[(size_t)k * n + i] * b[k];
+    for (int k = n - 1; k > i; --k) v -= A[(size_t)k * n + i] * b[k];
     b[i] = v / A[(size_t)i * n + i];
   }
   return true;
 }
-
-void plus_pose(const double* p, const double* d, double* out) {
-  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  double qd[4];
-  if (nd > 0) {
-    const double s = sin(nd) / nd;
-    qd[0] = cos(nd); qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
-  } else { qd[0] = 1; qd[1] = qd[2] = qd[3] = 0; }
-  const double* q = p;
-  out[0] = qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2] - qd[3] * q[3];
-  out[1] = qd[0] * q[1] + qd[1] * q[0] + qd[2] * q[3] - qd[3] * q[2];
-  out[2] = qd[0] * q[2] - qd[1] * q[3] + qd[2] * q[0] + qd[3] * q[1];
-  out[3] = qd[0] * q[3] + qd[1] * q[2] - qd[2] * q[1] + qd[3] * q[0];
-  out[4] = p[4] + d[3]; out[5] = p[5] + d[4]; out[6] = p[6] + d[5];
-}
 }  // namespace
+
+
 
 struct svo_ba {
   svo_ctx* ctx = nullptr;
@@ -509,10 +747,18 @@ struct svo_ba {
   void* allreduce_user = nullptr;
   // device problem
   BaDev d;
-  size_t cap_points = 0, cap_obs = 0, cap_chunks = 0, cap_pay1 = 0, cap_pairs = 0, cap_list = 0;
+  size_t cap_points = 0, cap_obs = 0, cap_chunks = 0, cap_pay1 = 0, cap_pairs = 0;
   // host mirrors of the loaded problem
   std::vector<double> h_poses, h_cand_poses;
   int n_points = 0;
+  LmDev* d_lm = nullptr;
+  uint8_t* d_arena = nullptr;     // all per-solve inputs in one allocation: one H2D per solve
+  uint8_t* h_arena = nullptr;     // pinned staging image of the arena
+  size_t arena_cap = 0;
+  BaDev* d_params = nullptr;      // device copy of the kernel parameters (graph kernels read it)
+  hipGraphExec_t graph_exec = nullptr;
+  double t_launch = 0, t_sync = 0, t_upload = 0, t_total = 0; long n_chunks = 0, n_solves = 0;
+  int graph_threads = 0;          // solve-kernel block size baked into the graph
   hipStream_t stream = nullptr;  // BA has its own stream so a solve can overlap the tracker's kernels
   double* step_buf[2] = {nullptr, nullptr};
   double* h_pin = nullptr;  // pinned staging: payload1 / payload2 / dc / poses
@@ -537,16 +783,30 @@ static int ba_alloc(svo_ba* ba) {
 #define A(ptr, T, cnt) SVO_HIP_CHECK(ctx, hipMalloc((void**)&(ptr), sizeof(T) * (size_t)(cnt)))
   // two [dc | poses] step buffers: the candidate of an accepted step becomes the linearisation point by a pointer swap
   A(ba->step_buf[0], double, (nmax > 0 ? nmax : 1) + 7 * Kmax); A(ba->step_buf[1], double, (nmax > 0 ? nmax : 1) + 7 * Kmax);
-  A(d.points, double, 3 * ba->cap_points); A(d.cand_points, double, 3 * ba->cap_points);
   A(d.sp, double, 3 * ba->cap_points);
-  A(d.obs_pose, int32_t, ba->cap_obs); A(d.obs_point, int32_t, ba->cap_obs); A(d.obs_uv, double, 2 * ba->cap_obs);
-  A(d.lm_start, int32_t, ba->cap_points + 1); A(d.chunk_start, int32_t, ba->cap_chunks + 1);
   A(d.pay1, double, ba->cap_pay1); A(d.pay2, double, 4);
-  A(d.pair_base, int32_t, ba->cap_obs + 1); A(d.obs_pos, int32_t, ba->cap_obs + 1); A(d.obsV, double, 18 * ba->cap_obs);
-  A(d.lmV, double, 4 * ba->cap_points); A(d.list_start, int32_t, 2 * (64 * 64 + 64 + 1) + 8);
+  A(ba->d_lm, LmDev, 1); A(ba->d_params, BaDev, 1);
+  A(d.obsV, double, 18 * ba->cap_obs);
+  A(d.lmV, double, 4 * ba->cap_points);
 #undef A
+  {
+    // pre-size the per-solve input arena and the pair-block store for window-shaped problems (every landmark seen
+    // at most once per pose) so that the hot path never allocates; bulk problems beyond this grow lazily
+    const size_t M = ba->cap_obs, Kc = (size_t)Kmax;
+    const size_t pairs = M * (Kc + 1) / 2 + 64;
+    const size_t est = 16 * 3 * ba->cap_points + 16 * M + 8 * M + 4 * (ba->cap_points + 1) + 4 * (M + 2) * 3 + 8 * pairs + 8 * (Kc * Kc + Kc + 2) + 16 * 256;
+    if (est < ((size_t)512 << 20)) {
+      ba->arena_cap = est;
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_arena, ba->arena_cap));
+      SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_arena, ba->arena_cap, hipHostMallocDefault));
+    }
+    if (2 * pairs * 288 < ((size_t)512 << 20)) {
+      ba->cap_pairs = 2 * pairs;
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
+    }
+  }
   SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
-  ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 64 + 16 * (size_t)Kmax);
+  ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 1400 + 16 * (size_t)Kmax) + 2 * sizeof(BaDev);  // payloads | flags | LmDev image | poses
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
   return SVO_OK;
 }
@@ -585,8 +845,12 @@ extern "C" int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const 
 extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (!ba) return;
   BaDev& d = ba->d;
-  void* ptrs[] = {ba->step_buf[0], ba->step_buf[1], d.points, d.cand_points, d.sp, d.obs_pose, d.obs_point, d.obs_uv,
-                  d.lm_start, d.chunk_start, d.pay1, d.pay2, d.pair_base, d.pair_pos, d.obs_pos, d.pairB, d.obsV, d.lmV, d.list_start};
+  if (getenv("SVO_TIMING") && ba->n_chunks)
+    fprintf(stderr, "[svo ba] solves %ld chunks %ld graph-launch %.3f ms sync %.3f ms upload %.3f ms total %.3f ms\n", ba->n_solves, ba->n_chunks,
+            ba->t_launch, ba->t_sync, ba->t_upload, ba->t_total);
+  if (ba->graph_exec) (void)hipGraphExecDestroy(ba->graph_exec);
+  void* ptrs[] = {ba->d_lm, ba->d_params, ba->step_buf[0], ba->step_buf[1], d.sp, d.pay1, d.pay2, d.pairB, d.obsV, d.lmV, ba->d_arena};
+  if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
@@ -633,6 +897,9 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   d.C = (int)chunks.size() - 1;
   d.L = npts;
   hipStream_t st = ba->stream;
+  std::vector<int32_t> pair_base_v, pair_pos_v, obs_pos_v, ls;
+  bool has_empty_landmark = false;
+  for (int j = 0; j < npts; ++j) has_empty_landmark |= lm_start[j + 1] == lm_start[j];
   // deterministic mode: pair slots + destination lists (landmark order) if they fit
   {
     const int F = K - 1;
@@ -678,47 +945,178 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
           }
       }
       const size_t rows = ba->n_pair_rows;
-      if (rows > ba->cap_pairs || 2 * n_pairs + 2 > ba->cap_list) {
+      if (rows > ba->cap_pairs) {
         if (d.pairB) (void)hipFree(d.pairB);
-        if (d.pair_pos) (void)hipFree(d.pair_pos);
-        d.pairB = nullptr; d.pair_pos = nullptr;
+        d.pairB = nullptr;
         ba->cap_pairs = rows + rows / 4 + 1024;
-        ba->cap_list = 2 * n_pairs + n_pairs / 2 + 4096;
         SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
-        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pair_pos, sizeof(int32_t) * ba->cap_list));
       }
-      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.pair_base, pair_base.data(), sizeof(int32_t) * (M + 1), hipMemcpyHostToDevice, st));
-      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.pair_pos, pair_pos.data(), sizeof(int32_t) * (2 * n_pairs + 2), hipMemcpyHostToDevice, st));
-      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.obs_pos, obs_pos.data(), sizeof(int32_t) * (M + 1), hipMemcpyHostToDevice, st));
-      // list_start[q] = begin(q), list_start[nd + 1 + q] = end(q)
-      std::vector<int32_t> ls(2 * (size_t)nd + 2, 0);
+      ls.assign(2 * (size_t)nd + 2, 0);  // list_start[q] = begin(q), list_start[nd + 1 + q] = end(q)
       for (int q = 0; q < nd; ++q) { ls[q] = ba->h_list_begin[q]; ls[nd + 1 + q] = ba->h_list_end[q]; }
-      SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.list_start, ls.data(), sizeof(int32_t) * ls.size(), hipMemcpyHostToDevice, st));
-      if (npts) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
-      SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      pair_base_v.swap(pair_base); pair_pos_v.swap(pair_pos); obs_pos_v.swap(obs_pos);
     }
   }
+  // ---- one pinned staging image, one H2D: [points | points (candidate copy) | uv | obs_pose | obs_point |
+  //      lm_start | chunk_start | pair_base | obs_pos | pair_pos | list_start | poses]
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  size_t off = 0;
+  const size_t o_pts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
+  const size_t o_cpts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
+  const size_t o_uv = off; off = al(off + sizeof(double) * 2 * (size_t)M);
+  const size_t o_op = off; off = al(off + sizeof(int32_t) * (size_t)M);
+  const size_t o_oj = off; off = al(off + sizeof(int32_t) * (size_t)M);
+  const size_t o_lm = off; off = al(off + sizeof(int32_t) * ((size_t)npts + 1));
+  const size_t o_ch = off; off = al(off + sizeof(int32_t) * chunks.size());
+  const size_t o_pb = off; off = al(off + sizeof(int32_t) * pair_base_v.size());
+  const size_t o_ob = off; off = al(off + sizeof(int32_t) * obs_pos_v.size());
+  const size_t o_pp = off; off = al(off + sizeof(int32_t) * pair_pos_v.size());
+  const size_t o_ls = off; off = al(off + sizeof(int32_t) * ls.size());
+  const size_t total = off;
+  if (total > ba->arena_cap) {
+    if (ba->d_arena) (void)hipFree(ba->d_arena);
+    if (ba->h_arena) (void)hipHostFree(ba->h_arena);
+    ba->d_arena = nullptr; ba->h_arena = nullptr;
+    ba->arena_cap = total + total / 4 + 4096;
+    SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_arena, ba->arena_cap));
+    SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_arena, ba->arena_cap, hipHostMallocDefault));
+  }
+  uint8_t* h = ba->h_arena;
+  if (npts) { memcpy(h + o_pts, points3, sizeof(double) * 3 * (size_t)npts); memcpy(h + o_cpts, points3, sizeof(double) * 3 * (size_t)npts); }
+  if (M) {
+    memcpy(h + o_uv, uv, sizeof(double) * 2 * (size_t)M);
+    memcpy(h + o_op, op, sizeof(int32_t) * (size_t)M);
+    memcpy(h + o_oj, oj, sizeof(int32_t) * (size_t)M);
+  }
+  memcpy(h + o_lm, lm_start.data(), sizeof(int32_t) * lm_start.size());
+  memcpy(h + o_ch, chunks.data(), sizeof(int32_t) * chunks.size());
+  if (!pair_base_v.empty()) memcpy(h + o_pb, pair_base_v.data(), sizeof(int32_t) * pair_base_v.size());
+  if (!obs_pos_v.empty()) memcpy(h + o_ob, obs_pos_v.data(), sizeof(int32_t) * obs_pos_v.size());
+  if (!pair_pos_v.empty()) memcpy(h + o_pp, pair_pos_v.data(), sizeof(int32_t) * pair_pos_v.size());
+  if (!ls.empty()) memcpy(h + o_ls, ls.data(), sizeof(int32_t) * ls.size());
+  uint8_t* D = ba->d_arena;
+  d.points = (double*)(D + o_pts); d.cand_points = (double*)(D + o_cpts); d.obs_uv = (double*)(D + o_uv);
+  d.obs_pose = (int32_t*)(D + o_op); d.obs_point = (int32_t*)(D + o_oj); d.lm_start = (int32_t*)(D + o_lm);
+  d.chunk_start = (int32_t*)(D + o_ch); d.pair_base = (int32_t*)(D + o_pb); d.obs_pos = (int32_t*)(D + o_ob);
+  d.pair_pos = (int32_t*)(D + o_pp); d.list_start = (int32_t*)(D + o_ls);
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
   ba->h_cand_poses = ba->h_poses;
   d.poses = ba->step_buf[0] + (d.n > 0 ? d.n : 1);
   d.cand_poses = ba->step_buf[1] + (d.n > 0 ? d.n : 1);
   d.dc = ba->step_buf[1];
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, poses7, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
-  if (npts) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.points, points3, sizeof(double) * 3 * npts, hipMemcpyHostToDevice, st));
-  if (npts) SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.cand_points, points3, sizeof(double) * 3 * npts, hipMemcpyHostToDevice, st));
-  if (M) {
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.obs_pose, op, sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.obs_point, oj, sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.obs_uv, uv, sizeof(double) * 2 * M, hipMemcpyHostToDevice, st));
+  double* h_pose_stage = ba->h_pin;  // payload area is idle during the upload
+  memcpy(h_pose_stage, poses7, sizeof(double) * 7 * K);
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(D, h, total, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, h_pose_stage, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
+  if (d.det && has_empty_landmark && npts) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));  // the staging buffers are reused by the next upload
+  return SVO_OK;
+}
+
+// Device-resident LM loop: the host only enqueues iteration chunks and polls a pinned flag.
+static int ba_lm_device(svo_ba* ba, svo_ba_summary* sum) {
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  hipStream_t st = ba->stream;
+  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
+  const auto t_begin = std::chrono::steady_clock::now();
+  int* done_host = reinterpret_cast<int*>(ba->h_pin + ba->cap_pay1 + 16);
+  double* h_fin = reinterpret_cast<double*>(done_host + 6);
+  LmDev init;
+  memset(&init, 0, sizeof(init));
+  init.radius = ba->opt.initial_radius; init.decrease_factor = 2.0;
+  init.function_tol = ba->opt.function_tolerance; init.gradient_tol = ba->opt.gradient_tolerance;
+  init.parameter_tol = ba->opt.parameter_tolerance; init.max_iterations = ba->opt.max_iterations;
+  init.termination = 1;
+  LmDev* h_init = reinterpret_cast<LmDev*>(ba->h_pin + ba->cap_pay1 + 32);
+  *h_init = init;
+  memset(done_host, 0, 6 * sizeof(int));
+  h_fin[0] = h_fin[1] = 0.0;
+  d.lm = ba->d_lm;
+  d.pts[0] = d.points; d.pts[1] = d.cand_points;
+  d.step[0] = ba->step_buf[0]; d.step[1] = ba->step_buf[1];  // ba_upload put the poses into step_buf[0] + nn
+  d.done_host = done_host;
+  d.pay1_out = d.pay1; d.pay2_out = d.pay2;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_lm, h_init, sizeof(LmDev), hipMemcpyHostToDevice, st));
+  const size_t solve_lds = ((size_t)n * n + n + 8) * sizeof(double);
+  // One hipGraph = `chunk` LM iterations x 5 kernels, captured once per adjuster with worst-case grids
+  // (extra workgroups exit immediately); replayed with ONE launch call per chunk.
+  const int chunk = 3;  // iterations between two polls of the done flag (typical solve: 5-6 iterations)
+  const int Kmax = ba->max_poses, nmax = 6 * (Kmax - 1);
+  const int nd_max = (Kmax - 1) * (Kmax - 1) + (Kmax - 1) + 1;
+  const size_t solve_lds_max = ((size_t)nmax * nmax + nmax + 8) * sizeof(double);
+  const int solve_threads = nmax < 64 ? 64 : 128;
+  if (!ba->graph_exec) {
+    if (solve_lds_max > 64 * 1024)
+      SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_solve_gkernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_max));
+    hipGraph_t graph = nullptr;
+    SVO_HIP_CHECK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int lin_grid = 256;  // grid-stride over the wave chunks
+    for (int it = 0; it < chunk; ++it) {
+      hipLaunchKernelGGL(ba_linearize_gkernel, dim3(lin_grid), dim3(64), 64, st, ba->d_params);
+      hipLaunchKernelGGL(ba_reduce1_gkernel, dim3(nd_max), dim3(1024), 0, st, ba->d_params);
+      hipLaunchKernelGGL(ba_solve_gkernel, dim3(1), dim3(solve_threads), solve_lds_max, st, ba->d_params);
+      hipLaunchKernelGGL(ba_backsub_gkernel, dim3(lin_grid), dim3(64), 0, st, ba->d_params);
+      hipLaunchKernelGGL(ba_reduce2_gkernel, dim3(1), dim3(128), 0, st, ba->d_params);
+    }
+    SVO_HIP_CHECK(ctx, hipStreamEndCapture(st, &graph));
+    SVO_HIP_CHECK(ctx, hipGraphInstantiate(&ba->graph_exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
   }
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.lm_start, lm_start.data(), sizeof(int32_t) * (npts + 1), hipMemcpyHostToDevice, st));
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.chunk_start, chunks.data(), sizeof(int32_t) * chunks.size(), hipMemcpyHostToDevice, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));  // host vectors go out of scope
+  // parameters of this solve -> device (pinned staging, one copy)
+  BaDev* h_params = reinterpret_cast<BaDev*>(ba->h_pin + ba->cap_pay1 + 900);
+  *h_params = d;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_params, h_params, sizeof(BaDev), hipMemcpyHostToDevice, st));
+  (void)solve_lds;
+  int enqueued = 0;
+  bool done = false;
+  while (!done && enqueued < ba->opt.max_iterations + 2) {
+    const auto tl0 = std::chrono::steady_clock::now();
+    SVO_HIP_CHECK(ctx, hipGraphLaunch(ba->graph_exec, st));
+    enqueued += chunk;
+    const auto tl1 = std::chrono::steady_clock::now();
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    const auto tl2 = std::chrono::steady_clock::now();
+    ba->t_launch += std::chrono::duration<double, std::milli>(tl1 - tl0).count();
+    ba->t_sync += std::chrono::duration<double, std::milli>(tl2 - tl1).count();
+    ba->n_chunks++;
+    done = *reinterpret_cast<volatile int*>(done_host) != 0;
+    if (!done && ba->opt.max_time_s > 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() >= ba->opt.max_time_s) break;
+  }
+  int cur = 0, iterations = 0, successful = 0, termination = 1;
+  double initial_cost = 0, cost = 0;
+  if (done) {
+    iterations = done_host[1]; successful = done_host[2]; termination = done_host[3]; cur = done_host[4];
+    initial_cost = h_fin[0]; cost = h_fin[1];
+  } else {  // stopped by the wall clock (src/bundle_adjuster.cpp:11) or the safety cap: read the state back
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_init, ba->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, st));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    iterations = h_init->iterations; successful = h_init->successful; termination = 1; cur = h_init->cur;
+    initial_cost = h_init->initial_cost; cost = h_init->cost;
+  }
+  d.lm = nullptr;
+  d.points = d.pts[cur]; d.cand_points = d.pts[1 - cur];
+  d.poses = d.step[cur] + nn; d.cand_poses = d.step[1 - cur] + nn; d.dc = d.step[1 - cur];
+  double* h_p = ba->h_pin;  // payload area is free in this mode
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_p, d.poses, sizeof(double) * 7 * K, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  ba->h_poses.assign(h_p, h_p + 7 * (size_t)K);
+  ba->h_cand_poses = ba->h_poses;
+  if (sum) {
+    sum->iterations = iterations; sum->successful_steps = successful; sum->termination = termination;
+    sum->initial_cost = initial_cost; sum->final_cost = cost;
+    sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
   return SVO_OK;
 }
 
 // The LM loop (mirrors oracle/ora_ba.cpp step for step).
 static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
+  // Measured on MI355X (bench workload, ~14 LM iterations per solve): host-driven loop 81 us/iteration,
+  // device-resident loop with plain launches 97 us, hipGraph replay 81 us + idle tail iterations (7.6 us of dead
+  // time per graph node).  The host-driven loop stays the default; SVO_BA_DEVICE_LM=1 selects the graph path.
+  if (ba->d.det && !ba->allreduce && getenv("SVO_BA_DEVICE_LM")) return ba_lm_device(ba, sum);
+  ba->d.lm = nullptr;
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   hipStream_t st = ba->stream;
@@ -953,6 +1351,15 @@ extern "C" int svo_ba_add_keyframe(svo_ba* ba, const double* pose7, const int64_
   return SVO_OK;
 }
 
+extern "C" int svo_ba_reset(svo_ba* ba) {
+  if (!ba) return SVO_ERR_INVALID;
+  ba->window.clear();
+  ba->feat_pos.clear();
+  ba->new_frame_added = false;
+  ba->d.K = 0;
+  return SVO_OK;
+}
+
 extern "C" int svo_ba_window_count(svo_ba* ba) { return ba ? (int)ba->window.size() : 0; }
 
 extern "C" int svo_ba_get_pose(svo_ba* ba, int k, double* pose7) {
@@ -1001,9 +1408,13 @@ extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
     op.push_back(f.k); oj.push_back((int32_t)lm_ids.size() - 1);
     uv.push_back(f.u); uv.push_back(f.v);
   }
+  const auto tu0 = std::chrono::steady_clock::now();
   int rc = ba_upload(ba, K, poses.data(), (int)lm_ids.size(), points.data(), (int)op.size(), op.data(), oj.data(), uv.data());
   if (rc) return rc;
+  ba->t_upload += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   rc = ba_lm(ba, summary);
+  ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
+  ba->n_solves++;
   if (rc) return rc;
   std::vector<double> out_pts(points.size());
   rc = svo_ba_read_problem(ba, poses.data(), out_pts.data());

@@ -70,8 +70,10 @@ void BundleAdjuster::bundle_adjust_async() {
 
 void BundleAdjuster::reset() {
   wait();
-  if (ba_) svo_ba_destroy(ba_);
-  ba_ = nullptr;
+  last_keyframe_.reset();
+  last_iterations_ = 0;
+  new_frame_added_ = launch_needed_ = false;
+  if (ba_) { svo_ba_reset(ba_); return; }  // keep the buffers
   svo_ba_options opt;
   svo_ba_default_options(&opt);
   opt.max_features = max_features_;       // src/bundle_adjuster.hpp:75
