@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — stereo frames/s of the MI355X-native stereo-VO hot path (BASELINE.json metric).
 
-A "step" = one pass of the whole hot path (ImageProcessor::process + BundleAdjuster::bundle_adjust per
+A "step" = one pass of the whole hot path, on every one of `--streams` (default 4) independent stereo streams
+that share the GPU (own HIP stream, pipeline and BA worker each; exactly how ranks are used across GPUs), i.e. one pass (ImageProcessor::process + BundleAdjuster::bundle_adjust per
 frame: corner detection, pyramids, forward/backward LK + survivor filter, PnP-RANSAC, dedup, stereo
 disparity at the features, triangulation, sliding-window bundle adjustment) over one batch of B
 consecutive synthetic KITTI-shaped stereo pairs that are already resident in HBM, starting from a reset
@@ -38,7 +39,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per GPU)")
+    ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
+    ap.add_argument("--streams", type=int, default=4, help="independent stereo streams processed concurrently per GPU")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "ba50k"])
     ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -94,36 +96,75 @@ def cpu_baseline(p, L, R, frames):
                 sample=f"first {n} frames of the same batch, whole oracle pipeline, {dt:.1f} s"), res
 
 
+class _Stream:
+    """One independent stereo stream: its own svo_ctx (HIP stream), pipeline and BA worker, its own frames."""
+
+    def __init__(self, S, torch, local, seed, B):
+        self.ctx = S.Context(W, H, device=local, max_batch=B, max_corners=MAXC, max_candidates=1 << 16, max_features=MAX_FEAT)
+        self.p, self.L, self.R = render_batch(S, seed, B)
+        dev = torch.device("cuda", local)
+        self.dL = torch.from_numpy(self.L).to(dev)
+        self.dR = torch.from_numpy(self.R).to(dev)
+        pp = S.pipeline_default_params()
+        pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = self.p.focal, self.p.cx, self.p.cy, self.p.baseline
+        pp.width, pp.height = W, H
+        pp.max_corners, pp.quality, pp.min_feature_distance = MAXC, QUALITY, MIN_DIST
+        pp.max_features, pp.window_size = MAX_FEAT, WINDOW
+        pp.ba_max_iterations, pp.ba_max_time_s = 50, 0.0
+        self.pipe = S.Pipeline(self.ctx, pp)
+        self.B = B
+        self.res = None
+
+    def step(self):
+        self.pipe.reset()
+        self.res = self.pipe.process_batch_dev(self.dL.data_ptr(), self.dR.data_ptr(), self.B)
+
+    def close(self):
+        self.pipe.close()
+        self.ctx.close()
+
+
 def run_kitti(args):
+    import threading
     import stereo_vo_amd as S
     torch, dist, rank, local, world = dist_setup(args.gpus)
-    B = args.batch
-    ctx = S.Context(W, H, device=local, max_batch=B, max_corners=MAXC, max_candidates=1 << 16, max_features=MAX_FEAT)
-    p, L, R = render_batch(S, 0x5EED0001 + rank, B)
-    dev = torch.device("cuda", local)
-    dL = torch.from_numpy(L).to(dev)
-    dR = torch.from_numpy(R).to(dev)
+    B, NS = args.batch, max(1, args.streams)
+    streams = [_Stream(S, torch, local, 0x5EED0001 + rank * 64 + i, B) for i in range(NS)]
     torch.cuda.synchronize()
-    pp = S.pipeline_default_params()
-    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
-    pp.width, pp.height = W, H
-    pp.max_corners, pp.quality, pp.min_feature_distance = MAXC, QUALITY, MIN_DIST
-    pp.max_features, pp.window_size = MAX_FEAT, WINDOW
-    pp.ba_max_iterations, pp.ba_max_time_s = 50, 0.0
-    pipe = S.Pipeline(ctx, pp)
+    ctx = streams[0].ctx
+    dev = torch.device("cuda", local)
 
-    def step():
-        pipe.reset()
-        return pipe.process_batch_dev(dL.data_ptr(), dR.data_ptr(), B)
+    def run_steps(k):
+        """k steps on every stream; streams run concurrently (ctypes releases the GIL inside the library)."""
+        if NS == 1:
+            for _ in range(k):
+                streams[0].step()
+            return
+        def work(st):
+            for _ in range(k):
+                st.step()
+        th = [threading.Thread(target=work, args=(st,)) for st in streams]
+        [t.start() for t in th]
+        [t.join() for t in th]
 
-    res = None
-    for _ in range(args.warmup):
-        res = step()
+    run_steps(args.warmup)
+    # single-stream rate (latency-bound: one sequential VO chain) measured first, in the same run
+    single = None
+    if NS > 1:
+        barrier_sync(torch, dist, ctx)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            streams[0].step()
+        streams[0].ctx.sync()
+        dts = time.perf_counter() - t0
+        single = {"value": B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps,
+                  "note": "one stream alone on the GPU (per rank)"}
     ctx.profile_select(args.profile_kernel)
     barrier_sync(torch, dist, ctx)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
+    run_steps(args.steps)
+    for st in streams:
+        st.ctx.sync()
     barrier_sync(torch, dist, ctx)
     dt = time.perf_counter() - t0
     k_ms, k_n = ctx.profile_read()
@@ -132,7 +173,8 @@ def run_kitti(args):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    frames = world * B * args.steps
+    res = streams[0].res
+    frames = world * NS * B * args.steps
     n_kf = sum(r.is_keyframe for r in res)
     n_trk = [r.n_tracked for r in res if r.n_tracked]
     ba_it = sum(r.ba_iterations for r in res)
@@ -141,24 +183,28 @@ def run_kitti(args):
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
         "data": "synthetic",
-        "config": {"workload": "kitti_1241x376_1500corners_5kf_window (BASELINE configs[1])", "batch_per_gpu": B,
-                   "max_corners": MAXC, "quality": QUALITY, "min_distance": MIN_DIST, "window": WINDOW,
+        "config": {"workload": "kitti_1241x376_1500corners_5kf_window (BASELINE configs[1])", "batch_per_stream": B,
+                   "streams_per_gpu": NS, "max_corners": MAXC, "quality": QUALITY, "min_distance": MIN_DIST, "window": WINDOW,
                    "keyframes_per_step": n_kf, "mean_tracked": float(np.mean(n_trk)) if n_trk else 0.0,
-                   "ba_lm_iterations_per_step": ba_it, "sharding": "frames across ranks, no collective"},
+                   "ba_lm_iterations_per_step": ba_it,
+                   "sharding": "independent stereo streams: streams_per_gpu per rank, ranks hold different streams; no collective"},
     }
-    # roofline of the profiled kernel (HIP events on the library stream, over the timed region)
+    if single is not None:
+        out["single_stream"] = single
+    # roofline of the profiled kernel (HIP events on the library stream of stream 0, over the timed region)
     if k_n > 0:
         avg_us = 1e3 * k_ms / k_n
         out["roofline"] = roofline_for(args.profile_kernel, avg_us, res, k_n, args.steps)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cb, ores = cpu_baseline(p, L, R, args.cpu_frames)
+        cb, ores = cpu_baseline(streams[0].p, streams[0].L, streams[0].R, args.cpu_frames)
         out["cpu_baseline"] = cb
         m = min(len(ores), len(res))
-        same = all((a.n_detected, a.n_tracked, a.n_inliers, a.n_new, a.is_keyframe) ==
-                   (b.n_detected, b.n_tracked, b.n_inliers, b.n_new, b.is_keyframe) for a, b in zip(res[:m], ores[:m]))
-        out["parity_vs_cpu"] = {"frames": m, "index_sets_identical": bool(same)}
-    pipe.close()
-    ctx.close()
+        same = all((a.n_detected, a.n_tracked, a.n_inliers, a.n_new, a.is_keyframe, a.ba_iterations) ==
+                   (b.n_detected, b.n_tracked, b.n_inliers, b.n_new, b.is_keyframe, b.ba_iterations) and
+                   list(a.pose7) == list(b.pose7) for a, b in zip(res[:m], ores[:m]))
+        out["parity_vs_cpu"] = {"frames": m, "index_sets_and_poses_identical": bool(same)}
+    for st in streams:
+        st.close()
     if dist is not None:
         dist.destroy_process_group()
     return out if rank == 0 else None
