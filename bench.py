@@ -210,6 +210,17 @@ def run_kitti(args):
     return out if rank == 0 else None
 
 
+def pmc_traffic_bytes(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate runs, KB units, no 2x correction applied because
+    the kernel's loads are byte-granular gathers, which the guide calls uncalibrated).  None if absent."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))[kernel_name]
+        return (t["fetch_kb_per_launch"] + t["write_kb_per_launch"]) * 1024.0
+    except Exception:
+        return None
+
+
 def roofline_for(kernel, avg_us, res, launches, steps):
     """Algorithmic work per launch / measured average launch duration."""
     A = W * H
@@ -221,8 +232,9 @@ def roofline_for(kernel, avg_us, res, launches, steps):
         byts = 2 * 1.33 * A
         gbs = byts / (avg_us * 1e-6) / 1e9
         return {"kernel": "lk_fb_kernel", "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": avg_us, "launches": launches,
-                "note": f"{n:.0f} features/launch; per feature 2 directions x 4 levels x <=30 iterations x 441-px window"}
+                "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_traffic_bytes("lk_fb_kernel"), "avg_launch_us": avg_us,
+                "launches": launches, "algorithmic_bytes_per_launch": byts,
+                "note": f"latency/integer-VALU bound, not HBM bound (DESIGN.md section 4); {n:.0f} features/launch; per feature 2 directions x 4 levels x <=30 iterations x 441-px window"}
     if kernel == "corner_response":
         B = launches and (len(res))
         byts = 5.0 * A * B  # read u8, write f32 response per frame, B frames per launch
