@@ -52,8 +52,15 @@ struct LmDev {
   int have_scale;   // Jacobi scales fixed (first linearisation done)
   int step_valid;   // the solve kernel produced a step for this iteration
   int grad_check;   // previous step accepted: test the gradient of the new linearisation
+  unsigned bar;     // grid-barrier arrival counter of the persistent kernel (monotone within a launch)
+  int abort;        // a bounded spin gave up (never expected; keeps a bug from hanging the GPU)
   double sc[6 * 63], Df[6 * 63];
 };
+
+// Cross-workgroup reads inside the persistent kernel go through agent-scope (sc1) loads: never the scalar
+// cache, never a stale L1 line (cdna_hip_programming.md Guideline 16, Pitfall 6).
+__device__ __forceinline__ int ldv(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ldv(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 struct BaDev {
   int K = 0, n = 0, M = 0, L = 0, C = 0;
@@ -165,10 +172,10 @@ __device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius,
   const double* poses_ = P.poses;
   const double* points_ = P.points;
   if (P.lm) {
-    if (P.lm->done) return;
-    const int c = P.lm->cur;
+    if (ldv(&P.lm->done)) return;
+    const int c = ldv(&P.lm->cur);
     poses_ = P.step[c] + (P.n > 0 ? P.n : 1); points_ = P.pts[c];
-    radius = P.lm->radius; first_pass = !P.lm->have_scale;
+    radius = ldv(&P.lm->radius); first_pass = !ldv(&P.lm->have_scale);
   }
   extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2
   const int n = P.n;
@@ -333,11 +340,11 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
   double* cand_points_ = P.cand_points;
   const double* dc_ = P.dc;
   if (P.lm) {
-    if (P.lm->done || !P.lm->step_valid) return;
-    const int c = P.lm->cur, nn = P.n > 0 ? P.n : 1;
+    if (ldv(&P.lm->done) || !ldv(&P.lm->step_valid)) return;
+    const int c = ldv(&P.lm->cur), nn = P.n > 0 ? P.n : 1;
     poses_ = P.step[c] + nn; points_ = P.pts[c];
     dc_ = P.step[1 - c]; cand_poses_ = P.step[1 - c] + nn; cand_points_ = P.pts[1 - c];
-    radius = P.lm->radius;
+    radius = ldv(&P.lm->radius);
   }
   __shared__ double sAcc[4];
   if (threadIdx.x < 4) sAcc[threadIdx.x] = 0.0;
@@ -456,18 +463,18 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
 // (36 values), F pose vectors (18 values), 1 scalar pair; lane = (segment, element).
 constexpr int RSEG = 28;
 __device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
-  if (P.lm && P.lm->done) return;
+  if (P.lm && ldv(&P.lm->done)) return;
   if ((int)blockIdx.x >= (P.K - 1) * (P.K - 1) + (P.K - 1) + 1) return;
   __shared__ double sP[RSEG][36];
   const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
   const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
   const int stride = d < F * F ? 36 : (d < F * F + F ? 18 : 4);
   const double* base = d < F * F ? P.pairB : (d < F * F + F ? P.obsV : P.lmV);
-  const int seg = tid / width, e = tid % width;
   const int nd = F * F + F + 1;
   const int e0 = P.list_start[d], len = P.list_start[nd + 1 + d] - e0;
   const int seglen = (len + RSEG - 1) / RSEG;
-  if (seg < RSEG) {
+  for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {  // one pass with 1024 threads, two with 512
+    const int seg = item / width, e = item % width;
     double acc = 0.0;
     const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
     const double* src = base + (size_t)e0 * stride + e;
@@ -502,7 +509,7 @@ __device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
 }
 
 __device__ __forceinline__ void ba_reduce2_body(const BaDev& P) {
-  if (P.lm && (P.lm->done || !P.lm->step_valid)) return;
+  if (P.lm && (ldv(&P.lm->done) || !ldv(&P.lm->step_valid))) return;
   __shared__ double sP[RSEG][4];
   __shared__ double sOut[4];
   const int F = P.K - 1, tid = threadIdx.x;
@@ -537,54 +544,73 @@ __device__ __forceinline__ void ba_reduce2_body(const BaDev& P) {
   // ---- step control (same statements, same order as the host loop in ba_lm / oracle/ora_ba.cpp)
   LmDev& S = *P.lm;
   const int K = P.K, nn = P.n > 0 ? P.n : 1;
-  const double* poses = P.step[S.cur] + nn;
-  const double* cand = P.step[1 - S.cur] + nn;
+  const int cur = ldv(&S.cur);
+  double radius = ldv(&S.radius), decrease_factor = ldv(&S.decrease_factor), cost = ldv(&S.cost);
+  const double* poses = P.step[cur] + nn;
+  const double* cand = P.step[1 - cur] + nn;
   const double cost_new = sOut[0];
-  const double model_change = S.mcc + sOut[1];
+  const double model_change = ldv(&S.mcc) + sOut[1];
   double step2 = sOut[2], x2 = sOut[3];
   for (int k = 1; k < K; ++k)
     for (int a = 0; a < 7; ++a) {
-      const double dd = cand[7 * k + a] - poses[7 * k + a];
+      const double pv = ldv(&poses[7 * k + a]);
+      const double dd = ldv(&cand[7 * k + a]) - pv;
       step2 += dd * dd;
-      x2 += poses[7 * k + a] * poses[7 * k + a];
+      x2 += pv * pv;
     }
-  auto publish = [&]() {
-    P.done_host[1] = S.iterations; P.done_host[2] = S.successful; P.done_host[3] = S.termination; P.done_host[4] = S.cur;
+  auto publish = [&](int cur_now, double cost_now) {
+    P.done_host[1] = ldv(&S.iterations); P.done_host[2] = ldv(&S.successful); P.done_host[3] = S.termination; P.done_host[4] = cur_now;
     double* dh = reinterpret_cast<double*>(P.done_host + 6);
-    dh[0] = S.initial_cost; dh[1] = S.cost;
+    dh[0] = ldv(&S.initial_cost); dh[1] = cost_now;
     __threadfence_system();
     P.done_host[0] = 1;
   };
-  if (!(model_change > 0)) { S.radius /= S.decrease_factor; S.decrease_factor *= 2; return; }
-  if (sqrt(step2) <= S.parameter_tol * (sqrt(x2) + S.parameter_tol)) { S.termination = 0; S.done = 1; publish(); return; }
-  const double cost_change = S.cost - cost_new;
-  if (fabs(cost_change) <= S.function_tol * S.cost) {
-    if (cost_change > 0) { S.cur = 1 - S.cur; S.cost = cost_new; }
-    S.termination = 0; S.done = 1; publish();
+  if (!(model_change > 0)) { S.radius = radius / decrease_factor; S.decrease_factor = decrease_factor * 2; return; }
+  if (sqrt(step2) <= S.parameter_tol * (sqrt(x2) + S.parameter_tol)) { S.termination = 0; S.done = 1; publish(cur, cost); return; }
+  const double cost_change = cost - cost_new;
+  if (fabs(cost_change) <= S.function_tol * cost) {
+    int c2 = cur;
+    if (cost_change > 0) { c2 = 1 - cur; S.cur = c2; S.cost = cost_new; cost = cost_new; }
+    S.termination = 0; S.done = 1; publish(c2, cost);
     return;
   }
   const double rho = cost_change / model_change;
   if (rho > MIN_REL_DECREASE) {
-    S.cur = 1 - S.cur; S.cost = cost_new; ++S.successful;
+    S.cur = 1 - cur; S.cost = cost_new; S.successful = ldv(&S.successful) + 1;
     const double t = 2.0 * rho - 1.0;
-    S.radius = S.radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-    S.radius = fmin(MAX_RADIUS, S.radius);
+    radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    S.radius = fmin(MAX_RADIUS, radius);
     S.decrease_factor = 2.0;
     S.grad_check = 1;
   } else {
-    S.radius /= S.decrease_factor; S.decrease_factor *= 2;
+    S.radius = radius / decrease_factor; S.decrease_factor = decrease_factor * 2;
   }
 }
 
 // Reduced camera system: scaling, LM diagonal, Cholesky (column sweep, same operation order as the host
-// cholesky_solve), pose step and candidate poses.  One workgroup; n <= 6*63.
+// cholesky_solve), pose step and candidate poses.  One workgroup (WAVE = false) or ONE wavefront of a larger
+// workgroup (WAVE = true, the persistent kernel: LDS traffic of a single wave is ordered, so a workgroup-scope
+// fence + wave barrier replaces s_barrier and the other 15 wavefronts do not have to take part).
+template <bool WAVE>
 __device__ __forceinline__ void ba_solve_body(const BaDev& P) {
   LmDev& S = *P.lm;
-  if (S.done) return;
-  extern __shared__ double sm[];  // Sm (n*n) | b (n)
+  auto SYNC = [&]() {
+    if (WAVE) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+      __syncthreads();
+    }
+  };
+  if (ldv(&S.done)) return;
+  extern __shared__ double sm[];  // Sm (n*n) | b (n) | sc (n) | Df (n)
   const int n = P.n, K = P.K, tid = threadIdx.x, nn = n > 0 ? n : 1;
+  const int T = WAVE ? 64 : (int)blockDim.x;
   double* Sm = sm;
   double* sB = sm + (size_t)n * n;
+  double* sSc = sB + nn;
+  double* sDf = sSc + nn;
   __shared__ int sFail;
   const double* pay = P.pay1;
   const double* gred = pay + (size_t)n * n;
@@ -601,51 +627,56 @@ __device__ __forceinline__ void ba_solve_body(const BaDev& P) {
     sFail = 0;
     S.step_valid = 0;
     bool check = false;
-    if (!S.have_scale) {
-      for (int a = 0; a < n; ++a) S.sc[a] = 1.0 / (1.0 + sqrt(dU[a]));
+    if (!ldv(&S.have_scale)) {
+      for (int a = 0; a < n; ++a) S.sc[a] = 1.0 / (1.0 + sqrt(ldv(&dU[a])));
       S.have_scale = 1;
-      S.cost = pay[(size_t)n * n + 3 * n];
+      S.cost = ldv(&pay[(size_t)n * n + 3 * n]);
       S.initial_cost = S.cost;
       check = true;
-    } else if (S.grad_check) {
+    } else if (ldv(&S.grad_check)) {
       check = true;
     }
     S.grad_check = 0;
     if (check) {
-      double g2 = pay[(size_t)n * n + 3 * n + 1];
-      for (int a = 0; a < n; ++a) g2 += gc[a] * gc[a];
+      double g2 = ldv(&pay[(size_t)n * n + 3 * n + 1]);
+      for (int a = 0; a < n; ++a) { const double g = ldv(&gc[a]); g2 += g * g; }
       if (sqrt(g2) <= S.gradient_tol) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
     }
     if (!sFail) {
-      if (S.iterations >= S.max_iterations) { S.termination = 1; S.done = 1; publish(); sFail = 2; }
-      else if (S.radius <= MIN_RADIUS) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
-      else ++S.iterations;
+      if (ldv(&S.iterations) >= S.max_iterations) { S.termination = 1; S.done = 1; publish(); sFail = 2; }
+      else if (ldv(&S.radius) <= MIN_RADIUS) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
+      else S.iterations = ldv(&S.iterations) + 1;
     }
   }
-  __syncthreads();
+  SYNC();
   if (sFail) return;
-  const int T = blockDim.x;  // 64 (one wavefront, n < 64) or 128
-  const double radius = S.radius;
-  for (int a = tid; a < n; a += T) S.Df[a] = fmin(fmax(dU[a] * S.sc[a] * S.sc[a], MIN_DIAG), MAX_DIAG) / radius;
-  __syncthreads();
+  const double radius = ldv(&S.radius);
+  // Jacobi scales were written by lane 0 (possibly just now): re-read them through L2, keep copies in LDS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int a = tid; a < n; a += T) {
+    const double sca = ldv(&S.sc[a]);
+    sSc[a] = sca;
+    sDf[a] = fmin(fmax(ldv(&dU[a]) * sca * sca, MIN_DIAG), MAX_DIAG) / radius;
+  }
+  SYNC();
   for (int i = tid; i < n * n; i += T) {
     const int a = i / n, b = i % n;
-    double v = pay[i] * S.sc[a] * S.sc[b];
-    if (a == b) v += S.Df[a];
+    double v = ldv(&pay[i]) * sSc[a] * sSc[b];
+    if (a == b) v += sDf[a];
     Sm[i] = v;
   }
-  for (int a = tid; a < n; a += T) sB[a] = -(gred[a] + gc[a]) * S.sc[a];
-  __syncthreads();
+  for (int a = tid; a < n; a += T) sB[a] = -(ldv(&gred[a]) + ldv(&gc[a])) * sSc[a];
+  SYNC();
   // Cholesky, column by column (row i's dot products run sequentially in k, as on the host).  The right-hand
   // side rides along as an extra row: y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj is exactly the forward
   // substitution, product for product.
   for (int j = 0; j < n; ++j) {
     if (tid == 0) {
-      double s = Sm[(size_t)j * n + j];
-      for (int k = 0; k < j; ++k) s -= Sm[(size_t)j * n + k] * Sm[(size_t)j * n + k];
-      if (!(s > 0)) sFail = 1; else Sm[(size_t)j * n + j] = sqrt(s);
+      double sd = Sm[(size_t)j * n + j];
+      for (int k = 0; k < j; ++k) sd -= Sm[(size_t)j * n + k] * Sm[(size_t)j * n + k];
+      if (!(sd > 0)) sFail = 1; else Sm[(size_t)j * n + j] = sqrt(sd);
     }
-    __syncthreads();
+    SYNC();
     if (sFail) break;
     const double l = Sm[(size_t)j * n + j];
     for (int i = j + 1 + tid; i <= n; i += T) {
@@ -659,38 +690,44 @@ __device__ __forceinline__ void ba_solve_body(const BaDev& P) {
         sB[j] = v / l;
       }
     }
-    __syncthreads();
+    SYNC();
   }
   if (sFail) {  // not positive definite: an invalid step
-    if (tid == 0) { S.radius /= S.decrease_factor; S.decrease_factor *= 2; }
+    if (tid == 0) { S.radius = ldv(&S.radius) / S.decrease_factor; S.decrease_factor *= 2; }
     return;
   }
   // backward substitution (k descending) as a column sweep
   for (int k = n - 1; k >= 0; --k) {
     if (tid == 0) sB[k] = sB[k] / Sm[(size_t)k * n + k];
-    __syncthreads();
+    SYNC();
     const double bk = sB[k];
     for (int i = tid; i < k; i += T) sB[i] -= Sm[(size_t)k * n + i] * bk;
-    __syncthreads();
+    SYNC();
   }
   // step, model change (pose part), candidate poses
-  const int c = S.cur;
+  const int c = ldv(&S.cur);
   double* dc = P.step[1 - c];
   const double* poses = P.step[c] + nn;
   double* cand = P.step[1 - c] + nn;
   if (tid == 0) {
     double mcc = 0;
     for (int a = 0; a < n; ++a) {
-      mcc += 0.5 * sB[a] * (S.Df[a] * sB[a] - gc[a] * S.sc[a]);
-      dc[a] = sB[a] * S.sc[a];
+      mcc += 0.5 * sB[a] * (sDf[a] * sB[a] - ldv(&gc[a]) * sSc[a]);
+      S.Df[a] = sDf[a];
     }
     S.mcc = mcc;
     S.step_valid = 1;
   }
-  __syncthreads();
+  for (int a = tid; a < n; a += T) dc[a] = sB[a] * sSc[a];
   for (int k = tid; k < K; k += T) {
-    if (k == 0) { for (int a = 0; a < 7; ++a) cand[a] = poses[a]; }
-    else plus_pose(poses + 7 * k, dc + 6 * (k - 1), cand + 7 * k);
+    double pk[7], dk[6], out[7];
+    for (int a = 0; a < 7; ++a) pk[a] = ldv(&poses[7 * k + a]);
+    if (k == 0) { for (int a = 0; a < 7; ++a) cand[a] = pk[a]; }
+    else {
+      for (int a = 0; a < 6; ++a) dk[a] = sB[6 * (k - 1) + a] * sSc[6 * (k - 1) + a];
+      plus_pose(pk, dk, out);
+      for (int a = 0; a < 7; ++a) cand[7 * k + a] = out[a];
+    }
   }
 }
 
@@ -700,12 +737,61 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius) { ba_backsub_body(P, radius); }
 __global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) { ba_reduce1_body(P); }
 __global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) { ba_reduce2_body(P); }
-__global__ __launch_bounds__(128) void ba_solve_kernel(BaDev P) { ba_solve_body(P); }
+__global__ __launch_bounds__(128) void ba_solve_kernel(BaDev P) { ba_solve_body<false>(P); }
 __global__ __launch_bounds__(64) void ba_linearize_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_linearize_body(P, 0.0, 0); }
 __global__ __launch_bounds__(64) void ba_backsub_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_backsub_body(P, 0.0); }
 __global__ __launch_bounds__(1024) void ba_reduce1_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_reduce1_body(P); }
 __global__ __launch_bounds__(128) void ba_reduce2_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_reduce2_body(P); }
-__global__ __launch_bounds__(128) void ba_solve_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_solve_body(P); }
+__global__ __launch_bounds__(128) void ba_solve_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_solve_body<false>(P); }
+
+// ---- persistent single-launch solve: the five phases of an LM iteration separated by grid barriers
+// (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "barrier-counter": every storing wave drains,
+// workgroup barrier, lane-0 agent release, agent atomic arrive, relaxed sc1 poll with s_sleep, ONE agent acquire,
+// workgroup barrier).  All workgroups are trivially co-resident (grid <= 128 x 512 threads on 256 CUs); every spin
+// is bounded and raises LmDev::abort instead of hanging.
+__device__ __forceinline__ bool grid_barrier(LmDev* lm, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  __shared__ int sAbort;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(&lm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    int ab = 0;
+    while (__hip_atomic_load(&lm->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 21) || __hip_atomic_load(&lm->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&lm->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab = 1;
+        break;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    sAbort = ab;
+  }
+  __syncthreads();
+  return sAbort == 0;
+}
+
+__global__ __launch_bounds__(512) void ba_persistent_kernel(BaDev P, int max_loops) {
+  unsigned epoch = 0;
+  const unsigned G = gridDim.x;
+  for (int it = 0; it < max_loops; ++it) {
+    if (ldv(&P.lm->done)) break;  // written by workgroup 0 before the last barrier: uniform across the grid
+    ba_linearize_body(P, 0.0, 0);
+    if (!grid_barrier(P.lm, ++epoch * G)) break;
+    ba_reduce1_body(P);
+    if (!grid_barrier(P.lm, ++epoch * G)) break;
+    if (blockIdx.x == 0 && threadIdx.x < 64) ba_solve_body<true>(P);
+    if (!grid_barrier(P.lm, ++epoch * G)) break;
+    ba_backsub_body(P, 0.0);
+    if (!grid_barrier(P.lm, ++epoch * G)) break;
+    if (blockIdx.x == 0) ba_reduce2_body(P);
+    if (!grid_barrier(P.lm, ++epoch * G)) break;
+  }
+}
 
 // ----------------------------------------------------------------------------- host side
 namespace {
@@ -1043,7 +1129,7 @@ static int ba_lm_device(svo_ba* ba, svo_ba_summary* sum) {
   const int chunk = 3;  // iterations between two polls of the done flag (typical solve: 5-6 iterations)
   const int Kmax = ba->max_poses, nmax = 6 * (Kmax - 1);
   const int nd_max = (Kmax - 1) * (Kmax - 1) + (Kmax - 1) + 1;
-  const size_t solve_lds_max = ((size_t)nmax * nmax + nmax + 8) * sizeof(double);
+  const size_t solve_lds_max = ((size_t)nmax * nmax + 3 * nmax + 8) * sizeof(double);
   const int solve_threads = nmax < 64 ? 64 : 128;
   if (!ba->graph_exec) {
     if (solve_lds_max > 64 * 1024)
@@ -1110,8 +1196,69 @@ static int ba_lm_device(svo_ba* ba, svo_ba_summary* sum) {
   return SVO_OK;
 }
 
+// One launch per solve: the whole LM loop runs in ba_persistent_kernel.
+static int ba_lm_persistent(svo_ba* ba, svo_ba_summary* sum) {
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  hipStream_t st = ba->stream;
+  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
+  const auto t_begin = std::chrono::steady_clock::now();
+  int* done_host = reinterpret_cast<int*>(ba->h_pin + ba->cap_pay1 + 16);
+  double* h_fin = reinterpret_cast<double*>(done_host + 6);
+  LmDev* h_init = reinterpret_cast<LmDev*>(ba->h_pin + ba->cap_pay1 + 32);
+  memset(h_init, 0, sizeof(LmDev));
+  h_init->radius = ba->opt.initial_radius; h_init->decrease_factor = 2.0;
+  h_init->function_tol = ba->opt.function_tolerance; h_init->gradient_tol = ba->opt.gradient_tolerance;
+  h_init->parameter_tol = ba->opt.parameter_tolerance; h_init->max_iterations = ba->opt.max_iterations;
+  h_init->termination = 1;
+  memset(done_host, 0, 6 * sizeof(int));
+  h_fin[0] = h_fin[1] = 0.0;
+  d.lm = ba->d_lm;
+  d.pts[0] = d.points; d.pts[1] = d.cand_points;
+  d.step[0] = ba->step_buf[0]; d.step[1] = ba->step_buf[1];
+  d.done_host = done_host;
+  d.pay1_out = d.pay1; d.pay2_out = d.pay2;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_lm, h_init, sizeof(LmDev), hipMemcpyHostToDevice, st));
+  const int nd = (K - 1) * (K - 1) + (K - 1) + 1;
+  int grid = std::max(nd, svo_div_up(d.C, 8));
+  if (grid > 128) grid = 128;  // both the chunk loop and ... (reduce1 needs grid >= nd: K <= 11)
+  if (grid < nd) { d.lm = nullptr; ctx->err = "ba: window too large for the persistent kernel"; return SVO_ERR_INVALID; }
+  const size_t lds = ((size_t)n * n + 3 * (size_t)nn + 8) * sizeof(double);
+  hipLaunchKernelGGL(ba_persistent_kernel, dim3(grid), dim3(512), lds, st, d, ba->opt.max_iterations + 2);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  const bool done = done_host[0] != 0;
+  int cur = 0, iterations = 0, successful = 0, termination = 1;
+  double initial_cost = 0, cost = 0;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_init, ba->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (h_init->abort) { d.lm = nullptr; ctx->err = "ba: persistent kernel grid barrier timed out"; return SVO_ERR_HIP; }
+  if (done) {
+    iterations = done_host[1]; successful = done_host[2]; termination = done_host[3]; cur = done_host[4];
+    initial_cost = h_fin[0]; cost = h_fin[1];
+  } else {
+    iterations = h_init->iterations; successful = h_init->successful; termination = 1; cur = h_init->cur;
+    initial_cost = h_init->initial_cost; cost = h_init->cost;
+  }
+  d.lm = nullptr;
+  d.points = d.pts[cur]; d.cand_points = d.pts[1 - cur];
+  d.poses = d.step[cur] + nn; d.cand_poses = d.step[1 - cur] + nn; d.dc = d.step[1 - cur];
+  double* h_p = ba->h_pin;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_p, d.poses, sizeof(double) * 7 * K, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  ba->h_poses.assign(h_p, h_p + 7 * (size_t)K);
+  ba->h_cand_poses = ba->h_poses;
+  if (sum) {
+    sum->iterations = iterations; sum->successful_steps = successful; sum->termination = termination;
+    sum->initial_cost = initial_cost; sum->final_cost = cost;
+    sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+  return SVO_OK;
+}
+
 // The LM loop (mirrors oracle/ora_ba.cpp step for step).
 static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
+  if (ba->d.det && !ba->allreduce && getenv("SVO_BA_PERSISTENT") && ba->d.K <= 11 && !(ba->opt.max_time_s > 0)) return ba_lm_persistent(ba, sum);
   // Measured on MI355X (bench workload, ~14 LM iterations per solve): host-driven loop 81 us/iteration,
   // device-resident loop with plain launches 97 us, hipGraph replay 81 us + idle tail iterations (7.6 us of dead
   // time per graph node).  The host-driven loop stays the default; SVO_BA_DEVICE_LM=1 selects the graph path.
