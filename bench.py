@@ -54,12 +54,18 @@ def dist_setup(n):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "SVO_BENCH_FORCE_DEVICE" in os.environ:  # rehearsal of the N>1 code path on a one-GPU box (gloo backend)
+        local = int(os.environ["SVO_BENCH_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("SVO_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
         return torch, dist, rank, local, world
     return torch, None, rank, local, world
 

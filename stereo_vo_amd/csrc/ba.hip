@@ -911,6 +911,7 @@ extern "C" void svo_ba_default_options(svo_ba_options* o) {
 extern "C" int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const svo_camera_info* cam,
                              const svo_ba_options* opt, int max_landmarks, int max_observations) {
   if (!ctx || !out || !cam) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, window_size >= 1 && window_size <= 64, "ba_create: window size must be 1..64");
   SVO_REQUIRE(ctx, max_landmarks >= 1 && max_observations >= 1, "ba_create: capacities must be positive");
   svo_ba* ba = new svo_ba();
@@ -1444,6 +1445,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
 extern "C" int svo_ba_load_problem(svo_ba* ba, int n_poses, const double* poses7, int n_points, const double* points3,
                                    int n_obs, const int32_t* obs_pose, const int32_t* obs_point, const double* obs_uv) {
   if (!ba) return SVO_ERR_INVALID;
+  svo_use_device(ba->ctx);
   SVO_REQUIRE(ba->ctx, poses7 && (n_points == 0 || points3) && (n_obs == 0 || (obs_pose && obs_point && obs_uv)),
               "ba_load_problem: null buffer");
   return ba_upload(ba, n_poses, poses7, n_points, points3, n_obs, obs_pose, obs_point, obs_uv);
@@ -1451,6 +1453,7 @@ extern "C" int svo_ba_load_problem(svo_ba* ba, int n_poses, const double* poses7
 
 extern "C" int svo_ba_solve_problem(svo_ba* ba, svo_ba_summary* summary) {
   if (!ba) return SVO_ERR_INVALID;
+  svo_use_device(ba->ctx);
   SVO_REQUIRE(ba->ctx, ba->d.K >= 1, "ba_solve_problem: no problem loaded");
   return ba_lm(ba, summary);
 }
@@ -1531,6 +1534,7 @@ extern "C" int svo_ba_get_points(svo_ba* ba, const int64_t* ids, int n, float* x
 
 extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
   if (!ba) return SVO_ERR_INVALID;
+  svo_use_device(ba->ctx);
   if (summary) memset(summary, 0, sizeof(*summary));
   if (!ba->new_frame_added) return SVO_OK;  // src/bundle_adjuster.cpp:138
   const int K = (int)ba->window.size();

@@ -78,6 +78,9 @@ struct SvoProfScope {
 
 inline int svo_div_up(int a, int b) { return (a + b - 1) / b; }
 
+// Every C-ABI entry point may be called from a thread that never selected the context's GPU.
+inline void svo_use_device(const svo_ctx* c) { if (c) (void)hipSetDevice(c->device); }
+
 // Scratch carve-out from ctx->d_ws for host-pointer wrappers.
 struct SvoScratch {
   svo_ctx* ctx;

@@ -381,6 +381,7 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
 static int corner_check_args(svo_ctx* ctx, const void* img, int batch, int W, int H, int row_stride,
                              int max_corners, const void* xy, const void* n) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, img && xy && n, "corner_detect: null buffer");
   SVO_REQUIRE(ctx, W >= 3 && H >= 3 && W <= ctx->lim.max_width && H <= ctx->lim.max_height && row_stride >= W,
               "corner_detect: image size outside the limits given to svo_create");
@@ -437,6 +438,7 @@ extern "C" int svo_corner_detect(svo_ctx* ctx, const uint8_t* img, int width, in
 extern "C" int svo_corner_response(svo_ctx* ctx, const uint8_t* img, int width, int height, int row_stride,
                                    float* eig) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, img && eig, "corner_response: null buffer");
   SVO_REQUIRE(ctx, width >= 3 && height >= 3 && width <= ctx->lim.max_width && height <= ctx->lim.max_height,
               "corner_response: image size outside limits");

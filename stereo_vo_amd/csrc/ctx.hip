@@ -9,12 +9,14 @@ extern "C" void* svo_stream(svo_ctx* ctx) { return ctx ? (void*)ctx->stream : nu
 
 extern "C" int svo_sync(svo_ctx* ctx) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return SVO_OK;
 }
 
 extern "C" int svo_profile_select(svo_ctx* ctx, const char* kernel) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   static const char* names[] = {"", "corner_response", "corner_nms", "corner_select", "pyr_down", "lk_fb", "stereo_at",
                                 "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub"};
   int tag = 0;

@@ -170,6 +170,7 @@ extern "C" int svo_triangulate(svo_ctx* ctx, const float* xy, const float* disp,
                                float focal, float cx, float cy, float baseline, float* kept_xy, float* xyz,
                                int* kept_index, int* n_kept) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, n >= 0 && pose16 && n_kept && (n == 0 || (xy && disp && kept_xy && xyz)), "triangulate: null buffer");
   *n_kept = 0;
   if (n == 0) return SVO_OK;
@@ -202,6 +203,7 @@ extern "C" int svo_triangulate(svo_ctx* ctx, const float* xy, const float* disp,
 extern "C" int svo_dedup(svo_ctx* ctx, const float* detected_xy, int n_detected, const float* tracked_xy,
                          int n_tracked, float min_distance, float* kept_xy, int* n_kept) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, n_detected >= 0 && n_tracked >= 0 && n_kept, "dedup: bad sizes");
   SVO_REQUIRE(ctx, (n_detected == 0 || (detected_xy && kept_xy)) && (n_tracked == 0 || tracked_xy), "dedup: null buffer");
   *n_kept = 0;

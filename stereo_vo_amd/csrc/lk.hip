@@ -411,6 +411,7 @@ int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, 
 
 static int lk_check(svo_ctx* ctx, const void* a, const void* b, int w, int h, int stride) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, a && b, "lk: null image");
   SVO_REQUIRE(ctx, w >= 8 && h >= 8 && w <= ctx->lim.max_width && h <= ctx->lim.max_height && stride >= w,
               "lk: image size outside limits");

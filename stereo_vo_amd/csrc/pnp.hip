@@ -380,6 +380,7 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, i
                               double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence,
                               int* inliers, int* n_inliers) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, n >= 0 && rvec3 && tvec3 && n_inliers && (n == 0 || (xyz && xy && inliers)), "pnp_ransac: null buffer");
   SVO_REQUIRE(ctx, iterations >= 1 && iterations <= 1024, "pnp_ransac: iterations must be 1..1024");
   *n_inliers = 0;

@@ -36,6 +36,7 @@ extern "C" int svo_reproj_eval_dev(svo_ctx* ctx, int n, const double* pose7, con
                                    const double* obs2, double focal, double cx, double cy, double* r2,
                                    double* jpose14, double* jpoint6) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (pose7 && point3 && obs2 && r2)), "reproj_eval: null buffer");
   if (n == 0) return SVO_OK;
   const int block = 256;
@@ -50,6 +51,7 @@ extern "C" int svo_reproj_eval(svo_ctx* ctx, int n, const double* pose7, const d
                                const double* obs2, double focal, double cx, double cy, double* r2,
                                double* jpose14, double* jpoint6) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, n >= 0 && (n == 0 || (pose7 && point3 && obs2 && r2)), "reproj_eval: null buffer");
   hipStream_t st = ctx->stream;
   // host batches are streamed through the fixed workspace in chunks (34 doubles per observation)

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void stereo_dense_kernel(const uint8_t* __rest
 // ----------------------------------------------------------------------------- host side
 static int stereo_check(svo_ctx* ctx, const void* l, const void* r, int W, int H, int stride, int ndisp, int block) {
   if (!ctx) return SVO_ERR_INVALID;
+  svo_use_device(ctx);
   SVO_REQUIRE(ctx, l && r, "stereo: null image");
   SVO_REQUIRE(ctx, W >= 3 && H >= 3 && W <= ctx->lim.max_width && H <= ctx->lim.max_height && stride >= W,
               "stereo: image size outside limits");

@@ -481,6 +481,7 @@ extern "C" void svo_pipeline_default_params(svo_pipeline_params* p) {
 
 extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_pipeline_params* p) {
   if (!ctx || !out || !p) return SVO_ERR_INVALID;
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   SVO_REQUIRE(ctx, p->width >= 32 && p->height >= 32 && p->width <= ctx->lim.max_width && p->height <= ctx->lim.max_height,
               "pipeline_create: image size outside the context limits");
   SVO_REQUIRE(ctx, p->max_corners >= 4 && p->max_corners <= ctx->lim.max_corners && p->max_features >= 4 &&
@@ -512,6 +513,7 @@ extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
 
 extern "C" int svo_pipeline_reset(svo_pipeline* p) {
   if (!p) return SVO_ERR_INVALID;
+  (void)hipSetDevice(p->ctx->device);
   p->adjuster->wait();
   p->proc->reset();
   return SVO_OK;
@@ -525,6 +527,7 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
   const int W = p->prm.width, H = p->prm.height;
   const size_t istride = (size_t)W * H;
   ctx->err.clear();
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the calling thread may never have selected this GPU
   int rc = p->proc->prepare_batch(left, batch, W, H);
   if (rc) return rc;
   // The reference runs process() then bundle_adjust() per frame (src/vo_node.cpp:141-148).  Here the solve of
@@ -585,6 +588,7 @@ extern "C" int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, 
 
 extern "C" int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n) {
   if (!p || !n) return SVO_ERR_INVALID;
+  (void)hipSetDevice(p->ctx->device);
   p->adjuster->wait();
   std::vector<svo::Point2f> f;
   std::vector<size_t> id;
