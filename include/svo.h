@@ -286,6 +286,24 @@ int svo_synth_render(const svo_synth_params* p, int frame, uint8_t* left, uint8_
  * src/kitti_node.cpp:47-50). */
 int svo_synth_pose(const svo_synth_params* p, int frame, double* rt12);
 
+/* ------------------------------------------------ dataset ingestion, driver, ATE --
+ * KITTI odometry layout read by the reference's kitti_node (src/kitti_node.cpp:37-68): images
+ * <data_path><SS>/image_0|image_1/%06d.png (8-bit gray), poses <data_path>data_odometry_poses/dataset/poses/SS.txt
+ * (12 doubles per row, row-major 3x4 [R|t], camera in world).  PNG (zlib only) and PGM are decoded. */
+int svo_image_read_gray(const char* path, uint8_t* buf, size_t capacity, int* width, int* height);
+int svo_kitti_read_poses(const char* poses_file, double* rt12, int capacity_frames, int* n_frames);
+/* RMSE of positions after the best rigid (with_scale: similarity) alignment est -> gt. */
+int svo_ate_rmse(const double* est_xyz, const double* gt_xyz, int n, int with_scale, double* rmse);
+typedef struct svo_run_stats {
+  int frames, keyframes;
+  double ate_rmse; /* vs the poses file, evaluated at keyframes, rigid alignment; -1 without ground truth */
+  double seconds;
+} svo_run_stats;
+/* Non-ROS driver with vo_node's loop semantics (src/vo_node.cpp:141-150): process + bundle_adjust per frame,
+ * one camera-in-world pose per processed frame written to traj_rt12 (max_frames x 12, may be NULL). */
+int svo_kitti_run(svo_ctx* ctx, const svo_pipeline_params* params, const char* data_path, int sequence,
+                  int max_frames, double* traj_rt12, svo_run_stats* stats);
+
 #ifdef __cplusplus
 }
 #endif

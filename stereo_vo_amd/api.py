@@ -73,6 +73,7 @@ SYMBOLS = [
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
+    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run",
 ]
 
 
@@ -442,3 +443,43 @@ class Pipeline:
         n = C.c_int(0)
         self.ctx._chk(self.L.svo_pipeline_get_tracked(self.h, _p(ids), _p(xy), capacity, C.byref(n)), "svo_pipeline_get_tracked")
         return ids[:n.value].copy(), xy[:n.value].copy()
+
+
+class RunStats(C.Structure):
+    _fields_ = [("frames", C.c_int), ("keyframes", C.c_int), ("ate_rmse", C.c_double), ("seconds", C.c_double)]
+
+
+def image_read_gray(path, max_pixels=1 << 24):
+    buf = np.empty(max_pixels, np.uint8)
+    w, h = C.c_int(0), C.c_int(0)
+    rc = lib().svo_image_read_gray(path.encode(), _p(buf), C.c_size_t(max_pixels), C.byref(w), C.byref(h))
+    if rc:
+        raise SvoError(f"svo_image_read_gray({path}) rc={rc}")
+    return buf[:w.value * h.value].reshape(h.value, w.value).copy()
+
+
+def kitti_read_poses(path, max_frames=100000):
+    rt = np.empty((max_frames, 12))
+    n = C.c_int(0)
+    rc = lib().svo_kitti_read_poses(path.encode(), _p(rt), max_frames, C.byref(n))
+    if rc:
+        raise SvoError(f"svo_kitti_read_poses({path}) rc={rc}")
+    return rt[:n.value].reshape(-1, 3, 4).copy()
+
+
+def ate_rmse(est_xyz, gt_xyz, with_scale=False):
+    est_xyz, gt_xyz = _f64(est_xyz), _f64(gt_xyz)
+    out = C.c_double(0)
+    rc = lib().svo_ate_rmse(_p(est_xyz), _p(gt_xyz), est_xyz.shape[0], int(with_scale), C.byref(out))
+    if rc:
+        raise SvoError(f"svo_ate_rmse rc={rc}")
+    return out.value
+
+
+def kitti_run(ctx, params, data_path, sequence, max_frames):
+    """Non-ROS driver over a KITTI-layout directory (data_path must end with '/')."""
+    traj = np.zeros((max_frames, 12))
+    st = RunStats()
+    ctx._chk(lib().svo_kitti_run(ctx.h, C.byref(params), data_path.encode(), sequence, max_frames, _p(traj), C.byref(st)),
+             "svo_kitti_run")
+    return traj[:st.frames].reshape(-1, 3, 4).copy(), st

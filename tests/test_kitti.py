@@ -1,0 +1,100 @@
+"""KITTI-layout ingestion (src/kitti_node.cpp:37-68), the non-ROS driver with vo_node's
+loop semantics (src/vo_node.cpp:141-150) and ATE."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def _export(tmp, n=8, w=496, h=160, focal=300.0):
+    """Write a synthetic sequence in the KITTI odometry layout."""
+    from PIL import Image
+    import stereo_vo_amd as S
+    p = S.synth_default(w, h)
+    p.focal = focal
+    root = str(tmp) + "/"
+    os.makedirs(root + "07/image_0"); os.makedirs(root + "07/image_1")
+    os.makedirs(root + "data_odometry_poses/dataset/poses")
+    frames = []
+    with open(root + "data_odometry_poses/dataset/poses/07.txt", "w") as f:
+        for i in range(n):
+            L, R = S.synth_render(p, i)
+            frames.append((L, R))
+            Image.fromarray(L).save(root + "07/image_0/%06d.png" % i)
+            Image.fromarray(R).save(root + "07/image_1/%06d.png" % i, compress_level=1)
+            f.write(" ".join("%.12e" % v for v in S.synth_pose(p, i).ravel()) + "\n")
+    return p, root, frames
+
+
+def test_png_pgm_decoder_matches_pil(tmp_path):
+    from PIL import Image
+    import stereo_vo_amd as S
+    rng = np.random.default_rng(0)
+    g = rng.integers(0, 256, (37, 53)).astype(np.uint8)
+    smooth = np.clip(np.cumsum(rng.integers(-3, 4, (64, 80)), axis=1) + 120, 0, 255).astype(np.uint8)  # exercises Sub/Up/Paeth
+    for k, img in enumerate((g, smooth)):
+        for opt in (False, True):
+            f = str(tmp_path / f"a{k}{int(opt)}.png")
+            Image.fromarray(img).save(f, optimize=opt)
+            assert np.array_equal(S.image_read_gray(f), img)
+    rgb = rng.integers(0, 256, (20, 31, 3)).astype(np.uint8)
+    f = str(tmp_path / "c.png")
+    Image.fromarray(rgb).save(f)
+    c = rgb.astype(np.int64)
+    exp = ((299 * c[..., 0] + 587 * c[..., 1] + 114 * c[..., 2] + 500) // 1000).astype(np.uint8)
+    assert np.array_equal(S.image_read_gray(f), exp)
+    Image.fromarray((g.astype(np.uint32) * 257).astype(np.uint16)).save(str(tmp_path / "d.png"))  # 16-bit gray
+    assert np.array_equal(S.image_read_gray(str(tmp_path / "d.png")), g)
+    with open(tmp_path / "e.pgm", "wb") as fh:
+        fh.write(b"P5\n# comment\n53 37\n255\n" + g.tobytes())
+    assert np.array_equal(S.image_read_gray(str(tmp_path / "e.pgm")), g)
+    with pytest.raises(S.SvoError):
+        S.image_read_gray(str(tmp_path / "missing.png"))
+
+
+def test_poses_file_and_ate(tmp_path):
+    import stereo_vo_amd as S
+    p, root, _ = _export(tmp_path, n=3, w=64, h=48)
+    rt = S.kitti_read_poses(root + "data_odometry_poses/dataset/poses/07.txt")
+    assert rt.shape == (3, 3, 4) and np.allclose(rt[2], S.synth_pose(p, 2), atol=1e-11)
+    rng = np.random.default_rng(1)
+    gt = np.cumsum(rng.normal(0, 1, (50, 3)), axis=0)
+    a = 0.7
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    est = (gt - [1, 2, 3]) @ Rz          # a rigidly moved copy: ATE must vanish
+    assert S.ate_rmse(est, gt) < 1e-9
+    assert S.ate_rmse(est * 0.5, gt, with_scale=True) < 1e-9 and S.ate_rmse(est * 0.5, gt) > 0.1
+    noisy = est + rng.normal(0, 0.05, est.shape)
+    assert 0.05 < S.ate_rmse(noisy, gt) < 0.12
+
+
+@pytest.mark.gpu
+def test_kitti_driver_matches_oracle_and_ground_truth(ctx, tmp_path):
+    import stereo_vo_amd as S
+    n = 10
+    p, root, frames = _export(tmp_path, n=n)
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height, pp.min_feature_distance, pp.ba_max_time_s = p.width, p.height, 12.0, 0.0
+    traj, st = S.kitti_run(ctx, pp, root, 7, n)
+    assert st.frames == n and st.keyframes >= 3
+    o = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=p.width, height=p.height, max_corners=300,
+                   quality=0.1, min_feature_distance=12.0, parallax_thresh=20.0, window_size=5, max_features=400,
+                   ba_max_iterations=50, num_threads=4)
+    for i, (L, R) in enumerate(frames):
+        r = o.process(L, R)
+        q = np.array(list(r.pose7), np.float32)
+        if not q[:4].any():
+            continue
+        w, x, y, z = q[0], -q[1], -q[2], -q[3]
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], np.float32)
+        pw = Rm @ (-q[4:])
+        assert np.allclose(traj[i][:, 3], pw, rtol=0, atol=1e-5), i   # src/vo_node.cpp:149-150
+    # ATE is evaluated at keyframes: between keyframes the published pose is the last keyframe's (SURVEY C-12)
+    gt = np.array([S.synth_pose(p, i)[:, 3] for i in range(n)])
+    assert 0 <= st.ate_rmse < 0.25, st.ate_rmse                       # ~7 m of travel, 496x160 images
+    assert S.ate_rmse(traj[:, :, 3], gt) > st.ate_rmse                # all-frames ATE includes the keyframe lag
