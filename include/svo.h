@@ -183,7 +183,12 @@ typedef struct svo_ba_options {
   double function_tolerance, gradient_tolerance, parameter_tolerance; /* 1e-6, 1e-10, 1e-8 */
   double initial_radius;   /* 1e4 */
   int max_features;        /* per keyframe; reference 400 (src/bundle_adjuster.hpp:75) */
+  int accumulation;        /* how J^T J / the Schur products are summed: SVO_BA_ACC_* (default AUTO) */
 } svo_ba_options;
+
+/* AUTO: DETERMINISTIC (contribution slots + declared summation order: bit-identical to the oracle) while the
+ * pair blocks fit, else MFMA when eligible (<= 22 poses, one observation per (landmark, pose)), else ATOMICS. */
+enum { SVO_BA_ACC_AUTO = 0, SVO_BA_ACC_DETERMINISTIC = 1, SVO_BA_ACC_ATOMICS = 2, SVO_BA_ACC_MFMA = 3 };
 
 typedef struct svo_ba_summary {
   int iterations, successful_steps, termination; /* 0 conv, 1 no-conv(iter/time), 2 failure */
@@ -210,6 +215,12 @@ int svo_ba_add_keyframe(svo_ba* ba, const double* pose7, const int64_t* tracked_
 /* BundleAdjuster::bundle_adjust (src/bundle_adjuster.cpp:137-157): no-op unless a
  * keyframe was added since the last solve. */
 int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary);
+/* The dense SPD solve of the reduced camera system — what Ceres' DENSE_SCHUR does with Eigen's LLT inside
+ * ceres::Solve (src/bundle_adjuster.cpp:156).  Host-only (the system is at most 378 x 378).  A: n x n
+ * row-major, lower triangle read, overwritten by L; b: right-hand side, overwritten by the solution.
+ * Declared operation order (see host/linalg.cpp): bit-identical to the plain left-looking loop.
+ * Returns SVO_ERR_NUMERIC when A is not positive definite. */
+int svo_cholesky_solve(double* A, double* b, int n);
 /* pose of window slot k (0 = oldest, -1 = newest). */
 int svo_ba_get_pose(svo_ba* ba, int k, double* pose7);
 int svo_ba_window_count(svo_ba* ba);

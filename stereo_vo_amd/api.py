@@ -29,7 +29,10 @@ class BAOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int), ("max_time_s", C.c_double),
                 ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
                 ("parameter_tolerance", C.c_double), ("initial_radius", C.c_double),
-                ("max_features", C.c_int)]
+                ("max_features", C.c_int), ("accumulation", C.c_int)]
+
+
+BA_ACC = {"auto": 0, "deterministic": 1, "atomics": 2, "mfma": 3}
 
 
 class BASummary(C.Structure):
@@ -73,7 +76,7 @@ SYMBOLS = [
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
-    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run",
+    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve",
 ]
 
 
@@ -309,7 +312,7 @@ class BA:
     """svo_ba wrapper: sliding-window graph (add_keyframe / solve) and the bulk-problem interface."""
 
     def __init__(self, ctx, window_size, focal, cx, cy, baseline=0.0, max_landmarks=1 << 16,
-                 max_observations=1 << 18, max_iterations=50, max_time_s=0.0, max_features=400):
+                 max_observations=1 << 18, max_iterations=50, max_time_s=0.0, max_features=400, accumulation="auto"):
         self.ctx = ctx
         self.L = ctx.L
         cam = CameraInfo(focal, cx, cy, 0, 0, 0, 0, baseline)
@@ -318,6 +321,7 @@ class BA:
         opt.max_iterations = max_iterations
         opt.max_time_s = max_time_s
         opt.max_features = max_features
+        opt.accumulation = BA_ACC[accumulation]
         self.h = C.c_void_p()
         ctx._chk(self.L.svo_ba_create(ctx.h, C.byref(self.h), window_size, C.byref(cam), C.byref(opt),
                                       max_landmarks, max_observations), "svo_ba_create")
@@ -483,3 +487,13 @@ def kitti_run(ctx, params, data_path, sequence, max_frames):
     ctx._chk(lib().svo_kitti_run(ctx.h, C.byref(params), data_path.encode(), sequence, max_frames, _p(traj), C.byref(st)),
              "svo_kitti_run")
     return traj[:st.frames].reshape(-1, 3, 4).copy(), st
+
+
+def cholesky_solve(A, b):
+    """svo_cholesky_solve on copies: returns x with (L L^T) x = b, or raises SvoError when A is not SPD."""
+    A = np.array(A, np.float64, order="C")
+    b = np.array(b, np.float64)
+    rc = lib().svo_cholesky_solve(_p(A), _p(b), b.shape[0])
+    if rc != 0:
+        raise SvoError(f"svo_cholesky_solve rc={rc}")
+    return b

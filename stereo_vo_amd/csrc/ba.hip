@@ -38,6 +38,8 @@
 #include "kernels.h"
 #include "reproj_device.h"
 
+bool svo_host_cholesky_solve(double* A, double* b, int n);  // host/linalg.cpp
+
 namespace {
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, MAX_RADIUS = 1e16, MIN_RADIUS = 1e-32, MIN_REL_DECREASE = 1e-3;
 
@@ -94,6 +96,7 @@ struct BaDev {
   int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1): offsets into pairB / obsV / lmV rows
   double* pay1_out = nullptr;     // where the reduce kernels write (pinned host memory when single-rank)
   double* pay2_out = nullptr;
+  int dbg = 0;
 };
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
@@ -109,6 +112,24 @@ __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
 }
 
 __device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src); }
+
+// Landmark sums of the bulk (hardware-order) paths: NV per-observation terms are summed over each landmark's
+// lane segment [first, last] by a segmented inclusive scan (log2(maxlen) shuffle steps) and the segment total
+// is broadcast back — instead of every lane walking its whole segment.  Tree order: not for the declared-order
+// (deterministic) mode.
+template <int NV>
+__device__ __forceinline__ void segment_totals(double (&v)[NV], int lane, int first, int last, int maxlen) {
+  for (int off = 1; off < maxlen; off <<= 1) {
+    const bool take = lane - off >= first;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const double u = __shfl_up(v[i], off);
+      v[i] += take ? u : 0.0;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = shfl_d(v[i], last);
+}
 
 // residual + tangent Jacobians of one observation
 __device__ __forceinline__ void eval_obs(const double* __restrict__ pose, D3 p, double u, double v, double f, double cx,
@@ -333,6 +354,273 @@ __device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Bulk (non-deterministic) linearisation with the Schur products on the f64 matrix cores.
+//
+// For a landmark with V^-1 = Lc Lc^T (3x3 Cholesky) and Z_i = (W_i s) Lc (6x3 per observing pose), its whole
+// contribution to the reduced camera matrix is  -Z Z^T  with Z the (6 x poses) x 3 stack: one rank-3 update
+// of S.  S (n <= 128) is cut into 16x16 tiles; v_mfma_f64_16x16x4_f64 applies the update to one tile with
+// K = 3 of its 4 k-slots used.  A workgroup is 8 waves; the accumulators are shared by the workgroup, not
+// per wave: wave w keeps tiles (w, w..w+4 mod 8) — the circulant half of the symmetric matrix, 5 (4 for
+// w >= 4) accumulator tiles = 40 VGPRs — in registers across ALL landmarks the workgroup sees and flushes
+// them once at the end.
+//   phase 1 (wave = one chunk of <= 64 observations, lane = observation; as ba_linearize_body): residual,
+//            Jacobians, landmark sums by lane gathers, V^-1, Z -> LDS, plus a pose->lane byte table and the
+//            tile-row mask of every landmark; U / g_c / g_red go to a small LDS image (ds_add_f64).
+//   phase 2 (wave = tile row): for each of the 8 staged chunks, for each landmark whose mask touches the
+//            row: gather the A operand (16 rows x 3) once, the B operands per touched tile, MFMA.
+// Algorithmic work per landmark with L observations: 36 L^2 multiply-adds of Schur product — here
+// 2048 flop per touched tile on the matrix pipe instead of 36 L(L+1)/2 LDS atomics.
+constexpr int MF_WAVES = 8;
+constexpr int MF_TBL_ROW = 32;   // bytes per landmark in the pose->lane table: free poses <= 21 (n <= 128)
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+
+static inline size_t ba_mfma_lds_bytes(int n, int F) {
+  return sizeof(double) * ((size_t)MF_WAVES * 64 * 18 + (size_t)F * 21 + 2 * (size_t)n + 2) + (size_t)MF_WAVES * 64 * MF_TBL_ROW +
+         sizeof(uint32_t) * MF_WAVES * 64 + sizeof(int) * MF_WAVES;
+}
+
+__global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double radius, int first_pass) {
+  extern __shared__ double lds[];
+  const int n = P.n, F = P.K - 1;
+  double* sZ = lds;                                  // [8][64][18]
+  double* sU = sZ + MF_WAVES * 64 * 18;              // [F][21] upper triangle of U_p (row-major a <= b)
+  double* sGred = sU + F * 21;
+  double* sGc = sGred + n;
+  double* sAcc = sGc + n;                            // cost, sum g_p^2
+  uint8_t* sTbl = reinterpret_cast<uint8_t*>(sAcc + 2);                         // [8][64][32]
+  uint32_t* sMask = reinterpret_cast<uint32_t*>(sTbl + MF_WAVES * 64 * MF_TBL_ROW);  // [8][64]
+  int* sNlm = reinterpret_cast<int*>(sMask + MF_WAVES * 64);                    // [8]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < F * 21 + 2 * n + 2; i += blockDim.x) sU[i] = 0.0;
+  __syncthreads();
+
+  mf_d4 acc[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) acc[d] = mf_d4{0.0, 0.0, 0.0, 0.0};
+  // operand coordinates of this lane for the row tile and the 5 column tiles: global row g = 16 t + (lane & 15)
+  // -> (pose g / 6, component g % 6); k-slot kk = lane >> 4 (slot 3 is padding)
+  const int kk = lane >> 4;
+  // invalid lanes (padding rows / k-slot 3) read table byte MF_TBL_ROW-1, which no pose ever writes (-> 255 -> 0)
+  int tix[5], go_[5];
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    const int g = 16 * ((wave + d) & 7) + (lane & 15);
+    const int p = g / 6;
+    const bool valid = g < n && kk < 3;
+    tix[d] = valid ? p : MF_TBL_ROW - 1;
+    go_[d] = valid ? 3 * (g - 6 * p) + kk : 0;
+  }
+
+  double lcost = 0.0, lgp2 = 0.0;
+  const int groups = (P.C + MF_WAVES - 1) / MF_WAVES;
+  for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+    const int chunk = grp * MF_WAVES + wave;
+    // ---- phase 1 -------------------------------------------------------------------------------
+    {
+      uint64_t* t8 = reinterpret_cast<uint64_t*>(sTbl + wave * 64 * MF_TBL_ROW);
+#pragma unroll
+      for (int i = 0; i < MF_TBL_ROW / 8; ++i) t8[lane * (MF_TBL_ROW / 8) + i] = ~0ull;
+      sMask[wave * 64 + lane] = 0u;
+    }
+    int nlm = 0;
+    if (chunk < P.C) {
+      const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
+      const int o = c0 + lane;
+      const bool active = o < c1;
+      int k = 0, j = 0, first = lane, len = 0;
+      double r[2] = {0, 0}, Jc[12], Jp[6];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
+      if (active) {
+        k = P.obs_pose[o]; j = P.obs_point[o];
+        first = P.lm_start[j] - c0; len = P.lm_start[j + 1] - P.lm_start[j];
+        const D3 p{P.points[3 * j], P.points[3 * j + 1], P.points[3 * j + 2]};
+        eval_obs(P.poses + 7 * k, p, P.obs_uv[2 * o], P.obs_uv[2 * o + 1], P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+        lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+      }
+      int maxlen = len;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+      // landmark sums V = sum Jp^T Jp (symmetric: 6 terms), g_p = sum Jp^T r
+      double V[9], gp[3];
+      {
+        double t[9] = {Jp[0] * Jp[0] + Jp[3] * Jp[3], Jp[0] * Jp[1] + Jp[3] * Jp[4], Jp[0] * Jp[2] + Jp[3] * Jp[5],
+                       Jp[1] * Jp[1] + Jp[4] * Jp[4], Jp[1] * Jp[2] + Jp[4] * Jp[5], Jp[2] * Jp[2] + Jp[5] * Jp[5],
+                       Jp[0] * r[0] + Jp[3] * r[1], Jp[1] * r[0] + Jp[4] * r[1], Jp[2] * r[0] + Jp[5] * r[1]};
+        segment_totals<9>(t, lane, first, len > 0 ? first + len - 1 : lane, maxlen);
+        V[0] = t[0]; V[1] = V[3] = t[1]; V[2] = V[6] = t[2]; V[4] = t[3]; V[5] = V[7] = t[4]; V[8] = t[5];
+        gp[0] = t[6]; gp[1] = t[7]; gp[2] = t[8];
+      }
+      double s[3] = {1, 1, 1};
+      if (active) {
+        if (first_pass) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + sqrt(V[4 * a]));
+          if (lane == first) { P.sp[3 * j] = s[0]; P.sp[3 * j + 1] = s[1]; P.sp[3 * j + 2] = s[2]; }
+        } else {
+          s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
+        }
+        if (lane == first) lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+      }
+      double Vd[9], Vi[9], gps[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gps[a] = gp[a] * s[a];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) Vd[4 * a] += fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius;
+      inv3_sym(Vd, Vi);
+      // V^-1 = Lc Lc^T
+      double l00 = 0, l10 = 0, l20 = 0, l11 = 0, l21 = 0, l22 = 0;
+      if (Vi[0] > 0) {
+        l00 = sqrt(Vi[0]); l10 = Vi[3] / l00; l20 = Vi[6] / l00;
+        const double d1 = Vi[4] - l10 * l10;
+        if (d1 > 0) {
+          l11 = sqrt(d1); l21 = (Vi[7] - l20 * l10) / l11;
+          const double d2 = Vi[8] - l20 * l20 - l21 * l21;
+          if (d2 > 0) l22 = sqrt(d2);
+        }
+      }
+      const bool freep = active && k > 0;
+      const int base = 6 * (k - 1);
+      double Z[18];
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double w[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[b] = freep ? (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b] : 0.0;
+        Z[3 * a] = w[0] * l00 + w[1] * l10 + w[2] * l20;
+        Z[3 * a + 1] = w[1] * l11 + w[2] * l21;
+        Z[3 * a + 2] = w[2] * l22;
+        if (freep && !(P.dbg & 8)) {
+          // g_red part: -(W s) V^-1 (g_p s)
+          double y = 0;
+#pragma unroll
+          for (int b = 0; b < 3; ++b) y += (w[0] * Vi[b] + w[1] * Vi[3 + b] + w[2] * Vi[6 + b]) * gps[b];
+          atomicAdd(&sGred[base + a], -y);
+          atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
+        }
+      }
+      if (freep && !(P.dbg & 8)) {
+        double* u = sU + (k - 1) * 21;
+        int q = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = a; b < 6; ++b) atomicAdd(&u[q++], Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+      }
+      double* z = sZ + (size_t)(wave * 64 + lane) * 18;
+#pragma unroll
+      for (int i = 0; i < 18; ++i) z[i] = Z[i];
+      const unsigned long long flags = __ballot(active && lane == first);
+      nlm = __popcll(flags);
+      if (freep) {
+        const int lm_local = __popcll(flags & ((2ull << lane) - 1ull)) - 1;
+        sTbl[(wave * 64 + lm_local) * MF_TBL_ROW + (k - 1)] = (uint8_t)lane;
+        atomicOr(&sMask[wave * 64 + lm_local], (1u << (base >> 4)) | (1u << ((base + 5) >> 4)));
+      }
+    }
+    if (lane == 0) sNlm[wave] = nlm;
+    __syncthreads();
+    // ---- phase 2: wave = tile row --------------------------------------------------------------
+    for (int c = 0; c < ((P.dbg & 1) ? 0 : MF_WAVES); ++c) {
+      const int nl = sNlm[c];
+      const uint8_t* tb = sTbl + c * 64 * MF_TBL_ROW;
+      const double* zc = sZ + (size_t)c * 64 * 18;
+      // landmarks of this chunk whose poses touch my tile row, as a wave-uniform bit set
+      const uint32_t mvec = lane < nl ? sMask[c * 64 + lane] : 0u;
+      unsigned long long todo = __ballot((mvec >> wave) & 1u);
+      // two-stage pipeline: the pose->lane bytes of the next landmark are in flight while the current
+      // landmark's operands are read and multiplied; no lane-divergent control flow in the loop
+      int srcN[5];
+      int lmi = -1;
+      if (todo) {
+        lmi = __builtin_ctzll(todo); todo &= todo - 1ull;
+        const uint8_t* tl = tb + lmi * MF_TBL_ROW;
+#pragma unroll
+        for (int d = 0; d < 5; ++d) srcN[d] = tl[tix[d]];
+      }
+      while (lmi >= 0) {
+        const uint32_t mask = __builtin_amdgcn_readlane(mvec, lmi);
+        int src[5];
+        double op[5];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) { src[d] = srcN[d]; op[d] = zc[(src[d] & 63) * 18 + go_[d]]; }
+        lmi = -1;
+        if (todo) {
+          lmi = __builtin_ctzll(todo); todo &= todo - 1ull;
+          const uint8_t* tl = tb + lmi * MF_TBL_ROW;
+#pragma unroll
+          for (int d = 0; d < 5; ++d) srcN[d] = tl[tix[d]];
+        }
+#pragma unroll
+        for (int d = 0; d < 5; ++d) op[d] = src[d] != 255 ? op[d] : 0.0;
+        const double a_op = -op[0];
+#pragma unroll
+        for (int d = 0; d < 5; ++d) {
+          if (d == 4 && wave >= 4) continue;  // tile (w, w+4) is kept by w < 4 only
+          if (!((mask >> ((wave + d) & 7)) & 1u)) continue;
+          acc[d] = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op, op[d], acc[d], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- flush: tiles -> S (each unordered pose pair once; diagonal pose blocks in full) -----------
+  double* S = P.pay1;
+#pragma unroll
+  for (int d = 0; d < 5; ++d) {
+    if (P.dbg & 2) continue;
+    if (d == 4 && wave >= 4) continue;
+    const int cc = (wave + d) & 7;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+      const int row = 16 * wave + (lane >> 4) + 4 * rg, col = 16 * cc + (lane & 15);
+      const double v = acc[d][rg];
+      if (v == 0.0 || row >= n || col >= n) continue;
+      const int pr = row / 6, pc = col / 6;
+      if (d == 0) {
+        if (pr <= pc) atomicAdd(&S[(size_t)row * n + col], v);
+      } else if (pr == pc) {
+        atomicAdd(&S[(size_t)row * n + col], v);
+        atomicAdd(&S[(size_t)col * n + row], v);
+      } else if (pr < pc) {
+        atomicAdd(&S[(size_t)row * n + col], v);
+      } else {
+        atomicAdd(&S[(size_t)col * n + row], v);
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { lcost += __shfl_xor(lcost, off); lgp2 += __shfl_xor(lgp2, off); }
+  if (lane == 0) { atomicAdd(&sAcc[0], lcost); atomicAdd(&sAcc[1], lgp2); }
+  __syncthreads();
+  double* gGred = S + (size_t)n * n;
+  double* gGc = gGred + n;
+  double* gDU = gGc + n;
+  for (int i = threadIdx.x; i < F * 21; i += blockDim.x) {
+    const double v = sU[i];
+    if (v == 0.0) continue;
+    const int p = i / 21;
+    int q = i - 21 * p, a = 0;
+    while (q >= 6 - a) { q -= 6 - a; ++a; }
+    const int b = a + q, ra = 6 * p + a, rb = 6 * p + b;
+    atomicAdd(&S[(size_t)ra * n + rb], v);
+    if (a != b) atomicAdd(&S[(size_t)rb * n + ra], v);
+    else atomicAdd(&gDU[ra], v);
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    if (sGred[i] != 0.0) atomicAdd(&gGred[i], sGred[i]);
+    if (sGc[i] != 0.0) atomicAdd(&gGc[i], sGc[i]);
+  }
+  if (threadIdx.x < 2) atomicAdd(&gDU[n + threadIdx.x], sAcc[threadIdx.x]);
+}
+
 __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
   const double* poses_ = P.poses;
   const double* points_ = P.points;
@@ -378,7 +666,16 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
     double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, wd[3] = {0, 0, 0};
-    for (int t = 0; t < maxlen; ++t) {
+    if (!P.det) {
+      double t[12] = {Jp[0] * Jp[0] + Jp[3] * Jp[3], Jp[0] * Jp[1] + Jp[3] * Jp[4], Jp[0] * Jp[2] + Jp[3] * Jp[5],
+                      Jp[1] * Jp[1] + Jp[4] * Jp[4], Jp[1] * Jp[2] + Jp[4] * Jp[5], Jp[2] * Jp[2] + Jp[5] * Jp[5],
+                      Jp[0] * r[0] + Jp[3] * r[1], Jp[1] * r[0] + Jp[4] * r[1], Jp[2] * r[0] + Jp[5] * r[1],
+                      Jp[0] * jd[0] + Jp[3] * jd[1], Jp[1] * jd[0] + Jp[4] * jd[1], Jp[2] * jd[0] + Jp[5] * jd[1]};
+      segment_totals<12>(t, lane, first, len > 0 ? first + len - 1 : lane, maxlen);
+      V[0] = t[0]; V[1] = V[3] = t[1]; V[2] = V[6] = t[2]; V[4] = t[3]; V[5] = V[7] = t[4]; V[8] = t[5];
+      gp[0] = t[6]; gp[1] = t[7]; gp[2] = t[8]; wd[0] = t[9]; wd[1] = t[10]; wd[2] = t[11];
+    }
+    for (int t = 0; t < (P.det ? maxlen : 0); ++t) {
       const int src = (first + t) & 63;
       double q[6], rr[2], dd[2];
 #pragma unroll
@@ -795,31 +1092,7 @@ __global__ __launch_bounds__(512) void ba_persistent_kernel(BaDev P, int max_loo
 
 // ----------------------------------------------------------------------------- host side
 namespace {
-bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) {
-  for (int j = 0; j < n; ++j) {
-    double s = A[(size_t)j * n + j];
-    for (int k = 0; k < j; ++k) s -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
-    if (!(s > 0)) return false;
-    const double l = sqrt(s);
-    A[(size_t)j * n + j] = l;
-    for (int i = j + 1; i < n; ++i) {
-      double v = A[(size_t)i * n + j];
-      for (int k = 0; k < j; ++k) v -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
-      A[(size_t)i * n + j] = v / l;
-    }
-  }
-  for (int i = 0; i < n; ++i) {
-    double v = b[i];
-    for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
-    b[i] = v / A[(size_t)i * n + i];
-  }
-  for (int i = n - 1; i >= 0; --i) {  // inner index DESCENDING: the order the device column sweep produces
-    double v = b[i];
-    for (int k = n - 1; k > i; --k) v -= A[(size_t)k * n + i] * b[k];
-    b[i] = v / A[(size_t)i * n + i];
-  }
-  return true;
-}
+bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) { return svo_host_cholesky_solve(A.data(), b.data(), n); }
 }  // namespace
 
 
@@ -844,6 +1117,7 @@ struct svo_ba {
   BaDev* d_params = nullptr;      // device copy of the kernel parameters (graph kernels read it)
   hipGraphExec_t graph_exec = nullptr;
   double t_launch = 0, t_sync = 0, t_upload = 0, t_total = 0; long n_chunks = 0, n_solves = 0;
+  double t_lin = 0, t_host = 0, t_back = 0; long n_lin = 0, n_back = 0;  // host-driven loop phases (SVO_TIMING)
   int graph_threads = 0;          // solve-kernel block size baked into the graph
   hipStream_t stream = nullptr;  // BA has its own stream so a solve can overlap the tracker's kernels
   double* step_buf[2] = {nullptr, nullptr};
@@ -858,6 +1132,7 @@ struct svo_ba {
   std::vector<int64_t> solve_lm_ids;
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
+  bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
 };
 
 static int ba_alloc(svo_ba* ba) {
@@ -906,6 +1181,7 @@ extern "C" void svo_ba_default_options(svo_ba_options* o) {
   o->parameter_tolerance = 1e-8;
   o->initial_radius = 1e4;
   o->max_features = 400;
+  o->accumulation = SVO_BA_ACC_AUTO;
 }
 
 extern "C" int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const svo_camera_info* cam,
@@ -932,6 +1208,9 @@ extern "C" int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const 
 extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (!ba) return;
   BaDev& d = ba->d;
+  if (getenv("SVO_TIMING") && ba->n_lin)
+    fprintf(stderr, "[svo ba] host loop: linearize+reduce+D2H %.1f us x %ld, host solve %.1f us, backsub+D2H %.1f us x %ld\n",
+            1e3 * ba->t_lin / ba->n_lin, ba->n_lin, ba->n_back ? 1e3 * ba->t_host / ba->n_back : 0.0, ba->n_back ? 1e3 * ba->t_back / ba->n_back : 0.0, ba->n_back);
   if (getenv("SVO_TIMING") && ba->n_chunks)
     fprintf(stderr, "[svo ba] solves %ld chunks %ld graph-launch %.3f ms sync %.3f ms upload %.3f ms total %.3f ms\n", ba->n_solves, ba->n_chunks,
             ba->t_launch, ba->t_sync, ba->t_upload, ba->t_total);
@@ -995,6 +1274,17 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
       for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) pair_base[o + 1] = pair_base[o] + (lm_start[j + 1] - o);
     const size_t n_pairs = (size_t)pair_base[M];
     d.det = n_pairs <= ((size_t)1 << 21) ? 1 : 0;  // <= 604 MB of pair blocks
+    if (ba->opt.accumulation == SVO_BA_ACC_ATOMICS || ba->opt.accumulation == SVO_BA_ACC_MFMA) d.det = 0;
+    SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_DETERMINISTIC && !d.det), "ba: problem too large for deterministic accumulation");
+    {
+      bool dup = false;
+      for (int j = 0; j < npts && !dup; ++j) {
+        uint64_t seen = 0;
+        for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) { const uint64_t bit = 1ull << op[o]; dup |= (seen & bit) != 0; seen |= bit; }
+      }
+      ba->mfma_ok = !dup && d.n <= 128 && d.n > 0 && ba->opt.accumulation != SVO_BA_ACC_ATOMICS;
+      SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_MFMA && !ba->mfma_ok), "ba: MFMA accumulation needs <= 22 poses and one observation per (landmark, pose)");
+    }
     if (d.det) {
       // destination lists in landmark order; the landmark list is the identity over [0, npts)
       const int nd = F * F + F + 1;
@@ -1277,7 +1567,13 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   double* h_cp = h_dc + (n > 0 ? n : 1);  // contiguous with h_dc: one H2D per iteration
   const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
   const size_t lds_bytes = pay1 * sizeof(double);
-  if (!d.det && lds_bytes > 64 * 1024) {
+  const bool use_mfma = !d.det && ba->mfma_ok;
+  d.dbg = getenv("SVO_BA_DBG") ? atoi(getenv("SVO_BA_DBG")) : 0;
+  const size_t mfma_lds = ba_mfma_lds_bytes(n, K - 1);
+  const int mfma_grid = std::max(1, std::min(svo_div_up(d.C, MF_WAVES), 256));
+  if (use_mfma) {
+    SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
+  } else if (!d.det && lds_bytes > 64 * 1024) {
     SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
   }
   std::vector<double> sc(n, 0.0), Sm((size_t)n * n), rhs(n), Df(n), Sfull((size_t)n * n);
@@ -1288,12 +1584,16 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   double* cur_poses = d.poses;
   double* cand_poses = d.cand_poses;
 
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto linearize = [&](double rad) -> int {
+    const auto tp0 = now();
     d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
     if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       if (d.det) hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, rad, have_scale ? 0 : 1);  // one wave per workgroup: spreads the chunks over the CUs
+      else if (use_mfma) hipLaunchKernelGGL(ba_linearize_mfma_kernel, dim3(mfma_grid), dim3(64 * MF_WAVES), mfma_lds, st, d, rad, have_scale ? 0 : 1);
       else hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, st, d, rad, have_scale ? 0 : 1);
     }
     // single rank + deterministic mode: the reduce kernel writes the payload straight into pinned host
@@ -1318,6 +1618,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
             const size_t ij = (size_t)(6 * a + i) * n + 6 * b + j, ji = (size_t)(6 * b + j) * n + 6 * a + i;
             Sfull[ij] = (a == b || d.det) ? S[ij] : S[ij] + S[ji];
           }
+    ba->t_lin += ms(tp0, now()); ba->n_lin++;
     return SVO_OK;
   };
   auto gradient_norm = [&]() {
@@ -1352,6 +1653,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
       const double* gred = h_pay1 + (size_t)n * n;
       const double* gc = gred + n;
       const double* dU = gc + n;
+      const auto th0 = now();
       for (int a = 0; a < n; ++a) {
         Df[a] = std::min(std::max(dU[a] * sc[a] * sc[a], MIN_DIAG), MAX_DIAG) / radius;
         for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = Sfull[(size_t)a * n + b] * sc[a] * sc[b];
@@ -1372,6 +1674,8 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
           else plus_pose(&ba->h_poses[7 * k], &h_dc[6 * (k - 1)], &ba->h_cand_poses[7 * k]);
         }
         memcpy(h_cp, ba->h_cand_poses.data(), sizeof(double) * 7 * K);
+        const auto tb0 = now();
+        ba->t_host += ms(th0, tb0);
         // one H2D: [dc (n) | candidate poses (7K)] are adjacent both in the pinned buffer and on the device
         d.poses = cur_poses; d.cand_poses = cand_poses; d.dc = cand_poses - (n > 0 ? n : 1);
         SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.dc, h_dc, sizeof(double) * ((n > 0 ? n : 1) + 7 * K), hipMemcpyHostToDevice, st));
@@ -1390,6 +1694,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         }
         if (!(d.det && !ba->allreduce)) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay2, d.pay2, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
         SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        ba->t_back += ms(tb0, now()); ba->n_back++;
         cost_new = h_pay2[0];
         model_change = mcc + h_pay2[1];
         step2 = h_pay2[2]; x2 = h_pay2[3];

@@ -66,6 +66,46 @@ def test_oracle_sharded_equals_single():
         assert np.allclose(pts, ref[1][idx], rtol=1e-7, atol=1e-6)  # low-parallax points are ill-conditioned: relative
 
 
+def test_host_cholesky_follows_declared_order():
+    """svo_cholesky_solve (panel-blocked, vectorised) must produce the bits of the plain left-looking loop the
+    oracle uses: same products subtracted in the same order, no FMA, no reassociation."""
+    import math
+    import stereo_vo_amd as S
+
+    def plain(A, b):
+        n = len(b); A = [list(r) for r in A]; b = list(b)
+        for j in range(n):
+            s = A[j][j]
+            for k in range(j):
+                s -= A[j][k] * A[j][k]
+            l = math.sqrt(s); A[j][j] = l
+            for i in range(j + 1, n):
+                v = A[i][j]
+                for k in range(j):
+                    v -= A[i][k] * A[j][k]
+                A[i][j] = v / l
+        for i in range(n):
+            v = b[i]
+            for k in range(i):
+                v -= A[i][k] * b[k]
+            b[i] = v / A[i][i]
+        for i in range(n - 1, -1, -1):
+            v = b[i]
+            for k in range(n - 1, i, -1):
+                v -= A[k][i] * b[k]
+            b[i] = v / A[i][i]
+        return np.array(b)
+
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 4, 5, 6, 9, 24, 54, 114):
+        M = rng.normal(size=(n, n)); A = M @ M.T + n * np.eye(n); b = rng.normal(size=n)
+        x = S.api.cholesky_solve(A, b)
+        assert np.array_equal(x, plain(A.tolist(), b.tolist()))
+        assert np.allclose(A @ x, b, atol=1e-9)
+    with pytest.raises(S.api.SvoError):
+        S.api.cholesky_solve(-np.eye(3), np.ones(3))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,K,N,dense", [(1, 5, 400, False), (2, 6, 1500, False), (4, 10, 3000, False),
                                             (5, 20, 2000, True), (6, 2, 50, False)])
@@ -85,6 +125,40 @@ def test_hip_ba_matches_oracle(ctx, seed, K, N, dense):
     dt, ang = BP.pose_error(poses, po)
     assert dt < T_TOL and ang < R_TOL
     assert np.allclose(pts, pto, rtol=1e-6, atol=1e-5)
+    assert np.array_equal(poses[0], p["poses0"][0])
+    ba.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["atomics", "mfma"])
+@pytest.mark.parametrize("seed,K,N,dense", [(11, 5, 700, False), (12, 12, 2500, False), (13, 20, 1500, True),
+                                            (14, 22, 3000, False), (15, 2, 80, False)])
+def test_hip_ba_bulk_accumulation_modes(ctx, mode, seed, K, N, dense):
+    """The bulk accumulation paths (LDS atomics; f64 MFMA rank-3 updates of S) sum in hardware order, so
+    they are compared with the oracle to floating-point tolerance: first linearisation to 1e-12 relative
+    (one iteration from identical inputs), converged solve to 1e-6 relative cost, poses 1e-5 m / 1e-5 rad
+    (free scale gauge amplifies the summation noise; the deterministic mode is the bit-exact one)."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(seed, K, N, dense=dense)
+    kw = dict(max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0, accumulation=mode)
+    one = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_iterations=1, **kw)
+    one.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s1 = one.solve_problem()
+    poses1, pts1 = one.read_problem()
+    po1, pto1, so1 = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, max_iterations=1)
+    assert abs(s1.initial_cost - so1["initial_cost"]) <= 1e-12 * so1["initial_cost"]
+    assert abs(s1.final_cost - so1["final_cost"]) <= 1e-9 * so1["final_cost"]
+    assert np.allclose(poses1, po1, rtol=0, atol=1e-9) and np.allclose(pts1, pto1, rtol=1e-8, atol=1e-8)
+    one.close()
+    ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, **kw)
+    ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s = ba.solve_problem()
+    poses, pts = ba.read_problem()
+    po, pto, so = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=4)
+    assert s.termination == so["termination"] == 0
+    assert abs(s.final_cost - so["final_cost"]) <= 1e-6 * so["final_cost"]
+    dt, ang = BP.pose_error(poses, po)
+    assert dt < 1e-5 and ang < 1e-5
     assert np.array_equal(poses[0], p["poses0"][0])
     ba.close()
 
