@@ -96,7 +96,6 @@ struct BaDev {
   int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1): offsets into pairB / obsV / lmV rows
   double* pay1_out = nullptr;     // where the reduce kernels write (pinned host memory when single-rank)
   double* pay2_out = nullptr;
-  int dbg = 0;
 };
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
@@ -372,11 +371,12 @@ __device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius,
 // Algorithmic work per landmark with L observations: 36 L^2 multiply-adds of Schur product — here
 // 2048 flop per touched tile on the matrix pipe instead of 36 L(L+1)/2 LDS atomics.
 constexpr int MF_WAVES = 8;
+constexpr int MF_COPIES = 8;    // private copies of the U / g_c / g_red image (landmark index mod 8): same-pose lanes of a wave rarely share one
 constexpr int MF_TBL_ROW = 32;   // bytes per landmark in the pose->lane table: free poses <= 21 (n <= 128)
 typedef double mf_d4 __attribute__((ext_vector_type(4)));
 
 static inline size_t ba_mfma_lds_bytes(int n, int F) {
-  return sizeof(double) * ((size_t)MF_WAVES * 64 * 18 + (size_t)F * 21 + 2 * (size_t)n + 2) + (size_t)MF_WAVES * 64 * MF_TBL_ROW +
+  return sizeof(double) * ((size_t)MF_WAVES * 64 * 18 + MF_COPIES * ((size_t)F * 21 + 2 * (size_t)n) + 2) + (size_t)MF_WAVES * 64 * MF_TBL_ROW +
          sizeof(uint32_t) * MF_WAVES * 64 + sizeof(int) * MF_WAVES;
 }
 
@@ -384,15 +384,14 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
   extern __shared__ double lds[];
   const int n = P.n, F = P.K - 1;
   double* sZ = lds;                                  // [8][64][18]
-  double* sU = sZ + MF_WAVES * 64 * 18;              // [F][21] upper triangle of U_p (row-major a <= b)
-  double* sGred = sU + F * 21;
-  double* sGc = sGred + n;
-  double* sAcc = sGc + n;                            // cost, sum g_p^2
+  const int img = F * 21 + 2 * n;                    // one image: U upper triangles [F][21] | g_red [n] | g_c [n]
+  double* sImg = sZ + MF_WAVES * 64 * 18;            // [MF_COPIES][img]
+  double* sAcc = sImg + MF_COPIES * img;             // cost, sum g_p^2
   uint8_t* sTbl = reinterpret_cast<uint8_t*>(sAcc + 2);                         // [8][64][32]
   uint32_t* sMask = reinterpret_cast<uint32_t*>(sTbl + MF_WAVES * 64 * MF_TBL_ROW);  // [8][64]
   int* sNlm = reinterpret_cast<int*>(sMask + MF_WAVES * 64);                    // [8]
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  for (int i = threadIdx.x; i < F * 21 + 2 * n + 2; i += blockDim.x) sU[i] = 0.0;
+  for (int i = threadIdx.x; i < MF_COPIES * img + 2; i += blockDim.x) sImg[i] = 0.0;
   __syncthreads();
 
   mf_d4 acc[5];
@@ -414,8 +413,30 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
 
   double lcost = 0.0, lgp2 = 0.0;
   const int groups = (P.C + MF_WAVES - 1) / MF_WAVES;
+  // per-lane observation record of the NEXT group, fetched while the current group is in phase 2 (the
+  // index -> landmark -> point chain is three dependent HBM/L2 round trips that two waves per SIMD cannot hide)
+  struct Fetch { int c0, k, j, first, len; bool active; double u, v; D3 p; };
+  auto fetch = [&](int grp) {
+    Fetch f{0, 0, 0, lane, 0, false, 0.0, 0.0, D3{0, 0, 1}};
+    const int chunk = grp * MF_WAVES + wave;
+    if (grp < groups && chunk < P.C) {
+      f.c0 = P.chunk_start[chunk];
+      const int o = f.c0 + lane;
+      f.active = o < P.chunk_start[chunk + 1];
+      if (f.active) {
+        f.k = P.obs_pose[o]; f.j = P.obs_point[o];
+        const int l0 = P.lm_start[f.j];
+        f.first = l0 - f.c0; f.len = P.lm_start[f.j + 1] - l0;
+        f.p = D3{P.points[3 * f.j], P.points[3 * f.j + 1], P.points[3 * f.j + 2]};
+        f.u = P.obs_uv[2 * o]; f.v = P.obs_uv[2 * o + 1];
+      }
+    }
+    return f;
+  };
+  Fetch nxt = fetch(blockIdx.x);
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     const int chunk = grp * MF_WAVES + wave;
+    const Fetch cur = nxt;
     // ---- phase 1 -------------------------------------------------------------------------------
     {
       uint64_t* t8 = reinterpret_cast<uint64_t*>(sTbl + wave * 64 * MF_TBL_ROW);
@@ -425,20 +446,15 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
     }
     int nlm = 0;
     if (chunk < P.C) {
-      const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
-      const int o = c0 + lane;
-      const bool active = o < c1;
-      int k = 0, j = 0, first = lane, len = 0;
+      const bool active = cur.active;
+      const int k = cur.k, j = cur.j, first = cur.first, len = cur.len;
       double r[2] = {0, 0}, Jc[12], Jp[6];
 #pragma unroll
       for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
       if (active) {
-        k = P.obs_pose[o]; j = P.obs_point[o];
-        first = P.lm_start[j] - c0; len = P.lm_start[j + 1] - P.lm_start[j];
-        const D3 p{P.points[3 * j], P.points[3 * j + 1], P.points[3 * j + 2]};
-        eval_obs(P.poses + 7 * k, p, P.obs_uv[2 * o], P.obs_uv[2 * o + 1], P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+        eval_obs(P.poses + 7 * k, cur.p, cur.u, cur.v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
         lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
       }
       int maxlen = len;
@@ -488,6 +504,11 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
       }
       const bool freep = active && k > 0;
       const int base = 6 * (k - 1);
+      const unsigned long long flags = __ballot(active && lane == first);
+      const int lm_local = __popcll(flags & ((2ull << lane) - 1ull)) - 1;
+      double* sU = sImg + (lm_local & (MF_COPIES - 1)) * img;
+      double* sGred = sU + F * 21;
+      double* sGc = sGred + n;
       double Z[18];
 #pragma unroll
       for (int a = 0; a < 6; ++a) {
@@ -497,7 +518,7 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
         Z[3 * a] = w[0] * l00 + w[1] * l10 + w[2] * l20;
         Z[3 * a + 1] = w[1] * l11 + w[2] * l21;
         Z[3 * a + 2] = w[2] * l22;
-        if (freep && !(P.dbg & 8)) {
+        if (freep) {
           // g_red part: -(W s) V^-1 (g_p s)
           double y = 0;
 #pragma unroll
@@ -506,7 +527,7 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
           atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
         }
       }
-      if (freep && !(P.dbg & 8)) {
+      if (freep) {
         double* u = sU + (k - 1) * 21;
         int q = 0;
 #pragma unroll
@@ -517,18 +538,17 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
       double* z = sZ + (size_t)(wave * 64 + lane) * 18;
 #pragma unroll
       for (int i = 0; i < 18; ++i) z[i] = Z[i];
-      const unsigned long long flags = __ballot(active && lane == first);
       nlm = __popcll(flags);
       if (freep) {
-        const int lm_local = __popcll(flags & ((2ull << lane) - 1ull)) - 1;
         sTbl[(wave * 64 + lm_local) * MF_TBL_ROW + (k - 1)] = (uint8_t)lane;
         atomicOr(&sMask[wave * 64 + lm_local], (1u << (base >> 4)) | (1u << ((base + 5) >> 4)));
       }
     }
     if (lane == 0) sNlm[wave] = nlm;
     __syncthreads();
+    nxt = fetch(grp + gridDim.x);
     // ---- phase 2: wave = tile row --------------------------------------------------------------
-    for (int c = 0; c < ((P.dbg & 1) ? 0 : MF_WAVES); ++c) {
+    for (int c = 0; c < MF_WAVES; ++c) {
       const int nl = sNlm[c];
       const uint8_t* tb = sTbl + c * 64 * MF_TBL_ROW;
       const double* zc = sZ + (size_t)c * 64 * 18;
@@ -575,7 +595,6 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
   double* S = P.pay1;
 #pragma unroll
   for (int d = 0; d < 5; ++d) {
-    if (P.dbg & 2) continue;
     if (d == 4 && wave >= 4) continue;
     const int cc = (wave + d) & 7;
 #pragma unroll
@@ -604,7 +623,9 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
   double* gGc = gGred + n;
   double* gDU = gGc + n;
   for (int i = threadIdx.x; i < F * 21; i += blockDim.x) {
-    const double v = sU[i];
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < MF_COPIES; ++c) v += sImg[c * img + i];
     if (v == 0.0) continue;
     const int p = i / 21;
     int q = i - 21 * p, a = 0;
@@ -614,9 +635,11 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
     if (a != b) atomicAdd(&S[(size_t)rb * n + ra], v);
     else atomicAdd(&gDU[ra], v);
   }
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    if (sGred[i] != 0.0) atomicAdd(&gGred[i], sGred[i]);
-    if (sGc[i] != 0.0) atomicAdd(&gGc[i], sGc[i]);
+  for (int i = threadIdx.x; i < 2 * n; i += blockDim.x) {  // g_red then g_c: adjacent in the image and in the payload
+    double v = 0.0;
+#pragma unroll
+    for (int c = 0; c < MF_COPIES; ++c) v += sImg[c * img + F * 21 + i];
+    if (v != 0.0) atomicAdd(&gGred[i], v);
   }
   if (threadIdx.x < 2) atomicAdd(&gDU[n + threadIdx.x], sAcc[threadIdx.x]);
 }
@@ -1568,7 +1591,6 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
   const size_t lds_bytes = pay1 * sizeof(double);
   const bool use_mfma = !d.det && ba->mfma_ok;
-  d.dbg = getenv("SVO_BA_DBG") ? atoi(getenv("SVO_BA_DBG")) : 0;
   const size_t mfma_lds = ba_mfma_lds_bytes(n, K - 1);
   const int mfma_grid = std::max(1, std::min(svo_div_up(d.C, MF_WAVES), 256));
   if (use_mfma) {

@@ -10,7 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, CX, CY, W, H = 718.856, 607.1928, 185.2157, 1241, 376
-FP64_VEC_PEAK_TFLOPS = 78.6
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4: 2048 flop / 64 cycles / SIMD (measured: SQ_VALU_MFMA_BUSY_CYCLES = 64 x MFMA count)
 
 
 def make_problem(seed=0xBA000004, K=20, N=50000, dense=False, noise=0.5):
@@ -67,11 +67,15 @@ def run(args):
     torch, dist, rank, local, world = bench.dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     p = make_problem(dense=os.environ.get("SVO_BA_DENSE") == "1")
-    pts, op, oj, uv, mine = sharding.shard_problem(p["points0"], p["op"], p["oj"], p["uv"], rank, world)
+    # developer aid: SVO_BA_SHARD_OF=N times the per-rank load of an N-rank run on one GPU (no collective)
+    emu = int(os.environ.get("SVO_BA_SHARD_OF", "0"))
+    pts, op, oj, uv, mine = sharding.shard_problem(p["points0"], p["op"], p["oj"], p["uv"], rank if not emu else 0, world if not emu else emu)
     ctx = S.Context(64, 64, device=local)
     K = p["poses0"].shape[0]
     iters = args.steps
-    ba = S.BA(ctx, K, F, CX, CY, max_landmarks=len(pts) + 8, max_observations=len(op) + 8, max_iterations=iters, max_time_s=0.0)
+    acc_mode = os.environ.get("SVO_BA_ACC", "mfma")
+    ba = S.BA(ctx, K, F, CX, CY, max_landmarks=len(pts) + 8, max_observations=len(op) + 8, max_iterations=iters, max_time_s=0.0,
+              accumulation=acc_mode)
     if dist is not None:
         ba.set_allreduce(sharding.allreduce_device_fn(dist, dev))
     # warm-up solve (W iterations), then the timed solve of exactly K LM iterations from the same start
@@ -96,11 +100,19 @@ def run(args):
                       "landmarks": int(len(p["points0"])), "poses": K, "final_cost": s.final_cost,
                       "initial_cost": s.initial_cost, "collective": "allreduce(sum,f64) of %d doubles per LM iteration" % ((6 * (K - 1)) ** 2 + 18 * (K - 1) + 2)}}
     if k_n:
+        # roofline of the dominant kernel.  Two figures: `achieved` = SURVEY 8d algorithmic f64 flops of one
+        # linearisation / launch time (what the work needs); `mfma_issued` = MFMA instructions x 2048 flop /
+        # launch time (what the matrix pipe executed: K = 3 of 4 slots and padded 16x16 tiles included).
         avg_us = 1e3 * k_ms / k_n
         tf = fl_local / (avg_us * 1e-6) / 1e12
-        out["roofline"] = {"kernel": "ba_linearize_kernel", "bound": "mfma", "achieved": tf, "peak": FP64_VEC_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tf / FP64_VEC_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_us,
-                           "launches": k_n, "note": "FP64 vector rate (public spec 78.6 TF); per-rank algorithmic flops"}
+        Lc = np.bincount(oj, minlength=len(pts))
+        out["roofline"] = {"kernel": "ba_linearize_mfma_kernel" if acc_mode == "mfma" else "ba_linearize_kernel",
+                           "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_us,
+                           "launches": k_n, "accumulation": acc_mode,
+                           "note": "f64: matrix and vector peak are both 78.6 TF on MI355X; per-rank algorithmic flops "
+                                   "(466/observation + 50 + 144 L + 108 L(L+1) per landmark); MFMA pipe busy fraction "
+                                   "from rocprofv3 PMC is in profiles/r01_ba50k_mfma_pmc*.txt"}
     ba.close()
     ctx.close()
     if dist is not None:
