@@ -96,6 +96,14 @@ struct BaDev {
   int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1): offsets into pairB / obsV / lmV rows
   double* pay1_out = nullptr;     // where the reduce kernels write (pinned host memory when single-rank)
   double* pay2_out = nullptr;
+  const double* step_in = nullptr;  // pinned host [dc | candidate poses]: read in place by ba_backsub (no H2D blit per LM iteration)
+  // completion flags in pinned host memory (single-rank deterministic mode): the reduce kernels publish `seq` after
+  // their payload, the host loop polls the word instead of paying a stream wait per half-iteration
+  int* flag1 = nullptr;
+  int* flag2 = nullptr;
+  unsigned* arrive = nullptr;   // device counter of finished reduce1 workgroups (monotone; target = total so far)
+  unsigned arrive_target = 0;
+  int seq = 0;
 };
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
@@ -656,6 +664,12 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
     poses_ = P.step[c] + nn; points_ = P.pts[c];
     dc_ = P.step[1 - c]; cand_poses_ = P.step[1 - c] + nn; cand_points_ = P.pts[1 - c];
     radius = ldv(&P.lm->radius);
+  } else if (P.step_in) {
+    dc_ = P.step_in;
+    cand_poses_ = P.step_in + (P.n > 0 ? P.n : 1);
+    // the candidate becomes the linearisation point if the step is accepted: leave a device copy for later launches
+    if (blockIdx.x == 0)
+      for (int i = threadIdx.x; i < 7 * P.K; i += blockDim.x) P.cand_poses[i] = cand_poses_[i];
   }
   __shared__ double sAcc[4];
   if (threadIdx.x < 4) sAcc[threadIdx.x] = 0.0;
@@ -826,6 +840,18 @@ __device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
       out[(size_t)n * n + 3 * n + tid] = acc;
     }
   }
+  if (P.flag1) {
+    // payload (host memory) first, system-scope fence, then arrive; the last workgroup publishes the sequence word
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == P.arrive_target) {
+        __threadfence_system();
+        __hip_atomic_store(P.flag1, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 __device__ __forceinline__ void ba_reduce2_body(const BaDev& P) {
@@ -858,7 +884,13 @@ __device__ __forceinline__ void ba_reduce2_body(const BaDev& P) {
     sOut[tid] = acc;
     if (!P.lm) P.pay2_out[tid] = acc;
   }
-  if (!P.lm) return;
+  if (!P.lm) {
+    if (P.flag2 && tid < 64) {  // lanes 0-3 of this wave stored the payload; fence, then lane 0 publishes
+      __threadfence_system();
+      if (tid == 0) __hip_atomic_store(P.flag2, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   __syncthreads();
   if (tid != 0) return;
   // ---- step control (same statements, same order as the host loop in ba_lm / oracle/ora_ba.cpp)
@@ -1155,6 +1187,7 @@ struct svo_ba {
   std::vector<int64_t> solve_lm_ids;
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
 };
 
@@ -1170,6 +1203,8 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(d.pay1, double, ba->cap_pay1); A(d.pay2, double, 4);
   A(ba->d_lm, LmDev, 1); A(ba->d_params, BaDev, 1);
+  A(ba->d_arrive, unsigned, 1);
+  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
   A(d.lmV, double, 4 * ba->cap_points);
 #undef A
@@ -1238,7 +1273,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
     fprintf(stderr, "[svo ba] solves %ld chunks %ld graph-launch %.3f ms sync %.3f ms upload %.3f ms total %.3f ms\n", ba->n_solves, ba->n_chunks,
             ba->t_launch, ba->t_sync, ba->t_upload, ba->t_total);
   if (ba->graph_exec) (void)hipGraphExecDestroy(ba->graph_exec);
-  void* ptrs[] = {ba->d_lm, ba->d_params, ba->step_buf[0], ba->step_buf[1], d.sp, d.pay1, d.pay2, d.pairB, d.obsV, d.lmV, ba->d_arena};
+  void* ptrs[] = {ba->d_arrive, ba->d_lm, ba->d_params, ba->step_buf[0], ba->step_buf[1], d.sp, d.pay1, d.pay2, d.pairB, d.obsV, d.lmV, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1608,6 +1643,25 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
 
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+  // Single-rank deterministic solves poll completion words that the reduce kernels publish in pinned memory
+  // (after a system-scope fence) instead of a stream wait per half-iteration; SVO_BA_NO_POLL=1 restores the waits.
+  const bool poll = d.det && !ba->allreduce && !getenv("SVO_BA_NO_POLL");
+  int* h_flag1 = reinterpret_cast<int*>(h_pay2 + 6);
+  int* h_flag2 = reinterpret_cast<int*>(h_pay2 + 7);
+  d.flag1 = poll ? h_flag1 : nullptr; d.flag2 = poll ? h_flag2 : nullptr; d.arrive = ba->d_arrive;
+  int rc_poll = 0;
+  auto wait_flag = [&](int* flag, int seq) -> int {
+    const auto t0 = now();
+    unsigned spins = 0;
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      __builtin_ia32_pause();
+      if ((++spins & 0xFFFFu) == 0 && ms(t0, now()) > 10000.0) {  // never expected: fall back to the stream wait
+        SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { ctx->err = "ba: completion word never arrived"; return SVO_ERR_HIP; }
+      }
+    }
+    return SVO_OK;
+  };
   auto linearize = [&](double rad) -> int {
     const auto tp0 = now();
     d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
@@ -1623,14 +1677,17 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
     const bool zero_copy = d.det && !ba->allreduce;
     d.pay1_out = zero_copy ? h_pay1 : d.pay1;
     d.pay2_out = zero_copy ? h_pay2 : d.pay2;
-    if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3((K - 1) * (K - 1) + (K - 1) + 1), dim3(1024), 0, st, d);
+    const int nred = (K - 1) * (K - 1) + (K - 1) + 1;
+    if (poll) { ba->arrive_total += (unsigned)nred; d.arrive_target = ba->arrive_total; d.seq = ++ba->seq; }
+    if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3(nred), dim3(1024), 0, st, d);
     SVO_HIP_CHECK(ctx, hipGetLastError());
+    if (poll) { rc_poll = wait_flag(h_flag1, d.seq); if (rc_poll) return rc_poll; }
     if (ba->allreduce) {
       SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
       if (ba->allreduce(d.pay1, pay1, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
     }
     if (!zero_copy) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay1, d.pay1, sizeof(double) * pay1, hipMemcpyDeviceToHost, st));
-    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (!poll) SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
     // mirror the upper pair blocks (kernel writes each unordered pose pair once)
     const double* S = h_pay1;
     for (int a = 0; a < K - 1; ++a)
@@ -1700,7 +1757,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         ba->t_host += ms(th0, tb0);
         // one H2D: [dc (n) | candidate poses (7K)] are adjacent both in the pinned buffer and on the device
         d.poses = cur_poses; d.cand_poses = cand_poses; d.dc = cand_poses - (n > 0 ? n : 1);
-        SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.dc, h_dc, sizeof(double) * ((n > 0 ? n : 1) + 7 * K), hipMemcpyHostToDevice, st));
+        d.step_in = h_dc;  // zero-copy: the kernel reads the 6(K-1)+7K doubles straight from the pinned buffer
         if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay2, 0, sizeof(double) * 4, st));
         d.points = cur_points; d.cand_points = cand_points;
         if (d.C > 0) {
@@ -1708,14 +1765,16 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
           if (d.det) hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.C), dim3(64), 0, st, d, radius);
           else hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
         }
+        if (poll) d.seq = ++ba->seq;
         if (d.det) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(128), 0, st, d);
         SVO_HIP_CHECK(ctx, hipGetLastError());
+        if (poll) { rc = wait_flag(h_flag2, d.seq); if (rc) return rc; }
         if (ba->allreduce) {
           SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
           if (ba->allreduce(d.pay2, 4, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
         }
         if (!(d.det && !ba->allreduce)) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay2, d.pay2, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
-        SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        if (!poll) SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
         ba->t_back += ms(tb0, now()); ba->n_back++;
         cost_new = h_pay2[0];
         model_change = mcc + h_pay2[1];
@@ -1759,6 +1818,8 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         radius /= decrease_factor; decrease_factor *= 2; need_linearize = true;
       }
     }
+  if (poll) SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));  // nothing is pending; keeps later users of the stream ordered
+  d.flag1 = d.flag2 = nullptr;
   // leave the result in d.points / d.poses
   d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
   if (sum) {

@@ -20,9 +20,17 @@ size_t svo_k_pyramid_bytes(int w, int h);
 int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride,
                         size_t image_stride, uint8_t* pyr, size_t pyr_stride);
 // forward+backward LK and the survivor filter of FeatureTracker::track_features.
+// optional extras of the compaction step: per-feature state carried along with the kept features, and pinned
+// host words that receive (n_kept, av_parallax) directly
+struct SvoTrackCarry {
+  const float* init_src = nullptr; const long long* ids_src = nullptr;
+  float* init_dst = nullptr; long long* ids_dst = nullptr;
+  int* host_n = nullptr; float* host_av = nullptr;
+};
 int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
                 const float* initial_xy, const int* n_dev, int n_max, float* fwd_xy, uint8_t* keep_flag,
-                float* parallax, float* kept_xy, int* kept_index, int* n_kept, float* av_parallax);
+                float* parallax, float* kept_xy, int* kept_index, int* n_kept, float* av_parallax,
+                const SvoTrackCarry* carry = nullptr);
 int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
              int n, float* out_xy, uint8_t* status);
 // gathers used by the tracker / pipeline: dst[i] = src[idx[i]] for i < n (n on the device or host)

@@ -321,7 +321,8 @@ __global__ __launch_bounds__(LKT) void lk_fb_kernel(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __restrict__ fwd, const uint8_t* __restrict__ keep,
                                                              const float* __restrict__ parallax, const int* __restrict__ n_dev,
                                                              int n_host, float* __restrict__ kept_xy, int* __restrict__ kept_index,
-                                                             int* __restrict__ n_kept, float* __restrict__ av_parallax) {
+                                                             int* __restrict__ n_kept, float* __restrict__ av_parallax,
+                                                             SvoTrackCarry carry) {
   __shared__ int sWave[16];
   const int n = n_dev ? *n_dev : n_host;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -338,6 +339,10 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
       const int slot = base + off + __popcll(mask & ((1ull << lane) - 1ull));
       kept_xy[2 * slot] = fwd[2 * i]; kept_xy[2 * slot + 1] = fwd[2 * i + 1];
       kept_index[slot] = i;
+      if (carry.init_src) {  // the tracker's per-feature state follows the feature (C-1: old ids)
+        carry.init_dst[2 * slot] = carry.init_src[2 * i]; carry.init_dst[2 * slot + 1] = carry.init_src[2 * i + 1];
+        carry.ids_dst[slot] = carry.ids_src[i];
+      }
     }
     base += total;
     __syncthreads();
@@ -356,8 +361,13 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
     }
   }
   if (threadIdx.x == 0) {
+    const float av = n > 0 ? sum / (float)n : 0.f;
     *n_kept = base;
-    *av_parallax = n > 0 ? sum / (float)n : 0.f;
+    *av_parallax = av;
+    if (carry.host_n) {  // pinned host words: the keyframe gate reads them after the stream wait, no D2H blit
+      *carry.host_n = base;
+      *carry.host_av = av;
+    }
   }
 }
 
@@ -397,14 +407,14 @@ int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int
 
 int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy,
                 const float* initial_xy, const int* n_dev, int n_max, float* fwd_xy, uint8_t* keep_flag, float* parallax,
-                float* kept_xy, int* kept_index, int* n_kept, float* av_parallax) {
+                float* kept_xy, int* kept_index, int* n_kept, float* av_parallax, const SvoTrackCarry* carry) {
   if (n_max > 0) {
     SvoProfScope prof(ctx, SVO_PROF_LK_FB);
     hipLaunchKernelGGL(lk_fb_kernel, dim3(n_max), dim3(LKT), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
                        n_max, fwd_xy, keep_flag, parallax);
   }
   hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, fwd_xy, keep_flag, parallax, n_dev, n_max,
-                     kept_xy, kept_index, n_kept, av_parallax);
+                     kept_xy, kept_index, n_kept, av_parallax, carry ? *carry : SvoTrackCarry{});
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -175,24 +175,41 @@ void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const s
     SVO_TRY(hipMemcpyAsync(d_init_[cur_], features.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
     SVO_TRY(hipMemcpyAsync(d_ids_[cur_], id64.data(), sizeof(long long) * n, hipMemcpyHostToDevice, st));
   }
-  SVO_TRY(hipMemcpyAsync(d_last_pyr_, pyramid, svo_k_pyramid_bytes(width, height), hipMemcpyDeviceToDevice, st));  // clone, :14
+  remember(pyramid, width, height);  // clone, :14
   SVO_TRY(hipStreamSynchronize(st));  // id64 / features are host temporaries
   n_ = n_initial_ = n;
   has_image_ = true;
+}
+
+// The reference clones the image it will track from (src/feature_tracker.cpp:14,66).  With borrowed pyramids
+// (the owner keeps them alive and calls retain() before overwriting them) the clone is deferred to retain().
+void FeatureTracker::remember(const uint8_t* pyramid, int width, int height) {
+  last_w_ = width; last_h_ = height;
+  if (borrow_) { last_pyr_ = pyramid; return; }
+  SVO_TRY(hipMemcpyAsync(d_last_pyr_, pyramid, svo_k_pyramid_bytes(width, height), hipMemcpyDeviceToDevice, ctx_->stream));
+  last_pyr_ = d_last_pyr_;
+}
+
+void FeatureTracker::retain() {
+  if (!last_pyr_ || last_pyr_ == d_last_pyr_) return;
+  SVO_TRY(hipMemcpyAsync(d_last_pyr_, last_pyr_, svo_k_pyramid_bytes(last_w_, last_h_), hipMemcpyDeviceToDevice, ctx_->stream));
+  last_pyr_ = d_last_pyr_;
 }
 
 void FeatureTracker::track_features(float& av_parallax, float& percent_lost, const uint8_t* pyramid, int width, int height,
                                     bool /*flow_back: the reference always passes true*/) {  // src/feature_tracker.cpp:18-67
   hipStream_t st = ctx_->stream;
   const int nxt = 1 - cur_;
-  if (svo_k_track(ctx_, d_last_pyr_, pyramid, width, height, d_xy_[cur_], d_init_[cur_], nullptr, n_, d_fwd_, d_keep_, d_par_,
-                  d_xy_[nxt], d_kidx_, d_n_, d_av_)) return;
-  if (svo_k_gather_track(ctx_, d_kidx_, d_n_, n_, d_init_[cur_], d_ids_[cur_], d_init_[nxt], d_ids_[nxt])) return;  // C-1: old ids
   int* h_n = (int*)ctx_->h_pinned;
   float* h_av = (float*)ctx_->h_pinned + 1;
-  SVO_TRY(hipMemcpyAsync(h_n, d_n_, sizeof(int), hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipMemcpyAsync(h_av, d_av_, sizeof(float), hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipMemcpyAsync(d_last_pyr_, pyramid, svo_k_pyramid_bytes(width, height), hipMemcpyDeviceToDevice, st));  // :66
+  // one compaction launch also carries (initial position, id) along with the kept features (C-1: old ids) and
+  // writes (n_kept, av_parallax) into the pinned words: no gather launch, no D2H blits
+  SvoTrackCarry carry;
+  carry.init_src = d_init_[cur_]; carry.ids_src = d_ids_[cur_]; carry.init_dst = d_init_[nxt]; carry.ids_dst = d_ids_[nxt];
+  carry.host_n = h_n; carry.host_av = h_av;
+  if (svo_k_track(ctx_, last_pyr_, pyramid, width, height, d_xy_[cur_], d_init_[cur_], nullptr, n_, d_fwd_, d_keep_, d_par_,
+                  d_xy_[nxt], d_kidx_, d_n_, d_av_, &carry)) return;
+  remember(pyramid, width, height);  // :66
   SVO_TRY(hipStreamSynchronize(st));
   cur_ = nxt;
   n_ = *h_n;
@@ -261,6 +278,7 @@ ImageProcessor::ImageProcessor(svo_ctx* ctx, const float K[9], std::shared_ptr<F
       min_feature_distance(min_dist), parallax_thresh(par_thresh), max_corners_(max_corners), quality_(quality),
       max_batch_(max_batch < 1 ? 1 : max_batch) {
   memcpy(K_, K, sizeof(K_));
+  feature_tracker->borrow_pyramids(true);  // the batch pyramids outlive every frame of the batch; retain() in prepare_batch
   pyr_stride_ = svo_k_pyramid_bytes(ctx->lim.max_width, ctx->lim.max_height);
   const size_t mc = (size_t)max_corners_, mf = (size_t)ctx->lim.max_features;
   (void)hipMalloc((void**)&d_corners_, sizeof(float) * 2 * mc * max_batch_);
@@ -300,6 +318,7 @@ int ImageProcessor::prepare_batch(const uint8_t* left, int batch, int width, int
                                        (double)min_feature_distance, d_corners_, d_ncorners_);
   if (rc) return rc;
   pyr_stride_ = svo_k_pyramid_bytes(width, height);
+  feature_tracker->retain();  // the tracker's previous image may live in the buffer overwritten next
   rc = svo_k_build_pyramid(ctx_, left, batch, width, height, width, istride, d_pyr_, pyr_stride_);
   if (rc) return rc;
   int* h = (int*)((char*)ctx_->h_pinned + 8192);

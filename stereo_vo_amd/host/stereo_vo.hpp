@@ -117,8 +117,13 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   const float* device_features() const { return d_xy_[cur_]; }
   const long long* device_ids() const { return d_ids_[cur_]; }
   int count() const { return n_; }
-  void reset() { n_ = 0; n_initial_ = 0; has_image_ = false; }
+  void reset() { n_ = 0; n_initial_ = 0; has_image_ = false; last_pyr_ = nullptr; }
+  // Borrowed pyramids: the caller keeps every pyramid passed to init()/track_features() alive and calls retain()
+  // before overwriting it; the per-frame clone (src/feature_tracker.cpp:14,66) is then made only at retain().
+  void borrow_pyramids(bool on) { borrow_ = on; }
+  void retain();
  private:
+  void remember(const uint8_t* pyramid, int width, int height);
   svo_ctx* ctx_;
   int cap_;
   size_t pyr_cap_;
@@ -128,6 +133,9 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   float* d_fwd_ = nullptr; float* d_par_ = nullptr; uint8_t* d_keep_ = nullptr; int* d_kidx_ = nullptr;
   int* d_n_ = nullptr; float* d_av_ = nullptr;
   uint8_t* d_last_pyr_ = nullptr;
+  const uint8_t* last_pyr_ = nullptr;  // d_last_pyr_ or a borrowed pyramid
+  int last_w_ = 0, last_h_ = 0;
+  bool borrow_ = false;
   int cur_ = 0, n_ = 0, n_initial_ = 0;
   bool has_image_ = false;
 };
