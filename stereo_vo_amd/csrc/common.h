@@ -37,7 +37,52 @@ struct svo_ctx {
   int prof_tag = 0;
   std::vector<hipEvent_t> prof_ev;  // start/stop pairs
   int prof_used = 0;                // pairs recorded
+  // completion words (see SvoPublish)
+  int word_seq = 0;
+  unsigned arrive_total = 0;
 };
+
+// Host-visible completion words.  A kernel whose results the host needs writes them straight into pinned
+// host memory and then publishes a sequence number (system-scope fence, then one release store); the host
+// polls the word.  This replaces "D2H blit + hipStreamSynchronize" per readback: no copy kernel, no runtime
+// call on the wait, and with many stereo streams per GPU no contention on the runtime's locks.
+enum SvoWord { SVO_W_TRACK = 0, SVO_W_INIT, SVO_W_PNP_HYP, SVO_W_PNP_REF, SVO_W_TRI, SVO_W_N };
+struct SvoPublish {
+  int* word = nullptr;         // pinned host word
+  int seq = 0;                 // value that means "this launch is complete"
+  unsigned* arrive = nullptr;  // multi-workgroup kernels: device counter (monotone), last arrival publishes
+  unsigned target = 0;
+};
+inline int* svo_word(svo_ctx* c, int which) { return reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - 4096) + 16 * which; }
+inline SvoPublish svo_publish_next(svo_ctx* c, int which, int nblocks = 1) {
+  SvoPublish p;
+  p.word = svo_word(c, which);
+  p.seq = ++c->word_seq;
+  if (nblocks > 1) {
+    c->arrive_total += (unsigned)nblocks;
+    p.arrive = reinterpret_cast<unsigned*>(c->d_status + 8);
+    p.target = c->arrive_total;
+  }
+  return p;
+}
+int svo_wait_word(svo_ctx* c, const SvoPublish& p);  // ctx.hip: bounded spin, falls back to a stream wait
+
+#if defined(__HIPCC__)
+// Called by EVERY thread of the workgroup after its last store to host memory.
+__device__ __forceinline__ void svo_publish_block(const SvoPublish& p) {
+  if (!p.word) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool last = true;
+    if (p.arrive) last = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == p.target;
+    if (last) {
+      __threadfence_system();
+      __hip_atomic_store(p.word, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+#endif
 
 enum SvoProfTag { SVO_PROF_NONE = 0, SVO_PROF_CORNER_RESPONSE, SVO_PROF_CORNER_NMS, SVO_PROF_CORNER_SELECT,
                   SVO_PROF_PYR_DOWN, SVO_PROF_LK_FB, SVO_PROF_STEREO_AT, SVO_PROF_TRIANGULATE, SVO_PROF_PNP_HYP,

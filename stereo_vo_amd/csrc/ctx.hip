@@ -1,4 +1,6 @@
 // Context lifetime and workspace (svo.h: svo_create / svo_destroy / svo_stream / svo_sync).
+#include <chrono>
+
 #include "common.h"
 
 extern "C" const char* svo_version(void) { return "stereo_vo_amd 0.1 (gfx950, HIP, wave64)"; }
@@ -93,6 +95,20 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
   if ((e = hipMemsetAsync(c->d_status, 0, 64, c->stream)) != hipSuccess) return fail("memset", e);
   if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("sync", e);
   *out = c;
+  return SVO_OK;
+}
+
+int svo_wait_word(svo_ctx* c, const SvoPublish& p) {
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (__atomic_load_n(p.word, __ATOMIC_ACQUIRE) != p.seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xFFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+      // never expected: fall back to the stream wait so that a lost word cannot hang the caller
+      SVO_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+      if (__atomic_load_n(p.word, __ATOMIC_ACQUIRE) != p.seq) { c->err = "completion word never arrived"; return SVO_ERR_HIP; }
+    }
+  }
   return SVO_OK;
 }
 

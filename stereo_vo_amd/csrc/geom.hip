@@ -31,7 +31,8 @@ __device__ __forceinline__ int compact_slot(bool keep, int& base, int* sWave) {
 __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict__ xy, const float* __restrict__ disp,
                                                          const int* __restrict__ n_dev, int n_host, SvoMat4 M,
                                                          float* __restrict__ kept_xy, float* __restrict__ xyz,
-                                                         int* __restrict__ kept_index, int* __restrict__ n_kept) {
+                                                         int* __restrict__ kept_index, int* __restrict__ n_kept,
+                                                         SvoPublish pub) {
   __shared__ int sWave[CT / 64];
   const int n = n_dev ? *n_dev : n_host;
   int base = 0;
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict
     }
   }
   if (threadIdx.x == 0) *n_kept = base;
+  svo_publish_block(pub);  // the outputs may be pinned host memory (pipeline): the host polls instead of copying
 }
 
 // one wavefront per detected corner: 64 tracked features are tested per step, any hit drops the corner
@@ -121,6 +123,26 @@ int svo_k_gather_track(svo_ctx* ctx, const int* idx, const int* n_dev, int n_max
   return SVO_OK;
 }
 
+__global__ void tracker_init_kernel(const float* __restrict__ h_xy, const long long* __restrict__ h_ids, int n,
+                                    float* __restrict__ d_xy, float* __restrict__ d_init, long long* __restrict__ d_ids,
+                                    SvoPublish pub) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float x = h_xy[2 * i], y = h_xy[2 * i + 1];
+    d_xy[2 * i] = x; d_xy[2 * i + 1] = y;
+    d_init[2 * i] = x; d_init[2 * i + 1] = y;
+    d_ids[i] = h_ids[i];
+  }
+  svo_publish_block(pub);
+}
+
+int svo_k_tracker_init(svo_ctx* ctx, const float* h_xy, const long long* h_ids, int n, float* d_xy, float* d_init,
+                       long long* d_ids, const SvoPublish* pub) {
+  hipLaunchKernelGGL(tracker_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, h_xy, h_ids, n, d_xy, d_init, d_ids,
+                     pub ? *pub : SvoPublish{});
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
 int svo_k_gather_xy_ids(svo_ctx* ctx, const int* idx, int n, const float* xy_src, const long long* ids_src,
                         float* xy_dst, long long* ids_dst) {
   return svo_k_gather_track(ctx, idx, nullptr, n, xy_src, ids_src, xy_dst, ids_dst);
@@ -145,10 +167,10 @@ SvoMat4 svo_k_reprojection_matrix(const float* pose16, float focal, float cx, fl
 }
 
 int svo_k_triangulate(svo_ctx* ctx, const float* xy, const float* disp, const int* n_dev, int n_max,
-                      const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept) {
+                      const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept, const SvoPublish* pub) {
   SvoProfScope prof(ctx, SVO_PROF_TRIANGULATE);
   hipLaunchKernelGGL(triangulate_kernel, dim3(1), dim3(CT), 0, ctx->stream, xy, disp, n_dev, n_max, M, kept_xy, xyz,
-                     kept_index, n_kept);
+                     kept_index, n_kept, pub ? *pub : SvoPublish{});
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

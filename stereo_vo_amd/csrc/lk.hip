@@ -341,7 +341,9 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
       kept_index[slot] = i;
       if (carry.init_src) {  // the tracker's per-feature state follows the feature (C-1: old ids)
         carry.init_dst[2 * slot] = carry.init_src[2 * i]; carry.init_dst[2 * slot + 1] = carry.init_src[2 * i + 1];
-        carry.ids_dst[slot] = carry.ids_src[i];
+        const long long id = carry.ids_src[i];
+        carry.ids_dst[slot] = id;
+        if (carry.host_xy) { carry.host_xy[2 * slot] = fwd[2 * i]; carry.host_xy[2 * slot + 1] = fwd[2 * i + 1]; carry.host_ids[slot] = id; }
       }
     }
     base += total;
@@ -364,11 +366,12 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
     const float av = n > 0 ? sum / (float)n : 0.f;
     *n_kept = base;
     *av_parallax = av;
-    if (carry.host_n) {  // pinned host words: the keyframe gate reads them after the stream wait, no D2H blit
+    if (carry.host_n) {  // pinned host words: the keyframe gate reads them, no D2H blit
       *carry.host_n = base;
       *carry.host_av = av;
     }
   }
+  svo_publish_block(carry.pub);
 }
 
 // ----------------------------------------------------------------------------- host side

@@ -148,7 +148,8 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
                                                             int n, double f, double cx, double cy, PnpPose P0,
                                                             double thr2, double* __restrict__ hyp_pose,
                                                             int* __restrict__ hyp_count,
-                                                            unsigned long long* __restrict__ hyp_mask, int mask_words) {
+                                                            unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                            int* __restrict__ host_count, SvoPublish pub) {
   __shared__ LmShared S;
   __shared__ int sIdx[MODEL];
   __shared__ double sJ[MODEL][12], sE[MODEL][2];
@@ -218,16 +219,20 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
   }
   if (lane == 0) {
     hyp_count[h] = cnt;
+    if (host_count) host_count[h] = cnt;  // pinned: the host's RANSAC bookkeeping reads the counts in place
     for (int k = 0; k < 4; ++k) hyp_pose[7 * h + k] = P.q[k];
     for (int k = 0; k < 3; ++k) hyp_pose[7 * h + 4 + k] = P.t[k];
   }
+  svo_publish_block(pub);
 }
 
 __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
                                                          double f, double cx, double cy, const double* __restrict__ hyp_pose,
                                                          const unsigned long long* __restrict__ hyp_mask, int mask_words,
                                                          int best, double* __restrict__ out_pose, int* __restrict__ inliers,
-                                                         int* __restrict__ n_inliers) {
+                                                         int* __restrict__ n_inliers, double* __restrict__ host_pose,
+                                                         int* __restrict__ host_inliers, int* __restrict__ host_nin,
+                                                         SvoPublish pub) {
   __shared__ LmShared S;
   __shared__ double sPart[256][28];
   __shared__ int sBase;
@@ -237,7 +242,11 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
     int base = 0;
     for (int w = 0; w < mask_words; ++w) {
       const unsigned long long m = hyp_mask[(size_t)best * mask_words + w];
-      if ((m >> tid) & 1ull) inliers[base + __popcll(m & ((1ull << tid) - 1ull))] = w * 64 + tid;
+      if ((m >> tid) & 1ull) {
+        const int slot = base + __popcll(m & ((1ull << tid) - 1ull));
+        inliers[slot] = w * 64 + tid;
+        if (host_inliers) host_inliers[slot] = w * 64 + tid;
+      }
       base += __popcll(m);
     }
     if (tid == 0) {
@@ -293,7 +302,13 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
     for (int k = 0; k < 4; ++k) out_pose[k] = S.cur.q[k];
     for (int k = 0; k < 3; ++k) out_pose[4 + k] = S.cur.t[k];
     *n_inliers = m;
+    if (host_pose) {
+      for (int k = 0; k < 4; ++k) host_pose[k] = S.cur.q[k];
+      for (int k = 0; k < 3; ++k) host_pose[4 + k] = S.cur.t[k];
+      *host_nin = m;
+    }
   }
+  svo_publish_block(pub);
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -312,7 +327,7 @@ static int update_num_iters(double p, double ep, int model_points, int max_iters
 // Work buffers come from `s`.  On return rvec3/tvec3 are updated (host), d_inliers holds the list.
 int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy, int n, float focal, float cxf, float cyf,
               double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence, int* d_inliers,
-              int* n_inliers) {
+              int* n_inliers, int* h_inliers) {
   *n_inliers = 0;
   if (n < MODEL || iterations < 1) return SVO_OK;
   PnpPose P0;
@@ -334,16 +349,19 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   if (!d_pose || !d_count || !d_mask || !d_out || !d_nin) { ctx->err = "pnp: workspace too small"; return SVO_ERR_CAPACITY; }
   hipStream_t st = ctx->stream;
   const double thr2 = (double)reproj_err * (double)reproj_err;
+  // both kernels write what the host needs straight into pinned memory and publish a completion word:
+  // no D2H blits, no stream waits
+  int* h_count = (int*)ctx->h_pinned;
+  if ((size_t)iterations * sizeof(int) + 64 > 4096) { ctx->err = "pnp: too many iterations"; return SVO_ERR_CAPACITY; }
+  const SvoPublish pub1 = svo_publish_next(ctx, SVO_W_PNP_HYP, iterations);
   {
   SvoProfScope prof(ctx, SVO_PROF_PNP_HYP);
   hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3(iterations), dim3(64), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf,
-                     (double)cyf, P0, thr2, d_pose, d_count, d_mask, words);
+                     (double)cyf, P0, thr2, d_pose, d_count, d_mask, words, h_count, pub1);
   }
   SVO_HIP_CHECK(ctx, hipGetLastError());
-  int* h_count = (int*)ctx->h_pinned;
-  if ((size_t)iterations * sizeof(int) + 64 > ctx->pinned_bytes) { ctx->err = "pnp: too many iterations"; return SVO_ERR_CAPACITY; }
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_count, d_count, sizeof(int) * iterations, hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  int rc = svo_wait_word(ctx, pub1);
+  if (rc) return rc;
   int best = -1, best_cnt = 0, niters = iterations;
   for (int h = 0; h < niters; ++h) {
     if (h_count[h] > std::max(best_cnt, MODEL - 1)) {
@@ -352,17 +370,17 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
     }
   }
   if (best < 0) return SVO_OK;
+  double* h_out = (double*)((char*)ctx->h_pinned + 4096);
+  int* h_nin = (int*)((char*)ctx->h_pinned + 4096 + 64);
+  const SvoPublish pub2 = svo_publish_next(ctx, SVO_W_PNP_REF);
   {
   SvoProfScope prof(ctx, SVO_PROF_PNP_REFINE);
   hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf, (double)cyf,
-                     d_pose, d_mask, words, best, d_out, d_inliers, d_nin);
+                     d_pose, d_mask, words, best, d_out, d_inliers, d_nin, h_out, h_inliers, h_nin, pub2);
   }
   SVO_HIP_CHECK(ctx, hipGetLastError());
-  double* h_out = (double*)((char*)ctx->h_pinned + 4096);
-  int* h_nin = (int*)((char*)ctx->h_pinned + 4096 + 64);
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_out, d_out, sizeof(double) * 7, hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_nin, d_nin, sizeof(int), hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  rc = svo_wait_word(ctx, pub2);
+  if (rc) return rc;
   double q[4] = {h_out[0], h_out[1], h_out[2], h_out[3]};
   if (q[0] < 0) for (double& v : q) v = -v;
   const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -393,7 +411,7 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, i
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxyz, xyz, sizeof(float) * 3 * n, hipMemcpyHostToDevice, st));
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(dxy, xy, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
-  int rc = svo_k_pnp(ctx, s, dxyz, dxy, n, focal, cx, cy, rvec3, tvec3, iterations, reproj_err, confidence, din, n_inliers);
+  int rc = svo_k_pnp(ctx, s, dxyz, dxy, n, focal, cx, cy, rvec3, tvec3, iterations, reproj_err, confidence, din, n_inliers, nullptr);
   if (rc) return rc;
   if (*n_inliers > 0) {
     SVO_HIP_CHECK(ctx, hipMemcpyAsync(inliers, din, sizeof(int) * (size_t)*n_inliers, hipMemcpyDeviceToHost, st));

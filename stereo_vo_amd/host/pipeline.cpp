@@ -141,6 +141,15 @@ void BundleAdjuster::get_world_points(std::vector<Point3f>& world_points, const 
   svo_ba_get_points(ba_, id64.data(), (int)n, (float*)(world_points.data() + base));  // :159-163
 }
 
+void BundleAdjuster::get_world_points_into(float* xyz, const std::vector<size_t>& ids) {
+  wait();
+  const size_t n = ids.size();
+  if (!n || !ba_) return;
+  std::vector<int64_t> id64(n);
+  for (size_t i = 0; i < n; ++i) id64[i] = (int64_t)ids[i];
+  svo_ba_get_points(ba_, id64.data(), (int)n, xyz);  // :159-163
+}
+
 // ------------------------------------------------------------------------------------------ FeatureTracker
 FeatureTracker::FeatureTracker(svo_ctx* ctx, int max_features, int max_width, int max_height) : ctx_(ctx), cap_(max_features) {
   pyr_cap_ = svo_k_pyramid_bytes(max_width, max_height);
@@ -156,11 +165,18 @@ FeatureTracker::FeatureTracker(svo_ctx* ctx, int max_features, int max_width, in
   (void)hipMalloc((void**)&d_n_, sizeof(int));
   (void)hipMalloc((void**)&d_av_, sizeof(float));
   (void)hipMalloc((void**)&d_last_pyr_, pyr_cap_);
+  // pinned host mirrors of the current feature set: the compaction kernel writes them in place
+  (void)hipHostMalloc((void**)&h_mirror_, (sizeof(float) * 2 + sizeof(long long)) * (size_t)cap_ + 64, hipHostMallocDefault);
+  h_ids_ = reinterpret_cast<long long*>(h_mirror_);
+  h_xy_ = reinterpret_cast<float*>(h_ids_ + cap_);
+  h_n_ = reinterpret_cast<int*>(h_xy_ + 2 * (size_t)cap_);
+  h_av_ = reinterpret_cast<float*>(h_n_ + 1);
 }
 
 FeatureTracker::~FeatureTracker() {
   void* ptrs[] = {d_xy_[0], d_xy_[1], d_init_[0], d_init_[1], d_ids_[0], d_ids_[1], d_fwd_, d_par_, d_keep_, d_kidx_, d_n_, d_av_, d_last_pyr_};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h_mirror_) (void)hipHostFree(h_mirror_);
 }
 
 void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const std::vector<Point2f>& features,
@@ -168,15 +184,19 @@ void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const s
   hipStream_t st = ctx_->stream;
   int n = (int)ids.size();
   if (n > cap_) n = cap_;
-  std::vector<long long> id64(n);
-  for (int i = 0; i < n; ++i) id64[i] = (long long)ids[i];
-  if (n) {
-    SVO_TRY(hipMemcpyAsync(d_xy_[cur_], features.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
-    SVO_TRY(hipMemcpyAsync(d_init_[cur_], features.data(), sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
-    SVO_TRY(hipMemcpyAsync(d_ids_[cur_], id64.data(), sizeof(long long) * n, hipMemcpyHostToDevice, st));
+  // the previous init launch may still be reading the mirrors
+  if (pending_init_seq_) {
+    SvoPublish prev; prev.word = svo_word(ctx_, SVO_W_INIT); prev.seq = pending_init_seq_;
+    if (svo_wait_word(ctx_, prev)) return;
+    pending_init_seq_ = 0;
   }
+  if (n) memcpy(h_xy_, features.data(), sizeof(float) * 2 * n);
+  for (int i = 0; i < n; ++i) h_ids_[i] = (long long)ids[i];
+  const SvoPublish pub = svo_publish_next(ctx_, SVO_W_INIT);
+  pending_init_seq_ = pub.seq;
+  if (svo_k_tracker_init(ctx_, h_xy_, h_ids_, n, d_xy_[cur_], d_init_[cur_], d_ids_[cur_], &pub)) return;
   remember(pyramid, width, height);  // clone, :14
-  SVO_TRY(hipStreamSynchronize(st));  // id64 / features are host temporaries
+  if (!borrow_) SVO_TRY(hipStreamSynchronize(st));  // the caller may reuse `pyramid` right away
   n_ = n_initial_ = n;
   has_image_ = true;
 }
@@ -200,20 +220,22 @@ void FeatureTracker::track_features(float& av_parallax, float& percent_lost, con
                                     bool /*flow_back: the reference always passes true*/) {  // src/feature_tracker.cpp:18-67
   hipStream_t st = ctx_->stream;
   const int nxt = 1 - cur_;
-  int* h_n = (int*)ctx_->h_pinned;
-  float* h_av = (float*)ctx_->h_pinned + 1;
-  // one compaction launch also carries (initial position, id) along with the kept features (C-1: old ids) and
-  // writes (n_kept, av_parallax) into the pinned words: no gather launch, no D2H blits
+  // one compaction launch also carries (initial position, id) along with the kept features (C-1: old ids), mirrors
+  // the kept features / ids into pinned host memory and publishes (n_kept, av_parallax) + a completion word:
+  // no gather launch, no D2H blits, no stream wait
   SvoTrackCarry carry;
   carry.init_src = d_init_[cur_]; carry.ids_src = d_ids_[cur_]; carry.init_dst = d_init_[nxt]; carry.ids_dst = d_ids_[nxt];
-  carry.host_n = h_n; carry.host_av = h_av;
+  carry.host_n = h_n_; carry.host_av = h_av_; carry.host_xy = h_xy_; carry.host_ids = h_ids_;
+  carry.pub = svo_publish_next(ctx_, SVO_W_TRACK);
   if (svo_k_track(ctx_, last_pyr_, pyramid, width, height, d_xy_[cur_], d_init_[cur_], nullptr, n_, d_fwd_, d_keep_, d_par_,
                   d_xy_[nxt], d_kidx_, d_n_, d_av_, &carry)) return;
   remember(pyramid, width, height);  // :66
-  SVO_TRY(hipStreamSynchronize(st));
+  if (svo_wait_word(ctx_, carry.pub)) return;
+  if (!borrow_) SVO_TRY(hipStreamSynchronize(st));
+  pending_init_seq_ = 0;  // stream order: the init launch finished before this track did
   cur_ = nxt;
-  n_ = *h_n;
-  av_parallax = *h_av;                                                                    // :63
+  n_ = *h_n_;
+  av_parallax = *h_av_;                                                                   // :63
   percent_lost = (float)(1.0 - (double)((float)n_ / (float)n_initial_));                   // :64
 }
 
@@ -221,12 +243,8 @@ void FeatureTracker::get_tracked_features(std::vector<Point2f>& features, std::v
   features.resize(n_);
   ids.resize(n_);
   if (!n_) return;
-  std::vector<long long> id64(n_);
-  hipStream_t st = ctx_->stream;
-  SVO_TRY(hipMemcpyAsync(features.data(), d_xy_[cur_], sizeof(float) * 2 * n_, hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipMemcpyAsync(id64.data(), d_ids_[cur_], sizeof(long long) * n_, hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipStreamSynchronize(st));
-  for (int i = 0; i < n_; ++i) ids[i] = (size_t)id64[i];
+  memcpy(features.data(), h_xy_, sizeof(float) * 2 * n_);  // pinned mirrors, current since the last init / track
+  for (int i = 0; i < n_; ++i) ids[i] = (size_t)h_ids_[i];
 }
 
 // ------------------------------------------------------------------------------------------ ImageProcessor
@@ -294,11 +312,21 @@ ImageProcessor::ImageProcessor(svo_ctx* ctx, const float K[9], std::shared_ptr<F
   d_kxyz_ = d_kxy_ + 2 * mc;
   (void)hipMalloc((void**)&d_cnt_, sizeof(int) * 4);
   h_ncorners_.assign(max_batch_, 0);
+  // pinned host arena: world points for PnP | inlier list | triangulation outputs (count, kept 2-D, 3-D).
+  // Kernels read / write these in place; the host polls completion words (common.h SvoPublish).
+  const size_t bytes = sizeof(float) * 3 * mf + sizeof(int) * mf + 64 + sizeof(float) * 5 * mc + 256;
+  (void)hipHostMalloc((void**)&h_arena_, bytes, hipHostMallocDefault);
+  h_xyz_ = reinterpret_cast<float*>(h_arena_);
+  h_inl_ = reinterpret_cast<int*>(h_xyz_ + 3 * mf);
+  h_tri_cnt_ = h_inl_ + mf;
+  h_tri_xy_ = reinterpret_cast<float*>(h_tri_cnt_ + 16);
+  h_tri_xyz_ = h_tri_xy_ + 2 * mc;
 }
 
 ImageProcessor::~ImageProcessor() {
   void* ptrs[] = {d_corners_, d_ncorners_, d_pyr_, d_xyz_, d_trk_xy_, d_trk_ids_, d_inl_, d_new_xy_, d_disp_, d_kxy_, d_cnt_};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  if (h_arena_) (void)hipHostFree(h_arena_);
 }
 
 void ImageProcessor::reset() {
@@ -342,23 +370,19 @@ void ImageProcessor::triangulate_stereo(std::vector<Point3f>& features_3d, std::
                                         const float* d_features, const int* d_n, int n_max, const DeviceImage& left,
                                         const DeviceImage& right, const float camera_pose[16]) {
   if (n_max <= 0) return;
-  hipStream_t st = ctx_->stream;
   if (svo_stereo_disparity_at_dev(ctx_, left.data, right.data, left.width, left.height, left.stride, 16 * 3, 21, d_features,
                                   d_n, n_max, d_disp_)) return;  // :173-176
   const SvoMat4 M = svo_k_reprojection_matrix(camera_pose, K_[0], K_[2], K_[5], baseline);  // :178-189
-  if (svo_k_triangulate(ctx_, d_features, d_disp_, d_n, n_max, M, d_kxy_, d_kxyz_, nullptr, d_cnt_ + 1)) return;
-  // one readback: count + kept 2-D + 3-D (n_max entries each; only the first `count` are meaningful)
-  int* h_cnt = (int*)((char*)ctx_->h_pinned + 16384);
-  float* h_buf = (float*)((char*)ctx_->h_pinned + 16384 + 64);
-  SVO_TRY(hipMemcpyAsync(h_cnt, d_cnt_ + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipMemcpyAsync(h_buf, d_kxy_, sizeof(float) * 2 * n_max, hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipMemcpyAsync(h_buf + 2 * n_max, d_kxyz_, sizeof(float) * 3 * n_max, hipMemcpyDeviceToHost, st));
-  SVO_TRY(hipStreamSynchronize(st));
-  const int m = *h_cnt;
+  // the kernel's outputs are only consumed by the host (keyframe bookkeeping): it writes them into the pinned arena
+  // and publishes a completion word — no D2H blits, no stream wait
+  const SvoPublish pub = svo_publish_next(ctx_, SVO_W_TRI);
+  if (svo_k_triangulate(ctx_, d_features, d_disp_, d_n, n_max, M, h_tri_xy_, h_tri_xyz_, nullptr, h_tri_cnt_, &pub)) return;
+  if (svo_wait_word(ctx_, pub)) return;
+  const int m = *h_tri_cnt_;
   valid_features_2d.resize(m);
   features_3d.resize(m);
-  memcpy(valid_features_2d.data(), h_buf, sizeof(float) * 2 * m);
-  memcpy(features_3d.data(), h_buf + 2 * n_max, sizeof(float) * 3 * m);
+  memcpy(valid_features_2d.data(), h_tri_xy_, sizeof(float) * 2 * m);
+  memcpy(features_3d.data(), h_tri_xyz_, sizeof(float) * 3 * m);
 }
 
 void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp:18-163
@@ -404,25 +428,20 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
 
   PhaseTimer* ptp = new PhaseTimer(2);
   std::vector<Point2f> tracked_features;
-  std::vector<Point3f> tracked_world_points;
   std::vector<size_t> tracked_ids;
-  feature_tracker->get_tracked_features(tracked_features, tracked_ids);   // :71
-  bundle_adjuster->get_world_points(tracked_world_points, tracked_ids);   // :72
+  feature_tracker->get_tracked_features(tracked_features, tracked_ids);   // :71 (pinned mirrors: no copy, no wait)
   const int m = (int)tracked_ids.size();
+  bundle_adjuster->get_world_points_into(h_xyz_, tracked_ids);           // :72, straight into the pinned arena
 
   // PnP :74-82 (rvec/tvec are CV_32F in/out; the solver works in double)
   double rv[3] = {rvec[0], rvec[1], rvec[2]}, tv[3] = {tvec[0], tvec[1], tvec[2]};
   int num_inliers = 0;
-  std::vector<int> inlier_indices(m > 0 ? m : 1);
+  const int* inlier_indices = h_inl_;
   if (m > 0) {
-    SVO_TRY(hipMemcpyAsync(d_xyz_, tracked_world_points.data(), sizeof(float) * 3 * m, hipMemcpyHostToDevice, st));
+    SVO_TRY(hipMemcpyAsync(d_xyz_, h_xyz_, sizeof(float) * 3 * m, hipMemcpyHostToDevice, st));
     SvoScratch scratch(ctx_);
     if (svo_k_pnp(ctx_, scratch, d_xyz_, feature_tracker->device_features(), m, K_[0], K_[2], K_[5], rv, tv, 100, 8.0f, 0.99,
-                  d_inl_, &num_inliers)) return;
-    if (num_inliers > 0) {
-      SVO_TRY(hipMemcpyAsync(inlier_indices.data(), d_inl_, sizeof(int) * num_inliers, hipMemcpyDeviceToHost, st));
-      SVO_TRY(hipStreamSynchronize(st));
-    }
+                  d_inl_, &num_inliers, h_inl_)) return;
   }
   for (int i = 0; i < 3; ++i) { rvec[i] = (float)rv[i]; tvec[i] = (float)tv[i]; }
   stats_.n_inliers = num_inliers;
@@ -442,8 +461,9 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   delete ptp;
   ptp = new PhaseTimer(3);
   // dedup :113-128 on the device; the surviving corners stay in HBM for the stereo stage
-  if (num_inliers > 0)
-    SVO_TRY(hipMemcpyAsync(d_trk_xy_, kf->tracked_features_2d.data(), sizeof(float) * 2 * num_inliers, hipMemcpyHostToDevice, st));
+  if (num_inliers > 0 &&  // the inlier features are already in HBM: gather them by the device inlier list
+      svo_k_gather_xy_ids(ctx_, d_inl_, num_inliers, feature_tracker->device_features(), feature_tracker->device_ids(), d_trk_xy_,
+                          d_trk_ids_)) return;
   if (svo_k_dedup(ctx_, d_det, nullptr, n_det, d_trk_xy_, nullptr, num_inliers, min_feature_distance, d_new_xy_, d_cnt_)) return;
 
   // hmat = [R^T | -R^T t]  :130-134 (float Mats; the product accumulates in double)

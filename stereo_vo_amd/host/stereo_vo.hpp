@@ -85,6 +85,7 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   bool pending() const { return worker_.joinable(); }
   bool new_keyframe_pending() const { return launch_needed_; }  // caller-thread flag (the worker never touches it)
   void get_world_points(std::vector<Point3f>& world_points, const std::vector<size_t>& ids);
+  void get_world_points_into(float* xyz, const std::vector<size_t>& ids);  // same, into a caller buffer (3 floats per id)
   int last_iterations() const { return last_iterations_; }
   const double* solved_pose() const { return solved_pose_; }
   svo_ba* handle() { return ba_; }
@@ -134,6 +135,9 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   int* d_n_ = nullptr; float* d_av_ = nullptr;
   uint8_t* d_last_pyr_ = nullptr;
   const uint8_t* last_pyr_ = nullptr;  // d_last_pyr_ or a borrowed pyramid
+  uint8_t* h_mirror_ = nullptr;        // pinned: ids | xy | n | av_parallax, written by the kernels in place
+  long long* h_ids_ = nullptr; float* h_xy_ = nullptr; int* h_n_ = nullptr; float* h_av_ = nullptr;
+  int pending_init_seq_ = 0;           // completion word value of an init launch that may still read the mirrors (0: none)
   int last_w_ = 0, last_h_ = 0;
   bool borrow_ = false;
   int cur_ = 0, n_ = 0, n_initial_ = 0;
@@ -172,6 +176,9 @@ class ImageProcessor {  // src/image_processor.hpp:31-46
   // scratch
   float *d_xyz_ = nullptr, *d_trk_xy_ = nullptr, *d_new_xy_ = nullptr, *d_disp_ = nullptr, *d_kxy_ = nullptr, *d_kxyz_ = nullptr;
   long long* d_trk_ids_ = nullptr; int *d_inl_ = nullptr, *d_cnt_ = nullptr;
+  // pinned host arena (read / written in place by the kernels)
+  uint8_t* h_arena_ = nullptr; float* h_xyz_ = nullptr; int* h_inl_ = nullptr; int* h_tri_cnt_ = nullptr;
+  float *h_tri_xy_ = nullptr, *h_tri_xyz_ = nullptr;
   Stats stats_;
 };
 
