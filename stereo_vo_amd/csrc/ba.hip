@@ -1188,6 +1188,7 @@ struct svo_ba {
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
   unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
+  bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
 };
 
@@ -1296,6 +1297,7 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   SVO_REQUIRE(ctx, K >= 1 && K <= ba->max_poses, "ba: pose count outside the window capacity");
   SVO_REQUIRE(ctx, npts >= 0 && (size_t)npts <= ba->cap_points && M >= 0 && (size_t)M <= ba->cap_obs, "ba: problem exceeds capacity");
   BaDev& d = ba->d;
+  if (ba->upload_pending) { SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream)); ba->upload_pending = false; }
   d.K = K; d.n = 6 * (K - 1); d.M = M; d.f = ba->cam.focal; d.cx = ba->cam.cx; d.cy = ba->cam.cy;
   ba->n_points = npts;
   // CSR over landmark index + wave chunks (<= 64 observations, whole landmarks)
@@ -1443,7 +1445,9 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(D, h, total, hipMemcpyHostToDevice, st));
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, h_pose_stage, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
   if (d.det && has_empty_landmark && npts) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));  // the staging buffers are reused by the next upload
+  // no wait here: the pinned staging images are next touched by the host after the solve that follows has
+  // drained this stream (ba_lm), and the payload area is written by kernels ordered after the pose copy
+  ba->upload_pending = true;
   return SVO_OK;
 }
 
@@ -1843,7 +1847,9 @@ extern "C" int svo_ba_solve_problem(svo_ba* ba, svo_ba_summary* summary) {
   if (!ba) return SVO_ERR_INVALID;
   svo_use_device(ba->ctx);
   SVO_REQUIRE(ba->ctx, ba->d.K >= 1, "ba_solve_problem: no problem loaded");
-  return ba_lm(ba, summary);
+  const int rc = ba_lm(ba, summary);
+  if (!rc) ba->upload_pending = false;  // every LM path ends with the stream drained
+  return rc;
 }
 
 extern "C" int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3) {
@@ -1851,8 +1857,13 @@ extern "C" int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3) 
   svo_ctx* ctx = ba->ctx;
   if (poses7) memcpy(poses7, ba->h_poses.data(), sizeof(double) * 7 * (size_t)ba->d.K);
   if (points3 && ba->n_points) {
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(points3, ba->d.points, sizeof(double) * 3 * (size_t)ba->n_points, hipMemcpyDeviceToHost, ba->stream));
+    // through the pinned arena (idle once the solve has finished): the runtime's pageable path would stage and wait
+    const size_t bytes = sizeof(double) * 3 * (size_t)ba->n_points;
+    void* stage = bytes <= ba->arena_cap ? (void*)ba->h_arena : (void*)points3;
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(stage, ba->d.points, bytes, hipMemcpyDeviceToHost, ba->stream));
     SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+    ba->upload_pending = false;
+    if (stage != (void*)points3) memcpy(points3, stage, bytes);
   }
   return SVO_OK;
 }
@@ -1952,6 +1963,7 @@ extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
   if (rc) return rc;
   ba->t_upload += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   rc = ba_lm(ba, summary);
+  if (!rc) ba->upload_pending = false;
   ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   ba->n_solves++;
   if (rc) return rc;
