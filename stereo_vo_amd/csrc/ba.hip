@@ -30,6 +30,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <sched.h>
 #include <chrono>
 #include <deque>
 #include <memory>
@@ -1659,7 +1660,8 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
     unsigned spins = 0;
     while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
       __builtin_ia32_pause();
-      if ((++spins & 0xFFFFu) == 0 && ms(t0, now()) > 10000.0) {  // never expected: fall back to the stream wait
+      if (++spins > 4096u && (spins & 63u) == 0) sched_yield();  // long wait: stay polite when threads outnumber cores
+      if ((spins & 0xFFFFu) == 0 && ms(t0, now()) > 10000.0) {  // never expected: fall back to the stream wait
         SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { ctx->err = "ba: completion word never arrived"; return SVO_ERR_HIP; }
       }

@@ -1,5 +1,6 @@
 // Context lifetime and workspace (svo.h: svo_create / svo_destroy / svo_stream / svo_sync).
 #include <chrono>
+#include <sched.h>
 
 #include "common.h"
 
@@ -103,7 +104,8 @@ int svo_wait_word(svo_ctx* c, const SvoPublish& p) {
   unsigned spins = 0;
   while (__atomic_load_n(p.word, __ATOMIC_ACQUIRE) != p.seq) {
     __builtin_ia32_pause();
-    if ((++spins & 0xFFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
+    if (++spins > 4096u && (spins & 63u) == 0) sched_yield();  // long wait: stay polite when threads outnumber cores
+    if ((spins & 0xFFFFu) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 10.0) {
       // never expected: fall back to the stream wait so that a lost word cannot hang the caller
       SVO_HIP_CHECK(c, hipStreamSynchronize(c->stream));
       if (__atomic_load_n(p.word, __ATOMIC_ACQUIRE) != p.seq) { c->err = "completion word never arrived"; return SVO_ERR_HIP; }
