@@ -139,6 +139,8 @@ def run_kitti(args):
     import stereo_vo_amd as S
     torch, dist, rank, local, world = dist_setup(args.gpus)
     B, NS = args.batch, max(1, args.streams)
+    if NS >= 4:  # include/svo.h: adjusters on one shader engine per XCD, trackers on the other three
+        os.environ.setdefault("SVO_BA_CU_SHARE", "8")
     streams = [_Stream(S, torch, local, 0x5EED0001 + rank * 64 + i, B) for i in range(NS)]
     torch.cuda.synchronize()
     ctx = streams[0].ctx

@@ -57,6 +57,12 @@ typedef struct svo_limits {
   int max_features;          /* tracked features per frame (ref: 400, src/bundle_adjuster.hpp:75) */
 } svo_limits;
 
+/* Environment knobs read at creation (deployment tuning, no effect on results):
+ *   SVO_BA_CU_SHARE=n   when several stereo streams share one GPU: window-sized bundle adjusters (svo_ba_create with
+ *                       max_observations <= 100000) launch on their own n compute units of every 32 and the
+ *                       context's stream on the remaining ones (HIP CU-masked streams).  n = 8 is one shader engine
+ *                       per XCD on MI355X; measured +12 % frames/s at 8 streams per GPU, -2 % with a single stream.
+ *                       Unset / 0: both use the whole GPU. */
 int svo_create(svo_ctx** out, int device, const svo_limits* limits);
 void svo_destroy(svo_ctx* ctx);
 const char* svo_last_error(const svo_ctx* ctx);

@@ -1226,7 +1226,20 @@ static int ba_alloc(svo_ba* ba) {
       SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
     }
   }
-  SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
+  {
+    // SVO_BA_CU_SHARE=n (n = 8 on MI355X: one shader engine of every XCD; see include/svo.h): window-sized adjusters
+    // run on their own n CUs of every 32 and the context's stream on the others, so that the LM loop's small dependent
+    // kernels never queue behind other stereo streams' wide LK launches.  Bulk-sized adjusters keep the whole GPU.
+    const char* e = getenv("SVO_BA_CU_SHARE");
+    const int nres = e ? atoi(e) : 0;
+    if (nres > 0 && nres < 32 && ba->max_obs <= 100000) {
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = (1u << nres) - 1u;
+      SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
+    } else {
+      SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
+    }
+  }
   ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 1400 + 16 * (size_t)Kmax) + 2 * sizeof(BaDev);  // payloads | flags | LmDev image | poses
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
   return SVO_OK;

@@ -72,7 +72,15 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
   };
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
-  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+  {
+    const char* ev = getenv("SVO_BA_CU_SHARE");  // see ba.hip / include/svo.h: the complement of the adjusters' CUs
+    const int nres = ev ? atoi(ev) : 0;
+    if (nres > 0 && nres < 32) {
+      uint32_t mask[8];
+      for (int i = 0; i < 8; ++i) mask[i] = ~((1u << nres) - 1u);
+      if ((e = hipExtStreamCreateWithCUMask(&c->stream, 8, mask)) != hipSuccess) return fail("stream (CU mask)", e);
+    } else if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return fail("stream", e);
+  }
   const size_t px = (size_t)c->lim.max_width * c->lim.max_height;
   const size_t B = (size_t)c->lim.max_batch;
   // generic scratch: enough for two images + pyramids + dense outputs of the host-pointer wrappers
