@@ -50,7 +50,7 @@ __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1)
 
 // Exact wave-wide integer sum without LDS traffic.  Bounds (8-bit images): |I|,|J| <= 255*32 = 8160 after the
 // 2^-9 descale, Scharr |g| <= 16*255 = 4080, so one product is < 2^25 (8160*4080 = 33,292,800; 4080^2 < 2^24),
-// a thread's partial over its <= 2 pixels is < 2^26 and the sum over a 16-lane DPP row is < 2^30: the row
+// a thread's partial over its PPT <= 4 pixels is < 2^27 and the sum over a 16-lane DPP row is < 2^31: the row
 // reduction is exact in int32.  The four row totals are then added in 64 bits on the scalar unit.  Integer
 // addition is associative, so the result does not depend on the order (this is what lets the oracle use a
 // plain sequential int64 sum).
@@ -63,7 +63,13 @@ __device__ __forceinline__ long long wave_sum_i64(int v) {
          (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
 }
 
-constexpr int LKT = 256;         // threads (4 wavefronts) per feature
+#ifndef SVO_LK_THREADS
+#define SVO_LK_THREADS 256
+#endif
+constexpr int LKT = SVO_LK_THREADS;  // threads per feature (4 wavefronts by default; 128 also keeps the int32 row sums exact)
+constexpr int NW = LKT / 64;
+constexpr int PPT = (21 * 21 + LKT - 1) / LKT;  // window pixels per thread
+static_assert(LKT % 64 == 0 && PPT * 16 * 33292800ll < 2147483647ll, "row sums must stay exact in int32");
 constexpr int RM = 5;            // margin of the staged target region around the 22x22 window
 constexpr int RS = G + 2 * RM;   // 32
 
@@ -72,7 +78,7 @@ struct LkShared {
   uint8_t jreg[RS * RS];     // target-image region; restaged only when the window leaves it
   short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
   short gx[G * G], gy[G * G];
-  long long red[2][3][4];    // cross-wave partials (double-buffered: one barrier per reduction point)
+  long long red[2][3][NW];   // cross-wave partials (double-buffered: one barrier per reduction point)
 };
 
 // Exact 64-bit sums of NV per-thread int32 partials over the 4 wavefronts of the workgroup.
@@ -86,7 +92,12 @@ __device__ __forceinline__ void block_sum_split(const int* v, long long* out, Lk
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < NV; ++k) out[k] = S.red[phase][k][0] + S.red[phase][k][1] + S.red[phase][k][2] + S.red[phase][k][3];
+  for (int k = 0; k < NV; ++k) {
+    long long t = S.red[phase][k][0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += S.red[phase][k][w];
+    out[k] = t;
+  }
   phase ^= 1;
 }
 
@@ -141,7 +152,7 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       S.gx[i] = (short)vx; S.gy[i] = (short)vy;
     }
     __syncthreads();
-    int pA[3] = {0, 0, 0};  // <= 2 pixels per thread, each product < 2^24.1: fits int32
+    int pA[3] = {0, 0, 0};  // PPT pixels per thread, each product < 2^24.1: fits int32
     for (int i = lane; i < WIN * WIN; i += LKT) {
       const int r = i / WIN, c = i % WIN;
       const int o = r * G + c, o1 = o + G;
@@ -171,10 +182,10 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
     float outx = nx, outy = ny;
     nx -= (float)HALF; ny -= (float)HALF;
     float pdx = 0.f, pdy = 0.f;
-    // window-pixel offsets of this thread inside the staged region (<= 2 pixels per thread)
-    int woff[2], wi[2];
+    // window-pixel offsets of this thread inside the staged region (PPT pixels per thread)
+    int woff[PPT], wi[PPT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < PPT; ++u) {
       const int i = lane + LKT * u;
       wi[u] = i < WIN * WIN ? i : -1;
       woff[u] = i < WIN * WIN ? (i / WIN) * RS + (i % WIN) : 0;
@@ -207,7 +218,7 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       const int ob = (iny - ry0) * RS + (inx - rx0);
       int pb[2] = {0, 0};
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
+      for (int u = 0; u < PPT; ++u) {
         if (wi[u] >= 0) {
           const int o = ob + woff[u];
           const int diff = descale(S.jreg[o] * iw00 + S.jreg[o + 1] * iw01 + S.jreg[o + RS] * iw10 + S.jreg[o + RS + 1] * iw11, 9) - S.Iw[wi[u]];
