@@ -42,6 +42,7 @@
 bool svo_host_cholesky_solve(double* A, double* b, int n);  // host/linalg.cpp
 
 namespace {
+constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, MAX_RADIUS = 1e16, MIN_RADIUS = 1e-32, MIN_REL_DECREASE = 1e-3;
 
 // LM state of the device-resident loop (deterministic, single-rank solves): the host never sees an
@@ -104,6 +105,8 @@ struct BaDev {
   int* flag2 = nullptr;
   unsigned* arrive = nullptr;   // device counter of finished reduce1 workgroups (monotone; target = total so far)
   unsigned arrive_target = 0;
+  unsigned* arrive2 = nullptr;  // fused back-substitution + reduce2: counter of finished backsub workgroups
+  unsigned arrive2_target = 0;  // 0: separate ba_reduce2_kernel launch
   int seq = 0;
 };
 
@@ -782,7 +785,51 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
       }
     }
   }
-  if (P.det) return;
+  if (P.det) {
+    if (!P.arrive2_target) return;  // ba_reduce2_kernel follows as its own launch
+    // ---- fused reduce2: the workgroup that finishes last forms the declared-order sums over lmV and publishes.
+    // Writers: stores, agent-scope fence, arrive.  Reader: sees the final count, fences (acquire), reads lmV —
+    // same code and order as ba_reduce2_body, so the result is bit-identical to the two-launch form.
+    __shared__ int sLast;
+    __shared__ double sP2[RSEG][4];
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0)
+      sLast = __hip_atomic_fetch_add(P.arrive2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == P.arrive2_target;
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    const int F = P.K - 1, tid = threadIdx.x;
+    const int dl = F * F + F;  // the landmark list
+    const int e0 = P.list_start[dl], len = P.list_start[F * F + F + 1 + 1 + dl] - e0;
+    const int seglen = (len + RSEG - 1) / RSEG;
+    for (int item = tid; item < RSEG * 4; item += (int)blockDim.x) {
+      const int seg = item / 4, e = item % 4;
+      double acc = 0.0;
+      const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+      const double* src = P.lmV + 4 * (size_t)e0 + e;
+      for (int q0 = b0; q0 < b1; q0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[4 * (size_t)(q0 + u)] : 0.0;  // plain loads: the fence above is the acquire
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (q0 + u < b1) acc += v[u];
+      }
+      sP2[seg][e] = acc;
+    }
+    __syncthreads();
+    if (tid < 4) {
+      double acc = 0.0;
+      for (int sg = 0; sg < RSEG; ++sg) acc += sP2[sg][tid];
+      P.pay2_out[tid] = acc;
+    }
+    if (P.flag2 && tid < 64) {  // lanes 0-3 of wave 0 stored the payload; fence, then lane 0 publishes
+      __threadfence_system();
+      if (tid == 0) __hip_atomic_store(P.flag2, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     a_cost += __shfl_xor(a_cost, off); a_mc += __shfl_xor(a_mc, off);
@@ -796,7 +843,6 @@ __device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
 // R(list): 28 consecutive segments summed sequentially, then the segment sums added sequentially
 // (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: F*F pose-pair blocks
 // (36 values), F pose vectors (18 values), 1 scalar pair; lane = (segment, element).
-constexpr int RSEG = 28;
 __device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
   if (P.lm && ldv(&P.lm->done)) return;
   if ((int)blockIdx.x >= (P.K - 1) * (P.K - 1) + (P.K - 1) + 1) return;
@@ -1188,7 +1234,7 @@ struct svo_ba {
   std::vector<int64_t> solve_lm_ids;
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, arrive2_total = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
 };
@@ -1205,8 +1251,8 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(d.pay1, double, ba->cap_pay1); A(d.pay2, double, 4);
   A(ba->d_lm, LmDev, 1); A(ba->d_params, BaDev, 1);
-  A(ba->d_arrive, unsigned, 1);
-  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, sizeof(unsigned)));
+  A(ba->d_arrive, unsigned, 2);
+  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 2 * sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
   A(d.lmV, double, 4 * ba->cap_points);
 #undef A
@@ -1469,6 +1515,7 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
 static int ba_lm_device(svo_ba* ba, svo_ba_summary* sum) {
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
+  d.arrive2_target = 0; d.step_in = nullptr; d.flag1 = d.flag2 = nullptr;  // host-loop-only features
   hipStream_t st = ba->stream;
   const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1567,6 +1614,7 @@ static int ba_lm_device(svo_ba* ba, svo_ba_summary* sum) {
 static int ba_lm_persistent(svo_ba* ba, svo_ba_summary* sum) {
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
+  d.arrive2_target = 0; d.step_in = nullptr; d.flag1 = d.flag2 = nullptr;  // host-loop-only features
   hipStream_t st = ba->stream;
   const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -1664,6 +1712,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   // Single-rank deterministic solves poll completion words that the reduce kernels publish in pinned memory
   // (after a system-scope fence) instead of a stream wait per half-iteration; SVO_BA_NO_POLL=1 restores the waits.
   const bool poll = d.det && !ba->allreduce && !getenv("SVO_BA_NO_POLL");
+  const bool fuse2 = d.det && d.C > 0 && !getenv("SVO_BA_NO_FUSE");  // back-substitution + reduce2 in one launch (last workgroup reduces)
   int* h_flag1 = reinterpret_cast<int*>(h_pay2 + 6);
   int* h_flag2 = reinterpret_cast<int*>(h_pay2 + 7);
   d.flag1 = poll ? h_flag1 : nullptr; d.flag2 = poll ? h_flag2 : nullptr; d.arrive = ba->d_arrive;
@@ -1781,11 +1830,16 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
         d.points = cur_points; d.cand_points = cand_points;
         if (d.C > 0) {
           SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB, st);
-          if (d.det) hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.C), dim3(64), 0, st, d, radius);
+          if (d.det) {
+            d.arrive2 = ba->d_arrive + 1;
+            d.arrive2_target = 0;
+            if (fuse2) { if (poll) d.seq = ++ba->seq; ba->arrive2_total += (unsigned)d.C; d.arrive2_target = ba->arrive2_total; }
+            hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.C), dim3(64), 0, st, d, radius);
+          }
           else hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
         }
-        if (poll) d.seq = ++ba->seq;
-        if (d.det) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(128), 0, st, d);
+        if (poll && !fuse2) d.seq = ++ba->seq;
+        if (d.det && !fuse2) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(128), 0, st, d);
         SVO_HIP_CHECK(ctx, hipGetLastError());
         if (poll) { rc = wait_flag(h_flag2, d.seq); if (rc) return rc; }
         if (ba->allreduce) {
