@@ -21,7 +21,13 @@
 // bit-identical between CPU and GPU and independent of grid size.  (Needed because the reference's
 // problem has a scale gauge: with one fixed pose and only reprojection factors the iterates slide along
 // a flat direction and amplify any summation-order difference; measured 3e-2 pose drift otherwise.)
-// Problems whose pair slots would not fit (config 4) keep the atomic path and a tolerance-level result.
+// Problems whose pair slots would not fit (config 4), or that ask for it (svo_ba_options.accumulation), sum in
+// hardware order with a tolerance-level result: ba_linearize_mfma_kernel applies each landmark's Schur
+// contribution as a rank-3 update of S on the f64 matrix cores (<= 22 poses), the LDS-atomic kernel is the fallback.
+// Host <-> device hand-over of the host-driven loop (single rank, deterministic mode): the reduce kernels write the
+// payloads into pinned host memory and publish a completion word that the host polls; the step [dc | candidate
+// poses] is read by ba_backsub_kernel in place from pinned memory; back-substitution and reduce2 are one launch
+// (the last workgroup reduces).  Per LM iteration: 3 launches, no copy, no stream wait.
 // The n x n (n = 6 (K-1) <= 114) Cholesky, step control and termination run on the host from the
 // (all-reduced) payloads, so every rank of a sharded run takes identical decisions.
 // A rank of a sharded run holds all poses and its own landmarks; `allreduce` sums payload1/2 in place
