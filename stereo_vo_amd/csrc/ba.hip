@@ -26,8 +26,8 @@
 // contribution as a rank-3 update of S on the f64 matrix cores (<= 22 poses), the LDS-atomic kernel is the fallback.
 // Host <-> device hand-over of the host-driven loop (single rank, deterministic mode): the reduce kernels write the
 // payloads into pinned host memory and publish a completion word that the host polls; the step [dc | candidate
-// poses] is read by ba_backsub_kernel in place from pinned memory; back-substitution and reduce2 are one launch
-// (the last workgroup reduces).  Per LM iteration: 3 launches, no copy, no stream wait.
+// poses] is read by ba_backsub_kernel in place from pinned memory.  Per LM iteration: 4 launches, no copy, no stream
+// wait (SVO_BA_FUSE=1 folds reduce2 into the back-substitution launch: last workgroup reduces; measured, not default).
 // The n x n (n = 6 (K-1) <= 114) Cholesky, step control and termination run on the host from the
 // (all-reduced) payloads, so every rank of a sharded run takes identical decisions.
 // A rank of a sharded run holds all poses and its own landmarks; `allreduce` sums payload1/2 in place
@@ -865,13 +865,13 @@ __device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
     double acc = 0.0;
     const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
     const double* src = base + (size_t)e0 * stride + e;
-    // 8 independent loads in flight, adds strictly in list order
-    for (int q0 = b0; q0 < b1; q0 += 8) {
-      double v[8];
+    // 16 independent loads in flight, adds strictly in list order
+    for (int q0 = b0; q0 < b1; q0 += 16) {
+      double v[16];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[(size_t)(q0 + u) * stride] : 0.0;
+      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? src[(size_t)(q0 + u) * stride] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 8; ++u)
+      for (int u = 0; u < 16; ++u)
         if (q0 + u < b1) acc += v[u];
     }
     sP[seg][e] = acc;
@@ -1718,7 +1718,10 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   // Single-rank deterministic solves poll completion words that the reduce kernels publish in pinned memory
   // (after a system-scope fence) instead of a stream wait per half-iteration; SVO_BA_NO_POLL=1 restores the waits.
   const bool poll = d.det && !ba->allreduce && !getenv("SVO_BA_NO_POLL");
-  const bool fuse2 = d.det && d.C > 0 && !getenv("SVO_BA_NO_FUSE");  // back-substitution + reduce2 in one launch (last workgroup reduces)
+  // SVO_BA_FUSE=1: back-substitution + reduce2 in one launch (the last workgroup reduces).  Measured on the bench
+  // workload: +1.5 % frames/s at 8 streams, -4 % for a single stream (27 vs 22 us per half-iteration: the agent-scope
+  // fences and the 64-thread tail cost more than the saved launch), so the two-launch form stays the default.
+  const bool fuse2 = d.det && d.C > 0 && getenv("SVO_BA_FUSE") != nullptr;
   int* h_flag1 = reinterpret_cast<int*>(h_pay2 + 6);
   int* h_flag2 = reinterpret_cast<int*>(h_pay2 + 7);
   d.flag1 = poll ? h_flag1 : nullptr; d.flag2 = poll ? h_flag2 : nullptr; d.arrive = ba->d_arrive;
