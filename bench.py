@@ -120,7 +120,7 @@ class _Stream:
         pp.width, pp.height = W, H
         pp.max_corners, pp.quality, pp.min_feature_distance = MAXC, QUALITY, MIN_DIST
         pp.max_features, pp.window_size = MAX_FEAT, WINDOW
-        pp.ba_max_iterations, pp.ba_max_time_s = 50, 0.0
+        pp.ba_max_iterations, pp.ba_max_time_s = int(os.environ.get("SVO_BENCH_BA_ITERS", "50")), 0.0  # env: sensitivity experiments only
         self.pipe = S.Pipeline(self.ctx, pp)
         self.B = B
         self.res = None
