@@ -10,7 +10,8 @@
 //                          23x23 (left) and 23x70 (right) patches are staged in LDS, prefiltered in LDS,
 //                          and the 48 SADs are accumulated by 4 waves (lane = disparity, wave = row
 //                          group) with LDS integer atomics.  No intermediate image touches HBM.
-//   stereo_prefilter_kernel + stereo_dense_kernel : the drop-in for StereoBM::compute (full CV_16S map).
+//   stereo_prefilter_kernel + stereo_dense_kernel : the drop-in for StereoBM::compute (full CV_16S map),
+//                          separable running-window SADs kept in LDS (see the kernel).
 #include "common.h"
 
 namespace {
@@ -136,21 +137,29 @@ __global__ __launch_bounds__(256) void stereo_prefilter_kernel(const uint8_t* __
   out[(size_t)y * W + x] = (uint8_t)prefilter_at(I, x, y, W, H);
 }
 
-// Dense map.  Workgroup = 64 columns x 4 rows of output; lane = column, each lane keeps the running
-// 21-column window of absolute differences for one disparity at a time.  Prefiltered tiles in LDS.
+// Dense map.  Workgroup = 64 columns x 8 rows of output, prefiltered tiles in LDS.  The SAD over the block x block
+// window is separable: per disparity slot, column threads form the vertical sums of |L - R| for the 8 output rows by a
+// running window (add the entering row, subtract the leaving one), then the horizontal sums over `block` columns are
+// formed for 4 adjacent outputs at a time (21 + 6 LDS reads instead of 4 x 21).  Three slots are processed per pass
+// (3 x 84 column threads of the 256); slot `ndisp` is the texture sum |L - cap| (same window, same machinery).  All
+// SADs of the tile (<= 441 * 62 < 2^16) are kept in LDS as uint16 [slot][pixel]; the winner / uniqueness / sub-pixel
+// selection then reads them per pixel.  Integer arithmetic throughout: bit-identical to the direct double loop.
 namespace {
-constexpr int DT_W = 64, DT_H = 4;
+constexpr int DT_W = 64, DT_H = 8, DT_PIX = DT_W * DT_H;
+constexpr int DT_TH = DT_H + MAX_BLOCK - 1;         // 28 tile rows
+constexpr int DT_TWL = DT_W + MAX_BLOCK - 1;        // 84 left tile columns
+constexpr int DT_TWR = DT_TWL + MAX_NDISP;          // right tile columns
+constexpr int DT_SLOTS = 3;                         // disparity slots per pass
 }
 __global__ __launch_bounds__(256) void stereo_dense_kernel(const uint8_t* __restrict__ Lp, const uint8_t* __restrict__ Rp,
                                                            int W, int H, int ndisp, int block,
                                                            int16_t* __restrict__ out) {
-  constexpr int TH = DT_H + MAX_BLOCK - 1;
-  constexpr int TWL = DT_W + MAX_BLOCK - 1;
-  constexpr int TWR = TWL + MAX_NDISP;
-  __shared__ uint8_t sL[TH][TWL + 1], sR[TH][TWR + 1];
+  __shared__ uint8_t sL[DT_TH][DT_TWL + 4], sR[DT_TH][DT_TWR + 4];
+  __shared__ unsigned short sV[DT_SLOTS][DT_H][DT_TWL + 4];
+  extern __shared__ unsigned short sSad[];  // [ndisp + 1][DT_PIX]
   const int half = block / 2;
   const int x0 = blockIdx.x * DT_W, y0 = blockIdx.y * DT_H;
-  const int tid = threadIdx.x, lane = tid & 63, row = tid >> 6;
+  const int tid = threadIdx.x;
   const int th = DT_H + block - 1, twl = DT_W + block - 1, twr = twl + ndisp - 1;
   for (int i = tid; i < th * twl; i += 256) {
     const int r = i / twl, c = i % twl;
@@ -163,23 +172,69 @@ __global__ __launch_bounds__(256) void stereo_dense_kernel(const uint8_t* __rest
     sR[r][c] = (gx >= 0 && gx < W && gy >= 0 && gy < H) ? Rp[(size_t)gy * W + gx] : 0;
   }
   __syncthreads();
-  const int x = x0 + lane, y = y0 + row;
-  if (x >= W || y >= H) return;
-  int16_t res = -16;
-  if (x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half) {
-    int sad[MAX_NDISP + 2];
-    int tsum = 0;
-    for (int r = 0; r < block; ++r)
-      for (int c = 0; c < block; ++c) tsum += abs((int)sL[row + r][lane + c] - CAP);
-    for (int i = 0; i < ndisp; ++i) {
-      int acc = 0;
-      for (int r = 0; r < block; ++r)
-        for (int c = 0; c < block; ++c) acc += abs((int)sL[row + r][lane + c] - (int)sR[row + r][lane + c + i]);
-      sad[i + 1] = acc;
+  const int nslots = ndisp + 1;
+  const int vs = tid / DT_TWL, vc = tid % DT_TWL;   // vertical pass: slot-in-pass, tile column (tid < 252 active)
+  for (int s0 = 0; s0 < nslots; s0 += DT_SLOTS) {
+    // ---- vertical running sums
+    if (vs < DT_SLOTS && vc < twl && s0 + vs < nslots) {
+      const int slot = s0 + vs;
+      const bool tex = slot == ndisp;
+      auto AD = [&](int r) -> int {
+        const int l = sL[r][vc];
+        return tex ? abs(l - CAP) : abs(l - (int)sR[r][vc + slot]);
+      };
+      int sum = 0;
+      for (int r = 0; r < block; ++r) sum += AD(r);
+      sV[vs][0][vc] = (unsigned short)sum;
+      for (int r = 1; r < DT_H; ++r) {
+        sum += AD(r + block - 1) - AD(r - 1);
+        sV[vs][r][vc] = (unsigned short)sum;
+      }
     }
-    res = (int16_t)bm_select(sad + 1, ndisp, tsum);
+    __syncthreads();
+    // ---- horizontal sums: work item = (slot-in-pass, row, group of 4 adjacent outputs)
+    for (int item = tid; item < DT_SLOTS * DT_H * (DT_W / 4); item += 256) {
+      const int hs = item / (DT_H * (DT_W / 4)), rem = item % (DT_H * (DT_W / 4));
+      const int r = rem / (DT_W / 4), xg = (rem % (DT_W / 4)) * 4;
+      if (s0 + hs >= nslots) continue;
+      const unsigned short* v = &sV[hs][r][xg];
+      int h0 = 0;
+      for (int c = 0; c < block; ++c) h0 += v[c];
+      const int h1 = h0 - v[0] + v[block], h2 = h1 - v[1] + v[block + 1], h3 = h2 - v[2] + v[block + 2];
+      unsigned short* o = &sSad[(size_t)(s0 + hs) * DT_PIX + r * DT_W + xg];
+      o[0] = (unsigned short)h0; o[1] = (unsigned short)h1; o[2] = (unsigned short)h2; o[3] = (unsigned short)h3;
+    }
+    __syncthreads();
   }
-  out[(size_t)y * W + x] = res;
+  // ---- selection (StereoBM winner, uniqueness, texture, sub-pixel): two pixels per thread
+  for (int pix = tid; pix < DT_PIX; pix += 256) {
+    const int x = x0 + (pix % DT_W), y = y0 + pix / DT_W;
+    if (x >= W || y >= H) continue;
+    int res = -16;
+    if (x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half) {
+      auto S = [&](int i) -> int { return sSad[(size_t)i * DT_PIX + pix]; };
+      const int tsum = S(ndisp);
+      if (tsum >= TEXTURE_THRESHOLD) {
+        int minsad = 0x7fffffff, mind = -1;
+        for (int i = 0; i < ndisp; ++i) {
+          const int v = S(i);
+          if (v < minsad) { minsad = v; mind = i; }
+        }
+        const int thresh = minsad + (minsad * UNIQUENESS_RATIO / 100);
+        bool unique = true;
+        for (int i = 0; i < ndisp && unique; ++i)
+          if ((i < mind - 1 || i > mind + 1) && S(i) <= thresh) unique = false;
+        if (unique) {
+          // borders as bm_select: s[-1] = s[1], s[ndisp] = s[ndisp - 2]
+          const int p = mind + 1 < ndisp ? S(mind + 1) : S(ndisp - 2);
+          const int n = mind - 1 >= 0 ? S(mind - 1) : S(1);
+          const int dd = p + n - 2 * minsad + abs(p - n);
+          res = (short)(((ndisp - mind - 1) * 256 + (dd != 0 ? (p - n) * 256 / dd : 0) + 15) >> 4);
+        }
+      }
+    }
+    out[(size_t)y * W + x] = (int16_t)res;
+  }
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -252,7 +307,9 @@ extern "C" int svo_stereo_bm(svo_ctx* ctx, const uint8_t* left, const uint8_t* r
   const dim3 g1(svo_div_up(width, 64), svo_div_up(height, 4));
   hipLaunchKernelGGL(stereo_prefilter_kernel, g1, dim3(256), 0, st, dL, width, height, width, dLp);
   hipLaunchKernelGGL(stereo_prefilter_kernel, g1, dim3(256), 0, st, dR, width, height, width, dRp);
-  hipLaunchKernelGGL(stereo_dense_kernel, dim3(svo_div_up(width, DT_W), svo_div_up(height, DT_H)), dim3(256), 0, st, dLp,
+  const size_t sad_lds = sizeof(unsigned short) * (size_t)(num_disparities + 1) * DT_PIX;  // <= 66,560 B
+  SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)stereo_dense_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sad_lds));
+  hipLaunchKernelGGL(stereo_dense_kernel, dim3(svo_div_up(width, DT_W), svo_div_up(height, DT_H)), dim3(256), sad_lds, st, dLp,
                      dRp, width, height, num_disparities, block_size, dD);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(disp16, dD, sizeof(int16_t) * px, hipMemcpyDeviceToHost, st));
