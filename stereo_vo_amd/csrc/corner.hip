@@ -3,9 +3,9 @@
 // operation order is the one declared in oracle/ora_corner.cpp and repeated here bit for bit).
 //
 // Three launches per batch of frames (grid.z / blockIdx.x = frame):
-//   corner_response_kernel : u8 tile (+2 halo) staged in LDS -> Sobel -> products -> 3x3 box (double)
-//                            -> min eigenvalue map (f32) + per-image max (order-preserving uint atomicMax).
-//                            HBM: reads A bytes, writes 4A.
+//   corner_response_kernel : streaming, wavefront = 62-column strip, lane = column: Sobel -> products -> 3x3 box
+//                            (double, DPP neighbour moves + 3-row register window) -> min eigenvalue map (f32) +
+//                            per-image max (order-preserving uint atomicMax).  HBM: reads ~1.1 A bytes, writes 4A.
 //   corner_nms_kernel      : threshold at quality*max, 3x3 non-max suppression, wave-aggregated
 //                            append of (value key << 32 | raster index) candidates.  Reads 4A.
 //   corner_select_kernel   : one 1024-thread workgroup per image.  The reference's greedy
@@ -20,7 +20,6 @@
 #include "common.h"
 
 namespace {
-constexpr int TX = 64, TY = 16;          // output tile of the response kernel
 constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAX_ACCEPT = 16384;    // accepted corners held in LDS for the final sort (aliases the key cache)
 constexpr int SEL_CAP_K = 12288;         // candidates whose keys/state are cached in LDS during the rounds
@@ -41,78 +40,133 @@ template <typename T>
 __device__ __forceinline__ void st_l2(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }  // namespace
 
+// Streaming form: one wavefront owns a strip of 62 output columns x RS_ROWS rows and walks it top to bottom.
+// lane = image column (one halo column on each side), pixel rows are read once (1 byte per lane, one 64-byte
+// request per row and wave, RS_PF rows ahead), neighbours come from wave-shift DPP moves, the 3x3 box sum is a
+// horizontal 3-sum (DPP) followed by a 3-row sliding window in registers: no LDS, every pixel read ~1.1 times,
+// every response written once.  The box sum adds nine float products whose exponents span < 2^29, so the double
+// sum is exact in any order (oracle/ora_corner.cpp adds them row by row): reordering keeps the result bit-identical.
+// Image borders: Sobel reads BORDER_REFLECT_101 pixels; the box filter reflects COVARIANCE coordinates (a position
+// outside the image takes the covariance computed at its reflection), i.e. cov(-1) := cov(1), cov(n) := cov(n-2).
+namespace {
+constexpr int RS_COLS = 62;   // output columns per wavefront (64 lanes minus one halo column per side)
+constexpr int RS_ROWS = 24;   // output rows per wavefront
+constexpr int RS_PF = 3;      // pixel rows in flight (= the unroll factor: the three-row windows rotate by renaming)
+
+__device__ __forceinline__ int wave_from_lower(int v) { return __builtin_amdgcn_mov_dpp(v, 0x138, 0xf, 0xf, false); }   // lane i <- lane i-1 (wave_shr:1)
+__device__ __forceinline__ int wave_from_upper(int v) { return __builtin_amdgcn_mov_dpp(v, 0x130, 0xf, 0xf, false); }   // lane i <- lane i+1 (wave_shl:1)
+__device__ __forceinline__ float wave_from_lower(float v) { return __int_as_float(wave_from_lower(__float_as_int(v))); }
+__device__ __forceinline__ float wave_from_upper(float v) { return __int_as_float(wave_from_upper(__float_as_int(v))); }
+}  // namespace
+
 __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t* __restrict__ imgs, int W, int H,
                                                               int row_stride, size_t image_stride,
                                                               float* __restrict__ eig,
                                                               unsigned* __restrict__ maxkey) {
-  __shared__ uint8_t sI[(TY + 4)][(TX + 4)];
-  __shared__ float sXX[(TY + 2)][(TX + 2)], sXY[(TY + 2)][(TX + 2)], sYY[(TY + 2)][(TX + 2)];
-  __shared__ unsigned sMax;
   const int b = blockIdx.z;
   const uint8_t* img = imgs + (size_t)b * image_stride;
-  const int x0 = blockIdx.x * TX, y0 = blockIdx.y * TY;
-  const int tid = threadIdx.x;
-  if (tid == 0) sMax = 0u;
-  // stage the u8 tile, image coordinates reflected (BORDER_REFLECT_101)
-  for (int i = tid; i < (TY + 4) * (TX + 4); i += 256) {
-    const int ty = i / (TX + 4), tx = i % (TX + 4);
-    const int gx = reflect101(x0 + tx - 2, W), gy = reflect101(y0 + ty - 2, H);
-    sI[ty][tx] = img[(size_t)gy * row_stride + gx];
-  }
-  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const int ncs = (W + RS_COLS - 1) / RS_COLS, nrs = (H + RS_ROWS - 1) / RS_ROWS;
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: strip bounds stay scalar
+  if (wid >= ncs * nrs) return;  // whole wavefront
+  const int cs = wid % ncs, rs = wid / ncs;
+  const int x = cs * RS_COLS - 1 + lane;             // image column of this lane (may be -1 or >= W)
+  const int y0 = rs * RS_ROWS, y1 = min(y0 + RS_ROWS, H);
+  const int xr = reflect101(x, W);
+  // lanes 0 / 63 have no lower / upper neighbour lane: they fetch that pixel themselves
+  const int xe = reflect101(lane == 0 ? x - 1 : x + 1, W);
+  const bool edge = lane == 0 || lane == 63;
+  const bool fix_lo = x == -1, fix_hi = x == W;      // covariance taken from the reflected column (lane + 2 / lane - 2)
+  const bool border_wave = cs == 0 || (cs + 1) * RS_COLS - 1 + 1 >= W;  // wave-uniform: some lane is outside [0, W)
   const double scale = 1.0 / (4.0 * 3.0 * 255.0);
   const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
-  // covariance terms on the (TX+2)x(TY+2) extended tile; the box filter reflects COVARIANCE
-  // coordinates, so an out-of-image position takes the value computed at its reflection.
-  for (int i = tid; i < (TY + 2) * (TX + 2); i += 256) {
-    const int ey = i / (TX + 2), ex = i % (TX + 2);
-    const int gx = x0 + ex - 1, gy = y0 + ey - 1;
-    float xx = 0.f, xy = 0.f, yy = 0.f;
-    if (gx >= -1 && gx <= W && gy >= -1 && gy <= H) {
-      const int cx = reflect101(gx, W) - x0 + 2, cy = reflect101(gy, H) - y0 + 2;  // tile coords of the centre
-      float rdx[3], rdy[3];
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int l = sI[cy + j - 1][cx - 1], m = sI[cy + j - 1][cx], r = sI[cy + j - 1][cx + 1];
-        rdx[j] = (float)(r - l);
-        rdy[j] = (float)m * k0 + (float)(l + r) * k1;
-      }
-      const float dx = (rdx[0] + rdx[2]) * k1 + rdx[1] * k0;
-      const float dy = rdy[2] - rdy[0];
-      xx = dx * dx; xy = dx * dy; yy = dy * dy;
-    }
-    sXX[ey][ex] = xx; sXY[ey][ex] = xy; sYY[ey][ex] = yy;
-  }
-  __syncthreads();
+  float* E = eig + (size_t)b * W * H;
+  const bool out_lane = lane >= 1 && lane <= RS_COLS && x < W;
+
+  // covariance rows needed: j in [j0, j1]; pixel rows j0-1 .. j1+1 (reflected)
+  const int j0 = y0 > 0 ? y0 - 1 : 0, j1 = y1 < H ? y1 : H - 1;
+  auto load_row = [&](int py, int& c, int& e) {
+    const uint8_t* row = img + (size_t)reflect101(py, H) * row_stride;
+    c = row[xr];
+    e = edge ? (int)row[xe] : 0;
+  };
+  // per pixel row: rdx = r - l, rdy = m k0 + (l + r) k1 (the row terms of the separable Sobel pair)
+  auto row_terms = [&](int c, int e, float& rdx, float& rdy) {
+    int l = wave_from_lower(c), r = wave_from_upper(c);
+    if (lane == 0) l = e;
+    if (lane == 63) r = e;
+    rdx = (float)(r - l);
+    rdy = (float)c * k0 + (float)(l + r) * k1;
+  };
+  const int p_first = j0 - 1;            // first pixel row
+  const int p_last = j1 + 1;             // last pixel row
   unsigned lmax = 0u;
-  for (int i = tid; i < TY * TX; i += 256) {
-    const int oy = i / TX, ox = i % TX;
-    const int gx = x0 + ox, gy = y0 + oy;
-    if (gx >= W || gy >= H) continue;
-    double s[3][3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      s[0][j] = ((double)sXX[oy + j][ox] + (double)sXX[oy + j][ox + 1]) + (double)sXX[oy + j][ox + 2];
-      s[1][j] = ((double)sXY[oy + j][ox] + (double)sXY[oy + j][ox + 1]) + (double)sXY[oy + j][ox + 2];
-      s[2][j] = ((double)sYY[oy + j][ox] + (double)sYY[oy + j][ox + 1]) + (double)sYY[oy + j][ox + 2];
-    }
-    const float a = (float)((s[0][0] + s[0][1]) + s[0][2]) * 0.5f;
-    const float bq = (float)((s[1][0] + s[1][1]) + s[1][2]);
-    const float c = (float)((s[2][0] + s[2][1]) + s[2][2]) * 0.5f;
+  auto emit = [&](int y, const double* top, const double* mid, const double* bot) {
+    const float a = (float)((top[0] + mid[0]) + bot[0]) * 0.5f;
+    const float bq = (float)((top[1] + mid[1]) + bot[1]);
+    const float c = (float)((top[2] + mid[2]) + bot[2]) * 0.5f;
     const float d = a - c;
     const float e = (a + c) - sqrtf(d * d + bq * bq);
-    eig[(size_t)b * W * H + (size_t)gy * W + gx] = e;
-    const unsigned k = f32_key(e);
-    lmax = k > lmax ? k : lmax;
+    if (out_lane) {
+      E[(size_t)y * W + x] = e;
+      const unsigned k = f32_key(e);
+      lmax = k > lmax ? k : lmax;
+    }
+  };
+  // One step consumes pixel row p (already in c/e), refills that queue slot with row p + 3, completes covariance row
+  // j = p - 1 and output row j - 1.  The three-row windows (row terms A,B,C; horizontal sums HA,HB,HC) rotate by
+  // renaming: the loop is unrolled by three and each copy is called with permuted arguments, so nothing is moved.
+  auto step = [&](int p, int& c, int& e, float& dxA, float& dyA, float& dxB, float& dyB, float& dxC, float& dyC, double* HA,
+                  double* HB, double* HC) {
+    const int cc = c, ee = e;
+    if (p + RS_PF <= p_last) load_row(p + RS_PF, c, e);
+    row_terms(cc, ee, dxC, dyC);
+    const int j = p - 1;
+    if (j < j0) return;
+    const float dx = (dxA + dxC) * k1 + dxB * k0;
+    const float dy = dyC - dyA;
+    float xx = dx * dx, xy = dx * dy, yy = dy * dy;
+    if (border_wave) {                    // covariance coordinates reflect: column -1 := column 1, column W := column W-2
+      const int src = fix_lo ? lane + 2 : lane - 2;
+      const float x2 = __shfl(xx, src), y2 = __shfl(xy, src), z2 = __shfl(yy, src);
+      if (fix_lo || fix_hi) { xx = x2; xy = y2; yy = z2; }
+    }
+    HC[0] = ((double)wave_from_lower(xx) + (double)xx) + (double)wave_from_upper(xx);
+    HC[1] = ((double)wave_from_lower(xy) + (double)xy) + (double)wave_from_upper(xy);
+    HC[2] = ((double)wave_from_lower(yy) + (double)yy) + (double)wave_from_upper(yy);
+    const int y = j - 1;                  // output row whose window (j-2, j-1, j) is now complete
+    if (y < y0) return;
+    if (y == 0) emit(0, HC, HB, HC);      // covariance row -1 := row 1 (first strip only)
+    else emit(y, HA, HB, HC);
+  };
+  int c0, e0, c1, e1, c2, e2;
+  load_row(p_first, c0, e0); load_row(p_first + 1, c1, e1); load_row(p_first + 2, c2, e2);
+  float dx0 = 0.f, dy0 = 0.f, dx1 = 0.f, dy1 = 0.f, dx2 = 0.f, dy2 = 0.f;
+  double h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0}, h2[3] = {0, 0, 0};
+  int p = p_first;
+  for (; p + 2 <= p_last; p += 3) {
+    step(p, c0, e0, dx1, dy1, dx2, dy2, dx0, dy0, h1, h2, h0);
+    step(p + 1, c1, e1, dx2, dy2, dx0, dy0, dx1, dy1, h2, h0, h1);
+    step(p + 2, c2, e2, dx0, dy0, dx1, dy1, dx2, dy2, h0, h1, h2);
   }
-  // wave max then one LDS atomic per wave, one global atomic per block
+  // 0..2 leftover rows; then the last strip emits row H-1 with covariance row H := row H-2 (hp = sums of the row
+  // before the last covariance row, hl = the last one; copied by value in wave-uniform branches: no scratch)
+  double hp[3] = {h1[0], h1[1], h1[2]}, hl[3] = {h2[0], h2[1], h2[2]};
+  if (p <= p_last) {
+    step(p, c0, e0, dx1, dy1, dx2, dy2, dx0, dy0, h1, h2, h0);
+    for (int q = 0; q < 3; ++q) { hp[q] = h2[q]; hl[q] = h0[q]; }
+    ++p;
+    if (p <= p_last) {
+      step(p, c1, e1, dx2, dy2, dx0, dy0, dx1, dy1, h2, h0, h1);
+      for (int q = 0; q < 3; ++q) { hp[q] = h0[q]; hl[q] = h1[q]; }
+    }
+  }
+  if (j1 == H - 1 && y1 == H && H - 1 >= y0) emit(H - 1, hp, hl, hp);
   for (int off = 32; off > 0; off >>= 1) {
     const unsigned o = __shfl_xor(lmax, off);
     lmax = o > lmax ? o : lmax;
   }
-  if ((tid & 63) == 0) atomicMax(&sMax, lmax);
-  __syncthreads();
-  if (tid == 0) atomicMax(&maxkey[b], sMax);
+  if (lane == 0 && lmax) atomicMax(&maxkey[b], lmax);
 }
 
 __global__ __launch_bounds__(256) void corner_nms_kernel(const float* __restrict__ eig, int W, int H,
@@ -354,7 +408,7 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * NC_STRIDE * batch, st));
   {
     SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
-    hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(W, TX), svo_div_up(H, TY), batch), dim3(256), 0, st,
+    hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(svo_div_up(W, RS_COLS) * svo_div_up(H, RS_ROWS), 4), 1, batch), dim3(256), 0, st,
                        imgs, W, H, row_stride, image_stride, ctx->d_eig, ctx->d_maxkey);
   }
   {
@@ -448,7 +502,7 @@ extern "C" int svo_corner_response(svo_ctx* ctx, const uint8_t* img, int width, 
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_img, width, img, row_stride, width, height, hipMemcpyHostToDevice, st));
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned), st));
-  hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(width, TX), svo_div_up(height, TY), 1), dim3(256), 0,
+  hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(svo_div_up(width, RS_COLS) * svo_div_up(height, RS_ROWS), 4), 1, 1), dim3(256), 0,
                      st, d_img, width, height, width, (size_t)width * height, ctx->d_eig, ctx->d_maxkey);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(eig, ctx->d_eig, sizeof(float) * (size_t)width * height, hipMemcpyDeviceToHost, st));
