@@ -95,3 +95,25 @@ def test_hip_pipeline_degenerate_frames(ctx):
     r = g.process_batch(L[1:2], R[1:2])[0]
     assert r.n_tracked > 0
     g.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SVO_BA_CU_SHARE": "8"}, {"SVO_BA_FUSE": "1"}, {"SVO_BA_NO_POLL": "1"},
+                                 {"SVO_BA_DEVICE_LM": "1"}])
+def test_hip_pipeline_optional_paths_keep_parity(env):
+    """Deployment knobs must not change results: CU-partitioned streams, the fused back-substitution/reduce2 launch, the
+    stream-wait (non-polling) host loop and the device-resident LM graph all have to reproduce the oracle's index sets
+    and poses exactly.  The knobs are read from the environment at creation, hence one child process each."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_full.py"), "8"], env=e, capture_output=True,
+                         text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if "pose diff" in l]
+    assert len(lines) == 8
+    for l in lines:
+        assert "ids_same" in l and l.rstrip().endswith("pose diff 0.00e+00"), l
