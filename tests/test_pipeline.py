@@ -110,7 +110,7 @@ def test_hip_pipeline_optional_paths_keep_parity(env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     e = dict(os.environ)
     e.update(env)
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "compare_full.py"), "8"], env=e, capture_output=True,
+    out = subprocess.run([sys.executable, os.path.join(root, "tests", "compare_full.py"), "8"], env=e, capture_output=True,
                          text=True, timeout=240)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if "pose diff" in l]
