@@ -24,7 +24,7 @@ constexpr int SEL_THREADS = 1024;
 constexpr int SEL_MAX_ACCEPT = 16384;    // accepted corners held in LDS for the final sort (aliases the key cache)
 constexpr int SEL_CAP_K = 12288;         // candidates whose keys/state are cached in LDS during the rounds
 constexpr int SEL_CAP_C = 8192;          // cell-table entries cached in LDS
-constexpr int SEL_LDS_BYTES = SEL_CAP_K * 8 + SEL_CAP_C * 4 + SEL_CAP_K;  // 143,360 B of the CU's 160 KiB (>= SEL_MAX_ACCEPT * 8)
+constexpr int SEL_LDS_BYTES = SEL_CAP_K * 8 + SEL_CAP_C * 2 + SEL_CAP_K + SEL_CAP_K * 2;  // keys | cell table (u16) | state | blocker (u16): 151,552 B of the CU's 160 KiB (>= SEL_MAX_ACCEPT * 8)
 constexpr int NC_STRIDE = 32;            // per-image candidate counters live on separate 128-B lines
 
 __device__ __forceinline__ unsigned f32_key(float v) {
@@ -307,12 +307,13 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   // The rounds below re-read keys, states and the cell table many times; from L2 every read is a ~0.7 us
   // round trip (measured 950 us for this kernel), so when they fit they are cached in LDS first.
   unsigned long long* keysL = reinterpret_cast<unsigned long long*>(lds_raw);
-  int* cellL = reinterpret_cast<int*>(lds_raw + (size_t)SEL_CAP_K * 8);
-  uint8_t* stateL = lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 4;
+  unsigned short* cellL = reinterpret_cast<unsigned short*>(lds_raw + (size_t)SEL_CAP_K * 8);  // positions <= n <= 12288
+  uint8_t* stateL = lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 2;
+  unsigned short* blkL = reinterpret_cast<unsigned short*>(lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 2 + SEL_CAP_K);
   const bool use_lds = n <= SEL_CAP_K && ncell + 1 <= SEL_CAP_C;
   if (use_lds) {
-    for (int i = tid; i < n; i += SEL_THREADS) { keysL[i] = ld_l2(&S[i]); stateL[i] = 0; }
-    for (int i = tid; i <= ncell; i += SEL_THREADS) cellL[i] = ld_l2(&cs[i]);
+    for (int i = tid; i < n; i += SEL_THREADS) { keysL[i] = ld_l2(&S[i]); stateL[i] = 0; blkL[i] = 0xFFFFu; }
+    for (int i = tid; i <= ncell; i += SEL_THREADS) cellL[i] = (unsigned short)ld_l2(&cs[i]);
     __syncthreads();
   }
   auto KEY = [&](int i) -> unsigned long long { return use_lds ? keysL[i] : ld_l2(&S[i]); };
@@ -320,13 +321,65 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   auto SET_STATE = [&](int i, uint8_t v) { if (use_lds) ((volatile uint8_t*)stateL)[i] = v; else st_l2(&st[i], v); };
   auto CELL = [&](int i) -> int { return use_lds ? cellL[i] : ld_l2(&cs[i]); };
   // (d) monotone fixed-point rounds.  state: 0 undecided, 1 accepted, 2 rejected.
+  // The dependency chains of the bench images are ~100 links deep (8,144 candidates, 1,897 accepted) and a wavefront
+  // pays for its slowest lane, so what matters is the cost of re-examining a pending candidate.  Each pending candidate
+  // keeps a resume point (u16 in LDS: neighbour row << 14 | index of its first still-undecided stronger neighbour, the
+  // "blocker").  Neighbours scanned before the blocker are final (weaker, too far, or stronger-and-rejected), so a
+  // re-examination reads the blocker's state — accepted: reject at once; undecided: nothing to do — and otherwise
+  // resumes the scan behind it: every neighbour is visited once per candidate in total.  A register bit mask of the
+  // thread's pending candidates skips the decided ones without touching LDS.  Same fixed point as the plain rounds.
   const float md2 = min_distance * min_distance;
+  unsigned pend = 0u;   // bit k <-> candidate tid + k * SEL_THREADS (n <= 12288 when the LDS tables are in use: k < 12)
+  if (use_lds)
+    for (int k = 0; tid + k * SEL_THREADS < n; ++k) pend |= 1u << k;
   for (int round = 0; round < 4096; ++round) {
     if (tid == 0) sFlag = 0;
     __syncthreads();
     // Decisions are monotone and LDS is coherent inside the workgroup, so a thread may re-examine its undecided
     // candidates several times between two barriers: dependency chains resolve without paying a barrier per link.
     int pending = 1;
+    if (use_lds) {
+      for (int rep = 0; rep < 256 && pend; ++rep) {
+        unsigned m = pend;
+        while (m) {
+          const int k = __builtin_ctz(m);
+          m &= m - 1u;
+          const int i = tid + k * SEL_THREADS;
+          const unsigned enc = ((volatile unsigned short*)blkL)[i];
+          int r0 = 0, pstart = -1;
+          if (enc != 0xFFFFu) {
+            const int pb = (int)(enc & 0x3FFFu);
+            const uint8_t sb = ((volatile uint8_t*)stateL)[pb];
+            if (sb == 0) continue;                                                   // blocker still undecided
+            if (sb == 1) { ((volatile uint8_t*)stateL)[i] = 2; pend &= ~(1u << k); continue; }   // blocker accepted
+            r0 = (int)(enc >> 14); pstart = pb + 1;                                  // blocker rejected: resume behind it
+          }
+          const unsigned long long kk = keysL[i];
+          const unsigned idx = (unsigned)(kk & 0xffffffffu);
+          const int x = (int)(idx % W), y = (int)(idx / W);
+          const int cx = x / cell, cy = y / cell;
+          const int x1 = cx > 0 ? cx - 1 : 0, x2 = cx < gw - 1 ? cx + 1 : gw - 1;
+          const int y1 = cy > 0 ? cy - 1 : 0, y2 = cy < gh - 1 ? cy + 1 : gh - 1;
+          int decided = 1;  // 1 accepted unless the scan finds otherwise
+          for (int r = r0; y1 + r <= y2 && decided == 1; ++r) {
+            const int yy = y1 + r;
+            const int p0 = cellL[yy * gw + x1], p1 = cellL[yy * gw + x2 + 1];  // cells x1..x2 of a row are contiguous
+            for (int p = (r == r0 && pstart >= 0) ? pstart : p0; p < p1; ++p) {
+              const unsigned long long km = keysL[p];
+              if (km <= kk) continue;  // only stronger candidates matter (keys are unique)
+              const unsigned im = (unsigned)(km & 0xffffffffu);
+              const float dx = (float)(x - (int)(im % W)), dy = (float)(y - (int)(im / W));
+              if (!(dx * dx + dy * dy < md2)) continue;
+              const uint8_t sm = ((volatile uint8_t*)stateL)[p];
+              if (sm == 1) { decided = 2; break; }
+              if (sm == 0) { blkL[i] = (unsigned short)((r << 14) | p); decided = 0; break; }
+            }
+          }
+          if (decided) { ((volatile uint8_t*)stateL)[i] = (uint8_t)decided; pend &= ~(1u << k); }
+        }
+      }
+      pending = pend != 0u;
+    } else {
     for (int rep = 0; rep < 16 && pending; ++rep) {
     pending = 0;
     for (int i = tid; i < n; i += SEL_THREADS) {
@@ -354,6 +407,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
       if (rejected) SET_STATE(i, (uint8_t)2);
       else if (!blocked) SET_STATE(i, (uint8_t)1);
       else pending = 1;
+    }
     }
     }
     if (pending) sFlag = 1;
