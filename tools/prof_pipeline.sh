@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_pipe
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- python3 bench.py > $OUT/bench_stats.log 2>&1 || exit 1
-tail -1 $OUT/bench_stats.log > $OUT/bench_under_rocprof.json
+grep '^{"metric"' $OUT/bench_stats.log | tail -1 > $OUT/bench_under_rocprof.json
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/$C -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --streams 1 > $OUT/bench_$C.log 2>&1 || exit 1
 done
