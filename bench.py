@@ -101,9 +101,27 @@ def cpu_baseline(p, L, R, frames):
     n = min(frames, L.shape[0])
     t0 = time.perf_counter()
     res = [pipe.process(L[i], R[i]) for i in range(n)]
-    dt = time.perf_counter() - t0
+    reps = 1
+    while time.perf_counter() - t0 < 8.0 and reps < 12:  # bounded sample of ~10 s: the same frames again, fresh pipeline
+        again = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=MAXC,
+                           quality=QUALITY, min_feature_distance=MIN_DIST, parallax_thresh=20.0, window_size=WINDOW,
+                           max_features=MAX_FEAT, ba_max_iterations=50, num_threads=cores)
+        for i in range(n):
+            again.process(L[i], R[i])
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    # the reference runs Ceres with 4 threads (src/bundle_adjuster.cpp:12): the same sample once more at 4 threads
+    os.environ["OMP_NUM_THREADS"] = "4"
+    pipe4 = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=MAXC,
+                       quality=QUALITY, min_feature_distance=MIN_DIST, parallax_thresh=20.0, window_size=WINDOW,
+                       max_features=MAX_FEAT, ba_max_iterations=50, num_threads=4)
+    t1 = time.perf_counter()
+    for i in range(n):
+        pipe4.process(L[i], R[i])
+    dt4 = time.perf_counter() - t1
     return dict(value=n / dt, unit="frames/s", cores=cores, kind="port",
-                sample=f"first {n} frames of the same batch, whole oracle pipeline, {dt:.1f} s"), res
+                sample=f"first {n} frames of the same batch, whole oracle pipeline, {reps} passes of {dt:.1f} s",
+                value_4_threads=n / dt4), res
 
 
 class _Stream:
@@ -214,7 +232,19 @@ def run_kitti(args):
         same = all((a.n_detected, a.n_tracked, a.n_inliers, a.n_new, a.is_keyframe, a.ba_iterations) ==
                    (b.n_detected, b.n_tracked, b.n_inliers, b.n_new, b.is_keyframe, b.ba_iterations) and
                    list(a.pose7) == list(b.pose7) for a, b in zip(res[:m], ores[:m]))
-        out["parity_vs_cpu"] = {"frames": m, "index_sets_and_poses_identical": bool(same)}
+        # ATE of the GPU trajectory against the CPU path's trajectory on identical inputs (BASELINE metric; m)
+        def centres(rs):
+            c = []
+            for r in rs:
+                q, t = np.array(r.pose7[:4]), np.array(r.pose7[4:])
+                w, x, y, z = q
+                Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                               [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                               [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+                c.append(-Rm.T @ t)  # camera in world (src/vo_node.cpp:149-150)
+            return np.array(c)
+        ate = float(S.api.ate_rmse(centres(res[:m]), centres(ores[:m]), False)) if m >= 3 else 0.0
+        out["parity_vs_cpu"] = {"frames": m, "index_sets_and_poses_identical": bool(same), "ate_rmse_m": ate}
     for st in streams:
         st.close()
     if dist is not None:
