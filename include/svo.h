@@ -286,6 +286,16 @@ int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, const uint8
 /* Feature-set taps for parity tests: ids + positions the tracker holds after the last frame. */
 int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n);
 
+/* FeatureTracker::draw_track + get_drawing (src/feature_tracker.cpp:74-91; used by src/vo_node.cpp:137,188):
+ * the keyframe image as RGB (3 bytes per pixel, width*height*3 output) with one green arrow of thickness 4 per feature
+ * from its keyframe position to its current position.  Host-side visualisation with this repository's own rasteriser
+ * (same picture as cv::arrowedLine, not pixel-identical). */
+int svo_draw_track(const uint8_t* gray, int width, int height, int row_stride, const float* from_xy,
+                   const float* to_xy, int n, uint8_t* rgb);
+/* The same for a pipeline's tracker: `keyframe_gray` is the host copy of the image the tracker was (re)initialised
+ * on (the reference keeps a clone, :14); arrows come from the tracker's initial / current feature positions. */
+int svo_pipeline_draw_track(svo_pipeline* p, const uint8_t* keyframe_gray, int row_stride, uint8_t* rgb);
+
 /* ------------------------------------------------------------- synthetic data --
  * Deterministic KITTI-shaped stereo stream: integer PRNG, ray-cast
  * textured billboards; host buffers; bit-identical on every host. Not part of the

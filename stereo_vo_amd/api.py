@@ -76,7 +76,7 @@ SYMBOLS = [
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
-    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve",
+    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve", "svo_draw_track", "svo_pipeline_draw_track",
 ]
 
 
@@ -441,6 +441,13 @@ class Pipeline:
                       "svo_pipeline_process_batch_dev")
         return list(res)
 
+    def draw_track(self, keyframe_gray):
+        """RGB drawing of the tracker state over the (host) keyframe image: FeatureTracker::draw_track + get_drawing."""
+        g = np.ascontiguousarray(keyframe_gray, np.uint8)
+        out = np.empty(g.shape + (3,), np.uint8)
+        self.ctx._chk(self.L.svo_pipeline_draw_track(self.h, _p(g), g.shape[1], _p(out)), "svo_pipeline_draw_track")
+        return out
+
     def tracked(self, capacity=8192):
         ids = np.empty(capacity, np.int64)
         xy = np.empty((capacity, 2), np.float32)
@@ -497,3 +504,15 @@ def cholesky_solve(A, b):
     if rc != 0:
         raise SvoError(f"svo_cholesky_solve rc={rc}")
     return b
+
+
+def draw_track(gray, from_xy, to_xy):
+    """svo_draw_track: gray (H, W) uint8 -> RGB (H, W, 3) with a green arrow per (from, to) pair."""
+    g = np.ascontiguousarray(gray, np.uint8)
+    a = np.ascontiguousarray(from_xy, np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(to_xy, np.float32).reshape(-1, 2)
+    out = np.empty(g.shape + (3,), np.uint8)
+    rc = lib().svo_draw_track(_p(g), g.shape[1], g.shape[0], g.shape[1], _p(a), _p(b), a.shape[0], _p(out))
+    if rc:
+        raise SvoError(f"svo_draw_track rc={rc}")
+    return out

@@ -247,6 +247,16 @@ void FeatureTracker::get_tracked_features(std::vector<Point2f>& features, std::v
   for (int i = 0; i < n_; ++i) ids[i] = (size_t)h_ids_[i];
 }
 
+// draw_track's inputs (src/feature_tracker.cpp:78-82): keyframe position and current position of every feature
+void FeatureTracker::get_track_arrows(std::vector<Point2f>& initial, std::vector<Point2f>& current) {
+  initial.resize(n_);
+  current.resize(n_);
+  if (!n_) return;
+  memcpy(current.data(), h_xy_, sizeof(float) * 2 * n_);
+  // visualisation path, not the hot path: a plain copy of the device-resident keyframe positions
+  SVO_TRY(hipMemcpy(initial.data(), d_init_[cur_], sizeof(float) * 2 * n_, hipMemcpyDeviceToHost));
+}
+
 // ------------------------------------------------------------------------------------------ ImageProcessor
 namespace {
 // cv::Rodrigues on a CV_32F rvec: evaluated in double, stored as float.
@@ -623,6 +633,15 @@ extern "C" int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, 
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(p->d_imgs, left, bytes, hipMemcpyHostToDevice, ctx->stream));
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(p->d_imgs + bytes, right, bytes, hipMemcpyHostToDevice, ctx->stream));
   return svo_pipeline_process_batch_dev(p, p->d_imgs, p->d_imgs + bytes, batch, results);
+}
+
+extern "C" int svo_pipeline_draw_track(svo_pipeline* p, const uint8_t* keyframe_gray, int row_stride, uint8_t* rgb) {
+  if (!p || !keyframe_gray || !rgb) return SVO_ERR_INVALID;
+  (void)hipSetDevice(p->ctx->device);
+  std::vector<svo::Point2f> cur, init;
+  p->tracker->get_track_arrows(init, cur);
+  return svo_draw_track(keyframe_gray, p->prm.width, p->prm.height, row_stride, (const float*)init.data(),
+                        (const float*)cur.data(), (int)cur.size(), rgb);
 }
 
 extern "C" int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n) {

@@ -105,7 +105,7 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   std::thread worker_;
 };
 
-class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing are visualisation: out of scope)
+class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing: get_track_arrows + svo_draw_track)
  public:
   FeatureTracker(svo_ctx* ctx, int max_features, int max_width, int max_height);
   ~FeatureTracker();
@@ -114,6 +114,9 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   void init(const uint8_t* pyramid, int width, int height, const std::vector<Point2f>& features, const std::vector<size_t>& ids);
   void track_features(float& av_parallax, float& percent_lost, const uint8_t* pyramid, int width, int height, bool flow_back);
   void get_tracked_features(std::vector<Point2f>& features, std::vector<size_t>& ids);
+  // inputs of draw_track (src/feature_tracker.cpp:74-83): per feature its keyframe position and its current position;
+  // svo_draw_track rasterises them over the keyframe image (draw_track / get_drawing of the reference)
+  void get_track_arrows(std::vector<Point2f>& initial, std::vector<Point2f>& current);
   // device views of the current feature set (for the in-library pipeline)
   const float* device_features() const { return d_xy_[cur_]; }
   const long long* device_ids() const { return d_ids_[cur_]; }

@@ -98,3 +98,54 @@ def test_kitti_driver_matches_oracle_and_ground_truth(ctx, tmp_path):
     gt = np.array([S.synth_pose(p, i)[:, 3] for i in range(n)])
     assert 0 <= st.ate_rmse < 0.25, st.ate_rmse                       # ~7 m of travel, 496x160 images
     assert S.ate_rmse(traj[:, :, 3], gt) > st.ate_rmse                # all-frames ATE includes the keyframe lag
+
+
+def test_draw_track_host_rasteriser():
+    """f4 — FeatureTracker::draw_track / get_drawing (src/feature_tracker.cpp:74-91): gray -> RGB, a green arrow of
+    thickness 4 per feature from its keyframe position to its current one.  Own rasteriser (visualisation only):
+    checked structurally, not against OpenCV pixels."""
+    import stereo_vo_amd as S
+    g = (np.arange(80 * 120).reshape(80, 120) % 251).astype(np.uint8)
+    a = np.array([[20.0, 20.0], [100.0, 60.0], [5.0, 70.0]], np.float32)
+    b = np.array([[60.0, 20.0], [100.0, 30.0], [5.0, 70.0]], np.float32)   # horizontal, vertical, zero-length
+    img = S.api.draw_track(g, a, b)
+    assert img.shape == (80, 120, 3) and img.dtype == np.uint8
+    green = (img[..., 0] == 0) & (img[..., 1] == 255) & (img[..., 2] == 0)
+    # untouched pixels are the gray value replicated (cvtColor GRAY2RGB)
+    assert np.array_equal(img[~green], np.repeat(g[~green][:, None], 3, 1))
+    # the shafts: every pixel on the centre lines is green, the band is ~4 px wide
+    assert green[20, 20:61].all() and green[30:61, 100].all()
+    assert 3 <= green[:, 40].sum() <= 5 and 3 <= green[45, :].sum() <= 5
+    # arrow head of the horizontal arrow: two strokes of 0.1 x 40 = 4 px behind the tip, above and below the shaft
+    assert green[17, 57] or green[17, 58] or green[16, 57]
+    assert green[23, 57] or green[23, 58] or green[24, 57]
+    assert green[70, 5]                                    # zero-length arrow still marks its point
+    # end points far outside the image are clipped, not walked for ever
+    far = S.api.draw_track(g, np.array([[10.0, 10.0]], np.float32), np.array([[1e7, -1e7]], np.float32))
+    assert far.shape == (80, 120, 3)
+    # nothing to draw: plain gray -> RGB
+    assert np.array_equal(S.api.draw_track(g, np.zeros((0, 2)), np.zeros((0, 2))), np.repeat(g[..., None], 3, 2))
+
+
+@pytest.mark.gpu
+def test_pipeline_draw_track(ctx, frames):
+    """svo_pipeline_draw_track: arrows from the tracker's keyframe positions to its current positions."""
+    import stereo_vo_amd as S
+    p, fr = frames
+    L, R = np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = L.shape[2], L.shape[1]
+    pp.ba_max_time_s = 0.0
+    pipe = S.Pipeline(ctx, pp)
+    res = pipe.process_batch(L[:3], R[:3])
+    assert res[0].is_keyframe
+    ids, xy = pipe.tracked()
+    img = pipe.draw_track(L[0])
+    assert img.shape == L[0].shape + (3,)
+    green = (img[..., 0] == 0) & (img[..., 1] == 255) & (img[..., 2] == 0)
+    assert green.sum() >= len(ids)  # every tracked feature leaves at least its brush stamp
+    inside = [(int(round(x)), int(round(y))) for x, y in xy if 2 <= x < L.shape[2] - 2 and 2 <= y < L.shape[1] - 2]
+    if not res[1].is_keyframe and not res[2].is_keyframe:
+        assert all(green[y, x] for x, y in inside)  # arrow tips sit on the current feature positions
+    pipe.close()
