@@ -117,3 +117,59 @@ def test_hip_pipeline_optional_paths_keep_parity(env):
     assert len(lines) == 8
     for l in lines:
         assert "ids_same" in l and l.rstrip().endswith("pose diff 0.00e+00"), l
+
+
+def _run_pair(g, o, L, R, batch):
+    n_kf = 0
+    for b0 in range(0, L.shape[0], batch):
+        rg = g.process_batch(L[b0:b0 + batch], R[b0:b0 + batch])
+        for k, r in enumerate(rg):
+            ro = o.process(L[b0 + k], R[b0 + k])
+            key = lambda x: (x.n_detected, x.n_tracked, x.n_inliers, x.n_new, x.is_keyframe, x.ba_iterations)
+            assert key(r) == key(ro), (b0 + k, key(r), key(ro))
+            assert list(r.pose7) == list(ro.pose7), (b0 + k, list(r.pose7), list(ro.pose7))
+            n_kf += r.is_keyframe
+        ig, xg = g.tracked()
+        io, xo = o.tracked()
+        assert np.array_equal(ig, io) and np.array_equal(xg.view(np.uint32), xo.view(np.uint32))
+    return n_kf
+
+
+@pytest.mark.gpu
+def test_hip_pipeline_config3_ten_keyframe_window(ctx):
+    """BASELINE configs[2] shape: 10-keyframe sliding window (11 poses, n = 60), long enough for the window to slide."""
+    import stereo_vo_amd as S
+    p, L, R = _seq(30)
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = p.width, p.height
+    pp.max_corners, pp.min_feature_distance, pp.max_features, pp.window_size = 600, 10.0, 600, 10
+    pp.ba_max_time_s = 0.0
+    g = S.Pipeline(ctx, pp)
+    o = _ora_pipe(p, min_feature_distance=10.0, max_corners=600, max_features=600, window_size=10)
+    assert _run_pair(g, o, L, R, 4) >= 12  # more keyframes than the window holds
+    g.close()
+
+
+@pytest.mark.gpu
+def test_hip_pipeline_config5_hd_many_features():
+    """BASELINE configs[4] shape: 1280x720, ~10k features per frame (d435i intrinsics).  Exercises the
+    candidate counts beyond the LDS tables of corner_select, >8k-feature LK launches and a ~10k-landmark window solve."""
+    import stereo_vo_amd as S
+    c = S.Context(1280, 720, max_batch=2, max_corners=10240, max_candidates=1 << 17, max_features=10240)
+    p = S.synth_default(1280, 720)
+    p.focal, p.cx, p.cy, p.baseline = 385.7545, 640.0, 360.0, 0.05
+    fr = [S.synth_render(p, i) for i in range(4)]
+    L, R = np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = 1280, 720
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 10000, 0.01, 6.0, 10000, 10
+    pp.ba_max_time_s = 0.0
+    g = S.Pipeline(c, pp)
+    o = _ora_pipe(p, min_feature_distance=6.0, max_corners=10000, quality=0.01, max_features=10000, window_size=10)
+    _run_pair(g, o, L, R, 2)
+    ids, _ = g.tracked()
+    assert len(ids) > 3000
+    g.close()
+    c.close()
