@@ -34,8 +34,12 @@ def allreduce_device_fn(dist, device):
     """svo_allreduce_fn for the HIP library: RCCL all-reduce (sum) of `n` doubles at device pointer `ptr`."""
     import torch
 
+    views = {}  # (ptr, n) -> zero-copy tensor view of the library's payload buffer (built once: two calls per LM iteration)
+
     def fn(ptr, n):
-        t = torch.as_tensor(_DevBuf(ptr, n), device=device)
+        t = views.get((ptr, n))
+        if t is None:
+            t = views[(ptr, n)] = torch.as_tensor(_DevBuf(ptr, n), device=device)
         dist.all_reduce(t)
         torch.cuda.synchronize(device)
         return 0
