@@ -157,13 +157,15 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       const int r = i / WIN, c = i % WIN;
       const int o = r * G + c, o1 = o + G;
       const int rr = (r + 1) * RP + (c + 1);
-      const int ival = descale(S.raw[rr] * iw00 + S.raw[rr + 1] * iw01 + S.raw[rr + RP] * iw10 + S.raw[rr + RP + 1] * iw11, 9);
-      const int ixv = descale(S.gx[o] * iw00 + S.gx[o + 1] * iw01 + S.gx[o1] * iw10 + S.gx[o1 + 1] * iw11, 14);
-      const int iyv = descale(S.gy[o] * iw00 + S.gy[o + 1] * iw01 + S.gy[o1] * iw10 + S.gy[o1 + 1] * iw11, 14);
+      // every factor fits 24 signed bits (pixels <= 255, weights <= 2^14, |gradients| <= 4080): v_mul_i32_i24 is a
+      // full-rate instruction, the generic 32-bit multiply is quarter rate
+      const int ival = descale(__mul24(S.raw[rr], iw00) + __mul24(S.raw[rr + 1], iw01) + __mul24(S.raw[rr + RP], iw10) + __mul24(S.raw[rr + RP + 1], iw11), 9);
+      const int ixv = descale(__mul24(S.gx[o], iw00) + __mul24(S.gx[o + 1], iw01) + __mul24(S.gx[o1], iw10) + __mul24(S.gx[o1 + 1], iw11), 14);
+      const int iyv = descale(__mul24(S.gy[o], iw00) + __mul24(S.gy[o + 1], iw01) + __mul24(S.gy[o1], iw10) + __mul24(S.gy[o1 + 1], iw11), 14);
       S.Iw[i] = (short)ival; S.dIx[i] = (short)ixv; S.dIy[i] = (short)iyv;
-      pA[0] += ixv * ixv;
-      pA[1] += ixv * iyv;
-      pA[2] += iyv * iyv;
+      pA[0] += __mul24(ixv, ixv);
+      pA[1] += __mul24(ixv, iyv);
+      pA[2] += __mul24(iyv, iyv);
     }
     long long sA[3];
     block_sum_split<3>(pA, sA, S, phase);  // the barrier inside also publishes Iw/dIx/dIy
@@ -221,9 +223,9 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       for (int u = 0; u < PPT; ++u) {
         if (wi[u] >= 0) {
           const int o = ob + woff[u];
-          const int diff = descale(S.jreg[o] * iw00 + S.jreg[o + 1] * iw01 + S.jreg[o + RS] * iw10 + S.jreg[o + RS + 1] * iw11, 9) - S.Iw[wi[u]];
-          pb[0] += diff * S.dIx[wi[u]];
-          pb[1] += diff * S.dIy[wi[u]];
+          const int diff = descale(__mul24(S.jreg[o], iw00) + __mul24(S.jreg[o + 1], iw01) + __mul24(S.jreg[o + RS], iw10) + __mul24(S.jreg[o + RS + 1], iw11), 9) - S.Iw[wi[u]];
+          pb[0] += __mul24(diff, S.dIx[wi[u]]);   // |diff| <= 8160, |gradient| <= 4080
+          pb[1] += __mul24(diff, S.dIy[wi[u]]);
         }
       }
       long long sb[2];
