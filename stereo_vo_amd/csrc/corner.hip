@@ -34,6 +34,11 @@ __device__ __forceinline__ unsigned f32_key(float v) {
 __device__ __forceinline__ float key_f32(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+// Candidate key = (response key << 32) | (y << 16 | x).  The low word orders candidates exactly like the raster index
+// y * W + x (x < W <= 65535), which is the tie-break of the total order, and decodes without integer divisions.
+__device__ __forceinline__ unsigned pack_xy(int x, int y) { return ((unsigned)y << 16) | (unsigned)x; }
+__device__ __forceinline__ int key_x(unsigned lo) { return (int)(lo & 0xFFFFu); }
+__device__ __forceinline__ int key_y(unsigned lo) { return (int)(lo >> 16); }
 template <typename T>
 __device__ __forceinline__ T ld_l2(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T>
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256) void corner_nms_kernel(const float* __restrict
   if (is_cand) {
     const int pos = sBase + local;
     if (pos < cap)
-      cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(v) << 32) | (unsigned)(y * W + x);
+      cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(v) << 32) | pack_xy(x, y);
     else
       atomicOr(status, 1);
   }
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
     const int m = n < max_corners ? n : max_corners;
     for (int i = tid; i < m; i += SEL_THREADS) {
       const unsigned idx = (unsigned)(sKeys[i] & 0xffffffffu);
-      oxy[2 * i] = (float)(idx % W); oxy[2 * i + 1] = (float)(idx / W);
+      oxy[2 * i] = (float)key_x(idx); oxy[2 * i + 1] = (float)key_y(idx);
     }
     if (tid == 0) out_n[b] = m;
     return;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   __syncthreads();
   for (int i = tid; i < n; i += SEL_THREADS) {
     const unsigned idx = (unsigned)(C[i] & 0xffffffffu);
-    const int cx = (int)(idx % W) / cell, cy = (int)(idx / W) / cell;
+    const int cx = key_x(idx) / cell, cy = key_y(idx) / cell;
     atomicAdd(&cc[cy * gw + cx], 1);
   }
   __syncthreads();
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   for (int i = tid; i < n; i += SEL_THREADS) {
     const unsigned long long k = C[i];
     const unsigned idx = (unsigned)(k & 0xffffffffu);
-    const int cid = ((int)(idx / W) / cell) * gw + (int)(idx % W) / cell;
+    const int cid = (key_y(idx) / cell) * gw + key_x(idx) / cell;
     const int slot = atomicSub(&cc[cid], 1) - 1;
     const int pos = ld_l2(&cs[cid]) + slot;
     st_l2(&S[pos], k);
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
           }
           const unsigned long long kk = keysL[i];
           const unsigned idx = (unsigned)(kk & 0xffffffffu);
-          const int x = (int)(idx % W), y = (int)(idx / W);
+          const int x = key_x(idx), y = key_y(idx);
           const int cx = x / cell, cy = y / cell;
           const int x1 = cx > 0 ? cx - 1 : 0, x2 = cx < gw - 1 ? cx + 1 : gw - 1;
           const int y1 = cy > 0 ? cy - 1 : 0, y2 = cy < gh - 1 ? cy + 1 : gh - 1;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
               const unsigned long long km = keysL[p];
               if (km <= kk) continue;  // only stronger candidates matter (keys are unique)
               const unsigned im = (unsigned)(km & 0xffffffffu);
-              const float dx = (float)(x - (int)(im % W)), dy = (float)(y - (int)(im / W));
+              const float dx = (float)(x - key_x(im)), dy = (float)(y - key_y(im));
               if (!(dx * dx + dy * dy < md2)) continue;
               const uint8_t sm = ((volatile uint8_t*)stateL)[p];
               if (sm == 1) { decided = 2; break; }
@@ -387,7 +392,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
       if (STATE(i) != 0) continue;
       const unsigned long long k = KEY(i);
       const unsigned idx = (unsigned)(k & 0xffffffffu);
-      const int x = (int)(idx % W), y = (int)(idx / W);
+      const int x = key_x(idx), y = key_y(idx);
       const int cx = x / cell, cy = y / cell;
       const int x1 = cx > 0 ? cx - 1 : 0, x2 = cx < gw - 1 ? cx + 1 : gw - 1;
       const int y1 = cy > 0 ? cy - 1 : 0, y2 = cy < gh - 1 ? cy + 1 : gh - 1;
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
           const unsigned long long km = KEY(p);
           if (km <= k) continue;  // only stronger candidates matter (keys are unique)
           const unsigned im = (unsigned)(km & 0xffffffffu);
-          const float dx = (float)(x - (int)(im % W)), dy = (float)(y - (int)(im / W));
+          const float dx = (float)(x - key_x(im)), dy = (float)(y - key_y(im));
           if (!(dx * dx + dy * dy < md2)) continue;
           const uint8_t sm = STATE(p);
           if (sm == 1) { rejected = true; break; }
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   const int m = A < max_corners ? A : max_corners;
   for (int i = tid; i < m; i += SEL_THREADS) {
     const unsigned idx = (unsigned)(sKeys[i] & 0xffffffffu);
-    oxy[2 * i] = (float)(idx % W); oxy[2 * i + 1] = (float)(idx / W);
+    oxy[2 * i] = (float)key_x(idx); oxy[2 * i + 1] = (float)key_y(idx);
   }
   if (tid == 0) out_n[b] = m;
 }
@@ -458,6 +463,7 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
 static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, int H, int row_stride,
                          size_t image_stride, int max_corners, double quality, double min_distance,
                          float* xy, int* n) {
+  SVO_REQUIRE(ctx, W <= 65535 && H <= 65535, "corner_detect: image sides above 65535 (candidate keys pack y << 16 | x)");
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned) * batch, st));
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * NC_STRIDE * batch, st));

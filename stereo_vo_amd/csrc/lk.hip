@@ -130,7 +130,7 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
     // stage the (WIN+3)^2 raw patch: tile (r,c) <-> image (ipy-1+r, ipx-1+c), reflect-101
     for (int i = lane; i < RP * RP; i += LKT) {
       const int r = i / RP, c = i % RP;
-      S.raw[i] = Ip[(size_t)reflect101(ipy - 1 + r, Ih_) * Iw_ + reflect101(ipx - 1 + c, Iw_)];
+      S.raw[i] = Ip[__mul24(reflect101(ipy - 1 + r, Ih_), Iw_) + reflect101(ipx - 1 + c, Iw_)];  // 24-bit factors: full-rate multiply
     }
     __syncthreads();
     // Scharr at the (WIN+1)^2 grid; zero outside the image (BORDER_CONSTANT derivative padding)
@@ -209,10 +209,10 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
         rx0 = inx - RM; ry0 = iny - RM;
         __syncthreads();
         if (rx0 >= 0 && ry0 >= 0 && rx0 + RS <= Jw_ && ry0 + RS <= Jh_) {
-          for (int i = lane; i < RS * RS; i += LKT) S.jreg[i] = Jp[(size_t)(ry0 + i / RS) * Jw_ + rx0 + i % RS];
+          for (int i = lane; i < RS * RS; i += LKT) S.jreg[i] = Jp[__mul24(ry0 + i / RS, Jw_) + rx0 + i % RS];
         } else {
           for (int i = lane; i < RS * RS; i += LKT)
-            S.jreg[i] = Jp[(size_t)reflect101(ry0 + i / RS, Jh_) * Jw_ + reflect101(rx0 + i % RS, Jw_)];
+            S.jreg[i] = Jp[__mul24(reflect101(ry0 + i / RS, Jh_), Jw_) + reflect101(rx0 + i % RS, Jw_)];
         }
         __syncthreads();
         staged = true;
