@@ -864,12 +864,13 @@ __device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
     const int seg = item / width, e = item % width;
     double acc = 0.0;
     const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-    const double* src = base + (size_t)e0 * stride + e;
-    // 16 independent loads in flight, adds strictly in list order
-    for (int q0 = b0; q0 < b1; q0 += 16) {
+    // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
+    // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
+    const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e;
+    for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
       double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? src[(size_t)(q0 + u) * stride] : 0.0;
+      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (q0 + u < b1) acc += v[u];
