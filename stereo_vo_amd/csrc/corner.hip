@@ -175,6 +175,8 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t* __r
   if (lane == 0 && lmax) atomicMax(&maxkey[b], lmax);
 }
 
+constexpr int NMS_ROWS = 8;   // pixel rows per thread: a workgroup covers 64 x 32 pixels (one pixel per thread left the
+                              // kernel bound by workgroup turnover: 30 k workgroups, 90 us per 16 frames)
 __global__ __launch_bounds__(256) void corner_nms_kernel(const float* __restrict__ eig, int W, int H,
                                                          const unsigned* __restrict__ maxkey, double quality,
                                                          unsigned long long* __restrict__ cand,
@@ -184,41 +186,49 @@ __global__ __launch_bounds__(256) void corner_nms_kernel(const float* __restrict
   const float maxv = key_f32(maxkey[b]);
   const float thr = (float)((double)maxv * quality);
   const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int yb = blockIdx.y * (4 * NMS_ROWS) + (threadIdx.x >> 6);
   __shared__ int sCount, sBase;
   if (threadIdx.x == 0) sCount = 0;
   __syncthreads();
-  bool is_cand = false;
-  float v = 0.f;
-  if (!(x < 1 || x > W - 2 || y < 1 || y > H - 2)) {
+  float val[NMS_ROWS];
+  unsigned found = 0u;  // bit k: row yb + 4 k holds a candidate
+#pragma unroll
+  for (int k = 0; k < NMS_ROWS; ++k) {
+    const int y = yb + 4 * k;
+    val[k] = 0.f;
+    if (x < 1 || x > W - 2 || y < 1 || y > H - 2) continue;
     const float c = E[(size_t)y * W + x];
-    v = c > thr ? c : 0.0f;
-    if (v != 0.0f) {
-      float m = v;
+    const float v = c > thr ? c : 0.0f;
+    if (v == 0.0f) continue;
+    float m = v;
 #pragma unroll
-      for (int j = -1; j <= 1; ++j)
+    for (int j = -1; j <= 1; ++j)
 #pragma unroll
-        for (int i = -1; i <= 1; ++i) {
-          const float nv = E[(size_t)(y + j) * W + (x + i)];
-          const float t = nv > thr ? nv : 0.0f;
-          m = t > m ? t : m;
-        }
-      is_cand = v == m;
-    }
+      for (int i = -1; i <= 1; ++i) {
+        const float nv = E[(size_t)(y + j) * W + (x + i)];
+        const float t = nv > thr ? nv : 0.0f;
+        m = t > m ? t : m;
+      }
+    if (v == m) { val[k] = v; found |= 1u << k; }
   }
   // one global atomic per workgroup that has candidates (a per-thread returning atomic on one word
   // serialises at ~88/us: measured 550 us for 16 frames before this change)
   int local = 0;
-  if (is_cand) local = atomicAdd(&sCount, 1);
+  if (found) local = atomicAdd(&sCount, __popc(found));
   __syncthreads();
   if (threadIdx.x == 0 && sCount > 0) sBase = atomicAdd(&ncand[b * NC_STRIDE], sCount);
   __syncthreads();
-  if (is_cand) {
-    const int pos = sBase + local;
-    if (pos < cap)
-      cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(v) << 32) | pack_xy(x, y);
-    else
-      atomicOr(status, 1);
+  if (found) {
+    int pos = sBase + local;
+#pragma unroll
+    for (int k = 0; k < NMS_ROWS; ++k) {
+      if (!((found >> k) & 1u)) continue;
+      if (pos < cap)
+        cand[(size_t)b * cap + pos] = ((unsigned long long)f32_key(val[k]) << 32) | pack_xy(x, yb + 4 * k);
+      else
+        atomicOr(status, 1);
+      ++pos;
+    }
   }
 }
 
@@ -474,7 +484,7 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
   }
   {
   SvoProfScope prof(ctx, SVO_PROF_CORNER_NMS);
-  hipLaunchKernelGGL(corner_nms_kernel, dim3(svo_div_up(W, 64), svo_div_up(H, 4), batch), dim3(256), 0, st,
+  hipLaunchKernelGGL(corner_nms_kernel, dim3(svo_div_up(W, 64), svo_div_up(H, 4 * NMS_ROWS), batch), dim3(256), 0, st,
                      ctx->d_eig, W, H, ctx->d_maxkey, quality, ctx->d_cand, ctx->d_ncand, ctx->lim.max_candidates,
                      ctx->d_status);
   }
