@@ -357,15 +357,25 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
   }
   // sequential f32 sum in feature order (the reference's loop order decides the rounding, SURVEY C-2):
   // values are staged in LDS by all threads so the single summing lane never waits on global memory
-  __shared__ float sPar[4096];
+  __shared__ __align__(16) float sPar[4096];
   float sum = 0.f;
   for (int c0 = 0; c0 < n; c0 += 4096) {
     __syncthreads();
     for (int i = threadIdx.x; i < 4096 && c0 + i < n; i += 1024) sPar[i] = keep[c0 + i] ? parallax[c0 + i] : -1.0f;
     __syncthreads();
     if (threadIdx.x == 0) {
+      // dropped features were staged as -1: adding +0.0f instead leaves the running sum bit-identical (it is >= +0)
+      // and keeps the loop branch-free, four LDS words per read
       const int m = n - c0 < 4096 ? n - c0 : 4096;
-      for (int i = 0; i < m; ++i) { const float v = sPar[i]; if (v >= 0.f) sum += v; }
+      int i = 0;
+      for (; i + 4 <= m; i += 4) {
+        const float4 q = *reinterpret_cast<const float4*>(&sPar[i]);
+        sum += q.x >= 0.f ? q.x : 0.f;
+        sum += q.y >= 0.f ? q.y : 0.f;
+        sum += q.z >= 0.f ? q.z : 0.f;
+        sum += q.w >= 0.f ? q.w : 0.f;
+      }
+      for (; i < m; ++i) { const float v = sPar[i]; sum += v >= 0.f ? v : 0.f; }
     }
   }
   if (threadIdx.x == 0) {
