@@ -173,3 +173,48 @@ def test_hip_pipeline_config5_hd_many_features():
     assert len(ids) > 3000
     g.close()
     c.close()
+
+
+@pytest.mark.gpu
+def test_hip_pipelines_concurrent_streams_keep_parity():
+    """Several independent stereo streams on one GPU, one host thread each (the bench's default shape): every stream must
+    still reproduce its own oracle run exactly — nothing in the library may be shared between contexts."""
+    import threading
+    import stereo_vo_amd as S
+    n, ns = 10, 4
+    seqs = [_seq(n, seed=0x5EED0100 + 17 * i) for i in range(ns)]
+    out, err = [None] * ns, [None] * ns
+
+    def work(i):
+        try:
+            p, L, R = seqs[i]
+            c = S.Context(p.width, p.height, max_batch=5, max_corners=600, max_candidates=1 << 16, max_features=600)
+            pp = S.pipeline_default_params()
+            pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+            pp.width, pp.height = p.width, p.height
+            pp.max_corners, pp.min_feature_distance, pp.max_features = 600, 10.0, 600
+            pp.ba_max_time_s = 0.0
+            g = S.Pipeline(c, pp)
+            res = []
+            for rep in range(3):  # same frames three times from a reset pipeline: also exercises reset under load
+                g.reset()
+                res = g.process_batch(L[:5], R[:5]) + g.process_batch(L[5:], R[5:])
+            out[i] = ([(r.n_detected, r.n_tracked, r.n_inliers, r.n_new, r.is_keyframe, r.ba_iterations, list(r.pose7)) for r in res],
+                      g.tracked())
+            g.close()
+            c.close()
+        except Exception as e:  # surfaced in the main thread
+            err[i] = e
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(ns)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not any(err), err
+    for i in range(ns):
+        p, L, R = seqs[i]
+        o = _ora_pipe(p, min_feature_distance=10.0, max_corners=600, max_features=600)
+        ref = [o.process(L[k], R[k]) for k in range(n)]
+        got, (ig, xg) = out[i]
+        assert got == [(r.n_detected, r.n_tracked, r.n_inliers, r.n_new, r.is_keyframe, r.ba_iterations, list(r.pose7)) for r in ref]
+        io, xo = o.tracked()
+        assert np.array_equal(ig, io) and np.array_equal(xg.view(np.uint32), xo.view(np.uint32))
