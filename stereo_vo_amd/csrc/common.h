@@ -6,16 +6,35 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "svo.h"
 
+// Last-error text of a context.  The caller thread and the asynchronous bundle-adjustment worker may both report
+// (and the caller clears / tests it between frames), so every access is serialised.
+struct SvoErr {
+  SvoErr& operator=(const std::string& v) { std::lock_guard<std::mutex> g(mu_); s_ = v; return *this; }
+  SvoErr& operator=(const char* v) { std::lock_guard<std::mutex> g(mu_); s_ = v ? v : ""; return *this; }
+  bool empty() const { std::lock_guard<std::mutex> g(mu_); return s_.empty(); }
+  void clear() { std::lock_guard<std::mutex> g(mu_); s_.clear(); }
+  const char* c_str() const {  // a per-thread copy: stays valid while another thread reports
+    thread_local std::string copy;
+    std::lock_guard<std::mutex> g(mu_);
+    copy = s_;
+    return copy.c_str();
+  }
+ private:
+  mutable std::mutex mu_;
+  std::string s_;
+};
+
 struct svo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   svo_limits lim{};
-  std::string err;
+  SvoErr err;
   // persistent device workspace (allocated once in svo_create)
   uint8_t* d_ws = nullptr;   // generic scratch for host-pointer entry points
   size_t ws_bytes = 0;

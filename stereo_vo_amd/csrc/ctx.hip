@@ -101,6 +101,7 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
   ALLOC(c->d_status, 64);
 #undef ALLOC
   if ((e = hipHostMalloc(&c->h_pinned, c->pinned_bytes, hipHostMallocDefault)) != hipSuccess) return fail("pinned", e);
+  memset(c->h_pinned, 0, c->pinned_bytes);  // completion words are compared by equality: never start from recycled bytes
   if ((e = hipMemsetAsync(c->d_status, 0, 64, c->stream)) != hipSuccess) return fail("memset", e);
   if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("sync", e);
   *out = c;

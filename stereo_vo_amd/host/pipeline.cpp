@@ -8,26 +8,40 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <chrono>
+#include <unordered_map>
 
 #include "kernels.h"
 #include "stereo_vo.hpp"
 
 namespace svo {
 
-// SVO_TIMING=1: wall-clock per phase of the host-side chain, printed when the pipeline is destroyed.
+// SVO_TIMING=1: wall-clock per phase of the host-side chain, summed over every pipeline of the process (stream threads
+// and bundle-adjustment workers add concurrently: atomic nanosecond counters) and printed when a pipeline is destroyed.
+// Scoped objects only, so an early return cannot leak one; a no-op unless the variable is set.
 struct PhaseTimer {
-  static double acc[8];
+  static std::atomic<uint64_t> acc_ns[8];
+  static bool enabled() { static const bool on = getenv("SVO_TIMING") != nullptr; return on; }
   static const char* name(int i) {
     static const char* n[8] = {"prepare_batch", "track", "pnp", "dedup+stereo+triangulate", "add_keyframe+init", "bundle_adjust", "first_keyframe", "other"};
     return n[i];
   }
   int id;
   std::chrono::steady_clock::time_point t0;
-  explicit PhaseTimer(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
-  ~PhaseTimer() { acc[id] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  explicit PhaseTimer(int i) : id(i) { if (enabled()) t0 = std::chrono::steady_clock::now(); }
+  void next(int i) { stop(); id = i; if (enabled()) t0 = std::chrono::steady_clock::now(); }  // close this phase, open phase i
+  void stop() {
+    if (id >= 0 && enabled())
+      acc_ns[id].fetch_add((uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(),
+                           std::memory_order_relaxed);
+    id = -1;
+  }
+  ~PhaseTimer() { stop(); }
+  PhaseTimer(const PhaseTimer&) = delete;
+  PhaseTimer& operator=(const PhaseTimer&) = delete;
 };
-double PhaseTimer::acc[8] = {0};
+std::atomic<uint64_t> PhaseTimer::acc_ns[8];
 
 #define SVO_TRY(expr)            \
   do {                           \
@@ -64,7 +78,7 @@ void BundleAdjuster::bundle_adjust_async() {
   svo_ctx* c = ctx_;
   worker_ = std::thread([this, c]() {
     (void)hipSetDevice(c->device);
-    this->bundle_adjust();
+    this->run_bundle_adjust();
   });
 }
 
@@ -81,7 +95,7 @@ void BundleAdjuster::reset() {
   opt.max_time_s = max_time_s_;           // src/bundle_adjuster.cpp:11
   const int max_lm = 1 << 20;             // landmark store grows monotonically (SURVEY C-3)
   const int max_obs = (int)(window_size_ + 1) * max_features_ + 64;
-  svo_ba_create(ctx_, &ba_, (int)window_size_, &info_, &opt, max_lm > max_obs ? max_obs : max_lm, max_obs);
+  if (svo_ba_create(ctx_, &ba_, (int)window_size_, &info_, &opt, max_lm > max_obs ? max_obs : max_lm, max_obs)) ba_ = nullptr;
   last_keyframe_.reset();
   last_iterations_ = 0;
 }
@@ -110,9 +124,16 @@ void BundleAdjuster::add_keyframe(std::shared_ptr<Keyframe> kf) {  // src/bundle
   launch_needed_ = true;
 }
 
-void BundleAdjuster::bundle_adjust() {  // src/bundle_adjuster.cpp:137-157
+void BundleAdjuster::bundle_adjust() {  // src/bundle_adjuster.cpp:137-157 (synchronous use, caller thread)
+  wait();
+  launch_needed_ = false;
+  run_bundle_adjust();
+}
+
+// The solve itself; runs on the caller thread (bundle_adjust) or on the worker (bundle_adjust_async), never both:
+// every caller-thread entry point joins the worker first.  Touches no caller-thread flag.
+void BundleAdjuster::run_bundle_adjust() {
   last_iterations_ = 0;
-  if (!worker_.joinable() || std::this_thread::get_id() != worker_.get_id()) launch_needed_ = false;  // synchronous use
   if (!ba_ || !last_keyframe_) return;
   if (new_frame_added_) {  // :138
     PhaseTimer pt(5);
@@ -153,28 +174,38 @@ void BundleAdjuster::get_world_points_into(float* xyz, const std::vector<size_t>
 // ------------------------------------------------------------------------------------------ FeatureTracker
 FeatureTracker::FeatureTracker(svo_ctx* ctx, int max_features, int max_width, int max_height) : ctx_(ctx), cap_(max_features) {
   pyr_cap_ = svo_k_pyramid_bytes(max_width, max_height);
+  hipError_t e = hipSetDevice(ctx->device);
+  auto dev = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
   for (int b = 0; b < 2; ++b) {
-    (void)hipMalloc((void**)&d_xy_[b], sizeof(float) * 2 * cap_);
-    (void)hipMalloc((void**)&d_init_[b], sizeof(float) * 2 * cap_);
-    (void)hipMalloc((void**)&d_ids_[b], sizeof(long long) * cap_);
+    dev((void**)&d_xy_[b], sizeof(float) * 2 * cap_);
+    dev((void**)&d_init_[b], sizeof(float) * 2 * cap_);
+    dev((void**)&d_ids_[b], sizeof(long long) * cap_);
   }
-  (void)hipMalloc((void**)&d_fwd_, sizeof(float) * 2 * cap_);
-  (void)hipMalloc((void**)&d_par_, sizeof(float) * cap_);
-  (void)hipMalloc((void**)&d_keep_, cap_);
-  (void)hipMalloc((void**)&d_kidx_, sizeof(int) * cap_);
-  (void)hipMalloc((void**)&d_n_, sizeof(int));
-  (void)hipMalloc((void**)&d_av_, sizeof(float));
-  (void)hipMalloc((void**)&d_last_pyr_, pyr_cap_);
+  dev((void**)&d_fwd_, sizeof(float) * 2 * cap_);
+  dev((void**)&d_par_, sizeof(float) * cap_);
+  dev((void**)&d_keep_, cap_);
+  dev((void**)&d_kidx_, sizeof(int) * cap_);
+  dev((void**)&d_n_, sizeof(int));
+  dev((void**)&d_av_, sizeof(float));
+  dev((void**)&d_last_pyr_, pyr_cap_);
   // pinned host mirrors of the current feature set: the compaction kernel writes them in place
-  (void)hipHostMalloc((void**)&h_mirror_, (sizeof(float) * 2 + sizeof(long long)) * (size_t)cap_ + 64, hipHostMallocDefault);
+  const size_t mirror_bytes = (sizeof(float) * 2 + sizeof(long long)) * (size_t)cap_ + 64;
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h_mirror_, mirror_bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {  // surfaced as SVO_ERR_HIP by svo_pipeline_create / the adapters (ok() == false)
+    ctx_->err = std::string("FeatureTracker: allocation failed: ") + hipGetErrorString(e);
+    return;
+  }
+  memset(h_mirror_, 0, mirror_bytes);
   h_ids_ = reinterpret_cast<long long*>(h_mirror_);
   h_xy_ = reinterpret_cast<float*>(h_ids_ + cap_);
   h_n_ = reinterpret_cast<int*>(h_xy_ + 2 * (size_t)cap_);
   h_av_ = reinterpret_cast<float*>(h_n_ + 1);
+  alloc_ok_ = true;
 }
 
 FeatureTracker::~FeatureTracker() {
-  void* ptrs[] = {d_xy_[0], d_xy_[1], d_init_[0], d_init_[1], d_ids_[0], d_ids_[1], d_fwd_, d_par_, d_keep_, d_kidx_, d_n_, d_av_, d_last_pyr_};
+  void* ptrs[] = {d_xy_[0], d_xy_[1], d_init_[0], d_init_[1], d_ids_[0], d_ids_[1], d_fwd_, d_par_, d_keep_, d_kidx_, d_n_, d_av_, d_last_pyr_,
+                  d_host_img_, d_host_pyr_};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h_mirror_) (void)hipHostFree(h_mirror_);
 }
@@ -192,6 +223,8 @@ void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const s
   }
   if (n) memcpy(h_xy_, features.data(), sizeof(float) * 2 * n);
   for (int i = 0; i < n; ++i) h_ids_[i] = (long long)ids[i];
+  init_xy_.assign(features.begin(), features.begin() + n);  // initial_features (src/feature_tracker.cpp:9-12), host side
+  init_ids_.assign(h_ids_, h_ids_ + n);
   const SvoPublish pub = svo_publish_next(ctx_, SVO_W_INIT);
   pending_init_seq_ = pub.seq;
   if (svo_k_tracker_init(ctx_, h_xy_, h_ids_, n, d_xy_[cur_], d_init_[cur_], d_ids_[cur_], &pub)) return;
@@ -247,14 +280,61 @@ void FeatureTracker::get_tracked_features(std::vector<Point2f>& features, std::v
   for (int i = 0; i < n_; ++i) ids[i] = (size_t)h_ids_[i];
 }
 
-// draw_track's inputs (src/feature_tracker.cpp:78-82): keyframe position and current position of every feature
+// draw_track's inputs (src/feature_tracker.cpp:78-82): keyframe position (initial_features.at(id)) and current position of
+// every feature.  Host data only: the current set lives in the pinned mirrors, the keyframe set was copied at init().
 void FeatureTracker::get_track_arrows(std::vector<Point2f>& initial, std::vector<Point2f>& current) {
   initial.resize(n_);
   current.resize(n_);
   if (!n_) return;
   memcpy(current.data(), h_xy_, sizeof(float) * 2 * n_);
-  // visualisation path, not the hot path: a plain copy of the device-resident keyframe positions
-  SVO_TRY(hipMemcpy(initial.data(), d_init_[cur_], sizeof(float) * 2 * n_, hipMemcpyDeviceToHost));
+  std::unordered_map<long long, Point2f> at;
+  at.reserve(init_ids_.size() * 2);
+  for (size_t i = 0; i < init_ids_.size(); ++i) at.emplace(init_ids_[i], init_xy_[i]);  // insert(): the first entry of an id wins (:10)
+  for (int i = 0; i < n_; ++i) {
+    const auto it = at.find(h_ids_[i]);
+    initial[i] = it != at.end() ? it->second : current[i];
+  }
+}
+
+void FeatureTracker::draw_track() {  // src/feature_tracker.cpp:74-83 (the pixels are drawn by whoever holds the image)
+  if (!drawing_) return;
+  get_track_arrows(drawn_initial_, drawn_current_);
+  ++draw_serial_;
+}
+
+// mono8 host image -> HBM staging -> 4-level pyramid (what the device-resident methods take)
+int FeatureTracker::upload_pyramid(const uint8_t* image, int width, int height, int stride) {
+  if (!alloc_ok_ || !image || width < 1 || height < 1 || stride < width) return SVO_ERR_INVALID;
+  if (svo_k_pyramid_bytes(width, height) > pyr_cap_) { ctx_->err = "FeatureTracker: image larger than the tracker's capacity"; return SVO_ERR_CAPACITY; }
+  if (!d_host_img_) {
+    SVO_HIP_CHECK(ctx_, hipMalloc((void**)&d_host_img_, pyr_cap_));  // level 0 of the largest pyramid bounds the image
+    SVO_HIP_CHECK(ctx_, hipMalloc((void**)&d_host_pyr_, pyr_cap_));
+  }
+  SVO_HIP_CHECK(ctx_, hipMemcpy2DAsync(d_host_img_, (size_t)width, image, (size_t)stride, (size_t)width, (size_t)height,
+                                       hipMemcpyHostToDevice, ctx_->stream));
+  return svo_k_build_pyramid(ctx_, d_host_img_, 1, width, height, width, (size_t)width * height, d_host_pyr_, svo_k_pyramid_bytes(width, height));
+}
+
+int FeatureTracker::init_host(const uint8_t* image, int width, int height, int stride, const std::vector<Point2f>& features,
+                              const std::vector<size_t>& ids) {
+  const bool b = borrow_;
+  borrow_ = false;  // the staging pyramid is overwritten by the next call: clone it now (src/feature_tracker.cpp:14)
+  int rc = upload_pyramid(image, width, height, stride);
+  if (!rc) init(d_host_pyr_, width, height, features, ids);
+  borrow_ = b;
+  return rc ? rc : (ctx_->err.empty() ? SVO_OK : SVO_ERR_HIP);
+}
+
+int FeatureTracker::track_features_host(float& av_parallax, float& percent_lost, const uint8_t* image, int width, int height,
+                                        int stride, bool flow_back) {
+  if (!has_image_) return SVO_ERR_INVALID;
+  const bool b = borrow_;
+  borrow_ = false;
+  retain();  // the previous image may be a borrowed pyramid
+  int rc = upload_pyramid(image, width, height, stride);
+  if (!rc) track_features(av_parallax, percent_lost, d_host_pyr_, width, height, flow_back);
+  borrow_ = b;
+  return rc ? rc : (ctx_->err.empty() ? SVO_OK : SVO_ERR_HIP);
 }
 
 // ------------------------------------------------------------------------------------------ ImageProcessor
@@ -309,32 +389,41 @@ ImageProcessor::ImageProcessor(svo_ctx* ctx, const float K[9], std::shared_ptr<F
   feature_tracker->borrow_pyramids(true);  // the batch pyramids outlive every frame of the batch; retain() in prepare_batch
   pyr_stride_ = svo_k_pyramid_bytes(ctx->lim.max_width, ctx->lim.max_height);
   const size_t mc = (size_t)max_corners_, mf = (size_t)ctx->lim.max_features;
-  (void)hipMalloc((void**)&d_corners_, sizeof(float) * 2 * mc * max_batch_);
-  (void)hipMalloc((void**)&d_ncorners_, sizeof(int) * max_batch_);
-  (void)hipMalloc((void**)&d_pyr_, pyr_stride_ * max_batch_);
-  (void)hipMalloc((void**)&d_xyz_, sizeof(float) * 3 * mf);
-  (void)hipMalloc((void**)&d_trk_xy_, sizeof(float) * 2 * mf);
-  (void)hipMalloc((void**)&d_trk_ids_, sizeof(long long) * mf);
-  (void)hipMalloc((void**)&d_inl_, sizeof(int) * mf);
-  (void)hipMalloc((void**)&d_new_xy_, sizeof(float) * 2 * mc);
-  (void)hipMalloc((void**)&d_disp_, sizeof(float) * mc);
-  (void)hipMalloc((void**)&d_kxy_, sizeof(float) * 5 * mc + 64);  // kept xy (2) + xyz (3) contiguous for one copy
-  d_kxyz_ = d_kxy_ + 2 * mc;
-  (void)hipMalloc((void**)&d_cnt_, sizeof(int) * 4);
+  hipError_t e = hipSetDevice(ctx->device);
+  auto dev = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+  dev((void**)&d_corners_, sizeof(float) * 2 * mc * max_batch_);
+  dev((void**)&d_ncorners_, sizeof(int) * max_batch_);
+  dev((void**)&d_pyr_, pyr_stride_ * max_batch_);
+  dev((void**)&d_xyz_, sizeof(float) * 3 * mf);
+  dev((void**)&d_trk_xy_, sizeof(float) * 2 * mf);
+  dev((void**)&d_trk_ids_, sizeof(long long) * mf);
+  dev((void**)&d_inl_, sizeof(int) * mf);
+  dev((void**)&d_new_xy_, sizeof(float) * 2 * mc);
+  dev((void**)&d_disp_, sizeof(float) * mc);
+  dev((void**)&d_kxy_, sizeof(float) * 5 * mc + 64);  // kept xy (2) + xyz (3) contiguous for one copy
+  dev((void**)&d_cnt_, sizeof(int) * 4);
   h_ncorners_.assign(max_batch_, 0);
-  // pinned host arena: world points for PnP | inlier list | triangulation outputs (count, kept 2-D, 3-D).
-  // Kernels read / write these in place; the host polls completion words (common.h SvoPublish).
-  const size_t bytes = sizeof(float) * 3 * mf + sizeof(int) * mf + 64 + sizeof(float) * 5 * mc + 256;
-  (void)hipHostMalloc((void**)&h_arena_, bytes, hipHostMallocDefault);
+  // pinned host arena: world points for PnP | inlier list | triangulation outputs (count, kept 2-D, 3-D) | batch corner
+  // counts + status.  Kernels read / write these in place; the host polls completion words (common.h SvoPublish).
+  const size_t bytes = sizeof(float) * 3 * mf + sizeof(int) * mf + 64 + sizeof(float) * 5 * mc + 256 + sizeof(int) * ((size_t)max_batch_ + 16);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h_arena_, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {  // surfaced as SVO_ERR_HIP by svo_pipeline_create / the adapters (ok() == false)
+    ctx_->err = std::string("ImageProcessor: allocation failed: ") + hipGetErrorString(e);
+    return;
+  }
+  memset(h_arena_, 0, bytes);
+  d_kxyz_ = d_kxy_ + 2 * mc;
   h_xyz_ = reinterpret_cast<float*>(h_arena_);
   h_inl_ = reinterpret_cast<int*>(h_xyz_ + 3 * mf);
   h_tri_cnt_ = h_inl_ + mf;
   h_tri_xy_ = reinterpret_cast<float*>(h_tri_cnt_ + 16);
   h_tri_xyz_ = h_tri_xy_ + 2 * mc;
+  h_batch_cnt_ = reinterpret_cast<int*>(h_tri_xyz_ + 3 * mc + 16);
+  alloc_ok_ = feature_tracker->ok() && bundle_adjuster->handle() != nullptr;
 }
 
 ImageProcessor::~ImageProcessor() {
-  void* ptrs[] = {d_corners_, d_ncorners_, d_pyr_, d_xyz_, d_trk_xy_, d_trk_ids_, d_inl_, d_new_xy_, d_disp_, d_kxy_, d_cnt_};
+  void* ptrs[] = {d_corners_, d_ncorners_, d_pyr_, d_xyz_, d_trk_xy_, d_trk_ids_, d_inl_, d_new_xy_, d_disp_, d_kxy_, d_cnt_, d_stage_};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h_arena_) (void)hipHostFree(h_arena_);
 }
@@ -348,6 +437,7 @@ void ImageProcessor::reset() {
 
 int ImageProcessor::prepare_batch(const uint8_t* left, int batch, int width, int height) {
   PhaseTimer pt(0);
+  if (!alloc_ok_) return SVO_ERR_HIP;
   if (batch < 1 || batch > max_batch_ || batch > ctx_->lim.max_batch) { ctx_->err = "prepare_batch: batch outside limits"; return SVO_ERR_INVALID; }
   width_ = width; height_ = height; batch_ = batch;
   const size_t istride = (size_t)width * height;
@@ -359,7 +449,7 @@ int ImageProcessor::prepare_batch(const uint8_t* left, int batch, int width, int
   feature_tracker->retain();  // the tracker's previous image may live in the buffer overwritten next
   rc = svo_k_build_pyramid(ctx_, left, batch, width, height, width, istride, d_pyr_, pyr_stride_);
   if (rc) return rc;
-  int* h = (int*)((char*)ctx_->h_pinned + 8192);
+  int* h = h_batch_cnt_;
   if (hipMemcpyAsync(h, d_ncorners_, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx_->stream) != hipSuccess ||
       hipMemcpyAsync(h + batch, ctx_->d_status, sizeof(int), hipMemcpyDeviceToHost, ctx_->stream) != hipSuccess ||
       hipStreamSynchronize(ctx_->stream) != hipSuccess) {
@@ -393,6 +483,28 @@ void ImageProcessor::triangulate_stereo(std::vector<Point3f>& features_3d, std::
   features_3d.resize(m);
   memcpy(valid_features_2d.data(), h_tri_xy_, sizeof(float) * 2 * m);
   memcpy(features_3d.data(), h_tri_xyz_, sizeof(float) * 3 * m);
+}
+
+int ImageProcessor::process_host(const uint8_t* left, int left_stride, const uint8_t* right, int right_stride, int width,
+                                 int height, double t) {
+  if (!alloc_ok_) return SVO_ERR_HIP;
+  SVO_REQUIRE(ctx_, left && right && width >= 32 && height >= 32 && left_stride >= width && right_stride >= width &&
+                        width <= ctx_->lim.max_width && height <= ctx_->lim.max_height, "process_host: bad image arguments");
+  const size_t bytes = (size_t)width * height;
+  if (stage_bytes_ < 2 * bytes) {
+    if (d_stage_) (void)hipFree(d_stage_);
+    d_stage_ = nullptr; stage_bytes_ = 0;
+    SVO_HIP_CHECK(ctx_, hipMalloc((void**)&d_stage_, 2 * bytes));
+    stage_bytes_ = 2 * bytes;
+  }
+  SVO_HIP_CHECK(ctx_, hipMemcpy2DAsync(d_stage_, (size_t)width, left, (size_t)left_stride, (size_t)width, (size_t)height,
+                                       hipMemcpyHostToDevice, ctx_->stream));
+  SVO_HIP_CHECK(ctx_, hipMemcpy2DAsync(d_stage_ + bytes, (size_t)width, right, (size_t)right_stride, (size_t)width, (size_t)height,
+                                       hipMemcpyHostToDevice, ctx_->stream));
+  ctx_->err.clear();
+  batch_ = 0;  // no prepared batch: process() detects and builds the pyramid for this frame
+  process(StereoPair(DeviceImage{d_stage_, width, height, width}, DeviceImage{d_stage_ + bytes, width, height, width}, t, -1));
+  return ctx_->err.empty() ? SVO_OK : SVO_ERR_HIP;
 }
 
 void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp:18-163
@@ -436,7 +548,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   stats_.percent_lost = percent_lost;
   if (av_parallax <= parallax_thresh && (double)percent_lost < 0.4) return;  // :63-65
 
-  PhaseTimer* ptp = new PhaseTimer(2);
+  PhaseTimer phase(2);
   std::vector<Point2f> tracked_features;
   std::vector<size_t> tracked_ids;
   feature_tracker->get_tracked_features(tracked_features, tracked_ids);   // :71 (pinned mirrors: no copy, no wait)
@@ -468,8 +580,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
     kf->tracked_features_2d[i] = tracked_features[idx];
   }
 
-  delete ptp;
-  ptp = new PhaseTimer(3);
+  phase.next(3);
   // dedup :113-128 on the device; the surviving corners stay in HBM for the stereo stage
   if (num_inliers > 0 &&  // the inlier features are already in HBM: gather them by the device inlier list
       svo_k_gather_xy_ids(ctx_, d_inl_, num_inliers, feature_tracker->device_features(), feature_tracker->device_ids(), d_trk_xy_,
@@ -487,9 +598,9 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   hmat[15] = 1.f;
   triangulate_stereo(kf->new_features_3d, kf->new_features_2d, d_new_xy_, d_cnt_, n_det, sp.left, sp.right, hmat);  // :137-142
 
-  delete ptp;
-  PhaseTimer pt4(4);
+  phase.next(4);
   bundle_adjuster->add_keyframe(kf);  // :144
+  feature_tracker->draw_track();      // :146 (arrow snapshot; a no-op unless an adapter enabled drawing)
 
   std::vector<Point2f> features_2d_for_tracker(kf->tracked_features_2d);  // :148-162
   features_2d_for_tracker.insert(features_2d_for_tracker.end(), kf->new_features_2d.begin(), kf->new_features_2d.end());
@@ -546,15 +657,21 @@ extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_p
   const float K[9] = {(float)p->cam.focal, 0.f, (float)p->cam.cx, 0.f, (float)p->cam.focal, (float)p->cam.cy, 0.f, 0.f, 1.f};
   pl->proc.reset(new svo::ImageProcessor(ctx, K, pl->tracker, pl->adjuster, (float)p->cam.baseline, p->min_feature_distance,
                                          p->parallax_thresh, p->max_corners, p->quality, ctx->lim.max_batch));
+  if (!pl->tracker->ok() || !pl->proc->ok()) {  // an allocation failed: report it here, not as a kernel fault later
+    delete pl;
+    return SVO_ERR_HIP;
+  }
   *out = pl;
   return SVO_OK;
 }
 
 extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
   if (!p) return;
-  if (getenv("SVO_TIMING")) {
-    for (int i = 0; i < 8; ++i)
-      if (svo::PhaseTimer::acc[i] > 0) fprintf(stderr, "[svo timing] %-28s %10.3f ms\n", svo::PhaseTimer::name(i), svo::PhaseTimer::acc[i]);
+  if (svo::PhaseTimer::enabled()) {
+    for (int i = 0; i < 8; ++i) {
+      const uint64_t ns = svo::PhaseTimer::acc_ns[i].load(std::memory_order_relaxed);
+      if (ns) fprintf(stderr, "[svo timing] %-28s %10.3f ms\n", svo::PhaseTimer::name(i), 1e-6 * (double)ns);
+    }
   }
   if (p->d_imgs) (void)hipFree(p->d_imgs);
   delete p;

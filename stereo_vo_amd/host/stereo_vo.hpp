@@ -91,6 +91,7 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   svo_ba* handle() { return ba_; }
   void reset();
  private:
+  void run_bundle_adjust();
   svo_ctx* ctx_;
   svo_ba* ba_ = nullptr;
   size_t window_size_;
@@ -117,6 +118,21 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   // inputs of draw_track (src/feature_tracker.cpp:74-83): per feature its keyframe position and its current position;
   // svo_draw_track rasterises them over the keyframe image (draw_track / get_drawing of the reference)
   void get_track_arrows(std::vector<Point2f>& initial, std::vector<Point2f>& current);
+  // draw_track as the reference calls it from ImageProcessor::process (src/image_processor.cpp:146): when enabled,
+  // snapshots the arrows of the current feature set (host data only; the adapter rasterises them over the keyframe
+  // image it keeps).  Disabled by default: the C-ABI pipeline draws on demand (svo_pipeline_draw_track).
+  void enable_drawing(bool on) { drawing_ = on; }
+  void draw_track();
+  unsigned drawing_serial() const { return draw_serial_; }   // bumped by every draw_track() snapshot
+  const std::vector<Point2f>& drawn_initial() const { return drawn_initial_; }
+  const std::vector<Point2f>& drawn_current() const { return drawn_current_; }
+  // Host-image forms of init / track_features (what the reference's cv::Mat overloads bind to): upload the mono8 image
+  // (row stride in bytes), build its pyramid on the device, then run the device-resident method.
+  int init_host(const uint8_t* image, int width, int height, int stride, const std::vector<Point2f>& features,
+                const std::vector<size_t>& ids);
+  int track_features_host(float& av_parallax, float& percent_lost, const uint8_t* image, int width, int height, int stride,
+                          bool flow_back);
+  bool ok() const { return alloc_ok_; }
   // device views of the current feature set (for the in-library pipeline)
   const float* device_features() const { return d_xy_[cur_]; }
   const long long* device_ids() const { return d_ids_[cur_]; }
@@ -128,7 +144,16 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   void retain();
  private:
   void remember(const uint8_t* pyramid, int width, int height);
+  int upload_pyramid(const uint8_t* image, int width, int height, int stride);
   svo_ctx* ctx_;
+  bool alloc_ok_ = false;
+  uint8_t* d_host_img_ = nullptr;   // staging of the host-image entry points: image | its pyramid (allocated on first use)
+  uint8_t* d_host_pyr_ = nullptr;
+  std::vector<long long> init_ids_;  // host copy of the keyframe feature set (initial_features, src/feature_tracker.hpp:49)
+  std::vector<Point2f> init_xy_;
+  bool drawing_ = false;
+  unsigned draw_serial_ = 0;
+  std::vector<Point2f> drawn_initial_, drawn_current_;
   int cap_;
   size_t pyr_cap_;
   float* d_xy_[2] = {nullptr, nullptr};
@@ -157,6 +182,11 @@ class ImageProcessor {  // src/image_processor.hpp:31-46
   // consecutive frames resident in HBM.  process() on those frames then only runs the sequential chain.
   int prepare_batch(const uint8_t* left, int batch, int width, int height);
   void process(const StereoPair& stereo_pair);
+  // Host-image form (what the reference's StereoPair of cv::Mat binds to): uploads both mono8 images (row strides in
+  // bytes) into HBM staging owned by this object, then process().  Returns an svo_status.
+  int process_host(const uint8_t* left, int left_stride, const uint8_t* right, int right_stride, int width, int height,
+                   double t);
+  bool ok() const { return alloc_ok_; }
   // per-frame diagnostics of the last process() call
   struct Stats { int n_detected = 0, n_tracked = 0, n_inliers = 0, n_new = 0, is_keyframe = 0; float av_parallax = 0, percent_lost = 0; };
   const Stats& stats() const { return stats_; }
@@ -166,6 +196,8 @@ class ImageProcessor {  // src/image_processor.hpp:31-46
                           const float* d_features, const int* d_n, int n_max, const DeviceImage& left,
                           const DeviceImage& right, const float camera_pose[16]);
   svo_ctx* ctx_;
+  bool alloc_ok_ = false;
+  uint8_t* d_stage_ = nullptr; size_t stage_bytes_ = 0;  // process_host: left | right
   float K_[9];
   std::shared_ptr<FeatureTracker> feature_tracker;
   std::shared_ptr<BundleAdjuster> bundle_adjuster;
@@ -180,7 +212,7 @@ class ImageProcessor {  // src/image_processor.hpp:31-46
   float *d_xyz_ = nullptr, *d_trk_xy_ = nullptr, *d_new_xy_ = nullptr, *d_disp_ = nullptr, *d_kxy_ = nullptr, *d_kxyz_ = nullptr;
   long long* d_trk_ids_ = nullptr; int *d_inl_ = nullptr, *d_cnt_ = nullptr;
   // pinned host arena (read / written in place by the kernels)
-  uint8_t* h_arena_ = nullptr; float* h_xyz_ = nullptr; int* h_inl_ = nullptr; int* h_tri_cnt_ = nullptr;
+  uint8_t* h_arena_ = nullptr; float* h_xyz_ = nullptr; int* h_inl_ = nullptr; int* h_tri_cnt_ = nullptr; int* h_batch_cnt_ = nullptr;
   float *h_tri_xy_ = nullptr, *h_tri_xyz_ = nullptr;
   Stats stats_;
 };
