@@ -72,9 +72,24 @@ int svo_sync(svo_ctx* ctx);
 /* library build tag; "gfx950" must appear in it. */
 const char* svo_version(void);
 
+/* The reference's first-party literals as compiled into the kernels and the host chain (csrc/ref_constants.h), for
+ * audit: tests check them against values extracted from the reference's source text (tests/golden/constants_golden.json).
+ * All doubles; names follow that fixture.  Reference lines: src/image_processor.cpp:22,23,63,80,174,176,194,
+ * src/feature_tracker.cpp:24-26,47,53,81, src/vo_node.cpp:33-36, src/bundle_adjuster.hpp:75, src/bundle_adjuster.cpp:11-12. */
+typedef struct svo_reference_constants_t {
+  double gftt_max_corners, gftt_quality, min_detected, keyframe_percent_lost;
+  double pnp_iterations, pnp_reproj_error, pnp_confidence;
+  double stereo_num_disparities, stereo_block_size, stereo_disparity_scale, triangulate_min_disparity_exclusive;
+  double lk_win_w, lk_win_h, lk_max_level, lk_max_iterations, lk_epsilon, lk_min_eig_threshold;
+  double fb_max_distance, max_parallax, draw_thickness;
+  double parallax_thresh, min_feature_distance, sliding_window_size, max_features;
+  double ba_max_solver_time_s, ba_num_threads;
+} svo_reference_constants_t;
+int svo_reference_constants(svo_reference_constants_t* out);
+
 /* Measurement aid (not a reference interface): time every launch of ONE named kernel with HIP events
  * recorded on the context stream.  kernel: "corner_response", "corner_nms", "corner_select", "pyr_down",
- * "lk_fb", "stereo_at", "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub";
+ * "lk_fb", "stereo_at", "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub", "ba_step";
  * NULL/"" disables.  svo_profile_read synchronises the stream and returns the summed duration and the
  * launch count since the last svo_profile_select. */
 int svo_profile_select(svo_ctx* ctx, const char* kernel);
@@ -202,9 +217,58 @@ typedef struct svo_ba_summary {
   double solve_ms;
 } svo_ba_summary;
 
+/* Sums `n_doubles` doubles at DEVICE pointer `dev_ptr` in place over all ranks (in-process emulation of the collective
+ * for tests; production ranks hand over an RCCL communicator with svo_ba_set_comm instead). */
 typedef int (*svo_allreduce_fn)(void* dev_ptr, size_t n_doubles, void* user);
 
+/* ---- step control of ceres::Solve (src/bundle_adjuster.cpp:140) with pluggable passes ------------------------------
+ * The LM loop itself (host/lm.cpp) is one piece of host code shared by every backend and every rank.  A backend
+ * provides the two passes over the observations; payloads are host arrays ALREADY SUMMED over all ranks:
+ *   payload1 (n*n + 3n + 2 doubles, n = 6 (K-1)): [S (n x n, full) | g_red | g_c | diag U | cost | sum g_p^2]
+ *   payload2 (4 doubles): [candidate cost | landmark part of the model change | sum dp^2 | sum p^2]
+ * linearize: pass A at the current point with `radius`; `first` != 0 fixes the landmarks' Jacobi scales.
+ * step:      pass B at the current point: pose step dc (n) and candidate poses (7K) in, candidate landmarks formed,
+ *            payload2 out.  The backend may also produce the NEXT iteration's payload1 in the same call, so that an LM
+ *            iteration costs one host round trip (see host/lm.cpp):
+ *              ctl->spec_radius > 0: pass A at the candidate with that radius in the same sweep; both payloads are
+ *                summed by ONE collective;
+ *              else ctl->chain != 0: once payload2 is summed, take Ceres' accept / radius decision where the sums live
+ *                (svo_lm_decide, host/lm_decide.h, from ctl->cost, ctl->mcc, radius, ctl->decrease_factor) and run pass
+ *                A for it: at the candidate with the new radius if accepted, at the current point with the reduced
+ *                radius if not.
+ *            *next_radius = the radius that pass A ran with (0: none was produced), *next_at_candidate = where.
+ *            The step control re-derives the decision itself and uses payload1_next only if both agree.
+ * accept:    the candidate becomes the current point.
+ * Callbacks return 0 or an svo_status. */
+typedef struct svo_lm_step_ctl {
+  double cost, mcc, decrease_factor;
+  double spec_radius;
+  int chain;
+} svo_lm_step_ctl;
+typedef struct svo_lm_ops {
+  void* user;
+  int (*linearize)(void* user, double radius, int first, double* payload1);
+  int (*step)(void* user, const double* dc, const double* cand_poses7, double radius, const svo_lm_step_ctl* ctl,
+              double* payload2, double* payload1_next, double* next_radius, int* next_at_candidate);
+  int (*accept)(void* user);
+} svo_lm_ops;
+typedef struct svo_lm_stats {
+  int linearize_calls;   /* stand-alone pass-A calls (each one exchange) */
+  int step_calls;        /* pass-B calls (each one exchange) */
+  int speculations;      /* steps that also produced a linearisation for the next iteration (same sweep or chained) */
+  int speculation_hits;  /* ... that the step control could use: the iteration cost exactly one host round trip */
+  int single_exchange;   /* steps whose pass A rode in the SAME collective as payload2 (saturated-radius prediction) */
+} svo_lm_stats;
+
 void svo_ba_default_options(svo_ba_options* o);
+/* The LM loop over caller-provided passes.  poses7: K x 7 current poses, updated in place on every accepted step
+ * (pose 0 is constant, src/bundle_adjuster.cpp:130).  opt NULL = defaults.  stats may be NULL. */
+int svo_lm_solve(int n_poses, double* poses7, const svo_lm_ops* ops, const svo_ba_options* opt,
+                 svo_ba_summary* summary, svo_lm_stats* stats);
+/* Ceres' accept / radius rule for one step (host/lm_decide.h; the kernels evaluate the same function): what a backend's
+ * `step` uses for ctl->chain when its sums live on the host. */
+int svo_lm_decide_step(double cost, double mcc, double radius, double decrease_factor, double cost_new,
+                       double model_change_points, int* accept, double* next_radius);
 int svo_ba_create(svo_ctx* ctx, svo_ba** out, int window_size, const svo_camera_info* cam,
                   const svo_ba_options* opt, int max_landmarks, int max_observations);
 void svo_ba_destroy(svo_ba* ba);
@@ -236,13 +300,25 @@ int svo_ba_get_points(svo_ba* ba, const int64_t* ids, int n, float* xyz);
 /* Bulk problem interface (synthetic BA of BASELINE config 4; also what a
  * sharded rank loads): poses K x 7 (pose 0 constant), points N x 3, observations
  * sorted by landmark: obs_pose/obs_point/obs_uv.  In a sharded run every rank
- * loads all poses and only its own landmarks; `allreduce` (may be NULL for one
- * rank) is called on a device buffer of doubles once or twice per LM iteration
- * and must sum it in place over all ranks (RCCL all-reduce). */
+ * loads all poses and only its own landmarks; the payloads are summed over the ranks by
+ * RCCL (svo_ba_set_comm) or by the `allreduce` callback (tests), once per LM iteration
+ * when the speculative linearisation hits (host/lm.cpp), twice otherwise. */
 int svo_ba_load_problem(svo_ba* ba, int n_poses, const double* poses7, int n_points,
                         const double* points3, int n_obs, const int32_t* obs_pose,
                         const int32_t* obs_point, const double* obs_uv);
 int svo_ba_set_allreduce(svo_ba* ba, svo_allreduce_fn fn, void* user);
+/* Sharded run over RCCL: `nccl_comm` is the rank's ncclComm_t (as void*).  The library calls
+ * ncclAllReduce(sum, f64, in place) on the adjuster's own stream — one call per LM iteration when the speculative
+ * linearisation hits (n*n + 3n + 2 + 8 doubles: 107 KB at K = 20), no host code in between.  NULL detaches. */
+int svo_ba_set_comm(svo_ba* ba, void* nccl_comm);
+/* RCCL communicator helpers for callers that have no other RCCL binding (C++ consumers such as the reference's
+ * vo_node; bench.py).  They use the librccl already loaded in the process, else /opt/rocm/lib/librccl.so.1.
+ * id128: 128-byte ncclUniqueId created on one rank and distributed by any out-of-band channel. */
+int svo_rccl_unique_id(void* id128);
+int svo_rccl_comm_create(void** nccl_comm, int n_ranks, int rank, const void* id128, int device);
+int svo_rccl_comm_destroy(void* nccl_comm);
+/* counters of the last svo_ba_solve / svo_ba_solve_problem */
+int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats);
 int svo_ba_solve_problem(svo_ba* ba, svo_ba_summary* summary);
 int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3);
 

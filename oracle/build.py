@@ -11,7 +11,7 @@ LIB = os.path.join(HERE, "_build", "libsvo_oracle.so")
 
 def build_oracle(force=False):
     srcs = sorted(glob.glob(os.path.join(HERE, "*.cpp")))
-    deps = srcs + [os.path.join(HERE, "svo_oracle.h")]
+    deps = srcs + [os.path.join(HERE, "svo_oracle.h"), os.path.join(HERE, "ora_constants.h")]
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     stale = not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps)
     if force or stale:

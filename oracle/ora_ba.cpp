@@ -9,6 +9,8 @@
 // Stated differences: (1) the model cost change is evaluated in its algebraically equal closed form
 // 1/2 y^T (D^2 y - g'); (2) the gradient test uses the 2-norm (an upper bound of Ceres' max-norm) so
 // that every quantity a sharded run decides on is a sum; (3) no wall-clock limit (SURVEY C-10).
+// (Round 1 also took the candidate step when the function tolerance fired; Ceres' FunctionToleranceReached()
+// returns before the step is accepted, and so does this restatement now.)
 //
 // Declared summation order (what makes the HIP solver bit-identical to this one, and this one independent
 // of its thread count): every sum over observations of ONE landmark runs sequentially in observation
@@ -165,201 +167,267 @@ void reduce_list(int count, int width, Get get, double* out) {
 }
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Stateful form: one object holds the problem, the current point (poses, points), the candidate and the Jacobi scales.
+// ora_ba_solve below drives it with the plain (non-speculative) LM loop; tests also drive it through the PRODUCT's
+// step control (svo_lm_solve in libsvo_hip.so) to check that host logic without a GPU.
+struct ora_ba_state {
+  Problem P;
+  std::vector<double> poses, points;            // current point (owned copies)
+  std::vector<double> cand_poses, cand_points;  // candidate
+  std::vector<int> pair_base;
+  std::vector<std::vector<int>> blk_list, pose_list;
+  std::vector<double> pairB, obsV, lmV, sp;
+  int L = 0, F = 0, num_threads = 1;
+  bool have_scale = false;
+  size_t pay1 = 0;
+};
+
+extern "C" ora_ba_state* ora_ba_open(int n_poses, const double* poses7, int n_points, const double* points3, int n_obs,
+                                     const int32_t* obs_pose, const int32_t* obs_point, const double* obs_uv,
+                                     double focal, double cx, double cy, int num_threads) {
+  ora_ba_state* S = new ora_ba_state();
+  S->poses.assign(poses7, poses7 + 7 * (size_t)n_poses);
+  S->points.assign(points3, points3 + 3 * (size_t)n_points);
+  S->cand_poses = S->poses;
+  S->cand_points = S->points;
+  Problem& P = S->P;
+  P = Problem{n_poses, n_points, n_obs, 6 * (n_poses - 1), S->poses.data(), S->points.data(), obs_pose, obs_point, obs_uv, focal, cx, cy, {}, {}};
+  for (int o = 0; o < n_obs; ++o)
+    if (o == 0 || obs_point[o] != obs_point[o - 1]) { P.lm_start.push_back(o); P.lm_id.push_back(obs_point[o]); }
+  P.lm_start.push_back(n_obs);
+  S->L = (int)P.lm_id.size();
+  S->F = n_poses - 1;
+  S->num_threads = num_threads < 1 ? 1 : num_threads;
+  const int L = S->L, F = S->F, n = P.n;
+  S->pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  // contribution slots and destination lists (landmark order)
+  S->pair_base.assign((size_t)n_obs + 1, 0);
+  for (int l = 0; l < L; ++l)
+    for (int o = P.lm_start[l]; o < P.lm_start[l + 1]; ++o) S->pair_base[o + 1] = S->pair_base[o] + (P.lm_start[l + 1] - o);
+  S->blk_list.assign((size_t)F * F, {});
+  S->pose_list.assign(F, {});
+  for (int l = 0; l < L; ++l)
+    for (int i = P.lm_start[l]; i < P.lm_start[l + 1]; ++i) {
+      const int ki = obs_pose[i] - 1;
+      if (ki < 0) continue;
+      S->pose_list[ki].push_back(i);
+      for (int t = i; t < P.lm_start[l + 1]; ++t) {
+        const int kt = obs_pose[t] - 1;
+        if (kt < 0) continue;
+        const int slot = S->pair_base[i] + (t - i);
+        S->blk_list[(size_t)ki * F + kt].push_back(slot * 2);  // entry = slot*2 + transposed
+        if (t != i) S->blk_list[(size_t)kt * F + ki].push_back(slot * 2 + 1);
+      }
+    }
+  S->pairB.assign((size_t)S->pair_base[n_obs] * 36, 0.0);
+  S->obsV.assign((size_t)n_obs * 18, 0.0);
+  S->lmV.assign((size_t)L * 4, 0.0);
+  S->sp.assign((size_t)L * 3, 0.0);
+  return S;
+}
+
+extern "C" void ora_ba_close(ora_ba_state* S) { delete S; }
+extern "C" size_t ora_ba_payload1_len(const ora_ba_state* S) { return S->pay1; }
+
+extern "C" void ora_ba_read(const ora_ba_state* S, double* poses7, double* points3) {
+  if (poses7) std::memcpy(poses7, S->poses.data(), sizeof(double) * S->poses.size());
+  if (points3) std::memcpy(points3, S->points.data(), sizeof(double) * S->points.size());
+}
+
+// pass A: linearise at the current point (at_candidate = 0) or at the candidate (1), fill the slots, reduce into
+// this rank's payload1 for `rad`.  `first` fixes the Jacobi scales of the landmarks from this Jacobian.
+extern "C" void ora_ba_linearize(ora_ba_state* S, int at_candidate, double rad, int first, double* pay) {
+  const Problem& P = S->P;
+  const double* poses = at_candidate ? S->cand_poses.data() : S->poses.data();
+  const double* points = at_candidate ? S->cand_points.data() : S->points.data();
+  const int L = S->L, F = S->F, n = P.n, num_threads = S->num_threads;
+  const double min_diag = 1e-6, max_diag = 1e32;
+  std::vector<double>&pairB = S->pairB, &obsV = S->obsV, &lmV = S->lmV, &sp = S->sp;
+  const std::vector<int>& pair_base = S->pair_base;
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (int l = 0; l < L; ++l) {
+    const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1], len = o1 - o0;
+    std::vector<double> R((size_t)len * 2), JC((size_t)len * 12, 0.0), JP((size_t)len * 6), WS((size_t)len * 18), YY((size_t)len * 18);
+    double V[9] = {0}, gp[3] = {0}, cost_l = 0.0;
+    for (int o = o0; o < o1; ++o) {
+      double* r = &R[2 * (o - o0)];
+      double* Jc = &JC[12 * (o - o0)];
+      double* Jp = &JP[6 * (o - o0)];
+      eval_obs(P, poses, points, o, r, P.op[o] > 0 ? Jc : nullptr, Jp);
+      cost_l += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+      for (int a = 0; a < 3; ++a) {
+        gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+        for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+      }
+    }
+    double* s = &sp[(size_t)l * 3];
+    if (first) for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + std::sqrt(V[4 * a]));
+    double Vd[9], gps[3], Vi[9] = {0};
+    for (int a = 0; a < 3; ++a) {
+      gps[a] = gp[a] * s[a];
+      for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+    }
+    for (int a = 0; a < 3; ++a) Vd[4 * a] += std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad;
+    inv3_sym(Vd, Vi);
+    lmV[4 * (size_t)l] = cost_l;
+    lmV[4 * (size_t)l + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+    for (int o = o0; o < o1; ++o) {
+      if (P.op[o] <= 0) continue;
+      const double* r = &R[2 * (o - o0)];
+      const double* Jc = &JC[12 * (o - o0)];
+      const double* Jp = &JP[6 * (o - o0)];
+      double* Ws = &WS[18 * (o - o0)];
+      double* Y = &YY[18 * (o - o0)];
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) Ws[3 * a + b] = (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b];
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
+      double* ov = &obsV[(size_t)o * 18];
+      for (int a = 0; a < 6; ++a) {
+        ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+        ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+        ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+      }
+    }
+    for (int i = o0; i < o1; ++i) {
+      if (P.op[i] <= 0) continue;
+      const double* Y = &YY[18 * (i - o0)];
+      const double* Jc = &JC[12 * (i - o0)];
+      for (int t = i; t < o1; ++t) {
+        if (P.op[t] <= 0) continue;
+        const double* Wt = &WS[18 * (t - o0)];
+        double* B = &pairB[(size_t)(pair_base[i] + (t - i)) * 36];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 6; ++b) {
+            const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+            B[6 * a + b] = t == i ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+          }
+      }
+    }
+  }
+  if (first) S->have_scale = true;
+  std::fill(pay, pay + S->pay1, 0.0);
+  double* Sx = pay;
+  double* gred = Sx + (size_t)n * n;
+  double* gc = gred + n;
+  double* dU = gc + n;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
+  for (int d = 0; d < F * F + F + 1; ++d) {
+    if (d < F * F) {
+      const std::vector<int>& lst = S->blk_list[d];
+      double B[36];
+      reduce_list((int)lst.size(), 36, [&](int e, double* out) {
+        const double* src = &pairB[(size_t)(lst[e] >> 1) * 36];
+        if (lst[e] & 1) { for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[6 * a + b] = src[6 * b + a]; }
+        else std::memcpy(out, src, 36 * sizeof(double));
+      }, B);
+      const int ka = d / F, kb = d % F;
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) Sx[(size_t)(6 * ka + a) * n + 6 * kb + b] = B[6 * a + b];
+    } else if (d < F * F + F) {
+      const int k = d - F * F;
+      const std::vector<int>& lst = S->pose_list[k];
+      double v[18];
+      reduce_list((int)lst.size(), 18, [&](int e, double* out) { std::memcpy(out, &obsV[(size_t)lst[e] * 18], 18 * sizeof(double)); }, v);
+      for (int a = 0; a < 6; ++a) { gc[6 * k + a] = v[a]; gred[6 * k + a] = v[6 + a]; dU[6 * k + a] = v[12 + a]; }
+    } else {
+      double v[2];
+      reduce_list(L, 2, [&](int e, double* out) { out[0] = lmV[4 * (size_t)e]; out[1] = lmV[4 * (size_t)e + 1]; }, v);
+      pay[S->pay1 - 2] = v[0];
+      pay[S->pay1 - 1] = v[1];
+    }
+  }
+}
+
+// pass B: back-substitute at the current point with the pose step dc (unscaled tangent) and the candidate poses the
+// caller formed from it; builds the candidate landmarks and this rank's payload2.
+extern "C" void ora_ba_backsub(ora_ba_state* S, const double* dc, const double* cand_poses7, double rad, double* pay2) {
+  const Problem& P = S->P;
+  const int L = S->L, num_threads = S->num_threads;
+  const double min_diag = 1e-6, max_diag = 1e32;
+  std::memcpy(S->cand_poses.data(), cand_poses7, sizeof(double) * S->cand_poses.size());
+  S->cand_points = S->points;
+  std::vector<double>&lmV = S->lmV, &sp = S->sp, &cand_points = S->cand_points;
+#pragma omp parallel for schedule(static) num_threads(num_threads)
+  for (int l = 0; l < L; ++l) {
+    const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
+    double V[9] = {0}, gp[3] = {0}, wd[3] = {0};
+    for (int o = o0; o < o1; ++o) {
+      double r[2], Jc[12], Jp[6];
+      const int k = P.op[o];
+      eval_obs(P, S->poses.data(), S->points.data(), o, r, k > 0 ? Jc : nullptr, Jp);
+      double jd[2] = {0, 0};
+      if (k > 0)
+        for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * dc[6 * (k - 1) + a]; jd[1] += Jc[6 + a] * dc[6 * (k - 1) + a]; }
+      for (int a = 0; a < 3; ++a) {
+        gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+        wd[a] += Jp[a] * jd[0] + Jp[3 + a] * jd[1];
+        for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+      }
+    }
+    const double* s = &sp[(size_t)l * 3];
+    double Vd[9], De[3], rh[3], Vi[9] = {0};
+    for (int a = 0; a < 3; ++a) {
+      rh[a] = -(gp[a] + wd[a]) * s[a];
+      for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+    }
+    for (int a = 0; a < 3; ++a) { De[a] = std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad; Vd[4 * a] += De[a]; }
+    inv3_sym(Vd, Vi);
+    const double* p0 = &S->points[3 * (size_t)P.lm_id[l]];
+    double* pt = &cand_points[3 * (size_t)P.lm_id[l]];
+    double mc = 0, dp2 = 0, p2 = 0;
+    for (int a = 0; a < 3; ++a) {
+      const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
+      mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
+      const double d = y * s[a];
+      dp2 += d * d;
+      p2 += p0[a] * p0[a];
+      pt[a] = p0[a] + d;
+    }
+    double cn = 0;
+    for (int o = o0; o < o1; ++o) {
+      double r[2];
+      eval_obs(P, S->cand_poses.data(), cand_points.data(), o, r, nullptr, nullptr);
+      cn += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    }
+    lmV[4 * (size_t)l] = cn; lmV[4 * (size_t)l + 1] = mc; lmV[4 * (size_t)l + 2] = dp2; lmV[4 * (size_t)l + 3] = p2;
+  }
+  reduce_list(L, 4, [&](int e, double* out) { std::memcpy(out, &lmV[4 * (size_t)e], 4 * sizeof(double)); }, pay2);
+}
+
+// the candidate becomes the current point
+extern "C" void ora_ba_accept(ora_ba_state* S) {
+  S->poses = S->cand_poses;
+  S->points = S->cand_points;
+}
+
 extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* points3, int n_obs,
                             const int32_t* obs_pose, const int32_t* obs_point, const double* obs_uv,
                             double focal, double cx, double cy, int max_iterations,
                             double function_tol, double gradient_tol, double parameter_tol,
                             double initial_radius, int num_threads, ora_allreduce_fn allreduce,
                             void* user, double* summary5) {
-  Problem P{n_poses, n_points, n_obs, 6 * (n_poses - 1), poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, {}, {}};
-  for (int o = 0; o < n_obs; ++o) {
-    if (o == 0 || obs_point[o] != obs_point[o - 1]) { P.lm_start.push_back(o); P.lm_id.push_back(obs_point[o]); }
-  }
-  P.lm_start.push_back(n_obs);
-  const int L = (int)P.lm_id.size();
-  const int n = P.n, F = n_poses - 1;
-  const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
-  if (num_threads < 1) num_threads = 1;
-
-  // contribution slots and destination lists (landmark order)
-  std::vector<int> pair_base(n_obs + 1, 0);
-  for (int l = 0; l < L; ++l)
-    for (int o = P.lm_start[l]; o < P.lm_start[l + 1]; ++o) pair_base[o + 1] = pair_base[o] + (P.lm_start[l + 1] - o);
-  const int n_pairs = pair_base[n_obs];
-  std::vector<std::vector<int>> blk_list((size_t)F * F), pose_list(F);  // entry = slot*2 + transposed
-  for (int l = 0; l < L; ++l)
-    for (int i = P.lm_start[l]; i < P.lm_start[l + 1]; ++i) {
-      const int ki = obs_pose[i] - 1;
-      if (ki < 0) continue;
-      pose_list[ki].push_back(i);
-      for (int t = i; t < P.lm_start[l + 1]; ++t) {
-        const int kt = obs_pose[t] - 1;
-        if (kt < 0) continue;
-        const int slot = pair_base[i] + (t - i);
-        blk_list[(size_t)ki * F + kt].push_back(slot * 2);
-        if (t != i) blk_list[(size_t)kt * F + ki].push_back(slot * 2 + 1);
-      }
-    }
-  std::vector<double> pairB((size_t)n_pairs * 36), obsV((size_t)n_obs * 18), lmV((size_t)L * 4);
-
-  std::vector<double> sp((size_t)L * 3, 0.0), sc(n, 0.0);   // Jacobi scales
+  ora_ba_state* S = ora_ba_open(n_poses, poses7, n_points, points3, n_obs, obs_pose, obs_point, obs_uv, focal, cx, cy, num_threads);
+  const int n = S->P.n;
+  const size_t pay1 = S->pay1;
+  std::vector<double> sc(n, 0.0), pay(pay1), Sm((size_t)n * n), rhs(n), dc(n), cand_poses((size_t)7 * n_poses);
   bool have_scale = false;
-  std::vector<double> pay(pay1), Sm((size_t)n * n), rhs(n), dc(n);
-  std::vector<double> cand_poses((size_t)7 * n_poses), cand_points((size_t)3 * n_points);
   double radius = initial_radius, decrease_factor = 2.0;
   const double min_diag = 1e-6, max_diag = 1e32, max_radius = 1e16, min_radius = 1e-32;
   const double min_rel_decrease = 1e-3;
-
-  // pass A: linearise at (poses, points), fill the slots, reduce into payload1 for the current radius.
+  double pay2[4];
   auto linearize = [&](double rad) {
-#pragma omp parallel for schedule(static) num_threads(num_threads)
-    for (int l = 0; l < L; ++l) {
-      const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1], len = o1 - o0;
-      std::vector<double> R((size_t)len * 2), JC((size_t)len * 12, 0.0), JP((size_t)len * 6), WS((size_t)len * 18), YY((size_t)len * 18);
-      double V[9] = {0}, gp[3] = {0}, cost_l = 0.0;
-      for (int o = o0; o < o1; ++o) {
-        double* r = &R[2 * (o - o0)];
-        double* Jc = &JC[12 * (o - o0)];
-        double* Jp = &JP[6 * (o - o0)];
-        eval_obs(P, P.poses, P.points, o, r, P.op[o] > 0 ? Jc : nullptr, Jp);
-        cost_l += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-        for (int a = 0; a < 3; ++a) {
-          gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
-          for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
-        }
-      }
-      double* s = &sp[(size_t)l * 3];
-      if (!have_scale) for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + std::sqrt(V[4 * a]));
-      double Vd[9], gps[3], Vi[9] = {0};
-      for (int a = 0; a < 3; ++a) {
-        gps[a] = gp[a] * s[a];
-        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
-      }
-      for (int a = 0; a < 3; ++a) Vd[4 * a] += std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad;
-      inv3_sym(Vd, Vi);
-      lmV[4 * (size_t)l] = cost_l;
-      lmV[4 * (size_t)l + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
-      for (int o = o0; o < o1; ++o) {
-        if (P.op[o] <= 0) continue;
-        const double* r = &R[2 * (o - o0)];
-        const double* Jc = &JC[12 * (o - o0)];
-        const double* Jp = &JP[6 * (o - o0)];
-        double* Ws = &WS[18 * (o - o0)];
-        double* Y = &YY[18 * (o - o0)];
-        for (int a = 0; a < 6; ++a)
-          for (int b = 0; b < 3; ++b) Ws[3 * a + b] = (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b];
-        for (int a = 0; a < 6; ++a)
-          for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
-        double* ov = &obsV[(size_t)o * 18];
-        for (int a = 0; a < 6; ++a) {
-          ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
-          ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
-          ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
-        }
-      }
-      for (int i = o0; i < o1; ++i) {
-        if (P.op[i] <= 0) continue;
-        const double* Y = &YY[18 * (i - o0)];
-        const double* Jc = &JC[12 * (i - o0)];
-        for (int t = i; t < o1; ++t) {
-          if (P.op[t] <= 0) continue;
-          const double* Wt = &WS[18 * (t - o0)];
-          double* B = &pairB[(size_t)(pair_base[i] + (t - i)) * 36];
-          for (int a = 0; a < 6; ++a)
-            for (int b = 0; b < 6; ++b) {
-              const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-              B[6 * a + b] = t == i ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-            }
-        }
-      }
-    }
-    std::fill(pay.begin(), pay.end(), 0.0);
-    double* S = pay.data();
-    double* gred = S + (size_t)n * n;
-    double* gc = gred + n;
-    double* dU = gc + n;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(num_threads)
-    for (int d = 0; d < F * F + F + 1; ++d) {
-      if (d < F * F) {
-        const std::vector<int>& lst = blk_list[d];
-        double B[36];
-        reduce_list((int)lst.size(), 36, [&](int e, double* out) {
-          const double* src = &pairB[(size_t)(lst[e] >> 1) * 36];
-          if (lst[e] & 1) { for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[6 * a + b] = src[6 * b + a]; }
-          else std::memcpy(out, src, 36 * sizeof(double));
-        }, B);
-        const int ka = d / F, kb = d % F;
-        for (int a = 0; a < 6; ++a)
-          for (int b = 0; b < 6; ++b) S[(size_t)(6 * ka + a) * n + 6 * kb + b] = B[6 * a + b];
-      } else if (d < F * F + F) {
-        const int k = d - F * F;
-        const std::vector<int>& lst = pose_list[k];
-        double v[18];
-        reduce_list((int)lst.size(), 18, [&](int e, double* out) { std::memcpy(out, &obsV[(size_t)lst[e] * 18], 18 * sizeof(double)); }, v);
-        for (int a = 0; a < 6; ++a) { gc[6 * k + a] = v[a]; gred[6 * k + a] = v[6 + a]; dU[6 * k + a] = v[12 + a]; }
-      } else {
-        double v[2];
-        reduce_list(L, 2, [&](int e, double* out) { out[0] = lmV[4 * (size_t)e]; out[1] = lmV[4 * (size_t)e + 1]; }, v);
-        pay[pay1 - 2] = v[0];
-        pay[pay1 - 1] = v[1];
-      }
-    }
+    ora_ba_linearize(S, 0, rad, have_scale ? 0 : 1, pay.data());
     if (allreduce) allreduce(pay.data(), pay1, user);
   };
-
-  // pass B: back-substitute with the pose step dc (unscaled tangent), build candidate, payload2.
-  double pay2[4];
   auto backsub = [&](double rad) {
     for (int k = 0; k < n_poses; ++k) {
-      if (k == 0) std::memcpy(&cand_poses[0], P.poses, 7 * sizeof(double));
-      else plus_pose(P.poses + 7 * k, &dc[6 * (k - 1)], &cand_poses[7 * k]);
+      if (k == 0) std::memcpy(&cand_poses[0], S->poses.data(), 7 * sizeof(double));
+      else plus_pose(S->poses.data() + 7 * k, &dc[6 * (k - 1)], &cand_poses[7 * k]);
     }
-    std::memcpy(cand_points.data(), P.points, sizeof(double) * 3 * n_points);
-#pragma omp parallel for schedule(static) num_threads(num_threads)
-    for (int l = 0; l < L; ++l) {
-      const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
-      double V[9] = {0}, gp[3] = {0}, wd[3] = {0};
-      for (int o = o0; o < o1; ++o) {
-        double r[2], Jc[12], Jp[6];
-        const int k = P.op[o];
-        eval_obs(P, P.poses, P.points, o, r, k > 0 ? Jc : nullptr, Jp);
-        double jd[2] = {0, 0};
-        if (k > 0)
-          for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * dc[6 * (k - 1) + a]; jd[1] += Jc[6 + a] * dc[6 * (k - 1) + a]; }
-        for (int a = 0; a < 3; ++a) {
-          gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
-          wd[a] += Jp[a] * jd[0] + Jp[3 + a] * jd[1];
-          for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
-        }
-      }
-      const double* s = &sp[(size_t)l * 3];
-      double Vd[9], De[3], rh[3], Vi[9] = {0};
-      for (int a = 0; a < 3; ++a) {
-        rh[a] = -(gp[a] + wd[a]) * s[a];
-        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
-      }
-      for (int a = 0; a < 3; ++a) { De[a] = std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad; Vd[4 * a] += De[a]; }
-      inv3_sym(Vd, Vi);
-      const double* p0 = &P.points[3 * (size_t)P.lm_id[l]];
-      double* pt = &cand_points[3 * (size_t)P.lm_id[l]];
-      double mc = 0, dp2 = 0, p2 = 0;
-      for (int a = 0; a < 3; ++a) {
-        const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
-        mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
-        const double d = y * s[a];
-        dp2 += d * d;
-        p2 += p0[a] * p0[a];
-        pt[a] = p0[a] + d;
-      }
-      double cn = 0;
-      for (int o = o0; o < o1; ++o) {
-        double r[2];
-        eval_obs(P, cand_poses.data(), cand_points.data(), o, r, nullptr, nullptr);
-        cn += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-      }
-      lmV[4 * (size_t)l] = cn; lmV[4 * (size_t)l + 1] = mc; lmV[4 * (size_t)l + 2] = dp2; lmV[4 * (size_t)l + 3] = p2;
-    }
-    reduce_list(L, 4, [&](int e, double* out) { std::memcpy(out, &lmV[4 * (size_t)e], 4 * sizeof(double)); }, pay2);
+    ora_ba_backsub(S, dc.data(), cand_poses.data(), rad, pay2);
     if (allreduce) allreduce(pay2, 4, user);
   };
 
@@ -382,14 +450,14 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
     if (radius <= min_radius) { termination = 0; break; }
     ++iterations;
     if (need_linearize) { linearize(radius); need_linearize = false; }
-    const double* S = pay.data();
-    const double* gred = S + (size_t)n * n;
+    const double* Sx = pay.data();
+    const double* gred = Sx + (size_t)n * n;
     const double* gc = gred + n;
     const double* dU = gc + n;
     std::vector<double> Df(n);
     for (int a = 0; a < n; ++a) {
       Df[a] = std::min(std::max(dU[a] * sc[a] * sc[a], min_diag), max_diag) / radius;
-      for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = S[(size_t)a * n + b] * sc[a] * sc[b];
+      for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = Sx[(size_t)a * n + b] * sc[a] * sc[b];
       Sm[(size_t)a * n + a] += Df[a];
       rhs[a] = -(gred[a] + gc[a]) * sc[a];
     }
@@ -408,9 +476,9 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
       step2 = pay2[2]; x2 = pay2[3];
       for (int k = 1; k < n_poses; ++k)
         for (int a = 0; a < 7; ++a) {
-          const double d = cand_poses[7 * k + a] - P.poses[7 * k + a];
+          const double d = cand_poses[7 * k + a] - S->poses[7 * k + a];
           step2 += d * d;
-          x2 += P.poses[7 * k + a] * P.poses[7 * k + a];
+          x2 += S->poses[7 * k + a] * S->poses[7 * k + a];
         }
       step_ok = model_change > 0;
     }
@@ -420,21 +488,15 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
     }
     if (std::sqrt(step2) <= parameter_tol * (std::sqrt(x2) + parameter_tol)) { termination = 0; break; }
     const double cost_change = cost - cost_new;
-    if (std::fabs(cost_change) <= function_tol * cost) {
-      if (cost_change > 0) {  // Ceres stops here without taking the step; keep the better point
-        std::memcpy(P.poses, cand_poses.data(), sizeof(double) * 7 * n_poses);
-        std::memcpy(P.points, cand_points.data(), sizeof(double) * 3 * n_points);
-        cost = cost_new;
-      }
-      termination = 0;
+    if (std::fabs(cost_change) <= function_tol * cost) {  // Ceres: FunctionToleranceReached() returns BEFORE the step is
+      termination = 0;                                    // tested / taken: the candidate is discarded, x stays
       break;
     }
     const double rho = cost_change / model_change;
     if (std::getenv("SVO_BA_TRACE"))
       std::fprintf(stderr, "[ora] it %d cost %.17g new %.17g model %.17g rho %.6g radius %.6g\n", iterations, cost, cost_new, model_change, rho, radius);
     if (rho > min_rel_decrease) {
-      std::memcpy(P.poses, cand_poses.data(), sizeof(double) * 7 * n_poses);
-      std::memcpy(P.points, cand_points.data(), sizeof(double) * 3 * n_points);
+      ora_ba_accept(S);
       cost = cost_new;
       ++successful;
       const double t = 2.0 * rho - 1.0;
@@ -451,6 +513,8 @@ extern "C" int ora_ba_solve(int n_poses, double* poses7, int n_points, double* p
     }
   }
 done:
+  ora_ba_read(S, poses7, points3);
+  ora_ba_close(S);
   summary5[0] = iterations; summary5[1] = successful; summary5[2] = termination;
   summary5[3] = initial_cost; summary5[4] = cost;
   return 0;

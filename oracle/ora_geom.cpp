@@ -2,6 +2,7 @@
 // These follow reference source directly (no third-party algorithm involved).
 #include <cmath>
 
+#include "ora_constants.h"
 #include "svo_oracle.h"
 
 // ImageProcessor::triangulate_stereo, src/image_processor.cpp:178-207.
@@ -29,7 +30,7 @@ extern "C" int ora_triangulate(const float* xy, const float* disp, int n, const 
   int m = 0;
   for (int i = 0; i < n; ++i) {
     const float d = disp[i];
-    if (!(d > 0.0f)) continue;
+    if (!(d > ora_k::kTriangulateMinDisparity)) continue;
     const float v[4] = {xy[2 * i], xy[2 * i + 1], d, 1.0f};
     float wv[4];
     for (int r = 0; r < 4; ++r) {

@@ -19,11 +19,13 @@
 #include <cstring>
 #include <vector>
 
+#include "ora_constants.h"
 #include "svo_oracle.h"
 
 namespace {
-const int kWin = 21, kHalf = 10, kLevels = 4, kMaxIter = 30;
-const float kMinEigThreshold = 1e-2f;
+const int kWin = ora_k::kLkWin, kHalf = kWin / 2, kLevels = ora_k::kLkMaxLevel + 1, kMaxIter = ora_k::kLkMaxIterations;
+const float kMinEigThreshold = ora_k::kLkMinEigThreshold;
+const double kEps = ora_k::kLkEpsilon;
 const float kFltScale = 1.0f / (float)(1 << 20);
 const float kFltEpsilon = 1.1920928955078125e-7f;
 
@@ -175,8 +177,8 @@ uint8_t lk_point(const Pyramid& A, const Pyramid& B, float px0, float py0, float
       const float dy = (A12 * b1 - A11 * b2) * D;
       nx += dx; ny += dy;
       outx = nx + (float)kHalf; outy = ny + (float)kHalf;
-      if ((double)dx * (double)dx + (double)dy * (double)dy <= 0.01 * 0.01) break;
-      if (j > 0 && std::fabs(dx + pdx) < 0.01 && std::fabs(dy + pdy) < 0.01) {
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= kEps * kEps) break;
+      if (j > 0 && std::fabs(dx + pdx) < kEps && std::fabs(dy + pdy) < kEps) {
         outx -= dx * 0.5f; outy -= dy * 0.5f;
         break;
       }
@@ -249,11 +251,11 @@ extern "C" int ora_track_features(const uint8_t* prev, const uint8_t* next, int 
   for (int i = 0; i < n; ++i) {
     if (!s1[i] || !s2[i]) continue;
     const float ex = xy[2 * i] - back[2 * i], ey = xy[2 * i + 1] - back[2 * i + 1];
-    if (!((double)ex * (double)ex + (double)ey * (double)ey < 4.0)) continue;
+    if (!((double)ex * (double)ex + (double)ey * (double)ey < ora_k::kFbMaxDistance * ora_k::kFbMaxDistance)) continue;
     const float dx = fwd[2 * i] - initial_xy[2 * i];
     const float dy = fwd[2 * i + 1] - initial_xy[2 * i + 1];
     const float parallax = std::sqrt(dx * dx + dy * dy);
-    if (parallax > 200.f) continue;
+    if (parallax > ora_k::kMaxParallax) continue;
     kept_xy[2 * m] = fwd[2 * i];
     kept_xy[2 * m + 1] = fwd[2 * i + 1];
     kept_index[m] = i;

@@ -4,6 +4,15 @@
 // (src/vo_node.cpp:141-148) — whole-pipeline CPU restatement built on the ora_* stages.
 // TEST INFRASTRUCTURE ONLY.  Control flow, constants, id assignment and pose conventions follow
 // first-party reference source; the stages it calls carry the pin status stated in svo_oracle.h.
+// Stated differences from the reference as it would run under OpenCV 3.x (the HIP path makes the same choices):
+//  (1) rvec / tvec are stored as float between frames, the type they are created with (:54-55).  OpenCV's
+//      solvePnPRansac re-creates its outputs as CV_64F, after which `tmp.copyTo(hmat(cv::Rect(..)))`
+//      (:131-134) has mismatched types and re-allocates the temporary ROI header instead of writing into the CV_32F
+//      hmat, i.e. camera_pose would stay the identity from the second keyframe on (a latent bug).  The restatement
+//      implements the evident intent: hmat = [R^T | -R^T t] from the float rvec / tvec.
+//  (2) zero tracked features: av_parallax = 0 instead of the reference's 0/0 = NaN (:59,63); the keyframe gate then
+//      fires through percent_lost = 1 either way.
+//  (3) SURVEY C-1, C-3, C-4, C-5, C-7, C-9, C-12, C-13 as listed there (replicate / guard decisions).
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -12,6 +21,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "ora_constants.h"
 #include "svo_oracle.h"
 
 namespace {
@@ -174,7 +184,7 @@ struct ora_pipeline {
                    const float* pose16, std::vector<float>& out2d, std::vector<float>& out3d) {
     const int n = (int)feats.size() / 2;
     std::vector<float> disp(n), k2(2 * (size_t)n), k3(3 * (size_t)n);
-    ora_stereo_disparity_at(L, R, prm.width, prm.height, prm.width, 48, 21, feats.data(), n, disp.data());
+    ora_stereo_disparity_at(L, R, prm.width, prm.height, prm.width, ora_k::kStereoNumDisparities, ora_k::kStereoBlockSize, feats.data(), n, disp.data());
     const int m = ora_triangulate(feats.data(), disp.data(), n, pose16, (float)prm.focal, (float)prm.cx,
                                   (float)prm.cy, (float)prm.baseline, k2.data(), k3.data(), nullptr);
     out2d.assign(k2.begin(), k2.begin() + 2 * m);
@@ -189,7 +199,7 @@ struct ora_pipeline {
                                      prm.min_feature_distance, det.data(), nullptr);  // :22
     det.resize(2 * (size_t)nd);
     res->n_detected = nd;
-    if (nd < 4) return;  // :23-25
+    if (nd < ora_k::kMinDetected) return;  // :23-25
     if (!last_keyframe) {  // :30-58
       const float eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
       auto kf = std::make_shared<Keyframe>();
@@ -223,7 +233,7 @@ struct ora_pipeline {
     res->n_tracked = m;
     res->av_parallax = av;
     res->percent_lost = percent_lost;
-    if (av <= prm.parallax_thresh && (double)percent_lost < 0.4) return;  // :63-65
+    if (av <= prm.parallax_thresh && (double)percent_lost < ora_k::kKeyframePercentLost) return;  // :63-65
     // PnP :67-92
     std::vector<float> wp(3 * (size_t)m);
     for (int i = 0; i < m; ++i)
@@ -231,7 +241,7 @@ struct ora_pipeline {
     std::vector<int> inl(m > 0 ? m : 1);
     double rv[3] = {rvec[0], rvec[1], rvec[2]}, tv[3] = {tvec[0], tvec[1], tvec[2]};
     const int ni = ora_pnp_ransac(wp.data(), feature_set.data(), m, (float)prm.focal, (float)prm.cx,
-                                  (float)prm.cy, rv, tv, 100, 8.0f, 0.99, inl.data());
+                                  (float)prm.cy, rv, tv, ora_k::kPnpIterations, ora_k::kPnpReprojError, ora_k::kPnpConfidence, inl.data());
     for (int i = 0; i < 3; ++i) { rvec[i] = (float)rv[i]; tvec[i] = (float)tv[i]; }  // CV_32F in/out
     res->n_inliers = ni;
     float Rm[9], q[4];
@@ -295,5 +305,18 @@ extern "C" int ora_pipeline_get_tracked(ora_pipeline* p, int64_t* ids, float* xy
     xy[2 * i] = p->feature_set[2 * i];
     xy[2 * i + 1] = p->feature_set[2 * i + 1];
   }
+  return n;
+}
+
+// The literals above as one table (order = tests/test_constants.py ORACLE_NAMES): lets the tests compare this
+// restatement's constants with the values extracted from the reference text.
+extern "C" int ora_reference_constants(double* out, int capacity) {
+  const double v[] = {(double)ora_k::kMinDetected, ora_k::kKeyframePercentLost, (double)ora_k::kPnpIterations, (double)ora_k::kPnpReprojError,
+                      ora_k::kPnpConfidence, (double)ora_k::kStereoNumDisparities, (double)ora_k::kStereoBlockSize,
+                      (double)ora_k::kStereoDisparityScale, (double)ora_k::kTriangulateMinDisparity, (double)ora_k::kLkWin,
+                      (double)ora_k::kLkMaxLevel, (double)ora_k::kLkMaxIterations, ora_k::kLkEpsilon, (double)ora_k::kLkMinEigThreshold,
+                      ora_k::kFbMaxDistance, (double)ora_k::kMaxParallax};
+  const int n = (int)(sizeof(v) / sizeof(v[0]));
+  for (int i = 0; i < n && i < capacity; ++i) out[i] = v[i];
   return n;
 }

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <vector>
 
+#include "ora_constants.h"
 #include "svo_oracle.h"
 
 namespace {
@@ -95,6 +96,6 @@ extern "C" void ora_stereo_disparity_at(const uint8_t* left, const uint8_t* righ
     const int x = (int)xy[2 * i], y = (int)xy[2 * i + 1];  // at<float>(it->y, it->x) truncation
     int16_t v = -16;
     if (x >= x0 && x < x1 && y >= y0 && y < y1) v = bm_pixel(lp.data(), rp.data(), w, x, y, ndisp, half);
-    disp[i] = (float)v * (1.0f / 16.0f);
+    disp[i] = (float)v * ora_k::kStereoDisparityScale;
   }
 }

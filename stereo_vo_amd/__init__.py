@@ -7,4 +7,4 @@ GPU is visible, compute entry points raise.
 """
 from .api import (SvoError, lib, lib_path, Context, Limits, SynthParams, synth_render, synth_pose,  # noqa: F401
                   CameraInfo, BAOptions, BASummary, PipelineParams, FrameResult, BA, Pipeline,
-                  pipeline_default_params, synth_default, image_read_gray, kitti_read_poses, ate_rmse, kitti_run)
+                  pipeline_default_params, synth_default, image_read_gray, kitti_read_poses, ate_rmse, kitti_run, lm_solve, LmStats)

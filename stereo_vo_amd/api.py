@@ -59,11 +59,98 @@ class SynthParams(C.Structure):
                 ("step_x", C.c_double), ("yaw_per_frame", C.c_double), ("n_billboards", C.c_int)]
 
 
+REFERENCE_CONSTANT_NAMES = (
+    "gftt_max_corners", "gftt_quality", "min_detected", "keyframe_percent_lost", "pnp_iterations", "pnp_reproj_error",
+    "pnp_confidence", "stereo_num_disparities", "stereo_block_size", "stereo_disparity_scale",
+    "triangulate_min_disparity_exclusive", "lk_win_w", "lk_win_h", "lk_max_level", "lk_max_iterations", "lk_epsilon",
+    "lk_min_eig_threshold", "fb_max_distance", "max_parallax", "draw_thickness", "parallax_thresh", "min_feature_distance",
+    "sliding_window_size", "max_features", "ba_max_solver_time_s", "ba_num_threads")
+
+
+class ReferenceConstants(C.Structure):
+    _fields_ = [(n, C.c_double) for n in REFERENCE_CONSTANT_NAMES]
+
+
+def reference_constants():
+    """The reference's first-party literals as compiled into the library (svo_reference_constants)."""
+    c = ReferenceConstants()
+    if lib().svo_reference_constants(C.byref(c)) != 0:
+        raise SvoError("svo_reference_constants failed")
+    return {n: getattr(c, n) for n in REFERENCE_CONSTANT_NAMES}
+
+
+class LmStats(C.Structure):
+    _fields_ = [("linearize_calls", C.c_int), ("step_calls", C.c_int), ("speculations", C.c_int), ("speculation_hits", C.c_int),
+                ("single_exchange", C.c_int)]
+
+
+class LmStepCtl(C.Structure):
+    _fields_ = [("cost", C.c_double), ("mcc", C.c_double), ("decrease_factor", C.c_double), ("spec_radius", C.c_double),
+                ("chain", C.c_int)]
+
+
+LM_LINEARIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_double))
+LM_STEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.POINTER(LmStepCtl),
+                         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int))
+LM_ACCEPT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p)
+
+
+class LmOps(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("linearize", LM_LINEARIZE_FN), ("step", LM_STEP_FN), ("accept", LM_ACCEPT_FN)]
+
+
+def lm_decide_step(cost, mcc, radius, decrease_factor, cost_new, model_change_points):
+    """svo_lm_decide_step: Ceres' accept / radius rule -> (accept, next_radius)."""
+    acc, rad = C.c_int(0), C.c_double(0.0)
+    lib().svo_lm_decide_step(C.c_double(cost), C.c_double(mcc), C.c_double(radius), C.c_double(decrease_factor), C.c_double(cost_new),
+                             C.c_double(model_change_points), C.byref(acc), C.byref(rad))
+    return bool(acc.value), rad.value
+
+
+def lm_solve(poses7, linearize, step, accept, max_iterations=50, max_time_s=0.0):
+    """svo_lm_solve — the product's LM step control (host/lm.cpp) over caller-provided passes (no GPU involved).
+    linearize(radius, first) -> payload1 array;
+    step(dc, cand_poses, radius, ctl) -> (payload2, payload1_next or None, next_radius, next_at_candidate) with ctl an
+    LmStepCtl (cost, mcc, decrease_factor, spec_radius, chain);  accept() -> None.
+    Returns (poses7, BASummary, LmStats)."""
+    poses = np.ascontiguousarray(poses7, np.float64).copy()
+    K = poses.shape[0]
+    n = 6 * (K - 1)
+    pay1 = n * n + 3 * n + 2
+
+    def _lin(user, radius, first, out):
+        np.ctypeslib.as_array(out, shape=(pay1,))[:] = linearize(radius, first)
+        return 0
+
+    def _step(user, dc, cand, radius, ctl, out2, out1, out_radius, out_at_cand):
+        d = np.ctypeslib.as_array(dc, shape=(max(n, 1),))[:n].copy()
+        c = np.ctypeslib.as_array(cand, shape=(K, 7)).copy()
+        p2, p1, nr, at_cand = step(d, c, radius, ctl.contents)
+        np.ctypeslib.as_array(out2, shape=(4,))[:] = p2
+        if p1 is not None:
+            np.ctypeslib.as_array(out1, shape=(pay1,))[:] = p1
+        out_radius[0] = nr if p1 is not None else 0.0
+        out_at_cand[0] = int(bool(at_cand))
+        return 0
+
+    def _acc(user):
+        accept()
+        return 0
+    ops = LmOps(None, LM_LINEARIZE_FN(_lin), LM_STEP_FN(_step), LM_ACCEPT_FN(_acc))
+    opt = ba_default_options()
+    opt.max_iterations, opt.max_time_s = max_iterations, max_time_s
+    s, st = BASummary(), LmStats()
+    rc = lib().svo_lm_solve(K, _p(poses), C.byref(ops), C.byref(opt), C.byref(s), C.byref(st))
+    if rc:
+        raise SvoError(f"svo_lm_solve failed ({rc})")
+    return poses, s, st
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/svo.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "svo_create", "svo_destroy", "svo_last_error", "svo_stream", "svo_sync", "svo_version",
+    "svo_create", "svo_destroy", "svo_last_error", "svo_stream", "svo_sync", "svo_version", "svo_reference_constants",
     "svo_profile_select", "svo_profile_read",
     "svo_reproj_eval", "svo_reproj_eval_dev",
     "svo_corner_detect", "svo_corner_detect_batch_dev", "svo_corner_response",
@@ -72,7 +159,8 @@ SYMBOLS = [
     "svo_pnp_ransac",
     "svo_ba_default_options", "svo_ba_create", "svo_ba_destroy", "svo_ba_reset", "svo_ba_add_keyframe", "svo_ba_solve",
     "svo_ba_get_pose", "svo_ba_window_count", "svo_ba_get_points", "svo_ba_load_problem",
-    "svo_ba_set_allreduce", "svo_ba_solve_problem", "svo_ba_read_problem",
+    "svo_ba_set_allreduce", "svo_ba_solve_problem", "svo_ba_read_problem", "svo_ba_set_comm", "svo_ba_last_stats", "svo_lm_solve", "svo_lm_decide_step",
+    "svo_rccl_unique_id", "svo_rccl_comm_create", "svo_rccl_comm_destroy",
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
@@ -354,10 +442,19 @@ class BA:
         self.ctx._chk(self.L.svo_ba_set_allreduce(self.h, self._cb if self._cb else C.cast(None, ALLREDUCE_FN), None),
                       "svo_ba_set_allreduce")
 
+    def set_comm(self, nccl_comm):
+        """nccl_comm: ncclComm_t as an int / c_void_p (see rccl_comm_create); None detaches."""
+        self.ctx._chk(self.L.svo_ba_set_comm(self.h, C.c_void_p(nccl_comm) if nccl_comm else None), "svo_ba_set_comm")
+
     def solve_problem(self):
         s = BASummary()
         self.ctx._chk(self.L.svo_ba_solve_problem(self.h, C.byref(s)), "svo_ba_solve_problem")
         return s
+
+    def last_stats(self):
+        st = LmStats()
+        self.ctx._chk(self.L.svo_ba_last_stats(self.h, C.byref(st)), "svo_ba_last_stats")
+        return st
 
     def read_problem(self):
         K, N = self._shape
@@ -395,6 +492,33 @@ class BA:
         out = np.empty((ids.shape[0], 3), np.float32)
         self.ctx._chk(self.L.svo_ba_get_points(self.h, _p(ids), ids.shape[0], _p(out)), "svo_ba_get_points")
         return out
+
+
+def rccl_unique_id():
+    """128-byte ncclUniqueId (bytes) from the librccl the library binds; distribute it to every rank out of band."""
+    buf = C.create_string_buffer(128)
+    if lib().svo_rccl_unique_id(buf) != 0:
+        raise SvoError("svo_rccl_unique_id failed (librccl not available?)")
+    return buf.raw
+
+
+def rccl_comm_create(n_ranks, rank, id128, device):
+    comm = C.c_void_p()
+    rc = lib().svo_rccl_comm_create(C.byref(comm), n_ranks, rank, C.c_char_p(id128), device)
+    if rc != 0:
+        raise SvoError(f"svo_rccl_comm_create failed ({rc})")
+    return comm.value
+
+
+def rccl_comm_destroy(comm):
+    lib().svo_rccl_comm_destroy.argtypes = [C.c_void_p]
+    lib().svo_rccl_comm_destroy(comm)
+
+
+def ba_default_options():
+    o = BAOptions()
+    lib().svo_ba_default_options(C.byref(o))
+    return o
 
 
 def pipeline_default_params():

@@ -50,7 +50,7 @@ def build_hip(force=False):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed on " + s)
     if force or procs or not os.path.exists(LIB):
-        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lz"])
+        _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-lz", "-ldl"])
     return LIB
 
 

@@ -1,37 +1,37 @@
 // a9/a10/a12/a13 — sliding-window bundle adjustment: BundleAdjuster (reference src/bundle_adjuster.cpp:5-163)
 // whose solve is ceres::Solve with DENSE_SCHUR (:9-12,140) over ReprojectionFactor residuals
 // (src/reprojection_factor.cpp:10-88), quaternion (x) identity local parameterization (:19-20,123),
-// oldest pose constant (:130).  LM semantics: SURVEY.md Appendix B as restated in oracle/ora_ba.cpp.
+// oldest pose constant (:130).  LM semantics: SURVEY.md Appendix B; the step control itself is host/lm.cpp
+// (svo_lm_solve), this file provides its two passes as HIP kernels plus the graph bookkeeping.
 //
-// Per LM iteration two kernels, each a single pass over the observations (landmark-major CSR):
-//   ba_linearize_kernel : lane = observation.  Residual + analytic Jacobians (FP64 VALU, fused device
-//       function, nothing written back), per-landmark V / g_p by in-wave segment gathers, 3x3 inverse,
-//       Y = W s Vd^-1, and the landmark's Schur contribution -Y_k (W_k' s)^T accumulated into a
-//       per-workgroup LDS image of the reduced camera system (ds_add_f64), flushed once per workgroup
-//       with global f64 atomics into payload1 = [S | g_red | g_c | diag U | cost | sum g_p^2].
-//   ba_backsub_kernel   : recomputes the landmark blocks (cheaper than 144 B/observation of W traffic),
-//       back-substitutes the camera step, writes candidate points and evaluates the candidate cost in
-//       the same pass -> payload2 = [cost_new | model-change(points) | sum dp^2 | sum p^2].
-// Deterministic mode (window-sized problems, i.e. everything the pipeline solves): instead of LDS/global
-// atomics the kernels write per-pair 6x6 blocks, per-observation vectors and per-landmark scalars to
-// contribution slots, and ba_reduce1/2_kernel sum every destination with the DECLARED order
-// "28 consecutive segments of ceil(len/28) entries summed sequentially, then the 28 segment sums added
-// sequentially" over its slot list in landmark order (one lane per (segment, element)).  The oracle performs the
-// same sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is
-// bit-identical between CPU and GPU and independent of grid size.  (Needed because the reference's
-// problem has a scale gauge: with one fixed pose and only reprojection factors the iterates slide along
-// a flat direction and amplify any summation-order difference; measured 3e-2 pose drift otherwise.)
-// Problems whose pair slots would not fit (config 4), or that ask for it (svo_ba_options.accumulation), sum in
-// hardware order with a tolerance-level result: ba_linearize_mfma_kernel applies each landmark's Schur
-// contribution as a rank-3 update of S on the f64 matrix cores (<= 22 poses), the LDS-atomic kernel is the fallback.
-// Host <-> device hand-over of the host-driven loop (single rank, deterministic mode): the reduce kernels write the
-// payloads into pinned host memory and publish a completion word that the host polls; the step [dc | candidate
-// poses] is read by ba_backsub_kernel in place from pinned memory.  Per LM iteration: 4 launches, no copy, no stream
-// wait (SVO_BA_FUSE=1 folds reduce2 into the back-substitution launch: last workgroup reduces; measured, not default).
-// The n x n (n = 6 (K-1) <= 114) Cholesky, step control and termination run on the host from the
-// (all-reduced) payloads, so every rank of a sharded run takes identical decisions.
-// A rank of a sharded run holds all poses and its own landmarks; `allreduce` sums payload1/2 in place
-// on the device (RCCL all-reduce over xGMI) — the only exchange of the path.
+// Pass A "linearize" and pass B "backsub" are single sweeps over the observations (landmark-major CSR, wave chunks of
+// <= 64 observations made of whole landmarks, lane = observation):
+//   pass A: residual + analytic Jacobians (FP64 VALU, fused device function, nothing written back), per-landmark V / g_p
+//           by in-wave segment gathers, 3x3 inverse, Y = W s Vd^-1 and the landmark's Schur contribution
+//           -Y_k (W_k' s)^T  -> payload1 = [S | g_red | g_c | diag U | cost | sum g_p^2].
+//   pass B: recomputes the landmark blocks (cheaper than 144 B/observation of W traffic), back-substitutes the camera
+//           step, writes the candidate landmarks and evaluates the candidate cost
+//           -> payload2 = [cost_new | model-change(points) | sum dp^2 | sum p^2].
+// One exchange per LM iteration (host/lm.cpp): pass B of iteration i and pass A of iteration i+1 (at the candidate,
+// with the radius an accepted step produces) run back to back and their payloads leave together:
+//   deterministic mode (window-sized problems, everything the pipeline solves): ONE kernel does both passes
+//     (ba_step_kernel: the candidate landmark never leaves the registers of its wave) and writes per-pair 6x6 blocks,
+//     per-observation vectors and per-landmark scalars to DESTINATION-ORDERED contribution slots; ONE reduce kernel
+//     (ba_reduce_kernel) sums every destination in the DECLARED order "28 consecutive segments of ceil(len/28) entries
+//     summed sequentially, then the 28 segment sums added sequentially" (lane = (segment, element)), writes
+//     [payload2 | payload1] straight into pinned host memory and publishes a completion word the host polls:
+//     2 launches, 1 host round trip, no copy kernel, no stream wait per LM iteration.  The oracle performs the same
+//     sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is bit-identical
+//     between CPU and GPU and independent of grid size.  (Needed because the reference's problem has a scale gauge:
+//     with one fixed pose and only reprojection factors the iterates slide along a flat direction and amplify any
+//     summation-order difference; measured 3e-2 pose drift otherwise.)
+//   bulk modes (config 4; svo_ba_options.accumulation): hardware-order sums with a tolerance-level result.
+//     ba_backsub_kernel, then ba_linearize_mfma_kernel (each landmark's Schur contribution as a rank-3 update of S on
+//     the f64 matrix cores, <= 22 poses) or the LDS-atomic ba_linearize_kernel, both accumulating into ONE device
+//     buffer [payload2 | payload1] that a single ncclAllReduce on the adjuster's stream sums over the ranks
+//     (svo_ba_set_comm), followed by one D2H copy.
+// The n x n (n = 6 (K-1) <= 114) Cholesky, step control and termination run on the host from the (all-reduced)
+// payloads, so every rank of a sharded run takes identical decisions.  A rank holds all poses and its own landmarks.
 #include <math.h>
 #include <stdlib.h>
 
@@ -43,78 +43,74 @@
 #include <vector>
 
 #include "kernels.h"
+#include "lm_decide.h"
+#include "ref_constants.h"
 #include "reproj_device.h"
 
-bool svo_host_cholesky_solve(double* A, double* b, int n);  // host/linalg.cpp
+int svo_rccl_allreduce_f64(void* buf, size_t count, void* comm, hipStream_t stream, const char** err);  // csrc/rccl.hip
 
 namespace {
 constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
-constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, MAX_RADIUS = 1e16, MIN_RADIUS = 1e-32, MIN_REL_DECREASE = 1e-3;
-
-// LM state of the device-resident loop (deterministic, single-rank solves): the host never sees an
-// iteration, it enqueues chunks of [linearize, reduce1, solve, backsub, reduce2+decide] and polls `done`.
-struct LmDev {
-  double radius, decrease_factor, cost, initial_cost, mcc;
-  double function_tol, gradient_tol, parameter_tol;
-  int max_iterations;
-  int iterations, successful, termination, done;
-  int cur;          // which (points, step) buffer pair holds the linearisation point
-  int have_scale;   // Jacobi scales fixed (first linearisation done)
-  int step_valid;   // the solve kernel produced a step for this iteration
-  int grad_check;   // previous step accepted: test the gradient of the new linearisation
-  unsigned bar;     // grid-barrier arrival counter of the persistent kernel (monotone within a launch)
-  int abort;        // a bounded spin gave up (never expected; keeps a bug from hanging the GPU)
-  double sc[6 * 63], Df[6 * 63];
-};
-
-// Cross-workgroup reads inside the persistent kernel go through agent-scope (sc1) loads: never the scalar
-// cache, never a stale L1 line (cdna_hip_programming.md Guideline 16, Pitfall 6).
-__device__ __forceinline__ int ldv(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ldv(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32;
+constexpr int PAY2_SLOTS = 8;  // payload2 (4 doubles) is padded to 8 so that payload1 starts 64-byte aligned behind it
 
 struct BaDev {
   int K = 0, n = 0, M = 0, L = 0, C = 0;
-  LmDev* lm = nullptr;           // non-null: buffers/radius come from the device state
-  double* pts[2] = {nullptr, nullptr};
-  double* step[2] = {nullptr, nullptr};  // [dc (max(n,1)) | poses (7K)] x 2
-  int* done_host = nullptr;      // pinned: ints [done, iterations, successful, termination, cur, pad], then doubles [initial_cost, cost]
-  double* poses = nullptr;       // K x 7 (linearisation point)
-  double* cand_poses = nullptr;  // K x 7
-  double* dc = nullptr;          // n
-  double* points = nullptr;      // Npts x 3
+  const double* poses = nullptr;   // K x 7: the point pass A linearises at / pass B steps from
+  double* cand_poses = nullptr;    // K x 7 device copy of the candidate poses (written by pass B's first workgroup)
+  const double* points = nullptr;  // Npts x 3
   double* cand_points = nullptr;
   int32_t* obs_pose = nullptr;
   int32_t* obs_point = nullptr;
   double* obs_uv = nullptr;
-  int32_t* lm_start = nullptr;   // per landmark index j (dense over [0,Npts]): first obs; lm_start[j+1] end
+  int32_t* lm_start = nullptr;     // per landmark index j (dense over [0,Npts]): first obs; lm_start[j+1] end
   int32_t* chunk_start = nullptr;
-  double* sp = nullptr;          // Npts x 3 point Jacobi scales
-  double* pay1 = nullptr;
-  double* pay2 = nullptr;
+  double* sp = nullptr;            // Npts x 3 point Jacobi scales
+  double* pay1 = nullptr;          // device payload1 (bulk kernels accumulate here with atomics)
+  double* pay2 = nullptr;          // device payload2
   double f = 0, cx = 0, cy = 0;
   // deterministic mode: contribution slots + destination lists
   int det = 0;
-  // Contributions are stored DESTINATION-ORDERED so the reduce kernels stream contiguous memory:
+  // Contributions are stored DESTINATION-ORDERED so the reduce kernel streams contiguous memory:
   int32_t* pair_base = nullptr;   // per observation: first pair slot (pairs (o, t>=o) of its landmark)
   int32_t* pair_pos = nullptr;    // per pair slot: [position in its block list, position in the mirrored list or -1]
   int32_t* obs_pos = nullptr;     // per observation: position in its pose list or -1
   double* pairB = nullptr;        // (sum of block-list lengths) x 36, block lists back to back
   double* obsV = nullptr;         // (free observations) x 18  (g_c | g_red part | diag U), pose lists back to back
-  double* lmV = nullptr;          // Npts x 4, by landmark index (zero for landmarks without observations)
+  double* lmV = nullptr;          // Npts x 4, by landmark index: pass A's (cost, g_p^2) (zero for landmarks without observations)
+  double* lmV2 = nullptr;         // Npts x 4, by landmark index: pass B's (cost_new, model change, dp^2, p^2)
   int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1): offsets into pairB / obsV / lmV rows
-  double* pay1_out = nullptr;     // where the reduce kernels write (pinned host memory when single-rank)
+  double* pay1_out = nullptr;     // where the reduce kernel writes (pinned host memory when single-rank)
   double* pay2_out = nullptr;
-  const double* step_in = nullptr;  // pinned host [dc | candidate poses]: read in place by ba_backsub (no H2D blit per LM iteration)
-  // completion flags in pinned host memory (single-rank deterministic mode): the reduce kernels publish `seq` after
-  // their payload, the host loop polls the word instead of paying a stream wait per half-iteration
-  int* flag1 = nullptr;
-  int* flag2 = nullptr;
-  unsigned* arrive = nullptr;   // device counter of finished reduce1 workgroups (monotone; target = total so far)
+  const double* step_in = nullptr;  // [dc (max(n,1)) | candidate poses (7K)]: pinned host memory (read in place, no H2D blit) or device
+  // completion flag in pinned host memory (single-rank deterministic mode): the reduce kernel publishes `seq` after its
+  // payload, the host polls the word instead of paying a stream wait
+  int* flag = nullptr;
+  unsigned* arrive = nullptr;   // device counter of finished reduce workgroups (monotone; target = total so far)
   unsigned arrive_target = 0;
-  unsigned* arrive2 = nullptr;  // fused back-substitution + reduce2: counter of finished backsub workgroups
-  unsigned arrive2_target = 0;  // 0: separate ba_reduce2_kernel launch
   int seq = 0;
+  double* ctl_dev = nullptr;    // device [accept (0/1) | next radius]: the chained decision, read by the next pass A
 };
+
+// Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
+struct LmCtl { double cost, mcc, radius, decrease_factor; int chain; };
+
+// The decision for the summed payload2 -> ctl_dev (for the pass-A launch queued behind) and payload slots 4 / 5 (for the host).
+__device__ __forceinline__ void decide_device(const LmCtl& c, double cost_new, double mc_points, double* ctl_dev, double* pay2buf) {
+  const SvoLmDecision d = svo_lm_decide(c.cost, c.mcc, c.radius, c.decrease_factor, cost_new, mc_points);
+  ctl_dev[0] = (double)d.accept; ctl_dev[1] = d.next_radius;
+  pay2buf[4] = (double)d.accept; pay2buf[5] = d.next_radius;
+}
+
+// Pass A behind a chained decision: linearise at the candidate with the new radius (accepted) or at the current point
+// with the reduced radius (rejected).
+__device__ __forceinline__ void apply_ctl(BaDev& P, double& radius, const double* __restrict__ ctl) {
+  if (!ctl) return;
+  const double acc = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  radius = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (acc != 0.0) { P.points = P.cand_points; P.poses = P.cand_poses; }
+}
+
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
   const double a = V[0], b = V[1], c = V[2], d = V[4], e = V[5], f = V[8];
@@ -172,50 +168,282 @@ __device__ __forceinline__ void eval_obs(const double* __restrict__ pose, D3 p, 
 }
 }  // namespace
 
-// sin/cos with a declared operation sequence (see oracle/ora_ba.cpp): bit-identical on host and device.
-__host__ __device__ inline void det_sincos(double x, double* sn, double* cs) {
-  int k = 0;
-  while (x > 0.5) { x *= 0.5; ++k; }
-  const double x2 = x * x;
-  double s = x * (1.0 + x2 * (-1.0 / 6.0 + x2 * (1.0 / 120.0 + x2 * (-1.0 / 5040.0 + x2 * (1.0 / 362880.0 + x2 * (-1.0 / 39916800.0 +
-             x2 * (1.0 / 6227020800.0 + x2 * (-1.0 / 1307674368000.0))))))));
-  double c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24.0 + x2 * (-1.0 / 720.0 + x2 * (1.0 / 40320.0 + x2 * (-1.0 / 3628800.0 +
-             x2 * (1.0 / 479001600.0 + x2 * (-1.0 / 87178291200.0)))))));
-  for (int i = 0; i < k; ++i) {
-    const double s2 = 2.0 * s * c;
-    c = 1.0 - 2.0 * s * s;
-    s = s2;
+// One lane's observation: indices, its landmark's lane segment [first, first + len) inside the chunk, the landmark
+// position and the measurement.
+struct ObsRec { bool active; int o, k, j, first, len; D3 p; double u, v; };
+
+__device__ __forceinline__ ObsRec load_obs(const BaDev& P, int chunk, int lane, const double* __restrict__ points) {
+  ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
+  const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
+  R.o = c0 + lane;
+  R.active = R.o < c1;
+  if (R.active) {
+    R.k = P.obs_pose[R.o]; R.j = P.obs_point[R.o];
+    const int l0 = P.lm_start[R.j];
+    R.first = l0 - c0; R.len = P.lm_start[R.j + 1] - l0;
+    R.p = D3{points[3 * R.j], points[3 * R.j + 1], points[3 * R.j + 2]};
+    R.u = P.obs_uv[2 * R.o]; R.v = P.obs_uv[2 * R.o + 1];
   }
-  *sn = s; *cs = c;
+  return R;
 }
 
-__host__ __device__ inline void plus_pose(const double* p, const double* d, double* out) {
-  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  double qd[4];
-  if (nd > 0) {
-    double sn, cs;
-    det_sincos(nd, &sn, &cs);
-    const double s = sn / nd;
-    qd[0] = cs; qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
-  } else { qd[0] = 1; qd[1] = qd[2] = qd[3] = 0; }
-  const double* q = p;
-  out[0] = qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2] - qd[3] * q[3];
-  out[1] = qd[0] * q[1] + qd[1] * q[0] + qd[2] * q[3] - qd[3] * q[2];
-  out[2] = qd[0] * q[2] - qd[1] * q[3] + qd[2] * q[0] + qd[3] * q[1];
-  out[3] = qd[0] * q[3] + qd[1] * q[2] - qd[2] * q[1] + qd[3] * q[0];
-  out[4] = p[4] + d[3]; out[5] = p[5] + d[4]; out[6] = p[6] + d[5];
+// Pass A for one wave chunk at (poses_, R.p).  Deterministic mode: contributions go to the slots.  Otherwise into the
+// workgroup's LDS image of payload1 (ds_add_f64), lcost / lgp2 accumulate this lane's share of the two scalars.
+__device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius,
+                                                int first_pass, double* sS, double* sGred, double* sGc, double* sDU,
+                                                double& lcost, double& lgp2) {
+  const int lane = threadIdx.x & 63, n = P.n;
+  const bool active = R.active;
+  const int k = R.k, j = R.j, first = R.first, len = R.len, o = R.o;
+  double r[2] = {0, 0}, Jc[12], Jp[6];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
+  if (active) {
+    eval_obs(poses_ + 7 * k, R.p, R.u, R.v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+    lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+  }
+  const double my_cost = active ? 0.5 * (r[0] * r[0] + r[1] * r[1]) : 0.0;
+  double cost_l = 0.0;  // landmark cost, summed in observation order (deterministic mode)
+  int maxlen = len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+  // landmark sums: every lane of a segment gathers the whole segment in observation order
+  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+  for (int t = 0; t < maxlen; ++t) {
+    const int src = (first + t) & 63;
+    double q[6], rr[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q[i] = shfl_d(Jp[i], src);
+    rr[0] = shfl_d(r[0], src); rr[1] = shfl_d(r[1], src);
+    const double ct = shfl_d(my_cost, src);
+    if (t < len) {
+      cost_l += ct;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gp[a] += q[a] * rr[0] + q[3 + a] * rr[1];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b] + q[3 + a] * q[3 + b];
+      }
+    }
+  }
+  double s[3] = {1, 1, 1};
+  if (active) {
+    if (first_pass) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + sqrt(V[4 * a]));
+      if (lane == first) { P.sp[3 * j] = s[0]; P.sp[3 * j + 1] = s[1]; P.sp[3 * j + 2] = s[2]; }
+    } else {
+      s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
+    }
+    if (lane == first) {
+      lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+      if (P.det) { P.lmV[4 * (size_t)j] = cost_l; P.lmV[4 * (size_t)j + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
+    }
+  }
+  double Vd[9], Vi[9], gps[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gps[a] = gp[a] * s[a];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) Vd[4 * a] += fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius;
+  inv3_sym(Vd, Vi);
+  // W s and Y = (W s) Vd^-1 for free poses
+  double Ws[18], Y[18];
+  const bool freep = active && k > 0;
+  const int base = 6 * (k - 1);
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Ws[3 * a + b] = freep ? (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b] : 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
+  if (freep && P.det) {
+    double* ov = P.obsV + (size_t)P.obs_pos[o] * 18;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+      ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+      ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+    }
+  }
+  if (freep && !P.det) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
+      atomicAdd(&sDU[base + a], Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]);
+      atomicAdd(&sGred[base + a], -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]));
+#pragma unroll
+      for (int b = 0; b < 6; ++b) atomicAdd(&sS[(base + a) * n + base + b], Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+    }
+  }
+  // Schur pairs: lane (pose k) x every later-or-equal member of its segment; mirrored on the host
+  for (int t = 0; t < maxlen; ++t) {
+    const int src = (first + t) & 63;
+    const int kt = __shfl(k, src);
+    double Wt[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
+    if (freep && t < len && kt > 0 && src >= lane) {
+      if (P.det) {
+        const int slot = P.pair_base[o] + (src - lane);
+        const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
+        double* B = P.pairB + (size_t)posA * 36;
+        double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+            const double w = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+            B[6 * a + b] = w;
+            if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
+          }
+      } else {
+        const int bt = 6 * (kt - 1);
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b)
+            atomicAdd(&sS[(base + a) * n + bt + b],
+                      -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]));
+      }
+    }
+  }
 }
 
-__device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius, int first_pass) {
-  const double* poses_ = P.poses;
-  const double* points_ = P.points;
-  if (P.lm) {
-    if (ldv(&P.lm->done)) return;
-    const int c = ldv(&P.lm->cur);
-    poses_ = P.step[c] + (P.n > 0 ? P.n : 1); points_ = P.pts[c];
-    radius = ldv(&P.lm->radius); first_pass = !ldv(&P.lm->have_scale);
+// Pass B for one wave chunk: back-substitution of the pose step dc_ at (poses_, R.p), candidate landmark (returned in
+// `cand`, valid in every active lane of the landmark's segment; written to cand_points_ by the segment's first lane),
+// candidate residual against cand_poses_.  Deterministic mode: the landmark's four scalars go to lmV2.  Otherwise
+// a_* accumulate this lane's share of payload2.
+__device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_,
+                                              const double* __restrict__ cand_poses_, const double* __restrict__ dc_,
+                                              double* __restrict__ cand_points_, double radius, D3& cand, double& a_cost,
+                                              double& a_mc, double& a_dp2, double& a_p2) {
+  const int lane = threadIdx.x & 63;
+  const bool active = R.active;
+  const int k = R.k, j = R.j, first = R.first, len = R.len;
+  double r[2] = {0, 0}, Jc[12], Jp[6], jd[2] = {0, 0};
+  double det_c = 0.0, det_mc = 0.0, det_dp2 = 0.0, det_p2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
+  const D3 p = R.p;
+  cand = p;
+  if (active) {
+    eval_obs(poses_ + 7 * k, p, R.u, R.v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+    if (k > 0) {
+      const double* d = dc_ + 6 * (k - 1);
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * d[a]; jd[1] += Jc[6 + a] * d[a]; }
+    }
   }
-  extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2
+  int maxlen = len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, wd[3] = {0, 0, 0};
+  if (!P.det) {
+    double t[12] = {Jp[0] * Jp[0] + Jp[3] * Jp[3], Jp[0] * Jp[1] + Jp[3] * Jp[4], Jp[0] * Jp[2] + Jp[3] * Jp[5],
+                    Jp[1] * Jp[1] + Jp[4] * Jp[4], Jp[1] * Jp[2] + Jp[4] * Jp[5], Jp[2] * Jp[2] + Jp[5] * Jp[5],
+                    Jp[0] * r[0] + Jp[3] * r[1], Jp[1] * r[0] + Jp[4] * r[1], Jp[2] * r[0] + Jp[5] * r[1],
+                    Jp[0] * jd[0] + Jp[3] * jd[1], Jp[1] * jd[0] + Jp[4] * jd[1], Jp[2] * jd[0] + Jp[5] * jd[1]};
+    segment_totals<12>(t, lane, first, len > 0 ? first + len - 1 : lane, maxlen);
+    V[0] = t[0]; V[1] = V[3] = t[1]; V[2] = V[6] = t[2]; V[4] = t[3]; V[5] = V[7] = t[4]; V[8] = t[5];
+    gp[0] = t[6]; gp[1] = t[7]; gp[2] = t[8]; wd[0] = t[9]; wd[1] = t[10]; wd[2] = t[11];
+  }
+  for (int t = 0; t < (P.det ? maxlen : 0); ++t) {
+    const int src = (first + t) & 63;
+    double q[6], rr[2], dd[2];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q[i] = shfl_d(Jp[i], src);
+    rr[0] = shfl_d(r[0], src); rr[1] = shfl_d(r[1], src);
+    dd[0] = shfl_d(jd[0], src); dd[1] = shfl_d(jd[1], src);
+    if (t < len) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        gp[a] += q[a] * rr[0] + q[3 + a] * rr[1];
+        wd[a] += q[a] * dd[0] + q[3 + a] * dd[1];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b] + q[3 + a] * q[3 + b];
+      }
+    }
+  }
+  if (active) {
+    const double s[3] = {P.sp[3 * j], P.sp[3 * j + 1], P.sp[3 * j + 2]};
+    double Vd[9], Vi[9], De[3], rh[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      rh[a] = -(gp[a] + wd[a]) * s[a];
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { De[a] = fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius; Vd[4 * a] += De[a]; }
+    inv3_sym(Vd, Vi);
+    double np[3];
+    const double pv[3] = {p.x, p.y, p.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
+      const double d = y * s[a];
+      np[a] = pv[a] + d;
+      if (lane == first) {
+        a_mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
+        a_dp2 += d * d;
+        a_p2 += pv[a] * pv[a];
+      }
+    }
+    cand = D3{np[0], np[1], np[2]};
+    if (lane == first) { cand_points_[3 * j] = np[0]; cand_points_[3 * j + 1] = np[1]; cand_points_[3 * j + 2] = np[2]; }
+    double r0, r1;
+    reproj_residual(cand_poses_ + 7 * k, cand, R.u, R.v, P.f, P.cx, P.cy, r0, r1);
+    a_cost += 0.5 * (r0 * r0 + r1 * r1);
+    det_c = 0.5 * (r0 * r0 + r1 * r1);
+    det_mc = 0.0; det_dp2 = 0.0; det_p2 = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
+      const double d = y * s[a];
+      det_mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
+      det_dp2 += d * d;
+      det_p2 += pv[a] * pv[a];
+    }
+  }
+  if (P.det) {  // candidate cost of the landmark in observation order, then the landmark's slot
+    double cn = 0.0;
+    for (int t = 0; t < maxlen; ++t) {
+      const double ct = shfl_d(det_c, (first + t) & 63);
+      if (t < len) cn += ct;
+    }
+    if (active && lane == first) {
+      double* lv = P.lmV2 + 4 * (size_t)j;
+      lv[0] = cn; lv[1] = det_mc; lv[2] = det_dp2; lv[3] = det_p2;
+    }
+  }
+}
+
+// [dc | candidate poses] -> LDS (the source may be pinned host memory: ONE PCIe round trip per workgroup instead of one
+// per use); the first workgroup also leaves the device copy of the candidate poses that later launches linearise at.
+__device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
+  const int nn = P.n > 0 ? P.n : 1, tot = nn + 7 * P.K;
+  for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+    const double v = P.step_in[i];
+    sStep[i] = v;
+    if (blockIdx.x == 0 && i >= nn) P.cand_poses[i - nn] = v;
+  }
+  __syncthreads();
+}
+constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
+
+// ---- pass A alone (first linearisation of a solve, re-linearisation after a rejected step or a missed speculation)
+__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+  apply_ctl(P, radius, ctl);
+  extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2  (bulk mode only)
   const int n = P.n;
   const int pay1 = n * n + 3 * n + 2;
   double* sS = lds;
@@ -230,136 +458,10 @@ __device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius,
   double lcost = 0.0, lgp2 = 0.0;
   const int wpb = blockDim.x >> 6;
   for (int chunk = blockIdx.x * wpb + wave; chunk < P.C; chunk += gridDim.x * wpb) {
-    const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
-    const int o = c0 + lane;
-    const bool active = o < c1;
-    int k = 0, j = 0, first = lane, len = 0;
-    double r[2] = {0, 0}, Jc[12], Jp[6];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
-    if (active) {
-      k = P.obs_pose[o]; j = P.obs_point[o];
-      first = P.lm_start[j] - c0; len = P.lm_start[j + 1] - P.lm_start[j];
-      const D3 p{points_[3 * j], points_[3 * j + 1], points_[3 * j + 2]};
-      eval_obs(poses_ + 7 * k, p, P.obs_uv[2 * o], P.obs_uv[2 * o + 1], P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
-      lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
-    }
-    const double my_cost = active ? 0.5 * (r[0] * r[0] + r[1] * r[1]) : 0.0;
-    double cost_l = 0.0;  // landmark cost, summed in observation order (deterministic mode)
-    int maxlen = len;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
-    // landmark sums: every lane of a segment gathers the whole segment in observation order
-    double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
-    for (int t = 0; t < maxlen; ++t) {
-      const int src = (first + t) & 63;
-      double q[6], rr[2];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) q[i] = shfl_d(Jp[i], src);
-      rr[0] = shfl_d(r[0], src); rr[1] = shfl_d(r[1], src);
-      const double ct = shfl_d(my_cost, src);
-      if (t < len) {
-        cost_l += ct;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          gp[a] += q[a] * rr[0] + q[3 + a] * rr[1];
-#pragma unroll
-          for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b] + q[3 + a] * q[3 + b];
-        }
-      }
-    }
-    double s[3] = {1, 1, 1};
-    if (active) {
-      if (first_pass) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + sqrt(V[4 * a]));
-        if (lane == first) { P.sp[3 * j] = s[0]; P.sp[3 * j + 1] = s[1]; P.sp[3 * j + 2] = s[2]; }
-      } else {
-        s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
-      }
-      if (lane == first) {
-        lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
-        if (P.det) { P.lmV[4 * (size_t)j] = cost_l; P.lmV[4 * (size_t)j + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
-      }
-    }
-    double Vd[9], Vi[9], gps[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      gps[a] = gp[a] * s[a];
-#pragma unroll
-      for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
-    }
-#pragma unroll
-    for (int a = 0; a < 3; ++a) Vd[4 * a] += fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius;
-    inv3_sym(Vd, Vi);
-    // W s and Y = (W s) Vd^-1 for free poses
-    double Ws[18], Y[18];
-    const bool freep = active && k > 0;
-    const int base = 6 * (k - 1);
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) Ws[3 * a + b] = freep ? (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b] : 0.0;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
-    if (freep && P.det) {
-      double* ov = P.obsV + (size_t)P.obs_pos[o] * 18;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
-        ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
-        ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
-      }
-    }
-    if (freep && !P.det) {
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
-        atomicAdd(&sDU[base + a], Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]);
-        atomicAdd(&sGred[base + a], -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]));
-#pragma unroll
-        for (int b = 0; b < 6; ++b) atomicAdd(&sS[(base + a) * n + base + b], Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
-      }
-    }
-    // Schur pairs: lane (pose k) x every later-or-equal member of its segment; mirrored on the host
-    for (int t = 0; t < maxlen; ++t) {
-      const int src = (first + t) & 63;
-      const int kt = __shfl(k, src);
-      double Wt[18];
-#pragma unroll
-      for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
-      if (freep && t < len && kt > 0 && src >= lane) {
-        if (P.det) {
-          const int slot = P.pair_base[o] + (src - lane);
-          const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
-          double* B = P.pairB + (size_t)posA * 36;
-          double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-              const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-              const double w = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-              B[6 * a + b] = w;
-              if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
-            }
-        } else {
-          const int bt = 6 * (kt - 1);
-#pragma unroll
-          for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = 0; b < 6; ++b)
-              atomicAdd(&sS[(base + a) * n + bt + b],
-                        -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]));
-        }
-      }
-    }
+    const ObsRec R = load_obs(P, chunk, lane, P.points);
+    linearize_chunk(P, R, P.poses, radius, first_pass, sS, sGred, sGc, sDU, lcost, lgp2);
   }
-  if (P.det) return;  // sums are formed by ba_reduce1_kernel in the declared order
+  if (P.det) return;  // sums are formed by ba_reduce_kernel in the declared order
   // block totals of cost / gp2
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { lcost += __shfl_xor(lcost, off); lgp2 += __shfl_xor(lgp2, off); }
@@ -370,6 +472,154 @@ __device__ __forceinline__ void ba_linearize_body(const BaDev& P, double radius,
     if (v != 0.0) atomicAdd(&P.pay1[i], v);
   }
 }
+
+// ---- pass B alone (bulk modes; the speculative pass A follows as its own launch on the MFMA / LDS-atomic kernel)
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius) {
+  __shared__ double sStep[STEP_LDS_DOUBLES];
+  __shared__ double sAcc[4];
+  if (threadIdx.x < 4) sAcc[threadIdx.x] = 0.0;
+  stage_step(P, sStep);
+  const double* dc_ = sStep;
+  const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double a_cost = 0, a_mc = 0, a_dp2 = 0, a_p2 = 0;
+  const int wpb = blockDim.x >> 6;
+  for (int chunk = blockIdx.x * wpb + wave; chunk < P.C; chunk += gridDim.x * wpb) {
+    const ObsRec R = load_obs(P, chunk, lane, P.points);
+    D3 cand;
+    backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, a_cost, a_mc, a_dp2, a_p2);
+  }
+  if (P.det) return;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a_cost += __shfl_xor(a_cost, off); a_mc += __shfl_xor(a_mc, off);
+    a_dp2 += __shfl_xor(a_dp2, off); a_p2 += __shfl_xor(a_p2, off);
+  }
+  if (lane == 0) { atomicAdd(&sAcc[0], a_cost); atomicAdd(&sAcc[1], a_mc); atomicAdd(&sAcc[2], a_dp2); atomicAdd(&sAcc[3], a_p2); }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(&P.pay2[threadIdx.x], sAcc[threadIdx.x]);
+}
+
+// ---- deterministic mode, one LM iteration in one sweep: pass B at the current point, then (spec_radius > 0) pass A at
+// the candidate it just formed, with the radius an accepted step will have.  One wave per workgroup (spreads the
+// chunks over the CUs); the candidate landmark stays in registers between the passes.
+__global__ __launch_bounds__(64) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
+  __shared__ double sStep[STEP_LDS_DOUBLES];
+  stage_step(P, sStep);
+  const double* dc_ = sStep;
+  const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+  const int lane = threadIdx.x & 63;
+  double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
+  for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
+    ObsRec R = load_obs(P, chunk, lane, P.points);
+    D3 cand;
+    backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
+    if (spec_radius > 0) {
+      R.p = cand;
+      linearize_chunk(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+    }
+  }
+}
+
+// sharded runs: the decision is taken from the ALL-REDUCED payload2 (device buffer [payload2 | payload1])
+__global__ __launch_bounds__(64) void ba_decide_kernel(LmCtl ctl, double* paybuf, double* ctl_dev) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) decide_device(ctl, paybuf[0], paybuf[1], ctl_dev, paybuf);
+}
+
+// R(list): 28 consecutive segments summed sequentially, then the segment sums added sequentially
+// (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: with payload1, F*F pose-pair blocks
+// (36 values), F pose vectors (18 values), 1 scalar pair from lmV; with payload2, one more workgroup for the four
+// scalars of lmV2; lane = (segment, element).  The last workgroup to arrive publishes the completion word.
+__global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int with_pay2, LmCtl ctl) {
+  __shared__ double sP[RSEG][36];
+  __shared__ double sOut[4];
+  const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
+  const int nd = F * F + F + 1;
+  if (d < nd1) {
+    const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
+    const int stride = d < F * F ? 36 : (d < F * F + F ? 18 : 4);
+    const double* base = d < F * F ? P.pairB : (d < F * F + F ? P.obsV : P.lmV);
+    const int e0 = P.list_start[d], len = P.list_start[nd + 1 + d] - e0;
+    const int seglen = (len + RSEG - 1) / RSEG;
+    for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {  // one pass with 1024 threads
+      const int seg = item / width, e = item % width;
+      double acc = 0.0;
+      const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+      // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
+      // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
+      const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e;
+      for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (q0 + u < b1) acc += v[u];
+      }
+      sP[seg][e] = acc;
+    }
+    __syncthreads();
+    if (tid < width) {
+      double acc = 0.0;
+      for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
+      double* out = P.pay1_out;
+      if (d < F * F) {
+        const int ka = d / F, kb = d % F;
+        out[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
+      } else if (d < F * F + F) {
+        const int k = d - F * F;
+        if (tid < 6) out[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
+        else if (tid < 12) out[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
+        else out[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
+      } else {
+        out[(size_t)n * n + 3 * n + tid] = acc;
+      }
+    }
+  } else if (with_pay2) {
+    const int dl = F * F + F;  // the landmark list
+    const int seg = tid / 4, e = tid % 4;
+    const int e0 = P.list_start[dl], len = P.list_start[nd + 1 + dl] - e0;
+    const int seglen = (len + RSEG - 1) / RSEG;
+    if (seg < RSEG) {
+      double acc = 0.0;
+      const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+      const double* src = P.lmV2 + 4 * (size_t)e0 + e;
+      for (int q0 = b0; q0 < b1; q0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[4 * (size_t)(q0 + u)] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (q0 + u < b1) acc += v[u];
+      }
+      sP[seg][e] = acc;
+    }
+    __syncthreads();
+    if (tid < 4) {
+      double acc = 0.0;
+      for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
+      P.pay2_out[tid] = acc;
+      sOut[tid] = acc;
+    }
+    if (ctl.chain) {  // single rank: these ARE the global sums; decide here, pass A is queued right behind this launch
+      __syncthreads();
+      if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
+    }
+  }
+  if (P.flag) {
+    // payload (host memory) first, system-scope fence, then arrive; the last workgroup publishes the sequence word
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      if (old + 1u == P.arrive_target) {
+        __threadfence_system();
+        __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 
 // ---------------------------------------------------------------------------------------------------
 // Bulk (non-deterministic) linearisation with the Schur products on the f64 matrix cores.
@@ -398,7 +648,8 @@ static inline size_t ba_mfma_lds_bytes(int n, int F) {
          sizeof(uint32_t) * MF_WAVES * 64 + sizeof(int) * MF_WAVES;
 }
 
-__global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double radius, int first_pass) {
+__global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+  apply_ctl(P, radius, ctl);
   extern __shared__ double lds[];
   const int n = P.n, F = P.K - 1;
   double* sZ = lds;                                  // [8][64][18]
@@ -662,576 +913,37 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
   if (threadIdx.x < 2) atomicAdd(&gDU[n + threadIdx.x], sAcc[threadIdx.x]);
 }
 
-__device__ __forceinline__ void ba_backsub_body(const BaDev& P, double radius) {
-  const double* poses_ = P.poses;
-  const double* points_ = P.points;
-  const double* cand_poses_ = P.cand_poses;
-  double* cand_points_ = P.cand_points;
-  const double* dc_ = P.dc;
-  if (P.lm) {
-    if (ldv(&P.lm->done) || !ldv(&P.lm->step_valid)) return;
-    const int c = ldv(&P.lm->cur), nn = P.n > 0 ? P.n : 1;
-    poses_ = P.step[c] + nn; points_ = P.pts[c];
-    dc_ = P.step[1 - c]; cand_poses_ = P.step[1 - c] + nn; cand_points_ = P.pts[1 - c];
-    radius = ldv(&P.lm->radius);
-  } else if (P.step_in) {
-    dc_ = P.step_in;
-    cand_poses_ = P.step_in + (P.n > 0 ? P.n : 1);
-    // the candidate becomes the linearisation point if the step is accepted: leave a device copy for later launches
-    if (blockIdx.x == 0)
-      for (int i = threadIdx.x; i < 7 * P.K; i += blockDim.x) P.cand_poses[i] = cand_poses_[i];
-  }
-  __shared__ double sAcc[4];
-  if (threadIdx.x < 4) sAcc[threadIdx.x] = 0.0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double a_cost = 0, a_mc = 0, a_dp2 = 0, a_p2 = 0;
-  const int wpb = blockDim.x >> 6;
-  for (int chunk = blockIdx.x * wpb + wave; chunk < P.C; chunk += gridDim.x * wpb) {
-    const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
-    const int o = c0 + lane;
-    const bool active = o < c1;
-    int k = 0, j = 0, first = lane, len = 0;
-    double r[2] = {0, 0}, Jc[12], Jp[6], jd[2] = {0, 0}, u = 0, v = 0;
-    double det_c = 0.0, det_mc = 0.0, det_dp2 = 0.0, det_p2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
-    D3 p{0, 0, 1};
-    if (active) {
-      k = P.obs_pose[o]; j = P.obs_point[o];
-      first = P.lm_start[j] - c0; len = P.lm_start[j + 1] - P.lm_start[j];
-      p = D3{points_[3 * j], points_[3 * j + 1], points_[3 * j + 2]};
-      u = P.obs_uv[2 * o]; v = P.obs_uv[2 * o + 1];
-      eval_obs(poses_ + 7 * k, p, u, v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
-      if (k > 0) {
-        const double* d = dc_ + 6 * (k - 1);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * d[a]; jd[1] += Jc[6 + a] * d[a]; }
-      }
-    }
-    int maxlen = len;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
-    double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, wd[3] = {0, 0, 0};
-    if (!P.det) {
-      double t[12] = {Jp[0] * Jp[0] + Jp[3] * Jp[3], Jp[0] * Jp[1] + Jp[3] * Jp[4], Jp[0] * Jp[2] + Jp[3] * Jp[5],
-                      Jp[1] * Jp[1] + Jp[4] * Jp[4], Jp[1] * Jp[2] + Jp[4] * Jp[5], Jp[2] * Jp[2] + Jp[5] * Jp[5],
-                      Jp[0] * r[0] + Jp[3] * r[1], Jp[1] * r[0] + Jp[4] * r[1], Jp[2] * r[0] + Jp[5] * r[1],
-                      Jp[0] * jd[0] + Jp[3] * jd[1], Jp[1] * jd[0] + Jp[4] * jd[1], Jp[2] * jd[0] + Jp[5] * jd[1]};
-      segment_totals<12>(t, lane, first, len > 0 ? first + len - 1 : lane, maxlen);
-      V[0] = t[0]; V[1] = V[3] = t[1]; V[2] = V[6] = t[2]; V[4] = t[3]; V[5] = V[7] = t[4]; V[8] = t[5];
-      gp[0] = t[6]; gp[1] = t[7]; gp[2] = t[8]; wd[0] = t[9]; wd[1] = t[10]; wd[2] = t[11];
-    }
-    for (int t = 0; t < (P.det ? maxlen : 0); ++t) {
-      const int src = (first + t) & 63;
-      double q[6], rr[2], dd[2];
-#pragma unroll
-      for (int i = 0; i < 6; ++i) q[i] = shfl_d(Jp[i], src);
-      rr[0] = shfl_d(r[0], src); rr[1] = shfl_d(r[1], src);
-      dd[0] = shfl_d(jd[0], src); dd[1] = shfl_d(jd[1], src);
-      if (t < len) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          gp[a] += q[a] * rr[0] + q[3 + a] * rr[1];
-          wd[a] += q[a] * dd[0] + q[3 + a] * dd[1];
-#pragma unroll
-          for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b] + q[3 + a] * q[3 + b];
-        }
-      }
-    }
-    if (active) {
-      const double s[3] = {P.sp[3 * j], P.sp[3 * j + 1], P.sp[3 * j + 2]};
-      double Vd[9], Vi[9], De[3], rh[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        rh[a] = -(gp[a] + wd[a]) * s[a];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
-      }
-#pragma unroll
-      for (int a = 0; a < 3; ++a) { De[a] = fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius; Vd[4 * a] += De[a]; }
-      inv3_sym(Vd, Vi);
-      double np[3];
-      const double pv[3] = {p.x, p.y, p.z};
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
-        const double d = y * s[a];
-        np[a] = pv[a] + d;
-        if (lane == first) {
-          a_mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
-          a_dp2 += d * d;
-          a_p2 += pv[a] * pv[a];
-        }
-      }
-      if (lane == first) { cand_points_[3 * j] = np[0]; cand_points_[3 * j + 1] = np[1]; cand_points_[3 * j + 2] = np[2]; }
-      double r0, r1;
-      reproj_residual(cand_poses_ + 7 * k, D3{np[0], np[1], np[2]}, u, v, P.f, P.cx, P.cy, r0, r1);
-      a_cost += 0.5 * (r0 * r0 + r1 * r1);
-      det_c = 0.5 * (r0 * r0 + r1 * r1);
-      det_mc = 0.0; det_dp2 = 0.0; det_p2 = 0.0;
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
-        const double d = y * s[a];
-        det_mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
-        det_dp2 += d * d;
-        det_p2 += pv[a] * pv[a];
-      }
-    }
-    if (P.det) {  // candidate cost of the landmark in observation order, then the landmark's slot
-      double cn = 0.0;
-      for (int t = 0; t < maxlen; ++t) {
-        const double ct = shfl_d(det_c, (first + t) & 63);
-        if (t < len) cn += ct;
-      }
-      if (active && lane == first) {
-        double* lv = P.lmV + 4 * (size_t)j;
-        lv[0] = cn; lv[1] = det_mc; lv[2] = det_dp2; lv[3] = det_p2;
-      }
-    }
-  }
-  if (P.det) {
-    if (!P.arrive2_target) return;  // ba_reduce2_kernel follows as its own launch
-    // ---- fused reduce2: the workgroup that finishes last forms the declared-order sums over lmV and publishes.
-    // Writers: stores, agent-scope fence, arrive.  Reader: sees the final count, fences (acquire), reads lmV —
-    // same code and order as ba_reduce2_body, so the result is bit-identical to the two-launch form.
-    __shared__ int sLast;
-    __shared__ double sP2[RSEG][4];
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0)
-      sLast = __hip_atomic_fetch_add(P.arrive2, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == P.arrive2_target;
-    __syncthreads();
-    if (!sLast) return;
-    __threadfence();
-    const int F = P.K - 1, tid = threadIdx.x;
-    const int dl = F * F + F;  // the landmark list
-    const int e0 = P.list_start[dl], len = P.list_start[F * F + F + 1 + 1 + dl] - e0;
-    const int seglen = (len + RSEG - 1) / RSEG;
-    for (int item = tid; item < RSEG * 4; item += (int)blockDim.x) {
-      const int seg = item / 4, e = item % 4;
-      double acc = 0.0;
-      const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-      const double* src = P.lmV + 4 * (size_t)e0 + e;
-      for (int q0 = b0; q0 < b1; q0 += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[4 * (size_t)(q0 + u)] : 0.0;  // plain loads: the fence above is the acquire
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (q0 + u < b1) acc += v[u];
-      }
-      sP2[seg][e] = acc;
-    }
-    __syncthreads();
-    if (tid < 4) {
-      double acc = 0.0;
-      for (int sg = 0; sg < RSEG; ++sg) acc += sP2[sg][tid];
-      P.pay2_out[tid] = acc;
-    }
-    if (P.flag2 && tid < 64) {  // lanes 0-3 of wave 0 stored the payload; fence, then lane 0 publishes
-      __threadfence_system();
-      if (tid == 0) __hip_atomic_store(P.flag2, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a_cost += __shfl_xor(a_cost, off); a_mc += __shfl_xor(a_mc, off);
-    a_dp2 += __shfl_xor(a_dp2, off); a_p2 += __shfl_xor(a_p2, off);
-  }
-  if (lane == 0) { atomicAdd(&sAcc[0], a_cost); atomicAdd(&sAcc[1], a_mc); atomicAdd(&sAcc[2], a_dp2); atomicAdd(&sAcc[3], a_p2); }
-  __syncthreads();
-  if (threadIdx.x < 4) atomicAdd(&P.pay2[threadIdx.x], sAcc[threadIdx.x]);
-}
-
-// R(list): 28 consecutive segments summed sequentially, then the segment sums added sequentially
-// (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: F*F pose-pair blocks
-// (36 values), F pose vectors (18 values), 1 scalar pair; lane = (segment, element).
-__device__ __forceinline__ void ba_reduce1_body(const BaDev& P) {
-  if (P.lm && ldv(&P.lm->done)) return;
-  if ((int)blockIdx.x >= (P.K - 1) * (P.K - 1) + (P.K - 1) + 1) return;
-  __shared__ double sP[RSEG][36];
-  const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
-  const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
-  const int stride = d < F * F ? 36 : (d < F * F + F ? 18 : 4);
-  const double* base = d < F * F ? P.pairB : (d < F * F + F ? P.obsV : P.lmV);
-  const int nd = F * F + F + 1;
-  const int e0 = P.list_start[d], len = P.list_start[nd + 1 + d] - e0;
-  const int seglen = (len + RSEG - 1) / RSEG;
-  for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {  // one pass with 1024 threads, two with 512
-    const int seg = item / width, e = item % width;
-    double acc = 0.0;
-    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-    // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
-    // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
-    const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e;
-    for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
-      double v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (q0 + u < b1) acc += v[u];
-    }
-    sP[seg][e] = acc;
-  }
-  __syncthreads();
-  if (tid < width) {
-    double acc = 0.0;
-    for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-    double* out = P.pay1_out;
-    if (d < F * F) {
-      const int ka = d / F, kb = d % F;
-      out[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
-    } else if (d < F * F + F) {
-      const int k = d - F * F;
-      if (tid < 6) out[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
-      else if (tid < 12) out[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
-      else out[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
-    } else {
-      out[(size_t)n * n + 3 * n + tid] = acc;
-    }
-  }
-  if (P.flag1) {
-    // payload (host memory) first, system-scope fence, then arrive; the last workgroup publishes the sequence word
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1u == P.arrive_target) {
-        __threadfence_system();
-        __hip_atomic_store(P.flag1, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ void ba_reduce2_body(const BaDev& P) {
-  if (P.lm && (ldv(&P.lm->done) || !ldv(&P.lm->step_valid))) return;
-  __shared__ double sP[RSEG][4];
-  __shared__ double sOut[4];
-  const int F = P.K - 1, tid = threadIdx.x;
-  const int d = F * F + F;  // the landmark list
-  const int seg = tid / 4, e = tid % 4;
-  const int e0 = P.list_start[d], len = P.list_start[F * F + F + 1 + 1 + d] - e0;
-  const int seglen = (len + RSEG - 1) / RSEG;
-  if (seg < RSEG) {
-    double acc = 0.0;
-    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-    const double* src = P.lmV + 4 * (size_t)e0 + e;
-    for (int q0 = b0; q0 < b1; q0 += 8) {
-      double v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[4 * (size_t)(q0 + u)] : 0.0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (q0 + u < b1) acc += v[u];
-    }
-    sP[seg][e] = acc;
-  }
-  __syncthreads();
-  if (tid < 4) {
-    double acc = 0.0;
-    for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-    sOut[tid] = acc;
-    if (!P.lm) P.pay2_out[tid] = acc;
-  }
-  if (!P.lm) {
-    if (P.flag2 && tid < 64) {  // lanes 0-3 of this wave stored the payload; fence, then lane 0 publishes
-      __threadfence_system();
-      if (tid == 0) __hip_atomic_store(P.flag2, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-  __syncthreads();
-  if (tid != 0) return;
-  // ---- step control (same statements, same order as the host loop in ba_lm / oracle/ora_ba.cpp)
-  LmDev& S = *P.lm;
-  const int K = P.K, nn = P.n > 0 ? P.n : 1;
-  const int cur = ldv(&S.cur);
-  double radius = ldv(&S.radius), decrease_factor = ldv(&S.decrease_factor), cost = ldv(&S.cost);
-  const double* poses = P.step[cur] + nn;
-  const double* cand = P.step[1 - cur] + nn;
-  const double cost_new = sOut[0];
-  const double model_change = ldv(&S.mcc) + sOut[1];
-  double step2 = sOut[2], x2 = sOut[3];
-  for (int k = 1; k < K; ++k)
-    for (int a = 0; a < 7; ++a) {
-      const double pv = ldv(&poses[7 * k + a]);
-      const double dd = ldv(&cand[7 * k + a]) - pv;
-      step2 += dd * dd;
-      x2 += pv * pv;
-    }
-  auto publish = [&](int cur_now, double cost_now) {
-    P.done_host[1] = ldv(&S.iterations); P.done_host[2] = ldv(&S.successful); P.done_host[3] = S.termination; P.done_host[4] = cur_now;
-    double* dh = reinterpret_cast<double*>(P.done_host + 6);
-    dh[0] = ldv(&S.initial_cost); dh[1] = cost_now;
-    __threadfence_system();
-    P.done_host[0] = 1;
-  };
-  if (!(model_change > 0)) { S.radius = radius / decrease_factor; S.decrease_factor = decrease_factor * 2; return; }
-  if (sqrt(step2) <= S.parameter_tol * (sqrt(x2) + S.parameter_tol)) { S.termination = 0; S.done = 1; publish(cur, cost); return; }
-  const double cost_change = cost - cost_new;
-  if (fabs(cost_change) <= S.function_tol * cost) {
-    int c2 = cur;
-    if (cost_change > 0) { c2 = 1 - cur; S.cur = c2; S.cost = cost_new; cost = cost_new; }
-    S.termination = 0; S.done = 1; publish(c2, cost);
-    return;
-  }
-  const double rho = cost_change / model_change;
-  if (rho > MIN_REL_DECREASE) {
-    S.cur = 1 - cur; S.cost = cost_new; S.successful = ldv(&S.successful) + 1;
-    const double t = 2.0 * rho - 1.0;
-    radius = radius / fmax(1.0 / 3.0, 1.0 - t * t * t);
-    S.radius = fmin(MAX_RADIUS, radius);
-    S.decrease_factor = 2.0;
-    S.grad_check = 1;
-  } else {
-    S.radius = radius / decrease_factor; S.decrease_factor = decrease_factor * 2;
-  }
-}
-
-// Reduced camera system: scaling, LM diagonal, Cholesky (column sweep, same operation order as the host
-// cholesky_solve), pose step and candidate poses.  One workgroup (WAVE = false) or ONE wavefront of a larger
-// workgroup (WAVE = true, the persistent kernel: LDS traffic of a single wave is ordered, so a workgroup-scope
-// fence + wave barrier replaces s_barrier and the other 15 wavefronts do not have to take part).
-template <bool WAVE>
-__device__ __forceinline__ void ba_solve_body(const BaDev& P) {
-  LmDev& S = *P.lm;
-  auto SYNC = [&]() {
-    if (WAVE) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    } else {
-      __syncthreads();
-    }
-  };
-  if (ldv(&S.done)) return;
-  extern __shared__ double sm[];  // Sm (n*n) | b (n) | sc (n) | Df (n)
-  const int n = P.n, K = P.K, tid = threadIdx.x, nn = n > 0 ? n : 1;
-  const int T = WAVE ? 64 : (int)blockDim.x;
-  double* Sm = sm;
-  double* sB = sm + (size_t)n * n;
-  double* sSc = sB + nn;
-  double* sDf = sSc + nn;
-  __shared__ int sFail;
-  const double* pay = P.pay1;
-  const double* gred = pay + (size_t)n * n;
-  const double* gc = gred + n;
-  const double* dU = gc + n;
-  auto publish = [&]() {
-    P.done_host[1] = S.iterations; P.done_host[2] = S.successful; P.done_host[3] = S.termination; P.done_host[4] = S.cur;
-    double* dh = reinterpret_cast<double*>(P.done_host + 6);
-    dh[0] = S.initial_cost; dh[1] = S.cost;
-    __threadfence_system();
-    P.done_host[0] = 1;
-  };
-  if (tid == 0) {
-    sFail = 0;
-    S.step_valid = 0;
-    bool check = false;
-    if (!ldv(&S.have_scale)) {
-      for (int a = 0; a < n; ++a) S.sc[a] = 1.0 / (1.0 + sqrt(ldv(&dU[a])));
-      S.have_scale = 1;
-      S.cost = ldv(&pay[(size_t)n * n + 3 * n]);
-      S.initial_cost = S.cost;
-      check = true;
-    } else if (ldv(&S.grad_check)) {
-      check = true;
-    }
-    S.grad_check = 0;
-    if (check) {
-      double g2 = ldv(&pay[(size_t)n * n + 3 * n + 1]);
-      for (int a = 0; a < n; ++a) { const double g = ldv(&gc[a]); g2 += g * g; }
-      if (sqrt(g2) <= S.gradient_tol) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
-    }
-    if (!sFail) {
-      if (ldv(&S.iterations) >= S.max_iterations) { S.termination = 1; S.done = 1; publish(); sFail = 2; }
-      else if (ldv(&S.radius) <= MIN_RADIUS) { S.termination = 0; S.done = 1; publish(); sFail = 2; }
-      else S.iterations = ldv(&S.iterations) + 1;
-    }
-  }
-  SYNC();
-  if (sFail) return;
-  const double radius = ldv(&S.radius);
-  // Jacobi scales were written by lane 0 (possibly just now): re-read them through L2, keep copies in LDS
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  for (int a = tid; a < n; a += T) {
-    const double sca = ldv(&S.sc[a]);
-    sSc[a] = sca;
-    sDf[a] = fmin(fmax(ldv(&dU[a]) * sca * sca, MIN_DIAG), MAX_DIAG) / radius;
-  }
-  SYNC();
-  for (int i = tid; i < n * n; i += T) {
-    const int a = i / n, b = i % n;
-    double v = ldv(&pay[i]) * sSc[a] * sSc[b];
-    if (a == b) v += sDf[a];
-    Sm[i] = v;
-  }
-  for (int a = tid; a < n; a += T) sB[a] = -(ldv(&gred[a]) + ldv(&gc[a])) * sSc[a];
-  SYNC();
-  // Cholesky, column by column (row i's dot products run sequentially in k, as on the host).  The right-hand
-  // side rides along as an extra row: y_j = (b_j - sum_{k<j} L_jk y_k) / L_jj is exactly the forward
-  // substitution, product for product.
-  for (int j = 0; j < n; ++j) {
-    if (tid == 0) {
-      double sd = Sm[(size_t)j * n + j];
-      for (int k = 0; k < j; ++k) sd -= Sm[(size_t)j * n + k] * Sm[(size_t)j * n + k];
-      if (!(sd > 0)) sFail = 1; else Sm[(size_t)j * n + j] = sqrt(sd);
-    }
-    SYNC();
-    if (sFail) break;
-    const double l = Sm[(size_t)j * n + j];
-    for (int i = j + 1 + tid; i <= n; i += T) {
-      if (i < n) {
-        double v = Sm[(size_t)i * n + j];
-        for (int k = 0; k < j; ++k) v -= Sm[(size_t)i * n + k] * Sm[(size_t)j * n + k];
-        Sm[(size_t)i * n + j] = v / l;
-      } else {  // the augmented row: forward substitution of column j
-        double v = sB[j];
-        for (int k = 0; k < j; ++k) v -= Sm[(size_t)j * n + k] * sB[k];
-        sB[j] = v / l;
-      }
-    }
-    SYNC();
-  }
-  if (sFail) {  // not positive definite: an invalid step
-    if (tid == 0) { S.radius = ldv(&S.radius) / S.decrease_factor; S.decrease_factor *= 2; }
-    return;
-  }
-  // backward substitution (k descending) as a column sweep
-  for (int k = n - 1; k >= 0; --k) {
-    if (tid == 0) sB[k] = sB[k] / Sm[(size_t)k * n + k];
-    SYNC();
-    const double bk = sB[k];
-    for (int i = tid; i < k; i += T) sB[i] -= Sm[(size_t)k * n + i] * bk;
-    SYNC();
-  }
-  // step, model change (pose part), candidate poses
-  const int c = ldv(&S.cur);
-  double* dc = P.step[1 - c];
-  const double* poses = P.step[c] + nn;
-  double* cand = P.step[1 - c] + nn;
-  if (tid == 0) {
-    double mcc = 0;
-    for (int a = 0; a < n; ++a) {
-      mcc += 0.5 * sB[a] * (sDf[a] * sB[a] - ldv(&gc[a]) * sSc[a]);
-      S.Df[a] = sDf[a];
-    }
-    S.mcc = mcc;
-    S.step_valid = 1;
-  }
-  for (int a = tid; a < n; a += T) dc[a] = sB[a] * sSc[a];
-  for (int k = tid; k < K; k += T) {
-    double pk[7], dk[6], out[7];
-    for (int a = 0; a < 7; ++a) pk[a] = ldv(&poses[7 * k + a]);
-    if (k == 0) { for (int a = 0; a < 7; ++a) cand[a] = pk[a]; }
-    else {
-      for (int a = 0; a < 6; ++a) dk[a] = sB[6 * (k - 1) + a] * sSc[6 * (k - 1) + a];
-      plus_pose(pk, dk, out);
-      for (int a = 0; a < 7; ++a) cand[7 * k + a] = out[a];
-    }
-  }
-}
-
-// By-value wrappers (host-driven loop) and by-pointer wrappers (hipGraph replay: the parameters live in
-// device memory so the instantiated graph never has to be updated between solves).
-__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass) { ba_linearize_body(P, radius, first_pass); }
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius) { ba_backsub_body(P, radius); }
-__global__ __launch_bounds__(1024) void ba_reduce1_kernel(BaDev P) { ba_reduce1_body(P); }
-__global__ __launch_bounds__(128) void ba_reduce2_kernel(BaDev P) { ba_reduce2_body(P); }
-__global__ __launch_bounds__(128) void ba_solve_kernel(BaDev P) { ba_solve_body<false>(P); }
-__global__ __launch_bounds__(64) void ba_linearize_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_linearize_body(P, 0.0, 0); }
-__global__ __launch_bounds__(64) void ba_backsub_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_backsub_body(P, 0.0); }
-__global__ __launch_bounds__(1024) void ba_reduce1_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_reduce1_body(P); }
-__global__ __launch_bounds__(128) void ba_reduce2_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_reduce2_body(P); }
-__global__ __launch_bounds__(128) void ba_solve_gkernel(const BaDev* __restrict__ Pp) { const BaDev P = *Pp; ba_solve_body<false>(P); }
-
-// ---- persistent single-launch solve: the five phases of an LM iteration separated by grid barriers
-// (cdna_hip_programming.md Guideline 16 / MI355X_MICROARCH.md "barrier-counter": every storing wave drains,
-// workgroup barrier, lane-0 agent release, agent atomic arrive, relaxed sc1 poll with s_sleep, ONE agent acquire,
-// workgroup barrier).  All workgroups are trivially co-resident (grid <= 128 x 512 threads on 256 CUs); every spin
-// is bounded and raises LmDev::abort instead of hanging.
-__device__ __forceinline__ bool grid_barrier(LmDev* lm, unsigned target) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  __shared__ int sAbort;
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(&lm->bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned spins = 0;
-    int ab = 0;
-    while (__hip_atomic_load(&lm->bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(4);
-      if (++spins > (1u << 21) || __hip_atomic_load(&lm->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-        __hip_atomic_store(&lm->abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ab = 1;
-        break;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    sAbort = ab;
-  }
-  __syncthreads();
-  return sAbort == 0;
-}
-
-__global__ __launch_bounds__(512) void ba_persistent_kernel(BaDev P, int max_loops) {
-  unsigned epoch = 0;
-  const unsigned G = gridDim.x;
-  for (int it = 0; it < max_loops; ++it) {
-    if (ldv(&P.lm->done)) break;  // written by workgroup 0 before the last barrier: uniform across the grid
-    ba_linearize_body(P, 0.0, 0);
-    if (!grid_barrier(P.lm, ++epoch * G)) break;
-    ba_reduce1_body(P);
-    if (!grid_barrier(P.lm, ++epoch * G)) break;
-    if (blockIdx.x == 0 && threadIdx.x < 64) ba_solve_body<true>(P);
-    if (!grid_barrier(P.lm, ++epoch * G)) break;
-    ba_backsub_body(P, 0.0);
-    if (!grid_barrier(P.lm, ++epoch * G)) break;
-    if (blockIdx.x == 0) ba_reduce2_body(P);
-    if (!grid_barrier(P.lm, ++epoch * G)) break;
-  }
-}
-
 // ----------------------------------------------------------------------------- host side
-namespace {
-bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) { return svo_host_cholesky_solve(A.data(), b.data(), n); }
-}  // namespace
-
-
-
 struct svo_ba {
   svo_ctx* ctx = nullptr;
   svo_camera_info cam{};
   svo_ba_options opt{};
   int window_size = 5, max_landmarks = 0, max_obs = 0, max_poses = 0;
-  svo_allreduce_fn allreduce = nullptr;
+  svo_allreduce_fn allreduce = nullptr;   // in-process emulation of the collective (tests)
   void* allreduce_user = nullptr;
+  void* comm = nullptr;                   // ncclComm_t of a sharded run (svo_ba_set_comm)
   // device problem
   BaDev d;
-  size_t cap_points = 0, cap_obs = 0, cap_chunks = 0, cap_pay1 = 0, cap_pairs = 0;
-  // host mirrors of the loaded problem
-  std::vector<double> h_poses, h_cand_poses;
+  size_t cap_points = 0, cap_obs = 0, cap_pay1 = 0, cap_pairs = 0;
+  std::vector<double> h_poses;            // K x 7 current poses (updated in place by svo_lm_solve)
   int n_points = 0;
-  LmDev* d_lm = nullptr;
   uint8_t* d_arena = nullptr;     // all per-solve inputs in one allocation: one H2D per solve
   uint8_t* h_arena = nullptr;     // pinned staging image of the arena
   size_t arena_cap = 0;
-  BaDev* d_params = nullptr;      // device copy of the kernel parameters (graph kernels read it)
-  hipGraphExec_t graph_exec = nullptr;
-  double t_launch = 0, t_sync = 0, t_upload = 0, t_total = 0; long n_chunks = 0, n_solves = 0;
-  double t_lin = 0, t_host = 0, t_back = 0; long n_lin = 0, n_back = 0;  // host-driven loop phases (SVO_TIMING)
-  int graph_threads = 0;          // solve-kernel block size baked into the graph
-  hipStream_t stream = nullptr;  // BA has its own stream so a solve can overlap the tracker's kernels
-  double* step_buf[2] = {nullptr, nullptr};
-  double* h_pin = nullptr;  // pinned staging: payload1 / payload2 / dc / poses
+  hipStream_t stream = nullptr;   // BA has its own stream so a solve can overlap the tracker's kernels
+  double* d_pay = nullptr;        // [payload2 (PAY2_SLOTS) | payload1]: one buffer, one all-reduce
+  double* d_step = nullptr;       // device copy of [dc | candidate poses] (bulk / sharded runs)
+  // pinned block, fixed layout (never depends on the window size): [flag word (64 B) | step: dc + candidate poses |
+  // payload2 (PAY2_SLOTS) | payload1]
+  uint8_t* h_pin = nullptr;
   size_t pin_bytes = 0;
+  int* h_flag = nullptr;
+  double* h_step = nullptr;
+  double* h_pay = nullptr;
+  // current / candidate buffers of the running solve (swapped on every accepted step)
+  double *cur_points = nullptr, *cand_points = nullptr, *cur_poses = nullptr, *cand_poses = nullptr;
+  bool have_scale = false;
+  std::vector<double> mirror;     // bulk modes: S with the pair blocks mirrored
   // sliding-window graph (BundleAdjuster state, host side; ids sequential — SURVEY C-3)
   struct Obs { float u, v; int64_t id; };
   struct PoseVar { double pose[7]; std::vector<Obs> obs; };
@@ -1241,34 +953,38 @@ struct svo_ba {
   std::vector<int64_t> solve_lm_ids;
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, arrive2_total = 0; int seq = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
+  svo_lm_stats stats{};
+  // SVO_TIMING accumulators
+  double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
 };
 
 static int ba_alloc(svo_ba* ba) {
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   const int Kmax = ba->max_poses, nmax = 6 * (Kmax - 1);
-  ba->cap_points = ba->max_landmarks; ba->cap_obs = ba->max_obs; ba->cap_chunks = ba->max_obs + 1;
+  ba->cap_points = ba->max_landmarks; ba->cap_obs = ba->max_obs;
   ba->cap_pay1 = (size_t)nmax * nmax + 3 * (size_t)nmax + 2;
+  const size_t step_doubles = (size_t)(nmax > 0 ? nmax : 1) + 7 * (size_t)Kmax;
 #define A(ptr, T, cnt) SVO_HIP_CHECK(ctx, hipMalloc((void**)&(ptr), sizeof(T) * (size_t)(cnt)))
-  // two [dc | poses] step buffers: the candidate of an accepted step becomes the linearisation point by a pointer swap
-  A(ba->step_buf[0], double, (nmax > 0 ? nmax : 1) + 7 * Kmax); A(ba->step_buf[1], double, (nmax > 0 ? nmax : 1) + 7 * Kmax);
   A(d.sp, double, 3 * ba->cap_points);
-  A(d.pay1, double, ba->cap_pay1); A(d.pay2, double, 4);
-  A(ba->d_lm, LmDev, 1); A(ba->d_params, BaDev, 1);
-  A(ba->d_arrive, unsigned, 2);
-  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 2 * sizeof(unsigned)));
+  A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
+  A(ba->d_step, double, step_doubles);
+  A(ba->d_arrive, unsigned, 8);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes]
+  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 8 * sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
   A(d.lmV, double, 4 * ba->cap_points);
+  A(d.lmV2, double, 4 * ba->cap_points);
 #undef A
   {
     // pre-size the per-solve input arena and the pair-block store for window-shaped problems (every landmark seen
     // at most once per pose) so that the hot path never allocates; bulk problems beyond this grow lazily
     const size_t M = ba->cap_obs, Kc = (size_t)Kmax;
     const size_t pairs = M * (Kc + 1) / 2 + 64;
-    const size_t est = 16 * 3 * ba->cap_points + 16 * M + 8 * M + 4 * (ba->cap_points + 1) + 4 * (M + 2) * 3 + 8 * pairs + 8 * (Kc * Kc + Kc + 2) + 16 * 256;
+    const size_t est = 16 * 3 * ba->cap_points + 16 * M + 8 * M + 4 * (ba->cap_points + 1) + 4 * (M + 2) * 3 + 8 * pairs + 8 * (Kc * Kc + Kc + 2) +
+                       2 * 56 * Kc + 16 * 256;
     if (est < ((size_t)512 << 20)) {
       ba->arena_cap = est;
       SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_arena, ba->arena_cap));
@@ -1293,20 +1009,26 @@ static int ba_alloc(svo_ba* ba) {
       SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
     }
   }
-  ba->pin_bytes = sizeof(double) * (ba->cap_pay1 + 1400 + 16 * (size_t)Kmax) + 2 * sizeof(BaDev);  // payloads | flags | LmDev image | poses
+  ba->pin_bytes = 64 + sizeof(double) * (step_doubles + PAY2_SLOTS + ba->cap_pay1);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
+  memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
+  ba->h_flag = reinterpret_cast<int*>(ba->h_pin);
+  ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64);
+  ba->h_pay = ba->h_step + step_doubles;
+  d.pay2 = ba->d_pay;
+  d.pay1 = ba->d_pay + PAY2_SLOTS;
   return SVO_OK;
 }
 
 extern "C" void svo_ba_default_options(svo_ba_options* o) {
   if (!o) return;
-  o->max_iterations = 50;
-  o->max_time_s = 0.1;
+  o->max_iterations = 50;                           // Ceres default
+  o->max_time_s = svo_ref::BA_MAX_SOLVER_TIME_S;    // src/bundle_adjuster.cpp:11
   o->function_tolerance = 1e-6;
   o->gradient_tolerance = 1e-10;
   o->parameter_tolerance = 1e-8;
   o->initial_radius = 1e4;
-  o->max_features = 400;
+  o->max_features = svo_ref::MAX_FEATURES;          // src/bundle_adjuster.hpp:75
   o->accumulation = SVO_BA_ACC_AUTO;
 }
 
@@ -1335,18 +1057,16 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (!ba) return;
   BaDev& d = ba->d;
   if (getenv("SVO_TIMING") && ba->n_lin)
-    fprintf(stderr, "[svo ba] host loop: linearize+reduce+D2H %.1f us x %ld, host solve %.1f us, backsub+D2H %.1f us x %ld\n",
-            1e3 * ba->t_lin / ba->n_lin, ba->n_lin, ba->n_back ? 1e3 * ba->t_host / ba->n_back : 0.0, ba->n_back ? 1e3 * ba->t_back / ba->n_back : 0.0, ba->n_back);
-  if (getenv("SVO_TIMING") && ba->n_chunks)
-    fprintf(stderr, "[svo ba] solves %ld chunks %ld graph-launch %.3f ms sync %.3f ms upload %.3f ms total %.3f ms\n", ba->n_solves, ba->n_chunks,
-            ba->t_launch, ba->t_sync, ba->t_upload, ba->t_total);
-  if (ba->graph_exec) (void)hipGraphExecDestroy(ba->graph_exec);
-  void* ptrs[] = {ba->d_arrive, ba->d_lm, ba->d_params, ba->step_buf[0], ba->step_buf[1], d.sp, d.pay1, d.pay2, d.pairB, d.obsV, d.lmV, ba->d_arena};
+    fprintf(stderr, "[svo ba] %ld solves: pass A alone %.1f us x %ld, step (pass B + speculative pass A) %.1f us x %ld, speculation %ld/%ld hit, "
+                    "upload %.3f ms, total %.3f ms\n", ba->n_solves, 1e3 * ba->t_lin / ba->n_lin, ba->n_lin,
+            ba->n_step ? 1e3 * ba->t_step / ba->n_step : 0.0, ba->n_step, ba->n_hit, ba->n_spec, ba->t_upload, ba->t_total);
+  if (ba->stream) (void)hipStreamSynchronize(ba->stream);
+  void* ptrs[] = {ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
-  if (ba->stream) { (void)hipStreamSynchronize(ba->stream); (void)hipStreamDestroy(ba->stream); }
+  if (ba->stream) (void)hipStreamDestroy(ba->stream);
   delete ba;
 }
 
@@ -1356,6 +1076,19 @@ extern "C" int svo_ba_set_allreduce(svo_ba* ba, svo_allreduce_fn fn, void* user)
   ba->allreduce_user = user;
   return SVO_OK;
 }
+
+extern "C" int svo_ba_set_comm(svo_ba* ba, void* nccl_comm) {
+  if (!ba) return SVO_ERR_INVALID;
+  ba->comm = nccl_comm;
+  return SVO_OK;
+}
+
+extern "C" int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats) {
+  if (!ba || !stats) return SVO_ERR_INVALID;
+  *stats = ba->stats;
+  return SVO_OK;
+}
+
 
 // Upload a landmark-major problem (shared by the bulk API and the sliding-window solve).
 static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const double* points3, int M,
@@ -1475,6 +1208,8 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   const size_t o_ob = off; off = al(off + sizeof(int32_t) * obs_pos_v.size());
   const size_t o_pp = off; off = al(off + sizeof(int32_t) * pair_pos_v.size());
   const size_t o_ls = off; off = al(off + sizeof(int32_t) * ls.size());
+  const size_t o_p0 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
+  const size_t o_p1 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
   const size_t total = off;
   if (total > ba->arena_cap) {
     if (ba->d_arena) (void)hipFree(ba->d_arena);
@@ -1498,419 +1233,299 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   if (!pair_pos_v.empty()) memcpy(h + o_pp, pair_pos_v.data(), sizeof(int32_t) * pair_pos_v.size());
   if (!ls.empty()) memcpy(h + o_ls, ls.data(), sizeof(int32_t) * ls.size());
   uint8_t* D = ba->d_arena;
-  d.points = (double*)(D + o_pts); d.cand_points = (double*)(D + o_cpts); d.obs_uv = (double*)(D + o_uv);
+  d.points = (double*)(D + o_pts); d.cand_points = (double*)(D + o_cpts);
+  ba->cur_points = (double*)(D + o_pts); ba->cand_points = (double*)(D + o_cpts);
+  ba->cur_poses = (double*)(D + o_p0); ba->cand_poses = (double*)(D + o_p1); d.obs_uv = (double*)(D + o_uv);
   d.obs_pose = (int32_t*)(D + o_op); d.obs_point = (int32_t*)(D + o_oj); d.lm_start = (int32_t*)(D + o_lm);
   d.chunk_start = (int32_t*)(D + o_ch); d.pair_base = (int32_t*)(D + o_pb); d.obs_pos = (int32_t*)(D + o_ob);
   d.pair_pos = (int32_t*)(D + o_pp); d.list_start = (int32_t*)(D + o_ls);
+  memcpy(h + o_p0, poses7, sizeof(double) * 7 * (size_t)K);
+  memcpy(h + o_p1, poses7, sizeof(double) * 7 * (size_t)K);
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
-  ba->h_cand_poses = ba->h_poses;
-  d.poses = ba->step_buf[0] + (d.n > 0 ? d.n : 1);
-  d.cand_poses = ba->step_buf[1] + (d.n > 0 ? d.n : 1);
-  d.dc = ba->step_buf[1];
-  double* h_pose_stage = ba->h_pin;  // payload area is idle during the upload
-  memcpy(h_pose_stage, poses7, sizeof(double) * 7 * K);
+  d.poses = (double*)(D + o_p0);
+  d.cand_poses = (double*)(D + o_p1);
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(D, h, total, hipMemcpyHostToDevice, st));
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(d.poses, h_pose_stage, sizeof(double) * 7 * K, hipMemcpyHostToDevice, st));
-  if (d.det && has_empty_landmark && npts) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
-  // no wait here: the pinned staging images are next touched by the host after the solve that follows has
-  // drained this stream (ba_lm), and the payload area is written by kernels ordered after the pose copy
+  if (d.det && has_empty_landmark && npts) {
+    SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
+    SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV2, 0, sizeof(double) * 4 * npts, st));
+  }
+  // no wait here: the pinned staging image is next touched by the host after the solve that follows has
+  // drained this stream (ba_lm)
   ba->upload_pending = true;
   return SVO_OK;
 }
 
-// Device-resident LM loop: the host only enqueues iteration chunks and polls a pinned flag.
-static int ba_lm_device(svo_ba* ba, svo_ba_summary* sum) {
+// ---- the two passes as svo_lm_ops (host/lm.cpp drives them) ---------------------------------------------------------
+namespace {
+inline std::chrono::steady_clock::time_point now() { return std::chrono::steady_clock::now(); }
+inline double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+  return std::chrono::duration<double, std::milli>(b - a).count();
+}
+
+// single-rank deterministic solves: the reduce kernel writes the payload straight into pinned host memory and publishes
+// a completion word (no copy kernel, no stream wait); SVO_BA_NO_POLL=1 restores device payload + D2H + stream wait
+bool ba_zero_copy(const svo_ba* ba) {
+  static const bool no_poll = getenv("SVO_BA_NO_POLL") != nullptr;
+  return ba->d.det && !ba->comm && !ba->allreduce && !no_poll;
+}
+
+int ba_wait_flag(svo_ba* ba, int seq) {
   svo_ctx* ctx = ba->ctx;
-  BaDev& d = ba->d;
-  d.arrive2_target = 0; d.step_in = nullptr; d.flag1 = d.flag2 = nullptr;  // host-loop-only features
-  hipStream_t st = ba->stream;
-  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
-  const auto t_begin = std::chrono::steady_clock::now();
-  int* done_host = reinterpret_cast<int*>(ba->h_pin + ba->cap_pay1 + 16);
-  double* h_fin = reinterpret_cast<double*>(done_host + 6);
-  LmDev init;
-  memset(&init, 0, sizeof(init));
-  init.radius = ba->opt.initial_radius; init.decrease_factor = 2.0;
-  init.function_tol = ba->opt.function_tolerance; init.gradient_tol = ba->opt.gradient_tolerance;
-  init.parameter_tol = ba->opt.parameter_tolerance; init.max_iterations = ba->opt.max_iterations;
-  init.termination = 1;
-  LmDev* h_init = reinterpret_cast<LmDev*>(ba->h_pin + ba->cap_pay1 + 32);
-  *h_init = init;
-  memset(done_host, 0, 6 * sizeof(int));
-  h_fin[0] = h_fin[1] = 0.0;
-  d.lm = ba->d_lm;
-  d.pts[0] = d.points; d.pts[1] = d.cand_points;
-  d.step[0] = ba->step_buf[0]; d.step[1] = ba->step_buf[1];  // ba_upload put the poses into step_buf[0] + nn
-  d.done_host = done_host;
-  d.pay1_out = d.pay1; d.pay2_out = d.pay2;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_lm, h_init, sizeof(LmDev), hipMemcpyHostToDevice, st));
-  const size_t solve_lds = ((size_t)n * n + n + 8) * sizeof(double);
-  // One hipGraph = `chunk` LM iterations x 5 kernels, captured once per adjuster with worst-case grids
-  // (extra workgroups exit immediately); replayed with ONE launch call per chunk.
-  const int chunk = 3;  // iterations between two polls of the done flag (typical solve: 5-6 iterations)
-  const int Kmax = ba->max_poses, nmax = 6 * (Kmax - 1);
-  const int nd_max = (Kmax - 1) * (Kmax - 1) + (Kmax - 1) + 1;
-  const size_t solve_lds_max = ((size_t)nmax * nmax + 3 * nmax + 8) * sizeof(double);
-  const int solve_threads = nmax < 64 ? 64 : 128;
-  if (!ba->graph_exec) {
-    if (solve_lds_max > 64 * 1024)
-      SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_solve_gkernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds_max));
-    hipGraph_t graph = nullptr;
-    SVO_HIP_CHECK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    const int lin_grid = 256;  // grid-stride over the wave chunks
-    for (int it = 0; it < chunk; ++it) {
-      hipLaunchKernelGGL(ba_linearize_gkernel, dim3(lin_grid), dim3(64), 64, st, ba->d_params);
-      hipLaunchKernelGGL(ba_reduce1_gkernel, dim3(nd_max), dim3(1024), 0, st, ba->d_params);
-      hipLaunchKernelGGL(ba_solve_gkernel, dim3(1), dim3(solve_threads), solve_lds_max, st, ba->d_params);
-      hipLaunchKernelGGL(ba_backsub_gkernel, dim3(lin_grid), dim3(64), 0, st, ba->d_params);
-      hipLaunchKernelGGL(ba_reduce2_gkernel, dim3(1), dim3(128), 0, st, ba->d_params);
+  const auto t0 = now();
+  unsigned spins = 0;
+  while (__atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE) != seq) {
+    __builtin_ia32_pause();
+    if (++spins > 4096u && (spins & 63u) == 0) sched_yield();  // long wait: stay polite when threads outnumber cores
+    if ((spins & 0xFFFFu) == 0 && ms_between(t0, now()) > 10000.0) {  // never expected: fall back to the stream wait
+      SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+      if (__atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE) != seq) { ctx->err = "ba: completion word never arrived"; return SVO_ERR_HIP; }
     }
-    SVO_HIP_CHECK(ctx, hipStreamEndCapture(st, &graph));
-    SVO_HIP_CHECK(ctx, hipGraphInstantiate(&ba->graph_exec, graph, nullptr, nullptr, 0));
-    (void)hipGraphDestroy(graph);
-  }
-  // parameters of this solve -> device (pinned staging, one copy)
-  BaDev* h_params = reinterpret_cast<BaDev*>(ba->h_pin + ba->cap_pay1 + 900);
-  *h_params = d;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_params, h_params, sizeof(BaDev), hipMemcpyHostToDevice, st));
-  (void)solve_lds;
-  int enqueued = 0;
-  bool done = false;
-  while (!done && enqueued < ba->opt.max_iterations + 2) {
-    const auto tl0 = std::chrono::steady_clock::now();
-    SVO_HIP_CHECK(ctx, hipGraphLaunch(ba->graph_exec, st));
-    enqueued += chunk;
-    const auto tl1 = std::chrono::steady_clock::now();
-    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    const auto tl2 = std::chrono::steady_clock::now();
-    ba->t_launch += std::chrono::duration<double, std::milli>(tl1 - tl0).count();
-    ba->t_sync += std::chrono::duration<double, std::milli>(tl2 - tl1).count();
-    ba->n_chunks++;
-    done = *reinterpret_cast<volatile int*>(done_host) != 0;
-    if (!done && ba->opt.max_time_s > 0 &&
-        std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() >= ba->opt.max_time_s) break;
-  }
-  int cur = 0, iterations = 0, successful = 0, termination = 1;
-  double initial_cost = 0, cost = 0;
-  if (done) {
-    iterations = done_host[1]; successful = done_host[2]; termination = done_host[3]; cur = done_host[4];
-    initial_cost = h_fin[0]; cost = h_fin[1];
-  } else {  // stopped by the wall clock (src/bundle_adjuster.cpp:11) or the safety cap: read the state back
-    SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_init, ba->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, st));
-    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    iterations = h_init->iterations; successful = h_init->successful; termination = 1; cur = h_init->cur;
-    initial_cost = h_init->initial_cost; cost = h_init->cost;
-  }
-  d.lm = nullptr;
-  d.points = d.pts[cur]; d.cand_points = d.pts[1 - cur];
-  d.poses = d.step[cur] + nn; d.cand_poses = d.step[1 - cur] + nn; d.dc = d.step[1 - cur];
-  double* h_p = ba->h_pin;  // payload area is free in this mode
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_p, d.poses, sizeof(double) * 7 * K, hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  ba->h_poses.assign(h_p, h_p + 7 * (size_t)K);
-  ba->h_cand_poses = ba->h_poses;
-  if (sum) {
-    sum->iterations = iterations; sum->successful_steps = successful; sum->termination = termination;
-    sum->initial_cost = initial_cost; sum->final_cost = cost;
-    sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
   return SVO_OK;
 }
 
-// One launch per solve: the whole LM loop runs in ba_persistent_kernel.
-static int ba_lm_persistent(svo_ba* ba, svo_ba_summary* sum) {
+// d_pay[off, off + cnt) summed in place over the ranks: ONE collective, asynchronous on the adjuster's stream with RCCL
+int ba_allreduce(svo_ba* ba, size_t off, size_t cnt) {
   svo_ctx* ctx = ba->ctx;
-  BaDev& d = ba->d;
-  d.arrive2_target = 0; d.step_in = nullptr; d.flag1 = d.flag2 = nullptr;  // host-loop-only features
-  hipStream_t st = ba->stream;
-  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
-  const auto t_begin = std::chrono::steady_clock::now();
-  int* done_host = reinterpret_cast<int*>(ba->h_pin + ba->cap_pay1 + 16);
-  double* h_fin = reinterpret_cast<double*>(done_host + 6);
-  LmDev* h_init = reinterpret_cast<LmDev*>(ba->h_pin + ba->cap_pay1 + 32);
-  memset(h_init, 0, sizeof(LmDev));
-  h_init->radius = ba->opt.initial_radius; h_init->decrease_factor = 2.0;
-  h_init->function_tol = ba->opt.function_tolerance; h_init->gradient_tol = ba->opt.gradient_tolerance;
-  h_init->parameter_tol = ba->opt.parameter_tolerance; h_init->max_iterations = ba->opt.max_iterations;
-  h_init->termination = 1;
-  memset(done_host, 0, 6 * sizeof(int));
-  h_fin[0] = h_fin[1] = 0.0;
-  d.lm = ba->d_lm;
-  d.pts[0] = d.points; d.pts[1] = d.cand_points;
-  d.step[0] = ba->step_buf[0]; d.step[1] = ba->step_buf[1];
-  d.done_host = done_host;
-  d.pay1_out = d.pay1; d.pay2_out = d.pay2;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_lm, h_init, sizeof(LmDev), hipMemcpyHostToDevice, st));
-  const int nd = (K - 1) * (K - 1) + (K - 1) + 1;
-  int grid = std::max(nd, svo_div_up(d.C, 8));
-  if (grid > 128) grid = 128;  // both the chunk loop and ... (reduce1 needs grid >= nd: K <= 11)
-  if (grid < nd) { d.lm = nullptr; ctx->err = "ba: window too large for the persistent kernel"; return SVO_ERR_INVALID; }
-  const size_t lds = ((size_t)n * n + 3 * (size_t)nn + 8) * sizeof(double);
-  hipLaunchKernelGGL(ba_persistent_kernel, dim3(grid), dim3(512), lds, st, d, ba->opt.max_iterations + 2);
-  SVO_HIP_CHECK(ctx, hipGetLastError());
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  const bool done = done_host[0] != 0;
-  int cur = 0, iterations = 0, successful = 0, termination = 1;
-  double initial_cost = 0, cost = 0;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_init, ba->d_lm, sizeof(LmDev), hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  if (h_init->abort) { d.lm = nullptr; ctx->err = "ba: persistent kernel grid barrier timed out"; return SVO_ERR_HIP; }
-  if (done) {
-    iterations = done_host[1]; successful = done_host[2]; termination = done_host[3]; cur = done_host[4];
-    initial_cost = h_fin[0]; cost = h_fin[1];
-  } else {
-    iterations = h_init->iterations; successful = h_init->successful; termination = 1; cur = h_init->cur;
-    initial_cost = h_init->initial_cost; cost = h_init->cost;
-  }
-  d.lm = nullptr;
-  d.points = d.pts[cur]; d.cand_points = d.pts[1 - cur];
-  d.poses = d.step[cur] + nn; d.cand_poses = d.step[1 - cur] + nn; d.dc = d.step[1 - cur];
-  double* h_p = ba->h_pin;
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_p, d.poses, sizeof(double) * 7 * K, hipMemcpyDeviceToHost, st));
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-  ba->h_poses.assign(h_p, h_p + 7 * (size_t)K);
-  ba->h_cand_poses = ba->h_poses;
-  if (sum) {
-    sum->iterations = iterations; sum->successful_steps = successful; sum->termination = termination;
-    sum->initial_cost = initial_cost; sum->final_cost = cost;
-    sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  if (ba->comm) {
+    const char* why = nullptr;
+    if (svo_rccl_allreduce_f64(ba->d_pay + off, cnt, ba->comm, ba->stream, &why)) {
+      ctx->err = std::string("ba: ncclAllReduce failed: ") + (why ? why : "?");
+      return SVO_ERR_HIP;
+    }
+  } else if (ba->allreduce) {
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+    if (ba->allreduce(ba->d_pay + off, cnt, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
   }
   return SVO_OK;
 }
 
-// The LM loop (mirrors oracle/ora_ba.cpp step for step).
-static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
-  if (ba->d.det && !ba->allreduce && getenv("SVO_BA_PERSISTENT") && ba->d.K <= 11 && !(ba->opt.max_time_s > 0)) return ba_lm_persistent(ba, sum);
-  // Measured on MI355X (bench workload, ~14 LM iterations per solve): host-driven loop 81 us/iteration,
-  // device-resident loop with plain launches 97 us, hipGraph replay 81 us + idle tail iterations (7.6 us of dead
-  // time per graph node).  The host-driven loop stays the default; SVO_BA_DEVICE_LM=1 selects the graph path.
-  if (ba->d.det && !ba->allreduce && getenv("SVO_BA_DEVICE_LM")) return ba_lm_device(ba, sum);
-  ba->d.lm = nullptr;
+// d_pay[off, off + cnt) -> h_pay, stream drained (the one host wait of an LM iteration outside the zero-copy mode)
+int ba_fetch(svo_ba* ba, size_t off, size_t cnt) {
   svo_ctx* ctx = ba->ctx;
-  BaDev& d = ba->d;
-  hipStream_t st = ba->stream;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->h_pay + off, ba->d_pay + off, sizeof(double) * cnt, hipMemcpyDeviceToHost, ba->stream));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+  return SVO_OK;
+}
+
+// payload1 as the step control wants it: S full.  The deterministic reduce writes every pose-pair block; the bulk kernels
+// write each unordered pose pair once, mirrored here.
+void ba_payload1_out(svo_ba* ba, const double* src, double* dst) {
+  const BaDev& d = ba->d;
   const int n = d.n, K = d.K;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
-  const auto t_begin = std::chrono::steady_clock::now();
-  double* h_pay1 = ba->h_pin;
-  double* h_pay2 = h_pay1 + pay1;
-  double* h_dc = h_pay2 + 8;
-  double* h_cp = h_dc + (n > 0 ? n : 1);  // contiguous with h_dc: one H2D per iteration
-  const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
-  const size_t lds_bytes = pay1 * sizeof(double);
-  const bool use_mfma = !d.det && ba->mfma_ok;
-  const size_t mfma_lds = ba_mfma_lds_bytes(n, K - 1);
-  const int mfma_grid = std::max(1, std::min(svo_div_up(d.C, MF_WAVES), 256));
-  if (use_mfma) {
+  memcpy(dst, src, sizeof(double) * pay1);
+  if (d.det) return;
+  for (int a = 0; a < K - 1; ++a)
+    for (int b = 0; b < K - 1; ++b) {
+      if (a == b) continue;
+      for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) {
+          const size_t ij = (size_t)(6 * a + i) * n + 6 * b + j, ji = (size_t)(6 * b + j) * n + 6 * a + i;
+          dst[ij] = src[ij] + src[ji];
+        }
+    }
+}
+
+// launch pass A in the bulk modes (accumulates into d.pay1, which the caller zeroed).  ctl != null: the point and the
+// radius come from the chained decision on the device.
+int ba_launch_bulk_linearize(svo_ba* ba, double radius, int first, const double* ctl) {
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  if (d.C <= 0) return SVO_OK;
+  const int n = d.n;
+  const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, ba->stream);
+  if (ba->mfma_ok) {
+    const size_t mfma_lds = ba_mfma_lds_bytes(n, d.K - 1);
+    const int mfma_grid = std::max(1, std::min(svo_div_up(d.C, MF_WAVES), 256));
     SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
-  } else if (!d.det && lds_bytes > 64 * 1024) {
-    SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  }
-  std::vector<double> sc(n, 0.0), Sm((size_t)n * n), rhs(n), Df(n), Sfull((size_t)n * n);
-  bool have_scale = false;
-  double radius = ba->opt.initial_radius, decrease_factor = 2.0;
-  double* cur_points = d.points;
-  double* cand_points = d.cand_points;
-  double* cur_poses = d.poses;
-  double* cand_poses = d.cand_poses;
-
-  auto now = [] { return std::chrono::steady_clock::now(); };
-  auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-  // Single-rank deterministic solves poll completion words that the reduce kernels publish in pinned memory
-  // (after a system-scope fence) instead of a stream wait per half-iteration; SVO_BA_NO_POLL=1 restores the waits.
-  const bool poll = d.det && !ba->allreduce && !getenv("SVO_BA_NO_POLL");
-  // SVO_BA_FUSE=1: back-substitution + reduce2 in one launch (the last workgroup reduces).  Measured on the bench
-  // workload: +1.5 % frames/s at 8 streams, -4 % for a single stream (27 vs 22 us per half-iteration: the agent-scope
-  // fences and the 64-thread tail cost more than the saved launch), so the two-launch form stays the default.
-  const bool fuse2 = d.det && d.C > 0 && getenv("SVO_BA_FUSE") != nullptr;
-  int* h_flag1 = reinterpret_cast<int*>(h_pay2 + 6);
-  int* h_flag2 = reinterpret_cast<int*>(h_pay2 + 7);
-  d.flag1 = poll ? h_flag1 : nullptr; d.flag2 = poll ? h_flag2 : nullptr; d.arrive = ba->d_arrive;
-  int rc_poll = 0;
-  auto wait_flag = [&](int* flag, int seq) -> int {
-    const auto t0 = now();
-    unsigned spins = 0;
-    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-      __builtin_ia32_pause();
-      if (++spins > 4096u && (spins & 63u) == 0) sched_yield();  // long wait: stay polite when threads outnumber cores
-      if ((spins & 0xFFFFu) == 0 && ms(t0, now()) > 10000.0) {  // never expected: fall back to the stream wait
-        SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { ctx->err = "ba: completion word never arrived"; return SVO_ERR_HIP; }
-      }
-    }
-    return SVO_OK;
-  };
-  auto linearize = [&](double rad) -> int {
-    const auto tp0 = now();
-    d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
-    if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
-    if (d.C > 0) {
-      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      if (d.det) hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, rad, have_scale ? 0 : 1);  // one wave per workgroup: spreads the chunks over the CUs
-      else if (use_mfma) hipLaunchKernelGGL(ba_linearize_mfma_kernel, dim3(mfma_grid), dim3(64 * MF_WAVES), mfma_lds, st, d, rad, have_scale ? 0 : 1);
-      else hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, st, d, rad, have_scale ? 0 : 1);
-    }
-    // single rank + deterministic mode: the reduce kernel writes the payload straight into pinned host
-    // memory (no copy kernel); a sharded run keeps it on the device for the all-reduce
-    const bool zero_copy = d.det && !ba->allreduce;
-    d.pay1_out = zero_copy ? h_pay1 : d.pay1;
-    d.pay2_out = zero_copy ? h_pay2 : d.pay2;
-    const int nred = (K - 1) * (K - 1) + (K - 1) + 1;
-    if (poll) { ba->arrive_total += (unsigned)nred; d.arrive_target = ba->arrive_total; d.seq = ++ba->seq; }
-    if (d.det) hipLaunchKernelGGL(ba_reduce1_kernel, dim3(nred), dim3(1024), 0, st, d);
-    SVO_HIP_CHECK(ctx, hipGetLastError());
-    if (poll) { rc_poll = wait_flag(h_flag1, d.seq); if (rc_poll) return rc_poll; }
-    if (ba->allreduce) {
-      SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-      if (ba->allreduce(d.pay1, pay1, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
-    }
-    if (!zero_copy) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay1, d.pay1, sizeof(double) * pay1, hipMemcpyDeviceToHost, st));
-    if (!poll) SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    // mirror the upper pair blocks (kernel writes each unordered pose pair once)
-    const double* S = h_pay1;
-    for (int a = 0; a < K - 1; ++a)
-      for (int b = 0; b < K - 1; ++b)
-        for (int i = 0; i < 6; ++i)
-          for (int j = 0; j < 6; ++j) {
-            const size_t ij = (size_t)(6 * a + i) * n + 6 * b + j, ji = (size_t)(6 * b + j) * n + 6 * a + i;
-            Sfull[ij] = (a == b || d.det) ? S[ij] : S[ij] + S[ji];
-          }
-    ba->t_lin += ms(tp0, now()); ba->n_lin++;
-    return SVO_OK;
-  };
-  auto gradient_norm = [&]() {
-    const double* gc = h_pay1 + (size_t)n * n + n;
-    double g2 = h_pay1[pay1 - 1];
-    for (int a = 0; a < n; ++a) g2 += gc[a] * gc[a];
-    return sqrt(g2);
-  };
-
-  int iterations = 0, successful = 0, termination = 1;
-  int rc = linearize(radius);
-  if (rc) return rc;
-  double cost = h_pay1[pay1 - 2];
-  const double initial_cost = cost;
-  {
-    const double* dU = h_pay1 + (size_t)n * n + 2 * (size_t)n;
-    for (int a = 0; a < n; ++a) sc[a] = 1.0 / (1.0 + sqrt(dU[a]));
-    have_scale = true;
-  }
-  bool need_linearize = false;
-  if (gradient_norm() <= ba->opt.gradient_tolerance) termination = 0;
-  else
-    while (true) {
-      if (iterations >= ba->opt.max_iterations) { termination = 1; break; }
-      if (ba->opt.max_time_s > 0 &&
-          std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count() >= ba->opt.max_time_s) {
-        termination = 1; break;  // src/bundle_adjuster.cpp:11 (wall clock; disabled for parity runs)
-      }
-      if (radius <= MIN_RADIUS) { termination = 0; break; }
-      ++iterations;
-      if (need_linearize) { rc = linearize(radius); if (rc) return rc; need_linearize = false; }
-      const double* gred = h_pay1 + (size_t)n * n;
-      const double* gc = gred + n;
-      const double* dU = gc + n;
-      const auto th0 = now();
-      for (int a = 0; a < n; ++a) {
-        Df[a] = std::min(std::max(dU[a] * sc[a] * sc[a], MIN_DIAG), MAX_DIAG) / radius;
-        for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = Sfull[(size_t)a * n + b] * sc[a] * sc[b];
-        Sm[(size_t)a * n + a] += Df[a];
-        rhs[a] = -(gred[a] + gc[a]) * sc[a];  // kernel accumulates only the -Y g_p part of the reduced gradient
-      }
-      const bool ok = n == 0 || cholesky_solve(Sm, rhs, n);
-      bool step_ok = false;
-      double cost_new = 0, model_change = 0, step2 = 0, x2 = 0;
-      if (ok) {
-        double mcc = 0;
-        for (int a = 0; a < n; ++a) {
-          mcc += 0.5 * rhs[a] * (Df[a] * rhs[a] - gc[a] * sc[a]);
-          h_dc[a] = rhs[a] * sc[a];
-        }
-        for (int k = 0; k < K; ++k) {
-          if (k == 0) memcpy(&ba->h_cand_poses[0], &ba->h_poses[0], 7 * sizeof(double));
-          else plus_pose(&ba->h_poses[7 * k], &h_dc[6 * (k - 1)], &ba->h_cand_poses[7 * k]);
-        }
-        memcpy(h_cp, ba->h_cand_poses.data(), sizeof(double) * 7 * K);
-        const auto tb0 = now();
-        ba->t_host += ms(th0, tb0);
-        // one H2D: [dc (n) | candidate poses (7K)] are adjacent both in the pinned buffer and on the device
-        d.poses = cur_poses; d.cand_poses = cand_poses; d.dc = cand_poses - (n > 0 ? n : 1);
-        d.step_in = h_dc;  // zero-copy: the kernel reads the 6(K-1)+7K doubles straight from the pinned buffer
-        if (!d.det) SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay2, 0, sizeof(double) * 4, st));
-        d.points = cur_points; d.cand_points = cand_points;
-        if (d.C > 0) {
-          SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB, st);
-          if (d.det) {
-            d.arrive2 = ba->d_arrive + 1;
-            d.arrive2_target = 0;
-            if (fuse2) { if (poll) d.seq = ++ba->seq; ba->arrive2_total += (unsigned)d.C; d.arrive2_target = ba->arrive2_total; }
-            hipLaunchKernelGGL(ba_backsub_kernel, dim3(d.C), dim3(64), 0, st, d, radius);
-          }
-          else hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
-        }
-        if (poll && !fuse2) d.seq = ++ba->seq;
-        if (d.det && !fuse2) hipLaunchKernelGGL(ba_reduce2_kernel, dim3(1), dim3(128), 0, st, d);
-        SVO_HIP_CHECK(ctx, hipGetLastError());
-        if (poll) { rc = wait_flag(h_flag2, d.seq); if (rc) return rc; }
-        if (ba->allreduce) {
-          SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-          if (ba->allreduce(d.pay2, 4, ba->allreduce_user)) { ctx->err = "ba: allreduce callback failed"; return SVO_ERR_INVALID; }
-        }
-        if (!(d.det && !ba->allreduce)) SVO_HIP_CHECK(ctx, hipMemcpyAsync(h_pay2, d.pay2, sizeof(double) * 4, hipMemcpyDeviceToHost, st));
-        if (!poll) SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        ba->t_back += ms(tb0, now()); ba->n_back++;
-        cost_new = h_pay2[0];
-        model_change = mcc + h_pay2[1];
-        step2 = h_pay2[2]; x2 = h_pay2[3];
-        for (int k = 1; k < K; ++k)
-          for (int a = 0; a < 7; ++a) {
-            const double dd = ba->h_cand_poses[7 * k + a] - ba->h_poses[7 * k + a];
-            step2 += dd * dd;
-            x2 += ba->h_poses[7 * k + a] * ba->h_poses[7 * k + a];
-          }
-        step_ok = model_change > 0;
-      }
-      if (!step_ok) { radius /= decrease_factor; decrease_factor *= 2; need_linearize = true; continue; }
-      auto accept = [&]() {
-        ba->h_poses = ba->h_cand_poses;
-        std::swap(cur_points, cand_points);
-        std::swap(cur_poses, cand_poses);  // the candidate poses are already on the device
-        cost = cost_new;
-      };
-      if (sqrt(step2) <= ba->opt.parameter_tolerance * (sqrt(x2) + ba->opt.parameter_tolerance)) { termination = 0; break; }
-      const double cost_change = cost - cost_new;
-      if (fabs(cost_change) <= ba->opt.function_tolerance * cost) {
-        if (cost_change > 0) accept();
-        termination = 0;
-        break;
-      }
-      const double rho = cost_change / model_change;
-      if (getenv("SVO_BA_TRACE"))
-        fprintf(stderr, "[hip] it %d cost %.17g new %.17g model %.17g rho %.6g radius %.6g\n", iterations, cost, cost_new, model_change, rho, radius);
-      if (rho > MIN_REL_DECREASE) {
-        accept();
-        ++successful;
-        const double t = 2.0 * rho - 1.0;
-        radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
-        radius = std::min(MAX_RADIUS, radius);
-        decrease_factor = 2.0;
-        rc = linearize(radius);
-        if (rc) return rc;
-        if (gradient_norm() <= ba->opt.gradient_tolerance) { termination = 0; break; }
-      } else {
-        radius /= decrease_factor; decrease_factor *= 2; need_linearize = true;
-      }
-    }
-  if (poll) SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));  // nothing is pending; keeps later users of the stream ordered
-  d.flag1 = d.flag2 = nullptr;
-  // leave the result in d.points / d.poses
-  d.points = cur_points; d.cand_points = cand_points; d.poses = cur_poses; d.cand_poses = cand_poses;
-  if (sum) {
-    sum->iterations = iterations; sum->successful_steps = successful; sum->termination = termination;
-    sum->initial_cost = initial_cost; sum->final_cost = cost;
-    sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+    hipLaunchKernelGGL(ba_linearize_mfma_kernel, dim3(mfma_grid), dim3(64 * MF_WAVES), mfma_lds, ba->stream, d, radius, first, ctl);
+  } else {
+    const size_t lds_bytes = pay1 * sizeof(double);
+    const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
+    if (lds_bytes > 64 * 1024)
+      SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, ba->stream, d, radius, first, ctl);
   }
   return SVO_OK;
+}
+
+// deterministic mode: aim the reduce kernel at pinned host memory or at the device payload; `publish` = this launch is
+// the last of the iteration: its last workgroup publishes the completion word the host polls
+void ba_aim_reduce(svo_ba* ba, int n_blocks, bool publish) {
+  BaDev& d = ba->d;
+  const bool zc = ba_zero_copy(ba);
+  d.pay2_out = zc ? ba->h_pay : ba->d_pay;
+  d.pay1_out = d.pay2_out + PAY2_SLOTS;
+  d.flag = zc && publish ? ba->h_flag : nullptr;
+  d.arrive = ba->d_arrive;
+  if (d.flag) { ba->arrive_total += (unsigned)n_blocks; d.arrive_target = ba->arrive_total; d.seq = ++ba->seq; }
+}
+
+const LmCtl kNoCtl = {0, 0, 0, 0, 0};
+
+int op_linearize(void* user, double radius, int first, double* pay1_out) {
+  svo_ba* ba = static_cast<svo_ba*>(user);
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  hipStream_t st = ba->stream;
+  const auto t0 = now();
+  const int n = d.n, K = d.K;
+  const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  if (d.det) {
+    const int nd = (K - 1) * (K - 1) + (K - 1) + 1;
+    if (d.C > 0) {
+      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
+      hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
+    }
+    ba_aim_reduce(ba, nd, true);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl);
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+    if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
+  } else {
+    SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
+    const int rc = ba_launch_bulk_linearize(ba, radius, first, nullptr);
+    if (rc) return rc;
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+  }
+  if (!ba_zero_copy(ba)) {
+    int rc = ba_allreduce(ba, PAY2_SLOTS, pay1);
+    if (!rc) rc = ba_fetch(ba, PAY2_SLOTS, pay1);
+    if (rc) return rc;
+  }
+  ba_payload1_out(ba, ba->h_pay + PAY2_SLOTS, pay1_out);
+  ba->t_lin += ms_between(t0, now()); ba->n_lin++;
+  return SVO_OK;
+}
+
+// Pass B, and — in the same call, without the host in between — pass A for the next LM iteration:
+//   ctl->spec_radius > 0  same sweep (deterministic: ONE kernel; bulk: back-to-back launches), ONE collective;
+//   ctl->chain            pass B -> [all-reduce of payload2] -> decision on the device -> pass A -> [all-reduce of payload1].
+int op_step(void* user, const double* dc, const double* cand_poses7, double radius, const svo_lm_step_ctl* ctl, double* pay2_out,
+            double* pay1_next_out, double* next_radius, int* next_at_candidate) {
+  svo_ba* ba = static_cast<svo_ba*>(user);
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  hipStream_t st = ba->stream;
+  const auto t0 = now();
+  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
+  const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  const double spec_radius = ctl->spec_radius;
+  const bool same_sweep = spec_radius > 0, chain = !same_sweep && ctl->chain != 0;
+  const bool sharded = ba->comm || ba->allreduce;
+  const LmCtl lc = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, chain && !sharded ? 1 : 0};
+  *next_radius = 0.0; *next_at_candidate = 0;
+  // [dc | candidate poses]: adjacent in the pinned block; the kernels stage them into LDS
+  if (n > 0) memcpy(ba->h_step, dc, sizeof(double) * n);
+  memcpy(ba->h_step + nn, cand_poses7, sizeof(double) * 7 * K);
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  d.ctl_dev = reinterpret_cast<double*>(ba->d_arrive + 2);
+  const bool zc = ba_zero_copy(ba);
+  if (zc) {
+    d.step_in = ba->h_step;  // read in place from pinned memory: no H2D blit per LM iteration
+  } else {
+    SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_step, ba->h_step, sizeof(double) * (nn + 7 * K), hipMemcpyHostToDevice, st));
+    d.step_in = ba->d_step;
+  }
+  const bool next = same_sweep || chain;
+  if (d.det) {
+    const int nd = (K - 1) * (K - 1) + (K - 1) + 1;
+    if (d.C > 0) {
+      SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
+      hipLaunchKernelGGL(ba_step_kernel, dim3(d.C), dim3(64), 0, st, d, radius, same_sweep ? spec_radius : 0.0);
+    }
+    if (!chain) {
+      const int blocks = (same_sweep ? nd : 0) + 1;
+      ba_aim_reduce(ba, blocks, true);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(1024), 0, st, d, same_sweep ? nd : 0, 1, kNoCtl);
+    } else {
+      ba_aim_reduce(ba, 1, false);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(1024), 0, st, d, 0, 1, lc);  // single rank: decides right there
+      if (sharded) {
+        int rc = ba_allreduce(ba, 0, PAY2_SLOTS);
+        if (rc) return rc;
+        const LmCtl lcs = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 1};
+        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, lcs, ba->d_pay, d.ctl_dev);
+      }
+      if (d.C > 0) {
+        SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
+        hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, 0.0, 0, (const double*)d.ctl_dev);
+      }
+      ba_aim_reduce(ba, nd, true);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl);
+    }
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+    if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
+  } else {
+    SVO_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pay, 0, sizeof(double) * (next ? PAY2_SLOTS + pay1 : PAY2_SLOTS), st));
+    if (d.C > 0) {
+      SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB, st);
+      const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
+    }
+    if (same_sweep) {  // pass A at the candidate the launch above just wrote
+      d.points = ba->cand_points; d.poses = ba->cand_poses;
+      const int rc = ba_launch_bulk_linearize(ba, spec_radius, 0, nullptr);
+      d.points = ba->cur_points; d.poses = ba->cur_poses;
+      if (rc) return rc;
+    } else if (chain) {
+      if (sharded) { const int rc = ba_allreduce(ba, 0, PAY2_SLOTS); if (rc) return rc; }
+      const LmCtl lcs = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 1};
+      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, lcs, ba->d_pay, d.ctl_dev);
+      const int rc = ba_launch_bulk_linearize(ba, 0.0, 0, d.ctl_dev);
+      if (rc) return rc;
+    }
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+  }
+  if (!zc) {
+    // same sweep: ONE collective for both payloads; chained: payload2 was summed before the decision, payload1 now
+    int rc = SVO_OK;
+    if (same_sweep) rc = ba_allreduce(ba, 0, PAY2_SLOTS + pay1);
+    else if (chain) rc = ba_allreduce(ba, PAY2_SLOTS, pay1);
+    else rc = ba_allreduce(ba, 0, PAY2_SLOTS);
+    if (!rc) rc = ba_fetch(ba, 0, next ? PAY2_SLOTS + pay1 : PAY2_SLOTS);
+    if (rc) return rc;
+  }
+  memcpy(pay2_out, ba->h_pay, sizeof(double) * 4);
+  if (same_sweep) {
+    *next_radius = spec_radius; *next_at_candidate = 1;
+  } else if (chain) {
+    *next_at_candidate = ba->h_pay[4] != 0.0;
+    *next_radius = ba->h_pay[5];
+  }
+  if (next) ba_payload1_out(ba, ba->h_pay + PAY2_SLOTS, pay1_next_out);
+  ba->t_step += ms_between(t0, now()); ba->n_step++;
+  return SVO_OK;
+}
+
+int op_accept(void* user) {
+  svo_ba* ba = static_cast<svo_ba*>(user);
+  std::swap(ba->cur_points, ba->cand_points);
+  std::swap(ba->cur_poses, ba->cand_poses);  // the candidate poses are already on the device (pass B's first workgroup)
+  return SVO_OK;
+}
+}  // namespace
+
+// ceres::Solve for the loaded problem: host/lm.cpp's step control over the HIP passes.
+static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  svo_lm_ops ops;
+  ops.user = ba;
+  ops.linearize = op_linearize;
+  ops.step = op_step;
+  ops.accept = op_accept;
+  memset(&ba->stats, 0, sizeof(ba->stats));
+  const int rc = svo_lm_solve(d.K, ba->h_poses.data(), &ops, &ba->opt, sum, &ba->stats);
+  ba->n_spec += ba->stats.speculations; ba->n_hit += ba->stats.speculation_hits;
+  // nothing is pending on the zero-copy path either; the wait keeps later users of the stream ordered
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+  d.flag = nullptr;
+  // leave the result in d.points / d.poses
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  return rc;
 }
 
 extern "C" int svo_ba_load_problem(svo_ba* ba, int n_poses, const double* poses7, int n_points, const double* points3,

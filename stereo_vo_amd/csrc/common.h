@@ -105,7 +105,7 @@ __device__ __forceinline__ void svo_publish_block(const SvoPublish& p) {
 
 enum SvoProfTag { SVO_PROF_NONE = 0, SVO_PROF_CORNER_RESPONSE, SVO_PROF_CORNER_NMS, SVO_PROF_CORNER_SELECT,
                   SVO_PROF_PYR_DOWN, SVO_PROF_LK_FB, SVO_PROF_STEREO_AT, SVO_PROF_TRIANGULATE, SVO_PROF_PNP_HYP,
-                  SVO_PROF_PNP_REFINE, SVO_PROF_BA_LINEARIZE, SVO_PROF_BA_BACKSUB };
+                  SVO_PROF_PNP_REFINE, SVO_PROF_BA_LINEARIZE, SVO_PROF_BA_BACKSUB, SVO_PROF_BA_STEP };
 
 // RAII event pair around one launch of the selected kernel (no-op for every other kernel).
 struct SvoProfScope {

@@ -21,7 +21,7 @@ extern "C" int svo_profile_select(svo_ctx* ctx, const char* kernel) {
   if (!ctx) return SVO_ERR_INVALID;
   svo_use_device(ctx);
   static const char* names[] = {"", "corner_response", "corner_nms", "corner_select", "pyr_down", "lk_fb", "stereo_at",
-                                "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub"};
+                                "triangulate", "pnp_hypotheses", "pnp_refine", "ba_linearize", "ba_backsub", "ba_step"};
   int tag = 0;
   if (kernel && kernel[0]) {
     tag = -1;

@@ -4,6 +4,7 @@
 // workgroup, ballot/popcount prefix inside each wave, LDS prefix across the 16 waves.  Output order is
 // the input order, as the reference's push_back loops produce.
 #include "kernels.h"
+#include "ref_constants.h"
 
 namespace {
 constexpr int CT = 1024;
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict
     bool keep = false;
     if (i < n) {
       x = xy[2 * i]; y = xy[2 * i + 1]; d = disp[i];
-      keep = d > 0.0f;  // src/image_processor.cpp:194
+      keep = d > svo_ref::TRIANGULATE_MIN_DISPARITY;  // src/image_processor.cpp:194
     }
     const int slot = compact_slot(keep, base, sWave);
     if (slot >= 0) {

@@ -17,13 +17,16 @@
 #include "kernels.h"
 
 namespace {
+#include "ref_constants.h"
 #ifndef SVO_LK_MAX_ITER
-#define SVO_LK_MAX_ITER 30
+#define SVO_LK_MAX_ITER svo_ref::LK_MAX_ITERATIONS
 #endif
-constexpr int WIN = 21, HALF = 10, LEVELS = 4, MAX_ITER = SVO_LK_MAX_ITER;
+constexpr int WIN = svo_ref::LK_WIN, HALF = WIN / 2, LEVELS = svo_ref::LK_MAX_LEVEL + 1, MAX_ITER = SVO_LK_MAX_ITER;
+static_assert(WIN == 21 && LEVELS == 4, "the LDS layout and the exact-sum bounds below are derived for a 21x21 window, 4 levels");
 constexpr int G = WIN + 1;      // 22: bilinear needs one extra row/col
 constexpr int RP = WIN + 3;     // 24: Scharr needs one more on each side
-constexpr float MIN_EIG = 1e-2f;
+constexpr float MIN_EIG = svo_ref::LK_MIN_EIG_THRESHOLD;
+constexpr double LK_EPS = svo_ref::LK_EPSILON;
 constexpr float FLT_SCALE = 1.0f / (float)(1 << 20);
 constexpr float FLT_EPS = 1.1920928955078125e-7f;
 
@@ -237,8 +240,8 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       const float dy = (A12 * b1 - A11 * b2) * D;
       nx += dx; ny += dy;
       outx = nx + (float)HALF; outy = ny + (float)HALF;
-      if ((double)dx * (double)dx + (double)dy * (double)dy <= 0.01 * 0.01) break;
-      if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= LK_EPS * LK_EPS) break;
+      if (j > 0 && (double)fabsf(dx + pdx) < LK_EPS && (double)fabsf(dy + pdy) < LK_EPS) {
         outx -= dx * 0.5f; outy -= dy * 0.5f;
         break;
       }
@@ -313,10 +316,10 @@ __global__ __launch_bounds__(LKT) void lk_fb_kernel(const uint8_t* __restrict__ 
     float par = 0.f;
     if (s1 && s2) {
       const float ex = x0 - bx, ey = y0 - by;
-      if ((double)ex * (double)ex + (double)ey * (double)ey < 4.0) {  // norm(old - back) < 2
+      if ((double)ex * (double)ex + (double)ey * (double)ey < svo_ref::FB_MAX_DISTANCE * svo_ref::FB_MAX_DISTANCE) {  // norm(old - back) < 2
         const float dx = fx - init_xy[2 * f], dy = fy - init_xy[2 * f + 1];
         par = sqrtf(dx * dx + dy * dy);
-        k = !(par > 200.f);
+        k = !(par > svo_ref::MAX_PARALLAX);
       }
     }
     fwd[2 * f] = fx; fwd[2 * f + 1] = fy; keep[f] = k; parallax[f] = par;

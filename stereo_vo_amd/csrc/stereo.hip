@@ -13,6 +13,7 @@
 //   stereo_prefilter_kernel + stereo_dense_kernel : the drop-in for StereoBM::compute (full CV_16S map),
 //                          separable running-window SADs kept in LDS (see the kernel).
 #include "common.h"
+#include "ref_constants.h"
 
 namespace {
 constexpr int CAP = 31, TEXTURE_THRESHOLD = 10, UNIQUENESS_RATIO = 15;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restric
     if (lane == 0) sT = t;
   }
   __syncthreads();
-  if (tid == 0) disp[f] = (float)bm_select(sSad + 1, ndisp, sT) * (1.0f / 16.0f);
+  if (tid == 0) disp[f] = (float)bm_select(sSad + 1, ndisp, sT) * svo_ref::STEREO_DISPARITY_SCALE;
 }
 
 __global__ __launch_bounds__(256) void stereo_prefilter_kernel(const uint8_t* __restrict__ img, int W, int H, int stride,

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstring>
 
+#include "ref_constants.h"
 #include "svo.h"
 
 namespace {
@@ -49,7 +50,7 @@ extern "C" int svo_draw_track(const uint8_t* gray, int width, int height, int ro
       uint8_t* p = rgb + 3 * ((size_t)y * width + x);
       p[0] = v; p[1] = v; p[2] = v;
     }
-  const int thickness = 4;        // :81
+  const int thickness = svo_ref::DRAW_THICKNESS;  // :81
   const double tip_length = 0.1;  // cv::arrowedLine default
   for (int i = 0; i < n; ++i) {
     const double ax = from_xy[2 * i], ay = from_xy[2 * i + 1], bx = to_xy[2 * i], by = to_xy[2 * i + 1];

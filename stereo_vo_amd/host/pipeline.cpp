@@ -13,6 +13,7 @@
 #include <unordered_map>
 
 #include "kernels.h"
+#include "ref_constants.h"
 #include "stereo_vo.hpp"
 
 namespace svo {
@@ -470,7 +471,7 @@ void ImageProcessor::triangulate_stereo(std::vector<Point3f>& features_3d, std::
                                         const float* d_features, const int* d_n, int n_max, const DeviceImage& left,
                                         const DeviceImage& right, const float camera_pose[16]) {
   if (n_max <= 0) return;
-  if (svo_stereo_disparity_at_dev(ctx_, left.data, right.data, left.width, left.height, left.stride, 16 * 3, 21, d_features,
+  if (svo_stereo_disparity_at_dev(ctx_, left.data, right.data, left.width, left.height, left.stride, svo_ref::STEREO_NUM_DISPARITIES, svo_ref::STEREO_BLOCK_SIZE, d_features,
                                   d_n, n_max, d_disp_)) return;  // :173-176
   const SvoMat4 M = svo_k_reprojection_matrix(camera_pose, K_[0], K_[2], K_[5], baseline);  // :178-189
   // the kernel's outputs are only consumed by the host (keyframe bookkeeping): it writes them into the pinned arena
@@ -519,7 +520,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   const uint8_t* pyr = d_pyr_ + (size_t)slot * pyr_stride_;
   const int n_det = h_ncorners_[slot];
   stats_.n_detected = n_det;
-  if (n_det < 4) return;  // :23-25
+  if (n_det < svo_ref::MIN_DETECTED) return;  // :23-25
 
   std::shared_ptr<Keyframe> last_keyframe = bundle_adjuster->get_last_keyframe();  // :27
   if (last_keyframe == nullptr) {  // :30-58
@@ -546,7 +547,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   stats_.n_tracked = feature_tracker->count();
   stats_.av_parallax = av_parallax;
   stats_.percent_lost = percent_lost;
-  if (av_parallax <= parallax_thresh && (double)percent_lost < 0.4) return;  // :63-65
+  if (av_parallax <= parallax_thresh && (double)percent_lost < svo_ref::KEYFRAME_PERCENT_LOST) return;  // :63-65
 
   PhaseTimer phase(2);
   std::vector<Point2f> tracked_features;
@@ -562,7 +563,8 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
   if (m > 0) {
     SVO_TRY(hipMemcpyAsync(d_xyz_, h_xyz_, sizeof(float) * 3 * m, hipMemcpyHostToDevice, st));
     SvoScratch scratch(ctx_);
-    if (svo_k_pnp(ctx_, scratch, d_xyz_, feature_tracker->device_features(), m, K_[0], K_[2], K_[5], rv, tv, 100, 8.0f, 0.99,
+    if (svo_k_pnp(ctx_, scratch, d_xyz_, feature_tracker->device_features(), m, K_[0], K_[2], K_[5], rv, tv, svo_ref::PNP_ITERATIONS, svo_ref::PNP_REPROJ_ERROR,
+                  svo_ref::PNP_CONFIDENCE,
                   d_inl_, &num_inliers, h_inl_)) return;
   }
   for (int i = 0; i < 3; ++i) { rvec[i] = (float)rv[i]; tvec[i] = (float)tv[i]; }
@@ -624,19 +626,35 @@ struct svo_pipeline {
   size_t d_imgs_bytes = 0;
 };
 
+extern "C" int svo_reference_constants(svo_reference_constants_t* c) {
+  if (!c) return SVO_ERR_INVALID;
+  c->gftt_max_corners = svo_ref::GFTT_MAX_CORNERS; c->gftt_quality = svo_ref::GFTT_QUALITY; c->min_detected = svo_ref::MIN_DETECTED;
+  c->keyframe_percent_lost = svo_ref::KEYFRAME_PERCENT_LOST;
+  c->pnp_iterations = svo_ref::PNP_ITERATIONS; c->pnp_reproj_error = svo_ref::PNP_REPROJ_ERROR; c->pnp_confidence = svo_ref::PNP_CONFIDENCE;
+  c->stereo_num_disparities = svo_ref::STEREO_NUM_DISPARITIES; c->stereo_block_size = svo_ref::STEREO_BLOCK_SIZE;
+  c->stereo_disparity_scale = svo_ref::STEREO_DISPARITY_SCALE; c->triangulate_min_disparity_exclusive = svo_ref::TRIANGULATE_MIN_DISPARITY;
+  c->lk_win_w = c->lk_win_h = svo_ref::LK_WIN; c->lk_max_level = svo_ref::LK_MAX_LEVEL; c->lk_max_iterations = svo_ref::LK_MAX_ITERATIONS;
+  c->lk_epsilon = svo_ref::LK_EPSILON; c->lk_min_eig_threshold = svo_ref::LK_MIN_EIG_THRESHOLD;
+  c->fb_max_distance = svo_ref::FB_MAX_DISTANCE; c->max_parallax = svo_ref::MAX_PARALLAX; c->draw_thickness = svo_ref::DRAW_THICKNESS;
+  c->parallax_thresh = svo_ref::PARALLAX_THRESH; c->min_feature_distance = svo_ref::MIN_FEATURE_DISTANCE;
+  c->sliding_window_size = svo_ref::SLIDING_WINDOW_SIZE; c->max_features = svo_ref::MAX_FEATURES;
+  c->ba_max_solver_time_s = svo_ref::BA_MAX_SOLVER_TIME_S; c->ba_num_threads = svo_ref::BA_NUM_THREADS;
+  return SVO_OK;
+}
+
 extern "C" void svo_pipeline_default_params(svo_pipeline_params* p) {
   if (!p) return;
   memset(p, 0, sizeof(*p));
   p->cam.focal = 718.856; p->cam.cx = 607.1928; p->cam.cy = 185.2157; p->cam.baseline = 0.537165718864418;  // config/kitti00.yaml:1-4
   p->width = 1241; p->height = 376;
-  p->max_corners = 300;            // src/image_processor.cpp:22
-  p->quality = 0.1;
-  p->min_feature_distance = 30.f;  // src/vo_node.cpp:34
-  p->parallax_thresh = 20.f;       // src/vo_node.cpp:33
-  p->window_size = 5;              // src/vo_node.cpp:36
-  p->max_features = 400;           // src/bundle_adjuster.hpp:75
-  p->ba_max_iterations = 50;
-  p->ba_max_time_s = 0.1;          // src/bundle_adjuster.cpp:11
+  p->max_corners = svo_ref::GFTT_MAX_CORNERS;              // src/image_processor.cpp:22
+  p->quality = svo_ref::GFTT_QUALITY;
+  p->min_feature_distance = svo_ref::MIN_FEATURE_DISTANCE;  // src/vo_node.cpp:34
+  p->parallax_thresh = svo_ref::PARALLAX_THRESH;            // src/vo_node.cpp:33
+  p->window_size = svo_ref::SLIDING_WINDOW_SIZE;            // src/vo_node.cpp:36
+  p->max_features = svo_ref::MAX_FEATURES;                  // src/bundle_adjuster.hpp:75
+  p->ba_max_iterations = 50;                                // Ceres default (Solver::Options::max_num_iterations)
+  p->ba_max_time_s = svo_ref::BA_MAX_SOLVER_TIME_S;         // src/bundle_adjuster.cpp:11
 }
 
 extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_pipeline_params* p) {

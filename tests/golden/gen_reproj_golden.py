@@ -4,7 +4,13 @@
 Runs ONLY in the build container (needs /root/reference as text).  It reads the reference's
 src/reprojection_factor.cpp, extracts the 18 scalar Jacobian assignment expressions
 (`jacobians[a][b] = ...;`, lines 63-83) and evaluates them with Python floats (IEEE-754 double, the
-same arithmetic the C++ performs); the residual follows the Eigen expression at lines 24-38.
+same arithmetic the C++ performs).  The residual is stored twice:
+  r       the Eigen expression of lines 24-38, restated here operation by operation (it is executable code in the
+          reference, but Eigen is not available to run it);
+  r_text  the reference's own scalar residual expressions — the commented MATLAB output at lines 53-54 — evaluated as
+          text exactly like the Jacobians.  Those expressions omit the 1/|q|^2 factor of line 33 (they were generated
+          for a unit quaternion), so r_text is stored only for the unit-quaternion cases (|q| = 1 to rounding), where
+          the two forms agree to ~1e-13 relative; null elsewhere.
 The output file holds inputs and expected outputs only (no reference text).
 """
 import json
@@ -30,6 +36,19 @@ def load_exprs():
     return exprs
 
 
+def load_residual_exprs():
+    """residuals[0|1] = ...; inside the comment block at src/reprojection_factor.cpp:52-55, as text."""
+    src = open(REF).read()
+    out = {}
+    for m in re.finditer(r"residuals\[(\d)\]\s*=\s*(.*?);", src, re.S):
+        e = m.group(2)
+        e = e.replace("camera_info.focal", "focal").replace("camera_info.cx", "cx").replace("camera_info.cy", "cy")
+        e = e.replace("obs(0)", "obs0").replace("obs(1)", "obs1")
+        out[int(m.group(1))] = compile(e, f"<r{m.group(1)}>", "eval")
+    assert sorted(out) == [0, 1], sorted(out)
+    return out
+
+
 def residual(q, t, p, obs, focal, cx, cy):
     # src/reprojection_factor.cpp:24-38 (Eigen expression order)
     w, x, y, z = q
@@ -47,6 +66,7 @@ def residual(q, t, p, obs, focal, cx, cy):
 
 def main():
     exprs = load_exprs()
+    rexprs = load_residual_exprs()
     rng = random.Random(0x5EED0011)
     cams = [(718.856, 607.1928, 185.2157), (385.7544860839844, 323.1204833984375, 236.7432098388672)]
     cases = []
@@ -84,10 +104,14 @@ def main():
             else:
                 jx[b] = val
         r = residual(q, t, p, obs, focal, cx, cy)
+        r_text = None
+        if scale == 1.0:  # unit quaternion: the commented scalar residuals (no 1/|q|^2) apply
+            renv = dict(env, cx=cx, cy=cy, obs0=obs[0], obs1=obs[1])
+            r_text = [eval(rexprs[0], {"__builtins__": {}}, renv), eval(rexprs[1], {"__builtins__": {}}, renv)]
         cases.append(dict(focal=focal, cx=cx, cy=cy, pose=q + t, point=p, obs=obs,
-                          r=r, jpose=jp, jpoint=jx))
+                          r=r, r_text=r_text, jpose=jp, jpoint=jx))
     with open(OUT, "w") as f:
-        json.dump(dict(source="src/reprojection_factor.cpp:24-38,63-83 evaluated as text",
+        json.dump(dict(source="src/reprojection_factor.cpp:24-38 (r, restated), :53-54 (r_text, evaluated as text), :63-83 (Jacobians, evaluated as text)",
                        cases=cases), f)
     print("wrote", OUT, len(cases))
 

@@ -227,3 +227,106 @@ class Pipeline:
             oracle().ora_pipeline_destroy(self.h)
         except Exception:
             pass
+
+
+ORACLE_CONSTANT_NAMES = ("min_detected", "keyframe_percent_lost", "pnp_iterations", "pnp_reproj_error", "pnp_confidence",
+                         "stereo_num_disparities", "stereo_block_size", "stereo_disparity_scale",
+                         "triangulate_min_disparity_exclusive", "lk_win_w", "lk_max_level", "lk_max_iterations", "lk_epsilon",
+                         "lk_min_eig_threshold", "fb_max_distance", "max_parallax")
+
+
+def reference_constants():
+    """The first-party literals as the oracle uses them (oracle/ora_constants.h), by the golden fixture's names."""
+    buf = np.zeros(64, np.float64)
+    n = oracle().ora_reference_constants(_p(buf), 64)
+    assert n == len(ORACLE_CONSTANT_NAMES), n
+    return dict(zip(ORACLE_CONSTANT_NAMES, buf[:n].tolist()))
+
+
+class BAState:
+    """ora_ba_state: passes A and B of the oracle's solver one at a time (this rank's unsummed payloads)."""
+
+    def __init__(self, poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, num_threads=1):
+        L = oracle()
+        L.ora_ba_open.restype = C.c_void_p
+        L.ora_ba_payload1_len.restype = C.c_size_t
+        L.ora_ba_payload1_len.argtypes = [C.c_void_p]
+        L.ora_ba_close.argtypes = [C.c_void_p]
+        L.ora_ba_accept.argtypes = [C.c_void_p]
+        L.ora_ba_read.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ora_ba_linearize.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.ora_ba_backsub.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        self.poses0, self.pts0 = _f64(poses7).copy(), _f64(points3).copy()
+        self.op = np.ascontiguousarray(obs_pose, np.int32)
+        self.oj = np.ascontiguousarray(obs_point, np.int32)
+        self.uv = _f64(obs_uv).copy()
+        self.K, self.N = self.poses0.shape[0], self.pts0.shape[0]
+        self.h = C.c_void_p(L.ora_ba_open(self.K, _p(self.poses0), self.N, _p(self.pts0), self.op.shape[0], _p(self.op), _p(self.oj),
+                                          _p(self.uv), C.c_double(focal), C.c_double(cx), C.c_double(cy), num_threads))
+        self.pay1 = L.ora_ba_payload1_len(self.h)
+
+    def linearize(self, at_candidate, radius, first):
+        out = np.zeros(self.pay1)
+        oracle().ora_ba_linearize(self.h, int(at_candidate), radius, int(first), _p(out))
+        return out
+
+    def backsub(self, dc, cand_poses, radius):
+        dc, cand = _f64(dc), _f64(cand_poses)
+        if dc.size == 0:
+            dc = np.zeros(1)
+        out = np.zeros(4)
+        oracle().ora_ba_backsub(self.h, _p(dc), _p(cand), radius, _p(out))
+        return out
+
+    def accept(self):
+        oracle().ora_ba_accept(self.h)
+
+    def read(self):
+        poses, pts = np.empty((self.K, 7)), np.empty((self.N, 3))
+        oracle().ora_ba_read(self.h, _p(poses), _p(pts))
+        return poses, pts
+
+    def close(self):
+        if self.h:
+            oracle().ora_ba_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def product_lm_over_oracle_passes(poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, allreduce=None, max_iterations=50,
+                                  num_threads=1):
+    """The PRODUCT's LM step control (svo_lm_solve in libsvo_hip.so, host code) driving the ORACLE's passes: checks the
+    product's host logic — speculation included — without a GPU.  allreduce(array) sums a host array in place over
+    the ranks (ONE call per exchange).  Returns (poses, points, BASummary, LmStats, exchanges)."""
+    import stereo_vo_amd as S
+    st = BAState(poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, num_threads)
+    exchanges = [0]
+
+    def exch(buf):
+        exchanges[0] += 1
+        if allreduce is not None:
+            allreduce(buf)
+        return buf
+
+    def linearize(radius, first):
+        return exch(st.linearize(0, radius, first))
+
+    def step(dc, cand, radius, ctl):
+        p2 = st.backsub(dc, cand, radius)
+        if ctl.spec_radius > 0:  # same sweep: ONE collective for both payloads
+            both = exch(np.concatenate([p2, st.linearize(1, ctl.spec_radius, 0)]))
+            return both[:4], both[4:], ctl.spec_radius, True
+        p2 = exch(p2)
+        if ctl.chain:  # decide from the SUMMED payload2 with the product's own rule, then pass A for the outcome
+            acc, nr = S.api.lm_decide_step(ctl.cost, ctl.mcc, radius, ctl.decrease_factor, p2[0], p2[1])
+            return p2, exch(st.linearize(1 if acc else 0, nr, 0)), nr, acc
+        return p2, None, 0.0, False
+    poses, summ, stats = S.lm_solve(poses7, linearize, step, st.accept, max_iterations=max_iterations)
+    _, pts = st.read()
+    st.close()
+    return poses, pts, summ, stats, exchanges[0]

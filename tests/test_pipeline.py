@@ -98,12 +98,11 @@ def test_hip_pipeline_degenerate_frames(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("env", [{"SVO_BA_CU_SHARE": "8"}, {"SVO_BA_FUSE": "1"}, {"SVO_BA_NO_POLL": "1"},
-                                 {"SVO_BA_DEVICE_LM": "1"}])
+@pytest.mark.parametrize("env", [{"SVO_BA_CU_SHARE": "8"}, {"SVO_BA_NO_POLL": "1"}, {"SVO_LM_NO_SPECULATION": "1"}])
 def test_hip_pipeline_optional_paths_keep_parity(env):
-    """Deployment knobs must not change results: CU-partitioned streams, the fused back-substitution/reduce2 launch, the
-    stream-wait (non-polling) host loop and the device-resident LM graph all have to reproduce the oracle's index sets
-    and poses exactly.  The knobs are read from the environment at creation, hence one child process each."""
+    """Deployment knobs must not change results: CU-partitioned streams, the stream-wait (non-polling) host loop and the
+    LM loop without chained / same-sweep linearisation (two host round trips per iteration) all have to reproduce the
+    oracle's index sets and poses exactly.  The knobs are read from the environment, hence one child process each."""
     import os
     import subprocess
     import sys

@@ -21,9 +21,18 @@ def _cases():
 
 
 def _check(c, r, jq, jx):
-    for got, exp in ((r, c["r"]), (jq, c["jpose"]), (jx, c["jpoint"])):
+    checks = [(r, c["r"]), (jq, c["jpose"]), (jx, c["jpoint"])]
+    if c.get("r_text") is not None:
+        # the reference's own scalar residual text (src/reprojection_factor.cpp:53-54), unit-quaternion cases only
+        checks.append((r, c["r_text"]))
+    for got, exp in checks:
         exp = np.asarray(exp)
         assert np.max(np.abs(got - exp)) <= RTOL * max(1.0, np.max(np.abs(exp)))
+
+
+def test_golden_holds_text_evaluated_residuals():
+    cs = _cases()
+    assert sum(c["r_text"] is not None for c in cs) == 128  # every unit-quaternion case
 
 
 def test_oracle_matches_reference_golden():
