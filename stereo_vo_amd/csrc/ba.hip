@@ -60,11 +60,10 @@ struct BaDev {
   double* cand_poses = nullptr;    // K x 7 device copy of the candidate poses (written by pass B's first workgroup)
   const double* points = nullptr;  // Npts x 3
   double* cand_points = nullptr;
-  int32_t* obs_pose = nullptr;
-  int32_t* obs_point = nullptr;
-  double* obs_uv = nullptr;
-  int32_t* lm_start = nullptr;     // per landmark index j (dense over [0,Npts]): first obs; lm_start[j+1] end
-  int32_t* chunk_start = nullptr;
+  // per observation SLOT (slot = 64 * chunk + lane; chunks are padded to a full wave so that a lane finds everything it
+  // needs with ONE dependent load round: no chunk table, no CSR walk):
+  const int4* rec = nullptr;       // {pose k (-1: padding lane), landmark j, first lane of the landmark's segment, segment length}
+  const double* obs_uv = nullptr;  // 2 per slot
   double* sp = nullptr;            // Npts x 3 point Jacobi scales
   double* pay1 = nullptr;          // device payload1 (bulk kernels accumulate here with atomics)
   double* pay2 = nullptr;          // device payload2
@@ -72,9 +71,9 @@ struct BaDev {
   // deterministic mode: contribution slots + destination lists
   int det = 0;
   // Contributions are stored DESTINATION-ORDERED so the reduce kernel streams contiguous memory:
-  int32_t* pair_base = nullptr;   // per observation: first pair slot (pairs (o, t>=o) of its landmark)
+  int32_t* pair_base = nullptr;   // per observation slot: first pair slot (pairs (o, t>=o) of its landmark)
   int32_t* pair_pos = nullptr;    // per pair slot: [position in its block list, position in the mirrored list or -1]
-  int32_t* obs_pos = nullptr;     // per observation: position in its pose list or -1
+  int32_t* obs_pos = nullptr;     // per observation slot: position in its pose list or -1
   double* pairB = nullptr;        // (sum of block-list lengths) x 36, block lists back to back
   double* obsV = nullptr;         // (free observations) x 18  (g_c | g_red part | diag U), pose lists back to back
   double* lmV = nullptr;          // Npts x 4, by landmark index: pass A's (cost, g_p^2) (zero for landmarks without observations)
@@ -174,15 +173,13 @@ struct ObsRec { bool active; int o, k, j, first, len; D3 p; double u, v; };
 
 __device__ __forceinline__ ObsRec load_obs(const BaDev& P, int chunk, int lane, const double* __restrict__ points) {
   ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
-  const int c0 = P.chunk_start[chunk], c1 = P.chunk_start[chunk + 1];
-  R.o = c0 + lane;
-  R.active = R.o < c1;
+  R.o = chunk * 64 + lane;
+  const int4 rc = P.rec[R.o];
+  R.u = P.obs_uv[2 * R.o]; R.v = P.obs_uv[2 * R.o + 1];
+  R.active = rc.x >= 0;
   if (R.active) {
-    R.k = P.obs_pose[R.o]; R.j = P.obs_point[R.o];
-    const int l0 = P.lm_start[R.j];
-    R.first = l0 - c0; R.len = P.lm_start[R.j + 1] - l0;
+    R.k = rc.x; R.j = rc.y; R.first = rc.z; R.len = rc.w;
     R.p = D3{points[3 * R.j], points[3 * R.j + 1], points[3 * R.j + 2]};
-    R.u = P.obs_uv[2 * R.o]; R.v = P.obs_uv[2 * R.o + 1];
   }
   return R;
 }
@@ -440,6 +437,37 @@ __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
 }
 constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
 
+// payload2 = R(landmark list) over the four per-landmark scalars of pass B (lmV2), in the declared order, by ANY workgroup
+// size: item = (segment, element), 112 items.  sP: RSEG * 4 doubles of LDS, sOut: 4.  Ends with a barrier: every thread
+// may read sOut afterwards.
+__device__ __forceinline__ void reduce_pay2(const BaDev& P, double* sP, double* sOut) {
+  const int F = P.K - 1, nd = F * F + F + 1, dl = F * F + F;  // dl: the landmark list
+  const int e0 = P.list_start[dl], len = P.list_start[nd + 1 + dl] - e0;
+  const int seglen = (len + RSEG - 1) / RSEG;
+  for (int item = threadIdx.x; item < RSEG * 4; item += (int)blockDim.x) {
+    const int seg = item >> 2, e = item & 3;
+    double acc = 0.0;
+    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+    const double* src = P.lmV2 + 4 * ((size_t)e0 + (size_t)b0) + e;
+    for (int q0 = b0; q0 < b1; q0 += 32, src += 4 * 32) {
+      double v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = q0 + u < b1 ? src[4 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 32; ++u)
+        if (q0 + u < b1) acc += v[u];
+    }
+    sP[4 * seg + e] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double acc = 0.0;
+    for (int sg = 0; sg < RSEG; ++sg) acc += sP[4 * sg + threadIdx.x];
+    sOut[threadIdx.x] = acc;
+  }
+  __syncthreads();
+}
+
 // ---- pass A alone (first linearisation of a solve, re-linearisation after a rejected step or a missed speculation)
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
   apply_ctl(P, radius, ctl);
@@ -470,6 +498,26 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
   for (int i = threadIdx.x; i < pay1; i += blockDim.x) {
     const double v = lds[i];
     if (v != 0.0) atomicAdd(&P.pay1[i], v);
+  }
+}
+
+// ---- single rank, deterministic mode, chained iteration: pass A that FIRST forms payload2 from pass B's per-landmark
+// scalars (every workgroup redundantly, in the declared order: 32 KB of L2 reads instead of a launch boundary), takes
+// Ceres' accept / radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
+__global__ __launch_bounds__(64) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
+  __shared__ double sP[RSEG * 4];
+  __shared__ double sOut[4];
+  reduce_pay2(P, sP, sOut);
+  const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
+  if (blockIdx.x == 0 && threadIdx.x < 6)
+    P.pay2_out[threadIdx.x] = threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius);
+  const double* points_ = dec.accept ? P.cand_points : P.points;
+  const double* poses_ = dec.accept ? P.cand_poses : P.poses;
+  const int lane = threadIdx.x & 63;
+  double unused0 = 0, unused1 = 0;
+  for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
+    const ObsRec R = load_obs(P, chunk, lane, points_);
+    linearize_chunk(P, R, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
   }
 }
 
@@ -505,19 +553,23 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
 // chunks over the CUs); the candidate landmark stays in registers between the passes.
 __global__ __launch_bounds__(64) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
   __shared__ double sStep[STEP_LDS_DOUBLES];
+  const int lane = threadIdx.x & 63;
+  int chunk = blockIdx.x;
+  // the observation records are requested BEFORE the step is staged: the HBM round trip and the PCIe round trip overlap
+  ObsRec R = load_obs(P, chunk < P.C ? chunk : 0, lane, P.points);
   stage_step(P, sStep);
   const double* dc_ = sStep;
   const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
-  const int lane = threadIdx.x & 63;
   double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
-  for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
-    ObsRec R = load_obs(P, chunk, lane, P.points);
+  while (chunk < P.C) {
     D3 cand;
     backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
     if (spec_radius > 0) {
       R.p = cand;
       linearize_chunk(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
     }
+    chunk += gridDim.x;
+    if (chunk < P.C) R = load_obs(P, chunk, lane, P.points);
   }
 }
 
@@ -545,15 +597,16 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int w
       const int seg = item / width, e = item % width;
       double acc = 0.0;
       const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-      // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
-      // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
+      // 32 independent loads in flight (one dependent round trip for lists of up to 896 entries: the data was written by
+      // the previous kernel on other XCDs, every round costs a trip to memory), adds strictly in list order.  The row
+      // pointer advances by addition: a per-element 64-bit index multiply is a quarter-rate instruction.
       const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e;
-      for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
-        double v[16];
+      for (int q0 = b0; q0 < b1; q0 += 32, pq += 32 * stride) {
+        double v[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
+        for (int u = 0; u < 32; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 32; ++u)
           if (q0 + u < b1) acc += v[u];
       }
       sP[seg][e] = acc;
@@ -576,33 +629,9 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int w
       }
     }
   } else if (with_pay2) {
-    const int dl = F * F + F;  // the landmark list
-    const int seg = tid / 4, e = tid % 4;
-    const int e0 = P.list_start[dl], len = P.list_start[nd + 1 + dl] - e0;
-    const int seglen = (len + RSEG - 1) / RSEG;
-    if (seg < RSEG) {
-      double acc = 0.0;
-      const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-      const double* src = P.lmV2 + 4 * (size_t)e0 + e;
-      for (int q0 = b0; q0 < b1; q0 += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = q0 + u < b1 ? src[4 * (size_t)(q0 + u)] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-          if (q0 + u < b1) acc += v[u];
-      }
-      sP[seg][e] = acc;
-    }
-    __syncthreads();
-    if (tid < 4) {
-      double acc = 0.0;
-      for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-      P.pay2_out[tid] = acc;
-      sOut[tid] = acc;
-    }
+    reduce_pay2(P, &sP[0][0], sOut);
+    if (tid < 4) P.pay2_out[tid] = sOut[tid];
     if (ctl.chain) {  // single rank: these ARE the global sums; decide here, pass A is queued right behind this launch
-      __syncthreads();
       if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
     }
   }
@@ -689,13 +718,11 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
     Fetch f{0, 0, 0, lane, 0, false, 0.0, 0.0, D3{0, 0, 1}};
     const int chunk = grp * MF_WAVES + wave;
     if (grp < groups && chunk < P.C) {
-      f.c0 = P.chunk_start[chunk];
-      const int o = f.c0 + lane;
-      f.active = o < P.chunk_start[chunk + 1];
+      const int o = chunk * 64 + lane;
+      const int4 rc = P.rec[o];
+      f.active = rc.x >= 0;
       if (f.active) {
-        f.k = P.obs_pose[o]; f.j = P.obs_point[o];
-        const int l0 = P.lm_start[f.j];
-        f.first = l0 - f.c0; f.len = P.lm_start[f.j + 1] - l0;
+        f.k = rc.x; f.j = rc.y; f.first = rc.z; f.len = rc.w;
         f.p = D3{P.points[3 * f.j], P.points[3 * f.j + 1], P.points[3 * f.j + 2]};
         f.u = P.obs_uv[2 * o]; f.v = P.obs_uv[2 * o + 1];
       }
@@ -983,8 +1010,10 @@ static int ba_alloc(svo_ba* ba) {
     // at most once per pose) so that the hot path never allocates; bulk problems beyond this grow lazily
     const size_t M = ba->cap_obs, Kc = (size_t)Kmax;
     const size_t pairs = M * (Kc + 1) / 2 + 64;
-    const size_t est = 16 * 3 * ba->cap_points + 16 * M + 8 * M + 4 * (ba->cap_points + 1) + 4 * (M + 2) * 3 + 8 * pairs + 8 * (Kc * Kc + Kc + 2) +
-                       2 * 56 * Kc + 16 * 256;
+    // per-slot arrays are padded to whole waves: a chunk closes when the next landmark would not fit, i.e. it holds more
+    // than 64 - max(landmark length) observations; 2 M + 64 slots bound it for landmark lengths <= 32
+    const size_t slots = 2 * M + 64;
+    const size_t est = 16 * 3 * ba->cap_points + (16 + 16 + 4 + 4) * slots + 8 * pairs + 8 * (Kc * Kc + Kc + 2) + 2 * 56 * Kc + 16 * 256;
     if (est < ((size_t)512 << 20)) {
       ba->arena_cap = est;
       SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_arena, ba->arena_cap));
@@ -1193,19 +1222,17 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
       pair_base_v.swap(pair_base); pair_pos_v.swap(pair_pos); obs_pos_v.swap(obs_pos);
     }
   }
-  // ---- one pinned staging image, one H2D: [points | points (candidate copy) | uv | obs_pose | obs_point |
-  //      lm_start | chunk_start | pair_base | obs_pos | pair_pos | list_start | poses]
+  // ---- one pinned staging image, one H2D: [points | points (candidate copy) | per-slot records | per-slot uv |
+  //      per-slot pair_base | per-slot obs_pos | pair_pos | list_start | poses x 2]
+  const size_t nslots = (size_t)d.C * 64;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
   const size_t o_pts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
   const size_t o_cpts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
-  const size_t o_uv = off; off = al(off + sizeof(double) * 2 * (size_t)M);
-  const size_t o_op = off; off = al(off + sizeof(int32_t) * (size_t)M);
-  const size_t o_oj = off; off = al(off + sizeof(int32_t) * (size_t)M);
-  const size_t o_lm = off; off = al(off + sizeof(int32_t) * ((size_t)npts + 1));
-  const size_t o_ch = off; off = al(off + sizeof(int32_t) * chunks.size());
-  const size_t o_pb = off; off = al(off + sizeof(int32_t) * pair_base_v.size());
-  const size_t o_ob = off; off = al(off + sizeof(int32_t) * obs_pos_v.size());
+  const size_t o_rec = off; off = al(off + sizeof(int4) * nslots);
+  const size_t o_uv = off; off = al(off + sizeof(double) * 2 * nslots);
+  const size_t o_pb = off; off = al(off + sizeof(int32_t) * (d.det ? nslots : 0));
+  const size_t o_ob = off; off = al(off + sizeof(int32_t) * (d.det ? nslots : 0));
   const size_t o_pp = off; off = al(off + sizeof(int32_t) * pair_pos_v.size());
   const size_t o_ls = off; off = al(off + sizeof(int32_t) * ls.size());
   const size_t o_p0 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
@@ -1221,23 +1248,37 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   }
   uint8_t* h = ba->h_arena;
   if (npts) { memcpy(h + o_pts, points3, sizeof(double) * 3 * (size_t)npts); memcpy(h + o_cpts, points3, sizeof(double) * 3 * (size_t)npts); }
-  if (M) {
-    memcpy(h + o_uv, uv, sizeof(double) * 2 * (size_t)M);
-    memcpy(h + o_op, op, sizeof(int32_t) * (size_t)M);
-    memcpy(h + o_oj, oj, sizeof(int32_t) * (size_t)M);
+  {
+    int4* rec = reinterpret_cast<int4*>(h + o_rec);
+    double* suv = reinterpret_cast<double*>(h + o_uv);
+    int32_t* spb = reinterpret_cast<int32_t*>(h + o_pb);
+    int32_t* sob = reinterpret_cast<int32_t*>(h + o_ob);
+    for (int c = 0; c < d.C; ++c) {
+      const int c0 = chunks[c], c1 = chunks[c + 1];
+      for (int lane = 0; lane < 64; ++lane) {
+        const size_t slot = (size_t)c * 64 + lane;
+        const int o = c0 + lane;
+        if (o < c1) {
+          const int j = oj[o];
+          rec[slot] = int4{op[o], j, lm_start[j] - c0, lm_start[j + 1] - lm_start[j]};
+          suv[2 * slot] = uv[2 * (size_t)o]; suv[2 * slot + 1] = uv[2 * (size_t)o + 1];
+          if (d.det) { spb[slot] = pair_base_v[o]; sob[slot] = obs_pos_v[o]; }
+        } else {
+          rec[slot] = int4{-1, 0, lane, 0};
+          suv[2 * slot] = 0.0; suv[2 * slot + 1] = 0.0;
+          if (d.det) { spb[slot] = 0; sob[slot] = -1; }
+        }
+      }
+    }
   }
-  memcpy(h + o_lm, lm_start.data(), sizeof(int32_t) * lm_start.size());
-  memcpy(h + o_ch, chunks.data(), sizeof(int32_t) * chunks.size());
-  if (!pair_base_v.empty()) memcpy(h + o_pb, pair_base_v.data(), sizeof(int32_t) * pair_base_v.size());
-  if (!obs_pos_v.empty()) memcpy(h + o_ob, obs_pos_v.data(), sizeof(int32_t) * obs_pos_v.size());
   if (!pair_pos_v.empty()) memcpy(h + o_pp, pair_pos_v.data(), sizeof(int32_t) * pair_pos_v.size());
   if (!ls.empty()) memcpy(h + o_ls, ls.data(), sizeof(int32_t) * ls.size());
   uint8_t* D = ba->d_arena;
   d.points = (double*)(D + o_pts); d.cand_points = (double*)(D + o_cpts);
   ba->cur_points = (double*)(D + o_pts); ba->cand_points = (double*)(D + o_cpts);
-  ba->cur_poses = (double*)(D + o_p0); ba->cand_poses = (double*)(D + o_p1); d.obs_uv = (double*)(D + o_uv);
-  d.obs_pose = (int32_t*)(D + o_op); d.obs_point = (int32_t*)(D + o_oj); d.lm_start = (int32_t*)(D + o_lm);
-  d.chunk_start = (int32_t*)(D + o_ch); d.pair_base = (int32_t*)(D + o_pb); d.obs_pos = (int32_t*)(D + o_ob);
+  ba->cur_poses = (double*)(D + o_p0); ba->cand_poses = (double*)(D + o_p1);
+  d.rec = (const int4*)(D + o_rec); d.obs_uv = (const double*)(D + o_uv);
+  d.pair_base = (int32_t*)(D + o_pb); d.obs_pos = (int32_t*)(D + o_ob);
   d.pair_pos = (int32_t*)(D + o_pp); d.list_start = (int32_t*)(D + o_ls);
   memcpy(h + o_p0, poses7, sizeof(double) * 7 * (size_t)K);
   memcpy(h + o_p1, poses7, sizeof(double) * 7 * (size_t)K);
@@ -1440,9 +1481,14 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       const int blocks = (same_sweep ? nd : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(1024), 0, st, d, same_sweep ? nd : 0, 1, kNoCtl);
+    } else if (!sharded && d.C > 0) {
+      // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
+      ba_aim_reduce(ba, 1, false);
+      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
+      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.C), dim3(64), 0, st, d, lc);
     } else {
       ba_aim_reduce(ba, 1, false);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(1024), 0, st, d, 0, 1, lc);  // single rank: decides right there
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(1024), 0, st, d, 0, 1, lc);
       if (sharded) {
         int rc = ba_allreduce(ba, 0, PAY2_SLOTS);
         if (rc) return rc;
@@ -1453,6 +1499,8 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
         SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
         hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, 0.0, 0, (const double*)d.ctl_dev);
       }
+    }
+    if (chain) {
       ba_aim_reduce(ba, nd, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl);
     }
