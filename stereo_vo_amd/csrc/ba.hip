@@ -36,6 +36,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <sched.h>
 #include <chrono>
 #include <deque>
@@ -280,7 +281,40 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
       for (int b = 0; b < 6; ++b) atomicAdd(&sS[(base + a) * n + base + b], Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
     }
   }
-  // Schur pairs: lane (pose k) x every later-or-equal member of its segment; mirrored on the host
+  // Schur pairs: lane (pose k) x every later-or-equal member of its segment
+  if (P.det && maxlen <= 8) {
+    // window-sized landmarks (<= 8 observations): the destination rows of all of this lane's pairs are fetched up front
+    // (contiguous int2 entries) instead of one dependent load per pair, and the loop runs over the lane distance d so
+    // that the prefetched entries are indexed statically
+    const int mine = freep ? first + len - lane : 0;  // pairs (lane, lane + d), d < mine
+    int2 pp[8];
+    const int2* ppsrc = reinterpret_cast<const int2*>(P.pair_pos) + (freep ? P.pair_base[o] : 0);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) pp[d] = d < mine ? ppsrc[d] : int2{-1, -1};
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+      if (d >= maxlen) break;  // wave-uniform
+      const int src = (lane + d) & 63;
+      const int kt = __shfl(k, src);
+      double Wt[18];
+#pragma unroll
+      for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
+      if (d < mine && kt > 0) {
+        double* B = pp[d].x >= 0 ? P.pairB + (size_t)pp[d].x * 36 : nullptr;   // block (k, kt) if it is an upper block
+        double* Bt = pp[d].y >= 0 ? P.pairB + (size_t)pp[d].y * 36 : nullptr;  // block (kt, k) if THAT is an upper block
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+            const double w = d == 0 ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
+            if (B) B[6 * a + b] = w;
+            if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
+          }
+      }
+    }
+    return;
+  }
   for (int t = 0; t < maxlen; ++t) {
     const int src = (first + t) & 63;
     const int kt = __shfl(k, src);
@@ -291,7 +325,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
       if (P.det) {
         const int slot = P.pair_base[o] + (src - lane);
         const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
-        double* B = P.pairB + (size_t)posA * 36;
+        double* B = posA >= 0 ? P.pairB + (size_t)posA * 36 : nullptr;
         double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
 #pragma unroll
         for (int a = 0; a < 6; ++a)
@@ -299,7 +333,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
           for (int b = 0; b < 6; ++b) {
             const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
             const double w = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-            B[6 * a + b] = w;
+            if (B) B[6 * a + b] = w;
             if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
           }
       } else {
@@ -440,21 +474,20 @@ constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
 // payload2 = R(landmark list) over the four per-landmark scalars of pass B (lmV2), in the declared order, by ANY workgroup
 // size: item = (segment, element), 112 items.  sP: RSEG * 4 doubles of LDS, sOut: 4.  Ends with a barrier: every thread
 // may read sOut afterwards.
-__device__ __forceinline__ void reduce_pay2(const BaDev& P, double* sP, double* sOut) {
-  const int F = P.K - 1, nd = F * F + F + 1, dl = F * F + F;  // dl: the landmark list
-  const int e0 = P.list_start[dl], len = P.list_start[nd + 1 + dl] - e0;
+template <int DEPTH>
+__device__ __forceinline__ void reduce_pay2(const BaDev& P, int e0, int len, double* sP, double* sOut) {
   const int seglen = (len + RSEG - 1) / RSEG;
   for (int item = threadIdx.x; item < RSEG * 4; item += (int)blockDim.x) {
     const int seg = item >> 2, e = item & 3;
     double acc = 0.0;
     const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
     const double* src = P.lmV2 + 4 * ((size_t)e0 + (size_t)b0) + e;
-    for (int q0 = b0; q0 < b1; q0 += 32, src += 4 * 32) {
-      double v[32];
+    for (int q0 = b0; q0 < b1; q0 += DEPTH, src += 4 * DEPTH) {  // DEPTH loads in flight, adds in list order
+      double v[DEPTH];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) v[u] = q0 + u < b1 ? src[4 * u] : 0.0;
+      for (int u = 0; u < DEPTH; ++u) v[u] = q0 + u < b1 ? src[4 * u] : 0.0;
 #pragma unroll
-      for (int u = 0; u < 32; ++u)
+      for (int u = 0; u < DEPTH; ++u)
         if (q0 + u < b1) acc += v[u];
     }
     sP[4 * seg + e] = acc;
@@ -504,20 +537,28 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 // ---- single rank, deterministic mode, chained iteration: pass A that FIRST forms payload2 from pass B's per-landmark
 // scalars (every workgroup redundantly, in the declared order: 32 KB of L2 reads instead of a launch boundary), takes
 // Ceres' accept / radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
-__global__ __launch_bounds__(64) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
+__global__ __launch_bounds__(128) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl, int lm_begin, int lm_count) {
   __shared__ double sP[RSEG * 4];
   __shared__ double sOut[4];
-  reduce_pay2(P, sP, sOut);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // wave 0 requests its chunk's records before the sums (both candidate landing points: the decision is not known yet)
+  const int chunk0 = blockIdx.x < P.C ? blockIdx.x : 0;
+  ObsRec Rc = load_obs(P, chunk0, lane, P.points);
+  D3 pc = Rc.p;
+  if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
+  // 112 (segment, element) items on 128 lanes, 64 loads in flight each: one dependent round trip
+  reduce_pay2<64>(P, lm_begin, lm_count, sP, sOut);
   const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
   if (blockIdx.x == 0 && threadIdx.x < 6)
     P.pay2_out[threadIdx.x] = threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius);
+  if (wave != 0) return;
   const double* points_ = dec.accept ? P.cand_points : P.points;
   const double* poses_ = dec.accept ? P.cand_poses : P.poses;
-  const int lane = threadIdx.x & 63;
+  if (dec.accept) Rc.p = pc;
   double unused0 = 0, unused1 = 0;
   for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
-    const ObsRec R = load_obs(P, chunk, lane, points_);
-    linearize_chunk(P, R, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+    if (chunk != (int)blockIdx.x) Rc = load_obs(P, chunk, lane, points_);
+    linearize_chunk(P, Rc, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
   }
 }
 
@@ -579,34 +620,37 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(LmCtl ctl, double* paybuf
 }
 
 // R(list): 28 consecutive segments summed sequentially, then the segment sums added sequentially
-// (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: with payload1, F*F pose-pair blocks
-// (36 values), F pose vectors (18 values), 1 scalar pair from lmV; with payload2, one more workgroup for the four
-// scalars of lmV2; lane = (segment, element).  The last workgroup to arrive publishes the completion word.
-__global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int with_pay2, LmCtl ctl) {
+// (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: with payload1, the F (F + 1) / 2 upper
+// pose-pair blocks (36 values; the lower ones are their exact transposes, mirrored on the host), F pose vectors
+// (18 values), 1 scalar pair from lmV; with payload2, one more workgroup for the four scalars of lmV2;
+// lane = (segment, element).  The last workgroup to arrive publishes the completion word.
+struct ListArgs { int n; int begin[48], end[48]; };  // destination lists of window-sized problems ride in the kernel arguments (n = 0: read P.list_start)
+
+__global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int with_pay2, LmCtl ctl, ListArgs la) {
   __shared__ double sP[RSEG][36];
   __shared__ double sOut[4];
   const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
-  const int nd = F * F + F + 1;
+  const int nU = F * (F + 1) / 2, nd = nU + F + 1;
   if (d < nd1) {
-    const int width = d < F * F ? 36 : (d < F * F + F ? 18 : 2);
-    const int stride = d < F * F ? 36 : (d < F * F + F ? 18 : 4);
-    const double* base = d < F * F ? P.pairB : (d < F * F + F ? P.obsV : P.lmV);
-    const int e0 = P.list_start[d], len = P.list_start[nd + 1 + d] - e0;
+    const int width = d < nU ? 36 : (d < nU + F ? 18 : 2);
+    const int stride = d < nU ? 36 : (d < nU + F ? 18 : 4);
+    const double* base = d < nU ? P.pairB : (d < nU + F ? P.obsV : P.lmV);
+    const int e0 = la.n ? la.begin[d] : P.list_start[d], len = (la.n ? la.end[d] : P.list_start[nd + 1 + d]) - e0;
     const int seglen = (len + RSEG - 1) / RSEG;
     for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {  // one pass with 1024 threads
       const int seg = item / width, e = item % width;
       double acc = 0.0;
       const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-      // 32 independent loads in flight (one dependent round trip for lists of up to 896 entries: the data was written by
-      // the previous kernel on other XCDs, every round costs a trip to memory), adds strictly in list order.  The row
-      // pointer advances by addition: a per-element 64-bit index multiply is a quarter-rate instruction.
+      // 16 independent loads in flight, adds strictly in list order (32 in flight measured slower: 1024-thread
+      // workgroups leave 128 VGPRs per lane).  The row pointer advances by addition: a per-element 64-bit index multiply
+      // is a quarter-rate instruction and was most of this loop's ALU time.
       const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e;
-      for (int q0 = b0; q0 < b1; q0 += 32, pq += 32 * stride) {
-        double v[32];
+      for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
+        double v[16];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
+        for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
+        for (int u = 0; u < 16; ++u)
           if (q0 + u < b1) acc += v[u];
       }
       sP[seg][e] = acc;
@@ -616,11 +660,13 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int w
       double acc = 0.0;
       for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
       double* out = P.pay1_out;
-      if (d < F * F) {
-        const int ka = d / F, kb = d % F;
+      if (d < nU) {
+        int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
+        while (rest >= F - ka) { rest -= F - ka; ++ka; }
+        const int kb = ka + rest;
         out[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
-      } else if (d < F * F + F) {
-        const int k = d - F * F;
+      } else if (d < nU + F) {
+        const int k = d - nU;
         if (tid < 6) out[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
         else if (tid < 12) out[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
         else out[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
@@ -629,7 +675,11 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int w
       }
     }
   } else if (with_pay2) {
-    reduce_pay2(P, &sP[0][0], sOut);
+    {
+      const int dl = nU + F;  // the landmark list
+      const int e0 = la.n ? la.begin[dl] : P.list_start[dl], e1 = la.n ? la.end[dl] : P.list_start[nd + 1 + dl];
+      reduce_pay2<16>(P, e0, e1 - e0, &sP[0][0], sOut);
+    }
     if (tid < 4) P.pay2_out[tid] = sOut[tid];
     if (ctl.chain) {  // single rank: these ARE the global sums; decide here, pass A is queued right behind this launch
       if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
@@ -641,10 +691,8 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int w
     __syncthreads();
     if (tid == 0) {
       const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      if (old + 1u == P.arrive_target) {
-        __threadfence_system();
-        __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+      // every workgroup pushed its payload to system scope before it arrived; the release store orders the word behind them
+      if (old + 1u == P.arrive_target) __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -978,6 +1026,9 @@ struct svo_ba {
   std::vector<double> feat_pos;  // 3 per feature id
   bool new_frame_added = false;
   std::vector<int64_t> solve_lm_ids;
+  std::vector<double> s_poses, s_points, s_uv, s_out_pts;   // per-solve scratch of svo_ba_solve (kept: no allocation per keyframe)
+  std::vector<int32_t> s_op, s_oj;
+  std::vector<int32_t> u_lm_start, u_chunks, u_pair_base, u_pair_pos, u_obs_pos, u_ls, u_cnt, u_fill;  // scratch of ba_upload
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
   unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
@@ -985,7 +1036,7 @@ struct svo_ba {
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
   // SVO_TIMING accumulators
-  double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
+  double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0, t_prep = 0, t_read = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
 };
 
 static int ba_alloc(svo_ba* ba) {
@@ -1030,7 +1081,16 @@ static int ba_alloc(svo_ba* ba) {
     // kernels never queue behind other stereo streams' wide LK launches.  Bulk-sized adjusters keep the whole GPU.
     const char* e = getenv("SVO_BA_CU_SHARE");
     const int nres = e ? atoi(e) : 0;
-    if (nres > 0 && nres < 32 && ba->max_obs <= 100000) {
+    // SVO_BA_XCD=1: a window-sized adjuster keeps to ONE XCD (adjusters are dealt round-robin over the eight): the slots
+    // pass A writes and the reduce kernel reads, the step, the decision — everything the dependent launches of an LM
+    // iteration hand to each other stays in one L2 instead of crossing the fabric at every kernel boundary.
+    static std::atomic<unsigned> next_xcd{0};
+    const char* ex = getenv("SVO_BA_XCD");
+    if (ex && atoi(ex) > 0 && ba->max_obs <= 100000) {
+      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      mask[next_xcd.fetch_add(1) % 8u] = 0xFFFFFFFFu;
+      SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
+    } else if (nres > 0 && nres < 32 && ba->max_obs <= 100000) {
       uint32_t mask[8];
       for (int i = 0; i < 8; ++i) mask[i] = (1u << nres) - 1u;
       SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
@@ -1087,8 +1147,9 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   BaDev& d = ba->d;
   if (getenv("SVO_TIMING") && ba->n_lin)
     fprintf(stderr, "[svo ba] %ld solves: pass A alone %.1f us x %ld, step (pass B + speculative pass A) %.1f us x %ld, speculation %ld/%ld hit, "
-                    "upload %.3f ms, total %.3f ms\n", ba->n_solves, 1e3 * ba->t_lin / ba->n_lin, ba->n_lin,
-            ba->n_step ? 1e3 * ba->t_step / ba->n_step : 0.0, ba->n_step, ba->n_hit, ba->n_spec, ba->t_upload, ba->t_total);
+                    "per solve: gather %.1f us, upload %.1f us, upload + LM %.1f us, read-back %.1f us\n", ba->n_solves, 1e3 * ba->t_lin / ba->n_lin, ba->n_lin,
+            ba->n_step ? 1e3 * ba->t_step / ba->n_step : 0.0, ba->n_step, ba->n_hit, ba->n_spec, 1e3 * ba->t_prep / std::max(ba->n_solves, 1l),
+            1e3 * ba->t_upload / std::max(ba->n_solves, 1l), 1e3 * ba->t_total / std::max(ba->n_solves, 1l), 1e3 * ba->t_read / std::max(ba->n_solves, 1l));
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
   void* ptrs[] = {ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
@@ -1120,6 +1181,9 @@ extern "C" int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats) {
 
 
 // Upload a landmark-major problem (shared by the bulk API and the sliding-window solve).
+// Destination index of pose-pair block (ka <= kb) among the F (F + 1) / 2 upper blocks, row-major.
+static inline int ba_upper_index(int ka, int kb, int F) { return ka * F - ka * (ka - 1) / 2 + (kb - ka); }
+
 static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const double* points3, int M,
                      const int32_t* op, const int32_t* oj, const double* uv) {
   svo_ctx* ctx = ba->ctx;
@@ -1129,15 +1193,20 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   if (ba->upload_pending) { SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream)); ba->upload_pending = false; }
   d.K = K; d.n = 6 * (K - 1); d.M = M; d.f = ba->cam.focal; d.cx = ba->cam.cx; d.cy = ba->cam.cy;
   ba->n_points = npts;
-  // CSR over landmark index + wave chunks (<= 64 observations, whole landmarks)
-  std::vector<int32_t> lm_start((size_t)npts + 1, 0), chunks;
+  // CSR over landmark index + wave chunks (<= 64 observations, whole landmarks).  All scratch vectors are members:
+  // a keyframe's solve allocates nothing.
+  std::vector<int32_t>&lm_start = ba->u_lm_start, &chunks = ba->u_chunks;
+  lm_start.assign((size_t)npts + 1, 0);
+  chunks.clear();
   for (int o = 0; o < M; ++o) {
     SVO_REQUIRE(ctx, oj[o] >= 0 && oj[o] < npts && op[o] >= 0 && op[o] < K, "ba: observation index out of range");
     SVO_REQUIRE(ctx, o == 0 || oj[o] >= oj[o - 1], "ba: observations must be sorted by landmark");
     lm_start[oj[o] + 1]++;
   }
+  bool has_empty_landmark = false;
   for (int j = 0; j < npts; ++j) {
     SVO_REQUIRE(ctx, lm_start[j + 1] <= 64, "ba: a landmark has more than 64 observations");
+    has_empty_landmark |= lm_start[j + 1] == 0;
     lm_start[j + 1] += lm_start[j];
   }
   chunks.push_back(0);
@@ -1152,63 +1221,74 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   d.C = (int)chunks.size() - 1;
   d.L = npts;
   hipStream_t st = ba->stream;
-  std::vector<int32_t> pair_base_v, pair_pos_v, obs_pos_v, ls;
-  bool has_empty_landmark = false;
-  for (int j = 0; j < npts; ++j) has_empty_landmark |= lm_start[j + 1] == lm_start[j];
+  std::vector<int32_t>&pair_base_v = ba->u_pair_base, &pair_pos_v = ba->u_pair_pos, &obs_pos_v = ba->u_obs_pos, &ls = ba->u_ls;
+  pair_pos_v.clear(); ls.clear();
   // deterministic mode: pair slots + destination lists (landmark order) if they fit
   {
     const int F = K - 1;
-    std::vector<int32_t> pair_base((size_t)M + 1, 0);
-    for (int j = 0; j < npts; ++j)
-      for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) pair_base[o + 1] = pair_base[o] + (lm_start[j + 1] - o);
-    const size_t n_pairs = (size_t)pair_base[M];
+    pair_base_v.assign((size_t)M + 1, 0);
+    bool dup = false;
+    for (int j = 0; j < npts; ++j) {
+      uint64_t seen = 0;
+      for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) {
+        pair_base_v[o + 1] = pair_base_v[o] + (lm_start[j + 1] - o);
+        const uint64_t bit = 1ull << op[o];
+        dup |= (seen & bit) != 0;
+        seen |= bit;
+      }
+    }
+    const size_t n_pairs = (size_t)pair_base_v[M];
     d.det = n_pairs <= ((size_t)1 << 21) ? 1 : 0;  // <= 604 MB of pair blocks
     if (ba->opt.accumulation == SVO_BA_ACC_ATOMICS || ba->opt.accumulation == SVO_BA_ACC_MFMA) d.det = 0;
     SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_DETERMINISTIC && !d.det), "ba: problem too large for deterministic accumulation");
-    {
-      bool dup = false;
-      for (int j = 0; j < npts && !dup; ++j) {
-        uint64_t seen = 0;
-        for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) { const uint64_t bit = 1ull << op[o]; dup |= (seen & bit) != 0; seen |= bit; }
-      }
-      ba->mfma_ok = !dup && d.n <= 128 && d.n > 0 && ba->opt.accumulation != SVO_BA_ACC_ATOMICS;
-      SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_MFMA && !ba->mfma_ok), "ba: MFMA accumulation needs <= 22 poses and one observation per (landmark, pose)");
-    }
+    ba->mfma_ok = !dup && d.n <= 128 && d.n > 0 && ba->opt.accumulation != SVO_BA_ACC_ATOMICS;
+    SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_MFMA && !ba->mfma_ok), "ba: MFMA accumulation needs <= 22 poses and one observation per (landmark, pose)");
+    ba->h_list_begin.clear(); ba->h_list_end.clear();
     if (d.det) {
-      // destination lists in landmark order; the landmark list is the identity over [0, npts)
-      const int nd = F * F + F + 1;
-      std::vector<int32_t> cnt(nd, 0), pair_pos(2 * n_pairs + 2, -1), obs_pos((size_t)M + 1, -1);
+      // Destination lists in landmark order.  S is symmetric and the list of block (kb, ka) holds the transposes of the
+      // list of (ka, kb) in the same order, so its sums are the exact transpose: only the F (F + 1) / 2 blocks ka <= kb
+      // are stored and reduced, the host mirrors them.  Then F pose lists; the landmark list is the identity over [0, npts).
+      const int nU = F * (F + 1) / 2, nd = nU + F + 1;
+      std::vector<int32_t>&cnt = ba->u_cnt, &fill = ba->u_fill;
+      cnt.assign(nd, 0);
+      pair_pos_v.assign(2 * n_pairs + 2, -1);
+      obs_pos_v.assign((size_t)M + 1, -1);
       for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
           // block lists are back to back in pairB, pose lists back to back in obsV, the landmark list is
           // rows [0, npts) of lmV
           ba->h_list_begin.assign(nd, 0); ba->h_list_end.assign(nd, 0);
           int32_t acc = 0;
-          for (int q = 0; q < F * F; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
+          for (int q = 0; q < nU; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
           ba->n_pair_rows = (size_t)acc;
           acc = 0;
-          for (int q = F * F; q < F * F + F; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
-          ba->h_list_begin[F * F + F] = 0; ba->h_list_end[F * F + F] = npts;
+          for (int q = nU; q < nU + F; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
+          ba->h_list_begin[nU + F] = 0; ba->h_list_end[nU + F] = npts;
         }
-        std::vector<int32_t> fill(nd, 0);
-        for (int j = 0; j < npts; ++j)
-          for (int i = lm_start[j]; i < lm_start[j + 1]; ++i) {
+        fill.assign(nd, 0);
+        for (int j = 0; j < npts; ++j) {
+          const int o1 = lm_start[j + 1];
+          for (int i = lm_start[j]; i < o1; ++i) {
             const int ki = op[i] - 1;
             if (ki < 0) continue;
-            if (pass == 0) cnt[F * F + ki]++;
-            else obs_pos[i] = ba->h_list_begin[F * F + ki] + fill[F * F + ki]++;
-            for (int t = i; t < lm_start[j + 1]; ++t) {
+            if (pass == 0) cnt[nU + ki]++;
+            else obs_pos_v[i] = ba->h_list_begin[nU + ki] + fill[nU + ki]++;
+            for (int t = i; t < o1; ++t) {
               const int kt = op[t] - 1;
               if (kt < 0) continue;
-              const int slot = pair_base[i] + (t - i);
-              const int da = ki * F + kt, db = kt * F + ki;
-              if (pass == 0) { cnt[da]++; if (t != i) cnt[db]++; }
+              // B enters block (ki, kt), its transpose block (kt, ki): whichever of them is an upper block is stored
+              // (both when ki == kt for t != i: two observations of one landmark in one pose)
+              const int slot = pair_base_v[i] + (t - i);
+              const bool fwd = ki <= kt, rev = t != i && kt <= ki;
+              const int da = fwd ? ba_upper_index(ki, kt, F) : 0, db = rev ? ba_upper_index(kt, ki, F) : 0;
+              if (pass == 0) { if (fwd) cnt[da]++; if (rev) cnt[db]++; }
               else {
-                pair_pos[2 * slot] = ba->h_list_begin[da] + fill[da]++;
-                if (t != i) pair_pos[2 * slot + 1] = ba->h_list_begin[db] + fill[db]++;
+                if (fwd) pair_pos_v[2 * slot] = ba->h_list_begin[da] + fill[da]++;
+                if (rev) pair_pos_v[2 * slot + 1] = ba->h_list_begin[db] + fill[db]++;
               }
             }
           }
+        }
       }
       const size_t rows = ba->n_pair_rows;
       if (rows > ba->cap_pairs) {
@@ -1219,7 +1299,6 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
       }
       ls.assign(2 * (size_t)nd + 2, 0);  // list_start[q] = begin(q), list_start[nd + 1 + q] = end(q)
       for (int q = 0; q < nd; ++q) { ls[q] = ba->h_list_begin[q]; ls[nd + 1 + q] = ba->h_list_end[q]; }
-      pair_base_v.swap(pair_base); pair_pos_v.swap(pair_pos); obs_pos_v.swap(obs_pos);
     }
   }
   // ---- one pinned staging image, one H2D: [points | points (candidate copy) | per-slot records | per-slot uv |
@@ -1356,7 +1435,13 @@ void ba_payload1_out(svo_ba* ba, const double* src, double* dst) {
   const int n = d.n, K = d.K;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   memcpy(dst, src, sizeof(double) * pay1);
-  if (d.det) return;
+  if (d.det) {  // upper pose-pair blocks were reduced; the lower ones are their exact transposes
+    for (int a = 0; a < K - 1; ++a)
+      for (int b = a + 1; b < K - 1; ++b)
+        for (int i = 0; i < 6; ++i)
+          for (int j = 0; j < 6; ++j) dst[(size_t)(6 * b + j) * n + 6 * a + i] = src[(size_t)(6 * a + i) * n + 6 * b + j];
+    return;
+  }
   for (int a = 0; a < K - 1; ++a)
     for (int b = 0; b < K - 1; ++b) {
       if (a == b) continue;
@@ -1406,6 +1491,17 @@ void ba_aim_reduce(svo_ba* ba, int n_blocks, bool publish) {
 
 const LmCtl kNoCtl = {0, 0, 0, 0, 0};
 
+// destination lists as kernel arguments when they fit (every window-sized problem: K <= 6 free... F*F + F + 1 <= 48)
+ListArgs ba_list_args(const svo_ba* ba) {
+  ListArgs la;
+  la.n = 0;
+  const size_t nd = ba->h_list_begin.size();
+  if (!ba->d.det || nd == 0 || nd > 48) return la;
+  la.n = (int)nd;
+  for (size_t q = 0; q < nd; ++q) { la.begin[q] = ba->h_list_begin[q]; la.end[q] = ba->h_list_end[q]; }
+  return la;
+}
+
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
   svo_ba* ba = static_cast<svo_ba*>(user);
   svo_ctx* ctx = ba->ctx;
@@ -1416,13 +1512,13 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   if (d.det) {
-    const int nd = (K - 1) * (K - 1) + (K - 1) + 1;
+    const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
     }
     ba_aim_reduce(ba, nd, true);
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl, ba_list_args(ba));
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
   } else {
@@ -1472,7 +1568,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
   }
   const bool next = same_sweep || chain;
   if (d.det) {
-    const int nd = (K - 1) * (K - 1) + (K - 1) + 1;
+    const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
       hipLaunchKernelGGL(ba_step_kernel, dim3(d.C), dim3(64), 0, st, d, radius, same_sweep ? spec_radius : 0.0);
@@ -1480,15 +1576,15 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     if (!chain) {
       const int blocks = (same_sweep ? nd : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(1024), 0, st, d, same_sweep ? nd : 0, 1, kNoCtl);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(1024), 0, st, d, same_sweep ? nd : 0, 1, kNoCtl, ba_list_args(ba));
     } else if (!sharded && d.C > 0) {
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.C), dim3(64), 0, st, d, lc);
+      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.C), dim3(128), 0, st, d, lc, ba->h_list_begin[nd - 1], ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1]);
     } else {
       ba_aim_reduce(ba, 1, false);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(1024), 0, st, d, 0, 1, lc);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(1024), 0, st, d, 0, 1, lc, ba_list_args(ba));
       if (sharded) {
         int rc = ba_allreduce(ba, 0, PAY2_SLOTS);
         if (rc) return rc;
@@ -1502,7 +1598,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     }
     if (chain) {
       ba_aim_reduce(ba, nd, true);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl, ba_list_args(ba));
     }
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
@@ -1678,29 +1774,55 @@ extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
   svo_use_device(ba->ctx);
   if (summary) memset(summary, 0, sizeof(*summary));
   if (!ba->new_frame_added) return SVO_OK;  // src/bundle_adjuster.cpp:138
+  const auto tp0 = std::chrono::steady_clock::now();
   const int K = (int)ba->window.size();
-  struct Flat { int k; float u, v; int64_t id; };
-  std::vector<Flat> flat;
-  for (int k = 0; k < K; ++k)
-    for (const auto& o : ba->window[k].obs) flat.push_back({k, o.u, o.v, o.id});
-  std::vector<int> perm(flat.size());
-  for (size_t i = 0; i < perm.size(); ++i) perm[i] = (int)i;
-  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return flat[a].id < flat[b].id; });
-  std::vector<double> poses(7 * (size_t)K), points, uv;
-  std::vector<int32_t> op, oj;
+  // Observations sorted by (landmark id, window slot) — the order ceres would visit nothing in particular, but the
+  // declared summation order is defined on it.  Every keyframe's observation list is ascending in id when it comes
+  // from the pipeline (tracked ids keep their order, new ids are larger), so a K-way merge replaces the sort; lists
+  // from other callers are checked and fall back to a stable sort.
+  std::vector<double>& poses = ba->s_poses; std::vector<double>& points = ba->s_points; std::vector<double>& uv = ba->s_uv;
+  std::vector<int32_t>& op = ba->s_op; std::vector<int32_t>& oj = ba->s_oj;
   std::vector<int64_t>& lm_ids = ba->solve_lm_ids;
-  lm_ids.clear();
+  poses.resize(7 * (size_t)K); points.clear(); uv.clear(); op.clear(); oj.clear(); lm_ids.clear();
+  points.reserve(3 * 4096); uv.reserve(2 * 4096); op.reserve(4096); oj.reserve(4096); lm_ids.reserve(4096);
   for (int k = 0; k < K; ++k) memcpy(&poses[7 * k], ba->window[k].pose, 7 * sizeof(double));
-  for (int idx : perm) {
-    const Flat& f = flat[idx];
-    if (lm_ids.empty() || lm_ids.back() != f.id) {
-      lm_ids.push_back(f.id);
-      for (int a = 0; a < 3; ++a) points.push_back(ba->feat_pos[3 * f.id + a]);
+  bool ascending = true;
+  size_t total = 0;
+  for (int k = 0; k < K; ++k) {
+    const auto& o = ba->window[k].obs;
+    total += o.size();
+    for (size_t i = 1; i < o.size() && ascending; ++i) ascending = o[i - 1].id <= o[i].id;
+  }
+  auto emit = [&](int k, const svo_ba::Obs& o) {
+    if (lm_ids.empty() || lm_ids.back() != o.id) {
+      lm_ids.push_back(o.id);
+      for (int a = 0; a < 3; ++a) points.push_back(ba->feat_pos[3 * o.id + a]);
     }
-    op.push_back(f.k); oj.push_back((int32_t)lm_ids.size() - 1);
-    uv.push_back(f.u); uv.push_back(f.v);
+    op.push_back(k); oj.push_back((int32_t)lm_ids.size() - 1);
+    uv.push_back(o.u); uv.push_back(o.v);
+  };
+  if (ascending && K <= 64) {
+    const svo_ba::Obs* cur[64];
+    const svo_ba::Obs* end[64];
+    for (int k = 0; k < K; ++k) { const auto& o = ba->window[k].obs; cur[k] = o.data(); end[k] = o.data() + o.size(); }
+    for (size_t done = 0; done < total; ++done) {
+      int best = -1;
+      int64_t best_id = 0;
+      for (int k = 0; k < K; ++k)  // smallest id first; equal ids in window-slot order (what the stable sort gives)
+        if (cur[k] != end[k] && (best < 0 || cur[k]->id < best_id)) { best = k; best_id = cur[k]->id; }
+      emit(best, *cur[best]++);
+    }
+  } else {
+    struct Flat { int k; const svo_ba::Obs* o; };
+    std::vector<Flat> flat;
+    flat.reserve(total);
+    for (int k = 0; k < K; ++k)
+      for (const auto& o : ba->window[k].obs) flat.push_back({k, &o});
+    std::stable_sort(flat.begin(), flat.end(), [](const Flat& a, const Flat& b) { return a.o->id < b.o->id; });
+    for (const Flat& f : flat) emit(f.k, *f.o);
   }
   const auto tu0 = std::chrono::steady_clock::now();
+  ba->t_prep += std::chrono::duration<double, std::milli>(tu0 - tp0).count();
   int rc = ba_upload(ba, K, poses.data(), (int)lm_ids.size(), points.data(), (int)op.size(), op.data(), oj.data(), uv.data());
   if (rc) return rc;
   ba->t_upload += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
@@ -1709,12 +1831,15 @@ extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
   ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   ba->n_solves++;
   if (rc) return rc;
-  std::vector<double> out_pts(points.size());
+  const auto tr0 = std::chrono::steady_clock::now();
+  std::vector<double>& out_pts = ba->s_out_pts;
+  out_pts.resize(points.size());
   rc = svo_ba_read_problem(ba, poses.data(), out_pts.data());
   if (rc) return rc;
   for (int k = 0; k < K; ++k) memcpy(ba->window[k].pose, &poses[7 * k], 7 * sizeof(double));
   for (size_t l = 0; l < lm_ids.size(); ++l)
     for (int a = 0; a < 3; ++a) ba->feat_pos[3 * lm_ids[l] + a] = out_pts[3 * l + a];
   ba->new_frame_added = false;  // :155
+  ba->t_read += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
   return SVO_OK;
 }

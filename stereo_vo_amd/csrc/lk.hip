@@ -53,26 +53,33 @@ __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1)
 
 // Exact wave-wide integer sum without LDS traffic.  Bounds (8-bit images): |I|,|J| <= 255*32 = 8160 after the
 // 2^-9 descale, Scharr |g| <= 16*255 = 4080, so one product is < 2^25 (8160*4080 = 33,292,800; 4080^2 < 2^24),
-// a thread's partial over its PPT <= 4 pixels is < 2^27 and the sum over a 16-lane DPP row is < 2^31: the row
-// reduction is exact in int32.  The four row totals are then added in 64 bits on the scalar unit.  Integer
-// addition is associative, so the result does not depend on the order (this is what lets the oracle use a
-// plain sequential int64 sum).
+// a thread's partial over its PPT <= 7 pixels is < 2^28 and the sum over EIGHT lanes (half a DPP row) is
+// 7 * 8 * 33,292,800 = 1,864,396,800 < 2^31: three DPP steps are exact in int32.  The eight half-row totals are then
+// added in 64 bits on the scalar unit.  Integer addition is associative, so the result does not depend on the
+// order (this is what lets the oracle use a plain sequential int64 sum).
 __device__ __forceinline__ long long wave_sum_i64(int v) {
   v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror
-  v += __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true);  // row_mirror
-  return (long long)__builtin_amdgcn_readlane(v, 0) + (long long)__builtin_amdgcn_readlane(v, 16) +
-         (long long)__builtin_amdgcn_readlane(v, 32) + (long long)__builtin_amdgcn_readlane(v, 48);
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror: every lane holds its 8-lane total
+  long long t = 0;
+#pragma unroll
+  for (int l = 0; l < 64; l += 8) t += (long long)__builtin_amdgcn_readlane(v, l);
+  return t;
 }
 
 #ifndef SVO_LK_THREADS
-#define SVO_LK_THREADS 256
+#define SVO_LK_THREADS 64
 #endif
-constexpr int LKT = SVO_LK_THREADS;  // threads per feature (4 wavefronts by default; 128 also keeps the int32 row sums exact)
+// Threads per feature.  64 (default): ONE wavefront owns a feature — 7 window pixels per lane, all sums by DPP, no
+// workgroup barrier anywhere (LDS traffic of a single wave is ordered; a wave-level fence replaces s_barrier), four
+// features per 256-thread workgroup.  256 / 128: the wavefronts of a workgroup share one feature and meet at a barrier
+// per iteration (measured on MI355X: 247 us per 731-feature launch with 256).
+constexpr int LKT = SVO_LK_THREADS;
 constexpr int NW = LKT / 64;
+constexpr int FPB = 256 / LKT;   // features per workgroup
 constexpr int PPT = (21 * 21 + LKT - 1) / LKT;  // window pixels per thread
-static_assert(LKT % 64 == 0 && PPT * 16 * 33292800ll < 2147483647ll, "row sums must stay exact in int32");
+static_assert(LKT == 64 || LKT == 128 || LKT == 256, "threads per feature");
+static_assert(PPT * 8 * 33292800ll < 2147483647ll, "half-row sums must stay exact in int32");
 constexpr int RM = 5;            // margin of the staged target region around the 22x22 window
 constexpr int RS = G + 2 * RM;   // 32
 
@@ -81,13 +88,31 @@ struct LkShared {
   uint8_t jreg[RS * RS];     // target-image region; restaged only when the window leaves it
   short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
   short gx[G * G], gy[G * G];
-  long long red[2][3][NW];   // cross-wave partials (double-buffered: one barrier per reduction point)
+  long long red[2][3][NW];   // cross-wave partials (double-buffered: one barrier per reduction point); unused with one wave
 };
 
-// Exact 64-bit sums of NV per-thread int32 partials over the 4 wavefronts of the workgroup.
+// The threads of ONE feature meet here.  One wavefront per feature: LDS operations of a wave complete in order, so a
+// workgroup-scope fence (the compiler's s_waitcnt) plus a wave barrier (no reordering across it) is all it takes.
+__device__ __forceinline__ void lk_sync() {
+  if (NW == 1) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  } else {
+    __syncthreads();
+  }
+}
+
+// Exact 64-bit sums of NV per-thread int32 partials over the wavefronts of the feature.
 template <int NV>
 __device__ __forceinline__ void block_sum_split(const int* v, long long* out, LkShared& S, int& phase) {
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (NW == 1) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) out[k] = wave_sum_i64(v[k]);
+    lk_sync();  // callers rely on the barrier inside (it also publishes LDS written before the reduction)
+    return;
+  }
+  const int wave = (threadIdx.x % LKT) >> 6, lane = threadIdx.x & 63;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const long long t = wave_sum_i64(v[k]);
@@ -106,7 +131,7 @@ __device__ __forceinline__ void block_sum_split(const int* v, long long* out, Lk
 
 // One feature through all pyramid levels; every lane of the wave returns the same values.
 __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, float* ox, float* oy, LkShared& S) {
-  const int lane = threadIdx.x;  // 0..LKT-1: index over the workgroup (4 wavefronts share one feature)
+  const int lane = threadIdx.x % LKT;  // 0..LKT-1: index over the threads that share this feature
   int phase = 0;
   uint8_t status = 1;
   float nx = 0.f, ny = 0.f;
@@ -129,13 +154,13 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
     int iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
     int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
     int iw11 = (1 << 14) - iw00 - iw01 - iw10;
-    __syncthreads();
+    lk_sync();
     // stage the (WIN+3)^2 raw patch: tile (r,c) <-> image (ipy-1+r, ipx-1+c), reflect-101
     for (int i = lane; i < RP * RP; i += LKT) {
       const int r = i / RP, c = i % RP;
       S.raw[i] = Ip[__mul24(reflect101(ipy - 1 + r, Ih_), Iw_) + reflect101(ipx - 1 + c, Iw_)];  // 24-bit factors: full-rate multiply
     }
-    __syncthreads();
+    lk_sync();
     // Scharr at the (WIN+1)^2 grid; zero outside the image (BORDER_CONSTANT derivative padding)
     for (int i = lane; i < G * G; i += LKT) {
       const int r = i / G, c = i % G;
@@ -154,7 +179,7 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       }
       S.gx[i] = (short)vx; S.gy[i] = (short)vy;
     }
-    __syncthreads();
+    lk_sync();
     int pA[3] = {0, 0, 0};  // PPT pixels per thread, each product < 2^24.1: fits int32
     for (int i = lane; i < WIN * WIN; i += LKT) {
       const int r = i / WIN, c = i % WIN;
@@ -210,14 +235,14 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       iw11 = (1 << 14) - iw00 - iw01 - iw10;
       if (!staged || inx < rx0 || inx > rx0 + 2 * RM || iny < ry0 || iny > ry0 + 2 * RM) {  // wave-uniform
         rx0 = inx - RM; ry0 = iny - RM;
-        __syncthreads();
+        lk_sync();
         if (rx0 >= 0 && ry0 >= 0 && rx0 + RS <= Jw_ && ry0 + RS <= Jh_) {
           for (int i = lane; i < RS * RS; i += LKT) S.jreg[i] = Jp[__mul24(ry0 + i / RS, Jw_) + rx0 + i % RS];
         } else {
           for (int i = lane; i < RS * RS; i += LKT)
             S.jreg[i] = Jp[__mul24(reflect101(ry0 + i / RS, Jh_), Jw_) + reflect101(rx0 + i % RS, Jw_)];
         }
-        __syncthreads();
+        lk_sync();
         staged = true;
       }
       const int ob = (iny - ry0) * RS + (inx - rx0);
@@ -284,26 +309,28 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(uint8_t* __restrict__ pyr
   pyr[(size_t)blockIdx.z * pyr_stride + dst_off + (size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
 }
 
-__global__ __launch_bounds__(LKT) void lk_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
-                                                int h, const float* __restrict__ xy, int n, float* __restrict__ out,
-                                                uint8_t* __restrict__ status) {
-  __shared__ LkShared S;
-  const int f = blockIdx.x;
-  if (f >= n) return;
+__global__ __launch_bounds__(LKT * FPB) void lk_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
+                                                      int h, const float* __restrict__ xy, int n, float* __restrict__ out,
+                                                      uint8_t* __restrict__ status) {
+  __shared__ LkShared SS[FPB];
+  LkShared& S = SS[threadIdx.x / LKT];
+  const int f = blockIdx.x * FPB + threadIdx.x / LKT;
+  if (f >= n) return;  // whole wavefronts leave (FPB > 1 only with one wavefront per feature: no workgroup barrier follows)
   const Pyr A = make_pyr(pyrA, w, h), B = make_pyr(pyrB, w, h);
   float ox, oy;
   const uint8_t s = lk_point(A, B, xy[2 * f], xy[2 * f + 1], &ox, &oy, S);
-  if (threadIdx.x == 0) { out[2 * f] = ox; out[2 * f + 1] = oy; status[f] = s; }
+  if (threadIdx.x % LKT == 0) { out[2 * f] = ox; out[2 * f + 1] = oy; status[f] = s; }
 }
 
 // forward + backward + keep predicate (src/feature_tracker.cpp:44-55)
-__global__ __launch_bounds__(LKT) void lk_fb_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
-                                                   int h, const float* __restrict__ xy, const float* __restrict__ init_xy,
-                                                   const int* __restrict__ n_dev, int n_host, float* __restrict__ fwd,
-                                                   uint8_t* __restrict__ keep, float* __restrict__ parallax) {
-  __shared__ LkShared S;
+__global__ __launch_bounds__(LKT * FPB) void lk_fb_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
+                                                         int h, const float* __restrict__ xy, const float* __restrict__ init_xy,
+                                                         const int* __restrict__ n_dev, int n_host, float* __restrict__ fwd,
+                                                         uint8_t* __restrict__ keep, float* __restrict__ parallax) {
+  __shared__ LkShared SS[FPB];
+  LkShared& S = SS[threadIdx.x / LKT];
   const int n = n_dev ? *n_dev : n_host;
-  const int f = blockIdx.x;
+  const int f = blockIdx.x * FPB + threadIdx.x / LKT;
   if (f >= n) return;
   const Pyr A = make_pyr(pyrA, w, h), B = make_pyr(pyrB, w, h);
   const float x0 = xy[2 * f], y0 = xy[2 * f + 1];
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(LKT) void lk_fb_kernel(const uint8_t* __restrict__ 
   const uint8_t s1 = lk_point(A, B, x0, y0, &fx, &fy, S);
   uint8_t s2 = 0;
   if (s1) s2 = lk_point(B, A, fx, fy, &bx, &by, S);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x % LKT == 0) {
     uint8_t k = 0;
     float par = 0.f;
     if (s1 && s2) {
@@ -422,7 +449,7 @@ int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int
 int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int w, int h, const float* xy, int n,
              float* out_xy, uint8_t* status) {
   if (n <= 0) return SVO_OK;
-  hipLaunchKernelGGL(lk_kernel, dim3(n), dim3(LKT), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, n, out_xy, status);
+  hipLaunchKernelGGL(lk_kernel, dim3(svo_div_up(n, FPB)), dim3(LKT * FPB), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, n, out_xy, status);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }
@@ -432,7 +459,7 @@ int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, 
                 float* kept_xy, int* kept_index, int* n_kept, float* av_parallax, const SvoTrackCarry* carry) {
   if (n_max > 0) {
     SvoProfScope prof(ctx, SVO_PROF_LK_FB);
-    hipLaunchKernelGGL(lk_fb_kernel, dim3(n_max), dim3(LKT), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
+    hipLaunchKernelGGL(lk_fb_kernel, dim3(svo_div_up(n_max, FPB)), dim3(LKT * FPB), 0, ctx->stream, pyr_prev, pyr_next, w, h, xy, initial_xy, n_dev,
                        n_max, fwd_xy, keep_flag, parallax);
   }
   hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, fwd_xy, keep_flag, parallax, n_dev, n_max,

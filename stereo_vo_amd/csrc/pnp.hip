@@ -280,9 +280,12 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
 #pragma unroll
     for (int e = 0; e < 28; ++e) sPart[tid][e] = v[e];
     __syncthreads();
+    // the declared binary tree (partial t += partial t + s for s = 128, 64, .., 1), element-parallel: the s x 28
+    // independent additions of a level are spread over all 256 threads instead of 28 sequential ones on s of them
     for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s)
-        for (int e = 0; e < 28; ++e) sPart[tid][e] += sPart[tid + s][e];
+      double* lo = &sPart[0][0];
+      const double* hi = &sPart[s][0];
+      for (int i = tid; i < s * 28; i += 256) lo[i] += hi[i];
       __syncthreads();
     }
     if (with_jac && tid == 0) {
