@@ -104,11 +104,13 @@ __device__ void retract(const PnpPose& P, const double* d, PnpPose& N) {
   for (int k = 0; k < 3; ++k) N.t[k] = P.t[k] + d[3 + k];
 }
 
-// Shared LM driver.  `Acc` evaluates cost (+ H,g into LDS when with_jac) at the pose in S.cur/S.cand for
-// the whole workgroup and returns the cost (uniform).
+// Shared LM driver.  `acc(pose, H, g)` evaluates the cost — and the normal equations into H / g (LDS) — at `pose` for the
+// whole workgroup and returns the cost (uniform).  The candidate is evaluated WITH its normal equations right away: an
+// accepted step (the common case) then needs no second sweep over the points; the numbers are the ones a re-evaluation
+// at the accepted pose would give, so the iterates are unchanged.
 struct LmShared {
   PnpPose cur, cand;
-  double H[36], g[6], d[6];
+  double H[36], g[6], Hc[36], gc[6], d[6];
   double cost;
   int ok;
 };
@@ -116,7 +118,7 @@ struct LmShared {
 template <typename Acc>
 __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
   double lambda = 1e-3;
-  double cost = acc(S.cur, true);
+  double cost = acc(S.cur, S.H, S.g);
   for (int it = 0; it < max_it; ++it) {
     if (threadIdx.x == 0) {
       S.ok = solve6(S.H, S.g, lambda, S.d) ? 1 : 0;
@@ -125,16 +127,18 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
     __syncthreads();
     const int ok = S.ok;
     if (!ok) { lambda *= 10; __syncthreads(); continue; }
-    const double c2 = acc(S.cand, false);
+    const double c2 = acc(S.cand, S.Hc, S.gc);
     if (c2 < cost) {
       const double* d = S.d;
       const double step2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
       __syncthreads();
       if (threadIdx.x == 0) S.cur = S.cand;
+      if (threadIdx.x < 36) S.H[threadIdx.x] = S.Hc[threadIdx.x];
+      if (threadIdx.x < 6) S.g[threadIdx.x] = S.gc[threadIdx.x];
       __syncthreads();
       lambda *= 0.1;
       if (lambda < 1e-9) lambda = 1e-9;
-      cost = acc(S.cur, true);
+      cost = c2;
       if (step2 < 1e-20) break;
     } else {
       lambda *= 10;
@@ -167,24 +171,24 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
     S.cur = P0;
   }
   __syncthreads();
-  auto acc = [&](const PnpPose& P, bool with_jac) -> double {
+  auto acc = [&](const PnpPose& P, double* H, double* g) -> double {
     double R[9];
     quat_to_R(P.q, R);
-    if (lane < MODEL) pnp_term(R, P.t, xyz, xy, sIdx[lane], f, cx, cy, sE[lane], with_jac ? sJ[lane] : nullptr);
+    if (lane < MODEL) pnp_term(R, P.t, xyz, xy, sIdx[lane], f, cx, cy, sE[lane], sJ[lane]);
     __syncthreads();
-    if (with_jac && lane < 27) {
+    if (lane < 27) {
       if (lane < 21) {  // upper-triangular entry (r,c)
         int r = 0, e = lane;
         while (e >= 6 - r) { e -= 6 - r; ++r; }
         const int c = r + e;
         double s = 0.0;
         for (int k = 0; k < MODEL; ++k) s += sJ[k][r] * sJ[k][c] + sJ[k][6 + r] * sJ[k][6 + c];
-        S.H[6 * r + c] = s;
+        H[6 * r + c] = s;
       } else {
         const int r = lane - 21;
         double s = 0.0;
         for (int k = 0; k < MODEL; ++k) s += sJ[k][r] * sE[k][0] + sJ[k][6 + r] * sE[k][1];
-        S.g[r] = s;
+        g[r] = s;
       }
     }
     double cost = 0.0;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
   }
   __syncthreads();
   const int m = sBase;
-  auto acc = [&](const PnpPose& P, bool with_jac) -> double {
+  auto acc = [&](const PnpPose& P, double* H, double* g) -> double {
     double R[9];
     quat_to_R(P.q, R);
     double v[28];
@@ -266,15 +270,13 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
     for (int k = tid; k < m; k += 256) {
       double e2[2], J[12];
       const int pi = __hip_atomic_load(&inliers[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by wave 0 above
-      v[27] += pnp_term(R, P.t, xyz, xy, pi, f, cx, cy, e2, with_jac ? J : nullptr);
-      if (with_jac) {
-        int o = 0;
+      v[27] += pnp_term(R, P.t, xyz, xy, pi, f, cx, cy, e2, J);
+      int o = 0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) {
-          v[21 + r] += J[r] * e2[0] + J[6 + r] * e2[1];
+      for (int r = 0; r < 6; ++r) {
+        v[21 + r] += J[r] * e2[0] + J[6 + r] * e2[1];
 #pragma unroll
-          for (int c = r; c < 6; ++c) { v[o] += J[r] * J[c] + J[6 + r] * J[6 + c]; ++o; }
-        }
+        for (int c = r; c < 6; ++c) { v[o] += J[r] * J[c] + J[6 + r] * J[6 + c]; ++o; }
       }
     }
 #pragma unroll
@@ -288,11 +290,11 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
       for (int i = tid; i < s * 28; i += 256) lo[i] += hi[i];
       __syncthreads();
     }
-    if (with_jac && tid == 0) {
+    if (tid == 0) {
       int o = 0;
       for (int r = 0; r < 6; ++r) {
-        S.g[r] = sPart[0][21 + r];
-        for (int c = r; c < 6; ++c) S.H[6 * r + c] = sPart[0][o++];
+        g[r] = sPart[0][21 + r];
+        for (int c = r; c < 6; ++c) H[6 * r + c] = sPart[0][o++];
       }
     }
     const double cost = sPart[0][27];

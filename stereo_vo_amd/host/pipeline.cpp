@@ -8,6 +8,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
+
 #include <atomic>
 #include <chrono>
 #include <unordered_map>
@@ -69,18 +71,43 @@ BundleAdjuster::BundleAdjuster(svo_ctx* ctx, size_t window_size, svo_camera_info
 }
 
 void BundleAdjuster::wait() {
-  if (worker_.joinable()) worker_.join();
+  // spin: the solve in flight takes well under a millisecond; yield when it does not show up quickly
+  unsigned spins = 0;
+  while (job_state_.load(std::memory_order_acquire) != 0) {
+    __builtin_ia32_pause();
+    if (++spins > 4096u && (spins & 63u) == 0) sched_yield();
+  }
+}
+
+void BundleAdjuster::worker_loop() {
+  (void)hipSetDevice(ctx_->device);
+  for (;;) {
+    // wait for a job: short spin, then sleep
+    unsigned spins = 0;
+    while (job_state_.load(std::memory_order_acquire) != 1 && !quit_.load(std::memory_order_acquire)) {
+      __builtin_ia32_pause();
+      if (++spins > 20000u) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [this] { return job_state_.load(std::memory_order_acquire) == 1 || quit_.load(std::memory_order_acquire); });
+        spins = 0;
+      }
+    }
+    if (quit_.load(std::memory_order_acquire)) return;
+    run_bundle_adjust();
+    job_state_.store(0, std::memory_order_release);
+  }
 }
 
 void BundleAdjuster::bundle_adjust_async() {
   wait();
   if (!launch_needed_) return;
   launch_needed_ = false;
-  svo_ctx* c = ctx_;
-  worker_ = std::thread([this, c]() {
-    (void)hipSetDevice(c->device);
-    this->run_bundle_adjust();
-  });
+  if (!worker_.joinable()) worker_ = std::thread([this]() { worker_loop(); });
+  {
+    std::lock_guard<std::mutex> lk(mu_);  // pairs with the predicate check of a sleeping worker
+    job_state_.store(1, std::memory_order_release);
+  }
+  cv_.notify_one();
 }
 
 void BundleAdjuster::reset() {
@@ -101,7 +128,18 @@ void BundleAdjuster::reset() {
   last_iterations_ = 0;
 }
 
-BundleAdjuster::~BundleAdjuster() { wait(); if (ba_) svo_ba_destroy(ba_); }
+BundleAdjuster::~BundleAdjuster() {
+  wait();
+  if (worker_.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      quit_.store(true, std::memory_order_release);
+    }
+    cv_.notify_one();
+    worker_.join();
+  }
+  if (ba_) svo_ba_destroy(ba_);
+}
 
 void BundleAdjuster::add_keyframe(std::shared_ptr<Keyframe> kf) {  // src/bundle_adjuster.cpp:60-135
   wait();
@@ -531,6 +569,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
     auto kf = std::make_shared<Keyframe>(Vector3f{{0, 0, 0}}, Quaternionf{1, 0, 0, 0}, sp.left, std::vector<Point2f>(),
                                          std::vector<size_t>(), valid_features_2d, features_3d);
     bundle_adjuster->add_keyframe(kf);
+    if (keyframe_hook_) keyframe_hook_();
     feature_tracker->init(pyr, width_, height_, kf->new_features_2d, kf->new_ids);
     tvec[0] = tvec[1] = tvec[2] = 0.f;
     rvec[0] = rvec[1] = rvec[2] = 0.f;
@@ -602,6 +641,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
 
   phase.next(4);
   bundle_adjuster->add_keyframe(kf);  // :144
+  if (keyframe_hook_) keyframe_hook_();  // the driver may start the solve now: the rest of process() does not touch the graph
   feature_tracker->draw_track();      // :146 (arrow snapshot; a no-op unless an adapter enabled drawing)
 
   std::vector<Point2f> features_2d_for_tracker(kf->tracked_features_2d);  // :148-162
@@ -727,7 +767,17 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
     }
     pending_from = -1;
   };
+  // The solve of a new keyframe starts inside process(), right after add_keyframe (hook below), so that the host-side
+  // gather / upload of the problem overlaps the tracker re-initialisation instead of following it.
+  int cur = 0;
+  p->proc->on_keyframe_added([&]() {
+    // process() joined the previous solve before editing the graph: its poses are final now
+    fill_pending(cur);
+    pending_from = cur;
+    p->adjuster->bundle_adjust_async();  // src/vo_node.cpp:147
+  });
   for (int i = 0; i < batch; ++i) {
+    cur = i;
     svo::DeviceImage L{left + i * istride, W, H, W}, R{right + i * istride, W, H, W};
     p->proc->process(svo::StereoPair(L, R, (double)i, i));  // src/vo_node.cpp:141-144
     svo_frame_result& r = results[i];
@@ -735,17 +785,17 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
     const auto& s = p->proc->stats();
     r.n_detected = s.n_detected; r.n_tracked = s.n_tracked; r.n_inliers = s.n_inliers; r.n_new = s.n_new;
     r.is_keyframe = s.is_keyframe; r.av_parallax = s.av_parallax; r.percent_lost = s.percent_lost;
-    if (!ctx->err.empty()) { p->adjuster->wait(); return SVO_ERR_HIP; }
+    if (!ctx->err.empty()) { p->adjuster->wait(); p->proc->on_keyframe_added(nullptr); return SVO_ERR_HIP; }
     if (p->adjuster->get_last_keyframe() == nullptr) continue;  // src/vo_node.cpp:146
-    if (p->adjuster->new_keyframe_pending()) {
-      // process() joined the previous solve before editing the graph: its poses are final now
+    if (p->adjuster->new_keyframe_pending()) {  // (not reached with the hook; kept for a processor without it)
       fill_pending(i);
       pending_from = i;
-      p->adjuster->bundle_adjust_async();  // src/vo_node.cpp:147
+      p->adjuster->bundle_adjust_async();
     } else if (pending_from < 0) {
       pending_from = i;  // no solve in flight: the pose is the last solved one
     }
   }
+  p->proc->on_keyframe_added(nullptr);
   p->adjuster->wait();
   if (pending_from < 0) pending_from = batch;
   fill_pending(batch);

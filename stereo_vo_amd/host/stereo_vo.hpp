@@ -19,7 +19,11 @@
 #define SVO_STEREO_VO_HPP_
 #include <cstddef>
 #include <cstdint>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -82,7 +86,7 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   // so results are identical to the synchronous call.
   void bundle_adjust_async();
   void wait();
-  bool pending() const { return worker_.joinable(); }
+  bool pending() const { return job_state_.load(std::memory_order_acquire) != 0; }
   bool new_keyframe_pending() const { return launch_needed_; }  // caller-thread flag (the worker never touches it)
   void get_world_points(std::vector<Point3f>& world_points, const std::vector<size_t>& ids);
   void get_world_points_into(float* xyz, const std::vector<size_t>& ids);  // same, into a caller buffer (3 floats per id)
@@ -103,7 +107,15 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   bool new_frame_added_ = false;   // owned by whoever runs bundle_adjust()
   bool launch_needed_ = false;     // owned by the caller thread
   double solved_pose_[7] = {1, 0, 0, 0, 0, 0, 0};
+  // One persistent worker per adjuster (created with the first asynchronous solve): a keyframe costs no thread
+  // creation.  job_state_: 0 idle, 1 posted / running.  The worker spins briefly for the next job (keyframes arrive
+  // every millisecond or so when a stream runs flat out), then sleeps on the condition variable.
+  void worker_loop();
   std::thread worker_;
+  std::atomic<int> job_state_{0};
+  std::atomic<bool> quit_{false};
+  std::mutex mu_;
+  std::condition_variable cv_;
 };
 
 class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing: get_track_arrows + svo_draw_track)
@@ -187,6 +199,9 @@ class ImageProcessor {  // src/image_processor.hpp:31-46
   int process_host(const uint8_t* left, int left_stride, const uint8_t* right, int right_stride, int width, int height,
                    double t);
   bool ok() const { return alloc_ok_; }
+  // Called by process() right after BundleAdjuster::add_keyframe (before the tracker is re-initialised): lets a driver
+  // start the asynchronous solve of the new keyframe while process() finishes.  Unset: nothing happens.
+  void on_keyframe_added(std::function<void()> hook) { keyframe_hook_ = std::move(hook); }
   // per-frame diagnostics of the last process() call
   struct Stats { int n_detected = 0, n_tracked = 0, n_inliers = 0, n_new = 0, is_keyframe = 0; float av_parallax = 0, percent_lost = 0; };
   const Stats& stats() const { return stats_; }
@@ -197,6 +212,7 @@ class ImageProcessor {  // src/image_processor.hpp:31-46
                           const DeviceImage& right, const float camera_pose[16]);
   svo_ctx* ctx_;
   bool alloc_ok_ = false;
+  std::function<void()> keyframe_hook_;
   uint8_t* d_stage_ = nullptr; size_t stage_bytes_ = 0;  // process_host: left | right
   float K_[9];
   std::shared_ptr<FeatureTracker> feature_tracker;
