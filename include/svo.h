@@ -93,6 +93,10 @@ int svo_reference_constants(svo_reference_constants_t* out);
  * NULL/"" disables.  svo_profile_read synchronises the stream and returns the summed duration and the
  * launch count since the last svo_profile_select. */
 int svo_profile_select(svo_ctx* ctx, const char* kernel);
+/* Measurement aid: the card's own ceilings for the roofline objects (SURVEY 8d asks for a measured FP64 figure).
+ * what: "f64_fma" (vector FMA), "f64_muladd" (separate multiply + add: what the parity-exact kernels issue),
+ * "f64_mfma" (v_mfma_f64_16x16x4_f64), "hbm_copy" (512 MiB device copy).  *value: flop/s or bytes/s (read + write). */
+int svo_measure_peak(svo_ctx* ctx, const char* what, double* value);
 int svo_profile_read(svo_ctx* ctx, double* total_ms, int* launches);
 
 /* ------------------------------------------------------------------ a11 --

@@ -151,7 +151,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
 # every symbol include/svo.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "svo_create", "svo_destroy", "svo_last_error", "svo_stream", "svo_sync", "svo_version", "svo_reference_constants",
-    "svo_profile_select", "svo_profile_read",
+    "svo_profile_select", "svo_profile_read", "svo_measure_peak",
     "svo_reproj_eval", "svo_reproj_eval_dev",
     "svo_corner_detect", "svo_corner_detect_batch_dev", "svo_corner_response",
     "svo_stereo_bm", "svo_stereo_disparity_at", "svo_stereo_disparity_at_dev",
@@ -272,6 +272,12 @@ class Context:
         return self.L.svo_stream(self.h)
 
     # ---- a11
+    def measure_peak(self, what):
+        """flop/s or bytes/s of this card for "f64_fma" / "f64_muladd" / "f64_mfma" / "hbm_copy" (svo_measure_peak)."""
+        v = C.c_double(0.0)
+        self._chk(self.L.svo_measure_peak(self.h, what.encode(), C.byref(v)), "svo_measure_peak")
+        return v.value
+
     def reproj_eval(self, pose7, point3, obs2, focal, cx, cy, want_jpose=True, want_jpoint=True):
         pose7, point3, obs2 = _f64(pose7), _f64(point3), _f64(obs2)
         n = pose7.shape[0]

@@ -27,7 +27,8 @@ def test_product_lm_control_equals_the_oracle_loop(seed, K, N, dense):
     assert st.speculations == s.iterations and misses <= 3
     assert st.linearize_calls <= 1 + misses
     # collectives: every stand-alone pass A; per step one (same sweep) or two (payload2, decision, payload1)
-    assert exchanges == st.linearize_calls + st.single_exchange + 2 * (st.step_calls - st.single_exchange)
+    chained = st.speculations - st.single_exchange
+    assert exchanges == st.linearize_calls + (st.step_calls - chained) + 2 * chained
 
 
 def test_speculation_can_be_disabled_without_changing_results(monkeypatch):

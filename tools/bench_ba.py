@@ -1,7 +1,9 @@
 """bench.py --workload ba50k: BASELINE.json configs[3] — synthetic 50k-landmark / 20-keyframe bundle
-adjustment, landmarks sharded across the ranks, one RCCL all-reduce of the reduced camera system per LM
-iteration (the path's only exchange step).  A step = one LM iteration (strong scaling: the
-problem is fixed, per-rank work shrinks with N)."""
+adjustment, landmarks sharded across the ranks (landmark j on rank j mod N, poses replicated), the reduced
+camera system summed over the ranks by RCCL called from the library on the adjuster's own stream
+(svo_ba_set_comm).  A step = one LM iteration (strong scaling: the problem is fixed, per-rank
+work shrinks with N).  The timed solve follows an untimed warm-up solve of the same problem (code objects
+loaded, workspaces sized, communicator warmed)."""
 import os
 import sys
 import time
@@ -10,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F, CX, CY, W, H = 718.856, 607.1928, 185.2157, 1241, 376
-FP64_MATRIX_PEAK_TFLOPS = 78.6  # v_mfma_f64_16x16x4: 2048 flop / 64 cycles / SIMD (measured: SQ_VALU_MFMA_BUSY_CYCLES = 64 x MFMA count)
+FP64_PUBLIC_PEAK_TFLOPS = 78.6  # AMD's public MI355X figure for the FP64 vector and matrix pipes (not in the local guide)
 
 
 def make_problem(seed=0xBA000004, K=20, N=50000, dense=False, noise=0.5):
@@ -59,6 +61,50 @@ def flops_per_iteration(op, oj, n_points):
     return 466.0 * len(op) + float(np.sum(50 + 144 * L + 216 * L * (L + 1) / 2))
 
 
+def bytes_per_iteration(n_obs, n_points, K):
+    """24 B per observation (uv + two indices), 48 B per landmark (read + write), 56 B per pose."""
+    return 24.0 * n_obs + 48.0 * n_points + 56.0 * K
+
+
+def rccl_comm(S, dist, torch, dev, rank, world, local):
+    """The rank's ncclComm_t for the library's own all-reduce: the unique id is created on rank 0 by the librccl the
+    library binds and broadcast through the process group (whatever its backend is)."""
+    from stereo_vo_amd import api
+    if dist.get_backend() == "nccl":
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(api.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        uid = bytes(idt.cpu().numpy().tobytes())
+    else:
+        box = [api.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, 0)
+        uid = box[0]
+    return api.rccl_comm_create(world, rank, uid, local)
+
+
+def cpu_baseline(p, K, seconds=12.0):
+    """The CPU oracle (restatement of ceres::Solve DENSE_SCHUR, kind "port") on a bounded sample of the SAME problem:
+    the first landmarks whose observations add up to ~1/8 of the problem, a few LM iterations, host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    cores = min(os.cpu_count() or 1, 16)
+    n_lm = len(p["points0"]) // 8
+    m = p["oj"] < n_lm
+    op, oj, uv, pts = p["op"][m], p["oj"][m], p["uv"][m], p["points0"][:n_lm]
+    t0 = time.perf_counter()
+    its = 0
+    while time.perf_counter() - t0 < seconds and its < 12:
+        _, _, so = O.ba_solve(p["poses0"], pts, op, oj, uv, F, CX, CY, max_iterations=3, num_threads=cores)
+        its += max(so["iterations"], 1)
+    dt = time.perf_counter() - t0
+    frac = len(op) / len(p["op"])
+    # iterations/s of the FULL problem: work is linear in the observations, so the sample's rate scales by its share
+    return dict(value=its / dt * frac, unit="iterations/s", cores=cores, kind="port",
+                sample=f"oracle ba_solve on the first {n_lm} landmarks ({len(op)} of {len(p['op'])} observations, {its} LM "
+                       f"iterations in {dt:.1f} s), rate scaled by the observation share {frac:.3f}")
+
+
 def run(args):
     sys.path.insert(0, ROOT)
     import stereo_vo_amd as S
@@ -76,9 +122,24 @@ def run(args):
     acc_mode = os.environ.get("SVO_BA_ACC", "mfma")
     ba = S.BA(ctx, K, F, CX, CY, max_landmarks=len(pts) + 8, max_observations=len(op) + 8, max_iterations=iters, max_time_s=0.0,
               accumulation=acc_mode)
+    comm = None
     if dist is not None:
-        ba.set_allreduce(sharding.allreduce_device_fn(dist, dev))
-    # warm-up solve (W iterations), then the timed solve of exactly K LM iterations from the same start
+        if os.environ.get("SVO_BA_COLLECTIVE", "rccl") == "rccl" and dist.get_backend() == "nccl":
+            comm = rccl_comm(S, dist, torch, dev, rank, world, local)
+            ba.set_comm(comm)  # ncclAllReduce from the library, on the adjuster's stream: no Python in the LM loop
+        else:
+            ba.set_allreduce(sharding.allreduce_device_fn(dist, dev))  # rehearsal on one GPU (gloo): callback
+    # warm-up solve, then the timed solve of exactly `iters` LM iterations from the same start
+    warm = max(1, min(args.warmup, iters))
+    wb = S.BA(ctx, K, F, CX, CY, max_landmarks=len(pts) + 8, max_observations=len(op) + 8, max_iterations=warm, max_time_s=0.0,
+              accumulation=acc_mode)
+    if comm is not None:
+        wb.set_comm(comm)
+    elif dist is not None:
+        wb.set_allreduce(sharding.allreduce_device_fn(dist, dev))
+    wb.load_problem(p["poses0"], pts, op, oj, uv)
+    ws = wb.solve_problem()
+    wb.close()
     ba.load_problem(p["poses0"], pts, op, oj, uv)
     ctx.profile_select("ba_linearize")
     bench.barrier_sync(torch, dist, ctx)
@@ -87,33 +148,51 @@ def run(args):
     bench.barrier_sync(torch, dist, ctx)
     dt = time.perf_counter() - t0
     k_ms, k_n = ctx.profile_read()
+    st = ba.last_stats()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     n_it = max(s.iterations, 1)
     fl_local = flops_per_iteration(op, oj, len(pts))
+    n = 6 * (K - 1)
     out = {"metric": "BA LM iterations/sec (50k landmarks x 20 keyframes)", "value": n_it / dt, "unit": "iterations/s",
-           "n_gpus": world, "steps": n_it, "warmup": 0, "ms_per_step": 1e3 * dt / n_it, "higher_is_better": True,
+           "n_gpus": world, "steps": n_it, "warmup": ws.iterations, "ms_per_step": 1e3 * dt / n_it, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "ba_50k_landmarks_20_keyframes (BASELINE configs[3])", "observations": int(len(p["op"])),
                       "landmarks": int(len(p["points0"])), "poses": K, "final_cost": s.final_cost,
-                      "initial_cost": s.initial_cost, "collective": "allreduce(sum,f64) of %d doubles per LM iteration" % ((6 * (K - 1)) ** 2 + 18 * (K - 1) + 2)}}
+                      "initial_cost": s.initial_cost, "accumulation": acc_mode,
+                      "sharding": "landmark j on rank j mod N, poses replicated",
+                      "collective": ("ncclAllReduce(sum, f64) from libsvo_hip.so on the adjuster's stream" if comm is not None else
+                                     "callback" if dist is not None else "none (single rank)"),
+                      "doubles_per_exchange": {"payload2": 8, "payload1": n * n + 3 * n + 2},
+                      "lm_stats": {"stand_alone_pass_A": st.linearize_calls, "steps": st.step_calls,
+                                   "next_linearisation_with_the_step": st.speculations, "usable": st.speculation_hits,
+                                   "payloads_in_one_collective": st.single_exchange}}}
     if k_n:
-        # roofline of the dominant kernel.  Two figures: `achieved` = SURVEY 8d algorithmic f64 flops of one
-        # linearisation / launch time (what the work needs); `mfma_issued` = MFMA instructions x 2048 flop /
-        # launch time (what the matrix pipe executed: K = 3 of 4 slots and padded 16x16 tiles included).
+        # roofline of the dominant kernel.  achieved = SURVEY 8d algorithmic f64 flops of one linearisation / launch time,
+        # HIP events on the adjuster's stream.  peak = the f64 MFMA rate MEASURED on this card (svo_measure_peak).
         avg_us = 1e3 * k_ms / k_n
         tf = fl_local / (avg_us * 1e-6) / 1e12
-        Lc = np.bincount(oj, minlength=len(pts))
+        peaks = {k: ctx.measure_peak(k) / 1e12 for k in ("f64_mfma", "f64_fma", "f64_muladd")}
+        hbm = ctx.measure_peak("hbm_copy") / 1e9
         out["roofline"] = {"kernel": "ba_linearize_mfma_kernel" if acc_mode == "mfma" else "ba_linearize_kernel",
-                           "bound": "mfma", "achieved": tf, "peak": FP64_MATRIX_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": tf / FP64_MATRIX_PEAK_TFLOPS, "traffic": None, "avg_launch_us": avg_us,
+                           "bound": "mfma", "achieved": tf, "peak": peaks["f64_mfma"],
+                           "unit": "TFLOP/s", "frac": tf / peaks["f64_mfma"], "traffic": None, "avg_launch_us": avg_us,
                            "launches": k_n, "accumulation": acc_mode,
-                           "note": "f64: matrix and vector peak are both 78.6 TF on MI355X; per-rank algorithmic flops "
-                                   "(466/observation + 50 + 144 L + 108 L(L+1) per landmark); MFMA pipe busy fraction "
-                                   "from rocprofv3 PMC is in profiles/r01_ba50k_mfma_pmc*.txt"}
+                           "measured_peaks_tflops": peaks, "public_peak_tflops": FP64_PUBLIC_PEAK_TFLOPS,
+                           "measured_hbm_copy_gbs": hbm,
+                           "algorithmic_bytes_per_launch": bytes_per_iteration(len(op), len(pts), K),
+                           "note": "per-rank algorithmic flops (466/observation + 50 + 144 L + 108 L(L+1) per landmark) over the "
+                                   "launch time; peaks measured on this card by svo_measure_peak; the kernel's parity-exact "
+                                   "residual/Jacobian part issues separate f64 multiply and add (f64_muladd row), only the "
+                                   "Schur products run on the matrix pipe"}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
+        out["cpu_baseline"] = cpu_baseline(p, K)
     ba.close()
+    if comm is not None:
+        from stereo_vo_amd import api
+        api.rccl_comm_destroy(comm)
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
