@@ -85,7 +85,7 @@ constexpr int RS = G + 2 * RM;   // 32
 
 struct LkShared {
   uint8_t raw[RP * RP];      // source patch of the template image (reflect-101 staged)
-  uint8_t jreg[RS * RS];     // target-image region; restaged only when the window leaves it
+  alignas(4) uint8_t jreg[RS * RS + 8];  // target-image region; restaged only when the window leaves it (+8: the aligned-dword reads of the last row)
   short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
   short gx[G * G], gy[G * G];
   long long red[2][3][NW];   // cross-wave partials (double-buffered: one barrier per reduction point); unused with one wave
@@ -130,7 +130,10 @@ __device__ __forceinline__ void block_sum_split(const int* v, long long* out, Lk
 }
 
 // One feature through all pyramid levels; every lane of the wave returns the same values.
+__device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py0, float* ox, float* oy, LkShared& S);
+
 __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, float* ox, float* oy, LkShared& S) {
+  if (NW == 1) return lk_point_wave(A, B, px0, py0, ox, oy, S);
   const int lane = threadIdx.x % LKT;  // 0..LKT-1: index over the threads that share this feature
   int phase = 0;
   uint8_t status = 1;
@@ -259,6 +262,171 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
       long long sb[2];
       block_sum_split<2>(pb, sb, S, phase);
       const long long sb1 = sb[0], sb2 = sb[1];
+      const float b1 = (float)(double)sb1 * FLT_SCALE;
+      const float b2 = (float)(double)sb2 * FLT_SCALE;
+      const float dx = (A12 * b2 - A22 * b1) * D;
+      const float dy = (A12 * b1 - A11 * b2) * D;
+      nx += dx; ny += dy;
+      outx = nx + (float)HALF; outy = ny + (float)HALF;
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= LK_EPS * LK_EPS) break;
+      if (j > 0 && (double)fabsf(dx + pdx) < LK_EPS && (double)fabsf(dy + pdy) < LK_EPS) {
+        outx -= dx * 0.5f; outy -= dy * 0.5f;
+        break;
+      }
+      pdx = dx; pdy = dy;
+    }
+    nx = outx; ny = outy;
+    if (status && level == 0) {
+      const float fx = nx - (float)HALF, fy = ny - (float)HALF;
+      const int ix = (int)floorf(fx), iy = (int)floorf(fy);
+      if (ix < -WIN || ix >= Jw_ || iy < -WIN || iy >= Jh_) status = 0;
+    }
+  }
+  *ox = nx; *oy = ny;
+  return status;
+}
+
+// ---- one wavefront per feature (LKT == 64) ------------------------------------------------------------------------
+// Lane = (window row r, third of the row): 63 lanes own 7 consecutive pixels of one row each.  The template (patch value
+// and both derivatives of its 7 pixels) lives in REGISTERS for all iterations of a level; the Scharr derivatives are
+// formed straight from the staged source patch (no derivative grid in LDS, no extra synchronisation); an iteration reads
+// its 2 x 8 target bytes as six aligned LDS dwords (v_alignbyte + bit-field extracts) instead of 28 byte reads, and every
+// horizontal neighbour is reused.  All sums are exact integers (see wave_sum_i64), so the pixel-to-lane mapping and the
+// order of additions cannot change a bit of the result: same numbers as the oracle's sequential int64 loops.
+__device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py0, float* ox, float* oy, LkShared& S) {
+  const int lane = threadIdx.x & 63;
+  const bool act = lane < 63;
+  const int r = act ? lane / 3 : 0, c0 = act ? 7 * (lane - 3 * (lane / 3)) : 0;
+  int phase = 0;
+  uint8_t status = 1;
+  float nx = 0.f, ny = 0.f;
+  for (int level = LEVELS - 1; level >= 0; --level) {
+    const uint8_t *Ip, *Jp;
+    int Iw_, Ih_, Jw_, Jh_;
+    pyr_level(A, level, Ip, Iw_, Ih_);
+    pyr_level(B, level, Jp, Jw_, Jh_);
+    const float sc = (float)(1.0 / (double)(1 << level));
+    float pxl = px0 * sc, pyl = py0 * sc;
+    if (level == LEVELS - 1) { nx = pxl; ny = pyl; } else { nx = nx * 2.0f; ny = ny * 2.0f; }
+    pxl -= (float)HALF; pyl -= (float)HALF;
+    const int ipx = (int)floorf(pxl), ipy = (int)floorf(pyl);
+    if (ipx < -WIN || ipx >= Iw_ || ipy < -WIN || ipy >= Ih_) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    float a = pxl - (float)ipx, b = pyl - (float)ipy;
+    int iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << 14));
+    int iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
+    int iw10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
+    int iw11 = (1 << 14) - iw00 - iw01 - iw10;
+    lk_sync();
+    // stage the (WIN+3)^2 raw patch: tile (r,c) <-> image (ipy-1+r, ipx-1+c), reflect-101
+    for (int i = lane; i < RP * RP; i += 64) {
+      const int rr = i / RP, cc = i % RP;
+      S.raw[i] = Ip[__mul24(reflect101(ipy - 1 + rr, Ih_), Iw_) + reflect101(ipx - 1 + cc, Iw_)];
+    }
+    lk_sync();
+    // template of my 7 pixels: rows r..r+3, columns c0..c0+9 of the patch
+    int tI[7], tX[7], tY[7];
+    int pA[3] = {0, 0, 0};
+    {
+      int t[4][10];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 10; ++i) t[j][i] = S.raw[(r + j) * RP + c0 + i];
+      // Scharr at grid rows r, r+1 and columns c0..c0+7; zero outside the image (BORDER_CONSTANT derivative padding)
+      int gx[2][8], gy[2][8];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int X = ipx + c0 + i, Y = ipy + r + j;
+          const int s0 = (t[j][i] + t[j + 2][i]) * 3 + t[j + 1][i] * 10, s2 = (t[j][i + 2] + t[j + 2][i + 2]) * 3 + t[j + 1][i + 2] * 10;
+          const int d0 = t[j + 2][i] - t[j][i], d1 = t[j + 2][i + 1] - t[j][i + 1], d2 = t[j + 2][i + 2] - t[j][i + 2];
+          const bool in = X >= 0 && X < Iw_ && Y >= 0 && Y < Ih_;
+          gx[j][i] = in ? (int)(short)(s2 - s0) : 0;
+          gy[j][i] = in ? (int)(short)((d2 + d0) * 3 + d1 * 10) : 0;
+        }
+#pragma unroll
+      for (int p = 0; p < 7; ++p) {
+        const int ival = descale(__mul24(t[1][p + 1], iw00) + __mul24(t[1][p + 2], iw01) + __mul24(t[2][p + 1], iw10) + __mul24(t[2][p + 2], iw11), 9);
+        const int ixv = descale(__mul24(gx[0][p], iw00) + __mul24(gx[0][p + 1], iw01) + __mul24(gx[1][p], iw10) + __mul24(gx[1][p + 1], iw11), 14);
+        const int iyv = descale(__mul24(gy[0][p], iw00) + __mul24(gy[0][p + 1], iw01) + __mul24(gy[1][p], iw10) + __mul24(gy[1][p + 1], iw11), 14);
+        // the patches are int16 in the reference arithmetic (oracle: (short) stores)
+        tI[p] = (int)(short)ival; tX[p] = (int)(short)ixv; tY[p] = (int)(short)iyv;
+        if (act) {
+          pA[0] += __mul24(tX[p], tX[p]);
+          pA[1] += __mul24(tX[p], tY[p]);
+          pA[2] += __mul24(tY[p], tY[p]);
+        }
+      }
+    }
+    long long sA[3];
+    block_sum_split<3>(pA, sA, S, phase);
+    const float A11 = (float)(double)sA[0] * FLT_SCALE;
+    const float A12 = (float)(double)sA[1] * FLT_SCALE;
+    const float A22 = (float)(double)sA[2] * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float dif = A11 - A22;
+    const float minEig = (A22 + A11 - sqrtf(dif * dif + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+    if (minEig < MIN_EIG || D < FLT_EPS) {
+      if (level == 0) status = 0;
+      continue;
+    }
+    D = 1.f / D;
+    float outx = nx, outy = ny;
+    nx -= (float)HALF; ny -= (float)HALF;
+    float pdx = 0.f, pdy = 0.f;
+    int rx0 = 0, ry0 = 0;
+    bool staged = false;
+    const uint32_t* jw = reinterpret_cast<const uint32_t*>(S.jreg);
+    for (int j = 0; j < MAX_ITER; ++j) {
+      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+      if (inx < -WIN || inx >= Jw_ || iny < -WIN || iny >= Jh_) {
+        if (level == 0) status = 0;
+        break;
+      }
+      a = nx - (float)inx; b = ny - (float)iny;
+      iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << 14));
+      iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << 14));
+      iw10 = __float2int_rn((1.f - a) * b * (float)(1 << 14));
+      iw11 = (1 << 14) - iw00 - iw01 - iw10;
+      if (!staged || inx < rx0 || inx > rx0 + 2 * RM || iny < ry0 || iny > ry0 + 2 * RM) {  // wave-uniform
+        rx0 = inx - RM; ry0 = iny - RM;
+        lk_sync();
+        if (rx0 >= 0 && ry0 >= 0 && rx0 + RS <= Jw_ && ry0 + RS <= Jh_) {
+          for (int i = lane; i < RS * RS; i += 64) S.jreg[i] = Jp[__mul24(ry0 + i / RS, Jw_) + rx0 + i % RS];
+        } else {
+          for (int i = lane; i < RS * RS; i += 64)
+            S.jreg[i] = Jp[__mul24(reflect101(ry0 + i / RS, Jh_), Jw_) + reflect101(rx0 + i % RS, Jw_)];
+        }
+        lk_sync();
+        staged = true;
+      }
+      // my two target rows, 8 bytes each, from three aligned dwords per row
+      const int base = (iny - ry0 + r) * RS + (inx - rx0) + c0;
+      const int wi = base >> 2, sh = base & 3;
+      const uint32_t u0 = jw[wi], u1 = jw[wi + 1], u2 = jw[wi + 2];
+      const uint32_t v0 = jw[wi + RS / 4], v1 = jw[wi + RS / 4 + 1], v2 = jw[wi + RS / 4 + 2];
+      const uint32_t tl = __builtin_amdgcn_alignbyte(u1, u0, sh), th = __builtin_amdgcn_alignbyte(u2, u1, sh);
+      const uint32_t bl = __builtin_amdgcn_alignbyte(v1, v0, sh), bh = __builtin_amdgcn_alignbyte(v2, v1, sh);
+      int tt[8], bb[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        tt[k] = (int)((tl >> (8 * k)) & 255u); tt[4 + k] = (int)((th >> (8 * k)) & 255u);
+        bb[k] = (int)((bl >> (8 * k)) & 255u); bb[4 + k] = (int)((bh >> (8 * k)) & 255u);
+      }
+      int pb[2] = {0, 0};
+      if (act) {
+#pragma unroll
+        for (int p = 0; p < 7; ++p) {
+          const int diff = descale(__mul24(tt[p], iw00) + __mul24(tt[p + 1], iw01) + __mul24(bb[p], iw10) + __mul24(bb[p + 1], iw11), 9) - tI[p];
+          pb[0] += __mul24(diff, tX[p]);   // |diff| <= 8160, |gradient| <= 4080
+          pb[1] += __mul24(diff, tY[p]);
+        }
+      }
+      const long long sb1 = wave_sum_i64(pb[0]), sb2 = wave_sum_i64(pb[1]);
       const float b1 = (float)(double)sb1 * FLT_SCALE;
       const float b2 = (float)(double)sb2 * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;
