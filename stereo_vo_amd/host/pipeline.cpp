@@ -70,12 +70,27 @@ BundleAdjuster::BundleAdjuster(svo_ctx* ctx, size_t window_size, svo_camera_info
   reset();
 }
 
+namespace {
+std::atomic<int> g_pipelines{0};
+}
+void pipeline_count_add(int delta) { g_pipelines.fetch_add(delta, std::memory_order_relaxed); }
+unsigned spin_budget() {
+  static const char* e = getenv("SVO_SPIN");  // override: pause iterations before sleeping
+  if (e && *e) return (unsigned)atol(e);
+  return g_pipelines.load(std::memory_order_relaxed) <= 2 ? 4000000u : 1500u;  // ~0.1 s (never sleeps in practice) / ~50 us
+}
+
 void BundleAdjuster::wait() {
-  // spin: the solve in flight takes well under a millisecond; yield when it does not show up quickly
+  // the solve in flight takes well under a millisecond: poll first, sleep if it does not show up within the budget
+  const unsigned budget = spin_budget();
   unsigned spins = 0;
   while (job_state_.load(std::memory_order_acquire) != 0) {
     __builtin_ia32_pause();
-    if (++spins > 4096u && (spins & 63u) == 0) sched_yield();
+    if (++spins > budget) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_done_.wait(lk, [this] { return job_state_.load(std::memory_order_acquire) == 0; });
+      return;
+    }
   }
 }
 
@@ -83,10 +98,11 @@ void BundleAdjuster::worker_loop() {
   (void)hipSetDevice(ctx_->device);
   for (;;) {
     // wait for a job: short spin, then sleep
+    const unsigned budget = spin_budget();
     unsigned spins = 0;
     while (job_state_.load(std::memory_order_acquire) != 1 && !quit_.load(std::memory_order_acquire)) {
       __builtin_ia32_pause();
-      if (++spins > 20000u) {
+      if (++spins > budget) {
         std::unique_lock<std::mutex> lk(mu_);
         cv_.wait(lk, [this] { return job_state_.load(std::memory_order_acquire) == 1 || quit_.load(std::memory_order_acquire); });
         spins = 0;
@@ -94,7 +110,11 @@ void BundleAdjuster::worker_loop() {
     }
     if (quit_.load(std::memory_order_acquire)) return;
     run_bundle_adjust();
-    job_state_.store(0, std::memory_order_release);
+    {
+      std::lock_guard<std::mutex> lk(mu_);  // pairs with the predicate check of a sleeping waiter
+      job_state_.store(0, std::memory_order_release);
+    }
+    cv_done_.notify_all();
   }
 }
 
@@ -706,6 +726,7 @@ extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_p
                        p->max_features <= ctx->lim.max_features, "pipeline_create: feature counts outside the context limits");
   SVO_REQUIRE(ctx, p->window_size >= 1 && p->window_size <= 63, "pipeline_create: window size must be 1..63");
   svo_pipeline* pl = new svo_pipeline();
+  svo::pipeline_count_add(1);
   pl->ctx = ctx;
   pl->prm = *p;
   pl->tracker = std::make_shared<svo::FeatureTracker>(ctx, ctx->lim.max_features, ctx->lim.max_width, ctx->lim.max_height);
@@ -717,6 +738,7 @@ extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_p
                                          p->parallax_thresh, p->max_corners, p->quality, ctx->lim.max_batch));
   if (!pl->tracker->ok() || !pl->proc->ok()) {  // an allocation failed: report it here, not as a kernel fault later
     delete pl;
+    svo::pipeline_count_add(-1);
     return SVO_ERR_HIP;
   }
   *out = pl;
@@ -733,6 +755,7 @@ extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
   }
   if (p->d_imgs) (void)hipFree(p->d_imgs);
   delete p;
+  svo::pipeline_count_add(-1);
 }
 
 extern "C" int svo_pipeline_reset(svo_pipeline* p) {

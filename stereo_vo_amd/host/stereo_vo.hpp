@@ -115,8 +115,17 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   std::atomic<int> job_state_{0};
   std::atomic<bool> quit_{false};
   std::mutex mu_;
-  std::condition_variable cv_;
+  std::condition_variable cv_;       // a job was posted (or quit)
+  std::condition_variable cv_done_;  // the job finished
 };
+
+// How long host threads busy-poll before they go to sleep (pause iterations).  One or two pipelines in the process:
+// latency mode, spin (a sleeping thread costs ~15 us to wake, twice per keyframe).  More: throughput mode — many stereo
+// streams share the host's CPU quota (16 cores per GPU on the target boxes; two spinning threads per stream exhaust it
+// at 8 streams and the scheduler then throttles every thread), so waits that usually last hundreds of microseconds
+// (the main thread joining a solve, the worker between solves) spin only briefly.
+unsigned spin_budget();
+void pipeline_count_add(int delta);
 
 class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing: get_track_arrows + svo_draw_track)
  public:

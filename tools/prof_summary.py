@@ -1,0 +1,104 @@
+"""Condense a tools/prof_round.sh output directory into the files that are committed under profiles/:
+  <tag>_kernel_stats_8streams.csv / _1stream.csv / _ba50k.csv   rocprofv3 --stats tables (name, calls, total, average, %)
+  <tag>_sq_counters.txt      per kernel and launch: instruction mix + parked / issue-stalled / issuing split
+  <tag>_traffic.json         HBM KB per launch per kernel (FETCH_SIZE + WRITE_SIZE passes) and bytes per stereo pair
+  <tag>_ba50k_mfma_pmc.txt   f64 MFMA counts and matrix-pipe busy cycles per launch
+  <tag>_summary.json         what bench.py reads: kernel_time_share (8 streams / 1 stream), lk_fb VALU instructions per
+                             launch, front-end HBM bytes per pair
+usage: prof_summary.py <prof dir> <out dir> <tag>"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+os.makedirs(out, exist_ok=True)
+
+
+def kname(full):
+    return full.replace("(anonymous namespace)::", "").split("(")[0]
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    return [(kname(r["Name"]), int(r["Calls"]), float(r["TotalDurationNs"]), float(r["AverageNs"]), float(r["Percentage"])) for r in rows]
+
+
+summary = {}
+for key, sub in (("8_streams", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
+    f = os.path.join(src, sub, "p_kernel_stats.csv")
+    if not os.path.exists(f):
+        continue
+    st = stats(f)
+    with open(os.path.join(out, f"{tag}_kernel_stats_{key}.csv"), "w") as w:
+        w.write("kernel,calls,total_ms,average_us,percent\n")
+        for n, c, t, a, p in st:
+            w.write(f"{n},{c},{t / 1e6:.3f},{a / 1e3:.2f},{p:.2f}\n")
+    summary["kernel_time_share_" + key] = {n: round(p, 2) for n, c, t, a, p in st if p >= 0.3}
+    summary["kernel_average_us_" + key] = {n: round(a / 1e3, 2) for n, c, t, a, p in st if p >= 0.3}
+for name in ("bench_s8.json", "bench_s1.json", "bench_ba.json", "gpu_busy_s8.txt", "by_grid_s1.txt", "by_grid_s8.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(out, f"{tag}_{name}"))
+
+
+def counters(sub):
+    f = glob.glob(os.path.join(src, sub, "*counter_collection.csv"))
+    if not f:
+        return {}, {}
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    seen = set()
+    for row in csv.DictReader(open(f[0])):
+        k = kname(row["Kernel_Name"])
+        agg[k][row["Counter_Name"]] += float(row["Counter_Value"])
+        key = (k, row["Dispatch_Id"])
+        if key not in seen:
+            seen.add(key)
+            calls[k] += 1
+    return agg, calls
+
+
+agg, calls = counters("sq")
+if agg:
+    with open(os.path.join(out, f"{tag}_sq_counters.txt"), "w") as w:
+        for k in sorted(agg, key=lambda k: -agg[k]["SQ_WAVE_CYCLES"])[:12]:
+            a, c = agg[k], calls[k]
+            wc = max(a["SQ_WAVE_CYCLES"], 1.0)
+            w.write("%s calls=%d per launch: waves=%.0f valu=%.0f lds=%.0f salu=%.0f wave_cycles(quad)=%.0f | of wave cycles: parked "
+                    "(waitcnt/barrier) %.1f%%, issue-stalled %.1f%%, issuing %.1f%%\n"
+                    % (k, c, a["SQ_WAVES"] / c, a["SQ_INSTS_VALU"] / c, a["SQ_INSTS_LDS"] / c, a["SQ_INSTS_SALU"] / c, a["SQ_WAVE_CYCLES"] / c,
+                       100 * a["SQ_WAIT_ANY"] / wc, 100 * a["SQ_WAIT_INST_ANY"] / wc, 100 * a["SQ_ACTIVE_INST_ANY"] / wc))
+    if "lk_fb_kernel" in agg:
+        summary["lk_fb_valu_wave_instructions_per_launch"] = agg["lk_fb_kernel"]["SQ_INSTS_VALU"] / calls["lk_fb_kernel"]
+        summary["lk_fb_waves_per_launch"] = agg["lk_fb_kernel"]["SQ_WAVES"] / calls["lk_fb_kernel"]
+
+traffic = collections.defaultdict(dict)
+launches = {}
+for c, key in (("FETCH_SIZE", "fetch_kb_per_launch"), ("WRITE_SIZE", "write_kb_per_launch")):
+    a, n = counters(c)
+    for k in a:
+        traffic[k][key] = a[k][c] / n[k]
+        launches[k] = n[k]
+if traffic:
+    # the counter passes ran `bench.py --steps 3 --warmup 1 --streams 1`: 4 steps of 16 frames
+    frames = 4 * 16
+    front = ("corner_response_kernel", "corner_nms_kernel", "corner_select_kernel", "pyr_copy_kernel", "pyr_down_kernel", "lk_fb_kernel",
+             "track_compact_kernel", "stereo_at_kernel")
+    per_pair = sum((traffic[k].get("fetch_kb_per_launch", 0) + traffic[k].get("write_kb_per_launch", 0)) * 1024.0 * launches[k]
+                   for k in front if k in traffic) / frames
+    summary["front_end_hbm_bytes_per_pair_pmc"] = per_pair
+    for k in traffic:
+        traffic[k]["launches"] = launches[k]
+    json.dump(dict(unit="KB per launch, raw FETCH_SIZE / WRITE_SIZE (no 2x correction: byte-granular gathers)", frames=frames,
+                   front_end_bytes_per_pair=per_pair, kernels=traffic), open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
+
+agg, calls = counters("ba_pmc")
+if agg:
+    with open(os.path.join(out, f"{tag}_ba50k_mfma_pmc.txt"), "w") as w:
+        for k in agg:
+            w.write(k + " calls=%d " % calls[k] + " ".join("%s=%.0f" % (c, v / calls[k]) for c, v in sorted(agg[k].items())) + "  (per launch)\n")
+json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
+print(json.dumps(summary)[:600])
