@@ -38,13 +38,17 @@ int decode_pgm(const std::vector<uint8_t>& d, uint8_t* buf, size_t cap, int* w, 
   while (got < 3 && pos < d.size()) {
     if (d[pos] == '#') { while (pos < d.size() && d[pos] != '\n') ++pos; continue; }
     if (d[pos] <= ' ') { ++pos; continue; }
-    int v = 0;
-    while (pos < d.size() && d[pos] >= '0' && d[pos] <= '9') v = v * 10 + (d[pos++] - '0');
-    vals[got++] = v;
+    if (d[pos] < '0' || d[pos] > '9') return SVO_ERR_INVALID;  // anything but a digit here is not a PGM header
+    long long v = 0;
+    while (pos < d.size() && d[pos] >= '0' && d[pos] <= '9') {
+      v = v * 10 + (d[pos++] - '0');
+      if (v > 65535) return SVO_ERR_INVALID;  // image sides are bounded by the corner key packing (y << 16 | x)
+    }
+    vals[got++] = (int)v;
   }
-  if (got < 3 || vals[2] != 255) return SVO_ERR_INVALID;
+  if (got < 3 || vals[2] != 255 || vals[0] <= 0 || vals[1] <= 0) return SVO_ERR_INVALID;
   ++pos;  // single whitespace after maxval
-  const size_t n = (size_t)vals[0] * vals[1];
+  const size_t n = (size_t)vals[0] * (size_t)vals[1];
   if (n > cap || pos + n > d.size()) return SVO_ERR_CAPACITY;
   memcpy(buf, d.data() + pos, n);
   *w = vals[0]; *h = vals[1];
@@ -56,16 +60,23 @@ int decode_png(const std::vector<uint8_t>& d, uint8_t* buf, size_t cap, int* w, 
   if (d.size() < 33 || memcmp(d.data(), sig, 8)) return SVO_ERR_INVALID;
   size_t pos = 8;
   int W = 0, H = 0, depth = 0, ctype = 0;
+  bool have_ihdr = false;
   std::vector<uint8_t> idat;
   while (pos + 12 <= d.size()) {
     const uint32_t len = be32(&d[pos]);
     const uint8_t* type = &d[pos + 4];
     const uint8_t* data = &d[pos + 8];
-    if (pos + 12 + len > d.size()) return SVO_ERR_INVALID;
+    if ((size_t)len > d.size() || pos + 12 + (size_t)len > d.size()) return SVO_ERR_INVALID;
     if (!memcmp(type, "IHDR", 4)) {
-      W = (int)be32(data); H = (int)be32(data + 4); depth = data[8]; ctype = data[9];
+      // exactly one IHDR, first chunk, 13 bytes (a short one would be read past its end)
+      if (have_ihdr || pos != 8 || len != 13) return SVO_ERR_INVALID;
+      have_ihdr = true;
+      const uint32_t w32 = be32(data), h32 = be32(data + 4);
+      if (w32 == 0 || h32 == 0 || w32 > 65535u || h32 > 65535u) return SVO_ERR_INVALID;
+      W = (int)w32; H = (int)h32; depth = data[8]; ctype = data[9];
       if (data[10] != 0 || data[11] != 0 || data[12] != 0) return SVO_ERR_INVALID;  // interlaced PNGs unsupported
     } else if (!memcmp(type, "IDAT", 4)) {
+      if (!have_ihdr) return SVO_ERR_INVALID;
       idat.insert(idat.end(), data, data + len);
     } else if (!memcmp(type, "IEND", 4)) {
       break;

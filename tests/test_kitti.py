@@ -149,3 +149,37 @@ def test_pipeline_draw_track(ctx, frames):
     if not res[1].is_keyframe and not res[2].is_keyframe:
         assert all(green[y, x] for x, y in inside)  # arrow tips sit on the current feature positions
     pipe.close()
+
+
+def test_decoders_reject_malformed_files(tmp_path):
+    """The decoders read files from disk: truncated / hostile headers must be an error, never an out-of-bounds read."""
+    import struct
+    import zlib
+    import stereo_vo_amd as S
+
+    def chunk(t, data):
+        return struct.pack(">I", len(data)) + t + data + struct.pack(">I", zlib.crc32(t + data) & 0xFFFFFFFF)
+    sig = b"\x89PNG\r\n\x1a\n"
+    ihdr = struct.pack(">IIBBBBB", 4, 4, 8, 0, 0, 0, 0)
+    idat = zlib.compress(b"".join(b"\x00" + bytes([10 * r] * 4) for r in range(4)))
+    good = sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b"")
+    bad = {
+        "short_ihdr.png": sig + chunk(b"IHDR", ihdr[:5]) + chunk(b"IDAT", idat) + chunk(b"IEND", b"") + b"\0" * 16,
+        "no_ihdr.png": sig + chunk(b"IDAT", idat) + chunk(b"IEND", b"") + b"\0" * 32,
+        "two_ihdr.png": sig + chunk(b"IHDR", ihdr) + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b""),
+        "zero_size.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0, 4, 8, 0, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b""),
+        "huge.png": sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 70000, 4, 8, 0, 0, 0, 0)) + chunk(b"IDAT", idat) + chunk(b"IEND", b""),
+        "chunk_len.png": sig + struct.pack(">I", 0xFFFFFFF0) + b"IHDR" + ihdr + b"\0" * 8,
+        "neg.pgm": b"P5\n-1 -1\n255\n" + b"\0" * 4,
+        "overflow.pgm": b"P5\n99999999999999999999 2\n255\n" + b"\0" * 4,
+        "zero.pgm": b"P5\n0 7\n255\n",
+        "truncated.pgm": b"P5\n8 8\n255\n" + b"\0" * 10,
+    }
+    f = tmp_path / "good.png"
+    f.write_bytes(good)
+    assert np.array_equal(S.image_read_gray(str(f)), np.array([[10 * r] * 4 for r in range(4)], np.uint8))
+    for name, blob in bad.items():
+        f = tmp_path / name
+        f.write_bytes(blob)
+        with pytest.raises(S.SvoError):
+            S.image_read_gray(str(f))

@@ -8,6 +8,8 @@ import pytest
 
 import oracle_lib as O
 
+BP_F, BP_CX, BP_CY = 718.856, 607.1928, 185.2157
+
 
 def _seq(n, w=496, h=160, focal=300.0, seed=0x5EED0001):
     import stereo_vo_amd as S
@@ -217,3 +219,48 @@ def test_hip_pipelines_concurrent_streams_keep_parity():
         assert got == [(r.n_detected, r.n_tracked, r.n_inliers, r.n_new, r.is_keyframe, r.ba_iterations, list(r.pose7)) for r in ref]
         io, xo = o.tracked()
         assert np.array_equal(ig, io) and np.array_equal(xg.view(np.uint32), xo.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_hip_capacity_overflow_is_reported_not_faulted():
+    """A workspace bound given at svo_create that turns out too small must come back as SVO_ERR_CAPACITY (status -3), not as
+    a kernel fault or silent truncation: here far fewer NMS candidate slots than the image produces."""
+    import stereo_vo_amd as S
+    p, L, R = _seq(2)
+    small = S.Context(640, 480, max_batch=1, max_corners=300, max_candidates=1024, max_features=400)
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = p.width, p.height
+    pp.quality = 1e-6  # every local maximum of the response is a candidate: thousands on this image
+    pp.ba_max_time_s = 0.0
+    g = S.Pipeline(small, pp)
+    with pytest.raises(S.SvoError) as e:
+        g.process_batch(L[:1], R[:1])
+    assert "-3" in str(e.value) or "max_candidates" in str(e.value)
+    # the context survives: the same call with enough slots for this quality level works
+    g.close()
+    small.close()
+
+
+@pytest.mark.gpu
+def test_hip_add_keyframe_more_tracked_than_max_features(ctx):
+    """SURVEY C-5: `max_features - num_tracked` is unsigned in the reference (src/bundle_adjuster.cpp:85) and would wrap when
+    more than max_features observations are tracked; the build guards it: every tracked observation is kept, no new
+    feature is admitted, nothing wraps."""
+    import stereo_vo_amd as S
+    ba = S.api.BA(ctx, 3, BP_F, BP_CX, BP_CY, max_features=50)
+    n0 = 80
+    xy = np.stack([np.linspace(20, 400, n0), np.full(n0, 100.0)], 1).astype(np.float32)
+    xyz = np.stack([np.linspace(-2, 2, n0), np.zeros(n0), np.full(n0, 8.0)], 1).astype(np.float32)
+    pose = np.array([1, 0, 0, 0, 0, 0, 0.0])
+    ids = ba.add_keyframe(pose, [], np.zeros((0, 2), np.float32), xy, xyz)
+    assert list(ids) == list(range(50))  # truncated to max_features (:85-90)
+    # second keyframe: 50 tracked (== max) + 30 offered new ones -> zero admitted
+    new = ba.add_keyframe(pose, ids, xy[:50], xy[50:], xyz[50:])
+    assert len(new) == 0
+    # a caller that tracks MORE than max_features (ids may repeat across calls; here 60 > 50 by observing 10 twice)
+    tid = np.concatenate([ids, ids[:10]])
+    txy = np.concatenate([xy[:50], xy[:10] + 0.25])
+    new = ba.add_keyframe(pose, tid, txy, xy[50:], xyz[50:])
+    assert len(new) == 0 and ba.window_count() == 3
+    ba.close()

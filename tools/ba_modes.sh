@@ -1,4 +1,7 @@
 #!/bin/bash
+set -uo pipefail
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
 # developer aid: per-rank BA iteration time of an N-rank run, emulated on one GPU, for each accumulation mode
 for n in 1 2 4 8; do for m in deterministic atomics mfma; do
   if [ $n = 1 ] && [ $m = deterministic ]; then continue; fi

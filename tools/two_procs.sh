@@ -1,4 +1,7 @@
 #!/bin/bash
+set -uo pipefail
+cd "$(dirname "$0")/.."
+mkdir -p gpurun_out
 # experiment: P bench processes on the same GPU at once, S streams each (is the ceiling the GPU or the per-process runtime?)
 P=${1:-2}; S=${2:-4}
 pids=""
