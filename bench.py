@@ -166,8 +166,6 @@ def run_kitti(args):
     import stereo_vo_amd as S
     torch, dist, rank, local, world = dist_setup(args.gpus)
     B, NS = args.batch, max(1, args.streams)
-    if NS >= 4:  # include/svo.h: adjusters on one shader engine per XCD, trackers on the other three
-        os.environ.setdefault("SVO_BA_CU_SHARE", "8")
     streams = [_Stream(S, torch, local, 0x5EED0001 + rank * 64 + i, B) for i in range(NS)]
     torch.cuda.synchronize()
     ctx = streams[0].ctx
@@ -200,12 +198,14 @@ def run_kitti(args):
                   "note": "one stream alone on the GPU (per rank)"}
     ctx.profile_select(args.profile_kernel)
     barrier_sync(torch, dist, ctx)
+    cpu0 = time.process_time()
     t0 = time.perf_counter()
     run_steps(args.steps)
     for st in streams:
         st.ctx.sync()
     barrier_sync(torch, dist, ctx)
     dt = time.perf_counter() - t0
+    host_cores = (time.process_time() - cpu0) / dt  # CPU time of all threads of this rank over the timed region
     k_ms, k_n = ctx.profile_read()
     ctx.profile_select(None)
     if dist is not None:
@@ -225,7 +225,7 @@ def run_kitti(args):
         "config": {"workload": "kitti_1241x376_1500corners_5kf_window (BASELINE configs[1])", "batch_per_stream": B,
                    "streams_per_gpu": NS, "max_corners": MAXC, "quality": QUALITY, "min_distance": MIN_DIST, "window": WINDOW,
                    "keyframes_per_step": n_kf, "mean_tracked": float(np.mean(n_trk)) if n_trk else 0.0,
-                   "ba_lm_iterations_per_step": ba_it,
+                   "ba_lm_iterations_per_step": ba_it, "host_cores_busy": round(host_cores, 2),
                    "sharding": "independent stereo streams: streams_per_gpu per rank, ranks hold different streams; no collective"},
     }
     if single is not None:

@@ -626,25 +626,35 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(LmCtl ctl, double* paybuf
 // lane = (segment, element).  The last workgroup to arrive publishes the completion word.
 struct ListArgs { int n; int begin[48], end[48]; };  // destination lists of window-sized problems ride in the kernel arguments (n = 0: read P.list_start)
 
-__global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int with_pay2, LmCtl ctl, ListArgs la) {
-  __shared__ double sP[RSEG][36];
+// Workgroups of 256 threads (a 1024-thread workgroup needs half a CU's wave slots at once and queues behind other
+// streams' kernels when several stereo streams share the GPU): a 36-wide pose-pair destination is cut into four
+// independent 9-element slices, an 18-wide pose destination into two — every (segment, element) sum and every
+// 28-term final sum stays inside one workgroup, so the declared order is untouched.
+constexpr int RED_SLICE = 9;
+__host__ __device__ inline int ba_reduce_blocks(int F) { return 4 * (F * (F + 1) / 2) + 2 * F + 1; }
+
+__global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, int with_pay2, LmCtl ctl, ListArgs la) {
+  __shared__ double sP[RSEG][RED_SLICE];
   __shared__ double sOut[4];
-  const int F = P.K - 1, n = P.n, tid = threadIdx.x, d = blockIdx.x;
+  const int F = P.K - 1, n = P.n, tid = threadIdx.x, b = blockIdx.x;
   const int nU = F * (F + 1) / 2, nd = nU + F + 1;
-  if (d < nd1) {
-    const int width = d < nU ? 36 : (d < nU + F ? 18 : 2);
-    const int stride = d < nU ? 36 : (d < nU + F ? 18 : 4);
-    const double* base = d < nU ? P.pairB : (d < nU + F ? P.obsV : P.lmV);
+  const int nb1 = with_pay1 ? ba_reduce_blocks(F) : 0;
+  if (b < nb1) {
+    // destination d and element slice [e_lo, e_lo + width)
+    int d, e_lo, width, stride;
+    const double* base;
+    if (b < 4 * nU) { d = b >> 2; e_lo = RED_SLICE * (b & 3); width = RED_SLICE; stride = 36; base = P.pairB; }
+    else if (b < 4 * nU + 2 * F) { d = nU + ((b - 4 * nU) >> 1); e_lo = RED_SLICE * ((b - 4 * nU) & 1); width = RED_SLICE; stride = 18; base = P.obsV; }
+    else { d = nU + F; e_lo = 0; width = 2; stride = 4; base = P.lmV; }
     const int e0 = la.n ? la.begin[d] : P.list_start[d], len = (la.n ? la.end[d] : P.list_start[nd + 1 + d]) - e0;
     const int seglen = (len + RSEG - 1) / RSEG;
-    for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {  // one pass with 1024 threads
-      const int seg = item / width, e = item % width;
+    if (tid < RSEG * width) {
+      const int seg = tid / width, e = tid % width;
       double acc = 0.0;
       const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-      // 16 independent loads in flight, adds strictly in list order (32 in flight measured slower: 1024-thread
-      // workgroups leave 128 VGPRs per lane).  The row pointer advances by addition: a per-element 64-bit index multiply
-      // is a quarter-rate instruction and was most of this loop's ALU time.
-      const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e;
+      // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
+      // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
+      const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e_lo + e;
       for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
         double v[16];
 #pragma unroll
@@ -660,18 +670,19 @@ __global__ __launch_bounds__(1024) void ba_reduce_kernel(BaDev P, int nd1, int w
       double acc = 0.0;
       for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
       double* out = P.pay1_out;
+      const int el = e_lo + tid;  // element of the destination
       if (d < nU) {
         int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
         while (rest >= F - ka) { rest -= F - ka; ++ka; }
         const int kb = ka + rest;
-        out[(size_t)(6 * ka + tid / 6) * n + 6 * kb + tid % 6] = acc;
+        out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6] = acc;
       } else if (d < nU + F) {
         const int k = d - nU;
-        if (tid < 6) out[(size_t)n * n + n + 6 * k + tid] = acc;                  // g_c
-        else if (tid < 12) out[(size_t)n * n + 6 * k + (tid - 6)] = acc;          // g_red (the -Y g_p part)
-        else out[(size_t)n * n + 2 * n + 6 * k + (tid - 12)] = acc;               // diag U
+        if (el < 6) out[(size_t)n * n + n + 6 * k + el] = acc;                  // g_c
+        else if (el < 12) out[(size_t)n * n + 6 * k + (el - 6)] = acc;          // g_red (the -Y g_p part)
+        else out[(size_t)n * n + 2 * n + 6 * k + (el - 12)] = acc;              // diag U
       } else {
-        out[(size_t)n * n + 3 * n + tid] = acc;
+        out[(size_t)n * n + 3 * n + el] = acc;
       }
     }
   } else if (with_pay2) {
@@ -1081,16 +1092,7 @@ static int ba_alloc(svo_ba* ba) {
     // kernels never queue behind other stereo streams' wide LK launches.  Bulk-sized adjusters keep the whole GPU.
     const char* e = getenv("SVO_BA_CU_SHARE");
     const int nres = e ? atoi(e) : 0;
-    // SVO_BA_XCD=1: a window-sized adjuster keeps to ONE XCD (adjusters are dealt round-robin over the eight): the slots
-    // pass A writes and the reduce kernel reads, the step, the decision — everything the dependent launches of an LM
-    // iteration hand to each other stays in one L2 instead of crossing the fabric at every kernel boundary.
-    static std::atomic<unsigned> next_xcd{0};
-    const char* ex = getenv("SVO_BA_XCD");
-    if (ex && atoi(ex) > 0 && ba->max_obs <= 100000) {
-      uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      mask[next_xcd.fetch_add(1) % 8u] = 0xFFFFFFFFu;
-      SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
-    } else if (nres > 0 && nres < 32 && ba->max_obs <= 100000) {
+    if (nres > 0 && nres < 32 && ba->max_obs <= 100000) {
       uint32_t mask[8];
       for (int i = 0; i < 8; ++i) mask[i] = (1u << nres) - 1u;
       SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
@@ -1512,13 +1514,13 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   if (d.det) {
-    const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
     }
-    ba_aim_reduce(ba, nd, true);
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl, ba_list_args(ba));
+    const int nb = ba_reduce_blocks(K - 1);
+    ba_aim_reduce(ba, nb, true);
+    hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl, ba_list_args(ba));
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
   } else {
@@ -1573,10 +1575,11 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
       hipLaunchKernelGGL(ba_step_kernel, dim3(d.C), dim3(64), 0, st, d, radius, same_sweep ? spec_radius : 0.0);
     }
+    const int nb = ba_reduce_blocks(K - 1);
     if (!chain) {
-      const int blocks = (same_sweep ? nd : 0) + 1;
+      const int blocks = (same_sweep ? nb : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(1024), 0, st, d, same_sweep ? nd : 0, 1, kNoCtl, ba_list_args(ba));
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, same_sweep ? 1 : 0, 1, kNoCtl, ba_list_args(ba));
     } else if (!sharded && d.C > 0) {
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);
@@ -1584,7 +1587,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.C), dim3(128), 0, st, d, lc, ba->h_list_begin[nd - 1], ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1]);
     } else {
       ba_aim_reduce(ba, 1, false);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(1024), 0, st, d, 0, 1, lc, ba_list_args(ba));
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, st, d, 0, 1, lc, ba_list_args(ba));
       if (sharded) {
         int rc = ba_allreduce(ba, 0, PAY2_SLOTS);
         if (rc) return rc;
@@ -1597,8 +1600,8 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       }
     }
     if (chain) {
-      ba_aim_reduce(ba, nd, true);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nd), dim3(1024), 0, st, d, nd, 0, kNoCtl, ba_list_args(ba));
+      ba_aim_reduce(ba, nb, true);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl, ba_list_args(ba));
     }
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }

@@ -77,7 +77,7 @@ void pipeline_count_add(int delta) { g_pipelines.fetch_add(delta, std::memory_or
 unsigned spin_budget() {
   static const char* e = getenv("SVO_SPIN");  // override: pause iterations before sleeping
   if (e && *e) return (unsigned)atol(e);
-  return g_pipelines.load(std::memory_order_relaxed) <= 2 ? 4000000u : 1500u;  // ~0.1 s (never sleeps in practice) / ~50 us
+  return g_pipelines.load(std::memory_order_relaxed) <= 2 ? 4000000u : 300u;  // ~0.1 s (never sleeps in practice) / ~10 us
 }
 
 void BundleAdjuster::wait() {
