@@ -49,6 +49,7 @@
 #include "reproj_device.h"
 
 int svo_rccl_allreduce_f64(void* buf, size_t count, void* comm, hipStream_t stream, const char** err);  // csrc/rccl.hip
+bool svo_throughput_mode();  // host/pipeline.cpp: more than two pipelines share the process
 
 namespace {
 constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
@@ -633,58 +634,77 @@ struct ListArgs { int n; int begin[48], end[48]; };  // destination lists of win
 constexpr int RED_SLICE = 9;
 __host__ __device__ inline int ba_reduce_blocks(int F) { return 4 * (F * (F + 1) / 2) + 2 * F + 1; }
 
+// One slice of payload1: destination d, elements [e_lo, e_lo + width).  Any workgroup size; ends with a barrier.
+__device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la, int b, double (*sP)[RED_SLICE]) {
+  const int F = P.K - 1, n = P.n, tid = threadIdx.x;
+  const int nU = F * (F + 1) / 2, nd = nU + F + 1;
+  int d, e_lo, width, stride;
+  const double* base;
+  if (b < 4 * nU) { d = b >> 2; e_lo = RED_SLICE * (b & 3); width = RED_SLICE; stride = 36; base = P.pairB; }
+  else if (b < 4 * nU + 2 * F) { d = nU + ((b - 4 * nU) >> 1); e_lo = RED_SLICE * ((b - 4 * nU) & 1); width = RED_SLICE; stride = 18; base = P.obsV; }
+  else { d = nU + F; e_lo = 0; width = 2; stride = 4; base = P.lmV; }
+  const int e0 = la.n ? la.begin[d] : P.list_start[d], len = (la.n ? la.end[d] : P.list_start[nd + 1 + d]) - e0;
+  const int seglen = (len + RSEG - 1) / RSEG;
+  for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {
+    const int seg = item / width, e = item % width;
+    double acc = 0.0;
+    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
+    // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
+    // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
+    const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e_lo + e;
+    for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (q0 + u < b1) acc += v[u];
+    }
+    sP[seg][e] = acc;
+  }
+  __syncthreads();
+  if (tid < width) {
+    double acc = 0.0;
+    for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
+    double* out = P.pay1_out;
+    const int el = e_lo + tid;  // element of the destination
+    if (d < nU) {
+      int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
+      while (rest >= F - ka) { rest -= F - ka; ++ka; }
+      const int kb = ka + rest;
+      out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6] = acc;
+    } else if (d < nU + F) {
+      const int k = d - nU;
+      if (el < 6) out[(size_t)n * n + n + 6 * k + el] = acc;                  // g_c
+      else if (el < 12) out[(size_t)n * n + 6 * k + (el - 6)] = acc;          // g_red (the -Y g_p part)
+      else out[(size_t)n * n + 2 * n + 6 * k + (el - 12)] = acc;              // diag U
+    } else {
+      out[(size_t)n * n + 3 * n + el] = acc;
+    }
+  }
+  __syncthreads();
+}
+
+// payload (host memory) first, system-scope fence, then arrive; the last workgroup publishes the sequence word
+__device__ __forceinline__ void reduce_publish(const BaDev& P) {
+  if (!P.flag) return;
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    // every workgroup pushed its payload to system scope before it arrived; the release store orders the word behind them
+    if (old + 1u == P.arrive_target) __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, int with_pay2, LmCtl ctl, ListArgs la) {
   __shared__ double sP[RSEG][RED_SLICE];
   __shared__ double sOut[4];
-  const int F = P.K - 1, n = P.n, tid = threadIdx.x, b = blockIdx.x;
+  const int F = P.K - 1, tid = threadIdx.x, b = blockIdx.x;
   const int nU = F * (F + 1) / 2, nd = nU + F + 1;
   const int nb1 = with_pay1 ? ba_reduce_blocks(F) : 0;
   if (b < nb1) {
-    // destination d and element slice [e_lo, e_lo + width)
-    int d, e_lo, width, stride;
-    const double* base;
-    if (b < 4 * nU) { d = b >> 2; e_lo = RED_SLICE * (b & 3); width = RED_SLICE; stride = 36; base = P.pairB; }
-    else if (b < 4 * nU + 2 * F) { d = nU + ((b - 4 * nU) >> 1); e_lo = RED_SLICE * ((b - 4 * nU) & 1); width = RED_SLICE; stride = 18; base = P.obsV; }
-    else { d = nU + F; e_lo = 0; width = 2; stride = 4; base = P.lmV; }
-    const int e0 = la.n ? la.begin[d] : P.list_start[d], len = (la.n ? la.end[d] : P.list_start[nd + 1 + d]) - e0;
-    const int seglen = (len + RSEG - 1) / RSEG;
-    if (tid < RSEG * width) {
-      const int seg = tid / width, e = tid % width;
-      double acc = 0.0;
-      const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-      // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
-      // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
-      const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e_lo + e;
-      for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
-        double v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (q0 + u < b1) acc += v[u];
-      }
-      sP[seg][e] = acc;
-    }
-    __syncthreads();
-    if (tid < width) {
-      double acc = 0.0;
-      for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-      double* out = P.pay1_out;
-      const int el = e_lo + tid;  // element of the destination
-      if (d < nU) {
-        int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
-        while (rest >= F - ka) { rest -= F - ka; ++ka; }
-        const int kb = ka + rest;
-        out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6] = acc;
-      } else if (d < nU + F) {
-        const int k = d - nU;
-        if (el < 6) out[(size_t)n * n + n + 6 * k + el] = acc;                  // g_c
-        else if (el < 12) out[(size_t)n * n + 6 * k + (el - 6)] = acc;          // g_red (the -Y g_p part)
-        else out[(size_t)n * n + 2 * n + 6 * k + (el - 12)] = acc;              // diag U
-      } else {
-        out[(size_t)n * n + 3 * n + el] = acc;
-      }
-    }
+    reduce_slice(P, la, b, sP);
   } else if (with_pay2) {
     {
       const int dl = nU + F;  // the landmark list
@@ -696,16 +716,58 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
       if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
     }
   }
-  if (P.flag) {
-    // payload (host memory) first, system-scope fence, then arrive; the last workgroup publishes the sequence word
-    __threadfence_system();
-    __syncthreads();
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-      // every workgroup pushed its payload to system scope before it arrived; the release store orders the word behind them
-      if (old + 1u == P.arrive_target) __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  reduce_publish(P);
+}
+
+// ---- single rank, deterministic mode, chained iteration, ONE launch for "decide + pass A + reduce": the workgroups
+// of ba_decide_linearize_kernel meet at a device-wide arrival counter once their pass-A slots are written (agent-scope
+// release), and the first ba_reduce_blocks() of them each reduce one slice of payload1 (agent-scope acquire) and publish.
+// All workgroups are co-resident (<= a few hundred waves on 256 CUs), the spin is bounded and raises no hang: a workgroup
+// that gives up exits without arriving, the host's completion-word wait then reports the error.
+__global__ __launch_bounds__(128) void ba_decide_linearize_reduce_kernel(BaDev P, LmCtl ctl, int lm_begin, int lm_count, ListArgs la,
+                                                                         unsigned* done, unsigned done_target) {
+  __shared__ double sP[RSEG][RED_SLICE];
+  __shared__ double sOut[4];
+  __shared__ int sGo;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunk0 = blockIdx.x < P.C ? blockIdx.x : 0;
+  ObsRec Rc = load_obs(P, chunk0, lane, P.points);
+  D3 pc = Rc.p;
+  if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
+  reduce_pay2<64>(P, lm_begin, lm_count, &sP[0][0], sOut);
+  const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
+  if (blockIdx.x == 0 && threadIdx.x < 6)
+    P.pay2_out[threadIdx.x] = threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius);
+  if (wave == 0) {
+    const double* points_ = dec.accept ? P.cand_points : P.points;
+    const double* poses_ = dec.accept ? P.cand_poses : P.poses;
+    if (dec.accept) Rc.p = pc;
+    double unused0 = 0, unused1 = 0;
+    for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
+      if (chunk != (int)blockIdx.x) Rc = load_obs(P, chunk, lane, points_);
+      if (blockIdx.x < P.C) linearize_chunk(P, Rc, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
     }
+    __threadfence();  // my slots are visible device-wide before I count as done
   }
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  const int nb = ba_reduce_blocks(P.K - 1);
+  if ((int)blockIdx.x >= nb) return;  // no slice of the reduction is mine
+  if (threadIdx.x == 0) {
+    int go = 1;
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_target) < 0) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 24)) { go = 0; break; }  // ~seconds: something is badly wrong; never hang the GPU
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    sGo = go;
+  }
+  __syncthreads();
+  if (!sGo) return;
+  __threadfence();
+  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice(P, la, sl, sP);
+  reduce_publish(P);
 }
 
 
@@ -1042,7 +1104,7 @@ struct svo_ba {
   std::vector<int32_t> u_lm_start, u_chunks, u_pair_base, u_pair_pos, u_obs_pos, u_ls, u_cnt, u_fill;  // scratch of ba_upload
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
@@ -1061,8 +1123,8 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
-  A(ba->d_arrive, unsigned, 8);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes]
-  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 8 * sizeof(unsigned)));
+  A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | pass-A done counter at +32 bytes]
+  SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
   A(d.lmV, double, 4 * ba->cap_points);
   A(d.lmV2, double, 4 * ba->cap_points);
@@ -1493,6 +1555,17 @@ void ba_aim_reduce(svo_ba* ba, int n_blocks, bool publish) {
 
 const LmCtl kNoCtl = {0, 0, 0, 0, 0};
 
+// The reduction of payload1 behind a device-wide arrival inside the pass-A launch (2 launches per LM iteration) or as
+// its own launch (3).  Measured on MI355X: alone on the GPU the agent-scope fences cost more than the launch they save
+// (38.3 vs 35.7 us per iteration, 1,595 vs 1,642 frames/s); with 8 stereo streams the GPU is launch-rate bound and the
+// fused form wins (6,090 vs 5,915 frames/s).  Default: fused when more than two pipelines share the process
+// (svo_throughput_mode, host/pipeline.cpp); SVO_BA_FUSED_REDUCE=0 / 1 forces either.
+bool ba_fused_reduce() {
+  static const char* e = getenv("SVO_BA_FUSED_REDUCE");
+  if (e && *e) return atoi(e) != 0;
+  return svo_throughput_mode();
+}
+
 // destination lists as kernel arguments when they fit (every window-sized problem: K <= 6 free... F*F + F + 1 <= 48)
 ListArgs ba_list_args(const svo_ba* ba) {
   ListArgs la;
@@ -1576,10 +1649,21 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       hipLaunchKernelGGL(ba_step_kernel, dim3(d.C), dim3(64), 0, st, d, radius, same_sweep ? spec_radius : 0.0);
     }
     const int nb = ba_reduce_blocks(K - 1);
+    bool fused = false;
     if (!chain) {
       const int blocks = (same_sweep ? nb : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, same_sweep ? 1 : 0, 1, kNoCtl, ba_list_args(ba));
+    } else if (!sharded && d.C > 0 && ba_fused_reduce()) {
+      // pass A forms payload2, takes the decision itself AND reduces payload1 behind a device-wide arrival: 2 launches
+      // per LM iteration
+      const int grid = std::max(d.C, nb);
+      ba_aim_reduce(ba, std::min(grid, nb), true);
+      ba->done_total += (unsigned)grid;
+      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
+      hipLaunchKernelGGL(ba_decide_linearize_reduce_kernel, dim3(grid), dim3(128), 0, st, d, lc, ba->h_list_begin[nd - 1],
+                         ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba->d_arrive + 8, ba->done_total);
+      fused = true;
     } else if (!sharded && d.C > 0) {
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);
@@ -1599,7 +1683,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
         hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, 0.0, 0, (const double*)d.ctl_dev);
       }
     }
-    if (chain) {
+    if (chain && !fused) {
       ba_aim_reduce(ba, nb, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl, ba_list_args(ba));
     }

@@ -70,15 +70,17 @@ BundleAdjuster::BundleAdjuster(svo_ctx* ctx, size_t window_size, svo_camera_info
   reset();
 }
 
-namespace {
-std::atomic<int> g_pipelines{0};
-}
+std::atomic<int> g_pipelines{0};  // pipelines currently INSIDE svo_pipeline_process_batch*: stereo streams running at this moment
 void pipeline_count_add(int delta) { g_pipelines.fetch_add(delta, std::memory_order_relaxed); }
 unsigned spin_budget() {
   static const char* e = getenv("SVO_SPIN");  // override: pause iterations before sleeping
   if (e && *e) return (unsigned)atol(e);
   return g_pipelines.load(std::memory_order_relaxed) <= 2 ? 4000000u : 300u;  // ~0.1 s (never sleeps in practice) / ~10 us
 }
+
+}  // namespace svo
+bool svo_throughput_mode() { return svo::g_pipelines.load(std::memory_order_relaxed) > 2; }
+namespace svo {
 
 void BundleAdjuster::wait() {
   // the solve in flight takes well under a millisecond: poll first, sleep if it does not show up within the budget
@@ -726,7 +728,6 @@ extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_p
                        p->max_features <= ctx->lim.max_features, "pipeline_create: feature counts outside the context limits");
   SVO_REQUIRE(ctx, p->window_size >= 1 && p->window_size <= 63, "pipeline_create: window size must be 1..63");
   svo_pipeline* pl = new svo_pipeline();
-  svo::pipeline_count_add(1);
   pl->ctx = ctx;
   pl->prm = *p;
   pl->tracker = std::make_shared<svo::FeatureTracker>(ctx, ctx->lim.max_features, ctx->lim.max_width, ctx->lim.max_height);
@@ -738,7 +739,6 @@ extern "C" int svo_pipeline_create(svo_ctx* ctx, svo_pipeline** out, const svo_p
                                          p->parallax_thresh, p->max_corners, p->quality, ctx->lim.max_batch));
   if (!pl->tracker->ok() || !pl->proc->ok()) {  // an allocation failed: report it here, not as a kernel fault later
     delete pl;
-    svo::pipeline_count_add(-1);
     return SVO_ERR_HIP;
   }
   *out = pl;
@@ -755,7 +755,6 @@ extern "C" void svo_pipeline_destroy(svo_pipeline* p) {
   }
   if (p->d_imgs) (void)hipFree(p->d_imgs);
   delete p;
-  svo::pipeline_count_add(-1);
 }
 
 extern "C" int svo_pipeline_reset(svo_pipeline* p) {
@@ -775,6 +774,7 @@ extern "C" int svo_pipeline_process_batch_dev(svo_pipeline* p, const uint8_t* le
   const size_t istride = (size_t)W * H;
   ctx->err.clear();
   SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));  // the calling thread may never have selected this GPU
+  struct Active { Active() { svo::pipeline_count_add(1); } ~Active() { svo::pipeline_count_add(-1); } } active;  // latency / throughput mode
   int rc = p->proc->prepare_batch(left, batch, W, H);
   if (rc) return rc;
   // The reference runs process() then bundle_adjust() per frame (src/vo_node.cpp:141-148).  Here the solve of

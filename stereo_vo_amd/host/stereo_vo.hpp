@@ -119,8 +119,8 @@ class BundleAdjuster {  // src/bundle_adjuster.hpp:86-126
   std::condition_variable cv_done_;  // the job finished
 };
 
-// How long host threads busy-poll before they go to sleep (pause iterations).  One or two pipelines in the process:
-// latency mode, spin (a sleeping thread costs ~15 us to wake, twice per keyframe).  More: throughput mode — many stereo
+// How long host threads busy-poll before they go to sleep (pause iterations).  One or two stereo streams running at
+// this moment (calls inside svo_pipeline_process_batch*): latency mode, spin (a sleeping thread costs ~15 us to wake, twice per keyframe).  More: throughput mode — many stereo
 // streams share the host's CPU quota (16 cores per GPU on the target boxes; two spinning threads per stream exhaust it
 // at 8 streams and the scheduler then throttles every thread), so waits that usually last hundreds of microseconds
 // (the main thread joining a solve, the worker between solves) spin only briefly.
