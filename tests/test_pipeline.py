@@ -266,3 +266,69 @@ def test_hip_add_keyframe_more_tracked_than_max_features(ctx):
     new = ba.add_keyframe(pose, tid, txy, xy[50:], xyz[50:])
     assert len(new) == 0 and ba.window_count() == 3
     ba.close()
+
+
+@pytest.mark.gpu
+def test_hip_config3_full_4541_frame_stream_properties():
+    """BASELINE configs[2] at its stated size: a 4,541-frame KITTI-00-shaped 1241x376 stream, 10-keyframe window, ONE
+    pipeline, host buffers in, nothing reset.  The oracle needs minutes for this, so the full run is checked through
+    size-independent properties — the results must not depend on how the stream is cut into batches (16 vs 7 frames per
+    call: identical counters, ids and poses for all 4,541 frames), feature ids only ever grow, the keyframe trajectory
+    stays within 1 % of the path length of the generator's ground truth — and against the oracle on the first 48 frames."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    import stereo_vo_amd as S
+    W, H, N = 1241, 376, 4541
+    p = S.synth_default(W, H)
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16)) as ex:
+        fr = list(ex.map(lambda i: S.synth_render(p, i), range(N)))
+    L = np.stack([f[0] for f in fr])
+    R = np.stack([f[1] for f in fr])
+    del fr
+    c = S.Context(W, H, max_batch=16, max_corners=1500, max_candidates=1 << 16, max_features=2000)
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = W, H
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 1500, 0.02, 10.0, 2000, 10
+    pp.ba_max_time_s = 0.0
+
+    def run(batch):
+        g = S.Pipeline(c, pp)
+        out = []
+        for f0 in range(0, N, batch):
+            out.extend(g.process_batch(L[f0:f0 + batch], R[f0:f0 + batch]))
+        ids, xy = g.tracked()
+        g.close()
+        return out, ids, xy
+    key = lambda r: (r.n_detected, r.n_tracked, r.n_inliers, r.n_new, r.is_keyframe, r.ba_iterations,
+                     np.float32(r.av_parallax).tobytes(), tuple(r.pose7))
+    a, ids_a, xy_a = run(16)
+    b, ids_b, xy_b = run(7)
+    assert len(a) == len(b) == N
+    bad = [i for i in range(N) if key(a[i]) != key(b[i])]
+    assert not bad, bad[:5]
+    assert np.array_equal(ids_a, ids_b) and np.array_equal(xy_a.view(np.uint32), xy_b.view(np.uint32))
+    n_kf = sum(r.is_keyframe for r in a)
+    assert n_kf > 1500 and len(ids_a) > 100 and len(set(ids_a.tolist())) == len(ids_a)
+    assert int(ids_a.max()) > 100_000  # ids are sequential in creation order and never reused (SURVEY C-3)
+    est, gt = [], []
+    for i, r in enumerate(a):
+        if r.is_keyframe and r.pose7[0] != 0:
+            w, x, y, z = r.pose7[:4]
+            Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                           [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                           [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            est.append(-Rm.T @ np.array(r.pose7[4:]))  # camera in world, src/vo_node.cpp:149-150
+            gt.append(S.synth_pose(p, i)[:, 3])
+    path = float(np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum())
+    ate = S.api.ate_rmse(np.array(est), np.array(gt), False)
+    assert path > 3000 and ate < 0.01 * path, (ate, path)
+    # the head of the stream against the oracle (bit-exact counters and poses)
+    o = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=1500, quality=0.02,
+                   min_feature_distance=10.0, parallax_thresh=20.0, window_size=10, max_features=2000, ba_max_iterations=50,
+                   num_threads=min(os.cpu_count() or 1, 16))
+    for i in range(48):
+        ro = o.process(L[i], R[i])
+        assert key(a[i])[:6] == (ro.n_detected, ro.n_tracked, ro.n_inliers, ro.n_new, ro.is_keyframe, ro.ba_iterations), i
+        assert list(a[i].pose7) == list(ro.pose7), i
+    c.close()
