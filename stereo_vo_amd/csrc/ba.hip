@@ -96,11 +96,21 @@ struct BaDev {
 // Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
 struct LmCtl { double cost, mcc, radius, decrease_factor; int chain; };
 
+// Pass A's contribution slots cross workgroups (and XCDs, each with its own L2) inside ONE launch when the reduction is
+// fused behind it.  Writers: plain stores (combined in L2), then ONE agent-scope release per wave (`buffer_wbl2`, a
+// write-back, no invalidate).  Readers: relaxed agent-scope loads, which are served from the device's coherence point
+// whatever the reader's L2 holds — so nobody executes `buffer_inv` (see reduce_publish).
+__device__ __forceinline__ double slot_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// A payload word on its way to the host (or to the all-reduce buffer): a relaxed system-scope store is written through every
+// cache level, so that `s_waitcnt vmcnt(0)` means "it has arrived" without any cache maintenance (see reduce_publish).
+__device__ __forceinline__ void pay_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 // The decision for the summed payload2 -> ctl_dev (for the pass-A launch queued behind) and payload slots 4 / 5 (for the host).
 __device__ __forceinline__ void decide_device(const LmCtl& c, double cost_new, double mc_points, double* ctl_dev, double* pay2buf) {
   const SvoLmDecision d = svo_lm_decide(c.cost, c.mcc, c.radius, c.decrease_factor, cost_new, mc_points);
   ctl_dev[0] = (double)d.accept; ctl_dev[1] = d.next_radius;
-  pay2buf[4] = (double)d.accept; pay2buf[5] = d.next_radius;
+  pay_store(&pay2buf[4], (double)d.accept); pay_store(&pay2buf[5], d.next_radius);
 }
 
 // Pass A behind a chained decision: linearise at the candidate with the new radius (accepted) or at the current point
@@ -475,7 +485,7 @@ constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
 // payload2 = R(landmark list) over the four per-landmark scalars of pass B (lmV2), in the declared order, by ANY workgroup
 // size: item = (segment, element), 112 items.  sP: RSEG * 4 doubles of LDS, sOut: 4.  Ends with a barrier: every thread
 // may read sOut afterwards.
-template <int DEPTH>
+template <int DEPTH, bool SAME_LAUNCH = false>  // SAME_LAUNCH: lmV2 was written by this very launch, read it at the coherence point
 __device__ __forceinline__ void reduce_pay2(const BaDev& P, int e0, int len, double* sP, double* sOut) {
   const int seglen = (len + RSEG - 1) / RSEG;
   for (int item = threadIdx.x; item < RSEG * 4; item += (int)blockDim.x) {
@@ -486,7 +496,7 @@ __device__ __forceinline__ void reduce_pay2(const BaDev& P, int e0, int len, dou
     for (int q0 = b0; q0 < b1; q0 += DEPTH, src += 4 * DEPTH) {  // DEPTH loads in flight, adds in list order
       double v[DEPTH];
 #pragma unroll
-      for (int u = 0; u < DEPTH; ++u) v[u] = q0 + u < b1 ? src[4 * u] : 0.0;
+      for (int u = 0; u < DEPTH; ++u) v[u] = q0 + u < b1 ? (SAME_LAUNCH ? slot_load(src + 4 * u) : src[4 * u]) : 0.0;
 #pragma unroll
       for (int u = 0; u < DEPTH; ++u)
         if (q0 + u < b1) acc += v[u];
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(128) void ba_decide_linearize_kernel(BaDev P, LmCtl
   reduce_pay2<64>(P, lm_begin, lm_count, sP, sOut);
   const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
   if (blockIdx.x == 0 && threadIdx.x < 6)
-    P.pay2_out[threadIdx.x] = threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius);
+    pay_store(&P.pay2_out[threadIdx.x], threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius));
   if (wave != 0) return;
   const double* points_ = dec.accept ? P.cand_points : P.points;
   const double* poses_ = dec.accept ? P.cand_poses : P.poses;
@@ -635,6 +645,7 @@ constexpr int RED_SLICE = 9;
 __host__ __device__ inline int ba_reduce_blocks(int F) { return 4 * (F * (F + 1) / 2) + 2 * F + 1; }
 
 // One slice of payload1: destination d, elements [e_lo, e_lo + width).  Any workgroup size; ends with a barrier.
+template <bool SAME_LAUNCH>  // the slots were written by this very launch (fused): read them at the coherence point
 __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la, int b, double (*sP)[RED_SLICE]) {
   const int F = P.K - 1, n = P.n, tid = threadIdx.x;
   const int nU = F * (F + 1) / 2, nd = nU + F + 1;
@@ -655,7 +666,7 @@ __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la,
     for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
       double v[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? pq[u * stride] : 0.0;
+      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? (SAME_LAUNCH ? slot_load(pq + u * stride) : pq[u * stride]) : 0.0;
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (q0 + u < b1) acc += v[u];
@@ -672,28 +683,35 @@ __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la,
       int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
       while (rest >= F - ka) { rest -= F - ka; ++ka; }
       const int kb = ka + rest;
-      out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6] = acc;
+      pay_store(&out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6], acc);
     } else if (d < nU + F) {
       const int k = d - nU;
-      if (el < 6) out[(size_t)n * n + n + 6 * k + el] = acc;                  // g_c
-      else if (el < 12) out[(size_t)n * n + 6 * k + (el - 6)] = acc;          // g_red (the -Y g_p part)
-      else out[(size_t)n * n + 2 * n + 6 * k + (el - 12)] = acc;              // diag U
+      if (el < 6) pay_store(&out[(size_t)n * n + n + 6 * k + el], acc);                 // g_c
+      else if (el < 12) pay_store(&out[(size_t)n * n + 6 * k + (el - 6)], acc);         // g_red (the -Y g_p part)
+      else pay_store(&out[(size_t)n * n + 2 * n + 6 * k + (el - 12)], acc);             // diag U
     } else {
-      out[(size_t)n * n + 3 * n + el] = acc;
+      pay_store(&out[(size_t)n * n + 3 * n + el], acc);
     }
   }
   __syncthreads();
 }
 
-// payload (host memory) first, system-scope fence, then arrive; the last workgroup publishes the sequence word
+// Publishing without cache maintenance.  A compiler fence at agent or system scope is `buffer_wbl2` + `buffer_inv`: it
+// writes back and INVALIDATES the whole L2 of the workgroup's XCD — harmless alone on the GPU, but with several stereo
+// streams sharing the chip every workgroup of every adjuster kept emptying the L2 under the other streams' kernels.
+// Nothing here needs it: the payload goes to fine-grained pinned host memory (hipHostMallocCoherent: uncached on the GPU
+// side, every store is written through), so `s_waitcnt vmcnt(0)` alone says "my payload stores are acknowledged"; the
+// arrival counter and the completion word are relaxed atomics (performed at the device's / system's coherence point).
+// The last workgroup to arrive has, transitively, seen every payload store acknowledged before it writes the word.
+__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 __device__ __forceinline__ void reduce_publish(const BaDev& P) {
   if (!P.flag) return;
-  __threadfence_system();
+  stores_acknowledged();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    // every workgroup pushed its payload to system scope before it arrived; the release store orders the word behind them
-    if (old + 1u == P.arrive_target) __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned old = __hip_atomic_fetch_add(P.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == P.arrive_target) __hip_atomic_store(P.flag, P.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -704,14 +722,14 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
   const int nU = F * (F + 1) / 2, nd = nU + F + 1;
   const int nb1 = with_pay1 ? ba_reduce_blocks(F) : 0;
   if (b < nb1) {
-    reduce_slice(P, la, b, sP);
+    reduce_slice<false>(P, la, b, sP);
   } else if (with_pay2) {
     {
       const int dl = nU + F;  // the landmark list
       const int e0 = la.n ? la.begin[dl] : P.list_start[dl], e1 = la.n ? la.end[dl] : P.list_start[nd + 1 + dl];
       reduce_pay2<16>(P, e0, e1 - e0, &sP[0][0], sOut);
     }
-    if (tid < 4) P.pay2_out[tid] = sOut[tid];
+    if (tid < 4) pay_store(&P.pay2_out[tid], sOut[tid]);
     if (ctl.chain) {  // single rank: these ARE the global sums; decide here, pass A is queued right behind this launch
       if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
     }
@@ -720,8 +738,9 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
 }
 
 // ---- single rank, deterministic mode, chained iteration, ONE launch for "decide + pass A + reduce": the workgroups
-// of ba_decide_linearize_kernel meet at a device-wide arrival counter once their pass-A slots are written (agent-scope
-// release), and the first ba_reduce_blocks() of them each reduce one slice of payload1 (agent-scope acquire) and publish.
+// of ba_decide_linearize_kernel meet at a device-wide arrival counter once their pass-A slots are written (one L2
+// write-back per wave), and the first ba_reduce_blocks() of them each reduce one slice of payload1 (loads served from the
+// coherence point) and publish.  No L2 invalidate anywhere inside the launch.
 // All workgroups are co-resident (<= a few hundred waves on 256 CUs), the spin is bounded and raises no hang: a workgroup
 // that gives up exits without arriving, the host's completion-word wait then reports the error.
 __global__ __launch_bounds__(128) void ba_decide_linearize_reduce_kernel(BaDev P, LmCtl ctl, int lm_begin, int lm_count, ListArgs la,
@@ -730,27 +749,28 @@ __global__ __launch_bounds__(128) void ba_decide_linearize_reduce_kernel(BaDev P
   __shared__ double sOut[4];
   __shared__ int sGo;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int chunk0 = blockIdx.x < P.C ? blockIdx.x : 0;
-  ObsRec Rc = load_obs(P, chunk0, lane, P.points);
-  D3 pc = Rc.p;
-  if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
-  reduce_pay2<64>(P, lm_begin, lm_count, &sP[0][0], sOut);
-  const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
-  if (blockIdx.x == 0 && threadIdx.x < 6)
-    P.pay2_out[threadIdx.x] = threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius);
-  if (wave == 0) {
-    const double* points_ = dec.accept ? P.cand_points : P.points;
-    const double* poses_ = dec.accept ? P.cand_poses : P.poses;
-    if (dec.accept) Rc.p = pc;
-    double unused0 = 0, unused1 = 0;
-    for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
-      if (chunk != (int)blockIdx.x) Rc = load_obs(P, chunk, lane, points_);
-      if (blockIdx.x < P.C) linearize_chunk(P, Rc, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+  if ((int)blockIdx.x < P.C) {  // workgroups beyond the chunks only reduce: no sums, no decision, no stores to write back
+    ObsRec Rc = load_obs(P, blockIdx.x, lane, P.points);
+    D3 pc = Rc.p;
+    if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
+    reduce_pay2<64>(P, lm_begin, lm_count, &sP[0][0], sOut);
+    const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
+    if (blockIdx.x == 0 && threadIdx.x < 6)
+      pay_store(&P.pay2_out[threadIdx.x], threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius));
+    if (wave == 0) {
+      const double* points_ = dec.accept ? P.cand_points : P.points;
+      const double* poses_ = dec.accept ? P.cand_poses : P.poses;
+      if (dec.accept) Rc.p = pc;
+      double unused0 = 0, unused1 = 0;
+      for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
+        if (chunk != (int)blockIdx.x) Rc = load_obs(P, chunk, lane, points_);
+        linearize_chunk(P, Rc, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write-back only: my slots are at the device's coherence point before I count as done
     }
-    __threadfence();  // my slots are visible device-wide before I count as done
   }
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int nb = ba_reduce_blocks(P.K - 1);
   if ((int)blockIdx.x >= nb) return;  // no slice of the reduction is mine
   if (threadIdx.x == 0) {
@@ -760,13 +780,117 @@ __global__ __launch_bounds__(128) void ba_decide_linearize_reduce_kernel(BaDev P
       __builtin_amdgcn_s_sleep(2);
       if (++spins > (1u << 24)) { go = 0; break; }  // ~seconds: something is badly wrong; never hang the GPU
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     sGo = go;
   }
   __syncthreads();
   if (!sGo) return;
-  __threadfence();
-  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice(P, la, sl, sP);
+  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sP);
+  reduce_publish(P);
+}
+
+// ---- single rank, deterministic mode: a WHOLE LM iteration in ONE launch.  Every kernel boundary costs an L2 write-back
+// at its end and an L2 invalidate at its start on all eight XCDs — for every stream on the GPU — so with several stereo
+// streams the number of launches per iteration, not their arithmetic, sets the pace.  Workgroup = one chunk (wave 0 works,
+// the second wave only helps with the sums):
+//   pass B  ->  [chained: device-wide arrival; the LAST workgroup to arrive forms payload2 in the declared order, takes
+//   Ceres' decision and posts it; the others wait for the post]  ->  pass A (at the candidate kept in registers, or at the
+//   current point)  ->  device-wide arrival  ->  the first ba_reduce_blocks() workgroups reduce payload1  ->  publish.
+// Same sweep (spec_radius > 0): pass A follows pass B directly, payload2 is reduced behind the second arrival.
+// with_pay1 = 0: pass B alone (the last iteration of a solve).
+// Cross-workgroup data moves by "plain stores + one write-back per wave" / "loads at the coherence point" (slot_load):
+// no L2 invalidate anywhere.  Waiting is bounded; admission (FusedAdmission) keeps all waiting workgroups resident.
+struct IterSync {
+  unsigned* arrived;   // pass B finished (monotone, target = total so far)
+  unsigned arrived_target;
+  unsigned* posted;    // the decision of launch `post_seq` is in ctl_dev
+  unsigned post_seq;
+  unsigned* done;      // pass A finished
+  unsigned done_target;
+};
+
+__device__ __forceinline__ bool wait_until(const unsigned* word, unsigned target, bool monotone) {
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (monotone ? (int)(v - target) >= 0 : v == target) return true;
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1u << 24)) return false;  // ~seconds: something is badly wrong; never hang the GPU
+  }
+}
+
+__global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius, double spec_radius, LmCtl ctl, int with_pay1,
+                                                         int lm_begin, int lm_count, ListArgs la, IterSync sy) {
+  __shared__ double sStep[STEP_LDS_DOUBLES];
+  __shared__ double sP[RSEG][RED_SLICE];
+  __shared__ double sOut[4];
+  __shared__ double sDec[2];
+  __shared__ int sGo, sLast;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  const bool worker = (int)blockIdx.x < P.C;  // workgroups beyond the chunks only reduce
+  if (worker) {
+    ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
+    if (wave == 0) R = load_obs(P, blockIdx.x, lane, P.points);  // requested before the step is staged: HBM and PCIe round trips overlap
+    stage_step(P, sStep);
+    const double* dc_ = sStep;
+    const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+    D3 cand = D3{0, 0, 1};
+    double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
+    if (wave == 0) {
+      backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
+      if (spec_radius > 0) {
+        R.p = cand;
+        linearize_chunk(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write-back only
+    }
+    if (ctl.chain) {
+      __syncthreads();
+      if (tid == 0) sLast = __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == sy.arrived_target;
+      __syncthreads();
+      if (sLast) {
+        reduce_pay2<64, true>(P, lm_begin, lm_count, &sP[0][0], sOut);
+        const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
+        if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
+        if (tid == 0) {
+          __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          sDec[0] = (double)dec.accept; sDec[1] = dec.next_radius;
+        }
+        stores_acknowledged();  // the decision (device) and payload2 (host) have arrived before anybody can see the post
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(sy.posted, sy.post_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) sGo = 1;
+        __syncthreads();
+      } else {
+        if (tid == 0) {
+          const bool ok = wait_until(sy.posted, sy.post_seq, false);
+          sDec[0] = slot_load(&P.ctl_dev[0]); sDec[1] = slot_load(&P.ctl_dev[1]);
+          sGo = ok;
+        }
+        __syncthreads();
+      }
+      if (!sGo) return;
+      if (wave == 0) {
+        const bool accept = sDec[0] != 0.0;
+        if (accept) R.p = cand;
+        linearize_chunk(P, R, accept ? cand_poses_ : P.poses, sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
+  const bool sums2 = !ctl.chain && blockIdx.x == 0;  // payload2 of a same-sweep / plain step: formed here, by workgroup 0
+  if ((int)blockIdx.x >= nb && !sums2) return;
+  if (tid == 0) sGo = wait_until(sy.done, sy.done_target, true);
+  __syncthreads();
+  if (!sGo) return;
+  if (sums2) {
+    reduce_pay2<64, true>(P, lm_begin, lm_count, &sP[0][0], sOut);
+    if (tid < 4) pay_store(&P.pay2_out[tid], sOut[tid]);
+  }
+  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sP);
   reduce_publish(P);
 }
 
@@ -1104,7 +1228,7 @@ struct svo_ba {
   std::vector<int32_t> u_lm_start, u_chunks, u_pair_base, u_pair_pos, u_obs_pos, u_ls, u_cnt, u_fill;  // scratch of ba_upload
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0; int seq = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0, arrived_total = 0, post_seq = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
@@ -1123,7 +1247,7 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
-  A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | pass-A done counter at +32 bytes]
+  A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
   A(d.lmV, double, 4 * ba->cap_points);
@@ -1163,7 +1287,7 @@ static int ba_alloc(svo_ba* ba) {
     }
   }
   ba->pin_bytes = 64 + sizeof(double) * (step_doubles + PAY2_SLOTS + ba->cap_pay1);
-  SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocDefault));
+  SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocCoherent));  // fine-grained: see reduce_publish
   memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
   ba->h_flag = reinterpret_cast<int*>(ba->h_pin);
   ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64);
@@ -1566,6 +1690,35 @@ bool ba_fused_reduce() {
   return svo_throughput_mode();
 }
 
+// Workgroups of the fused launch WAIT for each other, so all of one launch must be able to become resident while the
+// waiting workgroups of every other adjuster's launch hold their wave slots: the process admits fused launches only
+// while their workgroups together fit in 7/8 of what the device can hold of this kernel (occupancy x CUs; kernels that
+// never wait always drain and hand their slots over, so the sum of the WAITING workgroups is what has to fit; measured:
+// budgets of 1/2, 3/4 and 1/1 of the capacity give 6,630 / 6,690 / 6,780 frames/s at 8 streams).  A launch that is not admitted takes the
+// separate-launch path for that iteration — same arithmetic, same results.  (Other PROCESSES on the GPU are not
+// counted; the kernel's bounded spin turns that unlikely pile-up into a reported error, never a hang.)
+std::atomic<int> g_fused_blocks{0};
+int ba_fused_budget() {
+  static const int budget = [] {
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_decide_linearize_reduce_kernel, 128, 0) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (const char* e = getenv("SVO_BA_FUSED_BUDGET")) return atoi(e);  // experiments
+    return per_cu * cus / 8 * 7;
+  }();
+  return budget;
+}
+struct FusedAdmission {
+  int blocks = 0;
+  bool admit(int n) {
+    if (g_fused_blocks.fetch_add(n, std::memory_order_acq_rel) + n <= ba_fused_budget()) { blocks = n; return true; }
+    g_fused_blocks.fetch_sub(n, std::memory_order_acq_rel);
+    return false;
+  }
+  ~FusedAdmission() { if (blocks) g_fused_blocks.fetch_sub(blocks, std::memory_order_acq_rel); }
+};
+
 // destination lists as kernel arguments when they fit (every window-sized problem: K <= 6 free... F*F + F + 1 <= 48)
 ListArgs ba_list_args(const svo_ba* ba) {
   ListArgs la;
@@ -1644,17 +1797,39 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
   const bool next = same_sweep || chain;
   if (d.det) {
     const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
-    if (d.C > 0) {
+    const int nb = ba_reduce_blocks(K - 1);
+    const int lm_b = ba->h_list_begin[nd - 1], lm_n = ba->h_list_end[nd - 1] - lm_b;
+    bool fused = false;
+    FusedAdmission admission;  // released when this call returns: the completion word has arrived by then
+    const int grid1 = std::max(d.C, next ? nb : 1);
+    const bool one_launch = !sharded && d.C > 0 && ba_fused_reduce() && admission.admit(grid1);
+    if (one_launch) {
+      // the whole iteration — pass B, [decision,] pass A, reduction — in ONE launch
+      ba_aim_reduce(ba, next ? nb : 1, true);
+      IterSync sy;
+      sy.arrived = ba->d_arrive + 9;
+      if (chain) ba->arrived_total += (unsigned)d.C;
+      sy.arrived_target = ba->arrived_total;
+      sy.posted = ba->d_arrive + 10;
+      sy.post_seq = chain ? ++ba->post_seq : 0u;
+      sy.done = ba->d_arrive + 8;
+      ba->done_total += (unsigned)grid1;
+      sy.done_target = ba->done_total;
+      SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
+      hipLaunchKernelGGL(ba_iterate_kernel, dim3(grid1), dim3(128), 0, st, d, radius, same_sweep ? spec_radius : 0.0, lc, next ? 1 : 0,
+                         lm_b, lm_n, ba_list_args(ba), sy);
+      fused = true;
+    } else if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
       hipLaunchKernelGGL(ba_step_kernel, dim3(d.C), dim3(64), 0, st, d, radius, same_sweep ? spec_radius : 0.0);
     }
-    const int nb = ba_reduce_blocks(K - 1);
-    bool fused = false;
-    if (!chain) {
+    if (one_launch) {
+      // nothing more to queue
+    } else if (!chain) {
       const int blocks = (same_sweep ? nb : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, same_sweep ? 1 : 0, 1, kNoCtl, ba_list_args(ba));
-    } else if (!sharded && d.C > 0 && ba_fused_reduce()) {
+    } else if (!sharded && d.C > 0 && ba_fused_reduce() && admission.admit(std::max(d.C, nb))) {
       // pass A forms payload2, takes the decision itself AND reduces payload1 behind a device-wide arrival: 2 launches
       // per LM iteration
       const int grid = std::max(d.C, nb);

@@ -88,17 +88,20 @@ int svo_wait_word(svo_ctx* c, const SvoPublish& p);  // ctx.hip: bounded spin, f
 
 #if defined(__HIPCC__)
 // Called by EVERY thread of the workgroup after its last store to host memory.
+// Cache maintenance is kept to the one operation the protocol needs.  `__threadfence_system()` and an acq_rel atomic are
+// each `buffer_wbl2` + `buffer_inv`: the invalidate empties the whole L2 of the workgroup's XCD under every other kernel
+// running there (with eight stereo streams per GPU that was a steady drizzle of L2 wipes).  Nobody here READS another
+// workgroup's data, so no acquire is needed: a release fence per thread (write-back + wait for the acknowledgements),
+// the barrier, a relaxed arrival, and a relaxed system-scope store of the word by the last arrival — which, through
+// the counter, comes after every workgroup's acknowledged payload.
 __device__ __forceinline__ void svo_publish_block(const SvoPublish& p) {
   if (!p.word) return;
-  __threadfence_system();
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   __syncthreads();
   if (threadIdx.x == 0) {
     bool last = true;
-    if (p.arrive) last = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == p.target;
-    if (last) {
-      __threadfence_system();
-      __hip_atomic_store(p.word, p.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (p.arrive) last = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == p.target;
+    if (last) __hip_atomic_store(p.word, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 #endif
