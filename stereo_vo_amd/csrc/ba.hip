@@ -52,6 +52,7 @@ int svo_rccl_allreduce_f64(void* buf, size_t count, void* comm, hipStream_t stre
 bool svo_throughput_mode();  // host/pipeline.cpp: more than two pipelines share the process
 
 namespace {
+int g_ba_cu_share = 32;  // CUs of every 32 the adjusters' streams may use (SVO_BA_CU_SHARE; 32 = unmasked)
 constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32;
 constexpr int PAY2_SLOTS = 8;  // payload2 (4 doubles) is padded to 8 so that payload1 starts 64-byte aligned behind it
@@ -1282,6 +1283,7 @@ static int ba_alloc(svo_ba* ba) {
       uint32_t mask[8];
       for (int i = 0; i < 8; ++i) mask[i] = (1u << nres) - 1u;
       SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
+      g_ba_cu_share = nres;  // process-wide like the environment variable; read by ba_fused_budget() at the first admission
     } else {
       SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
     }
@@ -1704,8 +1706,7 @@ int ba_fused_budget() {
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_decide_linearize_reduce_kernel, 128, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (const char* e = getenv("SVO_BA_FUSED_BUDGET")) return atoi(e);  // experiments
-    return per_cu * cus / 8 * 7;
+    return per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
   }();
   return budget;
 }
