@@ -97,10 +97,25 @@ struct BaDev {
 // Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
 struct LmCtl { double cost, mcc, radius, decrease_factor; int chain; };
 
-// Pass A's contribution slots cross workgroups (and XCDs, each with its own L2) inside ONE launch when the reduction is
-// fused behind it.  Writers: plain stores (combined in L2), then ONE agent-scope release per wave (`buffer_wbl2`, a
-// write-back, no invalidate).  Readers: relaxed agent-scope loads, which are served from the device's coherence point
-// whatever the reader's L2 holds — so nobody executes `buffer_inv` (see reduce_publish).
+// Pass A's contribution slots (and pass B's per-landmark scalars) cross workgroups — and XCDs, each with its own L2 —
+// inside ONE launch when the whole LM iteration is a single kernel.  Measured on MI355X (tools/exp/l2_invalidate.hip: a
+// pointer chase through L2-resident data, 88 ns per load alone): with other streams executing agent-scope fences the same
+// chase takes 295 / 830 / 1,480 ns per load (seq_cst = `buffer_wbl2` + `buffer_inv`, 1 / 4 / 8 aggressor streams), 190-390 ns
+// with release fences only (`buffer_wbl2`), 170-480 ns with acquire fences only (`buffer_inv`); kernel boundaries of
+// other streams cost nothing.  So the hand-over here uses NO cache maintenance instruction at all.
+typedef double svo_d2 __attribute__((ext_vector_type(2)));
+// Two adjacent slot words.  WT (the launch that also consumes them): one 16-byte write-through store (sc1: the data goes to
+// the device's coherence point instead of staying dirty in this XCD's L2), so the hand-over needs no `buffer_wbl2` either —
+// `s_waitcnt vmcnt(0)` says "arrived".  The s_nop covers the wide-store data hazard the compiler cannot see inside asm.
+template <bool WT>
+__device__ __forceinline__ void slot_store2(double* p, double x, double y) {
+  if constexpr (WT) {
+    const svo_d2 v = {x, y};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+  } else {
+    p[0] = x; p[1] = y;
+  }
+}
 __device__ __forceinline__ double slot_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // A payload word on its way to the host (or to the all-reduce buffer): a relaxed system-scope store is written through every
@@ -199,6 +214,22 @@ __device__ __forceinline__ ObsRec load_obs(const BaDev& P, int chunk, int lane, 
 
 // Pass A for one wave chunk at (poses_, R.p).  Deterministic mode: contributions go to the slots.  Otherwise into the
 // workgroup's LDS image of payload1 (ds_add_f64), lcost / lgp2 accumulate this lane's share of the two scalars.
+// One 6x6 Schur / U contribution into its slot(s): block (k, kt) row-major, and/or its transpose into the mirrored pair's slot.
+template <bool WT>
+__device__ __forceinline__ void store_pair_block(double* B, double* Bt, const double (&w)[36]) {
+  if (B) {
+#pragma unroll
+    for (int i = 0; i < 36; i += 2) slot_store2<WT>(B + i, w[i], w[i + 1]);
+  }
+  if (Bt) {
+#pragma unroll
+    for (int b = 0; b < 6; ++b)
+#pragma unroll
+      for (int a = 0; a < 6; a += 2) slot_store2<WT>(Bt + 6 * b + a, w[6 * a + b], w[6 * (a + 1) + b]);
+  }
+}
+
+template <bool WT = false>  // WT: the slots are consumed inside this launch (see slot_store2)
 __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius,
                                                 int first_pass, double* sS, double* sGred, double* sGc, double* sDU,
                                                 double& lcost, double& lgp2) {
@@ -249,7 +280,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
     }
     if (lane == first) {
       lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
-      if (P.det) { P.lmV[4 * (size_t)j] = cost_l; P.lmV[4 * (size_t)j + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
+      if (P.det) slot_store2<WT>(&P.lmV[4 * (size_t)j], cost_l, gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]);
     }
   }
   double Vd[9], Vi[9], gps[3];
@@ -276,12 +307,15 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
     for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
   if (freep && P.det) {
     double* ov = P.obsV + (size_t)P.obs_pos[o] * 18;
+    double w[18];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
-      ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
-      ov[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
+      w[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+      w[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+      w[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
     }
+#pragma unroll
+    for (int a = 0; a < 18; a += 2) slot_store2<WT>(ov + a, w[a], w[a + 1]);
   }
   if (freep && !P.det) {
 #pragma unroll
@@ -314,15 +348,15 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
       if (d < mine && kt > 0) {
         double* B = pp[d].x >= 0 ? P.pairB + (size_t)pp[d].x * 36 : nullptr;   // block (k, kt) if it is an upper block
         double* Bt = pp[d].y >= 0 ? P.pairB + (size_t)pp[d].y * 36 : nullptr;  // block (kt, k) if THAT is an upper block
+        double w[36];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
           for (int b = 0; b < 6; ++b) {
             const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-            const double w = d == 0 ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-            if (B) B[6 * a + b] = w;
-            if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
+            w[6 * a + b] = d == 0 ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
           }
+        store_pair_block<WT>(B, Bt, w);
       }
     }
     return;
@@ -339,15 +373,15 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
         const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
         double* B = posA >= 0 ? P.pairB + (size_t)posA * 36 : nullptr;
         double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
+        double w[36];
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
           for (int b = 0; b < 6; ++b) {
             const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-            const double w = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-            if (B) B[6 * a + b] = w;
-            if (Bt) Bt[6 * b + a] = w;  // the mirrored pose pair receives the transpose
+            w[6 * a + b] = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
           }
+        store_pair_block<WT>(B, Bt, w);
       } else {
         const int bt = 6 * (kt - 1);
 #pragma unroll
@@ -365,6 +399,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
 // `cand`, valid in every active lane of the landmark's segment; written to cand_points_ by the segment's first lane),
 // candidate residual against cand_poses_.  Deterministic mode: the landmark's four scalars go to lmV2.  Otherwise
 // a_* accumulate this lane's share of payload2.
+template <bool WT = false>  // WT: lmV2 is consumed inside this launch
 __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_,
                                               const double* __restrict__ cand_poses_, const double* __restrict__ dc_,
                                               double* __restrict__ cand_points_, double radius, D3& cand, double& a_cost,
@@ -465,7 +500,7 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
     }
     if (active && lane == first) {
       double* lv = P.lmV2 + 4 * (size_t)j;
-      lv[0] = cn; lv[1] = det_mc; lv[2] = det_dp2; lv[3] = det_p2;
+      slot_store2<WT>(lv, cn, det_mc); slot_store2<WT>(lv + 2, det_dp2, det_p2);
     }
   }
 }
@@ -738,57 +773,6 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
   reduce_publish(P);
 }
 
-// ---- single rank, deterministic mode, chained iteration, ONE launch for "decide + pass A + reduce": the workgroups
-// of ba_decide_linearize_kernel meet at a device-wide arrival counter once their pass-A slots are written (one L2
-// write-back per wave), and the first ba_reduce_blocks() of them each reduce one slice of payload1 (loads served from the
-// coherence point) and publish.  No L2 invalidate anywhere inside the launch.
-// All workgroups are co-resident (<= a few hundred waves on 256 CUs), the spin is bounded and raises no hang: a workgroup
-// that gives up exits without arriving, the host's completion-word wait then reports the error.
-__global__ __launch_bounds__(128) void ba_decide_linearize_reduce_kernel(BaDev P, LmCtl ctl, int lm_begin, int lm_count, ListArgs la,
-                                                                         unsigned* done, unsigned done_target) {
-  __shared__ double sP[RSEG][RED_SLICE];
-  __shared__ double sOut[4];
-  __shared__ int sGo;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if ((int)blockIdx.x < P.C) {  // workgroups beyond the chunks only reduce: no sums, no decision, no stores to write back
-    ObsRec Rc = load_obs(P, blockIdx.x, lane, P.points);
-    D3 pc = Rc.p;
-    if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
-    reduce_pay2<64>(P, lm_begin, lm_count, &sP[0][0], sOut);
-    const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
-    if (blockIdx.x == 0 && threadIdx.x < 6)
-      pay_store(&P.pay2_out[threadIdx.x], threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius));
-    if (wave == 0) {
-      const double* points_ = dec.accept ? P.cand_points : P.points;
-      const double* poses_ = dec.accept ? P.cand_poses : P.poses;
-      if (dec.accept) Rc.p = pc;
-      double unused0 = 0, unused1 = 0;
-      for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
-        if (chunk != (int)blockIdx.x) Rc = load_obs(P, chunk, lane, points_);
-        linearize_chunk(P, Rc, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write-back only: my slots are at the device's coherence point before I count as done
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int nb = ba_reduce_blocks(P.K - 1);
-  if ((int)blockIdx.x >= nb) return;  // no slice of the reduction is mine
-  if (threadIdx.x == 0) {
-    int go = 1;
-    unsigned spins = 0;
-    while ((int)(__hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - done_target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 24)) { go = 0; break; }  // ~seconds: something is badly wrong; never hang the GPU
-    }
-    sGo = go;
-  }
-  __syncthreads();
-  if (!sGo) return;
-  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sP);
-  reduce_publish(P);
-}
-
 // ---- single rank, deterministic mode: a WHOLE LM iteration in ONE launch.  Every kernel boundary costs an L2 write-back
 // at its end and an L2 invalidate at its start on all eight XCDs — for every stream on the GPU — so with several stereo
 // streams the number of launches per iteration, not their arithmetic, sets the pace.  Workgroup = one chunk (wave 0 works,
@@ -798,8 +782,8 @@ __global__ __launch_bounds__(128) void ba_decide_linearize_reduce_kernel(BaDev P
 //   current point)  ->  device-wide arrival  ->  the first ba_reduce_blocks() workgroups reduce payload1  ->  publish.
 // Same sweep (spec_radius > 0): pass A follows pass B directly, payload2 is reduced behind the second arrival.
 // with_pay1 = 0: pass B alone (the last iteration of a solve).
-// Cross-workgroup data moves by "plain stores + one write-back per wave" / "loads at the coherence point" (slot_load):
-// no L2 invalidate anywhere.  Waiting is bounded; admission (FusedAdmission) keeps all waiting workgroups resident.
+// Cross-workgroup data moves by write-through stores (slot_store2<true>) and loads at the coherence point (slot_load):
+// no L2 write-back, no L2 invalidate anywhere inside the launch.  Waiting is bounded; admission (FusedAdmission) keeps all waiting workgroups resident.
 struct IterSync {
   unsigned* arrived;   // pass B finished (monotone, target = total so far)
   unsigned arrived_target;
@@ -837,12 +821,12 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
     D3 cand = D3{0, 0, 1};
     double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
     if (wave == 0) {
-      backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
+      backsub_chunk<true>(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
       if (spec_radius > 0) {
         R.p = cand;
-        linearize_chunk(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+        linearize_chunk<true>(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // write-back only
+      stores_acknowledged();  // lmV2 (and the slots of a same sweep) are at the coherence point
     }
     if (ctl.chain) {
       __syncthreads();
@@ -874,8 +858,8 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
       if (wave == 0) {
         const bool accept = sDec[0] != 0.0;
         if (accept) R.p = cand;
-        linearize_chunk(P, R, accept ? cand_poses_ : P.poses, sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        linearize_chunk<true>(P, R, accept ? cand_poses_ : P.poses, sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+        stores_acknowledged();
       }
     }
   }
@@ -1681,11 +1665,10 @@ void ba_aim_reduce(svo_ba* ba, int n_blocks, bool publish) {
 
 const LmCtl kNoCtl = {0, 0, 0, 0, 0};
 
-// The reduction of payload1 behind a device-wide arrival inside the pass-A launch (2 launches per LM iteration) or as
-// its own launch (3).  Measured on MI355X: alone on the GPU the agent-scope fences cost more than the launch they save
-// (38.3 vs 35.7 us per iteration, 1,595 vs 1,642 frames/s); with 8 stereo streams the GPU is launch-rate bound and the
-// fused form wins (6,090 vs 5,915 frames/s).  Default: fused when more than two pipelines share the process
-// (svo_throughput_mode, host/pipeline.cpp); SVO_BA_FUSED_REDUCE=0 / 1 forces either.
+// The whole LM iteration as ONE launch (ba_iterate_kernel) or as three (pass B, decision + pass A, reduction).  Measured
+// on MI355X: alone on the GPU the two device-wide waits cost more than the two launches they save (≈1,590 vs ≈1,700
+// frames/s); with 8 stereo streams the single launch wins (7,400 vs 6,250 frames/s).  Default: one launch when more than
+// two pipelines are inside process_batch (svo_throughput_mode, host/pipeline.cpp); SVO_BA_FUSED_REDUCE=0 / 1 forces either.
 bool ba_fused_reduce() {
   static const char* e = getenv("SVO_BA_FUSED_REDUCE");
   if (e && *e) return atoi(e) != 0;
@@ -1704,7 +1687,7 @@ int ba_fused_budget() {
   static const int budget = [] {
     int per_cu = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_decide_linearize_reduce_kernel, 128, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
   }();
@@ -1830,16 +1813,6 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       const int blocks = (same_sweep ? nb : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, same_sweep ? 1 : 0, 1, kNoCtl, ba_list_args(ba));
-    } else if (!sharded && d.C > 0 && ba_fused_reduce() && admission.admit(std::max(d.C, nb))) {
-      // pass A forms payload2, takes the decision itself AND reduces payload1 behind a device-wide arrival: 2 launches
-      // per LM iteration
-      const int grid = std::max(d.C, nb);
-      ba_aim_reduce(ba, std::min(grid, nb), true);
-      ba->done_total += (unsigned)grid;
-      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_decide_linearize_reduce_kernel, dim3(grid), dim3(128), 0, st, d, lc, ba->h_list_begin[nd - 1],
-                         ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba->d_arrive + 8, ba->done_total);
-      fused = true;
     } else if (!sharded && d.C > 0) {
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);

@@ -104,6 +104,23 @@ __device__ __forceinline__ void svo_publish_block(const SvoPublish& p) {
     if (last) __hip_atomic_store(p.word, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// The same without ANY cache maintenance, for kernels whose host payload is a few words: write them with svo_host_store
+// (relaxed system-scope stores are written through every cache level; `s_waitcnt vmcnt(0)` then means "acknowledged")
+// and publish with svo_publish_block_wt.  Used where many workgroups publish (one `buffer_wbl2` per workgroup adds up:
+// see the measurements at slot_store2 in ba.hip).
+template <typename T>
+__device__ __forceinline__ void svo_host_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void svo_publish_block_wt(const SvoPublish& p) {
+  if (!p.word) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool last = true;
+    if (p.arrive) last = __hip_atomic_fetch_add(p.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == p.target;
+    if (last) __hip_atomic_store(p.word, p.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 #endif
 
 enum SvoProfTag { SVO_PROF_NONE = 0, SVO_PROF_CORNER_RESPONSE, SVO_PROF_CORNER_NMS, SVO_PROF_CORNER_SELECT,

@@ -223,11 +223,11 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
   }
   if (lane == 0) {
     hyp_count[h] = cnt;
-    if (host_count) host_count[h] = cnt;  // pinned: the host's RANSAC bookkeeping reads the counts in place
+    if (host_count) svo_host_store(&host_count[h], cnt);  // pinned: the host's RANSAC bookkeeping reads the counts in place
     for (int k = 0; k < 4; ++k) hyp_pose[7 * h + k] = P.q[k];
     for (int k = 0; k < 3; ++k) hyp_pose[7 * h + 4 + k] = P.t[k];
   }
-  svo_publish_block(pub);
+  svo_publish_block_wt(pub);  // the only host payload is host_count (written through above): no write-back per workgroup
 }
 
 __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
