@@ -84,7 +84,7 @@ constexpr int RM = 5;            // margin of the staged target region around th
 constexpr int RS = G + 2 * RM;   // 32
 
 struct LkShared {
-  uint8_t raw[RP * RP];      // source patch of the template image (reflect-101 staged)
+  alignas(4) uint8_t raw[RP * RP];      // source patch of the template image (reflect-101 staged)
   alignas(4) uint8_t jreg[RS * RS + 8];  // target-image region; restaged only when the window leaves it (+8: the aligned-dword reads of the last row)
   short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
   short gx[G * G], gy[G * G];
@@ -287,6 +287,46 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
 }
 
 // ---- one wavefront per feature (LKT == 64) ------------------------------------------------------------------------
+// An N x N byte tile of an image level -> LDS, by one wavefront, in ONE memory round trip: every lane issues all of its
+// loads before it waits for any (the previous per-byte loop waited for each load — the compiler keeps a load and the LDS
+// store that depends on it together — which made a 32 x 32 restage cost 16 dependent trips to L2 / HBM; features that
+// drift restage up to 38 times per launch and were the launch's tail).  Inside the image: unaligned dword loads (N / 4 per
+// row); at the border: byte loads through reflect-101.  `dst` is dword-aligned, CAP its capacity in bytes.
+template <int N, int CAP>
+__device__ __forceinline__ void stage_tile(uint8_t* dst, const uint8_t* __restrict__ img, int w, int h, int x0, int y0, int lane) {
+  static_assert(N % 4 == 0 && N * N <= CAP, "tile rows are whole dwords");
+  constexpr int DW = N / 4, NDW = DW * N, PER = (NDW + 63) / 64;
+  if (x0 >= 0 && y0 >= 0 && x0 + N <= w && y0 + N <= h) {  // wave-uniform
+    uint32_t v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = lane + 64 * k;
+      v[k] = 0;
+      if (NDW % 64 == 0 || i < NDW) __builtin_memcpy(&v[k], img + __mul24(y0 + i / DW, w) + x0 + 4 * (i % DW), 4);
+    }
+    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int i = lane + 64 * k;
+      if (NDW % 64 == 0 || i < NDW) d32[i] = v[k];
+    }
+  } else {
+    constexpr int NB = N * N, PERB = (NB + 63) / 64;
+    uint8_t v[PERB];
+#pragma unroll
+    for (int k = 0; k < PERB; ++k) {
+      const int i = lane + 64 * k;
+      v[k] = 0;
+      if (NB % 64 == 0 || i < NB) v[k] = img[__mul24(reflect101(y0 + i / N, h), w) + reflect101(x0 + i % N, w)];
+    }
+#pragma unroll
+    for (int k = 0; k < PERB; ++k) {
+      const int i = lane + 64 * k;
+      if (NB % 64 == 0 || i < NB) dst[i] = v[k];
+    }
+  }
+}
+
 // Lane = (window row r, third of the row): 63 lanes own 7 consecutive pixels of one row each.  The template (patch value
 // and both derivatives of its 7 pixels) lives in REGISTERS for all iterations of a level; the Scharr derivatives are
 // formed straight from the staged source patch (no derivative grid in LDS, no extra synchronisation); an iteration reads
@@ -321,10 +361,7 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
     int iw11 = (1 << 14) - iw00 - iw01 - iw10;
     lk_sync();
     // stage the (WIN+3)^2 raw patch: tile (r,c) <-> image (ipy-1+r, ipx-1+c), reflect-101
-    for (int i = lane; i < RP * RP; i += 64) {
-      const int rr = i / RP, cc = i % RP;
-      S.raw[i] = Ip[__mul24(reflect101(ipy - 1 + rr, Ih_), Iw_) + reflect101(ipx - 1 + cc, Iw_)];
-    }
+    stage_tile<RP, sizeof(S.raw)>(S.raw, Ip, Iw_, Ih_, ipx - 1, ipy - 1, lane);
     lk_sync();
     // template of my 7 pixels: rows r..r+3, columns c0..c0+9 of the patch
     int tI[7], tX[7], tY[7];
@@ -395,12 +432,7 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
       if (!staged || inx < rx0 || inx > rx0 + 2 * RM || iny < ry0 || iny > ry0 + 2 * RM) {  // wave-uniform
         rx0 = inx - RM; ry0 = iny - RM;
         lk_sync();
-        if (rx0 >= 0 && ry0 >= 0 && rx0 + RS <= Jw_ && ry0 + RS <= Jh_) {
-          for (int i = lane; i < RS * RS; i += 64) S.jreg[i] = Jp[__mul24(ry0 + i / RS, Jw_) + rx0 + i % RS];
-        } else {
-          for (int i = lane; i < RS * RS; i += 64)
-            S.jreg[i] = Jp[__mul24(reflect101(ry0 + i / RS, Jh_), Jw_) + reflect101(rx0 + i % RS, Jw_)];
-        }
+        stage_tile<RS, RS * RS>(S.jreg, Jp, Jw_, Jh_, rx0, ry0, lane);
         lk_sync();
         staged = true;
       }

@@ -150,7 +150,7 @@ extern "C" int svo_lm_solve(int n_poses, double* poses7, const svo_lm_ops* ops, 
       const double* dU = gc + n;
       for (int a = 0; a < n; ++a) {
         Df[a] = std::min(std::max(dU[a] * sc[a] * sc[a], MIN_DIAG), MAX_DIAG) / radius;
-        for (int b = 0; b < n; ++b) Sm[(size_t)a * n + b] = S[(size_t)a * n + b] * sc[a] * sc[b];
+        for (int b = 0; b <= a; ++b) Sm[(size_t)a * n + b] = S[(size_t)a * n + b] * sc[a] * sc[b];  // the factorisation reads the lower triangle only
         Sm[(size_t)a * n + a] += Df[a];
         rhs[a] = -(gred[a] + gc[a]) * sc[a];  // the backend accumulates only the -Y g_p part of the reduced gradient
       }
