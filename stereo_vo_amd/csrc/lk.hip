@@ -55,16 +55,44 @@ __device__ __forceinline__ int descale(int v, int n) { return (v + (1 << (n - 1)
 // 2^-9 descale, Scharr |g| <= 16*255 = 4080, so one product is < 2^25 (8160*4080 = 33,292,800; 4080^2 < 2^24),
 // a thread's partial over its PPT <= 7 pixels is < 2^28 and the sum over EIGHT lanes (half a DPP row) is
 // 7 * 8 * 33,292,800 = 1,864,396,800 < 2^31: three DPP steps are exact in int32.  The eight half-row totals are then
-// added in 64 bits on the scalar unit.  Integer addition is associative, so the result does not depend on the
+// added as two 16-bit-split halves (see below).  Integer addition is associative, so the result does not depend on the
 // order (this is what lets the oracle use a plain sequential int64 sum).
 __device__ __forceinline__ long long wave_sum_i64(int v) {
   v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
   v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror: every lane holds its 8-lane total
-  long long t = 0;
-#pragma unroll
-  for (int l = 0; l < 64; l += 8) t += (long long)__builtin_amdgcn_readlane(v, l);
-  return t;
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);  // row_half_mirror: every lane holds its 8-lane total (< 2^31)
+  // The eight 8-lane totals need 34 bits.  v = hi * 65536 + lo with 0 <= lo < 65536, |hi| <= 2^15: both halves are summed
+  // across the wave in int32 by three more DPP steps (row_mirror, row_bcast:15 into rows 1 and 3, row_bcast:31 into rows
+  // 2 and 3; lane 63 ends up with the wave total) — 12 fewer v_readlane and 24 fewer dependent scalar adds per sum than
+  // reading the eight partials out one by one, on the critical path of every LK iteration.
+  int lo = v & 0xFFFF, hi = v >> 16;
+  lo += __builtin_amdgcn_mov_dpp(lo, 0x140, 0xf, 0xf, true);  // row_mirror: lanes of a row hold the row total
+  hi += __builtin_amdgcn_mov_dpp(hi, 0x140, 0xf, 0xf, true);
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);
+  const long long l = __builtin_amdgcn_readlane(lo, 63), h = __builtin_amdgcn_readlane(hi, 63);
+  return h * 65536 + l;
+}
+
+// The same exact sum S, delivered as (float)(double)S — the conversion the reference arithmetic applies — without 64-bit
+// or f64 operations: S = h * 65536 + l with |h| < 2^19 and 0 <= l < 2^19, so (float)h * 65536 and (float)l are both exact
+// and ONE IEEE f32 addition of two exact operands is the correctly rounded value of S, which is what rounding the
+// (exactly representable) double gives.
+__device__ __forceinline__ float wave_sum_f32(int v) {
+  v += __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true);
+  v += __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true);
+  v += __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true);
+  int lo = v & 0xFFFF, hi = v >> 16;
+  lo += __builtin_amdgcn_mov_dpp(lo, 0x140, 0xf, 0xf, true);
+  hi += __builtin_amdgcn_mov_dpp(hi, 0x140, 0xf, 0xf, true);
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+  lo += __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);
+  hi += __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);
+  const int l = __builtin_amdgcn_readlane(lo, 63), h = __builtin_amdgcn_readlane(hi, 63);
+  return (float)h * 65536.0f + (float)l;
 }
 
 #ifndef SVO_LK_THREADS
@@ -287,6 +315,21 @@ __device__ uint8_t lk_point(const Pyr& A, const Pyr& B, float px0, float py0, fl
 }
 
 // ---- one wavefront per feature (LKT == 64) ------------------------------------------------------------------------
+// The reference's convergence tests compare in double.  (double)|x| < 0.01: the largest float below the double 0.01 is
+// (float)0.01 itself (0.00999999977...), so the test is |x| <= 0.01f exactly.  dx^2 + dy^2 <= 1e-4 in double (products of
+// floats are exact there, one rounding in the sum): decided in f32 when the f32 value is clear of the threshold by more
+// than its own error (3 roundings, < 4e-7 relative), and in f64 — the reference expression itself — only in between.
+__device__ __forceinline__ bool below_eps(float x) {
+  static_assert(LK_EPS == 0.01, "the float threshold below is derived for epsilon = 0.01");
+  return fabsf(x) <= 0.01f;
+}
+__device__ __forceinline__ bool step_below_eps(float dx, float dy) {
+  const float s = dx * dx + dy * dy;
+  if (s < 0.9999e-4f) return true;
+  if (s > 1.0001e-4f) return false;
+  return (double)dx * (double)dx + (double)dy * (double)dy <= LK_EPS * LK_EPS;
+}
+
 // An N x N byte tile of an image level -> LDS, by one wavefront, in ONE memory round trip: every lane issues all of its
 // loads before it waits for any (the previous per-byte loop waited for each load — the compiler keeps a load and the LDS
 // store that depends on it together — which made a 32 x 32 restage cost 16 dependent trips to L2 / HBM; features that
@@ -458,15 +501,14 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
           pb[1] += __mul24(diff, tY[p]);
         }
       }
-      const long long sb1 = wave_sum_i64(pb[0]), sb2 = wave_sum_i64(pb[1]);
-      const float b1 = (float)(double)sb1 * FLT_SCALE;
-      const float b2 = (float)(double)sb2 * FLT_SCALE;
+      const float b1 = wave_sum_f32(pb[0]) * FLT_SCALE;
+      const float b2 = wave_sum_f32(pb[1]) * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;
       const float dy = (A12 * b1 - A11 * b2) * D;
       nx += dx; ny += dy;
       outx = nx + (float)HALF; outy = ny + (float)HALF;
-      if ((double)dx * (double)dx + (double)dy * (double)dy <= LK_EPS * LK_EPS) break;
-      if (j > 0 && (double)fabsf(dx + pdx) < LK_EPS && (double)fabsf(dy + pdy) < LK_EPS) {
+      if (step_below_eps(dx, dy)) break;
+      if (j > 0 && below_eps(dx + pdx) && below_eps(dy + pdy)) {
         outx -= dx * 0.5f; outy -= dy * 0.5f;
         break;
       }
