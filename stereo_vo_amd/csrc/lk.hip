@@ -462,7 +462,8 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
     bool staged = false;
     const uint32_t* jw = reinterpret_cast<const uint32_t*>(S.jreg);
     for (int j = 0; j < MAX_ITER; ++j) {
-      const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+      // wave-uniform values: on the scalar unit, so that the window tests below are scalar compares and plain branches
+      const int inx = __builtin_amdgcn_readfirstlane((int)floorf(nx)), iny = __builtin_amdgcn_readfirstlane((int)floorf(ny));
       if (inx < -WIN || inx >= Jw_ || iny < -WIN || iny >= Jh_) {
         if (level == 0) status = 0;
         break;
@@ -508,7 +509,7 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
       nx += dx; ny += dy;
       outx = nx + (float)HALF; outy = ny + (float)HALF;
       if (step_below_eps(dx, dy)) break;
-      if (j > 0 && below_eps(dx + pdx) && below_eps(dy + pdy)) {
+      if (j > 0 && ((int)below_eps(dx + pdx) & (int)below_eps(dy + pdy))) {  // one branch, not two
         outx -= dx * 0.5f; outy -= dy * 0.5f;
         break;
       }
