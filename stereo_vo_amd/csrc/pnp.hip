@@ -59,49 +59,77 @@ __device__ __forceinline__ double pnp_term(const double* R, const double* t, con
   return ex * ex + ey * ey;
 }
 
-__device__ bool solve6(const double* Hin, const double* g, double lambda, double* d) {
-  double L[36];
-  for (int r = 0; r < 6; ++r)
-    for (int c = r; c < 6; ++c) L[6 * c + r] = Hin[6 * r + c];
-  for (int r = 0; r < 6; ++r) L[6 * r + r] += lambda * Hin[6 * r + r] + 1e-12;
-  for (int j = 0; j < 6; ++j) {
-    double s = L[6 * j + j];
-    for (int k = 0; k < j; ++k) s -= L[6 * j + k] * L[6 * j + k];
-    if (!(s > 0)) return false;
-    const double ljj = sqrt(s);
-    L[6 * j + j] = ljj;
-    for (int i = j + 1; i < 6; ++i) {
-      double v = L[6 * i + j];
-      for (int k = 0; k < j; ++k) v -= L[6 * i + k] * L[6 * j + k];
-      L[6 * i + j] = v / ljj;
-    }
-  }
-  double y[6];
-  for (int i = 0; i < 6; ++i) {
-    double v = -g[i];
-    for (int k = 0; k < i; ++k) v -= L[6 * i + k] * y[k];
-    y[i] = v / L[6 * i + i];
-  }
-  for (int i = 5; i >= 0; --i) {
-    double v = y[i];
-    for (int k = i + 1; k < 6; ++k) v -= L[6 * k + i] * d[k];
-    d[i] = v / L[6 * i + i];
-  }
-  return true;
+// One damped Gauss-Newton step and its retraction, as declared in oracle/ora_pnp.cpp (solve6: lower Cholesky of
+// H + lambda diag(H) + 1e-12 I, left-looking, products subtracted one at a time in ascending k, forward then backward
+// substitution; retract: q+ = normalise(normalise([1, d/2]) (x) q), t+ = t + d[3:6]) — by ONE WAVEFRONT instead of one lane:
+// lane i < 6 owns row i of the factor, columns are finished left to right, every element receives exactly the oracle's
+// operations in the oracle's order (one square root per column, one division per element) — same bits —
+// but the 15 divisions of the column scalings and the 8 of the two quaternion normalisations run side by side: 28 dependent
+// f64 square roots / divisions per LM step instead of 45, and those sequences ARE the step (an f64 division is ~12 dependent
+// instructions).  Called by all 64 lanes of the first wavefront; values cross lanes through v_readlane (constant lanes).
+__device__ __forceinline__ double bcast_d(double v, int lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
 }
 
-__device__ void retract(const PnpPose& P, const double* d, PnpPose& N) {
-  double dq[4] = {1.0, 0.5 * d[0], 0.5 * d[1], 0.5 * d[2]};
-  const double nn = sqrt(dq[0] * dq[0] + dq[1] * dq[1] + dq[2] * dq[2] + dq[3] * dq[3]);
-  for (int k = 0; k < 4; ++k) dq[k] /= nn;
+__device__ bool solve6_retract_wave(const double* Hin, const double* g, double lambda, const PnpPose& P, double* d_out, PnpPose& N) {
+  const int lane = threadIdx.x & 63;
+  const int ii = lane < 6 ? lane : 5;  // idle lanes shadow row 5 (their results are never used)
+  double L[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    L[k] = k <= ii ? Hin[6 * k + ii] : 0.0;
+    if (k == ii) L[k] += lambda * Hin[6 * k + k] + 1e-12;
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double v = L[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v -= L[k] * bcast_d(L[k], j);
+    const double s = bcast_d(v, j);
+    if (!(s > 0)) return false;  // wave-uniform
+    const double ljj = sqrt(s);
+    L[j] = ii == j ? ljj : v / ljj;
+  }
+  const double mg = -g[ii];
+  double y = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    double v = mg;
+#pragma unroll
+    for (int k = 0; k < i; ++k) v -= L[k] * bcast_d(y, k);
+    const double yi = v / L[i];
+    if (ii == i) y = yi;
+  }
+  double dd = 0.0;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double v = y;
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) v -= bcast_d(L[i], k) * bcast_d(dd, k);
+    const double di = v / L[i];
+    if (ii == i) dd = di;
+  }
+  double d[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) d[k] = bcast_d(dd, k);
+  if (lane < 6) d_out[lane] = dd;
+  // retract(P, d, N): every lane forms the sums, lane k < 4 does the k-th division of each normalisation
+  const double dq0 = 1.0, dq1 = 0.5 * d[0], dq2 = 0.5 * d[1], dq3 = 0.5 * d[2];
+  const double nn = sqrt(dq0 * dq0 + dq1 * dq1 + dq2 * dq2 + dq3 * dq3);
+  const int kk = lane & 3;
+  const double mine = (kk == 0 ? dq0 : kk == 1 ? dq1 : kk == 2 ? dq2 : dq3) / nn;
+  const double n0 = bcast_d(mine, 0), n1 = bcast_d(mine, 1), n2_ = bcast_d(mine, 2), n3 = bcast_d(mine, 3);
   const double* q = P.q;
-  N.q[0] = dq[0] * q[0] - dq[1] * q[1] - dq[2] * q[2] - dq[3] * q[3];
-  N.q[1] = dq[0] * q[1] + dq[1] * q[0] + dq[2] * q[3] - dq[3] * q[2];
-  N.q[2] = dq[0] * q[2] - dq[1] * q[3] + dq[2] * q[0] + dq[3] * q[1];
-  N.q[3] = dq[0] * q[3] + dq[1] * q[2] - dq[2] * q[1] + dq[3] * q[0];
-  const double n2 = sqrt(N.q[0] * N.q[0] + N.q[1] * N.q[1] + N.q[2] * N.q[2] + N.q[3] * N.q[3]);
-  for (int k = 0; k < 4; ++k) N.q[k] /= n2;
-  for (int k = 0; k < 3; ++k) N.t[k] = P.t[k] + d[3 + k];
+  const double r0 = n0 * q[0] - n1 * q[1] - n2_ * q[2] - n3 * q[3];
+  const double r1 = n0 * q[1] + n1 * q[0] + n2_ * q[3] - n3 * q[2];
+  const double r2 = n0 * q[2] - n1 * q[3] + n2_ * q[0] + n3 * q[1];
+  const double r3 = n0 * q[3] + n1 * q[2] - n2_ * q[1] + n3 * q[0];
+  const double nr = sqrt(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3);
+  const double rq = (kk == 0 ? r0 : kk == 1 ? r1 : kk == 2 ? r2 : r3) / nr;
+  if (lane < 4) N.q[lane] = rq;
+  if (lane < 3) N.t[lane] = P.t[lane] + d[3 + lane];
+  return true;
 }
 
 // Shared LM driver.  `acc(pose, H, g)` evaluates the cost — and the normal equations into H / g (LDS) — at `pose` for the
@@ -120,9 +148,9 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
   double lambda = 1e-3;
   double cost = acc(S.cur, S.H, S.g);
   for (int it = 0; it < max_it; ++it) {
-    if (threadIdx.x == 0) {
-      S.ok = solve6(S.H, S.g, lambda, S.d) ? 1 : 0;
-      if (S.ok) retract(S.cur, S.d, S.cand);
+    if (threadIdx.x < 64) {
+      const bool ok = solve6_retract_wave(S.H, S.g, lambda, S.cur, S.d, S.cand);
+      if (threadIdx.x == 0) S.ok = ok ? 1 : 0;
     }
     __syncthreads();
     const int ok = S.ok;
