@@ -155,3 +155,37 @@ def test_hip_lk_and_track_bit_exact(ctx, frames):
         assert np.array_equal(kg[1], ko[1]) and np.array_equal(kg[0].view(np.uint32), ko[0].view(np.uint32))
         assert np.float32(kg[2]).view(np.uint32) == np.float32(ko[2]).view(np.uint32)
         assert 0 < len(ko[1]) < len(pts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,shift", [(96, 64, (1.6, -0.7)), (51, 37, (-2.3, 1.1)), (200, 31, (6.5, 0.4)), (33, 120, (0.3, -7.2))])
+def test_hip_lk_small_images_borders_and_restaging(ctx, w, h, shift):
+    """The LK kernel stages its tiles two ways: unaligned dword loads when the tile lies inside the pyramid level, byte
+    loads through reflect-101 otherwise.  Small and odd-sized images make the coarse levels smaller than a 24x24 / 32x32
+    tile (every tile reflects, some several times), a dense grid of points including the borders and beyond hits the
+    x0 + N == w boundary of the fast path at level 0, and a large shift makes windows walk out of the staged region
+    (restaging).  Positions and status must equal the oracle's bit for bit."""
+    rng = np.random.default_rng(w * 1000 + h)
+    big = rng.integers(0, 256, size=(h + 40, w + 40)).astype(np.float32)
+    # smooth the noise a little so that LK has a gradient to follow, then cut two shifted views
+    k = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    for ax in (0, 1):
+        big = np.apply_along_axis(lambda v: np.convolve(v, k, mode="same"), ax, big)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+
+    def view(dx, dy):
+        x, y = xx + 20 + dx, yy + 20 + dy
+        x0, y0 = np.floor(x).astype(int), np.floor(y).astype(int)
+        fx, fy = x - x0, y - y0
+        v = (big[y0, x0] * (1 - fx) * (1 - fy) + big[y0, x0 + 1] * fx * (1 - fy) + big[y0 + 1, x0] * (1 - fx) * fy +
+             big[y0 + 1, x0 + 1] * fx * fy)
+        return np.clip(np.rint(v), 0, 255).astype(np.uint8)
+
+    A, B = view(0.0, 0.0), view(*shift)
+    gx, gy = np.meshgrid(np.arange(-2.0, w + 3.0, 6.5), np.arange(-2.0, h + 3.0, 5.25))
+    pts = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float32)
+    out_g, st_g = ctx.lk_track(A, B, pts)  # the session context (1280x720 capacity) takes any smaller image
+    out_o, st_o = O.lk_track(A, B, pts)
+    assert np.array_equal(st_g, st_o)
+    assert np.array_equal(out_g.view(np.uint32), out_o.view(np.uint32))
+    assert st_o.sum() > 0
