@@ -550,6 +550,7 @@ __device__ __forceinline__ void reduce_pay2(const BaDev& P, int e0, int len, dou
 
 // ---- pass A alone (first linearisation of a solve, re-linearisation after a rejected step or a missed speculation)
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+  svo_latency_critical();
   apply_ctl(P, radius, ctl);
   extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2  (bulk mode only)
   const int n = P.n;
@@ -585,6 +586,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 // scalars (every workgroup redundantly, in the declared order: 32 KB of L2 reads instead of a launch boundary), takes
 // Ceres' accept / radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
 __global__ __launch_bounds__(128) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl, int lm_begin, int lm_count) {
+  svo_latency_critical();
   __shared__ double sP[RSEG * 4];
   __shared__ double sOut[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -640,6 +642,7 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
 // the candidate it just formed, with the radius an accepted step will have.  One wave per workgroup (spreads the
 // chunks over the CUs); the candidate landmark stays in registers between the passes.
 __global__ __launch_bounds__(64) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
+  svo_latency_critical();
   __shared__ double sStep[STEP_LDS_DOUBLES];
   const int lane = threadIdx.x & 63;
   int chunk = blockIdx.x;
@@ -752,6 +755,7 @@ __device__ __forceinline__ void reduce_publish(const BaDev& P) {
 }
 
 __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, int with_pay2, LmCtl ctl, ListArgs la) {
+  svo_latency_critical();
   __shared__ double sP[RSEG][RED_SLICE];
   __shared__ double sOut[4];
   const int F = P.K - 1, tid = threadIdx.x, b = blockIdx.x;

@@ -87,6 +87,11 @@ inline SvoPublish svo_publish_next(svo_ctx* c, int which, int nblocks = 1) {
 int svo_wait_word(svo_ctx* c, const SvoPublish& p);  // ctx.hip: bounded spin, falls back to a stream wait
 
 #if defined(__HIPCC__)
+// First statement of every small kernel that sits on a stereo stream's serial path (the keyframe chain, the adjuster's
+// passes): raised wave priority, so that on a SIMD shared with other streams' long tracker waves (priority 0, hundreds of
+// microseconds of VALU work each) these few instructions issue first.
+__device__ __forceinline__ void svo_latency_critical() { __builtin_amdgcn_s_setprio(3); }
+
 // Called by EVERY thread of the workgroup after its last store to host memory.
 // Cache maintenance is kept to the one operation the protocol needs.  `__threadfence_system()` and an acq_rel atomic are
 // each `buffer_wbl2` + `buffer_inv`: the invalidate empties the whole L2 of the workgroup's XCD under every other kernel

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict
                                                          float* __restrict__ kept_xy, float* __restrict__ xyz,
                                                          int* __restrict__ kept_index, int* __restrict__ n_kept,
                                                          SvoPublish pub) {
+  svo_latency_critical();
   __shared__ int sWave[CT / 64];
   const int n = n_dev ? *n_dev : n_host;
   int base = 0;
@@ -70,6 +71,7 @@ __global__ __launch_bounds__(256) void dedup_flag_kernel(const float* __restrict
                                                          int n_det_host, const float* __restrict__ trk,
                                                          const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
                                                          uint8_t* __restrict__ keep) {
+  svo_latency_critical();
   const int nd = n_det_dev ? *n_det_dev : n_det_host;
   const int nt = n_trk_dev ? *n_trk_dev : n_trk_host;
   const int lane = threadIdx.x & 63;
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256) void dedup_flag_kernel(const float* __restrict
 __global__ __launch_bounds__(CT) void dedup_compact_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
                                                            int n_det_host, const uint8_t* __restrict__ keepf,
                                                            float* __restrict__ kept_xy, int* __restrict__ n_kept) {
+  svo_latency_critical();
   __shared__ int sWave[CT / 64];
   const int nd = n_det_dev ? *n_det_dev : n_det_host;
   int base = 0;
@@ -107,6 +110,7 @@ __global__ __launch_bounds__(CT) void dedup_compact_kernel(const float* __restri
 __global__ void gather_track_kernel(const int* __restrict__ idx, const int* __restrict__ n_dev, int n_host,
                                     const float* __restrict__ init_src, const long long* __restrict__ ids_src,
                                     float* __restrict__ init_dst, long long* __restrict__ ids_dst) {
+  svo_latency_critical();
   const int n = n_dev ? *n_dev : n_host;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int s = idx[i];
@@ -127,6 +131,7 @@ int svo_k_gather_track(svo_ctx* ctx, const int* idx, const int* n_dev, int n_max
 __global__ void tracker_init_kernel(const float* __restrict__ h_xy, const long long* __restrict__ h_ids, int n,
                                     float* __restrict__ d_xy, float* __restrict__ d_init, long long* __restrict__ d_ids,
                                     SvoPublish pub) {
+  svo_latency_critical();
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float x = h_xy[2 * i], y = h_xy[2 * i + 1];
     d_xy[2 * i] = x; d_xy[2 * i + 1] = y;

@@ -602,6 +602,7 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
                                                              int n_host, float* __restrict__ kept_xy, int* __restrict__ kept_index,
                                                              int* __restrict__ n_kept, float* __restrict__ av_parallax,
                                                              SvoTrackCarry carry) {
+  svo_latency_critical();
   __shared__ int sWave[16];
   const int n = n_dev ? *n_dev : n_host;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

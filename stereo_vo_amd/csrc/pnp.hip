@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
                                                             int* __restrict__ hyp_count,
                                                             unsigned long long* __restrict__ hyp_mask, int mask_words,
                                                             int* __restrict__ host_count, SvoPublish pub) {
+  svo_latency_critical();
   __shared__ LmShared S;
   __shared__ int sIdx[MODEL];
   __shared__ double sJ[MODEL][12], sE[MODEL][2];
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
                                                          int* __restrict__ n_inliers, double* __restrict__ host_pose,
                                                          int* __restrict__ host_inliers, int* __restrict__ host_nin,
                                                          SvoPublish pub) {
+  svo_latency_critical();
   __shared__ LmShared S;
   __shared__ double sPart[256][28];
   __shared__ int sBase;

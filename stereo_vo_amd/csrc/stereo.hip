@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restric
                                                         int W, int H, int stride, int ndisp, int block,
                                                         const float* __restrict__ xy, const int* __restrict__ n_dev,
                                                         int n_host, float* __restrict__ disp) {
+  svo_latency_critical();
   const int n = n_dev ? *n_dev : n_host;
   const int f = blockIdx.x;
   if (f >= n) return;
