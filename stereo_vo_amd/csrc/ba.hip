@@ -509,7 +509,13 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
 // per use); the first workgroup also leaves the device copy of the candidate poses that later launches linearise at.
 __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
   const int nn = P.n > 0 ? P.n : 1, tot = nn + 7 * P.K;
-  for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+  // the first two rounds as ONE round trip (window problems: 72-124 words on 64 or 128 threads): both loads are issued,
+  // unconditionally and at clamped addresses, before either is stored — the plain loop waits for each PCIe read in turn
+  const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+  const double v0 = P.step_in[min(i0, tot - 1)], v1 = P.step_in[min(i1, tot - 1)];
+  if (i0 < tot) { sStep[i0] = v0; if (blockIdx.x == 0 && i0 >= nn) P.cand_poses[i0 - nn] = v0; }
+  if (i1 < tot) { sStep[i1] = v1; if (blockIdx.x == 0 && i1 >= nn) P.cand_poses[i1 - nn] = v1; }
+  for (int i = threadIdx.x + 2 * blockDim.x; i < tot; i += blockDim.x) {
     const double v = P.step_in[i];
     sStep[i] = v;
     if (blockIdx.x == 0 && i >= nn) P.cand_poses[i - nn] = v;

@@ -77,15 +77,36 @@ __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restric
   __shared__ int sT;
   const int rows = block + 2, lcols = block + 2, rcols = block + 1 + ndisp;
   const int ly0 = y - half - 1, lx0 = x - half - 1, rx0 = x - half - (ndisp - 1) - 1;
-  for (int i = tid; i < rows * lcols; i += 256) {
-    const int r = i / lcols, c = i % lcols;
-    const int gx = min(max(lx0 + c, 0), W - 1);
-    sLr[r][c] = L[(size_t)pf_row(ly0 + r, H) * stride + gx];
-  }
-  for (int i = tid; i < rows * rcols; i += 256) {
-    const int r = i / rcols, c = i % rcols;
-    const int gx = min(max(rx0 + c, 0), W - 1);
-    sRr[r][c] = R[(size_t)pf_row(ly0 + r, H) * stride + gx];
+  // both raw patches in ONE memory round trip: every thread issues all of its loads (3 left + 8 right at the maximum block
+  // and disparity range) before the first LDS store waits for any of them — a plain copy loop with a run-time trip count
+  // is compiled as load, wait, store per iteration: ten dependent trips to L2 / HBM per feature
+  {
+    constexpr int NL = (PR * LC + 255) / 256, NR = (PR * RC + 255) / 256;
+    uint8_t vl[NL], vr[NR];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + 256 * k;
+      const int ic = min(i, rows * lcols - 1);  // unconditional load of a valid address: predication would put a wait behind each load
+      const int r = ic / lcols, c = ic % lcols;
+      vl[k] = L[(size_t)pf_row(ly0 + r, H) * stride + min(max(lx0 + c, 0), W - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int i = tid + 256 * k;
+      const int ic = min(i, rows * rcols - 1);
+      const int r = ic / rcols, c = ic % rcols;
+      vr[k] = R[(size_t)pf_row(ly0 + r, H) * stride + min(max(rx0 + c, 0), W - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const int i = tid + 256 * k;
+      if (i < rows * lcols) sLr[i / lcols][i % lcols] = vl[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int i = tid + 256 * k;
+      if (i < rows * rcols) sRr[i / rcols][i % rcols] = vr[k];
+    }
   }
   if (tid < MAX_NDISP + 2) sSad[tid] = 0;
   if (tid == 0) sT = 0;
