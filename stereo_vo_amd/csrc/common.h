@@ -84,6 +84,14 @@ inline SvoPublish svo_publish_next(svo_ctx* c, int which, int nblocks = 1) {
   }
   return p;
 }
+// arrival counter only (a hand-over between the workgroups of one launch, no host word)
+inline SvoPublish svo_arrive_next(svo_ctx* c, int nblocks) {
+  SvoPublish p;
+  c->arrive_total += (unsigned)nblocks;
+  p.arrive = reinterpret_cast<unsigned*>(c->d_status + 8);
+  p.target = c->arrive_total;
+  return p;
+}
 int svo_wait_word(svo_ctx* c, const SvoPublish& p);  // ctx.hip: bounded spin, falls back to a stream wait
 
 #if defined(__HIPCC__)

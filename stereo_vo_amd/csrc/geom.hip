@@ -5,28 +5,10 @@
 // the input order, as the reference's push_back loops produce.
 #include "kernels.h"
 #include "ref_constants.h"
+#include "tail_device.h"
 
 namespace {
 constexpr int CT = 1024;
-
-// Stable compaction step for one chunk of CT items; returns this thread's output slot or -1.
-__device__ __forceinline__ int compact_slot(bool keep, int& base, int* sWave) {
-  const unsigned long long mask = __ballot(keep);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int before = __popcll(mask & ((1ull << lane) - 1ull));
-  if (lane == 0) sWave[wave] = __popcll(mask);
-  __syncthreads();
-  int off = 0, total = 0;
-  for (int w = 0; w < CT / 64; ++w) {
-    const int c = sWave[w];
-    if (w < wave) off += c;
-    total += c;
-  }
-  const int slot = keep ? base + off + before : -1;
-  base += total;
-  __syncthreads();
-  return slot;
-}
 }  // namespace
 
 __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict__ xy, const float* __restrict__ disp,
@@ -37,72 +19,45 @@ __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict
   svo_latency_critical();
   __shared__ int sWave[CT / 64];
   const int n = n_dev ? *n_dev : n_host;
-  int base = 0;
-  for (int c0 = 0; c0 < n; c0 += CT) {
-    const int i = c0 + threadIdx.x;
-    float x = 0.f, y = 0.f, d = 0.f;
-    bool keep = false;
-    if (i < n) {
-      x = xy[2 * i]; y = xy[2 * i + 1]; d = disp[i];
-      keep = d > svo_ref::TRIANGULATE_MIN_DISPARITY;  // src/image_processor.cpp:194
-    }
-    const int slot = compact_slot(keep, base, sWave);
-    if (slot >= 0) {
-      const float v[4] = {x, y, d, 1.0f};
-      float wv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s += (double)M.m[4 * r + k] * (double)v[k];
-        wv[r] = (float)s;
-      }
-      kept_xy[2 * slot] = x; kept_xy[2 * slot + 1] = y;
-      xyz[3 * slot] = wv[0] / wv[3]; xyz[3 * slot + 1] = wv[1] / wv[3]; xyz[3 * slot + 2] = wv[2] / wv[3];
-      if (kept_index) kept_index[slot] = i;
-    }
-  }
-  if (threadIdx.x == 0) *n_kept = base;
+  svo_triangulate_block<CT, false>(xy, disp, n, M, kept_xy, xyz, kept_index, n_kept, sWave);
   svo_publish_block(pub);  // the outputs may be pinned host memory (pipeline): the host polls instead of copying
 }
 
-// one wavefront per detected corner: 64 tracked features are tested per step, any hit drops the corner
-__global__ __launch_bounds__(256) void dedup_flag_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
-                                                         int n_det_host, const float* __restrict__ trk,
-                                                         const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
-                                                         uint8_t* __restrict__ keep) {
+// a6 in ONE launch.  One wavefront per detected corner: 64 tracked features are tested per step, any hit drops the corner;
+// the last workgroup to arrive compacts the survivors in input order (tail_device.h).
+__global__ __launch_bounds__(256) void dedup_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
+                                                    int n_det_host, const float* __restrict__ trk,
+                                                    const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
+                                                    uint8_t* keep, float* __restrict__ kept_xy, int* __restrict__ n_kept,
+                                                    unsigned* arrive, unsigned target) {
   svo_latency_critical();
+  __shared__ int sWave[4];
+  __shared__ int sLast;
   const int nd = n_det_dev ? *n_det_dev : n_det_host;
   const int nt = n_trk_dev ? *n_trk_dev : n_trk_host;
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= nd) return;
-  const float x = det[2 * i], y = det[2 * i + 1];
-  bool hit = false;
-  for (int j0 = 0; j0 < nt && !hit; j0 += 64) {
-    const int j = j0 + lane;
-    bool h = false;
-    if (j < nt) {
-      const float dx = x - trk[2 * j], dy = y - trk[2 * j + 1];
-      h = sqrtf(dx * dx + dy * dy) < min_d;  // src/image_processor.cpp:118-123
+  if (i < nd) {
+    const float x = det[2 * i], y = det[2 * i + 1];
+    bool hit = false;
+    for (int j0 = 0; j0 < nt && !hit; j0 += 64) {
+      const int j = j0 + lane;
+      bool h = false;
+      if (j < nt) {
+        const float dx = x - trk[2 * j], dy = y - trk[2 * j + 1];
+        h = sqrtf(dx * dx + dy * dy) < min_d;  // src/image_processor.cpp:118-123
+      }
+      hit = __any(h);
     }
-    hit = __any(h);
+    if (lane == 0) svo_wt_store(&keep[i], (uint8_t)(hit ? 0 : 1));
   }
-  if (lane == 0) keep[i] = hit ? 0 : 1;
-}
-
-__global__ __launch_bounds__(CT) void dedup_compact_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
-                                                           int n_det_host, const uint8_t* __restrict__ keepf,
-                                                           float* __restrict__ kept_xy, int* __restrict__ n_kept) {
-  svo_latency_critical();
-  __shared__ int sWave[CT / 64];
-  const int nd = n_det_dev ? *n_det_dev : n_det_host;
+  if (!svo_last_arrival(arrive, target, &sLast)) return;
   int base = 0;
-  for (int c0 = 0; c0 < nd; c0 += CT) {
-    const int i = c0 + threadIdx.x;
-    const bool keep = i < nd && keepf[i];
-    const int slot = compact_slot(keep, base, sWave);
-    if (slot >= 0) { kept_xy[2 * slot] = det[2 * i]; kept_xy[2 * slot + 1] = det[2 * i + 1]; }
+  for (int c0 = 0; c0 < nd; c0 += 256) {
+    const int k = c0 + threadIdx.x;
+    const bool kp = k < nd && svo_coherent_load(&keep[k]) != 0;
+    const int slot = svo_compact_slot<256>(kp, base, sWave);
+    if (slot >= 0) { kept_xy[2 * slot] = det[2 * k]; kept_xy[2 * slot + 1] = det[2 * k + 1]; }
   }
   if (threadIdx.x == 0) *n_kept = base;
 }
@@ -185,11 +140,10 @@ int svo_k_dedup(svo_ctx* ctx, const float* det_xy, const int* n_det_dev, int n_d
                 const int* n_trk_dev, int n_trk_max, float min_distance, float* kept_xy, int* n_kept) {
   if (n_det_max > ctx->lim.max_batch * ctx->lim.max_candidates) { ctx->err = "dedup: too many detected corners"; return SVO_ERR_CAPACITY; }
   uint8_t* flags = ctx->d_state;  // scratch (the corner-select state array is idle here)
-  if (n_det_max > 0)
-    hipLaunchKernelGGL(dedup_flag_kernel, dim3(svo_div_up(n_det_max, 4)), dim3(256), 0, ctx->stream, det_xy, n_det_dev,
-                       n_det_max, trk_xy, n_trk_dev, n_trk_max, min_distance, flags);
-  hipLaunchKernelGGL(dedup_compact_kernel, dim3(1), dim3(CT), 0, ctx->stream, det_xy, n_det_dev, n_det_max, flags, kept_xy,
-                     n_kept);
+  const int grid = n_det_max > 0 ? svo_div_up(n_det_max, 4) : 1;
+  const SvoPublish arr = svo_arrive_next(ctx, grid);
+  hipLaunchKernelGGL(dedup_kernel, dim3(grid), dim3(256), 0, ctx->stream, det_xy, n_det_dev, n_det_max, trk_xy, n_trk_dev,
+                     n_trk_max, min_distance, flags, kept_xy, n_kept, arr.arrive, arr.target);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -13,6 +13,11 @@ SvoMat4 svo_k_reprojection_matrix(const float* pose16, float focal, float cx, fl
 int svo_k_triangulate(svo_ctx* ctx, const float* xy, const float* disp, const int* n_dev, int n_max,
                       const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept,
                       const SvoPublish* pub = nullptr);
+// a7 (sparse) + a8 in one launch: disparities at the n features, triangulation / compaction by the last workgroup; the
+// outputs may be pinned host memory, `*pub_out` is the completion word to wait for (svo_wait_word)
+int svo_k_stereo_triangulate(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width, int height, int row_stride,
+                             int num_disparities, int block_size, const float* xy, const int* n_dev, int n_max, float* disp,
+                             const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept, int word, SvoPublish* pub_out);
 // a6
 int svo_k_dedup(svo_ctx* ctx, const float* det_xy, const int* n_det_dev, int n_det_max, const float* trk_xy,
                 const int* n_trk_dev, int n_trk_max, float min_distance, float* kept_xy, int* n_kept);
@@ -47,5 +52,6 @@ int svo_k_gather_xy_ids(svo_ctx* ctx, const int* idx, int n, const float* xy_src
 // a5 (device-pointer form)
 int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy, int n, float focal, float cx, float cy,
               double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence, int* d_inliers,
-              int* n_inliers, int* h_inliers = nullptr /* pinned: also receives the inlier list */);
+              int* n_inliers, int* h_inliers = nullptr /* pinned: also receives the inlier list */,
+              float* d_inlier_xy = nullptr /* device: xy of the inliers, in list order (the dedup stage's input) */);
 #endif

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
                                                          int best, double* __restrict__ out_pose, int* __restrict__ inliers,
                                                          int* __restrict__ n_inliers, double* __restrict__ host_pose,
                                                          int* __restrict__ host_inliers, int* __restrict__ host_nin,
-                                                         SvoPublish pub) {
+                                                         float* __restrict__ inlier_xy, SvoPublish pub) {
   svo_latency_critical();
   __shared__ LmShared S;
   __shared__ double sPart[256][28];
@@ -280,6 +280,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
         const int slot = base + __popcll(m & ((1ull << tid) - 1ull));
         inliers[slot] = w * 64 + tid;
         if (host_inliers) host_inliers[slot] = w * 64 + tid;
+        if (inlier_xy) { inlier_xy[2 * slot] = xy[2 * (w * 64 + tid)]; inlier_xy[2 * slot + 1] = xy[2 * (w * 64 + tid) + 1]; }  // the dedup stage's input, gathered here
       }
       base += __popcll(m);
     }
@@ -362,7 +363,7 @@ static int update_num_iters(double p, double ep, int model_points, int max_iters
 // Work buffers come from `s`.  On return rvec3/tvec3 are updated (host), d_inliers holds the list.
 int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy, int n, float focal, float cxf, float cyf,
               double* rvec3, double* tvec3, int iterations, float reproj_err, double confidence, int* d_inliers,
-              int* n_inliers, int* h_inliers) {
+              int* n_inliers, int* h_inliers, float* d_inlier_xy) {
   *n_inliers = 0;
   if (n < MODEL || iterations < 1) return SVO_OK;
   PnpPose P0;
@@ -411,7 +412,7 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   {
   SvoProfScope prof(ctx, SVO_PROF_PNP_REFINE);
   hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf, (double)cyf,
-                     d_pose, d_mask, words, best, d_out, d_inliers, d_nin, h_out, h_inliers, h_nin, pub2);
+                     d_pose, d_mask, words, best, d_out, d_inliers, d_nin, h_out, h_inliers, h_nin, d_inlier_xy, pub2);
   }
   SVO_HIP_CHECK(ctx, hipGetLastError());
   rc = svo_wait_word(ctx, pub2);

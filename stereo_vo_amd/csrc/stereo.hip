@@ -14,6 +14,7 @@
 //                          separable running-window SADs kept in LDS (see the kernel).
 #include "common.h"
 #include "ref_constants.h"
+#include "tail_device.h"
 
 namespace {
 constexpr int CAP = 31, TEXTURE_THRESHOLD = 10, UNIQUENESS_RATIO = 15;
@@ -53,21 +54,13 @@ __device__ __forceinline__ int bm_select(int* s /* points at index 0, s[-1] and 
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
-                                                        int W, int H, int stride, int ndisp, int block,
-                                                        const float* __restrict__ xy, const int* __restrict__ n_dev,
-                                                        int n_host, float* __restrict__ disp) {
-  svo_latency_critical();
-  const int n = n_dev ? *n_dev : n_host;
-  const int f = blockIdx.x;
-  if (f >= n) return;
-  const int half = block / 2;
-  const int x = (int)xy[2 * f], y = (int)xy[2 * f + 1];  // at<float>(it->y, it->x): truncation (SURVEY C-13)
+// Sparse StereoBM at one feature pixel (x, y) by one 256-thread workgroup; the disparity is returned in thread 0.
+// Control flow is workgroup-uniform (the function contains barriers).
+__device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
+                                                 int stride, int ndisp, int block, int x, int y) {
   const int tid = threadIdx.x;
-  if (!(x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half)) {
-    if (tid == 0) disp[f] = -1.0f;
-    return;
-  }
+  const int half = block / 2;
+  if (!(x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half)) return -1.0f;  // workgroup-uniform
   constexpr int PR = MAX_BLOCK + 2;              // raw rows
   constexpr int LC = MAX_BLOCK + 2;              // raw left cols
   constexpr int RC = MAX_BLOCK + 2 + MAX_NDISP;  // raw right cols
@@ -149,7 +142,47 @@ __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restric
     if (lane == 0) sT = t;
   }
   __syncthreads();
-  if (tid == 0) disp[f] = (float)bm_select(sSad + 1, ndisp, sT) * svo_ref::STEREO_DISPARITY_SCALE;
+  float d = 0.f;
+  if (tid == 0) d = (float)bm_select(sSad + 1, ndisp, sT) * svo_ref::STEREO_DISPARITY_SCALE;
+  return d;
+}
+
+__global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                        int W, int H, int stride, int ndisp, int block,
+                                                        const float* __restrict__ xy, const int* __restrict__ n_dev,
+                                                        int n_host, float* __restrict__ disp) {
+  svo_latency_critical();
+  const int n = n_dev ? *n_dev : n_host;
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  // at<float>(it->y, it->x): truncation (SURVEY C-13)
+  const float d = stereo_at_block(L, R, W, H, stride, ndisp, block, (int)xy[2 * f], (int)xy[2 * f + 1]);
+  if (threadIdx.x == 0) disp[f] = d;
+}
+
+// Sparse stereo AND the triangulation of src/image_processor.cpp:178-207 in one launch: one workgroup per feature, the
+// last one to arrive triangulates / compacts all of them (tail_device.h) and publishes the completion word.
+__global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                                 int W, int H, int stride, int ndisp, int block,
+                                                                 const float* __restrict__ xy, const int* __restrict__ n_dev,
+                                                                 int n_host, float* disp, SvoMat4 M,
+                                                                 float* __restrict__ kept_xy, float* __restrict__ xyz,
+                                                                 int* __restrict__ kept_index, int* __restrict__ n_kept,
+                                                                 SvoPublish pub) {
+  svo_latency_critical();
+  __shared__ int sWaveT[4];
+  __shared__ int sLast;
+  const int n = n_dev ? *n_dev : n_host;
+  const int f = blockIdx.x;
+  if (f < n) {
+    const float d = stereo_at_block(L, R, W, H, stride, ndisp, block, (int)xy[2 * f], (int)xy[2 * f + 1]);
+    if (threadIdx.x == 0) svo_wt_store(&disp[f], d);
+  }
+  if (!svo_last_arrival(pub.arrive, pub.target, &sLast)) return;
+  svo_triangulate_block<256, true>(xy, disp, n, M, kept_xy, xyz, kept_index, n_kept, sWaveT);
+  SvoPublish one = pub;
+  one.arrive = nullptr;  // the arrivals have been counted: this workgroup publishes alone
+  svo_publish_block(one);
 }
 
 __global__ __launch_bounds__(256) void stereo_prefilter_kernel(const uint8_t* __restrict__ img, int W, int H, int stride,
@@ -282,6 +315,22 @@ extern "C" int svo_stereo_disparity_at_dev(svo_ctx* ctx, const uint8_t* left, co
   SvoProfScope prof(ctx, SVO_PROF_STEREO_AT);
   hipLaunchKernelGGL(stereo_at_kernel, dim3(n_max), dim3(256), 0, ctx->stream, left, right, width, height, row_stride,
                      num_disparities, block_size, xy, n_dev, n_max, disp);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_k_stereo_triangulate(svo_ctx* ctx, const uint8_t* left, const uint8_t* right, int width, int height, int row_stride,
+                             int num_disparities, int block_size, const float* xy, const int* n_dev, int n_max, float* disp,
+                             const SvoMat4& M, float* kept_xy, float* xyz, int* kept_index, int* n_kept, int word, SvoPublish* pub_out) {
+  int rc = stereo_check(ctx, left, right, width, height, row_stride, num_disparities, block_size);
+  if (rc) return rc;
+  SVO_REQUIRE(ctx, n_max >= 1 && xy && disp && kept_xy && xyz && n_kept && pub_out, "stereo_triangulate: null buffer");
+  SvoPublish pub = svo_publish_next(ctx, word, n_max);
+  if (n_max == 1) { const SvoPublish a = svo_arrive_next(ctx, 1); pub.arrive = a.arrive; pub.target = a.target; }  // every workgroup counts
+  *pub_out = pub;
+  SvoProfScope prof(ctx, SVO_PROF_STEREO_AT);
+  hipLaunchKernelGGL(stereo_triangulate_kernel, dim3(n_max), dim3(256), 0, ctx->stream, left, right, width, height, row_stride,
+                     num_disparities, block_size, xy, n_dev, n_max, disp, M, kept_xy, xyz, kept_index, n_kept, pub);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -531,13 +531,13 @@ void ImageProcessor::triangulate_stereo(std::vector<Point3f>& features_3d, std::
                                         const float* d_features, const int* d_n, int n_max, const DeviceImage& left,
                                         const DeviceImage& right, const float camera_pose[16]) {
   if (n_max <= 0) return;
-  if (svo_stereo_disparity_at_dev(ctx_, left.data, right.data, left.width, left.height, left.stride, svo_ref::STEREO_NUM_DISPARITIES, svo_ref::STEREO_BLOCK_SIZE, d_features,
-                                  d_n, n_max, d_disp_)) return;  // :173-176
   const SvoMat4 M = svo_k_reprojection_matrix(camera_pose, K_[0], K_[2], K_[5], baseline);  // :178-189
-  // the kernel's outputs are only consumed by the host (keyframe bookkeeping): it writes them into the pinned arena
-  // and publishes a completion word — no D2H blits, no stream wait
-  const SvoPublish pub = svo_publish_next(ctx_, SVO_W_TRI);
-  if (svo_k_triangulate(ctx_, d_features, d_disp_, d_n, n_max, M, h_tri_xy_, h_tri_xyz_, nullptr, h_tri_cnt_, &pub)) return;
+  // ONE launch for :173-176 and :190-207; the tail's outputs are only consumed by the host (keyframe bookkeeping): it
+  // writes them into the pinned arena and publishes a completion word — no D2H blits, no stream wait
+  SvoPublish pub;
+  if (svo_k_stereo_triangulate(ctx_, left.data, right.data, left.width, left.height, left.stride, svo_ref::STEREO_NUM_DISPARITIES,
+                               svo_ref::STEREO_BLOCK_SIZE, d_features, d_n, n_max, d_disp_, M, h_tri_xy_, h_tri_xyz_, nullptr, h_tri_cnt_,
+                               SVO_W_TRI, &pub)) return;
   if (svo_wait_word(ctx_, pub)) return;
   const int m = *h_tri_cnt_;
   valid_features_2d.resize(m);
@@ -626,7 +626,7 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
     SvoScratch scratch(ctx_);
     if (svo_k_pnp(ctx_, scratch, d_xyz_, feature_tracker->device_features(), m, K_[0], K_[2], K_[5], rv, tv, svo_ref::PNP_ITERATIONS, svo_ref::PNP_REPROJ_ERROR,
                   svo_ref::PNP_CONFIDENCE,
-                  d_inl_, &num_inliers, h_inl_)) return;
+                  d_inl_, &num_inliers, h_inl_, d_trk_xy_)) return;  // the refinement also leaves the inliers' features for the dedup below
   }
   for (int i = 0; i < 3; ++i) { rvec[i] = (float)rv[i]; tvec[i] = (float)tv[i]; }
   stats_.n_inliers = num_inliers;
@@ -645,9 +645,6 @@ void ImageProcessor::process(const StereoPair& sp) {  // src/image_processor.cpp
 
   phase.next(3);
   // dedup :113-128 on the device; the surviving corners stay in HBM for the stereo stage
-  if (num_inliers > 0 &&  // the inlier features are already in HBM: gather them by the device inlier list
-      svo_k_gather_xy_ids(ctx_, d_inl_, num_inliers, feature_tracker->device_features(), feature_tracker->device_ids(), d_trk_xy_,
-                          d_trk_ids_)) return;
   if (svo_k_dedup(ctx_, d_det, nullptr, n_det, d_trk_xy_, nullptr, num_inliers, min_feature_distance, d_new_xy_, d_cnt_)) return;
 
   // hmat = [R^T | -R^T t]  :130-134 (float Mats; the product accumulates in double)
