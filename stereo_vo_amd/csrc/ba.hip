@@ -53,6 +53,18 @@ bool svo_throughput_mode();  // host/pipeline.cpp: more than two pipelines share
 
 namespace {
 int g_ba_cu_share = 32;  // CUs of every 32 the adjusters' streams may use (SVO_BA_CU_SHARE; 32 = unmasked)
+std::atomic<int> g_fused_blocks{0};  // workgroups of admitted kernels whose workgroups wait for each other (see ba_fused_budget)
+int ba_fused_budget();
+struct FusedAdmission {
+  int blocks = 0;
+  bool admit(int n) {
+    if (g_fused_blocks.fetch_add(n, std::memory_order_acq_rel) + n <= ba_fused_budget()) { blocks = n; return true; }
+    g_fused_blocks.fetch_sub(n, std::memory_order_acq_rel);
+    return false;
+  }
+  void release() { if (blocks) g_fused_blocks.fetch_sub(blocks, std::memory_order_acq_rel); blocks = 0; }
+  ~FusedAdmission() { release(); }
+};
 constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32;
 constexpr int PAY2_SLOTS = 8;  // payload2 (4 doubles) is padded to 8 so that payload1 starts 64-byte aligned behind it
@@ -507,8 +519,16 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
 
 // [dc | candidate poses] -> LDS (the source may be pinned host memory: ONE PCIe round trip per workgroup instead of one
 // per use); the first workgroup also leaves the device copy of the candidate poses that later launches linearise at.
+// RES (resident kernel: no kernel boundary since the block was written): [dc | candidate poses | current poses], read at the
+// coherence point — a plain load could be served from a cache line of an earlier iteration.
+template <bool RES = false>
 __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
-  const int nn = P.n > 0 ? P.n : 1, tot = nn + 7 * P.K;
+  const int nn = P.n > 0 ? P.n : 1, tot = nn + (RES ? 14 : 7) * P.K;
+  if (RES) {
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) sStep[i] = slot_load(&P.step_in[i]);  // the device copy workgroup 0 made of the host's block
+    __syncthreads();
+    return;
+  }
   // the first two rounds as ONE round trip (window problems: 72-124 words on 64 or 128 threads): both loads are issued,
   // unconditionally and at clamped addresses, before either is stored — the plain loop waits for each PCIe read in turn
   const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
@@ -523,6 +543,7 @@ __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
   __syncthreads();
 }
 constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
+constexpr int RES_STEP_LDS_DOUBLES = 6 * 63 + 14 * 64;  // + the current poses
 
 // payload2 = R(landmark list) over the four per-landmark scalars of pass B (lmV2), in the declared order, by ANY workgroup
 // size: item = (segment, element), 112 items.  sP: RSEG * 4 doubles of LDS, sOut: 4.  Ends with a barrier: every thread
@@ -813,28 +834,31 @@ __device__ __forceinline__ bool wait_until(const unsigned* word, unsigned target
   }
 }
 
-__global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius, double spec_radius, LmCtl ctl, int with_pay1,
-                                                         int lm_begin, int lm_count, ListArgs la, IterSync sy) {
-  __shared__ double sStep[STEP_LDS_DOUBLES];
-  __shared__ double sP[RSEG][RED_SLICE];
-  __shared__ double sOut[4];
-  __shared__ double sDec[2];
-  __shared__ int sGo, sLast;
+struct IterShared {
+  double sP[RSEG][RED_SLICE];
+  double sOut[4];
+  double sDec[2];
+  int sGo, sLast;
+};
+
+// RES: inside the resident kernel — the step block (with the current poses) is read coherently, see stage_step<true>.
+template <bool RES>
+__device__ __forceinline__ void iterate_body(const BaDev& P, double radius, double spec_radius, const LmCtl& ctl, int with_pay1,
+                                             int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy, double* sStep,
+                                             IterShared& sh) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-  // these few waves are some stream's critical path and share their SIMDs with other streams' long tracker waves: issue
-  // priority over them (measured at 8 streams: +1 %; a high-priority HIP stream instead costs 7 %)
-  __builtin_amdgcn_s_setprio(3);
   const bool worker = (int)blockIdx.x < P.C;  // workgroups beyond the chunks only reduce
   if (worker) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
     if (wave == 0) R = load_obs(P, blockIdx.x, lane, P.points);  // requested before the step is staged: HBM and PCIe round trips overlap
-    stage_step(P, sStep);
+    stage_step<RES>(P, sStep);
     const double* dc_ = sStep;
     const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+    const double* cur_poses_ = RES ? cand_poses_ + 7 * P.K : P.poses;
     D3 cand = D3{0, 0, 1};
     double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
     if (wave == 0) {
-      backsub_chunk<true>(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
+      backsub_chunk<true>(P, R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
       if (spec_radius > 0) {
         R.p = cand;
         linearize_chunk<true>(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
@@ -843,35 +867,35 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
     }
     if (ctl.chain) {
       __syncthreads();
-      if (tid == 0) sLast = __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == sy.arrived_target;
+      if (tid == 0) sh.sLast = __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == sy.arrived_target;
       __syncthreads();
-      if (sLast) {
-        reduce_pay2<64, true>(P, lm_begin, lm_count, &sP[0][0], sOut);
-        const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
-        if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
+      if (sh.sLast) {
+        reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
+        const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
+        if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
         if (tid == 0) {
           __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sDec[0] = (double)dec.accept; sDec[1] = dec.next_radius;
+          sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius;
         }
         stores_acknowledged();  // the decision (device) and payload2 (host) have arrived before anybody can see the post
         __syncthreads();
         if (tid == 0) __hip_atomic_store(sy.posted, sy.post_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) sGo = 1;
+        if (tid == 0) sh.sGo = 1;
         __syncthreads();
       } else {
         if (tid == 0) {
           const bool ok = wait_until(sy.posted, sy.post_seq, false);
-          sDec[0] = slot_load(&P.ctl_dev[0]); sDec[1] = slot_load(&P.ctl_dev[1]);
-          sGo = ok;
+          sh.sDec[0] = slot_load(&P.ctl_dev[0]); sh.sDec[1] = slot_load(&P.ctl_dev[1]);
+          sh.sGo = ok;
         }
         __syncthreads();
       }
-      if (!sGo) return;
+      if (!sh.sGo) return;
       if (wave == 0) {
-        const bool accept = sDec[0] != 0.0;
+        const bool accept = sh.sDec[0] != 0.0;
         if (accept) R.p = cand;
-        linearize_chunk<true>(P, R, accept ? cand_poses_ : P.poses, sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+        linearize_chunk<true>(P, R, accept ? cand_poses_ : cur_poses_, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
         stores_acknowledged();
       }
     }
@@ -881,17 +905,139 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
   const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
   const bool sums2 = !ctl.chain && blockIdx.x == 0;  // payload2 of a same-sweep / plain step: formed here, by workgroup 0
   if ((int)blockIdx.x >= nb && !sums2) return;
-  if (tid == 0) sGo = wait_until(sy.done, sy.done_target, true);
+  if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
   __syncthreads();
-  if (!sGo) return;
+  if (!sh.sGo) return;
   if (sums2) {
-    reduce_pay2<64, true>(P, lm_begin, lm_count, &sP[0][0], sOut);
-    if (tid < 4) pay_store(&P.pay2_out[tid], sOut[tid]);
+    reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
+    if (tid < 4) pay_store(&P.pay2_out[tid], sh.sOut[tid]);
   }
-  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sP);
+  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
   reduce_publish(P);
 }
 
+__global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius, double spec_radius, LmCtl ctl, int with_pay1,
+                                                         int lm_begin, int lm_count, ListArgs la, IterSync sy) {
+  __shared__ double sStep[STEP_LDS_DOUBLES];
+  __shared__ IterShared sh;
+  // these few waves are some stream's critical path and share their SIMDs with other streams' long tracker waves: issue
+  // priority over them (measured at 8 streams: +1 %; a high-priority HIP stream instead costs 7 %)
+  __builtin_amdgcn_s_setprio(3);
+  iterate_body<false>(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh);
+}
+
+// ---- the LM loop of a window solve WITHOUT launches: one resident kernel per solve, driven by the host through a command
+// block in pinned memory.  Measured on MI355X (tools/exp/concurrency.hip, pingpong.hip): a launch -> completion-word round
+// trip of a 4 us kernel costs 10 us alone and 40 us when eight host threads drive eight hardware queues (the command
+// processor's latency grows with the number of active queues; kernel durations do not change), while a resident kernel
+// answers a word written to pinned memory in 3 us — alone or next to seven others.
+//   host:  fills [header | dc | candidate poses | current poses], stores the sequence number last (release)
+//   workgroup 0, thread 0: polls the sequence word over PCIe, posts it to the other workgroups through device memory
+//   all:   read the header and the step block with system-scope loads, run the command, publish the completion word
+// Commands: one LM iteration (iterate_body), pass A alone (first linearisation / re-linearisation), exit.  The current
+// poses travel with every command (the previous candidate poses were staged by ANOTHER workgroup's plain stores: not
+// coherently readable here); landmarks, their scaling and every slot are either wave-local across iterations (a landmark's
+// observations live in one chunk = one resident wave) or handed over write-through (section 6 of DESIGN.md).
+// Every wait is bounded: a workgroup that gives up leaves, the host's completion-word wait then reports the error.
+enum { RES_OP_ITERATE = 1, RES_OP_LINEARIZE = 2, RES_OP_EXIT = 3 };
+constexpr int RES_HDR_WORDS = 16, RES_HDR_DOUBLES = 6;  // header: 16 words at byte 0, 6 doubles at byte 64; the step block at byte 128
+struct ResArgs {
+  double* dev_cmd;        // device copy of [header (16 doubles) | step block], made by workgroup 0 for everybody else
+  int cmd_doubles;        // 16 + n + 14 K
+  const unsigned* hdr;    // pinned
+  unsigned* post;         // device: sequence number of the command every workgroup may read
+  unsigned first_seq;     // sequence number of this solve's first command
+  double* points_a;       // the two landmark buffers; header word 5 says which one is current
+  double* points_b;
+};
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_resident_kernel(BaDev P, ResArgs ra, int lm_begin, int lm_count, ListArgs la, IterSync sy0) {
+  __shared__ double sStep[RES_STEP_LDS_DOUBLES];
+  __shared__ IterShared sh;
+  __shared__ unsigned sHdr[RES_HDR_WORDS];
+  __shared__ double sHdrD[RES_HDR_DOUBLES];
+  __shared__ int sAlive;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);
+  P.step_in = ra.dev_cmd + 16;
+  for (unsigned seq = ra.first_seq;; ++seq) {
+    if (blockIdx.x == 0) {
+      // the only reader of host memory: wait for the command, copy it to device memory (write-through), post it
+      if (tid == 0) {
+        int alive = 1;
+        unsigned spins = 0;
+        while (__hip_atomic_load(ra.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+          if (++spins > (1u << 22)) { alive = 0; break; }  // ~seconds without a command: the host is gone
+        }
+        sAlive = alive;
+      }
+      __syncthreads();
+      if (sAlive) {
+        const double* src = reinterpret_cast<const double*>(ra.hdr);
+        for (int i = tid; i < ra.cmd_doubles; i += blockDim.x)
+          __hip_atomic_store(&ra.dev_cmd[i], __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        stores_acknowledged();
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(ra.post, sAlive ? seq : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (tid == 0) {
+      int alive = 1;
+      {
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned v = __hip_atomic_load(ra.post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (v == seq) break;
+          if (v == 0xFFFFFFFFu || ++spins > (1u << 23)) { alive = 0; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      sAlive = alive;
+    }
+    __syncthreads();
+    if (!sAlive) return;
+    {
+      const unsigned* dw = reinterpret_cast<const unsigned*>(ra.dev_cmd);
+      if (tid < RES_HDR_WORDS) sHdr[tid] = __hip_atomic_load(dw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else if (tid >= 64 && tid < 64 + RES_HDR_DOUBLES) sHdrD[tid - 64] = slot_load(ra.dev_cmd + 8 + (tid - 64));
+    }
+    __syncthreads();
+    const int op = (int)sHdr[1];
+    if (op == RES_OP_EXIT) return;
+    const bool sel = sHdr[5] != 0;
+    P.points = sel ? ra.points_b : ra.points_a;
+    P.cand_points = sel ? ra.points_a : ra.points_b;
+    P.arrive_target = sHdr[9];
+    P.seq = (int)sHdr[10];
+    IterSync sy = sy0;
+    sy.arrived_target = sHdr[6]; sy.post_seq = sHdr[7]; sy.done_target = sHdr[8];
+    const double radius = sHdrD[0];
+    if (op == RES_OP_ITERATE) {
+      const LmCtl ctl = {sHdrD[2], sHdrD[3], radius, sHdrD[4], (int)sHdr[2]};
+      iterate_body<true>(P, radius, sHdrD[1], ctl, (int)sHdr[3], lm_begin, lm_count, la, sy, sStep, sh);
+    } else {  // pass A alone at the current point (first linearisation: header word 4), then the reduction
+      if ((int)blockIdx.x < P.C) {
+        stage_step<true>(P, sStep);
+        if (wave == 0) {
+          const ObsRec R = load_obs(P, blockIdx.x, lane, P.points);
+          double unused0 = 0, unused1 = 0;
+          linearize_chunk<true>(P, R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, (int)sHdr[4], nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+          stores_acknowledged();
+        }
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int nb = ba_reduce_blocks(P.K - 1);
+      if ((int)blockIdx.x < nb) {
+        if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
+        __syncthreads();
+        if (!sh.sGo) return;
+        for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
+        reduce_publish(P);
+      }
+    }
+    __syncthreads();  // the shared header is rewritten at the top of the loop
+  }
+}
 
 // ---------------------------------------------------------------------------------------------------
 // Bulk (non-deterministic) linearisation with the Schur products on the f64 matrix cores.
@@ -1209,6 +1355,13 @@ struct svo_ba {
   size_t pin_bytes = 0;
   int* h_flag = nullptr;
   double* h_step = nullptr;
+  double* d_cmd = nullptr;
+  unsigned* h_hdr = nullptr;     // command header of the resident LM kernel (pinned, in front of h_step)
+  bool resident = false;         // a resident kernel is serving this solve
+  unsigned res_seq = 0;          // last command sequence number
+  bool res_sel = false;          // which landmark buffer is current (toggles with every accepted step)
+  int res_blocks = 0;            // admitted workgroups of the resident kernel
+  FusedAdmission res_admission;  // the resident kernel's workgroups, admitted for the duration of a solve
   double* h_pay = nullptr;
   // current / candidate buffers of the running solve (swapped on every accepted step)
   double *cur_points = nullptr, *cand_points = nullptr, *cur_poses = nullptr, *cand_poses = nullptr;
@@ -1245,6 +1398,7 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
+  A(ba->d_cmd, double, 16 + step_doubles + 7 * (size_t)Kmax);  // the resident kernel's device copy of a command
   A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
@@ -1285,12 +1439,15 @@ static int ba_alloc(svo_ba* ba) {
       SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
     }
   }
-  ba->pin_bytes = 64 + sizeof(double) * (step_doubles + PAY2_SLOTS + ba->cap_pay1);
+  // pinned block: [completion word 64 B | resident-kernel command header 128 B | step: dc, candidate poses (, current poses) | payload]
+  const size_t pin_step_doubles = step_doubles + 7 * (size_t)Kmax;
+  ba->pin_bytes = 64 + 128 + sizeof(double) * (pin_step_doubles + PAY2_SLOTS + ba->cap_pay1);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocCoherent));  // fine-grained: see reduce_publish
   memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
   ba->h_flag = reinterpret_cast<int*>(ba->h_pin);
-  ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64);
-  ba->h_pay = ba->h_step + step_doubles;
+  ba->h_hdr = reinterpret_cast<unsigned*>(ba->h_pin + 64);
+  ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64 + 128);
+  ba->h_pay = ba->h_step + pin_step_doubles;
   d.pay2 = ba->d_pay;
   d.pay1 = ba->d_pay + PAY2_SLOTS;
   return SVO_OK;
@@ -1338,7 +1495,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
             ba->n_step ? 1e3 * ba->t_step / ba->n_step : 0.0, ba->n_step, ba->n_hit, ba->n_spec, 1e3 * ba->t_prep / std::max(ba->n_solves, 1l),
             1e3 * ba->t_upload / std::max(ba->n_solves, 1l), 1e3 * ba->t_total / std::max(ba->n_solves, 1l), 1e3 * ba->t_read / std::max(ba->n_solves, 1l));
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
-  void* ptrs[] = {ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
+  void* ptrs[] = {ba->d_cmd, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1695,26 +1852,18 @@ bool ba_fused_reduce() {
 // budgets of 1/2, 3/4 and 1/1 of the capacity give 6,630 / 6,690 / 6,780 frames/s at 8 streams).  A launch that is not admitted takes the
 // separate-launch path for that iteration — same arithmetic, same results.  (Other PROCESSES on the GPU are not
 // counted; the kernel's bounded spin turns that unlikely pile-up into a reported error, never a hang.)
-std::atomic<int> g_fused_blocks{0};
 int ba_fused_budget() {
   static const int budget = [] {
-    int per_cu = 0, cus = 0, dev = 0;
+    int per_cu = 0, per_cu_res = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_resident_kernel, 128, 0) != hipSuccess) return 0;
+    per_cu = std::min(per_cu, per_cu_res);  // one budget for both kernels whose workgroups wait: the tighter occupancy counts
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
   }();
   return budget;
 }
-struct FusedAdmission {
-  int blocks = 0;
-  bool admit(int n) {
-    if (g_fused_blocks.fetch_add(n, std::memory_order_acq_rel) + n <= ba_fused_budget()) { blocks = n; return true; }
-    g_fused_blocks.fetch_sub(n, std::memory_order_acq_rel);
-    return false;
-  }
-  ~FusedAdmission() { if (blocks) g_fused_blocks.fetch_sub(blocks, std::memory_order_acq_rel); }
-};
 
 // destination lists as kernel arguments when they fit (every window-sized problem: K <= 6 free... F*F + F + 1 <= 48)
 ListArgs ba_list_args(const svo_ba* ba) {
@@ -1727,6 +1876,78 @@ ListArgs ba_list_args(const svo_ba* ba) {
   return la;
 }
 
+// ---- resident LM kernel: host side -----------------------------------------------------------------------------
+// SVO_BA_RESIDENT=0 / 1 forces; default: on while more than two pipelines are inside process_batch (with one hardware
+// queue per stream every launch -> completion round trip pays the command processor's multi-queue latency).
+bool ba_resident_wanted() {
+  static const char* e = getenv("SVO_BA_RESIDENT");
+  if (e && *e) return atoi(e) != 0;
+  return svo_throughput_mode();
+}
+
+IterSync ba_iter_sync(svo_ba* ba) {
+  IterSync sy;
+  sy.arrived = ba->d_arrive + 9; sy.arrived_target = ba->arrived_total;
+  sy.posted = ba->d_arrive + 10; sy.post_seq = ba->post_seq;
+  sy.done = ba->d_arrive + 8; sy.done_target = ba->done_total;
+  return sy;
+}
+
+// One command: header words, header doubles, step block, then the sequence number (release).
+void ba_resident_command(svo_ba* ba, int op, int chain, int with_pay1, int first, double radius, double spec_radius,
+                         const svo_lm_step_ctl* ctl, const double* dc, const double* cand_poses7) {
+  BaDev& d = ba->d;
+  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
+  unsigned* w = ba->h_hdr;
+  double* hd = reinterpret_cast<double*>(ba->h_hdr + 16);
+  w[1] = (unsigned)op; w[2] = (unsigned)chain; w[3] = (unsigned)with_pay1; w[4] = (unsigned)first; w[5] = ba->res_sel ? 1u : 0u;
+  w[6] = ba->arrived_total; w[7] = ba->post_seq; w[8] = ba->done_total; w[9] = d.arrive_target; w[10] = (unsigned)d.seq;
+  hd[0] = radius; hd[1] = spec_radius;
+  hd[2] = ctl ? ctl->cost : 0.0; hd[3] = ctl ? ctl->mcc : 0.0; hd[4] = ctl ? ctl->decrease_factor : 0.0; hd[5] = 0.0;
+  if (op != RES_OP_EXIT) {
+    if (dc && n > 0) memcpy(ba->h_step, dc, sizeof(double) * n);
+    if (cand_poses7) memcpy(ba->h_step + nn, cand_poses7, sizeof(double) * 7 * K);
+    memcpy(ba->h_step + nn + 7 * K, ba->h_poses.data(), sizeof(double) * 7 * K);  // the current poses (lm.cpp keeps them up to date)
+  }
+  __atomic_store_n(&w[0], ++ba->res_seq, __ATOMIC_RELEASE);
+}
+
+inline FusedAdmission* ba_resident_admission(svo_ba* ba) { return &ba->res_admission; }
+
+// Starts the resident kernel for the loaded problem if the conditions hold; false: use the launch-per-pass paths.
+bool ba_resident_begin(svo_ba* ba) {
+  BaDev& d = ba->d;
+  ba->resident = false;
+  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !ba_resident_wanted()) return false;
+  const int nd = (d.K - 1) * d.K / 2 + (d.K - 1) + 1;
+  if ((int)ba->h_list_begin.size() < nd) return false;
+  const int grid = d.C;  // one workgroup per chunk; the reduction slices are looped over them
+  if (!ba_resident_admission(ba)->admit(grid)) return false;
+  ba->res_blocks = grid;
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  d.ctl_dev = reinterpret_cast<double*>(ba->d_arrive + 2);
+  d.pay2_out = ba->h_pay; d.pay1_out = ba->h_pay + PAY2_SLOTS;
+  d.flag = ba->h_flag; d.arrive = ba->d_arrive;
+  ba->res_sel = false;
+  ResArgs ra;
+  ra.dev_cmd = ba->d_cmd; ra.cmd_doubles = 16 + (d.n > 0 ? d.n : 1) + 14 * d.K;
+  ra.hdr = ba->h_hdr; ra.post = ba->d_arrive + 11; ra.first_seq = ba->res_seq + 1;
+  ra.points_a = ba->cur_points; ra.points_b = ba->cand_points;
+  hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream, d, ra, ba->h_list_begin[nd - 1],
+                     ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba_iter_sync(ba));
+  if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
+  ba->resident = true;
+  return true;
+}
+
+void ba_resident_end(svo_ba* ba) {
+  if (!ba->resident) return;
+  ba_resident_command(ba, RES_OP_EXIT, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
+  ba->resident = false;
+  (void)hipStreamSynchronize(ba->stream);  // the kernel has left: its workgroups no longer count
+  ba_resident_admission(ba)->release();
+}
+
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
   svo_ba* ba = static_cast<svo_ba*>(user);
   svo_ctx* ctx = ba->ctx;
@@ -1736,7 +1957,14 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
   const int n = d.n, K = d.K;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
-  if (d.det) {
+  if (d.det && ba->resident) {
+    const int nb = ba_reduce_blocks(K - 1);
+    ba_aim_reduce(ba, std::min(ba->res_blocks, nb), true);
+    ba->done_total += (unsigned)ba->res_blocks;
+    ba_resident_command(ba, RES_OP_LINEARIZE, 0, 1, first, radius, 0.0, nullptr, nullptr, nullptr);
+    const int rc = ba_wait_flag(ba, d.seq);
+    if (rc) return rc;
+  } else if (d.det) {
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
@@ -1792,7 +2020,16 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     d.step_in = ba->d_step;
   }
   const bool next = same_sweep || chain;
-  if (d.det) {
+  if (d.det && ba->resident) {
+    // the resident kernel runs the whole iteration on a command: no launch
+    const int nb = ba_reduce_blocks(K - 1);
+    ba_aim_reduce(ba, next ? std::min(ba->res_blocks, nb) : 1, true);
+    if (chain) { ba->arrived_total += (unsigned)d.C; ++ba->post_seq; }
+    ba->done_total += (unsigned)ba->res_blocks;
+    ba_resident_command(ba, RES_OP_ITERATE, chain ? 1 : 0, next ? 1 : 0, 0, radius, same_sweep ? spec_radius : 0.0, ctl, dc, cand_poses7);
+    const int rc = ba_wait_flag(ba, d.seq);
+    if (rc) return rc;
+  } else if (d.det) {
     const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
     const int nb = ba_reduce_blocks(K - 1);
     const int lm_b = ba->h_list_begin[nd - 1], lm_n = ba->h_list_end[nd - 1] - lm_b;
@@ -1897,6 +2134,7 @@ int op_accept(void* user) {
   svo_ba* ba = static_cast<svo_ba*>(user);
   std::swap(ba->cur_points, ba->cand_points);
   std::swap(ba->cur_poses, ba->cand_poses);  // the candidate poses are already on the device (pass B's first workgroup)
+  ba->res_sel = !ba->res_sel;                // the resident kernel is told with every command which buffer is current
   return SVO_OK;
 }
 }  // namespace
@@ -1911,7 +2149,9 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
+  ba_resident_begin(ba);  // window-sized, single rank, deterministic, wanted and admitted: the passes become commands
   const int rc = svo_lm_solve(d.K, ba->h_poses.data(), &ops, &ba->opt, sum, &ba->stats);
+  ba_resident_end(ba);    // on every path: a resident kernel must never be left waiting for a host that has moved on
   ba->n_spec += ba->stats.speculations; ba->n_hit += ba->stats.speculation_hits;
   // nothing is pending on the zero-copy path either; the wait keeps later users of the stream ordered
   SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
