@@ -30,7 +30,7 @@ import time
 
 # HIP runtime knob, read when the runtime initialises: the default of 4 hardware queues makes the 2 HIP streams of
 # each stereo stream (tracker + bundle adjuster) share queues and serialise; measured +6 % at 8 streams.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per HIP stream with a margin: a resident LM kernel holds its queue for a whole solve
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
