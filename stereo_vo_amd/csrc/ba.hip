@@ -939,7 +939,7 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
 // coherently readable here); landmarks, their scaling and every slot are either wave-local across iterations (a landmark's
 // observations live in one chunk = one resident wave) or handed over write-through (section 6 of DESIGN.md).
 // Every wait is bounded: a workgroup that gives up leaves, the host's completion-word wait then reports the error.
-enum { RES_OP_ITERATE = 1, RES_OP_LINEARIZE = 2, RES_OP_EXIT = 3 };
+enum { RES_OP_ITERATE = 1, RES_OP_LINEARIZE = 2, RES_OP_EXIT = 3, RES_OP_DELIVER = 4 };
 constexpr int RES_HDR_WORDS = 16, RES_HDR_DOUBLES = 6;  // header: 16 words at byte 0, 6 doubles at byte 64; the step block at byte 128
 struct ResArgs {
   double* dev_cmd;        // device copy of [header (16 doubles) | step block], made by workgroup 0 for everybody else
@@ -947,6 +947,7 @@ struct ResArgs {
   const unsigned* hdr;    // pinned
   unsigned* post;         // device: sequence number of the command every workgroup may read
   unsigned first_seq;     // sequence number of this solve's first command
+  double* export_points;  // pinned: where the exit command delivers the solved landmarks (null: no delivery)
   double* points_a;       // the two landmark buffers; header word 5 says which one is current
   double* points_b;
 };
@@ -1003,6 +1004,30 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
     const int op = (int)sHdr[1];
     if (op == RES_OP_EXIT) return;
+    if (op == RES_OP_DELIVER) {
+      // after the last iteration: every wave delivers its own landmarks (it is the only one that can read them without
+      // cache maintenance) into pinned memory that only the GPU writes (8-byte stores into lines the CPU holds DIRTY —
+      // the uploaded problem image — took 0.4 ms for 700 landmarks: every store made the host bridge fetch the line from
+      // a CPU cache first); the last workgroup publishes the completion word.
+      if (ra.export_points && (int)blockIdx.x < P.C && wave == 0) {
+        // a chunk's landmarks are consecutive indices: staged in LDS, then written by consecutive lanes to consecutive
+        // addresses (scattered 8-byte system-scope stores go out one PCIe write each: 0.4 ms for 700 landmarks)
+        const ObsRec R = load_obs(P, blockIdx.x, lane, sHdr[5] != 0 ? ra.points_b : ra.points_a);
+        const int j0 = __builtin_amdgcn_readfirstlane(R.j);  // lane 0 holds the chunk's first observation
+        const unsigned long long firsts = __ballot(R.active && lane == R.first);
+        const int count = __popcll(firsts);
+        if (R.active && lane == R.first) { sStep[3 * (R.j - j0)] = R.p.x; sStep[3 * (R.j - j0) + 1] = R.p.y; sStep[3 * (R.j - j0) + 2] = R.p.z; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (int i = lane; i < 3 * count; i += 64) pay_store(&ra.export_points[3 * (size_t)j0 + i], sStep[i]);
+      }
+      P.arrive_target = sHdr[9];
+      P.seq = (int)sHdr[10];
+      reduce_publish(P);
+      __syncthreads();
+      continue;
+    }
     const bool sel = sHdr[5] != 0;
     P.points = sel ? ra.points_b : ra.points_a;
     P.cand_points = sel ? ra.points_a : ra.points_b;
@@ -1361,6 +1386,10 @@ struct svo_ba {
   unsigned res_seq = 0;          // last command sequence number
   bool res_sel = false;          // which landmark buffer is current (toggles with every accepted step)
   int res_blocks = 0;            // admitted workgroups of the resident kernel
+  bool res_export = false;       // the exit command delivers the landmarks into the pinned image
+  bool host_points_valid = false;  // ... and did: h_arena + arena_pts_off holds the solved landmarks
+  size_t arena_pts_off = 0;
+  double* h_out_points = nullptr;  // pinned, GPU-written only
   FusedAdmission res_admission;  // the resident kernel's workgroups, admitted for the duration of a solve
   double* h_pay = nullptr;
   // current / candidate buffers of the running solve (swapped on every accepted step)
@@ -1441,13 +1470,15 @@ static int ba_alloc(svo_ba* ba) {
   }
   // pinned block: [completion word 64 B | resident-kernel command header 128 B | step: dc, candidate poses (, current poses) | payload]
   const size_t pin_step_doubles = step_doubles + 7 * (size_t)Kmax;
-  ba->pin_bytes = 64 + 128 + sizeof(double) * (pin_step_doubles + PAY2_SLOTS + ba->cap_pay1);
+  // ... | landmarks delivered by the resident kernel (written by the GPU only: the CPU never holds these lines dirty)]
+  ba->pin_bytes = 64 + 128 + sizeof(double) * (pin_step_doubles + PAY2_SLOTS + ba->cap_pay1 + 8 + 3 * ba->cap_points);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocCoherent));  // fine-grained: see reduce_publish
   memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
   ba->h_flag = reinterpret_cast<int*>(ba->h_pin);
   ba->h_hdr = reinterpret_cast<unsigned*>(ba->h_pin + 64);
   ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64 + 128);
   ba->h_pay = ba->h_step + pin_step_doubles;
+  ba->h_out_points = ba->h_pay + ((PAY2_SLOTS + ba->cap_pay1 + 7) & ~(size_t)7);
   d.pay2 = ba->d_pay;
   d.pay1 = ba->d_pay + PAY2_SLOTS;
   return SVO_OK;
@@ -1651,6 +1682,7 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
   const size_t o_pts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
+  ba->arena_pts_off = o_pts; ba->host_points_valid = false;
   const size_t o_cpts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
   const size_t o_rec = off; off = al(off + sizeof(int4) * nslots);
   const size_t o_uv = off; off = al(off + sizeof(double) * 2 * nslots);
@@ -1904,7 +1936,7 @@ void ba_resident_command(svo_ba* ba, int op, int chain, int with_pay1, int first
   w[6] = ba->arrived_total; w[7] = ba->post_seq; w[8] = ba->done_total; w[9] = d.arrive_target; w[10] = (unsigned)d.seq;
   hd[0] = radius; hd[1] = spec_radius;
   hd[2] = ctl ? ctl->cost : 0.0; hd[3] = ctl ? ctl->mcc : 0.0; hd[4] = ctl ? ctl->decrease_factor : 0.0; hd[5] = 0.0;
-  if (op != RES_OP_EXIT) {
+  if (op == RES_OP_ITERATE || op == RES_OP_LINEARIZE) {
     if (dc && n > 0) memcpy(ba->h_step, dc, sizeof(double) * n);
     if (cand_poses7) memcpy(ba->h_step + nn, cand_poses7, sizeof(double) * 7 * K);
     memcpy(ba->h_step + nn + 7 * K, ba->h_poses.data(), sizeof(double) * 7 * K);  // the current poses (lm.cpp keeps them up to date)
@@ -1933,6 +1965,8 @@ bool ba_resident_begin(svo_ba* ba) {
   ra.dev_cmd = ba->d_cmd; ra.cmd_doubles = 16 + (d.n > 0 ? d.n : 1) + 14 * d.K;
   ra.hdr = ba->h_hdr; ra.post = ba->d_arrive + 11; ra.first_seq = ba->res_seq + 1;
   ra.points_a = ba->cur_points; ra.points_b = ba->cand_points;
+  ra.export_points = ba->n_points ? ba->h_out_points : nullptr;
+  ba->res_export = ra.export_points != nullptr;
   hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream, d, ra, ba->h_list_begin[nd - 1],
                      ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba_iter_sync(ba));
   if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
@@ -1940,11 +1974,19 @@ bool ba_resident_begin(svo_ba* ba) {
   return true;
 }
 
-void ba_resident_end(svo_ba* ba) {
+// ok = the solve finished normally: the exit command also delivers the landmarks into the pinned problem image and
+// publishes a completion word, so the host needs neither a D2H copy nor a stream wait to read the result.
+void ba_resident_end(svo_ba* ba, bool ok) {
   if (!ba->resident) return;
+  ba->host_points_valid = false;
+  if (ok && ba->res_export) {
+    ba_aim_reduce(ba, ba->res_blocks, true);
+    ba_resident_command(ba, RES_OP_DELIVER, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
+    ba->host_points_valid = ba_wait_flag(ba, ba->d.seq) == SVO_OK;
+  }
   ba_resident_command(ba, RES_OP_EXIT, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
   ba->resident = false;
-  (void)hipStreamSynchronize(ba->stream);  // the kernel has left: its workgroups no longer count
+  if (!ba->host_points_valid) (void)hipStreamSynchronize(ba->stream);  // the kernel has left: its workgroups no longer count
   ba_resident_admission(ba)->release();
 }
 
@@ -2151,10 +2193,11 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   memset(&ba->stats, 0, sizeof(ba->stats));
   ba_resident_begin(ba);  // window-sized, single rank, deterministic, wanted and admitted: the passes become commands
   const int rc = svo_lm_solve(d.K, ba->h_poses.data(), &ops, &ba->opt, sum, &ba->stats);
-  ba_resident_end(ba);    // on every path: a resident kernel must never be left waiting for a host that has moved on
+  ba_resident_end(ba, rc == SVO_OK);  // on every path: a resident kernel must never be left waiting for a host that has moved on
   ba->n_spec += ba->stats.speculations; ba->n_hit += ba->stats.speculation_hits;
-  // nothing is pending on the zero-copy path either; the wait keeps later users of the stream ordered
-  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+  // nothing is pending on the zero-copy path either; the wait keeps later users of the stream ordered (the resident
+  // kernel's exit has published a completion word instead: stream order alone protects the next upload)
+  if (!ba->host_points_valid) SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
   d.flag = nullptr;
   // leave the result in d.points / d.poses
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
@@ -2183,7 +2226,14 @@ extern "C" int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3) 
   if (!ba) return SVO_ERR_INVALID;
   svo_ctx* ctx = ba->ctx;
   if (poses7) memcpy(poses7, ba->h_poses.data(), sizeof(double) * 7 * (size_t)ba->d.K);
-  if (points3 && ba->n_points) {
+  if (points3 && ba->n_points && ba->host_points_valid) {
+    // delivered by the resident kernel; a landmark without observations was never touched: it keeps its uploaded value
+    memcpy(points3, ba->h_out_points, sizeof(double) * 3 * (size_t)ba->n_points);
+    const double* in = reinterpret_cast<const double*>(ba->h_arena + ba->arena_pts_off);
+    const std::vector<int32_t>& lm = ba->u_lm_start;
+    for (int j = 0; j < ba->n_points && (size_t)j + 1 < lm.size(); ++j)
+      if (lm[j + 1] == lm[j]) { points3[3 * j] = in[3 * j]; points3[3 * j + 1] = in[3 * j + 1]; points3[3 * j + 2] = in[3 * j + 2]; }
+  } else if (points3 && ba->n_points) {
     // through the pinned arena (idle once the solve has finished): the runtime's pageable path would stage and wait
     const size_t bytes = sizeof(double) * 3 * (size_t)ba->n_points;
     void* stage = bytes <= ba->arena_cap ? (void*)ba->h_arena : (void*)points3;
