@@ -604,12 +604,16 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
                                                              SvoTrackCarry carry) {
   svo_latency_critical();
   __shared__ int sWave[16];
+  // parallax of the kept features, +0.0f for the dropped ones, in feature order: the summing lane adds every entry — adding
+  // +0.0f leaves a running sum that is >= +0 bit-identical — so its loop is one dependent add per feature and nothing else
+  __shared__ __align__(16) float sPar[4096];
   const int n = n_dev ? *n_dev : n_host;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int base = 0;
   for (int c0 = 0; c0 < n; c0 += 1024) {
     const int i = c0 + threadIdx.x;
     const bool k = i < n && keep[i];
+    if (i < 4096) sPar[i] = k ? parallax[i] : 0.0f;  // staged in the same memory round trip as the flags
     const unsigned long long mask = __ballot(k);
     if (lane == 0) sWave[wave] = __popcll(mask);
     __syncthreads();
@@ -629,27 +633,25 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __rest
     base += total;
     __syncthreads();
   }
-  // sequential f32 sum in feature order (the reference's loop order decides the rounding, SURVEY C-2):
-  // values are staged in LDS by all threads so the single summing lane never waits on global memory
-  __shared__ __align__(16) float sPar[4096];
+  // sequential f32 sum in feature order (the reference's loop order decides the rounding, SURVEY C-2)
   float sum = 0.f;
   for (int c0 = 0; c0 < n; c0 += 4096) {
-    __syncthreads();
-    for (int i = threadIdx.x; i < 4096 && c0 + i < n; i += 1024) sPar[i] = keep[c0 + i] ? parallax[c0 + i] : -1.0f;
-    __syncthreads();
+    if (c0 > 0) {  // beyond the first 4096 features: restage
+      __syncthreads();
+      for (int i = threadIdx.x; i < 4096 && c0 + i < n; i += 1024) sPar[i] = keep[c0 + i] ? parallax[c0 + i] : 0.0f;
+      __syncthreads();
+    }
     if (threadIdx.x == 0) {
-      // dropped features were staged as -1: adding +0.0f instead leaves the running sum bit-identical (it is >= +0)
-      // and keeps the loop branch-free, four LDS words per read
       const int m = n - c0 < 4096 ? n - c0 : 4096;
       int i = 0;
-      for (; i + 4 <= m; i += 4) {
-        const float4 q = *reinterpret_cast<const float4*>(&sPar[i]);
-        sum += q.x >= 0.f ? q.x : 0.f;
-        sum += q.y >= 0.f ? q.y : 0.f;
-        sum += q.z >= 0.f ? q.z : 0.f;
-        sum += q.w >= 0.f ? q.w : 0.f;
+      for (; i + 32 <= m; i += 32) {  // 8 LDS reads in flight, then 32 dependent adds
+        float4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const float4*>(&sPar[i + 4 * u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sum += q[u].x; sum += q[u].y; sum += q[u].z; sum += q[u].w; }
       }
-      for (; i < m; ++i) { const float v = sPar[i]; sum += v >= 0.f ? v : 0.f; }
+      for (; i < m; ++i) sum += sPar[i];
     }
   }
   if (threadIdx.x == 0) {
