@@ -5,14 +5,15 @@
 // deterministic RANSAC both this oracle and the HIP path implement:
 //   * model size 5; hypothesis h draws its 5 distinct indices from splitmix64 seeded with
 //     kSeed + h*kStride (so hypotheses are independent and can run in parallel);
-//   * minimal solve = damped Gauss-Newton (LM, <=12 iterations) on the 5 points starting from the
+//   * minimal solve = damped Gauss-Newton (LM, <=12 iterations, stopped like OpenCV's CvLevMarq when the relative
+//     parameter change of an accepted step drops below FLT_EPSILON) on the 5 points starting from the
 //     extrinsic guess, pose = unit quaternion + translation, left-multiplicative update
 //     q <- normalize([1, dw/2]) (x) q  (no trigonometry => bit-reproducible on CPU and GPU);
 //   * inlier iff z>0 and squared reprojection error <= reproj_err^2 (OpenCV compares squared
 //     error with the squared threshold);
 //   * hypotheses are consumed in order h=0,1,..; a hypothesis replaces the best only with strictly
 //     more inliers; the iteration cap is updated with OpenCV's RANSACUpdateNumIters formula;
-//   * the returned pose is an LM refinement of the best model over its inliers; the returned
+//   * the returned pose is an LM refinement (<=20 iterations, same stop) of the best model over its inliers; the returned
 //     inlier list is the best hypothesis' inlier set (ascending), as OpenCV returns the RANSAC mask.
 #include <algorithm>
 #include <cfloat>
@@ -24,6 +25,7 @@
 
 namespace {
 const uint64_t kSeed = 0x5EED0A5ull, kStride = 0xD1B54A32D192ED03ull;
+const double kRelStep2 = 1.4210854715202004e-14;  // FLT_EPSILON^2 = 2^-46, exact
 inline uint64_t splitmix(uint64_t& s) {
   uint64_t z = (s += 0x9E3779B97F4A7C15ull);
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -156,12 +158,17 @@ Pose lm_solve(Pose P, const float* xyz, const float* xy, const int* idx, int m, 
     const Pose N = retract(P, d);
     const double c2 = accumulate(N, xyz, xy, idx, m, f, cx, cy, nullptr, nullptr);
     if (c2 < cost) {
+      // CvLevMarq's stop (TermCriteria(MAX_ITER + EPS, 20, FLT_EPSILON) in solvePnP's iterative solver): relative L2 norm
+      // of the parameter change below FLT_EPSILON, measured against the pose BEFORE the step; parameters here are the
+      // translation and twice the quaternion's vector part (the rotation vector to first order)
+      const double x2 = ((P.t[0] * P.t[0] + P.t[1] * P.t[1]) + P.t[2] * P.t[2]) +
+                        4.0 * ((P.q[1] * P.q[1] + P.q[2] * P.q[2]) + P.q[3] * P.q[3]);
       P = N;
       lambda *= 0.1;
       if (lambda < 1e-9) lambda = 1e-9;
       const double step2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
       cost = accumulate(P, xyz, xy, idx, m, f, cx, cy, H, g);
-      if (step2 < 1e-20) break;
+      if (step2 < 1e-20 || step2 <= kRelStep2 * x2) break;
     } else {
       lambda *= 10;
       if (lambda > 1e6) break;

@@ -159,6 +159,9 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
     if (c2 < cost) {
       const double* d = S.d;
       const double step2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+      // CvLevMarq's stop: relative parameter change below FLT_EPSILON, against the pose before the step (oracle/ora_pnp.cpp)
+      const double x2 = ((S.cur.t[0] * S.cur.t[0] + S.cur.t[1] * S.cur.t[1]) + S.cur.t[2] * S.cur.t[2]) +
+                        4.0 * ((S.cur.q[1] * S.cur.q[1] + S.cur.q[2] * S.cur.q[2]) + S.cur.q[3] * S.cur.q[3]);
       __syncthreads();
       if (threadIdx.x == 0) S.cur = S.cand;
       if (threadIdx.x < 36) S.H[threadIdx.x] = S.Hc[threadIdx.x];
@@ -167,7 +170,7 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
       lambda *= 0.1;
       if (lambda < 1e-9) lambda = 1e-9;
       cost = c2;
-      if (step2 < 1e-20) break;
+      if (step2 < 1e-20 || step2 <= 1.4210854715202004e-14 * x2) break;  // FLT_EPSILON^2 = 2^-46
     } else {
       lambda *= 10;
       if (lambda > 1e6) break;
