@@ -947,6 +947,11 @@ struct ResArgs {
   const unsigned* hdr;    // pinned
   unsigned* post;         // device: sequence number of the command every workgroup may read
   unsigned first_seq;     // sequence number of this solve's first command
+  const void* arena_src;  // pinned problem image to fetch before the first command (null: already on the device)
+  void* arena_dst;
+  size_t arena_bytes;
+  unsigned* copied;       // device counter of workgroups that finished their share of the fetch (monotone)
+  unsigned copied_target;
   double* export_points;  // pinned: where the exit command delivers the solved landmarks (null: no delivery)
   double* points_a;       // the two landmark buffers; header word 5 says which one is current
   double* points_b;
@@ -961,13 +966,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   __builtin_amdgcn_s_setprio(3);
   P.step_in = ra.dev_cmd + 16;
+  if (ra.arena_src) {
+    // the problem image: fetched from pinned memory by all workgroups (16 bytes per thread and step, consecutive lanes =
+    // consecutive addresses), written through; workgroup 0 posts the first command only when every piece has arrived
+    const double* src = reinterpret_cast<const double*>(ra.arena_src);
+    double* dst = reinterpret_cast<double*>(ra.arena_dst);
+    const size_t n16 = ra.arena_bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n16; i += (size_t)gridDim.x * blockDim.x)
+      slot_store2<true>(dst + 2 * i, src[2 * i], src[2 * i + 1]);
+    stores_acknowledged();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(ra.copied, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   for (unsigned seq = ra.first_seq;; ++seq) {
     if (blockIdx.x == 0) {
       // the only reader of host memory: wait for the command, copy it to device memory (write-through), post it
       if (tid == 0) {
         int alive = 1;
         unsigned spins = 0;
-        while (__hip_atomic_load(ra.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+        if (ra.arena_src && seq == ra.first_seq && !wait_until(ra.copied, ra.copied_target, true)) alive = 0;
+        while (alive && __hip_atomic_load(ra.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
           if (++spins > (1u << 22)) { alive = 0; break; }  // ~seconds without a command: the host is gone
         }
         sAlive = alive;
@@ -1388,7 +1406,8 @@ struct svo_ba {
   int res_blocks = 0;            // admitted workgroups of the resident kernel
   bool res_export = false;       // the exit command delivers the landmarks into the pinned image
   bool host_points_valid = false;  // ... and did: h_arena + arena_pts_off holds the solved landmarks
-  size_t arena_pts_off = 0;
+  size_t arena_pts_off = 0, arena_bytes = 0;
+  bool arena_dirty = false;      // h_arena holds a problem image that is not on the device yet
   double* h_out_points = nullptr;  // pinned, GPU-written only
   FusedAdmission res_admission;  // the resident kernel's workgroups, admitted for the duration of a solve
   double* h_pay = nullptr;
@@ -1408,7 +1427,7 @@ struct svo_ba {
   std::vector<int32_t> u_lm_start, u_chunks, u_pair_base, u_pair_pos, u_obs_pos, u_ls, u_cnt, u_fill;  // scratch of ba_upload
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0, arrived_total = 0, post_seq = 0; int seq = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0, arrived_total = 0, post_seq = 0, copied_total = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
@@ -1740,11 +1759,23 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
   d.poses = (double*)(D + o_p0);
   d.cand_poses = (double*)(D + o_p1);
-  SVO_HIP_CHECK(ctx, hipMemcpyAsync(D, h, total, hipMemcpyHostToDevice, st));
+  // the image goes up when the solve knows how: fetched by the resident LM kernel itself (no blit, no extra launch in front
+  // of it), or by one H2D copy (ba_flush_arena)
+  ba->arena_bytes = (total + 15) & ~(size_t)15;
+  ba->arena_dirty = true;
   if (d.det && has_empty_landmark && npts) {
     SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
     SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV2, 0, sizeof(double) * 4 * npts, st));
   }
+  return SVO_OK;
+}
+
+// The problem image -> device by one H2D copy on the adjuster's stream (every path but the resident kernel's).
+static int ba_flush_arena(svo_ba* ba) {
+  if (!ba->arena_dirty) return SVO_OK;
+  svo_ctx* ctx = ba->ctx;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_arena, ba->h_arena, ba->arena_bytes, hipMemcpyHostToDevice, ba->stream));
+  ba->arena_dirty = false;
   // no wait here: the pinned staging image is next touched by the host after the solve that follows has
   // drained this stream (ba_lm)
   ba->upload_pending = true;
@@ -1966,10 +1997,15 @@ bool ba_resident_begin(svo_ba* ba) {
   ra.hdr = ba->h_hdr; ra.post = ba->d_arrive + 11; ra.first_seq = ba->res_seq + 1;
   ra.points_a = ba->cur_points; ra.points_b = ba->cand_points;
   ra.export_points = ba->n_points ? ba->h_out_points : nullptr;
+  ra.arena_src = ba->arena_dirty ? ba->h_arena : nullptr; ra.arena_dst = ba->d_arena; ra.arena_bytes = ba->arena_bytes;
+  ra.copied = ba->d_arrive + 12;
+  if (ba->arena_dirty) ba->copied_total += (unsigned)grid;
+  ra.copied_target = ba->copied_total;
   ba->res_export = ra.export_points != nullptr;
   hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream, d, ra, ba->h_list_begin[nd - 1],
                      ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba_iter_sync(ba));
-  if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
+  if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); if (ra.arena_src) ba->copied_total -= (unsigned)grid; return false; }
+  ba->arena_dirty = false;  // the kernel fetches it; the first completion word says it has
   ba->resident = true;
   return true;
 }
@@ -2191,7 +2227,10 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
-  ba_resident_begin(ba);  // window-sized, single rank, deterministic, wanted and admitted: the passes become commands
+  if (!ba_resident_begin(ba)) {  // window-sized, single rank, deterministic, wanted and admitted: the passes become commands
+    const int rcf = ba_flush_arena(ba);
+    if (rcf) return rcf;
+  }
   const int rc = svo_lm_solve(d.K, ba->h_poses.data(), &ops, &ba->opt, sum, &ba->stats);
   ba_resident_end(ba, rc == SVO_OK);  // on every path: a resident kernel must never be left waiting for a host that has moved on
   ba->n_spec += ba->stats.speculations; ba->n_hit += ba->stats.speculation_hits;
@@ -2233,6 +2272,9 @@ extern "C" int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3) 
     const std::vector<int32_t>& lm = ba->u_lm_start;
     for (int j = 0; j < ba->n_points && (size_t)j + 1 < lm.size(); ++j)
       if (lm[j + 1] == lm[j]) { points3[3 * j] = in[3 * j]; points3[3 * j + 1] = in[3 * j + 1]; points3[3 * j + 2] = in[3 * j + 2]; }
+  } else if (points3 && ba->n_points && ba->arena_dirty) {
+    // loaded, never solved: the image is still on the host
+    memcpy(points3, ba->h_arena + ba->arena_pts_off, sizeof(double) * 3 * (size_t)ba->n_points);
   } else if (points3 && ba->n_points) {
     // through the pinned arena (idle once the solve has finished): the runtime's pageable path would stage and wait
     const size_t bytes = sizeof(double) * 3 * (size_t)ba->n_points;
