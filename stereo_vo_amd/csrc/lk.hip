@@ -99,12 +99,14 @@ __device__ __forceinline__ float wave_sum_f32(int v) {
 #define SVO_LK_THREADS 64
 #endif
 // Threads per feature.  64 (default): ONE wavefront owns a feature — 7 window pixels per lane, all sums by DPP, no
-// workgroup barrier anywhere (LDS traffic of a single wave is ordered; a wave-level fence replaces s_barrier), four
-// features per 256-thread workgroup.  256 / 128: the wavefronts of a workgroup share one feature and meet at a barrier
+// workgroup barrier anywhere (LDS traffic of a single wave is ordered; a wave-level fence replaces s_barrier), one
+// feature per 64-thread workgroup.  256 / 128: the wavefronts of a workgroup share one feature and meet at a barrier
 // per iteration (measured on MI355X: 247 us per 731-feature launch with 256).
 constexpr int LKT = SVO_LK_THREADS;
 constexpr int NW = LKT / 64;
-constexpr int FPB = 256 / LKT;   // features per workgroup
+constexpr int FPB = LKT == 64 ? 1 : 256 / LKT;   // features per workgroup.  One: the dispatcher then places single waves, which it balances
+                                               // over the SIMDs better than 4-wave workgroups when other streams' kernels share the GPU
+                                               // (lk_fb under 8 streams: 238 -> 217 us per launch, +2 % frames/s; alone no difference)
 constexpr int PPT = (21 * 21 + LKT - 1) / LKT;  // window pixels per thread
 static_assert(LKT == 64 || LKT == 128 || LKT == 256, "threads per feature");
 static_assert(PPT * 8 * 33292800ll < 2147483647ll, "half-row sums must stay exact in int32");
