@@ -2002,7 +2002,8 @@ bool ba_resident_begin(svo_ba* ba) {
   if (ba->arena_dirty) ba->copied_total += (unsigned)grid;
   ra.copied_target = ba->copied_total;
   ba->res_export = ra.export_points != nullptr;
-  hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream,  // 64-thread workgroups: -4 % at 8 streams (the second wave halves the reductions' rounds) d, ra, ba->h_list_begin[nd - 1],
+  // 128 threads: the second wave halves the rounds of the reductions (64-thread workgroups: -4 % at 8 streams)
+  hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream, d, ra, ba->h_list_begin[nd - 1],
                      ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba_iter_sync(ba));
   if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); if (ra.arena_src) ba->copied_total -= (unsigned)grid; return false; }
   ba->arena_dirty = false;  // the kernel fetches it; the first completion word says it has
