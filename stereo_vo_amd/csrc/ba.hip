@@ -1404,6 +1404,7 @@ struct svo_ba {
   unsigned res_seq = 0;          // last command sequence number
   bool res_sel = false;          // which landmark buffer is current (toggles with every accepted step)
   int res_blocks = 0;            // admitted workgroups of the resident kernel
+  bool res_aborted = false;      // the last resident kernel may have left its abort mark behind
   bool res_export = false;       // the exit command delivers the landmarks into the pinned image
   bool host_points_valid = false;  // ... and did: h_arena + arena_pts_off holds the solved landmarks
   size_t arena_pts_off = 0, arena_bytes = 0;
@@ -1992,6 +1993,10 @@ bool ba_resident_begin(svo_ba* ba) {
   d.pay2_out = ba->h_pay; d.pay1_out = ba->h_pay + PAY2_SLOTS;
   d.flag = ba->h_flag; d.arrive = ba->d_arrive;
   ba->res_sel = false;
+  if (ba->res_aborted) {  // a kernel that gave up left its abort mark in the post word: clear it before anybody waits on it again
+    (void)hipMemsetAsync(ba->d_arrive + 11, 0, sizeof(unsigned), ba->stream);
+    ba->res_aborted = false;
+  }
   ResArgs ra;
   ra.dev_cmd = ba->d_cmd; ra.cmd_doubles = 16 + (d.n > 0 ? d.n : 1) + 14 * d.K;
   ra.hdr = ba->h_hdr; ra.post = ba->d_arrive + 11; ra.first_seq = ba->res_seq + 1;
@@ -2023,6 +2028,7 @@ void ba_resident_end(svo_ba* ba, bool ok) {
   }
   ba_resident_command(ba, RES_OP_EXIT, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
   ba->resident = false;
+  if (!ok) ba->res_aborted = true;  // the kernel may have timed out on its own
   if (!ba->host_points_valid) (void)hipStreamSynchronize(ba->stream);  // the kernel has left: its workgroups no longer count
   ba_resident_admission(ba)->release();
 }

@@ -243,3 +243,22 @@ def test_hip_sharded_callback_equals_unsharded(ctx):
     assert np.array_equal(res[0][1][0], res[1][1][0])  # identical poses on both "ranks"
     ref.close()
     [c.close() for c in ctxs]
+
+
+@pytest.mark.gpu
+def test_hip_ba_read_before_solve_returns_the_loaded_problem(ctx):
+    """The problem image goes to the device only when a solve knows how (fetched by the resident kernel, or one H2D copy):
+    reading a problem that was loaded but never solved must hand back exactly what was loaded, and a solve afterwards
+    must still see it."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(21, 5, 300)
+    ba = S.api.BA(ctx, 5, BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0)
+    ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    poses, pts = ba.read_problem()
+    assert np.array_equal(poses, p["poses0"]) and np.array_equal(pts, p["points0"])
+    s = ba.solve_problem()
+    po, pto, so = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=2)
+    assert s.iterations == so["iterations"]
+    poses, pts = ba.read_problem()
+    assert np.allclose(pts, pto, rtol=1e-6, atol=1e-5)
+    ba.close()
