@@ -14,13 +14,21 @@
 //           -> payload2 = [cost_new | model-change(points) | sum dp^2 | sum p^2].
 // One exchange per LM iteration (host/lm.cpp): pass B of iteration i and pass A of iteration i+1 (at the candidate,
 // with the radius an accepted step produces) run back to back and their payloads leave together:
-//   deterministic mode (window-sized problems, everything the pipeline solves): ONE kernel does both passes
-//     (ba_step_kernel: the candidate landmark never leaves the registers of its wave) and writes per-pair 6x6 blocks,
-//     per-observation vectors and per-landmark scalars to DESTINATION-ORDERED contribution slots; ONE reduce kernel
-//     (ba_reduce_kernel) sums every destination in the DECLARED order "28 consecutive segments of ceil(len/28) entries
-//     summed sequentially, then the 28 segment sums added sequentially" (lane = (segment, element)), writes
-//     [payload2 | payload1] straight into pinned host memory and publishes a completion word the host polls:
-//     2 launches, 1 host round trip, no copy kernel, no stream wait per LM iteration.  The oracle performs the same
+//   deterministic mode (window-sized problems, everything the pipeline solves): the passes write per-pair 6x6 blocks,
+//     per-observation vectors and per-landmark scalars to DESTINATION-ORDERED contribution slots, and every destination is
+//     summed in the DECLARED order "28 consecutive segments of ceil(len/28) entries summed sequentially, then the 28
+//     segment sums added sequentially" (lane = (segment, element)); [payload2 | decision | payload1] goes straight into
+//     pinned host memory behind a completion word the host polls: 1 host round trip, no copy kernel, no stream wait per
+//     LM iteration.  Three forms of the same arithmetic, chosen per solve:
+//       alone on the GPU      3 launches  ba_step_kernel -> ba_decide_linearize_kernel -> ba_reduce_kernel
+//       several stereo streams, kernel admitted
+//                             0 launches  ba_resident_kernel: one launch per SOLVE, the iterations are commands in pinned
+//                                         memory (a launch -> completion round trip costs 40 us with 16+ active hardware
+//                                         queues, a command to a resident kernel 3 us)
+//       several streams, not admitted / SVO_BA_RESIDENT=0
+//                             1 launch    ba_iterate_kernel (workgroups meet at device-wide arrivals)
+//     No cache maintenance instruction (buffer_wbl2 / buffer_inv) inside any of them: payload and slots that cross
+//     workgroups are written through and read at the coherence point.  The oracle performs the same
 //     sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is bit-identical
 //     between CPU and GPU and independent of grid size.  (Needed because the reference's problem has a scale gauge:
 //     with one fixed pose and only reprojection factors the iterates slide along a flat direction and amplify any
