@@ -2037,7 +2037,10 @@ void ba_resident_end(svo_ba* ba, bool ok) {
   ba_resident_command(ba, RES_OP_EXIT, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
   ba->resident = false;
   if (!ok) ba->res_aborted = true;  // the kernel may have timed out on its own
-  if (!ba->host_points_valid) (void)hipStreamSynchronize(ba->stream);  // the kernel has left: its workgroups no longer count
+  // the kernel has left: its workgroups no longer count.  A CU-masked stream is drained every time: a masked stream that
+  // never met a synchronisation point did not come back from hipStreamSynchronize at teardown (observed on the stereo
+  // stream when its per-batch wait was replaced by a completion word).
+  if (!ba->host_points_valid || g_ba_cu_share != 32) (void)hipStreamSynchronize(ba->stream);
   ba_resident_admission(ba)->release();
 }
 

@@ -103,7 +103,8 @@ def test_hip_pipeline_degenerate_frames(ctx):
 @pytest.mark.parametrize("env", [{"SVO_BA_CU_SHARE": "8"}, {"SVO_BA_NO_POLL": "1"}, {"SVO_LM_NO_SPECULATION": "1"},
                                  {"SVO_BA_FUSED_REDUCE": "1", "SVO_BA_RESIDENT": "0"}, {"SVO_BA_FUSED_REDUCE": "0", "SVO_SPIN": "50"},
                                  {"SVO_BA_FUSED_REDUCE": "1", "SVO_BA_RESIDENT": "0", "SVO_BA_CU_SHARE": "4"},
-                                 {"SVO_BA_RESIDENT": "1"}, {"SVO_BA_RESIDENT": "1", "SVO_BA_CU_SHARE": "4"}])
+                                 {"SVO_BA_RESIDENT": "1"}, {"SVO_BA_RESIDENT": "1", "SVO_BA_CU_SHARE": "4"},
+                                 {"SVO_BA_RESIDENT": "1", "SVO_BA_CU_SHARE": "24"}])
 def test_hip_pipeline_optional_paths_keep_parity(env):
     """Deployment knobs must not change results: CU-partitioned streams, the stream-wait (non-polling) host loop, the
     LM loop without chained / same-sweep linearisation (two host round trips per iteration), the whole LM iteration
