@@ -295,6 +295,9 @@ int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary);
  * Declared operation order (see host/linalg.cpp): bit-identical to the plain left-looking loop.
  * Returns SVO_ERR_NUMERIC when A is not positive definite. */
 int svo_cholesky_solve(double* A, double* b, int n);
+/* The same solve by ONE workgroup on the GPU (csrc/lm_device.h): what the controller workgroup of the device-resident
+ * solve runs between two passes, exposed for parity tests — bit-identical to svo_cholesky_solve.  Host pointers. */
+int svo_cholesky_solve_dev(svo_ctx* ctx, double* A, double* b, int n);
 /* pose of window slot k (0 = oldest, -1 = newest). */
 int svo_ba_get_pose(svo_ba* ba, int k, double* pose7);
 int svo_ba_window_count(svo_ba* ba);

@@ -164,7 +164,7 @@ SYMBOLS = [
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
-    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve", "svo_draw_track", "svo_pipeline_draw_track",
+    "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve", "svo_cholesky_solve_dev", "svo_draw_track", "svo_pipeline_draw_track",
 ]
 
 
@@ -258,6 +258,13 @@ class Context:
 
     def sync(self):
         self._chk(self.L.svo_sync(self.h), "svo_sync")
+
+    def cholesky_solve_dev(self, A, b):
+        """svo_cholesky_solve_dev on copies (the device-side solve of the LM controller workgroup)."""
+        A = np.array(A, np.float64, order="C")
+        b = np.array(b, np.float64)
+        self._chk(self.L.svo_cholesky_solve_dev(self.h, _p(A), _p(b), b.shape[0]), "svo_cholesky_solve_dev")
+        return b
 
     def profile_select(self, kernel):
         self._chk(self.L.svo_profile_select(self.h, kernel.encode() if kernel else None), "svo_profile_select")

@@ -53,6 +53,7 @@
 
 #include "kernels.h"
 #include "lm_decide.h"
+#include "lm_device.h"
 #include "ref_constants.h"
 #include "reproj_device.h"
 
@@ -112,6 +113,7 @@ struct BaDev {
   unsigned arrive_target = 0;
   int seq = 0;
   double* ctl_dev = nullptr;    // device [accept (0/1) | next radius]: the chained decision, read by the next pass A
+  int pay_dev = 0;              // the payload stays on the device and is read by other workgroups of THIS launch (ba_lm_kernel): agent-scope write-through, the slots' protocol
 };
 
 // Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
@@ -141,6 +143,11 @@ __device__ __forceinline__ double slot_load(const double* p) { return __hip_atom
 // A payload word on its way to the host (or to the all-reduce buffer): a relaxed system-scope store is written through every
 // cache level, so that `s_waitcnt vmcnt(0)` means "it has arrived" without any cache maintenance (see reduce_publish).
 __device__ __forceinline__ void pay_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// ... or on its way to the other workgroups of the same launch (P.pay_dev): the slots' protocol (sc1 write-through, read at the coherence point)
+__device__ __forceinline__ void pay_store(const BaDev& P, double* p, double v) {
+  if (P.pay_dev) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // The decision for the summed payload2 -> ctl_dev (for the pass-A launch queued behind) and payload slots 4 / 5 (for the host).
 __device__ __forceinline__ void decide_device(const LmCtl& c, double cost_new, double mc_points, double* ctl_dev, double* pay2buf) {
@@ -533,7 +540,8 @@ template <bool RES = false>
 __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
   const int nn = P.n > 0 ? P.n : 1, tot = nn + (RES ? 14 : 7) * P.K;
   if (RES) {
-    for (int i = threadIdx.x; i < tot; i += blockDim.x) sStep[i] = slot_load(&P.step_in[i]);  // the device copy workgroup 0 made of the host's block
+    if (P.step_in)  // null: the step control of ba_lm_kernel built the block in place
+      for (int i = threadIdx.x; i < tot; i += blockDim.x) sStep[i] = slot_load(&P.step_in[i]);  // the device copy workgroup 0 made of the host's block
     __syncthreads();
     return;
   }
@@ -717,6 +725,32 @@ struct ListArgs { int n; int begin[48], end[48]; };  // destination lists of win
 // 28-term final sum stays inside one workgroup, so the declared order is untouched.
 constexpr int RED_SLICE = 9;
 __host__ __device__ inline int ba_reduce_blocks(int F) { return 4 * (F * (F + 1) / 2) + 2 * F + 1; }
+// Payload that stays on the device for the other workgroups of the SAME launch (ba_lm_kernel) is staged slice by slice,
+// each slice in its own 128-byte line: writers on different XCDs never share a cache line.  Measured on MI355X with the
+// slices packed into the logical payload1 layout (72-byte slices, two or three writers per line): under load, readers
+// saw earlier versions of whole slices — and of words nobody had written for several solves — although every store had
+// been acknowledged before the arrival counter moved; partial-line write-through from two L2s does not merge reliably.
+constexpr int PAY_STAGE_STRIDE = 16;
+// logical payload1 index of element t of slice b (-1: t is beyond the slice's width)
+__device__ __forceinline__ int pay_stage_index(int b, int t, int F, int n) {
+  const int nU = F * (F + 1) / 2;
+  if (b < 4 * nU) {
+    if (t >= RED_SLICE) return -1;
+    const int d = b >> 2, el = RED_SLICE * (b & 3) + t;
+    int ka = 0, rest = d;
+    while (rest >= F - ka) { rest -= F - ka; ++ka; }
+    const int kb = ka + rest;
+    return (6 * ka + el / 6) * n + 6 * kb + el % 6;
+  }
+  if (b < 4 * nU + 2 * F) {
+    if (t >= RED_SLICE) return -1;
+    const int k = (b - 4 * nU) >> 1, el = RED_SLICE * ((b - 4 * nU) & 1) + t;
+    if (el < 6) return n * n + n + 6 * k + el;            // g_c
+    if (el < 12) return n * n + 6 * k + (el - 6);         // g_red (the -Y g_p part)
+    return n * n + 2 * n + 6 * k + (el - 12);             // diag U
+  }
+  return t < 2 ? n * n + 3 * n + t : -1;
+}
 
 // One slice of payload1: destination d, elements [e_lo, e_lo + width).  Any workgroup size; ends with a barrier.
 template <bool SAME_LAUNCH>  // the slots were written by this very launch (fused): read them at the coherence point
@@ -753,18 +787,21 @@ __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la,
     for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
     double* out = P.pay1_out;
     const int el = e_lo + tid;  // element of the destination
-    if (d < nU) {
+    if (P.pay_dev) {
+      // payload for the other workgroups of this launch: every slice owns one 128-byte line (see PAY_STAGE_STRIDE)
+      __hip_atomic_store(&out[PAY_STAGE_STRIDE * b + tid], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (d < nU) {
       int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
       while (rest >= F - ka) { rest -= F - ka; ++ka; }
       const int kb = ka + rest;
-      pay_store(&out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6], acc);
+      pay_store(P, &out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6], acc);
     } else if (d < nU + F) {
       const int k = d - nU;
-      if (el < 6) pay_store(&out[(size_t)n * n + n + 6 * k + el], acc);                 // g_c
-      else if (el < 12) pay_store(&out[(size_t)n * n + 6 * k + (el - 6)], acc);         // g_red (the -Y g_p part)
-      else pay_store(&out[(size_t)n * n + 2 * n + 6 * k + (el - 12)], acc);             // diag U
+      if (el < 6) pay_store(P, &out[(size_t)n * n + n + 6 * k + el], acc);                 // g_c
+      else if (el < 12) pay_store(P, &out[(size_t)n * n + 6 * k + (el - 6)], acc);         // g_red (the -Y g_p part)
+      else pay_store(P, &out[(size_t)n * n + 2 * n + 6 * k + (el - 12)], acc);             // diag U
     } else {
-      pay_store(&out[(size_t)n * n + 3 * n + el], acc);
+      pay_store(P, &out[(size_t)n * n + 3 * n + el], acc);
     }
   }
   __syncthreads();
@@ -880,7 +917,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
       if (sh.sLast) {
         reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
         const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
-        if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
+        if (tid < 6) pay_store(P, &P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
         if (tid == 0) {
           __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -918,7 +955,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
   if (!sh.sGo) return;
   if (sums2) {
     reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-    if (tid < 4) pay_store(&P.pay2_out[tid], sh.sOut[tid]);
+    if (tid < 4) pay_store(P, &P.pay2_out[tid], sh.sOut[tid]);
   }
   for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
   reduce_publish(P);
@@ -1087,6 +1124,445 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     __syncthreads();  // the shared header is rewritten at the top of the loop
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The WHOLE solve as one launch: ba_lm_kernel.  The resident kernel above still has the host in every LM iteration
+// (Cholesky of the reduced camera system + Ceres' step control: 13 us of PCIe turnaround for 1.3-4.4 us of arithmetic,
+// and one host thread per stereo stream).  Here the step control runs on the device, REPLICATED: when the reduction of
+// an iteration is complete (one device-wide arrival counter), every workgroup reads the summed payload at the coherence
+// point and runs host/lm.cpp's step control itself — the SAME functions (host/lm_math.h, host/lm_decide.h; the Cholesky
+// of csrc/lm_device.h applies host/linalg.cpp's operations in its order), hence the same bits and the same decision in
+// every workgroup — and goes straight on to its share of the next pass.  No command block, no post / poll hop, no
+// controller to wait for: an iteration is pass B -> arrival (the last workgroup forms payload2, decides, posts) ->
+// pass A -> arrival -> reduction slices -> arrival -> step control.  The host launches, and later finds poses,
+// landmarks, summary and ONE completion word in pinned memory.  Bit-identical to the host-driven loop
+// (tests/test_ba.py, tests/test_pipeline.py): every deciding operation is the same IEEE operation wherever it runs.
+// Steps always take the chained form; the same-sweep prediction only saved a collective / a host round trip.
+// The wall-clock cap of src/bundle_adjuster.cpp:11 cannot be evaluated consistently by replicated controllers:
+// solves with a cap below LM_DEVICE_MIN_TIME_CAP_S stay on the host-driven paths, larger caps (the reference's 0.1 s is
+// 30x the longest 50-iteration window solve) can never fire and are ignored.
+struct LmDevOpt { int max_iterations; double function_tolerance, gradient_tolerance, parameter_tolerance, initial_radius; };
+struct LmDevArgs {
+  unsigned* cnt;            // device counter block (LMC_*): all zero at entry, zeroed again by the last workgroup to leave
+  const void* arena_src;    // pinned problem image to fetch first (null: already on the device)
+  void* arena_dst;
+  size_t arena_bytes;
+  double* points_a;         // the two landmark buffers (current / candidate, swapped by every accepted step)
+  double* points_b;
+  double* export_points;    // pinned: the solved landmarks, by landmark index (null: none)
+  double* dev_pay;          // device [payload2 (PAY2_SLOTS) | payload1] of the running iteration
+  double* host_result;      // pinned: [LMR_* summary (16 doubles) | poses 7 K]
+  int* host_flag;           // pinned completion word of the solve
+  int host_seq;
+  LmDevOpt opt;
+  unsigned* dbg;            // per workgroup 8 words: its last command (diagnostics of a solve that gave up; null: none)
+};
+constexpr double LM_DEVICE_MIN_TIME_CAP_S = 0.02;
+enum { LMC_ARRIVE = 0, LMC_DONE = 1, LMC_ARRIVED = 2, LMC_POSTED = 3, LMC_COPIED = 4, LMC_EXITED = 5, LMC_CTL = 8, LMC_WORDS = 16 };
+enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
+       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_DOUBLES = 16 };
+enum { LMS_START = 0, LMS_FIRST, LMS_RELIN, LMS_STEP, LMS_ACCEPT_RELIN, LMS_DELIVER };
+enum { LMOP_EXIT = 0, LMOP_LINEARIZE, LMOP_ITERATE, LMOP_DELIVER, LMOP_ABORT };
+
+struct LmDevState {
+  double radius, df, cost, initial_cost, mcc;
+  int iterations, successful, termination, need_linearize, state, sel, chain, first;
+  unsigned arrived_total, post_seq, done_total, arrive_total;
+  int lin_calls, step_calls;
+  int go, act, use_next, accepted, relin;
+  long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: waiting for the reduction, step control, passes
+};
+constexpr double LM_MIN_RADIUS = 1e-32;
+
+// controller workspace (doubles): payload1 image, 4 vectors of n, payload2, term scratch
+static inline size_t ba_lm_ctl_doubles(int n, int K) { return (size_t)n * n + 3 * (size_t)n + 2 + 5 * (size_t)(n > 0 ? n : 1) + 8 + 14 * (size_t)K + 8; }
+
+// payload1 out of its staging (one 128-byte line per reduction slice) into the logical layout in LDS; up to 8 loads per
+// thread are in flight before the first is stored
+__device__ __forceinline__ void lm_fetch_staged(double* cP, const double* stage, int F, int n) {
+  const int count = PAY_STAGE_STRIDE * ba_reduce_blocks(F);
+  for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
+    double v[8];
+    int at[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+      at[u] = i < count ? pay_stage_index(i / PAY_STAGE_STRIDE, i % PAY_STAGE_STRIDE, F, n) : -1;
+      v[u] = at[u] >= 0 ? slot_load(&stage[i]) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (at[u] >= 0) cP[at[u]] = v[u];
+  }
+}
+
+// `count` doubles from device memory (written by other workgroups of this launch) into LDS: all loads of a thread are
+// issued before the first is stored (one memory round trip for up to 8 x blockDim words, then the next batch)
+__device__ __forceinline__ void lm_fetch(double* dst, const double* src, int count) {
+  for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+      v[u] = slot_load(&src[i < count ? i : count - 1]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+      if (i < count) dst[i] = v[u];
+    }
+  }
+}
+
+// Controller turn (every thread of every workgroup; identical inputs -> identical state everywhere): consume the
+// finished pass, run host/lm.cpp's step control up to the next pass.  Leaves the next pass' step block
+// [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
+__device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* sStep) {
+  const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
+  const int grid = (int)gridDim.x, nb = ba_reduce_blocks(K - 1);
+  const int pay1 = n * n + 3 * n + 2;
+  double* cP = cl;             // payload1 image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
+  double* cSc = cP + pay1;     // Jacobi scales of the pose columns
+  double* cDf = cSc + nn;
+  double* cRhs = cDf + nn;
+  double* cCol = cRhs + nn;
+  double* cTerm = cCol + nn;   // nn + 14 K: per-element terms of the sequential sums
+  double* cPay2 = cTerm + nn + 14 * K;  // 8
+  double* cDc = sStep;         // the step block is built in place
+  double* cCand = sStep + nn;
+  double* cPose = cCand + 7 * K;
+  const double* dpay1 = a.dev_pay + PAY_STAGE_STRIDE;  // payload2 owns the first line
+  const LmDevOpt& opt = a.opt;
+  enum { ACT_NONE = 0, ACT_LOOPTOP, ACT_FINISH, ACT_ACCEPT_TAIL, ACT_SOLVE };
+  int act = ACT_NONE;
+  // a command's bookkeeping, as the host keeps it for the resident kernel (op_linearize / op_step / ba_resident_end)
+  auto issue = [&](int op, int chain, int with_pay1) {
+    if (tid == 0) {
+      int publishers = grid;
+      if (op == LMOP_LINEARIZE) publishers = min(grid, nb);
+      else if (op == LMOP_ITERATE) publishers = with_pay1 ? min(grid, nb) : 1;
+      cs.arrive_total += (unsigned)publishers;
+      if (op != LMOP_DELIVER) cs.done_total += (unsigned)grid;
+      if (op == LMOP_ITERATE && chain) { cs.arrived_total += (unsigned)P.C; cs.post_seq++; }
+      const long long tn = (long long)wall_clock64();
+      cs.t_ctl += tn - cs.t_mark; cs.t_mark = tn;
+    }
+    __syncthreads();
+    return op;
+  };
+
+  const int st = cs.state;  // stable: written before the barrier that ended the previous turn
+  if (st == LMS_START) {
+    if (tid == 0) {
+      cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, gridDim.x, true) : 1;
+      cs.radius = opt.initial_radius; cs.df = 2.0; cs.cost = 0.0; cs.initial_cost = 0.0; cs.mcc = 0.0;
+      cs.t0 = cs.t_mark = (long long)wall_clock64();
+      cs.iterations = 0; cs.successful = 0; cs.termination = 1; cs.need_linearize = 0; cs.sel = 0; cs.chain = 0;
+      cs.arrived_total = 0; cs.post_seq = 0; cs.done_total = 0; cs.arrive_total = 0;
+      cs.lin_calls = 1; cs.step_calls = 0;
+      cs.t_wait = cs.t_ctl = cs.t_body = 0;
+      cs.state = LMS_FIRST; cs.first = 1;
+    }
+    __syncthreads();
+    if (!cs.go) return LMOP_ABORT;
+    lm_fetch(cPose, P.poses, 7 * K);
+    return issue(LMOP_LINEARIZE, 0, 1);
+  }
+  if (st == LMS_DELIVER) return LMOP_EXIT;
+
+  if (tid == 0) {  // the pass in flight is complete when all of its publishers have arrived
+    const long long w0 = (long long)wall_clock64();
+    cs.t_body += w0 - cs.t_mark;
+    cs.go = wait_until(a.cnt + LMC_ARRIVE, cs.arrive_total, true);
+    cs.t_mark = (long long)wall_clock64();
+    cs.t_wait += cs.t_mark - w0;
+    cs.first = 0;
+  }
+  __syncthreads();
+  if (!cs.go) return LMOP_ABORT;
+
+  if (st == LMS_STEP) {
+    if (tid < 6) cPay2[tid] = slot_load(&a.dev_pay[tid]);
+    for (int i = tid; i < 7 * K; i += nt) {  // terms of the pose part of |step|^2 and |x|^2 (host/lm.cpp after ops->step)
+      const double dd = cCand[i] - cPose[i];
+      cTerm[i] = dd * dd;
+      cTerm[7 * K + i] = cPose[i] * cPose[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double cost_new = cPay2[0], model_change = cs.mcc + cPay2[1];
+      double step2 = cPay2[2], x2 = cPay2[3];
+      for (int i = 7; i < 7 * K; ++i) { step2 += cTerm[i]; x2 += cTerm[7 * K + i]; }
+      const bool have_next = cs.chain != 0;
+      const bool next_at_cand = cPay2[4] != 0.0;
+      const double next_radius = cPay2[5];
+      int a_ = ACT_LOOPTOP, use = 0, relin = 0;
+      if (!(model_change > 0)) {  // invalid step: no model decrease
+        cs.radius /= cs.df; cs.df *= 2;
+        use = have_next && next_radius > 0 && next_radius == cs.radius && !next_at_cand;
+        cs.need_linearize = !use;
+      } else if (sqrt(step2) <= opt.parameter_tolerance * (sqrt(x2) + opt.parameter_tolerance)) {
+        cs.termination = 0; a_ = ACT_FINISH;
+      } else if (fabs(cs.cost - cost_new) <= opt.function_tolerance * cs.cost) {  // Ceres returns before the step is taken
+        cs.termination = 0; a_ = ACT_FINISH;
+      } else {
+        const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, cs.radius, cs.df, cost_new, cPay2[1]);
+        if (dec.accept) {
+          cs.sel ^= 1;  // the candidate becomes the current point (op_accept)
+          cs.cost = cost_new;
+          ++cs.successful;
+          cs.radius = dec.next_radius;
+          cs.df = 2.0;
+          use = have_next && next_radius > 0 && next_radius == cs.radius && next_at_cand;
+          relin = !use;
+          a_ = ACT_ACCEPT_TAIL;
+        } else {
+          cs.radius = dec.next_radius; cs.df *= 2;
+          use = have_next && next_radius > 0 && next_radius == cs.radius && !next_at_cand;
+          cs.need_linearize = !use;
+        }
+      }
+      cs.accepted = a_ == ACT_ACCEPT_TAIL;
+      cs.act = a_; cs.use_next = use; cs.relin = relin;
+    }
+    __syncthreads();
+    if (cs.accepted) for (int i = tid; i < 7 * K; i += nt) cPose[i] = cCand[i];
+    if (cs.use_next) lm_fetch_staged(cP, dpay1, K - 1, n);
+    act = cs.act;
+    const bool relin = act == ACT_ACCEPT_TAIL && cs.relin;
+    __syncthreads();  // thread 0 writes cs.act again below
+    if (relin) {  // the chained pass A did not run for this outcome (last iteration): linearise now
+      if (tid == 0) { ++cs.lin_calls; cs.state = LMS_ACCEPT_RELIN; }
+      return issue(LMOP_LINEARIZE, 0, 1);
+    }
+  } else {
+    // a stand-alone pass A has finished: its payload is the linearisation in use
+    lm_fetch_staged(cP, dpay1, K - 1, n);
+    __syncthreads();
+    if (st == LMS_FIRST) {
+      if (tid == 0) { cs.cost = cP[pay1 - 2]; cs.initial_cost = cs.cost; }
+      for (int q = tid; q < n; q += nt) cSc[q] = 1.0 / (1.0 + sqrt(cP[n * n + 2 * n + q]));
+      act = ACT_ACCEPT_TAIL;  // the same gradient test
+    } else if (st == LMS_RELIN) {
+      if (tid == 0) cs.need_linearize = 0;
+      act = ACT_SOLVE;
+    } else {
+      act = ACT_ACCEPT_TAIL;
+    }
+    __syncthreads();
+  }
+
+  for (;;) {  // uniform in the workgroup: every transition is decided by thread 0 and read between two barriers
+    if (act == ACT_ACCEPT_TAIL) {
+      for (int q = tid; q < n; q += nt) { const double g = cP[n * n + n + q]; cTerm[q] = g * g; }
+      __syncthreads();
+      if (tid == 0) {  // sqrt(sum g_p^2 + sum g_c^2): the 2-norm of the gradient (host/lm.cpp gradient_norm)
+        double g2 = cP[pay1 - 1];
+        for (int q = 0; q < n; ++q) g2 += cTerm[q];
+        if (sqrt(g2) <= opt.gradient_tolerance) { cs.termination = 0; cs.act = ACT_FINISH; } else cs.act = ACT_LOOPTOP;
+      }
+      __syncthreads();
+      act = cs.act;
+      __syncthreads();
+    }
+    if (act == ACT_LOOPTOP) {
+      if (tid == 0) {
+        int a_ = ACT_SOLVE;
+        if (cs.iterations >= opt.max_iterations) { cs.termination = 1; a_ = ACT_FINISH; }
+        else if (cs.radius <= LM_MIN_RADIUS) { cs.termination = 0; a_ = ACT_FINISH; }
+        else {
+          ++cs.iterations;
+          if (cs.need_linearize) { ++cs.lin_calls; cs.state = LMS_RELIN; a_ = ACT_NONE; }
+        }
+        cs.act = a_;
+      }
+      __syncthreads();
+      act = cs.act;
+      __syncthreads();
+      if (act == ACT_NONE) return issue(LMOP_LINEARIZE, 0, 1);
+    }
+    if (act == ACT_FINISH) {
+      if (tid == 0) cs.state = LMS_DELIVER;
+      if (blockIdx.x == 0) {
+        if (tid == 0) {
+          double* r = a.host_result;
+          pay_store(&r[LMR_ITERATIONS], (double)cs.iterations); pay_store(&r[LMR_SUCCESSFUL], (double)cs.successful);
+          pay_store(&r[LMR_TERMINATION], (double)cs.termination); pay_store(&r[LMR_INITIAL_COST], cs.initial_cost);
+          pay_store(&r[LMR_FINAL_COST], cs.cost); pay_store(&r[LMR_LINEARIZE_CALLS], (double)cs.lin_calls);
+          pay_store(&r[LMR_STEP_CALLS], (double)cs.step_calls); pay_store(&r[LMR_SEL], (double)cs.sel);
+          const long long tn = (long long)wall_clock64();
+          pay_store(&r[LMR_T_WAIT], (double)cs.t_wait); pay_store(&r[LMR_T_CTL], (double)(cs.t_ctl + (tn - cs.t_mark)));
+          pay_store(&r[LMR_T_BODY], (double)cs.t_body); pay_store(&r[LMR_T_TOTAL], (double)(tn - cs.t0));
+        }
+        for (int i = tid; i < 7 * K; i += nt) pay_store(&a.host_result[LMR_DOUBLES + i], cPose[i]);
+      }
+      return issue(LMOP_DELIVER, 0, 0);
+    }
+    // ACT_SOLVE: scaled, damped reduced camera system (host/lm.cpp) -> Cholesky -> pose step
+    const double radius = cs.radius;
+    for (int q = tid; q < n; q += nt) {
+      const double sq = cSc[q];
+      cDf[q] = fmin(fmax(cP[n * n + 2 * n + q] * sq * sq, MIN_DIAG), MAX_DIAG) / radius;
+      cRhs[q] = -(cP[n * n + q] + cP[n * n + n + q]) * sq;
+    }
+    __syncthreads();
+    // lower triangle of S' = S sc_a sc_b (+ Df on the diagonal).  The reduction wrote the upper pose-pair blocks; a lower
+    // block is the exact transpose of its mirror, diagonal blocks are complete.  A lower element of
+    // an off-diagonal block never serves as the SOURCE of another element (sources are upper-block or diagonal-block
+    // words), so the in-place write is race free.
+    for (int r = tid >> 3; r < n; r += nt >> 3) {
+      const double sr = cSc[r];
+      for (int c = tid & 7; c <= r; c += 8) {
+        const double v = (r / 6 > c / 6) ? cP[c * n + r] : cP[r * n + c];
+        double w = v * sr * cSc[c];
+        if (r == c) w += cDf[r];
+        cP[r * n + c] = w;
+      }
+    }
+    __syncthreads();
+    const bool ok = n == 0 || svo_dev_cholesky_solve(cP, cRhs, n, cCol);
+    if (ok) {
+      for (int q = tid; q < n; q += nt) {
+        const double rq = cRhs[q], sq = cSc[q];
+        cDc[q] = rq * sq;
+        cTerm[q] = 0.5 * rq * (cDf[q] * rq - cP[n * n + n + q] * sq);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        double mcc = 0.0;
+        for (int q = 0; q < n; ++q) mcc += cTerm[q];
+        cs.mcc = mcc;
+        cs.chain = cs.iterations < opt.max_iterations ? 1 : 0;  // the last iteration cannot use a new linearisation
+        ++cs.step_calls;
+        cs.state = LMS_STEP;
+      }
+      if (tid < K) {
+        if (tid == 0) for (int q = 0; q < 7; ++q) cCand[q] = cPose[q];
+        else svo_plus_pose(&cPose[7 * tid], &cDc[6 * (tid - 1)], &cCand[7 * tid]);
+      }
+      __syncthreads();
+      const int chain = cs.chain;
+      return issue(LMOP_ITERATE, chain, chain);
+    }
+    // not positive definite: invalid step, linearise again with the reduced radius
+    if (tid == 0) { cs.radius /= cs.df; cs.df *= 2; cs.need_linearize = 1; }
+    __syncthreads();
+    act = ACT_LOOPTOP;
+  }
+}
+
+// Landmarks of one wave chunk -> pinned memory (`out`, by landmark index).  A chunk's landmark indices ascend but need
+// not be dense (landmarks without observations are skipped when chunks are formed): the export covers the SPAN
+// [j0, j_last], staged in LDS and written by consecutive lanes to consecutive addresses (scattered 8-byte system-scope
+// stores go out one PCIe write each); the slots of unobserved landmarks inside the span carry zeros, the host restores
+// those from its own copy.  Spans beyond the staging fall back to per-landmark stores.
+__device__ __forceinline__ void deliver_chunk_points(const ObsRec& R, double* out, double* stage, int stage_doubles) {
+  const int lane = threadIdx.x & 63;
+  const int j0 = __builtin_amdgcn_readfirstlane(R.j);  // lane 0 holds the chunk's first observation
+  int jl = R.active ? R.j : j0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) jl = max(jl, __shfl_xor(jl, off));
+  const int span = jl - j0 + 1;
+  const bool first = R.active && lane == R.first;
+  if (3 * span > stage_doubles) {
+    if (first) { pay_store(&out[3 * (size_t)R.j], R.p.x); pay_store(&out[3 * (size_t)R.j + 1], R.p.y); pay_store(&out[3 * (size_t)R.j + 2], R.p.z); }
+    return;
+  }
+  for (int i = lane; i < 3 * span; i += 64) stage[i] = 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (first) { stage[3 * (R.j - j0)] = R.p.x; stage[3 * (R.j - j0) + 1] = R.p.y; stage[3 * (R.j - j0) + 2] = R.p.z; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  for (int i = lane; i < 3 * span; i += 64) pay_store(&out[3 * (size_t)j0 + i], stage[i]);
+}
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_lm_kernel(BaDev P, LmDevArgs a, int lm_begin, int lm_count, ListArgs la) {
+  extern __shared__ double ctl_lds[];  // the step control's workspace
+  __shared__ double sStep[RES_STEP_LDS_DOUBLES];  // [dc | candidate poses | current poses], built in place by the step control
+  __shared__ IterShared sh;
+  __shared__ LmDevState cs;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __builtin_amdgcn_s_setprio(3);
+  P.step_in = nullptr;  // the step block is already in LDS (stage_step<true> then only synchronises)
+  P.pay2_out = a.dev_pay; P.pay1_out = a.dev_pay + PAY_STAGE_STRIDE; P.pay_dev = 1;
+  P.arrive = a.cnt + LMC_ARRIVE;
+  P.flag = reinterpret_cast<int*>(a.cnt + LMC_CTL + 4);  // a word nobody reads: completion is the arrival counter itself
+  P.seq = 0;
+  P.ctl_dev = reinterpret_cast<double*>(a.cnt + LMC_CTL);
+  if (tid == 0) cs.state = LMS_START;
+  if (a.arena_src) {
+    const double* src = reinterpret_cast<const double*>(a.arena_src);
+    double* dst = reinterpret_cast<double*>(a.arena_dst);
+    const size_t n16 = a.arena_bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n16; i += (size_t)gridDim.x * blockDim.x)
+      slot_store2<true>(dst + 2 * i, src[2 * i], src[2 * i + 1]);
+    stores_acknowledged();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(a.cnt + LMC_COPIED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  bool leave_clean = false;
+  for (;;) {
+    const int op = lm_controller(P, a, cs, ctl_lds, sStep);
+    if (a.dbg && tid == 0) {
+      unsigned* g = a.dbg + 8 * blockIdx.x;
+      g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
+      g[4] = (unsigned)cs.chain; g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
+    }
+    if (op == LMOP_ABORT) return;
+    if (op == LMOP_EXIT) { leave_clean = true; break; }
+    const bool sel = cs.sel != 0;
+    P.points = sel ? a.points_b : a.points_a;
+    P.cand_points = sel ? a.points_a : a.points_b;
+    P.arrive_target = cs.arrive_total;
+    if (op == LMOP_DELIVER) {
+      if (a.export_points && (int)blockIdx.x < P.C && wave == 0) {
+        const ObsRec R = load_obs(P, blockIdx.x, lane, P.points);
+        deliver_chunk_points(R, a.export_points, sStep, RES_STEP_LDS_DOUBLES);  // the step block is no longer needed
+      }
+      P.flag = a.host_flag; P.seq = a.host_seq;
+      reduce_publish(P);
+      __syncthreads();
+      continue;  // the next controller turn answers "delivered": everybody leaves
+    }
+    IterSync sy;
+    sy.arrived = a.cnt + LMC_ARRIVED; sy.arrived_target = cs.arrived_total;
+    sy.posted = a.cnt + LMC_POSTED; sy.post_seq = cs.post_seq;
+    sy.done = a.cnt + LMC_DONE; sy.done_target = cs.done_total;
+    const double radius = cs.radius;
+    if (op == LMOP_ITERATE) {
+      const LmCtl ctl = {cs.cost, cs.mcc, radius, cs.df, cs.chain};
+      iterate_body<true>(P, radius, 0.0, ctl, cs.chain, lm_begin, lm_count, la, sy, sStep, sh);
+    } else {  // pass A alone at the current point, then the reduction
+      const int first = cs.first;
+      if ((int)blockIdx.x < P.C && wave == 0) {
+        const ObsRec R = load_obs(P, blockIdx.x, lane, P.points);
+        double unused0 = 0, unused1 = 0;
+        linearize_chunk<true>(P, R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, first, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+        stores_acknowledged();
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int nb = ba_reduce_blocks(P.K - 1);
+      if ((int)blockIdx.x < nb) {
+        if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
+        __syncthreads();
+        if (!sh.sGo) return;
+        for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
+        reduce_publish(P);
+      }
+    }
+    __syncthreads();
+  }
+  if (leave_clean && tid == 0) {
+    // the counters go back to zero for the next solve on this adjuster (stream order: it starts after this launch has ended)
+    if (__hip_atomic_fetch_add(a.cnt + LMC_EXITED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x)
+      for (int i = 0; i < LMC_CTL; ++i) __hip_atomic_store(a.cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1419,6 +1895,14 @@ struct svo_ba {
   bool arena_dirty = false;      // h_arena holds a problem image that is not on the device yet
   double* h_out_points = nullptr;  // pinned, GPU-written only
   FusedAdmission res_admission;  // the resident kernel's workgroups, admitted for the duration of a solve
+  // device-resident solve (ba_lm_kernel): counter block, pinned result block, state of the launch in flight
+  unsigned* d_lmc = nullptr;
+  double* d_pay_fg = nullptr;    // [payload2 | payload1] of ba_lm_kernel in FINE-GRAINED device memory (see ba_alloc)
+  unsigned* d_lmdbg = nullptr;   // SVO_BA_TRACE: last command of every workgroup of ba_lm_kernel
+  double* h_result = nullptr;    // pinned [LMR_DOUBLES | poses 7 Kmax], inside h_pin
+  bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
+  bool lm_counters_dirty = false;  // the last kernel did not leave through its clean exit: zero the counters before the next launch
+  std::chrono::steady_clock::time_point lm_t0;
   double* h_pay = nullptr;
   // current / candidate buffers of the running solve (swapped on every accepted step)
   double *cur_points = nullptr, *cand_points = nullptr, *cur_poses = nullptr, *cand_poses = nullptr;
@@ -1441,6 +1925,7 @@ struct svo_ba {
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
   // SVO_TIMING accumulators
+  double lm_t_wait = 0, lm_t_ctl = 0, lm_t_body = 0, lm_t_total = 0; long lm_n = 0, lm_iters = 0;
   double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0, t_prep = 0, t_read = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
 };
 
@@ -1456,6 +1941,17 @@ static int ba_alloc(svo_ba* ba) {
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
   A(ba->d_cmd, double, 16 + step_doubles + 7 * (size_t)Kmax);  // the resident kernel's device copy of a command
+  // The payload of the device-resident solve is written by some workgroups and read by ALL workgroups of the same launch,
+  // iteration after iteration at the same addresses.  In ordinary (coarse-grained) device memory that is not coherent
+  // across the eight XCDs' L2s inside a launch: measured on MI355X under load (4+ stereo streams), a workgroup's sc1 loads
+  // returned the PREVIOUS iteration's values for whole 72-byte reduction slices written from other XCDs (lines its own L2
+  // still held), its replicated step control then took a different branch than everybody else's.  Fine-grained memory is
+  // the architected answer: not retained in L2, coherent at agent scope.  (Counters only ever see atomics; the
+  // contribution slots are written and read once per iteration at addresses a workgroup's XCD does not otherwise touch.)
+  SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_pay_fg, sizeof(double) * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)), hipDeviceMallocFinegrained));
+  SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_lmc, sizeof(unsigned) * LMC_WORDS, hipDeviceMallocFinegrained));
+  if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 8 * 4096);
+  SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned)));
   A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
   A(d.obsV, double, 18 * ba->cap_obs);
@@ -1499,7 +1995,7 @@ static int ba_alloc(svo_ba* ba) {
   // pinned block: [completion word 64 B | resident-kernel command header 128 B | step: dc, candidate poses (, current poses) | payload]
   const size_t pin_step_doubles = step_doubles + 7 * (size_t)Kmax;
   // ... | landmarks delivered by the resident kernel (written by the GPU only: the CPU never holds these lines dirty)]
-  ba->pin_bytes = 64 + 128 + sizeof(double) * (pin_step_doubles + PAY2_SLOTS + ba->cap_pay1 + 8 + 3 * ba->cap_points);
+  ba->pin_bytes = 64 + 128 + sizeof(double) * (pin_step_doubles + PAY2_SLOTS + ba->cap_pay1 + 8 + 3 * ba->cap_points + LMR_DOUBLES + 7 * (size_t)Kmax + 8);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocCoherent));  // fine-grained: see reduce_publish
   memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
   ba->h_flag = reinterpret_cast<int*>(ba->h_pin);
@@ -1507,6 +2003,7 @@ static int ba_alloc(svo_ba* ba) {
   ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64 + 128);
   ba->h_pay = ba->h_step + pin_step_doubles;
   ba->h_out_points = ba->h_pay + ((PAY2_SLOTS + ba->cap_pay1 + 7) & ~(size_t)7);
+  ba->h_result = ba->h_out_points + ((3 * ba->cap_points + 7) & ~(size_t)7);
   d.pay2 = ba->d_pay;
   d.pay1 = ba->d_pay + PAY2_SLOTS;
   return SVO_OK;
@@ -1553,8 +2050,12 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
                     "per solve: gather %.1f us, upload %.1f us, upload + LM %.1f us, read-back %.1f us\n", ba->n_solves, 1e3 * ba->t_lin / ba->n_lin, ba->n_lin,
             ba->n_step ? 1e3 * ba->t_step / ba->n_step : 0.0, ba->n_step, ba->n_hit, ba->n_spec, 1e3 * ba->t_prep / std::max(ba->n_solves, 1l),
             1e3 * ba->t_upload / std::max(ba->n_solves, 1l), 1e3 * ba->t_total / std::max(ba->n_solves, 1l), 1e3 * ba->t_read / std::max(ba->n_solves, 1l));
+  if (getenv("SVO_TIMING") && ba->lm_n)
+    fprintf(stderr, "[svo ba] device-resident solves: %ld, %.1f LM iterations each; per solve (workgroup 0, us): total %.1f = waiting for the passes %.1f + step control %.1f "
+                    "+ own share of the passes %.1f\n", ba->lm_n, (double)ba->lm_iters / ba->lm_n, 1e-2 * ba->lm_t_total / ba->lm_n, 1e-2 * ba->lm_t_wait / ba->lm_n,
+            1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n);
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
-  void* ptrs[] = {ba->d_cmd, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
+  void* ptrs[] = {ba->d_pay_fg, ba->d_lmdbg, ba->d_lmc, ba->d_cmd, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1924,6 +2425,7 @@ bool ba_fused_reduce() {
 // budgets of 1/2, 3/4 and 1/1 of the capacity give 6,630 / 6,690 / 6,780 frames/s at 8 streams).  A launch that is not admitted takes the
 // separate-launch path for that iteration — same arithmetic, same results.  (Other PROCESSES on the GPU are not
 // counted; the kernel's bounded spin turns that unlikely pile-up into a reported error, never a hang.)
+int g_fused_per_cu = 0;  // workgroups per CU the budget is counted in
 int ba_fused_budget() {
   static const int budget = [] {
     int per_cu = 0, per_cu_res = 0, cus = 0, dev = 0;
@@ -1931,10 +2433,21 @@ int ba_fused_budget() {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_resident_kernel, 128, 0) != hipSuccess) return 0;
     per_cu = std::min(per_cu, per_cu_res);  // one budget for both kernels whose workgroups wait: the tighter occupancy counts
+    g_fused_per_cu = per_cu;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
   }();
   return budget;
+}
+
+// What `grid` workgroups of ba_lm_kernel with `lds` bytes of step-control workspace cost in the units of that budget: a
+// larger reduced camera system (10-keyframe windows) lowers the kernel's occupancy, its workgroups then count for more.
+int ba_lm_admission_cost(int grid, size_t lds) {
+  (void)ba_fused_budget();
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_lm_kernel, 128, lds) != hipSuccess || per_cu <= 0) return 1 << 30;
+  if (per_cu >= g_fused_per_cu) return grid;
+  return (grid * g_fused_per_cu + per_cu - 1) / per_cu;
 }
 
 // destination lists as kernel arguments when they fit (every window-sized problem: K <= 6 free... F*F + F + 1 <= 48)
@@ -2042,6 +2555,109 @@ void ba_resident_end(svo_ba* ba, bool ok) {
   // stream when its per-batch wait was replaced by a completion word).
   if (!ba->host_points_valid || g_ba_cu_share != 32) (void)hipStreamSynchronize(ba->stream);
   ba_resident_admission(ba)->release();
+}
+
+// ---- device-resident solve (ba_lm_kernel): host side -------------------------------------------------------------
+// SVO_BA_DEVICE_LM=0 / 1 forces; default: on for every window-sized single-rank deterministic solve that is admitted.
+bool ba_device_lm_wanted() {
+  static const char* e = getenv("SVO_BA_DEVICE_LM");
+  if (e && *e) return atoi(e) != 0;
+  return true;
+}
+
+size_t ba_lm_lds_bytes(const BaDev& d) { return sizeof(double) * ba_lm_ctl_doubles(d.n, d.K); }
+
+// Launches the whole solve of the loaded problem; false: not eligible / not admitted (use the host-driven paths).
+bool ba_device_lm_begin(svo_ba* ba) {
+  BaDev& d = ba->d;
+  ba->lm_inflight = false;
+  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !ba_device_lm_wanted()) return false;
+  if (ba->opt.max_time_s > 0 && ba->opt.max_time_s < LM_DEVICE_MIN_TIME_CAP_S) return false;  // see ba_lm_kernel
+  const int nd = (d.K - 1) * d.K / 2 + (d.K - 1) + 1;
+  if ((int)ba->h_list_begin.size() < nd) return false;
+  const size_t lds = ba_lm_lds_bytes(d);
+  if (lds > 96 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
+  const int grid = d.C;  // one workgroup per chunk: they wait for each other, so all of them must be resident
+  if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return false;
+  if (!ba_resident_admission(ba)->admit(ba_lm_admission_cost(grid, lds))) return false;
+  if (ba->lm_counters_dirty) {
+    if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), ba->stream) != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
+    ba->lm_counters_dirty = false;
+  }
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  d.flag = nullptr;
+  LmDevArgs a;
+  a.cnt = ba->d_lmc;
+  a.arena_src = ba->arena_dirty ? ba->h_arena : nullptr; a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;
+  a.points_a = ba->cur_points; a.points_b = ba->cand_points;
+  a.export_points = ba->n_points ? ba->h_out_points : nullptr;
+  a.dev_pay = ba->d_pay_fg;
+  a.host_result = ba->h_result;
+  a.host_flag = ba->h_flag; a.host_seq = ++ba->seq;
+  a.dbg = grid <= 4096 ? ba->d_lmdbg : nullptr;
+  a.opt.max_iterations = ba->opt.max_iterations;
+  a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
+  a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
+  ba->lm_t0 = now();
+  SvoProfScope prof(ba->ctx, SVO_PROF_BA_STEP, ba->stream);
+  hipLaunchKernelGGL(ba_lm_kernel, dim3(grid), dim3(128), lds, ba->stream, d, a, ba->h_list_begin[nd - 1],
+                     ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba));
+  if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
+  ba->arena_dirty = false;  // the kernel fetches it
+  ba->lm_inflight = true;
+  ba->res_export = a.export_points != nullptr;
+  return true;
+}
+
+// Joins the launch: completion word, then poses / summary / counters out of the pinned result block.
+int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
+  if (!ba->lm_inflight) return SVO_ERR_INVALID;
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  ba->lm_inflight = false;
+  const int rc = ba_wait_flag(ba, ba->seq);
+  ba_resident_admission(ba)->release();
+  if (rc) {
+    // a wait inside the kernel gave up (or the launch never ran): drain, and never trust the counters again
+    (void)hipStreamSynchronize(ba->stream);
+    if (getenv("SVO_BA_TRACE")) {  // which meeting was never complete
+      unsigned c[LMC_WORDS] = {0};
+      (void)hipMemcpy(c, ba->d_lmc, sizeof(c), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[svo ba] device solve gave up: grid %d K %d arrive %u done %u arrived %u posted %u copied %u exited %u\n", d.C, d.K,
+              c[LMC_ARRIVE], c[LMC_DONE], c[LMC_ARRIVED], c[LMC_POSTED], c[LMC_COPIED], c[LMC_EXITED]);
+      if (ba->d_lmdbg && d.C <= 4096) {
+        std::vector<unsigned> g(8 * (size_t)d.C);
+        (void)hipMemcpy(g.data(), ba->d_lmdbg, sizeof(unsigned) * g.size(), hipMemcpyDeviceToHost);
+        for (int b = 0; b < d.C; ++b) {
+          const unsigned* q = &g[8 * (size_t)b];
+          if (b == 0 || memcmp(q, &g[0], 20) != 0)
+            fprintf(stderr, "[svo ba]   workgroup %d: op %u state %u iterations %u need_linearize %u chain %u arrive_total %u done_total %u lin_calls %u\n", b, q[0], q[1],
+                    q[2], q[3], q[4], q[5], q[6], q[7]);
+        }
+      }
+    }
+    ba->lm_counters_dirty = true;
+    ba->host_points_valid = false;
+    return rc;
+  }
+  const double* r = ba->h_result;
+  memcpy(ba->h_poses.data(), r + LMR_DOUBLES, sizeof(double) * 7 * (size_t)d.K);
+  if (r[LMR_SEL] != 0.0) { std::swap(ba->cur_points, ba->cand_points); std::swap(ba->cur_poses, ba->cand_poses); }
+  ba->host_points_valid = ba->res_export;
+  memset(&ba->stats, 0, sizeof(ba->stats));
+  ba->stats.linearize_calls = (int)r[LMR_LINEARIZE_CALLS];
+  ba->stats.step_calls = (int)r[LMR_STEP_CALLS];
+  ba->stats.speculations = ba->stats.step_calls;
+  ba->stats.speculation_hits = ba->stats.step_calls - (ba->stats.linearize_calls - 1);
+  ba->lm_t_wait += r[LMR_T_WAIT]; ba->lm_t_ctl += r[LMR_T_CTL]; ba->lm_t_body += r[LMR_T_BODY]; ba->lm_t_total += r[LMR_T_TOTAL]; ba->lm_n++; ba->lm_iters += (long)r[LMR_ITERATIONS];
+  if (sum) {
+    sum->iterations = (int)r[LMR_ITERATIONS]; sum->successful_steps = (int)r[LMR_SUCCESSFUL]; sum->termination = (int)r[LMR_TERMINATION];
+    sum->initial_cost = r[LMR_INITIAL_COST]; sum->final_cost = r[LMR_FINAL_COST];
+    sum->solve_ms = ms_between(ba->lm_t0, now());
+  }
+  if (g_ba_cu_share != 32) SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));  // CU-masked streams are drained every time (see ba_resident_end)
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  return SVO_OK;
 }
 
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
@@ -2245,6 +2861,11 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
+  if (ba_device_lm_begin(ba)) {  // the whole solve is one launch: nothing for the host to do until the completion word
+    const int rcd = ba_device_lm_end(ba, sum);
+    d.flag = nullptr;
+    return rcd;
+  }
   if (!ba_resident_begin(ba)) {  // window-sized, single rank, deterministic, wanted and admitted: the passes become commands
     const int rcf = ba_flush_arena(ba);
     if (rcf) return rcf;

@@ -1,0 +1,91 @@
+// Device side of the LM step control: what host/lm.cpp + host/linalg.cpp do between two passes over the observations,
+// executed inside the solve kernel so that a whole ceres::Solve (reference src/bundle_adjuster.cpp:140) is a single
+// launch with no host round trip per iteration.  Every function applies the host's operations to every element in the
+// host's order (declared arithmetic of host/linalg.cpp: each element receives  a_ij - l_i0 l_j0 - l_i1 l_j1 - ...  one
+// product at a time in ascending k; forward substitution ascending, back substitution descending), so the bits are
+// the host's — checked by tests/test_ba.py::test_hip_device_cholesky_matches_host and by every pipeline parity test.
+#ifndef SVO_LM_DEVICE_H_
+#define SVO_LM_DEVICE_H_
+#include <hip/hip_runtime.h>
+
+#include "lm_math.h"
+
+#if defined(__HIPCC__)
+// value of `v` in lane `k` (k wave-uniform): two scalar reads instead of an LDS permute
+__device__ __forceinline__ double svo_readlane_f64(double v, int k) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+  return __hiloint2double(hi, lo);
+}
+
+// Dense SPD solve in LDS by the calling workgroup (128 threads).  A: n x n row-major, lower triangle read, overwritten by
+// L; b: right-hand side, overwritten by the solution; col: n doubles of scratch.  Right-looking: after column j is
+// final, every trailing element (i, c), j < c <= i, receives  -= l_ij * l_cj  — the same subtraction, in the same
+// ascending-k position of its sequence, as the left-looking loop.  Returns false (in every thread) when a pivot is not
+// positive.  Ends with a barrier.
+__device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, double* col) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tr = tid >> 3, tc = tid & 7, rstep = nt >> 3;  // trailing update: 8 columns x (threads / 8) rows per sweep
+  for (int j = 0; j < n; ++j) {
+    const double s = A[j * n + j];
+    if (!(s > 0)) {  // uniform: every thread reads the same word
+      __syncthreads();
+      return false;
+    }
+    const double l = sqrt(s);
+    for (int i = j + 1 + tid; i < n; i += nt) { const double v = A[i * n + j] / l; col[i] = v; A[i * n + j] = v; }
+    __syncthreads();
+    if (tid == 0) A[j * n + j] = l;  // behind the barrier: the other wavefront may still be reading the pivot
+    for (int i = j + 1 + tr; i < n; i += rstep) {
+      const double li = col[i];
+      for (int c = j + 1 + tc; c <= i; c += 8) A[i * n + c] -= li * col[c];
+    }
+    __syncthreads();
+  }
+  if (tid < 64 && n <= 64) {
+    // substitutions by the first wavefront, lane = row, x in a register; L is final (barrier above), so its loads do not
+    // wait for the running solution
+    const bool in = tid < n;
+    double bi = in ? b[tid] : 0.0;
+    const double di = in ? A[tid * n + tid] : 1.0;
+    for (int k = 0; k < n; ++k) {  // forward: b[i] -= L[i][k] x[k], ascending k
+      const double lik = (in && tid > k) ? A[tid * n + k] : 0.0;
+      const double xk = svo_readlane_f64(bi, k) / svo_readlane_f64(di, k);
+      if (tid == k) bi = xk;
+      else if (in && tid > k) bi -= lik * xk;
+    }
+    for (int k = n - 1; k >= 0; --k) {  // backward: b[i] -= L[k][i] x[k], descending k
+      const double lki = tid < k ? A[k * n + tid] : 0.0;
+      const double xk = svo_readlane_f64(bi, k) / svo_readlane_f64(di, k);
+      if (tid == k) bi = xk;
+      else if (tid < k) bi -= lki * xk;
+    }
+    if (in) b[tid] = bi;
+  } else if (tid < 64) {
+    for (int k = 0; k < n; ++k) {
+      if (tid == 0) b[k] = b[k] / A[k * n + k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double bk = b[k];
+      for (int i = k + 1 + tid; i < n; i += 64) b[i] -= A[i * n + k] * bk;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    for (int k = n - 1; k >= 0; --k) {
+      if (tid == 0) b[k] = b[k] / A[k * n + k];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double bk = b[k];
+      for (int i = tid; i < k; i += 64) b[i] -= A[k * n + i] * bk;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+  __syncthreads();
+  return true;
+}
+#endif
+#endif  // SVO_LM_DEVICE_H_

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "lm_decide.h"
+#include "lm_math.h"
 #include "svo.h"
 
 bool svo_host_cholesky_solve(double* A, double* b, int n);  // host/linalg.cpp
@@ -36,41 +37,6 @@ bool svo_host_cholesky_solve(double* A, double* b, int n);  // host/linalg.cpp
 namespace {
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, MAX_RADIUS = 1e16, MIN_RADIUS = 1e-32;
 
-// sin/cos with a declared operation sequence (no libm; see oracle/ora_ba.cpp): identical on every host
-void det_sincos(double x, double* sn, double* cs) {
-  int k = 0;
-  while (x > 0.5) { x *= 0.5; ++k; }
-  const double x2 = x * x;
-  double s = x * (1.0 + x2 * (-1.0 / 6.0 + x2 * (1.0 / 120.0 + x2 * (-1.0 / 5040.0 + x2 * (1.0 / 362880.0 + x2 * (-1.0 / 39916800.0 +
-             x2 * (1.0 / 6227020800.0 + x2 * (-1.0 / 1307674368000.0))))))));
-  double c = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24.0 + x2 * (-1.0 / 720.0 + x2 * (1.0 / 40320.0 + x2 * (-1.0 / 3628800.0 +
-             x2 * (1.0 / 479001600.0 + x2 * (-1.0 / 87178291200.0)))))));
-  for (int i = 0; i < k; ++i) {
-    const double s2 = 2.0 * s * c;
-    c = 1.0 - 2.0 * s * s;
-    s = s2;
-  }
-  *sn = s; *cs = c;
-}
-
-// Plus of ProductParameterization(QuaternionParameterization, Identity(3)) (src/bundle_adjuster.cpp:19-20):
-// q+ = [cos|d|, sin|d|/|d| d] (x) q, t+ = t + dt; no renormalisation.
-void plus_pose(const double* p, const double* d, double* out) {
-  const double nd = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-  double qd[4];
-  if (nd > 0) {
-    double sn, cs;
-    det_sincos(nd, &sn, &cs);
-    const double s = sn / nd;
-    qd[0] = cs; qd[1] = s * d[0]; qd[2] = s * d[1]; qd[3] = s * d[2];
-  } else { qd[0] = 1; qd[1] = qd[2] = qd[3] = 0; }
-  const double* q = p;
-  out[0] = qd[0] * q[0] - qd[1] * q[1] - qd[2] * q[2] - qd[3] * q[3];
-  out[1] = qd[0] * q[1] + qd[1] * q[0] + qd[2] * q[3] - qd[3] * q[2];
-  out[2] = qd[0] * q[2] - qd[1] * q[3] + qd[2] * q[0] + qd[3] * q[1];
-  out[3] = qd[0] * q[3] + qd[1] * q[2] - qd[2] * q[1] + qd[3] * q[0];
-  out[4] = p[4] + d[3]; out[5] = p[5] + d[4]; out[6] = p[6] + d[5];
-}
 }  // namespace
 
 extern "C" int svo_lm_decide_step(double cost, double mcc, double radius, double decrease_factor, double cost_new,
@@ -167,7 +133,7 @@ extern "C" int svo_lm_solve(int n_poses, double* poses7, const svo_lm_ops* ops, 
         }
         for (int k = 0; k < K; ++k) {
           if (k == 0) memcpy(&cand[0], &poses7[0], 7 * sizeof(double));
-          else plus_pose(&poses7[7 * k], &dc[6 * (k - 1)], &cand[7 * k]);
+          else svo_plus_pose(&poses7[7 * k], &dc[6 * (k - 1)], &cand[7 * k]);
         }
         ctl.cost = cost; ctl.mcc = mcc; ctl.decrease_factor = decrease_factor;
         if (allow_spec && iterations < opt.max_iterations) {  // the last iteration cannot use a new linearisation

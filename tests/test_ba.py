@@ -107,6 +107,21 @@ def test_host_cholesky_follows_declared_order():
 
 
 @pytest.mark.gpu
+def test_hip_device_cholesky_matches_host():
+    """The reduced-camera-system solve the controller workgroup of the device-resident LM loop runs (csrc/lm_device.h)
+    gives the bits of svo_cholesky_solve (host/linalg.cpp), which gives the bits of the oracle's plain loop (above)."""
+    import stereo_vo_amd as S
+    ctx = S.Context(64, 64)
+    rng = np.random.default_rng(6)
+    for n in (1, 2, 5, 6, 7, 24, 30, 54, 60, 66, 114):
+        M = rng.normal(size=(n, n)); A = M @ M.T + n * np.eye(n); b = rng.normal(size=n)
+        assert np.array_equal(ctx.cholesky_solve_dev(A, b), S.api.cholesky_solve(A, b)), n
+    with pytest.raises(S.api.SvoError):
+        ctx.cholesky_solve_dev(-np.eye(3), np.ones(3))
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed,K,N,dense", [(1, 5, 400, False), (2, 6, 1500, False), (4, 10, 3000, False),
                                             (5, 20, 2000, True), (6, 2, 50, False)])
 def test_hip_ba_matches_oracle(ctx, seed, K, N, dense):
