@@ -21,12 +21,12 @@
 //     pinned host memory behind a completion word the host polls: 1 host round trip, no copy kernel, no stream wait per
 //     LM iteration.  Three forms of the same arithmetic, chosen per solve:
 //       alone on the GPU      3 launches  ba_step_kernel -> ba_decide_linearize_kernel -> ba_reduce_kernel
-//       several stereo streams, kernel admitted
-//                             0 launches  ba_resident_kernel: one launch per SOLVE, the iterations are commands in pinned
-//                                         memory (a launch -> completion round trip costs 40 us with 16+ active hardware
-//                                         queues, a command to a resident kernel 3 us)
-//       several streams, not admitted / SVO_BA_RESIDENT=0
-//                             1 launch    ba_iterate_kernel (workgroups meet at device-wide arrivals)
+//       default, kernel admitted
+//                             1 launch per SOLVE  ba_lm_kernel: the step control (host/lm.cpp's arithmetic) runs on the
+//                                         device too, replicated in every workgroup; several solves (the lanes of a
+//                                         pipeline group) share one launch, blockIdx.y = solve
+//       not admitted / SVO_BA_DEVICE_LM=0, several stereo streams
+//                             1 launch per iteration  ba_iterate_kernel (workgroups meet at device-wide arrivals)
 //     No cache maintenance instruction (buffer_wbl2 / buffer_inv) inside any of them: payload and slots that cross
 //     workgroups are written through and read at the coherence point.  The oracle performs the same
 //     sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is bit-identical
@@ -52,6 +52,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "group_kernels.h"
 #include "lm_decide.h"
 #include "lm_device.h"
 #include "ref_constants.h"
@@ -890,7 +891,7 @@ struct IterShared {
 template <bool RES>
 __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, double spec_radius, const LmCtl& ctl, int with_pay1,
                                              int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy, double* sStep,
-                                             IterShared& sh) {
+                                             IterShared& sh, int n_blocks /* workgroups of THIS solve (a launch may hold several) */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
   const bool worker = (int)blockIdx.x < P.C;  // workgroups beyond the chunks only reduce
   if (worker) {
@@ -957,7 +958,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
     reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
     if (tid < 4) pay_store(P, &P.pay2_out[tid], sh.sOut[tid]);
   }
-  for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
+  for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
   reduce_publish(P);
 }
 
@@ -968,169 +969,14 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
   // these few waves are some stream's critical path and share their SIMDs with other streams' long tracker waves: issue
   // priority over them (measured at 8 streams: +1 %; a high-priority HIP stream instead costs 7 %)
   __builtin_amdgcn_s_setprio(3);
-  iterate_body<false>(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh);
-}
-
-// ---- the LM loop of a window solve WITHOUT launches: one resident kernel per solve, driven by the host through a command
-// block in pinned memory.  Measured on MI355X (tools/exp/concurrency.hip, pingpong.hip): a launch -> completion-word round
-// trip of a 4 us kernel costs 10 us alone and 40 us when eight host threads drive eight hardware queues (the command
-// processor's latency grows with the number of active queues; kernel durations do not change), while a resident kernel
-// answers a word written to pinned memory in 3 us — alone or next to seven others.
-//   host:  fills [header | dc | candidate poses | current poses], stores the sequence number last (release)
-//   workgroup 0, thread 0: polls the sequence word over PCIe, posts it to the other workgroups through device memory
-//   all:   read the header and the step block with system-scope loads, run the command, publish the completion word
-// Commands: one LM iteration (iterate_body), pass A alone (first linearisation / re-linearisation), exit.  The current
-// poses travel with every command (the previous candidate poses were staged by ANOTHER workgroup's plain stores: not
-// coherently readable here); landmarks, their scaling and every slot are either wave-local across iterations (a landmark's
-// observations live in one chunk = one resident wave) or handed over write-through (section 6 of DESIGN.md).
-// Every wait is bounded: a workgroup that gives up leaves, the host's completion-word wait then reports the error.
-enum { RES_OP_ITERATE = 1, RES_OP_LINEARIZE = 2, RES_OP_EXIT = 3, RES_OP_DELIVER = 4 };
-constexpr int RES_HDR_WORDS = 16, RES_HDR_DOUBLES = 6;  // header: 16 words at byte 0, 6 doubles at byte 64; the step block at byte 128
-struct ResArgs {
-  double* dev_cmd;        // device copy of [header (16 doubles) | step block], made by workgroup 0 for everybody else
-  int cmd_doubles;        // 16 + n + 14 K
-  const unsigned* hdr;    // pinned
-  unsigned* post;         // device: sequence number of the command every workgroup may read
-  unsigned first_seq;     // sequence number of this solve's first command
-  const void* arena_src;  // pinned problem image to fetch before the first command (null: already on the device)
-  void* arena_dst;
-  size_t arena_bytes;
-  unsigned* copied;       // device counter of workgroups that finished their share of the fetch (monotone)
-  unsigned copied_target;
-  double* export_points;  // pinned: where the exit command delivers the solved landmarks (null: no delivery)
-  double* points_a;       // the two landmark buffers; header word 5 says which one is current
-  double* points_b;
-};
-
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_resident_kernel(BaDev P, ResArgs ra, int lm_begin, int lm_count, ListArgs la, IterSync sy0) {
-  __shared__ double sStep[RES_STEP_LDS_DOUBLES];
-  __shared__ IterShared sh;
-  __shared__ unsigned sHdr[RES_HDR_WORDS];
-  __shared__ double sHdrD[RES_HDR_DOUBLES];
-  __shared__ int sAlive;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  __builtin_amdgcn_s_setprio(3);
-  P.step_in = ra.dev_cmd + 16;
-  if (ra.arena_src) {
-    // the problem image: fetched from pinned memory by all workgroups (16 bytes per thread and step, consecutive lanes =
-    // consecutive addresses), written through; workgroup 0 posts the first command only when every piece has arrived
-    const double* src = reinterpret_cast<const double*>(ra.arena_src);
-    double* dst = reinterpret_cast<double*>(ra.arena_dst);
-    const size_t n16 = ra.arena_bytes / 16;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n16; i += (size_t)gridDim.x * blockDim.x)
-      slot_store2<true>(dst + 2 * i, src[2 * i], src[2 * i + 1]);
-    stores_acknowledged();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(ra.copied, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  for (unsigned seq = ra.first_seq;; ++seq) {
-    if (blockIdx.x == 0) {
-      // the only reader of host memory: wait for the command, copy it to device memory (write-through), post it
-      if (tid == 0) {
-        int alive = 1;
-        unsigned spins = 0;
-        if (ra.arena_src && seq == ra.first_seq && !wait_until(ra.copied, ra.copied_target, true)) alive = 0;
-        while (alive && __hip_atomic_load(ra.hdr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
-          if (++spins > (1u << 22)) { alive = 0; break; }  // ~seconds without a command: the host is gone
-        }
-        sAlive = alive;
-      }
-      __syncthreads();
-      if (sAlive) {
-        const double* src = reinterpret_cast<const double*>(ra.hdr);
-        for (int i = tid; i < ra.cmd_doubles; i += blockDim.x)
-          __hip_atomic_store(&ra.dev_cmd[i], __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        stores_acknowledged();
-      }
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(ra.post, sAlive ? seq : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (tid == 0) {
-      int alive = 1;
-      {
-        unsigned spins = 0;
-        for (;;) {
-          const unsigned v = __hip_atomic_load(ra.post, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (v == seq) break;
-          if (v == 0xFFFFFFFFu || ++spins > (1u << 23)) { alive = 0; break; }
-          __builtin_amdgcn_s_sleep(1);
-        }
-      }
-      sAlive = alive;
-    }
-    __syncthreads();
-    if (!sAlive) return;
-    {
-      const unsigned* dw = reinterpret_cast<const unsigned*>(ra.dev_cmd);
-      if (tid < RES_HDR_WORDS) sHdr[tid] = __hip_atomic_load(dw + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else if (tid >= 32 && tid < 32 + RES_HDR_DOUBLES) sHdrD[tid - 32] = slot_load(ra.dev_cmd + 8 + (tid - 32));
-    }
-    __syncthreads();
-    const int op = (int)sHdr[1];
-    if (op == RES_OP_EXIT) return;
-    if (op == RES_OP_DELIVER) {
-      // after the last iteration: every wave delivers its own landmarks (it is the only one that can read them without
-      // cache maintenance) into pinned memory that only the GPU writes (8-byte stores into lines the CPU holds DIRTY —
-      // the uploaded problem image — took 0.4 ms for 700 landmarks: every store made the host bridge fetch the line from
-      // a CPU cache first); the last workgroup publishes the completion word.
-      if (ra.export_points && (int)blockIdx.x < P.C && wave == 0) {
-        // a chunk's landmarks are consecutive indices: staged in LDS, then written by consecutive lanes to consecutive
-        // addresses (scattered 8-byte system-scope stores go out one PCIe write each: 0.4 ms for 700 landmarks)
-        const ObsRec R = load_obs(P, blockIdx.x, lane, sHdr[5] != 0 ? ra.points_b : ra.points_a);
-        const int j0 = __builtin_amdgcn_readfirstlane(R.j);  // lane 0 holds the chunk's first observation
-        const unsigned long long firsts = __ballot(R.active && lane == R.first);
-        const int count = __popcll(firsts);
-        if (R.active && lane == R.first) { sStep[3 * (R.j - j0)] = R.p.x; sStep[3 * (R.j - j0) + 1] = R.p.y; sStep[3 * (R.j - j0) + 2] = R.p.z; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (int i = lane; i < 3 * count; i += 64) pay_store(&ra.export_points[3 * (size_t)j0 + i], sStep[i]);
-      }
-      P.arrive_target = sHdr[9];
-      P.seq = (int)sHdr[10];
-      reduce_publish(P);
-      __syncthreads();
-      continue;
-    }
-    const bool sel = sHdr[5] != 0;
-    P.points = sel ? ra.points_b : ra.points_a;
-    P.cand_points = sel ? ra.points_a : ra.points_b;
-    P.arrive_target = sHdr[9];
-    P.seq = (int)sHdr[10];
-    IterSync sy = sy0;
-    sy.arrived_target = sHdr[6]; sy.post_seq = sHdr[7]; sy.done_target = sHdr[8];
-    const double radius = sHdrD[0];
-    if (op == RES_OP_ITERATE) {
-      const LmCtl ctl = {sHdrD[2], sHdrD[3], radius, sHdrD[4], (int)sHdr[2]};
-      iterate_body<true>(P, radius, sHdrD[1], ctl, (int)sHdr[3], lm_begin, lm_count, la, sy, sStep, sh);
-    } else {  // pass A alone at the current point (first linearisation: header word 4), then the reduction
-      if ((int)blockIdx.x < P.C) {
-        stage_step<true>(P, sStep);
-        if (wave == 0) {
-          const ObsRec R = load_obs(P, blockIdx.x, lane, P.points);
-          double unused0 = 0, unused1 = 0;
-          linearize_chunk<true>(P, R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, (int)sHdr[4], nullptr, nullptr, nullptr, nullptr, unused0, unused1);
-          stores_acknowledged();
-        }
-      }
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int nb = ba_reduce_blocks(P.K - 1);
-      if ((int)blockIdx.x < nb) {
-        if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
-        __syncthreads();
-        if (!sh.sGo) return;
-        for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
-        reduce_publish(P);
-      }
-    }
-    __syncthreads();  // the shared header is rewritten at the top of the loop
-  }
+  iterate_body<false>(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------
-// The WHOLE solve as one launch: ba_lm_kernel.  The resident kernel above still has the host in every LM iteration
-// (Cholesky of the reduced camera system + Ceres' step control: 13 us of PCIe turnaround for 1.3-4.4 us of arithmetic,
-// and one host thread per stereo stream).  Here the step control runs on the device, REPLICATED: when the reduction of
+// The WHOLE solve as one launch: ba_lm_kernel.  Every other path has the host in every LM iteration (Cholesky of the
+// reduced camera system + Ceres' step control: 13 us of PCIe turnaround for 1.3-4.4 us of arithmetic, and one host thread
+// per stereo stream; round 2's resident kernel took commands from the host over PCIe and is gone).  Here the step control
+// runs on the device, REPLICATED: when the reduction of
 // an iteration is complete (one device-wide arrival counter), every workgroup reads the summed payload at the coherence
 // point and runs host/lm.cpp's step control itself — the SAME functions (host/lm_math.h, host/lm_decide.h; the Cholesky
 // of csrc/lm_device.h applies host/linalg.cpp's operations in its order), hence the same bits and the same decision in
@@ -1139,7 +985,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // pass A -> arrival -> reduction slices -> arrival -> step control.  The host launches, and later finds poses,
 // landmarks, summary and ONE completion word in pinned memory.  Bit-identical to the host-driven loop
 // (tests/test_ba.py, tests/test_pipeline.py): every deciding operation is the same IEEE operation wherever it runs.
-// Steps always take the chained form; the same-sweep prediction only saved a collective / a host round trip.
+// Steps take host/lm.cpp's two forms: chained (decision inside the launch, pass A behind it) or, after a saturated step,
+// same sweep (pass A at the candidate with the predicted radius right behind pass B: one device-wide meeting less).
 // The wall-clock cap of src/bundle_adjuster.cpp:11 cannot be evaluated consistently by replicated controllers:
 // solves with a cap below LM_DEVICE_MIN_TIME_CAP_S stay on the host-driven paths, larger caps (the reference's 0.1 s is
 // 30x the longest 50-iteration window solve) can never fire and are ignored.
@@ -1162,19 +1009,19 @@ struct LmDevArgs {
 constexpr double LM_DEVICE_MIN_TIME_CAP_S = 0.02;
 enum { LMC_ARRIVE = 0, LMC_DONE = 1, LMC_ARRIVED = 2, LMC_POSTED = 3, LMC_COPIED = 4, LMC_EXITED = 5, LMC_CTL = 8, LMC_WORDS = 16 };
 enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
-       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_DOUBLES = 16 };
+       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED, LMR_DOUBLES = 16 };
 enum { LMS_START = 0, LMS_FIRST, LMS_RELIN, LMS_STEP, LMS_ACCEPT_RELIN, LMS_DELIVER };
 enum { LMOP_EXIT = 0, LMOP_LINEARIZE, LMOP_ITERATE, LMOP_DELIVER, LMOP_ABORT };
 
 struct LmDevState {
-  double radius, df, cost, initial_cost, mcc;
-  int iterations, successful, termination, need_linearize, state, sel, chain, first;
+  double radius, df, cost, initial_cost, mcc, spec;  // spec: radius of the same-sweep pass A of the step in flight (0: none)
+  int iterations, successful, termination, need_linearize, state, sel, chain, first, saturated;
   unsigned arrived_total, post_seq, done_total, arrive_total;
-  int lin_calls, step_calls;
+  int lin_calls, step_calls, same_sweeps, next_used;
   int go, act, use_next, accepted, relin;
   long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: waiting for the reduction, step control, passes
 };
-constexpr double LM_MIN_RADIUS = 1e-32;
+constexpr double LM_MIN_RADIUS = 1e-32, LM_MAX_RADIUS = 1e16;
 
 // controller workspace (doubles): payload1 image, 4 vectors of n, payload2, term scratch
 static inline size_t ba_lm_ctl_doubles(int n, int K) { return (size_t)n * n + 3 * (size_t)n + 2 + 5 * (size_t)(n > 0 ? n : 1) + 8 + 14 * (size_t)K + 8; }
@@ -1221,7 +1068,7 @@ __device__ __forceinline__ void lm_fetch(double* dst, const double* src, int cou
 // [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
 __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* sStep) {
   const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
-  const int grid = (int)gridDim.x, nb = ba_reduce_blocks(K - 1);
+  const int grid = P.C, nb = ba_reduce_blocks(K - 1);  // one workgroup per chunk of THIS solve (the launch may hold several solves)
   const int pay1 = n * n + 3 * n + 2;
   double* cP = cl;             // payload1 image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
   double* cSc = cP + pay1;     // Jacobi scales of the pose columns
@@ -1256,12 +1103,12 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   const int st = cs.state;  // stable: written before the barrier that ended the previous turn
   if (st == LMS_START) {
     if (tid == 0) {
-      cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, gridDim.x, true) : 1;
+      cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, (unsigned)P.C, true) : 1;
       cs.radius = opt.initial_radius; cs.df = 2.0; cs.cost = 0.0; cs.initial_cost = 0.0; cs.mcc = 0.0;
       cs.t0 = cs.t_mark = (long long)wall_clock64();
-      cs.iterations = 0; cs.successful = 0; cs.termination = 1; cs.need_linearize = 0; cs.sel = 0; cs.chain = 0;
+      cs.iterations = 0; cs.successful = 0; cs.termination = 1; cs.need_linearize = 0; cs.sel = 0; cs.chain = 0; cs.spec = 0.0; cs.saturated = 0;
       cs.arrived_total = 0; cs.post_seq = 0; cs.done_total = 0; cs.arrive_total = 0;
-      cs.lin_calls = 1; cs.step_calls = 0;
+      cs.lin_calls = 1; cs.step_calls = 0; cs.same_sweeps = 0; cs.next_used = 0;
       cs.t_wait = cs.t_ctl = cs.t_body = 0;
       cs.state = LMS_FIRST; cs.first = 1;
     }
@@ -1295,12 +1142,13 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       const double cost_new = cPay2[0], model_change = cs.mcc + cPay2[1];
       double step2 = cPay2[2], x2 = cPay2[3];
       for (int i = 7; i < 7 * K; ++i) { step2 += cTerm[i]; x2 += cTerm[7 * K + i]; }
-      const bool have_next = cs.chain != 0;
-      const bool next_at_cand = cPay2[4] != 0.0;
-      const double next_radius = cPay2[5];
+      // the linearisation that rode along: chained (decision taken inside the launch) or same sweep (predicted)
+      const bool have_next = cs.chain != 0 || cs.spec > 0;
+      const bool next_at_cand = cs.spec > 0 ? true : cPay2[4] != 0.0;
+      const double next_radius = cs.spec > 0 ? cs.spec : cPay2[5];
       int a_ = ACT_LOOPTOP, use = 0, relin = 0;
       if (!(model_change > 0)) {  // invalid step: no model decrease
-        cs.radius /= cs.df; cs.df *= 2;
+        cs.radius /= cs.df; cs.df *= 2; cs.saturated = 0;
         use = have_next && next_radius > 0 && next_radius == cs.radius && !next_at_cand;
         cs.need_linearize = !use;
       } else if (sqrt(step2) <= opt.parameter_tolerance * (sqrt(x2) + opt.parameter_tolerance)) {
@@ -1313,18 +1161,20 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
           cs.sel ^= 1;  // the candidate becomes the current point (op_accept)
           cs.cost = cost_new;
           ++cs.successful;
+          cs.saturated = dec.next_radius == fmin(LM_MAX_RADIUS, cs.radius / (1.0 / 3.0));  // rho >= 0.9368: predict the same for the next step
           cs.radius = dec.next_radius;
           cs.df = 2.0;
           use = have_next && next_radius > 0 && next_radius == cs.radius && next_at_cand;
           relin = !use;
           a_ = ACT_ACCEPT_TAIL;
         } else {
-          cs.radius = dec.next_radius; cs.df *= 2;
+          cs.radius = dec.next_radius; cs.df *= 2; cs.saturated = 0;
           use = have_next && next_radius > 0 && next_radius == cs.radius && !next_at_cand;
           cs.need_linearize = !use;
         }
       }
       cs.accepted = a_ == ACT_ACCEPT_TAIL;
+      cs.next_used += use;
       cs.act = a_; cs.use_next = use; cs.relin = relin;
     }
     __syncthreads();
@@ -1395,6 +1245,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
           const long long tn = (long long)wall_clock64();
           pay_store(&r[LMR_T_WAIT], (double)cs.t_wait); pay_store(&r[LMR_T_CTL], (double)(cs.t_ctl + (tn - cs.t_mark)));
           pay_store(&r[LMR_T_BODY], (double)cs.t_body); pay_store(&r[LMR_T_TOTAL], (double)(tn - cs.t0));
+          pay_store(&r[LMR_SAME_SWEEP], (double)cs.same_sweeps); pay_store(&r[LMR_NEXT_USED], (double)cs.next_used);
         }
         for (int i = tid; i < 7 * K; i += nt) pay_store(&a.host_result[LMR_DOUBLES + i], cPose[i]);
       }
@@ -1434,7 +1285,14 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
         double mcc = 0.0;
         for (int q = 0; q < n; ++q) mcc += cTerm[q];
         cs.mcc = mcc;
-        cs.chain = cs.iterations < opt.max_iterations ? 1 : 0;  // the last iteration cannot use a new linearisation
+        cs.chain = 0; cs.spec = 0.0;
+        if (cs.iterations < opt.max_iterations) {  // the last iteration cannot use a new linearisation
+          // after a saturated step (Ceres' update is exactly radius / (1/3) for rho >= 0.9368) the next one is predicted
+          // saturated too: pass A at the candidate runs with that radius in the SAME sweep as pass B — no device-wide
+          // meeting for the decision; a misprediction costs one stand-alone pass A (host/lm.cpp, "same sweep")
+          if (cs.saturated) { cs.spec = fmin(LM_MAX_RADIUS, cs.radius / (1.0 / 3.0)); ++cs.same_sweeps; }
+          else cs.chain = 1;
+        }
         ++cs.step_calls;
         cs.state = LMS_STEP;
       }
@@ -1444,7 +1302,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       }
       __syncthreads();
       const int chain = cs.chain;
-      return issue(LMOP_ITERATE, chain, chain);
+      return issue(LMOP_ITERATE, chain, chain || cs.spec > 0);
     }
     // not positive definite: invalid step, linearise again with the reduced radius
     if (tid == 0) { cs.radius /= cs.df; cs.df *= 2; cs.need_linearize = 1; }
@@ -1481,12 +1339,31 @@ __device__ __forceinline__ void deliver_chunk_points(const ObsRec& R, double* ou
   for (int i = lane; i < 3 * span; i += 64) pay_store(&out[3 * (size_t)j0 + i], stage[i]);
 }
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_lm_kernel(BaDev P, LmDevArgs a, int lm_begin, int lm_count, ListArgs la) {
+// One solve of a launch: everything the kernel needs, in pinned host memory owned by the adjuster (stable while its solve
+// is in flight); the launch carries one pointer per solve, blockIdx.y selects it.
+struct LmLane { BaDev P; LmDevArgs a; int lm_begin, lm_count; ListArgs la; };
+struct LmLanePtrs { const LmLane* p[SVO_MAX_LANES]; };
+
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_lm_kernel(LmLanePtrs lanes) {
   extern __shared__ double ctl_lds[];  // the step control's workspace
   __shared__ double sStep[RES_STEP_LDS_DOUBLES];  // [dc | candidate poses | current poses], built in place by the step control
   __shared__ IterShared sh;
   __shared__ LmDevState cs;
+  __shared__ __align__(16) unsigned char sLaneRaw[sizeof(LmLane)];
+  LmLane& sLane = *reinterpret_cast<LmLane*>(sLaneRaw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    // the solve's record: one PCIe read per workgroup, then LDS / registers
+    const unsigned* src = reinterpret_cast<const unsigned*>(lanes.p[blockIdx.y]);
+    unsigned* dst = reinterpret_cast<unsigned*>(&sLane);
+    for (int i = tid; i < (int)(sizeof(LmLane) / 4); i += blockDim.x) dst[i] = src[i];
+  }
+  __syncthreads();
+  if ((int)blockIdx.x >= sLane.P.C) return;  // the launch is as wide as its largest solve
+  BaDev P = sLane.P;
+  const LmDevArgs& a = sLane.a;
+  const ListArgs& la = sLane.la;
+  const int lm_begin = sLane.lm_begin, lm_count = sLane.lm_count, n_blocks = P.C;
   __builtin_amdgcn_s_setprio(3);
   P.step_in = nullptr;  // the step block is already in LDS (stage_step<true> then only synchronises)
   P.pay2_out = a.dev_pay; P.pay1_out = a.dev_pay + PAY_STAGE_STRIDE; P.pay_dev = 1;
@@ -1499,7 +1376,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double* src = reinterpret_cast<const double*>(a.arena_src);
     double* dst = reinterpret_cast<double*>(a.arena_dst);
     const size_t n16 = a.arena_bytes / 16;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n16; i += (size_t)n_blocks * blockDim.x)
       slot_store2<true>(dst + 2 * i, src[2 * i], src[2 * i + 1]);
     stores_acknowledged();
     __syncthreads();
@@ -1537,7 +1414,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double radius = cs.radius;
     if (op == LMOP_ITERATE) {
       const LmCtl ctl = {cs.cost, cs.mcc, radius, cs.df, cs.chain};
-      iterate_body<true>(P, radius, 0.0, ctl, cs.chain, lm_begin, lm_count, la, sy, sStep, sh);
+      iterate_body<true>(P, radius, cs.spec, ctl, cs.chain || cs.spec > 0, lm_begin, lm_count, la, sy, sStep, sh, n_blocks);
     } else {  // pass A alone at the current point, then the reduction
       const int first = cs.first;
       if ((int)blockIdx.x < P.C && wave == 0) {
@@ -1553,7 +1430,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
         __syncthreads();
         if (!sh.sGo) return;
-        for (int sl = blockIdx.x; sl < nb; sl += gridDim.x) reduce_slice<true>(P, la, sl, sh.sP);
+        for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
         reduce_publish(P);
       }
     }
@@ -1561,7 +1438,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   if (leave_clean && tid == 0) {
     // the counters go back to zero for the next solve on this adjuster (stream order: it starts after this launch has ended)
-    if (__hip_atomic_fetch_add(a.cnt + LMC_EXITED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x)
+    if (__hip_atomic_fetch_add(a.cnt + LMC_EXITED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)n_blocks)
       for (int i = 0; i < LMC_CTL; ++i) __hip_atomic_store(a.cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -1882,25 +1759,20 @@ struct svo_ba {
   size_t pin_bytes = 0;
   int* h_flag = nullptr;
   double* h_step = nullptr;
-  double* d_cmd = nullptr;
-  unsigned* h_hdr = nullptr;     // command header of the resident LM kernel (pinned, in front of h_step)
-  bool resident = false;         // a resident kernel is serving this solve
-  unsigned res_seq = 0;          // last command sequence number
-  bool res_sel = false;          // which landmark buffer is current (toggles with every accepted step)
-  int res_blocks = 0;            // admitted workgroups of the resident kernel
-  bool res_aborted = false;      // the last resident kernel may have left its abort mark behind
-  bool res_export = false;       // the exit command delivers the landmarks into the pinned image
+  bool res_export = false;       // the device-resident solve delivers the landmarks into pinned memory
   bool host_points_valid = false;  // ... and did: h_arena + arena_pts_off holds the solved landmarks
   size_t arena_pts_off = 0, arena_bytes = 0;
   bool arena_dirty = false;      // h_arena holds a problem image that is not on the device yet
   double* h_out_points = nullptr;  // pinned, GPU-written only
-  FusedAdmission res_admission;  // the resident kernel's workgroups, admitted for the duration of a solve
+  FusedAdmission res_admission;  // ba_lm_kernel's workgroups, admitted for the duration of a solve
   // device-resident solve (ba_lm_kernel): counter block, pinned result block, state of the launch in flight
   unsigned* d_lmc = nullptr;
   double* d_pay_fg = nullptr;    // [payload2 | payload1] of ba_lm_kernel in FINE-GRAINED device memory (see ba_alloc)
   unsigned* d_lmdbg = nullptr;   // SVO_BA_TRACE: last command of every workgroup of ba_lm_kernel
   double* h_result = nullptr;    // pinned [LMR_DOUBLES | poses 7 Kmax], inside h_pin
   bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
+  hipStream_t lm_stream = nullptr;  // ... on this stream
+  LmLane* h_lane = nullptr;      // pinned launch record of this adjuster's solve
   bool lm_counters_dirty = false;  // the last kernel did not leave through its clean exit: zero the counters before the next launch
   std::chrono::steady_clock::time_point lm_t0;
   double* h_pay = nullptr;
@@ -1920,12 +1792,12 @@ struct svo_ba {
   std::vector<int32_t> u_lm_start, u_chunks, u_pair_base, u_pair_pos, u_obs_pos, u_ls, u_cnt, u_fill;  // scratch of ba_upload
   std::vector<int32_t> h_list_begin, h_list_end;
   size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0, arrived_total = 0, post_seq = 0, copied_total = 0; int seq = 0;
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0, arrived_total = 0, post_seq = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
   // SVO_TIMING accumulators
-  double lm_t_wait = 0, lm_t_ctl = 0, lm_t_body = 0, lm_t_total = 0; long lm_n = 0, lm_iters = 0;
+  double lm_t_wait = 0, lm_t_ctl = 0, lm_t_body = 0, lm_t_total = 0; long lm_n = 0, lm_iters = 0, lm_same = 0, lm_used = 0, lm_steps = 0, lm_lins = 0;
   double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0, t_prep = 0, t_read = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
 };
 
@@ -1940,7 +1812,6 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
-  A(ba->d_cmd, double, 16 + step_doubles + 7 * (size_t)Kmax);  // the resident kernel's device copy of a command
   // The payload of the device-resident solve is written by some workgroups and read by ALL workgroups of the same launch,
   // iteration after iteration at the same addresses.  In ordinary (coarse-grained) device memory that is not coherent
   // across the eight XCDs' L2s inside a launch: measured on MI355X under load (4+ stereo streams), a workgroup's sc1 loads
@@ -1950,6 +1821,7 @@ static int ba_alloc(svo_ba* ba) {
   // contribution slots are written and read once per iteration at addresses a workgroup's XCD does not otherwise touch.)
   SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_pay_fg, sizeof(double) * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)), hipDeviceMallocFinegrained));
   SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_lmc, sizeof(unsigned) * LMC_WORDS, hipDeviceMallocFinegrained));
+  SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_lane, sizeof(LmLane), hipHostMallocDefault));
   if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 8 * 4096);
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned)));
   A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
@@ -1999,7 +1871,6 @@ static int ba_alloc(svo_ba* ba) {
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocCoherent));  // fine-grained: see reduce_publish
   memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
   ba->h_flag = reinterpret_cast<int*>(ba->h_pin);
-  ba->h_hdr = reinterpret_cast<unsigned*>(ba->h_pin + 64);
   ba->h_step = reinterpret_cast<double*>(ba->h_pin + 64 + 128);
   ba->h_pay = ba->h_step + pin_step_doubles;
   ba->h_out_points = ba->h_pay + ((PAY2_SLOTS + ba->cap_pay1 + 7) & ~(size_t)7);
@@ -2052,14 +1923,15 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
             1e3 * ba->t_upload / std::max(ba->n_solves, 1l), 1e3 * ba->t_total / std::max(ba->n_solves, 1l), 1e3 * ba->t_read / std::max(ba->n_solves, 1l));
   if (getenv("SVO_TIMING") && ba->lm_n)
     fprintf(stderr, "[svo ba] device-resident solves: %ld, %.1f LM iterations each; per solve (workgroup 0, us): total %.1f = waiting for the passes %.1f + step control %.1f "
-                    "+ own share of the passes %.1f\n", ba->lm_n, (double)ba->lm_iters / ba->lm_n, 1e-2 * ba->lm_t_total / ba->lm_n, 1e-2 * ba->lm_t_wait / ba->lm_n,
-            1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n);
+                    "+ own share of the passes %.1f; steps %ld (same sweep %ld, next linearisation used %ld), stand-alone linearisations %ld\n", ba->lm_n, (double)ba->lm_iters / ba->lm_n, 1e-2 * ba->lm_t_total / ba->lm_n, 1e-2 * ba->lm_t_wait / ba->lm_n,
+            1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n, ba->lm_steps, ba->lm_same, ba->lm_used, ba->lm_lins);
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
-  void* ptrs[] = {ba->d_pay_fg, ba->d_lmdbg, ba->d_lmc, ba->d_cmd, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
+  void* ptrs[] = {ba->d_pay_fg, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
+  if (ba->h_lane) (void)hipHostFree(ba->h_lane);
   if (ba->stream) (void)hipStreamDestroy(ba->stream);
   delete ba;
 }
@@ -2431,7 +2303,7 @@ int ba_fused_budget() {
     int per_cu = 0, per_cu_res = 0, cus = 0, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_resident_kernel, 128, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_lm_kernel, 128, 8192) != hipSuccess) return 0;
     per_cu = std::min(per_cu, per_cu_res);  // one budget for both kernels whose workgroups wait: the tighter occupancy counts
     g_fused_per_cu = per_cu;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -2461,101 +2333,7 @@ ListArgs ba_list_args(const svo_ba* ba) {
   return la;
 }
 
-// ---- resident LM kernel: host side -----------------------------------------------------------------------------
-// SVO_BA_RESIDENT=0 / 1 forces; default: on while more than two pipelines are inside process_batch (with one hardware
-// queue per stream every launch -> completion round trip pays the command processor's multi-queue latency).
-bool ba_resident_wanted() {
-  static const char* e = getenv("SVO_BA_RESIDENT");
-  if (e && *e) return atoi(e) != 0;
-  return svo_throughput_mode();
-}
-
-IterSync ba_iter_sync(svo_ba* ba) {
-  IterSync sy;
-  sy.arrived = ba->d_arrive + 9; sy.arrived_target = ba->arrived_total;
-  sy.posted = ba->d_arrive + 10; sy.post_seq = ba->post_seq;
-  sy.done = ba->d_arrive + 8; sy.done_target = ba->done_total;
-  return sy;
-}
-
-// One command: header words, header doubles, step block, then the sequence number (release).
-void ba_resident_command(svo_ba* ba, int op, int chain, int with_pay1, int first, double radius, double spec_radius,
-                         const svo_lm_step_ctl* ctl, const double* dc, const double* cand_poses7) {
-  BaDev& d = ba->d;
-  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
-  unsigned* w = ba->h_hdr;
-  double* hd = reinterpret_cast<double*>(ba->h_hdr + 16);
-  w[1] = (unsigned)op; w[2] = (unsigned)chain; w[3] = (unsigned)with_pay1; w[4] = (unsigned)first; w[5] = ba->res_sel ? 1u : 0u;
-  w[6] = ba->arrived_total; w[7] = ba->post_seq; w[8] = ba->done_total; w[9] = d.arrive_target; w[10] = (unsigned)d.seq;
-  hd[0] = radius; hd[1] = spec_radius;
-  hd[2] = ctl ? ctl->cost : 0.0; hd[3] = ctl ? ctl->mcc : 0.0; hd[4] = ctl ? ctl->decrease_factor : 0.0; hd[5] = 0.0;
-  if (op == RES_OP_ITERATE || op == RES_OP_LINEARIZE) {
-    if (dc && n > 0) memcpy(ba->h_step, dc, sizeof(double) * n);
-    if (cand_poses7) memcpy(ba->h_step + nn, cand_poses7, sizeof(double) * 7 * K);
-    memcpy(ba->h_step + nn + 7 * K, ba->h_poses.data(), sizeof(double) * 7 * K);  // the current poses (lm.cpp keeps them up to date)
-  }
-  __atomic_store_n(&w[0], ++ba->res_seq, __ATOMIC_RELEASE);
-}
-
 inline FusedAdmission* ba_resident_admission(svo_ba* ba) { return &ba->res_admission; }
-
-// Starts the resident kernel for the loaded problem if the conditions hold; false: use the launch-per-pass paths.
-bool ba_resident_begin(svo_ba* ba) {
-  BaDev& d = ba->d;
-  ba->resident = false;
-  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !ba_resident_wanted()) return false;
-  const int nd = (d.K - 1) * d.K / 2 + (d.K - 1) + 1;
-  if ((int)ba->h_list_begin.size() < nd) return false;
-  const int grid = d.C;  // one workgroup per chunk; the reduction slices are looped over them
-  if (!ba_resident_admission(ba)->admit(grid)) return false;
-  ba->res_blocks = grid;
-  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
-  d.ctl_dev = reinterpret_cast<double*>(ba->d_arrive + 2);
-  d.pay2_out = ba->h_pay; d.pay1_out = ba->h_pay + PAY2_SLOTS;
-  d.flag = ba->h_flag; d.arrive = ba->d_arrive;
-  ba->res_sel = false;
-  if (ba->res_aborted) {  // a kernel that gave up left its abort mark in the post word: clear it before anybody waits on it again
-    (void)hipMemsetAsync(ba->d_arrive + 11, 0, sizeof(unsigned), ba->stream);
-    ba->res_aborted = false;
-  }
-  ResArgs ra;
-  ra.dev_cmd = ba->d_cmd; ra.cmd_doubles = 16 + (d.n > 0 ? d.n : 1) + 14 * d.K;
-  ra.hdr = ba->h_hdr; ra.post = ba->d_arrive + 11; ra.first_seq = ba->res_seq + 1;
-  ra.points_a = ba->cur_points; ra.points_b = ba->cand_points;
-  ra.export_points = ba->n_points ? ba->h_out_points : nullptr;
-  ra.arena_src = ba->arena_dirty ? ba->h_arena : nullptr; ra.arena_dst = ba->d_arena; ra.arena_bytes = ba->arena_bytes;
-  ra.copied = ba->d_arrive + 12;
-  if (ba->arena_dirty) ba->copied_total += (unsigned)grid;
-  ra.copied_target = ba->copied_total;
-  ba->res_export = ra.export_points != nullptr;
-  // 128 threads: the second wave halves the rounds of the reductions (64-thread workgroups: -4 % at 8 streams)
-  hipLaunchKernelGGL(ba_resident_kernel, dim3(grid), dim3(128), 0, ba->stream, d, ra, ba->h_list_begin[nd - 1],
-                     ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba), ba_iter_sync(ba));
-  if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); if (ra.arena_src) ba->copied_total -= (unsigned)grid; return false; }
-  ba->arena_dirty = false;  // the kernel fetches it; the first completion word says it has
-  ba->resident = true;
-  return true;
-}
-
-// ok = the solve finished normally: the exit command also delivers the landmarks into the pinned problem image and
-// publishes a completion word, so the host needs neither a D2H copy nor a stream wait to read the result.
-void ba_resident_end(svo_ba* ba, bool ok) {
-  if (!ba->resident) return;
-  ba->host_points_valid = false;
-  if (ok && ba->res_export) {
-    ba_aim_reduce(ba, ba->res_blocks, true);
-    ba_resident_command(ba, RES_OP_DELIVER, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
-    ba->host_points_valid = ba_wait_flag(ba, ba->d.seq) == SVO_OK;
-  }
-  ba_resident_command(ba, RES_OP_EXIT, 0, 0, 0, 0.0, 0.0, nullptr, nullptr, nullptr);
-  ba->resident = false;
-  if (!ok) ba->res_aborted = true;  // the kernel may have timed out on its own
-  // the kernel has left: its workgroups no longer count.  A CU-masked stream is drained every time: a masked stream that
-  // never met a synchronisation point did not come back from hipStreamSynchronize at teardown (observed on the stereo
-  // stream when its per-batch wait was replaced by a completion word).
-  if (!ba->host_points_valid || g_ba_cu_share != 32) (void)hipStreamSynchronize(ba->stream);
-  ba_resident_admission(ba)->release();
-}
 
 // ---- device-resident solve (ba_lm_kernel): host side -------------------------------------------------------------
 // SVO_BA_DEVICE_LM=0 / 1 forces; default: on for every window-sized single-rank deterministic solve that is admitted.
@@ -2567,46 +2345,83 @@ bool ba_device_lm_wanted() {
 
 size_t ba_lm_lds_bytes(const BaDev& d) { return sizeof(double) * ba_lm_ctl_doubles(d.n, d.K); }
 
-// Launches the whole solve of the loaded problem; false: not eligible / not admitted (use the host-driven paths).
-bool ba_device_lm_begin(svo_ba* ba) {
+// Fills the adjuster's launch record for the loaded problem; false: not eligible (use the host-driven paths).
+bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out) {
   BaDev& d = ba->d;
-  ba->lm_inflight = false;
-  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !ba_device_lm_wanted()) return false;
+  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !ba_device_lm_wanted() || !ba->h_lane) return false;
   if (ba->opt.max_time_s > 0 && ba->opt.max_time_s < LM_DEVICE_MIN_TIME_CAP_S) return false;  // see ba_lm_kernel
   const int nd = (d.K - 1) * d.K / 2 + (d.K - 1) + 1;
-  if ((int)ba->h_list_begin.size() < nd) return false;
+  if ((int)ba->h_list_begin.size() < nd || nd > 48) return false;  // the destination lists ride in the record
   const size_t lds = ba_lm_lds_bytes(d);
   if (lds > 96 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
-  const int grid = d.C;  // one workgroup per chunk: they wait for each other, so all of them must be resident
-  if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return false;
-  if (!ba_resident_admission(ba)->admit(ba_lm_admission_cost(grid, lds))) return false;
-  if (ba->lm_counters_dirty) {
-    if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), ba->stream) != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
-    ba->lm_counters_dirty = false;
-  }
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   d.flag = nullptr;
-  LmDevArgs a;
+  LmLane& L = *ba->h_lane;
+  L.P = d;
+  LmDevArgs& a = L.a;
   a.cnt = ba->d_lmc;
   a.arena_src = ba->arena_dirty ? ba->h_arena : nullptr; a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;
   a.points_a = ba->cur_points; a.points_b = ba->cand_points;
   a.export_points = ba->n_points ? ba->h_out_points : nullptr;
   a.dev_pay = ba->d_pay_fg;
   a.host_result = ba->h_result;
-  a.host_flag = ba->h_flag; a.host_seq = ++ba->seq;
-  a.dbg = grid <= 4096 ? ba->d_lmdbg : nullptr;
+  a.host_flag = ba->h_flag; a.host_seq = ba->seq + 1;  // committed by the launch
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
-  ba->lm_t0 = now();
-  SvoProfScope prof(ba->ctx, SVO_PROF_BA_STEP, ba->stream);
-  hipLaunchKernelGGL(ba_lm_kernel, dim3(grid), dim3(128), lds, ba->stream, d, a, ba->h_list_begin[nd - 1],
-                     ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1], ba_list_args(ba));
-  if (hipGetLastError() != hipSuccess) { ba_resident_admission(ba)->release(); return false; }
-  ba->arena_dirty = false;  // the kernel fetches it
-  ba->lm_inflight = true;
-  ba->res_export = a.export_points != nullptr;
+  a.dbg = d.C <= 4096 ? ba->d_lmdbg : nullptr;
+  L.lm_begin = ba->h_list_begin[nd - 1];
+  L.lm_count = ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1];
+  L.la = ba_list_args(ba);
+  *cost = ba_lm_admission_cost(d.C, lds);
+  *lds_out = lds;
   return true;
+}
+
+// ONE launch for the solves of `n` adjusters (the lanes of a pipeline group that reached a keyframe together; n = 1: a
+// single pipeline) on stream `st`.  Returns how many of them — a prefix — were admitted and launched; the others keep
+// their loaded problem and can be offered again later, or solved by the host-driven paths.
+int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st) {
+  LmLanePtrs ptrs;
+  int launched = 0, max_c = 0;
+  size_t max_lds = 0;
+  for (int i = 0; i < n && i < SVO_MAX_LANES; ++i) {
+    svo_ba* ba = bas[i];
+    int cost = 0;
+    size_t lds = 0;
+    ba->lm_inflight = false;
+    if (!ba_device_lm_fill(ba, &cost, &lds)) break;
+    if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) break;
+    if (!ba_resident_admission(ba)->admit(cost)) break;
+    if (ba->lm_counters_dirty) {
+      if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
+      ba->lm_counters_dirty = false;
+    }
+    ptrs.p[i] = ba->h_lane;
+    max_c = std::max(max_c, ba->d.C);
+    max_lds = std::max(max_lds, lds);
+    ++launched;
+  }
+  if (!launched) return 0;
+  const auto t0 = now();
+  {
+    SvoProfScope prof(bas[0]->ctx, SVO_PROF_BA_STEP, st);
+    hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
+  }
+  if (hipGetLastError() != hipSuccess) {
+    for (int i = 0; i < launched; ++i) ba_resident_admission(bas[i])->release();
+    return 0;
+  }
+  for (int i = 0; i < launched; ++i) {
+    svo_ba* ba = bas[i];
+    ++ba->seq;  // = a.host_seq
+    ba->lm_t0 = t0;
+    ba->arena_dirty = false;  // the kernel fetches it
+    ba->lm_inflight = true;
+    ba->lm_stream = st;
+    ba->res_export = ba->h_lane->a.export_points != nullptr;
+  }
+  return launched;
 }
 
 // Joins the launch: completion word, then poses / summary / counters out of the pinned result block.
@@ -2619,7 +2434,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   ba_resident_admission(ba)->release();
   if (rc) {
     // a wait inside the kernel gave up (or the launch never ran): drain, and never trust the counters again
-    (void)hipStreamSynchronize(ba->stream);
+    (void)hipStreamSynchronize(ba->lm_stream);
     if (getenv("SVO_BA_TRACE")) {  // which meeting was never complete
       unsigned c[LMC_WORDS] = {0};
       (void)hipMemcpy(c, ba->d_lmc, sizeof(c), hipMemcpyDeviceToHost);
@@ -2648,14 +2463,16 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   ba->stats.linearize_calls = (int)r[LMR_LINEARIZE_CALLS];
   ba->stats.step_calls = (int)r[LMR_STEP_CALLS];
   ba->stats.speculations = ba->stats.step_calls;
-  ba->stats.speculation_hits = ba->stats.step_calls - (ba->stats.linearize_calls - 1);
+  ba->stats.speculation_hits = (int)r[LMR_NEXT_USED];
+  ba->stats.single_exchange = (int)r[LMR_SAME_SWEEP];
+  ba->lm_same += (long)r[LMR_SAME_SWEEP]; ba->lm_used += (long)r[LMR_NEXT_USED]; ba->lm_steps += (long)r[LMR_STEP_CALLS]; ba->lm_lins += (long)r[LMR_LINEARIZE_CALLS];
   ba->lm_t_wait += r[LMR_T_WAIT]; ba->lm_t_ctl += r[LMR_T_CTL]; ba->lm_t_body += r[LMR_T_BODY]; ba->lm_t_total += r[LMR_T_TOTAL]; ba->lm_n++; ba->lm_iters += (long)r[LMR_ITERATIONS];
   if (sum) {
     sum->iterations = (int)r[LMR_ITERATIONS]; sum->successful_steps = (int)r[LMR_SUCCESSFUL]; sum->termination = (int)r[LMR_TERMINATION];
     sum->initial_cost = r[LMR_INITIAL_COST]; sum->final_cost = r[LMR_FINAL_COST];
     sum->solve_ms = ms_between(ba->lm_t0, now());
   }
-  if (g_ba_cu_share != 32) SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));  // CU-masked streams are drained every time (see ba_resident_end)
+  if (g_ba_cu_share != 32 && ba->lm_stream == ba->stream) SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));  // a CU-masked stream that never met a synchronisation point did not come back from hipStreamSynchronize at teardown (observed in round 2)
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   return SVO_OK;
 }
@@ -2669,14 +2486,7 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
   const int n = d.n, K = d.K;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
-  if (d.det && ba->resident) {
-    const int nb = ba_reduce_blocks(K - 1);
-    ba_aim_reduce(ba, std::min(ba->res_blocks, nb), true);
-    ba->done_total += (unsigned)ba->res_blocks;
-    ba_resident_command(ba, RES_OP_LINEARIZE, 0, 1, first, radius, 0.0, nullptr, nullptr, nullptr);
-    const int rc = ba_wait_flag(ba, d.seq);
-    if (rc) return rc;
-  } else if (d.det) {
+  if (d.det) {
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
@@ -2732,16 +2542,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     d.step_in = ba->d_step;
   }
   const bool next = same_sweep || chain;
-  if (d.det && ba->resident) {
-    // the resident kernel runs the whole iteration on a command: no launch
-    const int nb = ba_reduce_blocks(K - 1);
-    ba_aim_reduce(ba, next ? std::min(ba->res_blocks, nb) : 1, true);
-    if (chain) { ba->arrived_total += (unsigned)d.C; ++ba->post_seq; }
-    ba->done_total += (unsigned)ba->res_blocks;
-    ba_resident_command(ba, RES_OP_ITERATE, chain ? 1 : 0, next ? 1 : 0, 0, radius, same_sweep ? spec_radius : 0.0, ctl, dc, cand_poses7);
-    const int rc = ba_wait_flag(ba, d.seq);
-    if (rc) return rc;
-  } else if (d.det) {
+  if (d.det) {
     const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
     const int nb = ba_reduce_blocks(K - 1);
     const int lm_b = ba->h_list_begin[nd - 1], lm_n = ba->h_list_end[nd - 1] - lm_b;
@@ -2846,7 +2647,6 @@ int op_accept(void* user) {
   svo_ba* ba = static_cast<svo_ba*>(user);
   std::swap(ba->cur_points, ba->cand_points);
   std::swap(ba->cur_poses, ba->cand_poses);  // the candidate poses are already on the device (pass B's first workgroup)
-  ba->res_sel = !ba->res_sel;                // the resident kernel is told with every command which buffer is current
   return SVO_OK;
 }
 }  // namespace
@@ -2861,17 +2661,17 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
-  if (ba_device_lm_begin(ba)) {  // the whole solve is one launch: nothing for the host to do until the completion word
+  if (ba_device_lm_launch(&ba, 1, ba->stream) == 1) {  // the whole solve is one launch: nothing for the host to do until the completion word
     const int rcd = ba_device_lm_end(ba, sum);
     d.flag = nullptr;
     return rcd;
   }
-  if (!ba_resident_begin(ba)) {  // window-sized, single rank, deterministic, wanted and admitted: the passes become commands
+  {
     const int rcf = ba_flush_arena(ba);
     if (rcf) return rcf;
   }
+  ba->host_points_valid = false;
   const int rc = svo_lm_solve(d.K, ba->h_poses.data(), &ops, &ba->opt, sum, &ba->stats);
-  ba_resident_end(ba, rc == SVO_OK);  // on every path: a resident kernel must never be left waiting for a host that has moved on
   ba->n_spec += ba->stats.speculations; ba->n_hit += ba->stats.speculation_hits;
   // nothing is pending on the zero-copy path either; the wait keeps later users of the stream ordered (the resident
   // kernel's exit has published a completion word instead: stream order alone protects the next upload)
@@ -2989,11 +2789,14 @@ extern "C" int svo_ba_get_points(svo_ba* ba, const int64_t* ids, int n, float* x
   return SVO_OK;
 }
 
-extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
+// BundleAdjuster::bundle_adjust in three steps, so that a driver of several stereo streams (host/group.cpp) can assemble
+// on worker threads, launch the solves of several adjusters as ONE kernel and join them later; svo_ba_solve = all three.
+// prepare: host only (no launch) — the window's observations as a landmark-major problem image in pinned memory.
+// Returns 1 when there is nothing to solve (src/bundle_adjuster.cpp:138), 0 when a problem is loaded.
+int svo_ba_solve_prepare(svo_ba* ba) {
   if (!ba) return SVO_ERR_INVALID;
   svo_use_device(ba->ctx);
-  if (summary) memset(summary, 0, sizeof(*summary));
-  if (!ba->new_frame_added) return SVO_OK;  // src/bundle_adjuster.cpp:138
+  if (!ba->new_frame_added) return 1;  // src/bundle_adjuster.cpp:138
   const auto tp0 = std::chrono::steady_clock::now();
   const int K = (int)ba->window.size();
   // Observations sorted by (landmark id, window slot) — the order ceres would visit nothing in particular, but the
@@ -3046,7 +2849,36 @@ extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
   int rc = ba_upload(ba, K, poses.data(), (int)lm_ids.size(), points.data(), (int)op.size(), op.data(), oj.data(), uv.data());
   if (rc) return rc;
   ba->t_upload += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
-  rc = ba_lm(ba, summary);
+  return SVO_OK;
+}
+
+// launch: the prepared problems of `n` adjusters as ONE ba_lm_kernel launch on `stream`; returns how many (a prefix) were
+// eligible and admitted.  The others: offer them again, or svo_ba_solve_finish runs the host-driven loop for them.
+int svo_ba_solve_launch(svo_ba** bas, int n, void* stream) {
+  if (!bas || n < 1) return 0;
+  svo_use_device(bas[0]->ctx);
+  return ba_device_lm_launch(bas, n, stream ? (hipStream_t)stream : bas[0]->stream);
+}
+
+// 1: the launched solve has published its completion word (svo_ba_solve_finish will not block), 0: still running
+int svo_ba_solve_poll(svo_ba* ba) {
+  if (!ba || !ba->lm_inflight) return 1;
+  return __atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE) == ba->seq ? 1 : 0;
+}
+
+// finish: join the launched solve (or, if none was launched for this adjuster, run the host-driven loop now) and write
+// poses and landmarks back into the graph (src/bundle_adjuster.cpp:146-155).
+int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
+  if (!ba) return SVO_ERR_INVALID;
+  svo_use_device(ba->ctx);
+  if (summary) memset(summary, 0, sizeof(*summary));
+  const auto tu0 = std::chrono::steady_clock::now();
+  const int K = ba->d.K;
+  std::vector<double>& poses = ba->s_poses; std::vector<double>& points = ba->s_points;
+  std::vector<int64_t>& lm_ids = ba->solve_lm_ids;
+  int rc;
+  if (ba->lm_inflight) { rc = ba_device_lm_end(ba, summary); ba->d.flag = nullptr; }
+  else rc = ba_lm(ba, summary);
   if (!rc) ba->upload_pending = false;
   ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   ba->n_solves++;
@@ -3062,4 +2894,13 @@ extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
   ba->new_frame_added = false;  // :155
   ba->t_read += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
   return SVO_OK;
+}
+
+extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {
+  if (!ba) return SVO_ERR_INVALID;
+  if (summary) memset(summary, 0, sizeof(*summary));
+  const int rc = svo_ba_solve_prepare(ba);
+  if (rc == 1) return SVO_OK;  // src/bundle_adjuster.cpp:138
+  if (rc) return rc;
+  return svo_ba_solve_finish(ba, summary);
 }

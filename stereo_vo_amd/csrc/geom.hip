@@ -4,6 +4,7 @@
 // workgroup, ballot/popcount prefix inside each wave, LDS prefix across the 16 waves.  Output order is
 // the input order, as the reference's push_back loops produce.
 #include "kernels.h"
+#include "group_kernels.h"
 #include "ref_constants.h"
 #include "tail_device.h"
 
@@ -25,11 +26,11 @@ __global__ __launch_bounds__(CT) void triangulate_kernel(const float* __restrict
 
 // a6 in ONE launch.  One wavefront per detected corner: 64 tracked features are tested per step, any hit drops the corner;
 // the last workgroup to arrive compacts the survivors in input order (tail_device.h).
-__global__ __launch_bounds__(256) void dedup_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
-                                                    int n_det_host, const float* __restrict__ trk,
-                                                    const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
-                                                    uint8_t* keep, float* __restrict__ kept_xy, int* __restrict__ n_kept,
-                                                    unsigned* arrive, unsigned target) {
+__device__ __forceinline__ void dedup_body(const float* __restrict__ det, const int* __restrict__ n_det_dev,
+                                           int n_det_host, const float* __restrict__ trk,
+                                           const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
+                                           uint8_t* keep, float* __restrict__ kept_xy, int* __restrict__ n_kept,
+                                           unsigned* arrive, unsigned target) {
   svo_latency_critical();
   __shared__ int sWave[4];
   __shared__ int sLast;
@@ -60,6 +61,26 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float* __restrict__ de
     if (slot >= 0) { kept_xy[2 * slot] = det[2 * k]; kept_xy[2 * slot + 1] = det[2 * k + 1]; }
   }
   if (threadIdx.x == 0) *n_kept = base;
+}
+
+__global__ __launch_bounds__(256) void dedup_kernel(const float* __restrict__ det, const int* __restrict__ n_det_dev,
+                                                    int n_det_host, const float* __restrict__ trk,
+                                                    const int* __restrict__ n_trk_dev, int n_trk_host, float min_d,
+                                                    uint8_t* keep, float* __restrict__ kept_xy, int* __restrict__ n_kept,
+                                                    unsigned* arrive, unsigned target) {
+  dedup_body(det, n_det_dev, n_det_host, trk, n_trk_dev, n_trk_host, min_d, keep, kept_xy, n_kept, arrive, target);
+}
+
+// stream-batched form (group_kernels.h): blockIdx.y = lane, the same body
+__global__ __launch_bounds__(256) void dedup_group_kernel(SvoDedupLanes g) {
+  const SvoDedupLane& a = g.lane[blockIdx.y];
+  dedup_body(a.det, nullptr, a.n_det, a.trk, nullptr, a.n_trk, a.min_d, a.keep, a.kept_xy, a.n_kept, a.arrive, a.target);
+}
+
+int svo_kg_dedup(svo_ctx* ctx, hipStream_t st, const SvoDedupLanes& lanes, int n_lanes, int grid_x) {
+  hipLaunchKernelGGL(dedup_group_kernel, dim3(grid_x, n_lanes), dim3(256), 0, st, lanes);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
 }
 
 __global__ void gather_track_kernel(const int* __restrict__ idx, const int* __restrict__ n_dev, int n_host,

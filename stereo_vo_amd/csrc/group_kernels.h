@@ -1,0 +1,73 @@
+// Stream-batched launches: ONE launch of a stage of the hot path covers several stereo streams ("lanes" of a pipeline
+// group, host/group.cpp), blockIdx.y = lane.  The kernels run the SAME device bodies as the single-stream launches
+// (kernels.h) on per-lane argument records that travel in the kernel-argument segment, so a lane's results are bit for
+// bit those of its own svo_pipeline.  Why: with eight stereo streams as eight host threads and 16-24 hardware queues a
+// launch -> completion round trip costs 30-90 us instead of 7-11 and concurrent small kernels run 3-5x their solo time
+// (profiles/r02_exp_launch_rate.txt, r02_exp_placement.txt); one host thread and at most four queues avoid both.
+// Reference stages: src/feature_tracker.cpp:18-67 (track), src/image_processor.cpp:76-80 (PnP), :113-128 (dedup),
+// :173-207 (StereoBM at the features + triangulation).
+#ifndef SVO_GROUP_KERNELS_H_
+#define SVO_GROUP_KERNELS_H_
+#include "kernels.h"
+
+constexpr int SVO_MAX_LANES = 16;
+
+// a3 + the survivor filter of FeatureTracker::track_features, forward/backward LK and the stable compaction in ONE launch:
+// the last wavefront of a lane to arrive compacts the lane (no second launch, no second round trip).
+struct SvoLkLane {
+  const uint8_t* pyr_prev; const uint8_t* pyr_next;
+  const float* xy; const float* init_xy; const long long* ids;   // current features (device, or the pinned arrays a keyframe left)
+  int n;
+  float* fwd; uint8_t* keep; float* parallax;                      // per-feature scratch (device)
+  float* kept_xy; float* init_dst; long long* ids_dst;             // compacted set (device)
+  float* host_xy; long long* host_ids; int* host_n; float* host_av;  // pinned mirrors + (n_kept, av_parallax)
+  unsigned* arrive; unsigned arrive_target;                        // device arrival counter of the lane (monotone)
+  int* word; int seq;                                              // pinned completion word
+};
+struct SvoLkLanes { int w, h; SvoLkLane lane[SVO_MAX_LANES]; };
+// grid_x = the largest lane's feature count; every lane's arrive_target counts grid_x workgroups
+int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_lanes, int grid_x);
+
+// a5: hypotheses (100 workgroups per lane), then refinement of the hypothesis the host's RANSAC bookkeeping chose
+struct SvoPnpHypLane {
+  const float* xyz; const float* xy; int n; double f, cx, cy; double q0[4], t0[3]; double thr2;
+  double* hyp_pose; int* hyp_count; unsigned long long* hyp_mask; int mask_words; int* host_count;
+  SvoPublish pub;
+};
+struct SvoPnpHypLanes { SvoPnpHypLane lane[SVO_MAX_LANES]; };
+int svo_kg_pnp_hypotheses(svo_ctx* ctx, hipStream_t st, const SvoPnpHypLanes& lanes, int n_lanes, int iterations);
+struct SvoPnpRefLane {
+  const float* xyz; const float* xy; int n; double f, cx, cy; const double* hyp_pose; const unsigned long long* hyp_mask;
+  int mask_words; int best; double* out_pose; int* inliers; int* n_inliers; double* host_pose; int* host_inliers; int* host_nin;
+  float* inlier_xy; SvoPublish pub;
+};
+struct SvoPnpRefLanes { SvoPnpRefLane lane[SVO_MAX_LANES]; };
+int svo_kg_pnp_refine(svo_ctx* ctx, hipStream_t st, const SvoPnpRefLanes& lanes, int n_lanes);
+int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters);  // OpenCV's RANSACUpdateNumIters (csrc/pnp.hip)
+int svo_pnp_model_points();
+
+// a6: dedup of the detected corners against the tracked inliers
+struct SvoDedupLane {
+  const float* det; int n_det; const float* trk; int n_trk; float min_d; uint8_t* keep; float* kept_xy; int* n_kept;
+  unsigned* arrive; unsigned target;
+};
+struct SvoDedupLanes { SvoDedupLane lane[SVO_MAX_LANES]; };
+// grid_x = ceil(largest n_det / 4); every lane's target counts grid_x workgroups
+int svo_kg_dedup(svo_ctx* ctx, hipStream_t st, const SvoDedupLanes& lanes, int n_lanes, int grid_x);
+
+// a7 (sparse) + a8: disparities at the lane's features, triangulation / compaction by the lane's last workgroup
+struct SvoStereoTriLane {
+  const uint8_t* left; const uint8_t* right; const float* xy; const int* n_dev; int n_max; float* disp; SvoMat4 M;
+  float* kept_xy; float* xyz; int* n_kept; SvoPublish pub;
+};
+struct SvoStereoTriLanes { int w, h, stride, ndisp, block; SvoStereoTriLane lane[SVO_MAX_LANES]; };
+// grid_x = the largest lane's n_max; every lane's pub.target counts grid_x workgroups (pub.arrive must be set)
+int svo_kg_stereo_triangulate(svo_ctx* ctx, hipStream_t st, const SvoStereoTriLanes& lanes, int n_lanes, int grid_x);
+
+// a12 in steps (csrc/ba.hip): assemble on any thread, launch the solves of several adjusters as ONE kernel, join later
+int svo_ba_solve_prepare(svo_ba* ba);                          // 1: nothing to solve, 0: a problem is loaded, < 0: svo_status
+int svo_ba_solve_launch(svo_ba** bas, int n, void* stream);    // number launched (a prefix of bas)
+int svo_ba_solve_poll(svo_ba* ba);                             // 1: finish will not block
+int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary);  // join (or solve host-driven) + write back into the graph
+
+#endif

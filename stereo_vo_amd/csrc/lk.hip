@@ -15,6 +15,8 @@
 //                   backward tracking and the reference's keep/drop predicate are fused in one launch.
 //   track_compact_kernel : stable compaction + the sequential f32 parallax sum (order matters).
 #include "kernels.h"
+#include "group_kernels.h"
+#include "tail_device.h"
 
 namespace {
 #include "ref_constants.h"
@@ -598,6 +600,72 @@ __global__ __launch_bounds__(LKT * FPB) void lk_fb_kernel(const uint8_t* __restr
   }
 }
 
+// ---- stream-batched form (group_kernels.h): blockIdx.y = lane, blockIdx.x = feature; the same lk_point calls and the
+// same keep predicate as lk_fb_kernel, then the lane's LAST wavefront to arrive compacts the lane — the stable
+// compaction and the sequential f32 parallax sum of track_compact_kernel (src/feature_tracker.cpp:44-64, SURVEY C-2) by
+// one wavefront: ballot / popcount per 64 features; the sum adds every feature in order (+0.0f for a dropped one leaves
+// a running sum that is >= +0 bit-identical), 64 scalar lane reads per round.  Per-feature results cross workgroups
+// inside the launch: written through, read at the coherence point (tail_device.h); what the host consumes goes out as
+// system-scope stores, `s_waitcnt vmcnt(0)`, then the completion word — no cache maintenance instruction.
+__global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
+  static_assert(LKT == 64 && FPB == 1, "the stream-batched tracker is written for one wavefront per feature");
+  __shared__ LkShared S;
+  __shared__ int sLast;
+  const SvoLkLane& a = g.lane[blockIdx.y];
+  const int n = a.n, f = blockIdx.x, lane = threadIdx.x;
+  if (f < n) {
+    const Pyr A = make_pyr(a.pyr_prev, g.w, g.h), B = make_pyr(a.pyr_next, g.w, g.h);
+    const float x0 = a.xy[2 * f], y0 = a.xy[2 * f + 1];
+    float fx, fy, bx = 0.f, by = 0.f;
+    const uint8_t s1 = lk_point(A, B, x0, y0, &fx, &fy, S);
+    uint8_t s2 = 0;
+    if (s1) s2 = lk_point(B, A, fx, fy, &bx, &by, S);
+    if (lane == 0) {
+      uint8_t k = 0;
+      float par = 0.f;
+      if (s1 && s2) {
+        const float ex = x0 - bx, ey = y0 - by;
+        if ((double)ex * (double)ex + (double)ey * (double)ey < svo_ref::FB_MAX_DISTANCE * svo_ref::FB_MAX_DISTANCE) {  // norm(old - back) < 2
+          const float dx = fx - a.init_xy[2 * f], dy = fy - a.init_xy[2 * f + 1];
+          par = sqrtf(dx * dx + dy * dy);
+          k = !(par > svo_ref::MAX_PARALLAX);
+        }
+      }
+      svo_wt_store(&a.fwd[2 * f], fx); svo_wt_store(&a.fwd[2 * f + 1], fy);
+      svo_wt_store(&a.keep[f], k); svo_wt_store(&a.parallax[f], par);
+    }
+  }
+  if (!svo_last_arrival(a.arrive, a.arrive_target, &sLast)) return;
+  svo_latency_critical();
+  int base = 0;
+  float sum = 0.f;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int i = c0 + lane;
+    const bool k = i < n && svo_coherent_load(&a.keep[i]) != 0;
+    const float par = k ? svo_coherent_load(&a.parallax[i]) : 0.0f;
+    const unsigned long long mask = __ballot(k);
+    if (k) {
+      const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+      const float fx = svo_coherent_load(&a.fwd[2 * i]), fy = svo_coherent_load(&a.fwd[2 * i + 1]);
+      a.kept_xy[2 * slot] = fx; a.kept_xy[2 * slot + 1] = fy;
+      a.init_dst[2 * slot] = a.init_xy[2 * i]; a.init_dst[2 * slot + 1] = a.init_xy[2 * i + 1];  // the tracker's per-feature state follows the feature (C-1: old ids)
+      const long long id = a.ids[i];
+      a.ids_dst[slot] = id;
+      svo_host_store(&a.host_xy[2 * slot], fx); svo_host_store(&a.host_xy[2 * slot + 1], fy);
+      svo_host_store(&a.host_ids[slot], id);
+    }
+    base += __popcll(mask);
+#pragma unroll
+    for (int t = 0; t < 64; ++t) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(par), t));
+  }
+  if (lane == 0) {
+    svo_host_store(a.host_n, base);
+    svo_host_store(a.host_av, n > 0 ? sum / (float)n : 0.f);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(a.word, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Stable compaction of the kept features; av_parallax = (sequential float sum over kept)/n (SURVEY C-2).
 __global__ __launch_bounds__(1024) void track_compact_kernel(const float* __restrict__ fwd, const uint8_t* __restrict__ keep,
                                                              const float* __restrict__ parallax, const int* __restrict__ n_dev,
@@ -712,6 +780,13 @@ int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, 
   }
   hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, fwd_xy, keep_flag, parallax, n_dev, n_max,
                      kept_xy, kept_index, n_kept, av_parallax, carry ? *carry : SvoTrackCarry{});
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_lanes, int grid_x) {
+  SvoProfScope prof(ctx, SVO_PROF_LK_FB, st);
+  hipLaunchKernelGGL(lk_fb_group_kernel, dim3(grid_x, n_lanes), dim3(64), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

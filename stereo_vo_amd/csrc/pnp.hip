@@ -16,6 +16,7 @@
 #include <cfloat>
 
 #include "kernels.h"
+#include "group_kernels.h"
 
 namespace {
 constexpr int MODEL = 5;
@@ -179,12 +180,12 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__ xy,
-                                                            int n, double f, double cx, double cy, PnpPose P0,
-                                                            double thr2, double* __restrict__ hyp_pose,
-                                                            int* __restrict__ hyp_count,
-                                                            unsigned long long* __restrict__ hyp_mask, int mask_words,
-                                                            int* __restrict__ host_count, SvoPublish pub) {
+__device__ __forceinline__ void pnp_hypotheses_body(const float* __restrict__ xyz, const float* __restrict__ xy,
+                                                    int n, double f, double cx, double cy, PnpPose P0,
+                                                    double thr2, double* __restrict__ hyp_pose,
+                                                    int* __restrict__ hyp_count,
+                                                    unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                    int* __restrict__ host_count, SvoPublish pub) {
   svo_latency_critical();
   __shared__ LmShared S;
   __shared__ int sIdx[MODEL];
@@ -262,13 +263,13 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
   svo_publish_block_wt(pub);  // the only host payload is host_count (written through above): no write-back per workgroup
 }
 
-__global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
-                                                         double f, double cx, double cy, const double* __restrict__ hyp_pose,
-                                                         const unsigned long long* __restrict__ hyp_mask, int mask_words,
-                                                         int best, double* __restrict__ out_pose, int* __restrict__ inliers,
-                                                         int* __restrict__ n_inliers, double* __restrict__ host_pose,
-                                                         int* __restrict__ host_inliers, int* __restrict__ host_nin,
-                                                         float* __restrict__ inlier_xy, SvoPublish pub) {
+__device__ __forceinline__ void pnp_refine_body(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
+                                                double f, double cx, double cy, const double* __restrict__ hyp_pose,
+                                                const unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                int best, double* __restrict__ out_pose, int* __restrict__ inliers,
+                                                int* __restrict__ n_inliers, double* __restrict__ host_pose,
+                                                int* __restrict__ host_inliers, int* __restrict__ host_nin,
+                                                float* __restrict__ inlier_xy, SvoPublish pub) {
   svo_latency_critical();
   __shared__ LmShared S;
   __shared__ double sPart[256][28];
@@ -348,6 +349,41 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
     }
   }
   svo_publish_block(pub);
+}
+
+__global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__ xy,
+                                                            int n, double f, double cx, double cy, PnpPose P0,
+                                                            double thr2, double* __restrict__ hyp_pose,
+                                                            int* __restrict__ hyp_count,
+                                                            unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                            int* __restrict__ host_count, SvoPublish pub) {
+  pnp_hypotheses_body(xyz, xy, n, f, cx, cy, P0, thr2, hyp_pose, hyp_count, hyp_mask, mask_words, host_count, pub);
+}
+
+__global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
+                                                         double f, double cx, double cy, const double* __restrict__ hyp_pose,
+                                                         const unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                         int best, double* __restrict__ out_pose, int* __restrict__ inliers,
+                                                         int* __restrict__ n_inliers, double* __restrict__ host_pose,
+                                                         int* __restrict__ host_inliers, int* __restrict__ host_nin,
+                                                         float* __restrict__ inlier_xy, SvoPublish pub) {
+  pnp_refine_body(xyz, xy, n, f, cx, cy, hyp_pose, hyp_mask, mask_words, best, out_pose, inliers, n_inliers, host_pose, host_inliers,
+                  host_nin, inlier_xy, pub);
+}
+
+// stream-batched forms (group_kernels.h): blockIdx.y = lane, the same bodies
+__global__ __launch_bounds__(64) void pnp_hypotheses_group_kernel(SvoPnpHypLanes g) {
+  const SvoPnpHypLane& a = g.lane[blockIdx.y];
+  PnpPose P0;
+  for (int k = 0; k < 4; ++k) P0.q[k] = a.q0[k];
+  for (int k = 0; k < 3; ++k) P0.t[k] = a.t0[k];
+  pnp_hypotheses_body(a.xyz, a.xy, a.n, a.f, a.cx, a.cy, P0, a.thr2, a.hyp_pose, a.hyp_count, a.hyp_mask, a.mask_words, a.host_count, a.pub);
+}
+
+__global__ __launch_bounds__(256) void pnp_refine_group_kernel(SvoPnpRefLanes g) {
+  const SvoPnpRefLane& a = g.lane[blockIdx.y];
+  pnp_refine_body(a.xyz, a.xy, a.n, a.f, a.cx, a.cy, a.hyp_pose, a.hyp_mask, a.mask_words, a.best, a.out_pose, a.inliers, a.n_inliers,
+                  a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, a.pub);
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -456,5 +492,22 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, i
     SVO_HIP_CHECK(ctx, hipMemcpyAsync(inliers, din, sizeof(int) * (size_t)*n_inliers, hipMemcpyDeviceToHost, st));
     SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
   }
+  return SVO_OK;
+}
+
+int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters) { return update_num_iters(p, ep, model_points, max_iters); }
+int svo_pnp_model_points() { return MODEL; }
+
+int svo_kg_pnp_hypotheses(svo_ctx* ctx, hipStream_t st, const SvoPnpHypLanes& lanes, int n_lanes, int iterations) {
+  SvoProfScope prof(ctx, SVO_PROF_PNP_HYP, st);
+  hipLaunchKernelGGL(pnp_hypotheses_group_kernel, dim3(iterations, n_lanes), dim3(64), 0, st, lanes);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+int svo_kg_pnp_refine(svo_ctx* ctx, hipStream_t st, const SvoPnpRefLanes& lanes, int n_lanes) {
+  SvoProfScope prof(ctx, SVO_PROF_PNP_REFINE, st);
+  hipLaunchKernelGGL(pnp_refine_group_kernel, dim3(1, n_lanes), dim3(256), 0, st, lanes);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -13,6 +13,7 @@
 //   stereo_prefilter_kernel + stereo_dense_kernel : the drop-in for StereoBM::compute (full CV_16S map),
 //                          separable running-window SADs kept in LDS (see the kernel).
 #include "common.h"
+#include "group_kernels.h"
 #include "ref_constants.h"
 #include "tail_device.h"
 
@@ -162,13 +163,13 @@ __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restric
 
 // Sparse stereo AND the triangulation of src/image_processor.cpp:178-207 in one launch: one workgroup per feature, the
 // last one to arrive triangulates / compacts all of them (tail_device.h) and publishes the completion word.
-__global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
-                                                                 int W, int H, int stride, int ndisp, int block,
-                                                                 const float* __restrict__ xy, const int* __restrict__ n_dev,
-                                                                 int n_host, float* disp, SvoMat4 M,
-                                                                 float* __restrict__ kept_xy, float* __restrict__ xyz,
-                                                                 int* __restrict__ kept_index, int* __restrict__ n_kept,
-                                                                 SvoPublish pub) {
+__device__ __forceinline__ void stereo_triangulate_body(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                        int W, int H, int stride, int ndisp, int block,
+                                                        const float* __restrict__ xy, const int* __restrict__ n_dev,
+                                                        int n_host, float* disp, const SvoMat4& M,
+                                                        float* __restrict__ kept_xy, float* __restrict__ xyz,
+                                                        int* __restrict__ kept_index, int* __restrict__ n_kept,
+                                                        SvoPublish pub) {
   svo_latency_critical();
   __shared__ int sWaveT[4];
   __shared__ int sLast;
@@ -183,6 +184,30 @@ __global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* 
   SvoPublish one = pub;
   one.arrive = nullptr;  // the arrivals have been counted: this workgroup publishes alone
   svo_publish_block(one);
+}
+
+__global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
+                                                                 int W, int H, int stride, int ndisp, int block,
+                                                                 const float* __restrict__ xy, const int* __restrict__ n_dev,
+                                                                 int n_host, float* disp, SvoMat4 M,
+                                                                 float* __restrict__ kept_xy, float* __restrict__ xyz,
+                                                                 int* __restrict__ kept_index, int* __restrict__ n_kept,
+                                                                 SvoPublish pub) {
+  stereo_triangulate_body(L, R, W, H, stride, ndisp, block, xy, n_dev, n_host, disp, M, kept_xy, xyz, kept_index, n_kept, pub);
+}
+
+// stream-batched form (group_kernels.h): blockIdx.y = lane, the same body
+__global__ __launch_bounds__(256) void stereo_triangulate_group_kernel(SvoStereoTriLanes g) {
+  const SvoStereoTriLane& a = g.lane[blockIdx.y];
+  stereo_triangulate_body(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, a.xy, a.n_dev, a.n_max, a.disp, a.M, a.kept_xy, a.xyz,
+                          nullptr, a.n_kept, a.pub);
+}
+
+int svo_kg_stereo_triangulate(svo_ctx* ctx, hipStream_t st, const SvoStereoTriLanes& lanes, int n_lanes, int grid_x) {
+  SvoProfScope prof(ctx, SVO_PROF_STEREO_AT, st);
+  hipLaunchKernelGGL(stereo_triangulate_group_kernel, dim3(grid_x, n_lanes), dim3(256), 0, st, lanes);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
 }
 
 __global__ __launch_bounds__(256) void stereo_prefilter_kernel(const uint8_t* __restrict__ img, int W, int H, int stride,
