@@ -30,7 +30,7 @@ import time
 
 # HIP runtime knob, read when the runtime initialises: the default of 4 hardware queues makes the 2 HIP streams of
 # each stereo stream (tracker + bundle adjuster) share queues and serialise; measured +6 % at 8 streams.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # one hardware queue per HIP stream with a margin: a resident LM kernel holds its queue for a whole solve
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")  # the pipeline groups need four; beyond four a launch -> completion round trip costs 30-90 us instead of 7-11 (profiles/r02_exp_launch_rate.txt)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
     ap.add_argument("--streams", type=int, default=8, help="independent stereo streams processed concurrently per GPU")
+    ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
     ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
@@ -161,19 +162,59 @@ class _Stream:
         self.ctx.close()
 
 
+class _Group:
+    """`lanes` independent stereo streams behind ONE host thread (svo_pipeline_group): one context, stream-batched launches."""
+
+    def __init__(self, S, torch, local, seeds, B):
+        n = len(seeds)
+        self.ctx = S.Context(W, H, device=local, max_batch=n * B, max_corners=MAXC, max_candidates=1 << 16, max_features=MAX_FEAT)
+        data = [render_batch(S, sd, B) for sd in seeds]
+        self.p, self.L, self.R = data[0]
+        dev = torch.device("cuda", local)
+        self.dL = torch.from_numpy(np.stack([d[1] for d in data])).to(dev)  # (lanes, B, H, W)
+        self.dR = torch.from_numpy(np.stack([d[2] for d in data])).to(dev)
+        pp = S.pipeline_default_params()
+        pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = self.p.focal, self.p.cx, self.p.cy, self.p.baseline
+        pp.width, pp.height = W, H
+        pp.max_corners, pp.quality, pp.min_feature_distance = MAXC, QUALITY, MIN_DIST
+        pp.max_features, pp.window_size = MAX_FEAT, WINDOW
+        pp.ba_max_iterations, pp.ba_max_time_s = int(os.environ.get("SVO_BENCH_BA_ITERS", "50")), 0.0
+        self.pipe = S.PipelineGroup(self.ctx, pp, n)
+        self.B, self.n = B, n
+        self.res = None
+        self.all_res = None
+
+    def step(self):
+        self.pipe.reset()
+        self.all_res = self.pipe.process_batch_dev(self.dL.data_ptr(), self.dR.data_ptr(), self.B * W * H, self.B)
+        self.res = self.all_res[0]
+
+    def close(self):
+        self.pipe.close()
+        self.ctx.close()
+
+
 def run_kitti(args):
     import threading
     import stereo_vo_amd as S
     torch, dist, rank, local, world = dist_setup(args.gpus)
     B, NS = args.batch, max(1, args.streams)
-    streams = [_Stream(S, torch, local, 0x5EED0001 + rank * 64 + i, B) for i in range(NS)]
+    seeds = [0x5EED0001 + rank * 64 + i for i in range(NS)]
+    NG = max(0, min(args.groups, NS))
+    single_pipe = None
+    if NG > 0:  # pipeline groups: NG host threads, the streams dealt round-robin
+        streams = [_Group(S, torch, local, seeds[gi::NG], B) for gi in range(NG)]
+        if NS > 1:
+            single_pipe = _Stream(S, torch, local, seeds[0], B)
+    else:
+        streams = [_Stream(S, torch, local, sd, B) for sd in seeds]
     torch.cuda.synchronize()
     ctx = streams[0].ctx
     dev = torch.device("cuda", local)
 
     def run_steps(k):
         """k steps on every stream; streams run concurrently (ctypes releases the GIL inside the library)."""
-        if NS == 1:
+        if len(streams) == 1:
             for _ in range(k):
                 streams[0].step()
             return
@@ -188,11 +229,14 @@ def run_kitti(args):
     # single-stream rate (latency-bound: one sequential VO chain) measured first, in the same run
     single = None
     if NS > 1:
+        one = single_pipe if single_pipe is not None else streams[0]
+        for _ in range(max(1, args.warmup)):
+            one.step()
         barrier_sync(torch, dist, ctx)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            streams[0].step()
-        streams[0].ctx.sync()
+            one.step()
+        one.ctx.sync()
         dts = time.perf_counter() - t0
         single = {"value": B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps,
                   "note": "one stream alone on the GPU (per rank)"}
@@ -226,11 +270,13 @@ def run_kitti(args):
                    "streams_per_gpu": NS, "max_corners": MAXC, "quality": QUALITY, "min_distance": MIN_DIST, "window": WINDOW,
                    "keyframes_per_step": n_kf, "mean_tracked": float(np.mean(n_trk)) if n_trk else 0.0,
                    "ba_lm_iterations_per_step": ba_it, "host_cores_busy": round(host_cores, 2),
+                   "pipeline_groups": NG, "hardware_queues": int(os.environ.get("GPU_MAX_HW_QUEUES", "0")),
                    "sharding": "independent stereo streams: streams_per_gpu per rank, ranks hold different streams; no collective"},
     }
     if single is not None:
         out["single_stream"] = single
-    out["config"]["label"] = f"{NS} concurrent stream(s) per GPU, inputs resident in HBM (same {B} frames per step from a reset pipeline)"
+    out["config"]["label"] = (f"{NS} concurrent stream(s) per GPU" + (f" as {NG} pipeline group(s), one host thread each" if NG else ", one host thread each") +
+                              f", inputs resident in HBM (same {B} frames per step from a reset pipeline)")
     # roofline: (a) the SURVEY 8(d) contract figure of the whole front end, (b) the dominant kernel on the resource
     # that binds it (HIP events on the library's stream over the timed region + the committed SQ counter pass)
     avg_us = 1e3 * k_ms / k_n if k_n > 0 else None
@@ -260,8 +306,12 @@ def run_kitti(args):
             return np.array(c)
         ate = float(S.api.ate_rmse(centres(res[:m]), centres(ores[:m]), False)) if m >= 3 else 0.0
         out["parity_vs_cpu"] = {"frames": m, "index_sets_and_poses_identical": bool(same), "ate_rmse_m": ate}
+    if NG > 0:
+        out["config"]["launches_per_step"] = {k: v for k, v in streams[0].pipe.last_stats().items()}
     for st in streams:
         st.close()
+    if single_pipe is not None:
+        single_pipe.close()
     if dist is not None:
         dist.destroy_process_group()
     return out if rank == 0 else None

@@ -369,6 +369,29 @@ int svo_pipeline_process_batch(svo_pipeline* p, const uint8_t* left, const uint8
 /* Feature-set taps for parity tests: ids + positions the tracker holds after the last frame. */
 int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capacity, int* n);
 
+/* ------------------------------------------------------------ pipeline group --
+ * The same per-frame path (ImageProcessor::process + BundleAdjuster::bundle_adjust, src/image_processor.cpp:18-163,
+ * src/vo_node.cpp:141-148) for n_lanes independent stereo streams behind ONE caller thread: each lane keeps its own
+ * tracker, graph and poses exactly as an svo_pipeline does, every stage that several lanes reach together is ONE kernel
+ * launch (blockIdx.y = lane) and their bundle adjustments are ONE device-resident solve launch; lanes never wait for
+ * each other.  Lane results are bit-identical to n_lanes separate svo_pipeline objects.  The context's
+ * svo_limits.max_batch bounds n_lanes x frames per call.  (No reference counterpart: the reference is one stream in one
+ * process; this is how one GPU serves many of them — and what a rank of the multi-GPU bench runs.) */
+typedef struct svo_pipeline_group svo_pipeline_group;
+int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out, const svo_pipeline_params* p, int n_lanes);
+void svo_pipeline_group_destroy(svo_pipeline_group* g);
+int svo_pipeline_group_reset(svo_pipeline_group* g);
+int svo_pipeline_group_lanes(const svo_pipeline_group* g);
+/* left/right: DEVICE pointers; lane l's `batch` images (tight rows, image stride = width*height) start lane_stride bytes
+ * after lane l-1's.  results: n_lanes x batch, lane-major. */
+int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const uint8_t* left, const uint8_t* right, size_t lane_stride,
+                                         int batch, svo_frame_result* results);
+int svo_pipeline_group_get_tracked(svo_pipeline_group* g, int lane, int64_t* ids, float* xy, int capacity, int* n);
+/* Launch statistics of the last process_batch call, by stage: 0 track (LK + compaction), 1 PnP hypotheses, 2 PnP
+ * refinement, 3 dedup / stereo + triangulation, 4 bundle-adjustment solves, 5 corner detection + pyramids;
+ * launches6[i] launches carried lanes6[i] lane-stages in total. */
+int svo_pipeline_group_last_stats(const svo_pipeline_group* g, long* launches6, long* lanes6);
+
 /* FeatureTracker::draw_track + get_drawing (src/feature_tracker.cpp:74-91; used by src/vo_node.cpp:137,188):
  * the keyframe image as RGB (3 bytes per pixel, width*height*3 output) with one green arrow of thickness 4 per feature
  * from its keyframe position to its current position.  Host-side visualisation with this repository's own rasteriser

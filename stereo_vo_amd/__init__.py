@@ -6,5 +6,5 @@ wrappers that tests and bench.py use.  There is no CPU fallback: if the library 
 GPU is visible, compute entry points raise.
 """
 from .api import (SvoError, lib, lib_path, Context, Limits, SynthParams, synth_render, synth_pose,  # noqa: F401
-                  CameraInfo, BAOptions, BASummary, PipelineParams, FrameResult, BA, Pipeline,
+                  CameraInfo, BAOptions, BASummary, PipelineParams, FrameResult, BA, Pipeline, PipelineGroup,
                   pipeline_default_params, synth_default, image_read_gray, kitti_read_poses, ate_rmse, kitti_run, lm_solve, LmStats)

@@ -163,6 +163,8 @@ SYMBOLS = [
     "svo_rccl_unique_id", "svo_rccl_comm_create", "svo_rccl_comm_destroy",
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
+    "svo_pipeline_group_create", "svo_pipeline_group_destroy", "svo_pipeline_group_reset", "svo_pipeline_group_lanes",
+    "svo_pipeline_group_process_batch_dev", "svo_pipeline_group_get_tracked", "svo_pipeline_group_last_stats",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
     "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve", "svo_cholesky_solve_dev", "svo_draw_track", "svo_pipeline_draw_track",
 ]
@@ -591,6 +593,55 @@ class Pipeline:
         n = C.c_int(0)
         self.ctx._chk(self.L.svo_pipeline_get_tracked(self.h, _p(ids), _p(xy), capacity, C.byref(n)), "svo_pipeline_get_tracked")
         return ids[:n.value].copy(), xy[:n.value].copy()
+
+
+class PipelineGroup:
+    """svo_pipeline_group wrapper: n_lanes independent stereo streams behind one caller thread (stream-batched launches)."""
+
+    STAGES = ("track", "pnp_hypotheses", "pnp_refine", "dedup_stereo_triangulate", "bundle_adjust", "corners_pyramids")
+
+    def __init__(self, ctx, params, n_lanes):
+        self.ctx, self.L, self.prm, self.n_lanes = ctx, ctx.L, params, n_lanes
+        self.h = C.c_void_p()
+        self.L.svo_pipeline_group_destroy.argtypes = [C.c_void_p]
+        self.L.svo_pipeline_group_destroy.restype = None
+        self.L.svo_pipeline_group_process_batch_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        ctx._chk(self.L.svo_pipeline_group_create(ctx.h, C.byref(self.h), C.byref(params), n_lanes), "svo_pipeline_group_create")
+
+    def close(self):
+        if self.h:
+            self.L.svo_pipeline_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self.ctx._chk(self.L.svo_pipeline_group_reset(self.h), "svo_pipeline_group_reset")
+
+    def process_batch_dev(self, left_ptr, right_ptr, lane_stride, batch):
+        """left_ptr/right_ptr: raw device pointers to (n_lanes, B, H, W) uint8 images (lane_stride bytes between lanes).
+        Returns a list of n_lanes lists of FrameResult."""
+        res = (FrameResult * (self.n_lanes * batch))()
+        self.ctx._chk(self.L.svo_pipeline_group_process_batch_dev(self.h, C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_size_t(lane_stride),
+                                                                  batch, res), "svo_pipeline_group_process_batch_dev")
+        return [list(res[l * batch:(l + 1) * batch]) for l in range(self.n_lanes)]
+
+    def get_tracked(self, lane, capacity=8192):
+        ids = np.empty(capacity, np.int64)
+        xy = np.empty((capacity, 2), np.float32)
+        n = C.c_int(0)
+        self.ctx._chk(self.L.svo_pipeline_group_get_tracked(self.h, lane, _p(ids), _p(xy), capacity, C.byref(n)), "svo_pipeline_group_get_tracked")
+        return ids[:n.value].copy(), xy[:n.value].copy()
+
+    def last_stats(self):
+        """{stage: (launches, lane-stages carried)} of the last process_batch_dev call."""
+        a, b = (C.c_long * 6)(), (C.c_long * 6)()
+        self.ctx._chk(self.L.svo_pipeline_group_last_stats(self.h, a, b), "svo_pipeline_group_last_stats")
+        return {s: (a[i], b[i]) for i, s in enumerate(self.STAGES)}
 
 
 class RunStats(C.Structure):

@@ -114,7 +114,8 @@ struct BaDev {
   unsigned arrive_target = 0;
   int seq = 0;
   double* ctl_dev = nullptr;    // device [accept (0/1) | next radius]: the chained decision, read by the next pass A
-  int pay_dev = 0;              // the payload stays on the device and is read by other workgroups of THIS launch (ba_lm_kernel): agent-scope write-through, the slots' protocol
+  int pay_dev = 0;              // the payload stays on the device for the other workgroups of THIS launch (ba_lm_kernel): tagged granules, see granule_store
+  unsigned long long pay_tag = 0;  // ... the tag of the command in flight (unique per solve and command)
 };
 
 // Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
@@ -145,9 +146,50 @@ __device__ __forceinline__ double slot_load(const double* p) { return __hip_atom
 // cache level, so that `s_waitcnt vmcnt(0)` means "it has arrived" without any cache maintenance (see reduce_publish).
 __device__ __forceinline__ void pay_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // ... or on its way to the other workgroups of the same launch (P.pay_dev): the slots' protocol (sc1 write-through, read at the coherence point)
-__device__ __forceinline__ void pay_store(const BaDev& P, double* p, double v) {
-  if (P.pay_dev) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// Payload that stays on the device for the other workgroups of the SAME launch (ba_lm_kernel) travels as TAGGED GRANULES:
+// 16 bytes {value, tag}, written by ONE 16-byte write-through store, the tag unique per solve and command.  A reader takes
+// a value only when it finds the tag of the command it is waiting for, and reads again otherwise.  Why not "store,
+// s_waitcnt / release fence, arrival counter, load" as everywhere else: measured on MI355X under load (8 stereo streams, 8
+// solve launches in flight), a workgroup that had seen the arrival counter complete still read the PREVIOUS command's
+// values of a few reduction slices — with sc1 and sc0 sc1 loads, with atomic read-modify-writes as loads, with fine-grained
+// memory, with release fences in front of the arrivals — and a second read microseconds later returned the new ones: the
+// counter (one memory channel) can be observed before a write-through store to another channel.  Replicated step
+// control turns one such read into workgroups that take different branches; the tag makes the hand-over independent of
+// any ordering between different addresses.  (The contribution slots keep the counter protocol: a late slot would show
+// as a parity failure, which the bit-exact tests have never seen; they are read once per command, by one workgroup.)
+__device__ __forceinline__ void granule_store(double* g, double v, unsigned long long tag) { slot_store2<true>(g, v, __longlong_as_double((long long)tag)); }
+// up to 8 granules per call, all loads in flight together; idx < 0: skipped.  Returns the mask of granules whose tag matched.
+__device__ __forceinline__ unsigned granule_load8(const double* base, const int (&idx)[8], unsigned long long tag, double (&out)[8]) {
+  svo_d2 v0, v1, v2, v3, v4, v5, v6, v7;
+  const double* p0 = base + 2 * (idx[0] < 0 ? 0 : idx[0]); const double* p1 = base + 2 * (idx[1] < 0 ? 0 : idx[1]);
+  const double* p2 = base + 2 * (idx[2] < 0 ? 0 : idx[2]); const double* p3 = base + 2 * (idx[3] < 0 ? 0 : idx[3]);
+  const double* p4 = base + 2 * (idx[4] < 0 ? 0 : idx[4]); const double* p5 = base + 2 * (idx[5] < 0 ? 0 : idx[5]);
+  const double* p6 = base + 2 * (idx[6] < 0 ? 0 : idx[6]); const double* p7 = base + 2 * (idx[7] < 0 ? 0 : idx[7]);
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\tglobal_load_dwordx4 %1, %9, off sc1\n\tglobal_load_dwordx4 %2, %10, off sc1\n\t"
+      "global_load_dwordx4 %3, %11, off sc1\n\tglobal_load_dwordx4 %4, %12, off sc1\n\tglobal_load_dwordx4 %5, %13, off sc1\n\t"
+      "global_load_dwordx4 %6, %14, off sc1\n\tglobal_load_dwordx4 %7, %15, off sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4), "v"(p5), "v"(p6), "v"(p7)
+      : "memory");
+  const svo_d2 v[8] = {v0, v1, v2, v3, v4, v5, v6, v7};
+  unsigned ok = 0;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    out[u] = v[u].x;
+    if (idx[u] < 0 || (unsigned long long)__double_as_longlong(v[u].y) == tag) ok |= 1u << u;
+  }
+  return ok;
+}
+// one granule, waited for (bounded): false when its tag never showed up
+__device__ __forceinline__ bool granule_wait(const double* base, int idx, unsigned long long tag, double& out) {
+  const int only[8] = {idx, -1, -1, -1, -1, -1, -1, -1};
+  double v[8];
+  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+    if (granule_load8(base, only, tag, v) & 1u) { out = v[0]; return true; }
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
 }
 
 // The decision for the summed payload2 -> ctl_dev (for the pass-A launch queued behind) and payload slots 4 / 5 (for the host).
@@ -790,19 +832,19 @@ __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la,
     const int el = e_lo + tid;  // element of the destination
     if (P.pay_dev) {
       // payload for the other workgroups of this launch: every slice owns one 128-byte line (see PAY_STAGE_STRIDE)
-      __hip_atomic_store(&out[PAY_STAGE_STRIDE * b + tid], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      granule_store(&out[2 * (PAY_STAGE_STRIDE * b + tid)], acc, P.pay_tag);
     } else if (d < nU) {
       int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
       while (rest >= F - ka) { rest -= F - ka; ++ka; }
       const int kb = ka + rest;
-      pay_store(P, &out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6], acc);
+      pay_store(&out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6], acc);
     } else if (d < nU + F) {
       const int k = d - nU;
-      if (el < 6) pay_store(P, &out[(size_t)n * n + n + 6 * k + el], acc);                 // g_c
-      else if (el < 12) pay_store(P, &out[(size_t)n * n + 6 * k + (el - 6)], acc);         // g_red (the -Y g_p part)
-      else pay_store(P, &out[(size_t)n * n + 2 * n + 6 * k + (el - 12)], acc);             // diag U
+      if (el < 6) pay_store(&out[(size_t)n * n + n + 6 * k + el], acc);                 // g_c
+      else if (el < 12) pay_store(&out[(size_t)n * n + 6 * k + (el - 6)], acc);         // g_red (the -Y g_p part)
+      else pay_store(&out[(size_t)n * n + 2 * n + 6 * k + (el - 12)], acc);             // diag U
     } else {
-      pay_store(P, &out[(size_t)n * n + 3 * n + el], acc);
+      pay_store(&out[(size_t)n * n + 3 * n + el], acc);
     }
   }
   __syncthreads();
@@ -888,22 +930,27 @@ struct IterShared {
 };
 
 // RES: inside the resident kernel — the step block (with the current poses) is read coherently, see stage_step<true>.
-template <bool RES>
+// CPW: wave chunks per workgroup.  1: wave 0 works, the second wave only helps with the sums (ba_iterate_kernel: spreads the
+// chunks over the CUs).  2: both waves own a chunk (ba_lm_kernel: a solve then holds half as many wave slots — and, at 256
+// VGPRs a wave, half as many SIMD register files — for its whole duration).
+template <bool RES, int CPW = 1>
 __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, double spec_radius, const LmCtl& ctl, int with_pay1,
                                              int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy, double* sStep,
                                              IterShared& sh, int n_blocks /* workgroups of THIS solve (a launch may hold several) */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-  const bool worker = (int)blockIdx.x < P.C;  // workgroups beyond the chunks only reduce
+  const int my_chunk = (int)blockIdx.x * CPW + (wave < CPW ? wave : 0);
+  const bool worker = (int)blockIdx.x * CPW < P.C;  // workgroups beyond the chunks only reduce
+  const bool my_wave_works = wave < CPW && my_chunk < P.C;
   if (worker) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
-    if (wave == 0) R = load_obs(P, blockIdx.x, lane, P.points);  // requested before the step is staged: HBM and PCIe round trips overlap
+    if (my_wave_works) R = load_obs(P, my_chunk, lane, P.points);  // requested before the step is staged: HBM and PCIe round trips overlap
     stage_step<RES>(P, sStep);
     const double* dc_ = sStep;
     const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
     const double* cur_poses_ = RES ? cand_poses_ + 7 * P.K : P.poses;
     D3 cand = D3{0, 0, 1};
     double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
-    if (wave == 0) {
+    if (my_wave_works) {
       backsub_chunk<true>(P, R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
       if (spec_radius > 0) {
         R.p = cand;
@@ -918,12 +965,17 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
       if (sh.sLast) {
         reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
         const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
-        if (tid < 6) pay_store(P, &P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
-        if (tid == 0) {
-          __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius;
+        if (P.pay_dev) {  // tagged granules: payload2 + decision for the replicated step control, the decision for the waiting workgroups
+          if (tid < 6) granule_store(&P.pay2_out[2 * tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius), P.pay_tag);
+          if (tid == 0) { granule_store(&P.ctl_dev[0], (double)dec.accept, P.pay_tag); granule_store(&P.ctl_dev[2], dec.next_radius, P.pay_tag); }
+        } else {
+          if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
+          if (tid == 0) {
+            __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
+        if (tid == 0) { sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius; }
         stores_acknowledged();  // the decision (device) and payload2 (host) have arrived before anybody can see the post
         __syncthreads();
         if (tid == 0) __hip_atomic_store(sy.posted, sy.post_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -931,14 +983,20 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
         __syncthreads();
       } else {
         if (tid == 0) {
-          const bool ok = wait_until(sy.posted, sy.post_seq, false);
-          sh.sDec[0] = slot_load(&P.ctl_dev[0]); sh.sDec[1] = slot_load(&P.ctl_dev[1]);
+          bool ok = wait_until(sy.posted, sy.post_seq, false);
+          if (P.pay_dev) {
+            double d0 = 0, d1 = 0;
+            ok = ok && granule_wait(P.ctl_dev, 0, P.pay_tag, d0) && granule_wait(P.ctl_dev, 1, P.pay_tag, d1);
+            sh.sDec[0] = d0; sh.sDec[1] = d1;
+          } else {
+            sh.sDec[0] = slot_load(&P.ctl_dev[0]); sh.sDec[1] = slot_load(&P.ctl_dev[1]);
+          }
           sh.sGo = ok;
         }
         __syncthreads();
       }
       if (!sh.sGo) return;
-      if (wave == 0) {
+      if (my_wave_works) {
         const bool accept = sh.sDec[0] != 0.0;
         if (accept) R.p = cand;
         linearize_chunk<true>(P, R, accept ? cand_poses_ : cur_poses_, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
@@ -956,7 +1014,8 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
   if (!sh.sGo) return;
   if (sums2) {
     reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-    if (tid < 4) pay_store(P, &P.pay2_out[tid], sh.sOut[tid]);
+    if (P.pay_dev) { if (tid < 4) granule_store(&P.pay2_out[2 * tid], sh.sOut[tid], P.pay_tag); }
+    else if (tid < 4) pay_store(&P.pay2_out[tid], sh.sOut[tid]);
   }
   for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
   reduce_publish(P);
@@ -1003,13 +1062,18 @@ struct LmDevArgs {
   double* host_result;      // pinned: [LMR_* summary (16 doubles) | poses 7 K]
   int* host_flag;           // pinned completion word of the solve
   int host_seq;
+  // The counters are never reset: they run on from solve to solve (a reset by the finishing launch raced with the first
+  // arrivals of the adjuster's next launch on another stream — stores can land late, see granule_store); the finishing
+  // solve reports where it left them (LMR_C_*), the host hands that to the next one.
+  unsigned base_arrive, base_done, base_arrived, base_posted, base_copied;
   LmDevOpt opt;
   unsigned* dbg;            // per workgroup 8 words: its last command (diagnostics of a solve that gave up; null: none)
 };
 constexpr double LM_DEVICE_MIN_TIME_CAP_S = 0.02;
 enum { LMC_ARRIVE = 0, LMC_DONE = 1, LMC_ARRIVED = 2, LMC_POSTED = 3, LMC_COPIED = 4, LMC_EXITED = 5, LMC_CTL = 8, LMC_WORDS = 16 };
 enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
-       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED, LMR_DOUBLES = 16 };
+       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED,
+       LMR_C_ARRIVE, LMR_C_DONE, LMR_C_ARRIVED, LMR_C_POSTED, LMR_C_COPIED, LMR_DOUBLES = 24 };
 enum { LMS_START = 0, LMS_FIRST, LMS_RELIN, LMS_STEP, LMS_ACCEPT_RELIN, LMS_DELIVER };
 enum { LMOP_EXIT = 0, LMOP_LINEARIZE, LMOP_ITERATE, LMOP_DELIVER, LMOP_ABORT };
 
@@ -1018,7 +1082,9 @@ struct LmDevState {
   int iterations, successful, termination, need_linearize, state, sel, chain, first, saturated;
   unsigned arrived_total, post_seq, done_total, arrive_total;
   int lin_calls, step_calls, same_sweeps, next_used;
-  int go, act, use_next, accepted, relin;
+  int go, act, use_next, accepted, relin, bad;
+  unsigned long long tag;   // of the command in flight: (solve sequence << 20) | command number
+  unsigned op_count;
   long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: waiting for the reduction, step control, passes
 };
 constexpr double LM_MIN_RADIUS = 1e-32, LM_MAX_RADIUS = 1e16;
@@ -1026,23 +1092,37 @@ constexpr double LM_MIN_RADIUS = 1e-32, LM_MAX_RADIUS = 1e16;
 // controller workspace (doubles): payload1 image, 4 vectors of n, payload2, term scratch
 static inline size_t ba_lm_ctl_doubles(int n, int K) { return (size_t)n * n + 3 * (size_t)n + 2 + 5 * (size_t)(n > 0 ? n : 1) + 8 + 14 * (size_t)K + 8; }
 
-// payload1 out of its staging (one 128-byte line per reduction slice) into the logical layout in LDS; up to 8 loads per
-// thread are in flight before the first is stored
-__device__ __forceinline__ void lm_fetch_staged(double* cP, const double* stage, int F, int n) {
+// payload1 out of its staging (16 tagged granules per reduction slice) into the logical layout in LDS; up to 8 granules
+// per thread are in flight; a granule whose tag is not the awaited one is read again.  false: a tag never showed up.
+__device__ __forceinline__ bool lm_fetch_staged(double* cP, const double* stage, int F, int n, unsigned long long tag) {
   const int count = PAY_STAGE_STRIDE * ba_reduce_blocks(F);
+  bool good = true;
   for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
-    double v[8];
-    int at[8];
+    int gi[8], at[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
       at[u] = i < count ? pay_stage_index(i / PAY_STAGE_STRIDE, i % PAY_STAGE_STRIDE, F, n) : -1;
-      v[u] = at[u] >= 0 ? slot_load(&stage[i]) : 0.0;
+      gi[u] = at[u] >= 0 ? i : -1;
     }
+    double v[8];
+    unsigned ok = granule_load8(stage, gi, tag, v);
+    for (unsigned spins = 0; ok != 0xFFu && spins < (1u << 20); ++spins) {
+      __builtin_amdgcn_s_sleep(2);
+      int again[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) again[u] = (ok >> u) & 1u ? -1 : gi[u];
+      double w[8];
+      const unsigned ok2 = granule_load8(stage, again, tag, w);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (!((ok >> u) & 1u) && ((ok2 >> u) & 1u)) { v[u] = w[u]; ok |= 1u << u; }
+    }
+    good = good && ok == 0xFFu;
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (at[u] >= 0) cP[at[u]] = v[u];
   }
+  return good;
 }
 
 // `count` doubles from device memory (written by other workgroups of this launch) into LDS: all loads of a thread are
@@ -1068,7 +1148,7 @@ __device__ __forceinline__ void lm_fetch(double* dst, const double* src, int cou
 // [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
 __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* sStep) {
   const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
-  const int grid = P.C, nb = ba_reduce_blocks(K - 1);  // one workgroup per chunk of THIS solve (the launch may hold several solves)
+  const int grid = (P.C + 1) / 2, nb = ba_reduce_blocks(K - 1);  // workgroups of THIS solve: two wave chunks each (the launch may hold several solves)
   const int pay1 = n * n + 3 * n + 2;
   double* cP = cl;             // payload1 image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
   double* cSc = cP + pay1;     // Jacobi scales of the pose columns
@@ -1080,7 +1160,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   double* cDc = sStep;         // the step block is built in place
   double* cCand = sStep + nn;
   double* cPose = cCand + 7 * K;
-  const double* dpay1 = a.dev_pay + PAY_STAGE_STRIDE;  // payload2 owns the first line
+  const double* dpay1 = a.dev_pay + 2 * PAY_STAGE_STRIDE;  // granules: payload2 owns the first 8, the decision the next 8
   const LmDevOpt& opt = a.opt;
   enum { ACT_NONE = 0, ACT_LOOPTOP, ACT_FINISH, ACT_ACCEPT_TAIL, ACT_SOLVE };
   int act = ACT_NONE;
@@ -1092,9 +1172,11 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       else if (op == LMOP_ITERATE) publishers = with_pay1 ? min(grid, nb) : 1;
       cs.arrive_total += (unsigned)publishers;
       if (op != LMOP_DELIVER) cs.done_total += (unsigned)grid;
-      if (op == LMOP_ITERATE && chain) { cs.arrived_total += (unsigned)P.C; cs.post_seq++; }
+      if (op == LMOP_ITERATE && chain) { cs.arrived_total += (unsigned)grid; cs.post_seq++; }
+      cs.tag = ((unsigned long long)(unsigned)a.host_seq << 20) | (unsigned long long)(++cs.op_count & 0xFFFFFu);
       const long long tn = (long long)wall_clock64();
-      cs.t_ctl += tn - cs.t_mark; cs.t_mark = tn;
+      if (!a.dbg) cs.t_ctl += tn - cs.t_mark;
+      cs.t_mark = tn;
     }
     __syncthreads();
     return op;
@@ -1103,12 +1185,12 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   const int st = cs.state;  // stable: written before the barrier that ended the previous turn
   if (st == LMS_START) {
     if (tid == 0) {
-      cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, (unsigned)P.C, true) : 1;
+      cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, a.base_copied + (unsigned)grid, true) : 1;
       cs.radius = opt.initial_radius; cs.df = 2.0; cs.cost = 0.0; cs.initial_cost = 0.0; cs.mcc = 0.0;
       cs.t0 = cs.t_mark = (long long)wall_clock64();
       cs.iterations = 0; cs.successful = 0; cs.termination = 1; cs.need_linearize = 0; cs.sel = 0; cs.chain = 0; cs.spec = 0.0; cs.saturated = 0;
-      cs.arrived_total = 0; cs.post_seq = 0; cs.done_total = 0; cs.arrive_total = 0;
-      cs.lin_calls = 1; cs.step_calls = 0; cs.same_sweeps = 0; cs.next_used = 0;
+      cs.arrived_total = a.base_arrived; cs.post_seq = a.base_posted; cs.done_total = a.base_done; cs.arrive_total = a.base_arrive;
+      cs.lin_calls = 1; cs.step_calls = 0; cs.same_sweeps = 0; cs.next_used = 0; cs.bad = 0; cs.op_count = 0; cs.tag = 0;
       cs.t_wait = cs.t_ctl = cs.t_body = 0;
       cs.state = LMS_FIRST; cs.first = 1;
     }
@@ -1124,14 +1206,14 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     cs.t_body += w0 - cs.t_mark;
     cs.go = wait_until(a.cnt + LMC_ARRIVE, cs.arrive_total, true);
     cs.t_mark = (long long)wall_clock64();
-    cs.t_wait += cs.t_mark - w0;
+    if (!a.dbg) cs.t_wait += cs.t_mark - w0;
     cs.first = 0;
   }
   __syncthreads();
   if (!cs.go) return LMOP_ABORT;
 
   if (st == LMS_STEP) {
-    if (tid < 6) cPay2[tid] = slot_load(&a.dev_pay[tid]);
+    if (tid < (cs.chain ? 6 : 4) && !granule_wait(a.dev_pay, tid, cs.tag, cPay2[tid])) cs.bad = 1;  // the decision granules exist only behind a chained step
     for (int i = tid; i < 7 * K; i += nt) {  // terms of the pose part of |step|^2 and |x|^2 (host/lm.cpp after ops->step)
       const double dd = cCand[i] - cPose[i];
       cTerm[i] = dd * dd;
@@ -1179,7 +1261,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
     __syncthreads();
     if (cs.accepted) for (int i = tid; i < 7 * K; i += nt) cPose[i] = cCand[i];
-    if (cs.use_next) lm_fetch_staged(cP, dpay1, K - 1, n);
+    if (cs.use_next && !lm_fetch_staged(cP, dpay1, K - 1, n, cs.tag)) cs.bad = 1;
     act = cs.act;
     const bool relin = act == ACT_ACCEPT_TAIL && cs.relin;
     __syncthreads();  // thread 0 writes cs.act again below
@@ -1189,12 +1271,19 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
   } else {
     // a stand-alone pass A has finished: its payload is the linearisation in use
-    lm_fetch_staged(cP, dpay1, K - 1, n);
+    if (!lm_fetch_staged(cP, dpay1, K - 1, n, cs.tag)) cs.bad = 1;
     __syncthreads();
     if (st == LMS_FIRST) {
       if (tid == 0) { cs.cost = cP[pay1 - 2]; cs.initial_cost = cs.cost; }
       for (int q = tid; q < n; q += nt) cSc[q] = 1.0 / (1.0 + sqrt(cP[n * n + 2 * n + q]));
       act = ACT_ACCEPT_TAIL;  // the same gradient test
+      __syncthreads();
+      if (a.dbg && tid == 0) {  // diagnostics: the first payload and the scales derived from it
+        unsigned long long x = 0, y = 0;
+        for (int i = 0; i < pay1; ++i) if ((i >= n * n) || ((i % n) / 6 >= (i / n) / 6)) x = (x * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cP[i]);
+        for (int i = 0; i < n; ++i) y = (y * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cSc[i]);
+        cs.t_wait = (long long)x; cs.t_ctl = (long long)y;  // (diagnostic build: timing slots reused)
+      }
     } else if (st == LMS_RELIN) {
       if (tid == 0) cs.need_linearize = 0;
       act = ACT_SOLVE;
@@ -1204,6 +1293,8 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     __syncthreads();
   }
 
+  __syncthreads();
+  if (cs.bad) return LMOP_ABORT;  // a granule's tag never showed up (bounded wait): give up, the host reports it
   for (;;) {  // uniform in the workgroup: every transition is decided by thread 0 and read between two barriers
     if (act == ACT_ACCEPT_TAIL) {
       for (int q = tid; q < n; q += nt) { const double g = cP[n * n + n + q]; cTerm[q] = g * g; }
@@ -1246,6 +1337,9 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
           pay_store(&r[LMR_T_WAIT], (double)cs.t_wait); pay_store(&r[LMR_T_CTL], (double)(cs.t_ctl + (tn - cs.t_mark)));
           pay_store(&r[LMR_T_BODY], (double)cs.t_body); pay_store(&r[LMR_T_TOTAL], (double)(tn - cs.t0));
           pay_store(&r[LMR_SAME_SWEEP], (double)cs.same_sweeps); pay_store(&r[LMR_NEXT_USED], (double)cs.next_used);
+          pay_store(&r[LMR_C_ARRIVE], (double)(cs.arrive_total + (unsigned)grid)); pay_store(&r[LMR_C_DONE], (double)cs.done_total);  // + the delivery's arrivals
+          pay_store(&r[LMR_C_ARRIVED], (double)cs.arrived_total); pay_store(&r[LMR_C_POSTED], (double)cs.post_seq);
+          pay_store(&r[LMR_C_COPIED], (double)(a.base_copied + (a.arena_src ? (unsigned)grid : 0u)));
         }
         for (int i = tid; i < 7 * K; i += nt) pay_store(&a.host_result[LMR_DOUBLES + i], cPose[i]);
       }
@@ -1253,6 +1347,21 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
     // ACT_SOLVE: scaled, damped reduced camera system (host/lm.cpp) -> Cholesky -> pose step
     const double radius = cs.radius;
+    if (a.dbg) {
+      double* img = reinterpret_cast<double*>(a.dbg + 16 * 4096) + (size_t)blockIdx.x * 1024;
+      if (pay1 + n <= 1024) {
+        for (int i = tid; i < pay1; i += nt) img[i] = cP[i];
+        for (int i = tid; i < n; i += nt) img[pay1 + i] = cSc[i];
+      }
+    }
+    if (a.dbg && tid == 0) {  // diagnostics: what this workgroup's step control is about to factorise
+      unsigned long long x = 0, y = 0;
+      for (int i = 0; i < pay1; ++i) if ((i >= n * n) || ((i % n) / 6 >= (i / n) / 6)) x = (x * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cP[i]);
+      for (int i = 0; i < n; ++i) y = (y * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cSc[i]);
+      unsigned* gdb = a.dbg + 16 * blockIdx.x + 8;
+      gdb[0] = (unsigned)(x >> 32); gdb[1] = (unsigned)x; gdb[2] = (unsigned)(y >> 32); gdb[3] = (unsigned)y;
+      gdb[4] = (unsigned)((unsigned long long)cs.t_wait >> 32); gdb[5] = (unsigned)cs.t_wait; gdb[6] = (unsigned)cs.iterations; gdb[7] = (unsigned)((unsigned long long)cs.t_ctl >> 32);
+    }
     for (int q = tid; q < n; q += nt) {
       const double sq = cSc[q];
       cDf[q] = fmin(fmax(cP[n * n + 2 * n + q] * sq * sq, MIN_DIAG), MAX_DIAG) / radius;
@@ -1356,21 +1465,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the solve's record: one PCIe read per workgroup, then LDS / registers
     const unsigned* src = reinterpret_cast<const unsigned*>(lanes.p[blockIdx.y]);
     unsigned* dst = reinterpret_cast<unsigned*>(&sLane);
-    for (int i = tid; i < (int)(sizeof(LmLane) / 4); i += blockDim.x) dst[i] = src[i];
+    // system-scope loads: a plain load may be served from a line this XCD's L2 kept from the adjuster's PREVIOUS launch
+    // (measured: workgroups that took the previous problem's chunk count and left at once)
+    for (int i = tid; i < (int)(sizeof(LmLane) / 4); i += blockDim.x) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
-  if ((int)blockIdx.x >= sLane.P.C) return;  // the launch is as wide as its largest solve
+  constexpr int CPW = 2;  // both waves of a workgroup own a wave chunk
+  if ((int)blockIdx.x * CPW >= sLane.P.C) return;  // the launch is as wide as its largest solve
   BaDev P = sLane.P;
   const LmDevArgs& a = sLane.a;
   const ListArgs& la = sLane.la;
-  const int lm_begin = sLane.lm_begin, lm_count = sLane.lm_count, n_blocks = P.C;
+  const int lm_begin = sLane.lm_begin, lm_count = sLane.lm_count, n_blocks = (P.C + CPW - 1) / CPW;
+  const int my_chunk = (int)blockIdx.x * CPW + wave;
+  const bool my_wave_works = my_chunk < P.C;
   __builtin_amdgcn_s_setprio(3);
   P.step_in = nullptr;  // the step block is already in LDS (stage_step<true> then only synchronises)
-  P.pay2_out = a.dev_pay; P.pay1_out = a.dev_pay + PAY_STAGE_STRIDE; P.pay_dev = 1;
+  P.pay2_out = a.dev_pay; P.pay1_out = a.dev_pay + 2 * PAY_STAGE_STRIDE; P.pay_dev = 1;  // granules: [payload2 (8) | decision (8) | 16 per reduction slice]
   P.arrive = a.cnt + LMC_ARRIVE;
   P.flag = reinterpret_cast<int*>(a.cnt + LMC_CTL + 4);  // a word nobody reads: completion is the arrival counter itself
   P.seq = 0;
-  P.ctl_dev = reinterpret_cast<double*>(a.cnt + LMC_CTL);
+  P.ctl_dev = a.dev_pay + 2 * 8;
   if (tid == 0) cs.state = LMS_START;
   if (a.arena_src) {
     const double* src = reinterpret_cast<const double*>(a.arena_src);
@@ -1383,27 +1497,32 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid == 0) __hip_atomic_fetch_add(a.cnt + LMC_COPIED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  bool leave_clean = false;
   for (;;) {
     const int op = lm_controller(P, a, cs, ctl_lds, sStep);
     if (a.dbg && tid == 0) {
-      unsigned* g = a.dbg + 8 * blockIdx.x;
+      unsigned* g = a.dbg + 16 * blockIdx.x;
       g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
       g[4] = (unsigned)cs.chain; g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
     }
-    if (op == LMOP_ABORT) return;
-    if (op == LMOP_EXIT) { leave_clean = true; break; }
+    if (op == LMOP_ABORT || cs.bad) return;
+    if (op == LMOP_EXIT) break;
     const bool sel = cs.sel != 0;
     P.points = sel ? a.points_b : a.points_a;
     P.cand_points = sel ? a.points_a : a.points_b;
     P.arrive_target = cs.arrive_total;
+    P.pay_tag = cs.tag;
     if (op == LMOP_DELIVER) {
-      if (a.export_points && (int)blockIdx.x < P.C && wave == 0) {
-        const ObsRec R = load_obs(P, blockIdx.x, lane, P.points);
-        deliver_chunk_points(R, a.export_points, sStep, RES_STEP_LDS_DOUBLES);  // the step block is no longer needed
+      if (a.export_points && my_wave_works) {
+        const ObsRec R = load_obs(P, my_chunk, lane, P.points);
+        deliver_chunk_points(R, a.export_points, sStep + wave * (RES_STEP_LDS_DOUBLES / CPW), RES_STEP_LDS_DOUBLES / CPW);  // the step block is no longer needed
       }
-      P.flag = a.host_flag; P.seq = a.host_seq;
-      reduce_publish(P);
+      // everybody's results are out; the last workgroup to arrive publishes the host's completion word
+      stores_acknowledged();
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.cnt + LMC_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == P.arrive_target) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       __syncthreads();
       continue;  // the next controller turn answers "delivered": everybody leaves
     }
@@ -1414,11 +1533,11 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const double radius = cs.radius;
     if (op == LMOP_ITERATE) {
       const LmCtl ctl = {cs.cost, cs.mcc, radius, cs.df, cs.chain};
-      iterate_body<true>(P, radius, cs.spec, ctl, cs.chain || cs.spec > 0, lm_begin, lm_count, la, sy, sStep, sh, n_blocks);
+      iterate_body<true, CPW>(P, radius, cs.spec, ctl, cs.chain || cs.spec > 0, lm_begin, lm_count, la, sy, sStep, sh, n_blocks);
     } else {  // pass A alone at the current point, then the reduction
       const int first = cs.first;
-      if ((int)blockIdx.x < P.C && wave == 0) {
-        const ObsRec R = load_obs(P, blockIdx.x, lane, P.points);
+      if (my_wave_works) {
+        const ObsRec R = load_obs(P, my_chunk, lane, P.points);
         double unused0 = 0, unused1 = 0;
         linearize_chunk<true>(P, R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, first, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
         stores_acknowledged();
@@ -1435,11 +1554,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
     __syncthreads();
-  }
-  if (leave_clean && tid == 0) {
-    // the counters go back to zero for the next solve on this adjuster (stream order: it starts after this launch has ended)
-    if (__hip_atomic_fetch_add(a.cnt + LMC_EXITED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)n_blocks)
-      for (int i = 0; i < LMC_CTL; ++i) __hip_atomic_store(a.cnt + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1773,6 +1887,7 @@ struct svo_ba {
   bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
   hipStream_t lm_stream = nullptr;  // ... on this stream
   LmLane* h_lane = nullptr;      // pinned launch record of this adjuster's solve
+  unsigned lm_base[5] = {0, 0, 0, 0, 0};  // where the last solve left the device counters (arrive, done, arrived, posted, copied)
   bool lm_counters_dirty = false;  // the last kernel did not leave through its clean exit: zero the counters before the next launch
   std::chrono::steady_clock::time_point lm_t0;
   double* h_pay = nullptr;
@@ -1819,10 +1934,11 @@ static int ba_alloc(svo_ba* ba) {
   // still held), its replicated step control then took a different branch than everybody else's.  Fine-grained memory is
   // the architected answer: not retained in L2, coherent at agent scope.  (Counters only ever see atomics; the
   // contribution slots are written and read once per iteration at addresses a workgroup's XCD does not otherwise touch.)
-  SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_pay_fg, sizeof(double) * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)), hipDeviceMallocFinegrained));
+  SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_pay_fg, sizeof(double) * 2 * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)), hipDeviceMallocFinegrained));
   SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_lmc, sizeof(unsigned) * LMC_WORDS, hipDeviceMallocFinegrained));
-  SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_lane, sizeof(LmLane), hipHostMallocDefault));
-  if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 8 * 4096);
+  SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_lane, sizeof(LmLane), hipHostMallocCoherent));
+  if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 16 * 4096 + 2 * 1024 * 128 + 8 * 256);
+  if (ba->d_lmdbg) SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmdbg, 0, sizeof(unsigned) * (16 * 4096 + 2 * 1024 * 128 + 8 * 256)));
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned)));
   A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
@@ -2316,8 +2432,18 @@ int ba_fused_budget() {
 // larger reduced camera system (10-keyframe windows) lowers the kernel's occupancy, its workgroups then count for more.
 int ba_lm_admission_cost(int grid, size_t lds) {
   (void)ba_fused_budget();
+  static std::mutex mu;
+  static size_t cached_lds[8];
+  static int cached_per_cu[8], n_cached = 0;
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_lm_kernel, 128, lds) != hipSuccess || per_cu <= 0) return 1 << 30;
+  {
+    std::lock_guard<std::mutex> g(mu);
+    for (int i = 0; i < n_cached; ++i) if (cached_lds[i] == lds) per_cu = cached_per_cu[i];
+    if (!per_cu) {
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_lm_kernel, 128, lds) != hipSuccess || per_cu <= 0) return 1 << 30;
+      if (n_cached < 8) { cached_lds[n_cached] = lds; cached_per_cu[n_cached++] = per_cu; }
+    }
+  }
   if (per_cu >= g_fused_per_cu) return grid;
   return (grid * g_fused_per_cu + per_cu - 1) / per_cu;
 }
@@ -2360,20 +2486,21 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out) {
   L.P = d;
   LmDevArgs& a = L.a;
   a.cnt = ba->d_lmc;
-  a.arena_src = ba->arena_dirty ? ba->h_arena : nullptr; a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;
+  a.arena_src = nullptr; a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;  // copied in front of the launch (ba_device_lm_launch)
   a.points_a = ba->cur_points; a.points_b = ba->cand_points;
   a.export_points = ba->n_points ? ba->h_out_points : nullptr;
   a.dev_pay = ba->d_pay_fg;
   a.host_result = ba->h_result;
   a.host_flag = ba->h_flag; a.host_seq = ba->seq + 1;  // committed by the launch
+  a.base_arrive = a.base_done = a.base_arrived = a.base_posted = a.base_copied = 0;  // cleared in front of the launch
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
-  a.dbg = d.C <= 4096 ? ba->d_lmdbg : nullptr;
+  a.dbg = d.C <= 256 ? ba->d_lmdbg : nullptr;
   L.lm_begin = ba->h_list_begin[nd - 1];
   L.lm_count = ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1];
   L.la = ba_list_args(ba);
-  *cost = ba_lm_admission_cost(d.C, lds);
+  *cost = ba_lm_admission_cost((d.C + 1) / 2, lds);
   *lds_out = lds;
   return true;
 }
@@ -2393,12 +2520,20 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st) {
     if (!ba_device_lm_fill(ba, &cost, &lds)) break;
     if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) break;
     if (!ba_resident_admission(ba)->admit(cost)) break;
-    if (ba->lm_counters_dirty) {
-      if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
-      ba->lm_counters_dirty = false;
+    // the counters start from zero: cleared in front of the launch (the adjuster's previous solve no longer touches them
+    // once its completion word is out; a reset by the finishing kernel itself raced with this launch's first arrivals)
+    if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
+    ba->lm_counters_dirty = false;
+    // The problem image goes up by a copy IN FRONT of the launch (stream order + kernel boundary).  Round 2's resident kernel —
+    // and this one at first — fetched it itself, every workgroup a share, write-through, then an arrival counter: under load
+    // a workgroup could pass the counter and still read the previous solve's records (a late store again, see
+    // granule_store), i.e. garbage indices.
+    if (ba->arena_dirty && hipMemcpyAsync(ba->d_arena, ba->h_arena, ba->arena_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
+      ba_resident_admission(ba)->release();
+      break;
     }
     ptrs.p[i] = ba->h_lane;
-    max_c = std::max(max_c, ba->d.C);
+    max_c = std::max(max_c, (ba->d.C + 1) / 2);
     max_lds = std::max(max_lds, lds);
     ++launched;
   }
@@ -2440,14 +2575,41 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
       (void)hipMemcpy(c, ba->d_lmc, sizeof(c), hipMemcpyDeviceToHost);
       fprintf(stderr, "[svo ba] device solve gave up: grid %d K %d arrive %u done %u arrived %u posted %u copied %u exited %u\n", d.C, d.K,
               c[LMC_ARRIVE], c[LMC_DONE], c[LMC_ARRIVED], c[LMC_POSTED], c[LMC_COPIED], c[LMC_EXITED]);
+      if (ba->d_lmdbg && d.C <= 256) {
+        unsigned rr[8 * 256];
+        (void)hipMemcpy(rr, ba->d_lmdbg + 16 * 4096 + 2 * 1024 * 128, sizeof(rr), hipMemcpyDeviceToHost);
+        for (int b = 0; b < 256; ++b) if (rr[8 * b]) {
+          double lds, mem; unsigned long long a_ = ((unsigned long long)rr[8 * b + 2] << 32) | rr[8 * b + 3], b_ = ((unsigned long long)rr[8 * b + 4] << 32) | rr[8 * b + 5];
+          memcpy(&lds, &a_, 8); memcpy(&mem, &b_, 8);
+          fprintf(stderr, "[svo ba]   re-read mismatch in workgroup %d: %u words, first at staging item %u (slice %u): LDS %.17g, memory now %.17g; waited for arrive %u, counter %u\n", b, rr[8 * b],
+                  rr[8 * b + 1], rr[8 * b + 1] / 16, lds, mem, rr[8 * b + 6], rr[8 * b + 7]);
+        }
+        (void)hipMemset(ba->d_lmdbg + 16 * 4096 + 2 * 1024 * 128, 0, sizeof(rr));
+        const int nwg = (d.C + 1) / 2, p1 = d.n * d.n + 3 * d.n + 2 + d.n;
+        std::vector<double> img((size_t)nwg * 1024);
+        (void)hipMemcpy(img.data(), reinterpret_cast<double*>(ba->d_lmdbg + 16 * 4096), sizeof(double) * img.size(), hipMemcpyDeviceToHost);
+        if (p1 <= 1024) for (int b = 1; b < nwg; ++b) {
+          int nd = 0, first = -1, last = -1;
+          for (int i = 0; i < p1; ++i) if (memcmp(&img[(size_t)b * 1024 + i], &img[i], 8)) {
+            const int r = i / std::max(d.n, 1), c = i % std::max(d.n, 1);
+            if (i < d.n * d.n && c / 6 < r / 6) continue;  // lower blocks: never delivered
+            if (nd < 8) fprintf(stderr, "[svo ba]   image of workgroup %d differs at word %d (row %d col %d): %.17g vs %.17g\n", b, i, r, c, img[(size_t)b * 1024 + i], img[i]);
+            if (first < 0) first = i;
+            last = i; ++nd;
+          }
+          if (nd) fprintf(stderr, "[svo ba]   workgroup %d: %d differing words of %d, first %d last %d (n %d)\n", b, nd, p1, first, last, d.n);
+        }
+      }
       if (ba->d_lmdbg && d.C <= 4096) {
-        std::vector<unsigned> g(8 * (size_t)d.C);
+        std::vector<unsigned> g(16 * (size_t)d.C);
         (void)hipMemcpy(g.data(), ba->d_lmdbg, sizeof(unsigned) * g.size(), hipMemcpyDeviceToHost);
         for (int b = 0; b < d.C; ++b) {
-          const unsigned* q = &g[8 * (size_t)b];
+          const unsigned* q = &g[16 * (size_t)b];
           if (b == 0 || memcmp(q, &g[0], 20) != 0)
             fprintf(stderr, "[svo ba]   workgroup %d: op %u state %u iterations %u need_linearize %u chain %u arrive_total %u done_total %u lin_calls %u\n", b, q[0], q[1],
                     q[2], q[3], q[4], q[5], q[6], q[7]);
+          if (b == 0 || memcmp(q, &g[0], 20) != 0)
+            fprintf(stderr, "[svo ba]     last factorised at iteration %u: payload %08x%08x scales %08x%08x | first payload %08x%08x first scales(hi) %08x\n", q[14], q[8], q[9], q[10], q[11], q[12], q[13], q[15]);
         }
       }
     }
@@ -2456,6 +2618,8 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
     return rc;
   }
   const double* r = ba->h_result;
+  ba->lm_base[0] = (unsigned)r[LMR_C_ARRIVE]; ba->lm_base[1] = (unsigned)r[LMR_C_DONE]; ba->lm_base[2] = (unsigned)r[LMR_C_ARRIVED];
+  ba->lm_base[3] = (unsigned)r[LMR_C_POSTED]; ba->lm_base[4] = (unsigned)r[LMR_C_COPIED];
   memcpy(ba->h_poses.data(), r + LMR_DOUBLES, sizeof(double) * 7 * (size_t)d.K);
   if (r[LMR_SEL] != 0.0) { std::swap(ba->cur_points, ba->cand_points); std::swap(ba->cur_poses, ba->cand_poses); }
   ba->host_points_valid = ba->res_export;

@@ -605,8 +605,8 @@ __global__ __launch_bounds__(LKT * FPB) void lk_fb_kernel(const uint8_t* __restr
 // compaction and the sequential f32 parallax sum of track_compact_kernel (src/feature_tracker.cpp:44-64, SURVEY C-2) by
 // one wavefront: ballot / popcount per 64 features; the sum adds every feature in order (+0.0f for a dropped one leaves
 // a running sum that is >= +0 bit-identical), 64 scalar lane reads per round.  Per-feature results cross workgroups
-// inside the launch: written through, read at the coherence point (tail_device.h); what the host consumes goes out as
-// system-scope stores, `s_waitcnt vmcnt(0)`, then the completion word — no cache maintenance instruction.
+// inside the launch: written through, read at the coherence point (tail_device.h); the compacted set goes out with plain
+// stores behind ONE system-scope release fence of the compacting wavefront, then the completion word.
 __global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
   static_assert(LKT == 64 && FPB == 1, "the stream-batched tracker is written for one wavefront per feature");
   __shared__ LkShared S;
@@ -647,22 +647,27 @@ __global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
     if (k) {
       const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
       const float fx = svo_coherent_load(&a.fwd[2 * i]), fy = svo_coherent_load(&a.fwd[2 * i + 1]);
+      // plain stores, one release fence below: scalar write-through stores are one fabric write each (thousands per lane
+      // and frame: measured 200 us per track), the fence is one L2 write-back per lane and frame
       a.kept_xy[2 * slot] = fx; a.kept_xy[2 * slot + 1] = fy;
       a.init_dst[2 * slot] = a.init_xy[2 * i]; a.init_dst[2 * slot + 1] = a.init_xy[2 * i + 1];  // the tracker's per-feature state follows the feature (C-1: old ids)
       const long long id = a.ids[i];
       a.ids_dst[slot] = id;
-      svo_host_store(&a.host_xy[2 * slot], fx); svo_host_store(&a.host_xy[2 * slot + 1], fy);
-      svo_host_store(&a.host_ids[slot], id);
+      a.host_xy[2 * slot] = fx; a.host_xy[2 * slot + 1] = fy;
+      a.host_ids[slot] = id;
     }
     base += __popcll(mask);
 #pragma unroll
     for (int t = 0; t < 64; ++t) sum += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(par), t));
   }
   if (lane == 0) {
-    svo_host_store(a.host_n, base);
-    svo_host_store(a.host_av, n > 0 ? sum / (float)n : 0.f);
+    *a.host_n = base;
+    *a.host_av = n > 0 ? sum / (float)n : 0.f;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // release at system scope (write-back, no invalidate), then the word: the pinned mirrors are for the host, the device set
+  // for the lane's next stage, which the host may launch on ANOTHER stream as soon as it sees the word — i.e. before this
+  // launch (other lanes still tracking) has ended
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
   if (lane == 0) __hip_atomic_store(a.word, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 

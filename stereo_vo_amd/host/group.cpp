@@ -1,0 +1,971 @@
+// Pipeline group: ImageProcessor::process + BundleAdjuster::bundle_adjust (reference src/image_processor.cpp:18-163,
+// src/feature_tracker.cpp:18-67, driver rule src/vo_node.cpp:141-148) for SEVERAL stereo streams ("lanes") driven by ONE host
+// thread.  Every lane runs the reference's per-frame state machine — exactly the statements of host/pipeline.cpp's
+// ImageProcessor::process, cut at the points where the host needs a number from the GPU — and an event loop advances all
+// lanes: whatever stage several lanes reach in the same pass goes out as ONE launch (csrc/group_kernels.h, blockIdx.y =
+// lane) and the solves of the lanes that hit a keyframe together are one ba_lm_kernel launch.  Lanes never wait for each
+// other: a lane whose frame is no keyframe starts tracking its next frame while another lane is still in its PnP.
+//
+// Why (measured in round 2, profiles/r02_exp_launch_rate.txt, r02_exp_placement.txt, r02_kernel_stats_*): eight streams
+// as eight host threads on 16-24 hardware queues pay 30-90 us per launch -> completion round trip (7-11 us with at most
+// four queues) and their small kernels run 3-5x their solo time.  Here: one driver thread, four HIP streams (tracking +
+// front end, keyframe chain, two for solves), a small pool of host workers that only assemble bundle-adjustment problems.
+// Results per lane are bit for bit those of its own svo_pipeline (tests/test_group.py).
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <sched.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "group_kernels.h"
+#include "ref_constants.h"
+#include "svo.h"
+
+namespace {
+
+// cv::Rodrigues on a CV_32F rvec: evaluated in double, stored as float (host/pipeline.cpp).
+void rodrigues_f(const float* rv, float* R9) {
+  const double rx = rv[0], ry = rv[1], rz = rv[2];
+  const double th = sqrt(rx * rx + ry * ry + rz * rz);
+  double R[9];
+  if (th < 2.220446049250313e-16) {
+    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+  } else {
+    const double c = cos(th), s = sin(th), c1 = 1.0 - c, it = 1.0 / th;
+    const double x = rx * it, y = ry * it, z = rz * it;
+    R[0] = c + c1 * x * x; R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y; R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
+  }
+  for (int i = 0; i < 9; ++i) R9[i] = (float)R[i];
+}
+
+// Eigen::Quaternionf(Matrix3f) (src/image_processor.cpp:92), float arithmetic, row-major m.
+void quat_from_R(const float* m, float* q /*wxyz*/) {
+  float t = m[0] + m[4] + m[8];
+  if (t > 0.f) {
+    t = sqrtf(t + 1.0f);
+    q[0] = 0.5f * t;
+    t = 0.5f / t;
+    q[1] = (m[7] - m[5]) * t; q[2] = (m[2] - m[6]) * t; q[3] = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrtf(m[4 * i] - m[4 * j] - m[4 * k] + 1.0f);
+    q[1 + i] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (m[3 * k + j] - m[3 * j + k]) * t;
+    q[1 + j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    q[1 + k] = (m[3 * k + i] + m[3 * i + k]) * t;
+  }
+}
+
+enum LaneState { L_IDLE = 0, L_TRACK_WAIT, L_NEED_SOLVE, L_PNP_HYP_WAIT, L_PNP_REF_WAIT, L_TRI_WAIT, L_DONE };
+enum BaState { BA_NONE = 0, BA_ASSEMBLING, BA_READY, BA_INFLIGHT, BA_HOST_SOLVING, BA_HOST_DONE };
+enum Word { W_TRACK = 0, W_HYP, W_REF, W_TRI, W_COUNT };
+enum Counter { C_LK = 0, C_HYP, C_DEDUP, C_TRI, C_COUNT };
+
+struct Lane {
+  // ---- tracker state (FeatureTracker): feature set double-buffered on the device, mirrored in pinned memory
+  float* d_xy[2] = {nullptr, nullptr}; float* d_init[2] = {nullptr, nullptr}; long long* d_ids[2] = {nullptr, nullptr};
+  float* d_fwd = nullptr; float* d_par = nullptr; uint8_t* d_keep = nullptr;
+  float* h_xy[2] = {nullptr, nullptr}; long long* h_ids[2] = {nullptr, nullptr};  // pinned mirrors of the kept set (double-buffered with the device set)
+  float* h_kf_xy = nullptr; long long* h_kf_ids = nullptr;  // pinned: the feature set a keyframe hands to the tracker (src/image_processor.cpp:148-162)
+  int* h_n = nullptr; float* h_av = nullptr;
+  int cur = 0, n = 0, n_initial = 0;
+  bool from_host = false;           // the next track reads its features from h_kf_* (tracker (re)initialised by a keyframe)
+  const uint8_t* last_pyr = nullptr;
+  // ---- PnP
+  float* d_xyz = nullptr; double* d_hyp_pose = nullptr; int* d_hyp_count = nullptr; unsigned long long* d_hyp_mask = nullptr;
+  double* d_out = nullptr; int* d_nin = nullptr; int* d_inl = nullptr; float* d_trk_xy = nullptr;
+  float* h_xyz = nullptr; int* h_count = nullptr; double* h_out = nullptr; int* h_nin = nullptr; int* h_inl = nullptr;
+  // ---- dedup / sparse stereo / triangulation
+  uint8_t* d_flags = nullptr; float* d_new_xy = nullptr; int* d_cnt = nullptr; float* d_disp = nullptr;
+  float* d_kept_xy = nullptr; float* d_kept_xyz = nullptr;
+  int* h_tri_cnt = nullptr; float* h_tri_xy = nullptr; float* h_tri_xyz = nullptr;
+  // ---- hand-over words and arrival counters
+  int* words = nullptr;             // pinned, W_COUNT words 64 bytes apart
+  int seq[W_COUNT] = {0, 0, 0, 0};
+  unsigned* d_arrive = nullptr;     // device, C_COUNT counters 64 bytes apart (monotone)
+  unsigned arrive_total[C_COUNT] = {0, 0, 0, 0};
+  // ---- graph + solve (BundleAdjuster)
+  svo_ba* ba = nullptr;
+  std::atomic<int> ba_state{BA_NONE};
+  svo_ba_summary ba_summary{};
+  int ba_rc = 0;
+  int ba_launch = 0, ba_line = 0;  // which solve launch of the group carries this lane's solve, on which solve line
+  bool has_keyframe = false;
+  double solved_pose[7] = {1, 0, 0, 0, 0, 0, 0};
+  int last_iterations = 0;
+  // ---- ImageProcessor state
+  float rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+  // ---- the frame in flight
+  int state = L_IDLE;
+  bool queued = false;              // the stage the lane waits for has not been launched yet (its completion word still shows the previous launch)
+  int frame = 0;                    // index into the batch
+  int pending_from = -1;            // first frame of the batch whose pose waits for the running solve
+  bool first_keyframe = false;      // the triangulation in flight is frame 0's (src/image_processor.cpp:30-58)
+  int m_tracked = 0, num_inliers = 0, best = -1;
+  float rmat[9], quat[4];
+  std::vector<long long> kf_tracked_ids; std::vector<float> kf_tracked_xy;  // the keyframe under construction
+  std::vector<long long> ids64; std::vector<int64_t> new_ids;
+};
+
+struct Pool {  // host workers: they only assemble bundle-adjustment problems (and run the rare host-driven solve)
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::pair<Lane*, int>> jobs;  // (lane, 0: assemble / 1: host-driven solve)
+  bool quit = false;
+  int device = 0;
+  void start(int n, int dev) {
+    device = dev;
+    for (int i = 0; i < n; ++i) th.emplace_back([this] { run(); });
+  }
+  void post(Lane* l, int what) {
+    { std::lock_guard<std::mutex> g(mu); jobs.emplace_back(l, what); }
+    cv.notify_one();
+  }
+  void run() {
+    (void)hipSetDevice(device);
+    for (;;) {
+      std::pair<Lane*, int> j;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return quit || !jobs.empty(); });
+        if (quit && jobs.empty()) return;
+        j = jobs.front(); jobs.pop_front();
+      }
+      Lane* l = j.first;
+      if (j.second == 0) {
+        l->ba_rc = svo_ba_solve_prepare(l->ba);
+        l->ba_state.store(BA_READY, std::memory_order_release);
+      } else {
+        l->ba_rc = svo_ba_solve_finish(l->ba, &l->ba_summary);
+        l->ba_state.store(BA_HOST_DONE, std::memory_order_release);
+      }
+    }
+  }
+  void stop() {
+    { std::lock_guard<std::mutex> g(mu); quit = true; }
+    cv.notify_all();
+    for (auto& t : th) t.join();
+    th.clear();
+  }
+};
+
+}  // namespace
+
+struct svo_pipeline_group {
+  svo_ctx* ctx = nullptr;
+  svo_pipeline_params prm{};
+  int n_lanes = 0, max_batch = 0;
+  float K[9];
+  std::vector<Lane*> lanes;
+  std::vector<void*> dev_allocs, pin_allocs;
+  // bus lines: a lane always rides the same tracking line and the same keyframe-chain line (stream order keeps its
+  // consecutive stages coherent), solves take whichever solve line is free
+  static constexpr int MAX_LINES = 8;
+  int n_lk = 1, n_chain = 1, n_ba = 2;
+  hipStream_t st_lk[MAX_LINES] = {}, st_chain[MAX_LINES] = {}, st_ba[MAX_LINES] = {};
+  int ba_launch_id = 0;
+  // batch-wide front-end outputs
+  float* d_corners = nullptr; int* d_ncorners = nullptr; uint8_t* d_pyr[2] = {nullptr, nullptr}; int pyr_cur = 0;
+  size_t pyr_stride = 0;
+  int* h_counts = nullptr;  // pinned: n_lanes x max_batch corner counts + status
+  Pool pool;
+  int pnp_iterations = 0, mask_words_cap = 0;
+  // statistics of the last batch (launches by kind and the lanes they carried)
+  long launches[6] = {0, 0, 0, 0, 0, 0}, lanes_carried[6] = {0, 0, 0, 0, 0, 0};
+};
+
+namespace {
+
+int fail(svo_pipeline_group* g, const char* what, hipError_t e) {
+  g->ctx->err = std::string("pipeline group: ") + what + ": " + hipGetErrorString(e);
+  return SVO_ERR_HIP;
+}
+
+template <typename T>
+int dev_alloc(svo_pipeline_group* g, T** p, size_t count) {
+  const hipError_t e = hipMalloc((void**)p, sizeof(T) * (count ? count : 1));
+  if (e != hipSuccess) return fail(g, "hipMalloc", e);
+  g->dev_allocs.push_back(*p);
+  return SVO_OK;
+}
+
+int word_ready(const Lane* l, int w) { return __atomic_load_n(&l->words[16 * w], __ATOMIC_ACQUIRE) == l->seq[w]; }
+
+SvoPublish make_pub(Lane* l, int w, int counter, int nblocks) {
+  SvoPublish p;
+  p.word = &l->words[16 * w];
+  p.seq = ++l->seq[w];
+  if (counter >= 0) {
+    l->arrive_total[counter] += (unsigned)nblocks;
+    p.arrive = l->d_arrive + 16 * counter;
+    p.target = l->arrive_total[counter];
+  }
+  return p;
+}
+
+void fill_pending(Lane* l, svo_frame_result* res, int upto) {
+  if (l->pending_from < 0) return;
+  for (int j = l->pending_from; j < upto; ++j) {
+    memcpy(res[j].pose7, l->solved_pose, sizeof(res[j].pose7));
+    if (j == l->pending_from && res[j].is_keyframe) res[j].ba_iterations = l->last_iterations;
+  }
+  l->pending_from = -1;
+}
+
+// join the lane's solve (BundleAdjuster::bundle_adjust's tail, src/bundle_adjuster.cpp:146-155; host/pipeline.cpp run_bundle_adjust)
+int finish_solve(svo_pipeline_group* g, Lane* l) {
+  const int st = l->ba_state.load(std::memory_order_acquire);
+  if (st == BA_NONE) return SVO_OK;
+  int rc = SVO_OK;
+  if (st == BA_INFLIGHT) rc = svo_ba_solve_finish(l->ba, &l->ba_summary);
+  else rc = l->ba_rc;  // BA_HOST_DONE
+  l->ba_state.store(BA_NONE, std::memory_order_release);
+  if (rc) return rc;
+  l->last_iterations = l->ba_summary.iterations;
+  double p[7];
+  if ((rc = svo_ba_get_pose(l->ba, -1, p))) return rc;
+  for (int i = 0; i < 7; ++i) l->solved_pose[i] = (double)(float)p[i];  // Keyframe holds Quaternionf / Vector3f (:146-153)
+  (void)g;
+  return SVO_OK;
+}
+
+}  // namespace
+
+extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
+  if (!g) return;
+  (void)hipSetDevice(g->ctx->device);
+  g->pool.stop();
+  for (Lane* l : g->lanes) {
+    if (l->ba_state.load() == BA_INFLIGHT) { svo_ba_summary s; (void)svo_ba_solve_finish(l->ba, &s); }
+  }
+  (void)hipStreamSynchronize(g->ctx->stream);
+  for (int i = 0; i < svo_pipeline_group::MAX_LINES; ++i) {
+    if (g->st_lk[i] && g->st_lk[i] != g->ctx->stream) { (void)hipStreamSynchronize(g->st_lk[i]); (void)hipStreamDestroy(g->st_lk[i]); }
+    if (g->st_chain[i]) { (void)hipStreamSynchronize(g->st_chain[i]); (void)hipStreamDestroy(g->st_chain[i]); }
+    if (g->st_ba[i]) { (void)hipStreamSynchronize(g->st_ba[i]); (void)hipStreamDestroy(g->st_ba[i]); }
+  }
+  for (Lane* l : g->lanes) { if (l->ba) svo_ba_destroy(l->ba); delete l; }
+  for (void* p : g->dev_allocs) (void)hipFree(p);
+  for (void* p : g->pin_allocs) (void)hipHostFree(p);
+  delete g;
+}
+
+extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out, const svo_pipeline_params* p, int n_lanes) {
+  if (!ctx || !out || !p) return SVO_ERR_INVALID;
+  *out = nullptr;
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  SVO_REQUIRE(ctx, n_lanes >= 1 && n_lanes <= SVO_MAX_LANES, "pipeline_group_create: 1..16 lanes");
+  SVO_REQUIRE(ctx, p->width >= 32 && p->height >= 32 && p->width <= ctx->lim.max_width && p->height <= ctx->lim.max_height,
+              "pipeline_group_create: image size outside the context limits");
+  SVO_REQUIRE(ctx, p->max_corners >= 4 && p->max_corners <= ctx->lim.max_corners && p->max_features >= 4 &&
+                       p->max_features <= ctx->lim.max_features, "pipeline_group_create: feature counts outside the context limits");
+  SVO_REQUIRE(ctx, p->window_size >= 1 && p->window_size <= 63, "pipeline_group_create: window size must be 1..63");
+  SVO_REQUIRE(ctx, ctx->lim.max_batch >= n_lanes, "pipeline_group_create: svo_limits.max_batch must hold lanes x frames per call");
+  svo_pipeline_group* g = new svo_pipeline_group();
+  g->ctx = ctx; g->prm = *p; g->n_lanes = n_lanes;
+  g->max_batch = ctx->lim.max_batch / n_lanes;
+  const float K[9] = {(float)p->cam.focal, 0.f, (float)p->cam.cx, 0.f, (float)p->cam.focal, (float)p->cam.cy, 0.f, 0.f, 1.f};  // src/vo_node.cpp:104-108
+  memcpy(g->K, K, sizeof(K));
+  g->pnp_iterations = svo_ref::PNP_ITERATIONS;
+  const size_t mc = (size_t)p->max_corners, mf = (size_t)ctx->lim.max_features, B = (size_t)g->max_batch, S = (size_t)n_lanes;
+  const int words = (int)((mf + 63) / 64);
+  g->mask_words_cap = words;
+  int rc = SVO_OK;
+  auto chk = [&](hipError_t e, const char* what) { if (rc == SVO_OK && e != hipSuccess) rc = fail(g, what, e); };
+  {
+    auto knob = [](const char* name, int dflt, int hi) { const char* e = getenv(name); int v = e && *e ? atoi(e) : dflt; return v < 1 ? 1 : (v > hi ? hi : v); };
+    g->n_lk = knob("SVO_GROUP_LK_LINES", 1, svo_pipeline_group::MAX_LINES);
+    g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 1, svo_pipeline_group::MAX_LINES);
+    g->n_ba = knob("SVO_GROUP_BA_LINES", 2, svo_pipeline_group::MAX_LINES);
+    g->st_lk[0] = ctx->stream;
+    for (int i = 1; i < g->n_lk; ++i) chk(hipStreamCreateWithFlags(&g->st_lk[i], hipStreamNonBlocking), "stream");
+    for (int i = 0; i < g->n_chain; ++i) chk(hipStreamCreateWithFlags(&g->st_chain[i], hipStreamNonBlocking), "stream");
+    for (int i = 0; i < g->n_ba; ++i) chk(hipStreamCreateWithFlags(&g->st_ba[i], hipStreamNonBlocking), "stream");
+  }
+  g->pyr_stride = svo_k_pyramid_bytes(p->width, p->height);
+  if (!rc) rc = dev_alloc(g, &g->d_corners, 2 * mc * S * B);
+  if (!rc) rc = dev_alloc(g, &g->d_ncorners, S * B);
+  if (!rc) rc = dev_alloc(g, &g->d_pyr[0], g->pyr_stride * S * B);
+  if (!rc) rc = dev_alloc(g, &g->d_pyr[1], g->pyr_stride * S * B);
+  if (!rc) {
+    void* hp = nullptr;
+    chk(hipHostMalloc(&hp, sizeof(int) * (S * B + 16), hipHostMallocDefault), "hipHostMalloc");
+    if (hp) { g->pin_allocs.push_back(hp); g->h_counts = (int*)hp; memset(hp, 0, sizeof(int) * (S * B + 16)); }
+  }
+  for (int li = 0; li < n_lanes && !rc; ++li) {
+    Lane* l = new Lane();
+    g->lanes.push_back(l);
+    for (int b = 0; b < 2 && !rc; ++b) {
+      rc = dev_alloc(g, &l->d_xy[b], 2 * mf);
+      if (!rc) rc = dev_alloc(g, &l->d_init[b], 2 * mf);
+      if (!rc) rc = dev_alloc(g, &l->d_ids[b], mf);
+    }
+    if (!rc) rc = dev_alloc(g, &l->d_fwd, 2 * mf);
+    if (!rc) rc = dev_alloc(g, &l->d_par, mf);
+    if (!rc) rc = dev_alloc(g, &l->d_keep, mf);
+    if (!rc) rc = dev_alloc(g, &l->d_xyz, 3 * mf);
+    if (!rc) rc = dev_alloc(g, &l->d_hyp_pose, 7 * (size_t)g->pnp_iterations);
+    if (!rc) rc = dev_alloc(g, &l->d_hyp_count, (size_t)g->pnp_iterations);
+    if (!rc) rc = dev_alloc(g, &l->d_hyp_mask, (size_t)g->pnp_iterations * words);
+    if (!rc) rc = dev_alloc(g, &l->d_out, 8);
+    if (!rc) rc = dev_alloc(g, &l->d_nin, 16);
+    if (!rc) rc = dev_alloc(g, &l->d_inl, mf);
+    if (!rc) rc = dev_alloc(g, &l->d_trk_xy, 2 * mf);
+    if (!rc) rc = dev_alloc(g, &l->d_flags, mc);
+    if (!rc) rc = dev_alloc(g, &l->d_new_xy, 2 * mc);
+    if (!rc) rc = dev_alloc(g, &l->d_cnt, 16);
+    if (!rc) rc = dev_alloc(g, &l->d_disp, mc);
+    if (!rc) rc = dev_alloc(g, &l->d_kept_xy, 2 * mc);
+    if (!rc) rc = dev_alloc(g, &l->d_kept_xyz, 3 * mc);
+    if (!rc) rc = dev_alloc(g, &l->d_arrive, 16 * C_COUNT);
+    if (!rc) chk(hipMemset(l->d_arrive, 0, sizeof(unsigned) * 16 * C_COUNT), "hipMemset");
+    if (rc) break;
+    // one pinned arena per lane
+    const size_t f2 = sizeof(float) * 2 * mf, i8 = sizeof(long long) * mf;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 127) & ~(size_t)127; return o; };
+    const size_t o_xy0 = take(f2), o_xy1 = take(f2), o_id0 = take(i8), o_id1 = take(i8), o_kxy = take(f2), o_kid = take(i8), o_n = take(64),
+                 o_xyz = take(sizeof(float) * 3 * mf), o_cnt = take(sizeof(int) * (size_t)g->pnp_iterations), o_out = take(64), o_nin = take(64),
+                 o_inl = take(sizeof(int) * mf), o_tc = take(64), o_txy = take(sizeof(float) * 2 * mc), o_txyz = take(sizeof(float) * 3 * mc),
+                 o_words = take(64 * W_COUNT);
+    void* hp = nullptr;
+    chk(hipHostMalloc(&hp, off, hipHostMallocDefault), "hipHostMalloc");
+    if (rc) break;
+    g->pin_allocs.push_back(hp);
+    memset(hp, 0, off);  // completion words are compared by equality with a sequence number: never start from recycled bytes
+    char* h = (char*)hp;
+    l->h_xy[0] = (float*)(h + o_xy0); l->h_xy[1] = (float*)(h + o_xy1); l->h_ids[0] = (long long*)(h + o_id0); l->h_ids[1] = (long long*)(h + o_id1);
+    l->h_kf_xy = (float*)(h + o_kxy); l->h_kf_ids = (long long*)(h + o_kid);
+    l->h_n = (int*)(h + o_n); l->h_av = (float*)(h + o_n + 16);
+    l->h_xyz = (float*)(h + o_xyz); l->h_count = (int*)(h + o_cnt); l->h_out = (double*)(h + o_out); l->h_nin = (int*)(h + o_nin);
+    l->h_inl = (int*)(h + o_inl); l->h_tri_cnt = (int*)(h + o_tc); l->h_tri_xy = (float*)(h + o_txy); l->h_tri_xyz = (float*)(h + o_txyz);
+    l->words = (int*)(h + o_words);
+    svo_ba_options opt;
+    svo_ba_default_options(&opt);
+    opt.max_features = p->max_features;       // src/bundle_adjuster.hpp:75
+    opt.max_iterations = p->ba_max_iterations;
+    opt.max_time_s = p->ba_max_time_s;        // src/bundle_adjuster.cpp:11
+    const int max_obs = (p->window_size + 1) * p->max_features + 64;
+    rc = svo_ba_create(ctx, &l->ba, p->window_size, &p->cam, &opt, max_obs, max_obs);
+  }
+  if (rc) { svo_pipeline_group_destroy(g); return rc; }
+  {
+    const char* e = getenv("SVO_GROUP_WORKERS");
+    int nw = e ? atoi(e) : (n_lanes >= 4 ? 2 : 1);
+    if (nw < 1) nw = 1;
+    if (nw > 8) nw = 8;
+    g->pool.start(nw, ctx->device);
+  }
+  *out = g;
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
+  if (!g) return SVO_ERR_INVALID;
+  (void)hipSetDevice(g->ctx->device);
+  for (Lane* l : g->lanes) {
+    (void)finish_solve(g, l);
+    svo_ba_reset(l->ba);
+    l->has_keyframe = false; l->n = l->n_initial = 0; l->from_host = false; l->last_pyr = nullptr; l->cur = 0;
+    l->rvec[0] = l->rvec[1] = l->rvec[2] = l->tvec[0] = l->tvec[1] = l->tvec[2] = 0.f;
+    l->state = L_IDLE; l->queued = false; l->pending_from = -1; l->last_iterations = 0;
+    const double id7[7] = {1, 0, 0, 0, 0, 0, 0};
+    memcpy(l->solved_pose, id7, sizeof(id7));
+  }
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_group_lanes(const svo_pipeline_group* g) { return g ? g->n_lanes : 0; }
+
+extern "C" int svo_pipeline_group_get_tracked(svo_pipeline_group* g, int lane, int64_t* ids, float* xy, int capacity, int* n) {
+  if (!g || !n || lane < 0 || lane >= g->n_lanes) return SVO_ERR_INVALID;
+  const Lane* l = g->lanes[lane];
+  *n = l->n;
+  const float* sx = l->from_host ? l->h_kf_xy : l->h_xy[l->cur];
+  const long long* si = l->from_host ? l->h_kf_ids : l->h_ids[l->cur];
+  for (int i = 0; i < l->n && i < capacity; ++i) {
+    if (ids) ids[i] = (int64_t)si[i];
+    if (xy) { xy[2 * i] = sx[2 * i]; xy[2 * i + 1] = sx[2 * i + 1]; }
+  }
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_group_last_stats(const svo_pipeline_group* g, long* launches6, long* lanes6) {
+  if (!g || !launches6 || !lanes6) return SVO_ERR_INVALID;
+  for (int i = 0; i < 6; ++i) { launches6[i] = g->launches[i]; lanes6[i] = g->lanes_carried[i]; }
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const uint8_t* left, const uint8_t* right, size_t lane_stride,
+                                                    int batch, svo_frame_result* results) {
+  if (!g) return SVO_ERR_INVALID;
+  svo_ctx* ctx = g->ctx;
+  SVO_REQUIRE(ctx, left && right && results && batch >= 1 && batch <= g->max_batch, "pipeline_group_process_batch: bad arguments");
+  const int W = g->prm.width, H = g->prm.height, S = g->n_lanes, mc = g->prm.max_corners;
+  const size_t istride = (size_t)W * H;
+  SVO_REQUIRE(ctx, lane_stride >= istride * (size_t)batch, "pipeline_group_process_batch: lanes overlap");
+  ctx->err.clear();
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  for (int i = 0; i < 6; ++i) { g->launches[i] = 0; g->lanes_carried[i] = 0; }
+
+  // ---- a1 on every frame of every lane + the pyramids (the reference detects on every frame, src/image_processor.cpp:22)
+  g->pyr_cur ^= 1;  // the previous batch's pyramids stay valid: a lane's last tracked image lives there (src/feature_tracker.cpp:66)
+  uint8_t* pyr = g->d_pyr[g->pyr_cur];
+  int rc = SVO_OK;
+  if (lane_stride == istride * (size_t)batch) {
+    rc = svo_corner_detect_batch_dev(ctx, left, S * batch, W, H, W, istride, mc, g->prm.quality, (double)g->prm.min_feature_distance, g->d_corners, g->d_ncorners);
+    if (!rc) rc = svo_k_build_pyramid(ctx, left, S * batch, W, H, W, istride, pyr, g->pyr_stride);
+  } else {
+    for (int l = 0; l < S && !rc; ++l) {
+      rc = svo_corner_detect_batch_dev(ctx, left + l * lane_stride, batch, W, H, W, istride, mc, g->prm.quality, (double)g->prm.min_feature_distance,
+                                       g->d_corners + (size_t)l * batch * 2 * mc, g->d_ncorners + (size_t)l * batch);
+      if (!rc) rc = svo_k_build_pyramid(ctx, left + l * lane_stride, batch, W, H, W, istride, pyr + (size_t)l * batch * g->pyr_stride, g->pyr_stride);
+    }
+  }
+  if (rc) return rc;
+  g->launches[5] += 7; g->lanes_carried[5] += 7 * S;
+  int* hc = g->h_counts;
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(hc, g->d_ncorners, sizeof(int) * S * batch, hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(hc + S * batch, ctx->d_status, sizeof(int), hipMemcpyDeviceToHost, st));
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  if (hc[S * batch]) {
+    (void)hipMemsetAsync(ctx->d_status, 0, sizeof(int), st);
+    ctx->err = "corner detection exceeded a workspace bound (svo_limits.max_candidates)";
+    return SVO_ERR_CAPACITY;
+  }
+
+  auto RES = [&](int lane, int f) -> svo_frame_result& { return results[(size_t)lane * batch + f]; };
+  auto IMG = [&](const uint8_t* base, int lane, int f) { return base + lane * lane_stride + (size_t)f * istride; };
+  auto PYR = [&](int lane, int f) { return pyr + ((size_t)lane * batch + f) * g->pyr_stride; };
+  auto DET = [&](int lane, int f) { return g->d_corners + ((size_t)lane * batch + f) * 2 * mc; };
+  for (int li = 0; li < S; ++li) {
+    Lane* l = g->lanes[li];
+    l->frame = 0; l->state = L_IDLE; l->queued = false; l->pending_from = -1;
+    memset(&RES(li, 0), 0, sizeof(svo_frame_result) * batch);
+  }
+
+  // per-pass submission lists
+  std::vector<int> q_track, q_hyp, q_ref, q_tri, q_ba;
+  int error = SVO_OK;
+  const int MODEL = svo_pnp_model_points();
+  // SVO_GROUP_TRACE=1: (microseconds, lane, event) of this call on stderr — where a lane's time goes
+  static const bool trace_on = getenv("SVO_GROUP_TRACE") != nullptr;
+  struct Ev { double us; int lane; const char* what; int arg; };
+  std::vector<Ev> evs;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto EV = [&](int lane, const char* what, int arg) {
+    if (trace_on) evs.push_back({std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), lane, what, arg});
+  };
+
+  // frame finished (is_keyframe etc. already in the result): move on
+  auto frame_done = [&](int li) {
+    Lane* l = g->lanes[li];
+    svo_frame_result* res = &RES(li, 0);
+    const int i = l->frame;
+    if (l->has_keyframe && !(res[i].is_keyframe) && l->pending_from < 0) l->pending_from = i;  // no solve started here: the pose is the last solved one (src/vo_node.cpp:146-150)
+    l->frame = i + 1;
+    l->state = l->frame < batch ? L_IDLE : L_DONE;
+  };
+
+  // src/image_processor.cpp:137-162 once the triangulated new features are on the host: keyframe, solve, tracker
+  auto keyframe_tail = [&](int li) -> int {
+    Lane* l = g->lanes[li];
+    svo_frame_result* res = &RES(li, 0);
+    const int i = l->frame;
+    const int m_new = *l->h_tri_cnt;
+    double pose7[7];
+    if (l->first_keyframe) {
+      const double id7[7] = {1, 0, 0, 0, 0, 0, 0};  // :41 Vector3f zero, Quaternionf identity
+      memcpy(pose7, id7, sizeof(id7));
+      l->kf_tracked_ids.clear(); l->kf_tracked_xy.clear();
+    } else {
+      pose7[0] = l->quat[0]; pose7[1] = l->quat[1]; pose7[2] = l->quat[2]; pose7[3] = l->quat[3];
+      pose7[4] = l->tvec[0]; pose7[5] = l->tvec[1]; pose7[6] = l->tvec[2];
+    }
+    const int nt = (int)l->kf_tracked_ids.size();
+    l->new_ids.assign((size_t)(m_new > 0 ? m_new : 1), 0);
+    int kept = 0;
+    std::vector<int64_t> tid(l->kf_tracked_ids.begin(), l->kf_tracked_ids.end());
+    int rc2 = svo_ba_add_keyframe(l->ba, pose7, tid.data(), l->kf_tracked_xy.data(), nt, l->h_tri_xy, l->h_tri_xyz, m_new, l->new_ids.data(), &kept);  // :144
+    if (rc2) return rc2;
+    // the previous solve was joined before the graph was edited: its poses are final now
+    fill_pending(l, res, i);
+    l->pending_from = i;
+    l->has_keyframe = true;
+    l->ba_state.store(BA_ASSEMBLING, std::memory_order_release);  // src/vo_node.cpp:147, started here so that the assembly overlaps the next frames
+    g->pool.post(l, 0);
+    EV(li, "assembly_posted", i);
+    // tracker->init(left, tracked + new, ids) :148-162 — the next track reads these pinned arrays in place
+    int n = nt + kept;
+    if (n > ctx->lim.max_features) n = ctx->lim.max_features;
+    for (int k = 0; k < nt && k < n; ++k) { l->h_kf_xy[2 * k] = l->kf_tracked_xy[2 * k]; l->h_kf_xy[2 * k + 1] = l->kf_tracked_xy[2 * k + 1]; l->h_kf_ids[k] = l->kf_tracked_ids[k]; }
+    for (int k = nt; k < n; ++k) { l->h_kf_xy[2 * k] = l->h_tri_xy[2 * (k - nt)]; l->h_kf_xy[2 * k + 1] = l->h_tri_xy[2 * (k - nt) + 1]; l->h_kf_ids[k] = (long long)l->new_ids[k - nt]; }
+    l->n = l->n_initial = n;
+    l->from_host = true;
+    l->last_pyr = PYR(li, i);  // clone of the image, :14 (the batch buffers are double-buffered: it stays valid through the next batch)
+    if (l->first_keyframe) { l->tvec[0] = l->tvec[1] = l->tvec[2] = 0.f; l->rvec[0] = l->rvec[1] = l->rvec[2] = 0.f; }  // :54-55
+    res[i].is_keyframe = 1;
+    res[i].n_new = kept;
+    frame_done(li);
+    return SVO_OK;
+  };
+
+  // after PnP (:84-134): keyframe pose, inlier copy; then dedup + sparse stereo + triangulation go out
+  auto after_pnp = [&](int li) {
+    Lane* l = g->lanes[li];
+    svo_frame_result* res = &RES(li, 0);
+    res[l->frame].n_inliers = l->num_inliers;
+    rodrigues_f(l->rvec, l->rmat);   // :84-85
+    quat_from_R(l->rmat, l->quat);   // :87-92
+    const float* txy = l->h_xy[l->cur];
+    const long long* tids = l->h_ids[l->cur];
+    l->kf_tracked_ids.resize(l->num_inliers); l->kf_tracked_xy.resize(2 * (size_t)l->num_inliers);
+    for (int k = 0; k < l->num_inliers; ++k) {  // :104-108
+      const int idx = l->h_inl[k];
+      l->kf_tracked_ids[k] = tids[idx];
+      l->kf_tracked_xy[2 * k] = txy[2 * idx]; l->kf_tracked_xy[2 * k + 1] = txy[2 * idx + 1];
+    }
+    l->first_keyframe = false;
+    q_tri.push_back(li); l->queued = true;
+    l->state = L_TRI_WAIT;
+  };
+
+  // the keyframe path once the previous solve is joined (:71-82)
+  auto continue_keyframe = [&](int li) -> int {
+    Lane* l = g->lanes[li];
+    const int m = l->n;
+    l->m_tracked = m;
+    l->num_inliers = 0; l->best = -1;
+    if (m > 0) {
+      l->ids64.assign(l->h_ids[l->cur], l->h_ids[l->cur] + m);
+      std::vector<int64_t> id64(l->ids64.begin(), l->ids64.end());
+      const int rc2 = svo_ba_get_points(l->ba, id64.data(), m, l->h_xyz);  // :72 get_world_points
+      if (rc2) return rc2;
+    }
+    if (m >= MODEL) { q_hyp.push_back(li); l->queued = true; l->state = L_PNP_HYP_WAIT; }
+    else after_pnp(li);
+    return SVO_OK;
+  };
+
+  // the keyframe gate after tracking (:63-65)
+  auto after_track = [&](int li) -> int {
+    Lane* l = g->lanes[li];
+    svo_frame_result& r = RES(li, l->frame);
+    const float av = *l->h_av;
+    const float pl = (float)(1.0 - (double)((float)l->n / (float)l->n_initial));  // src/feature_tracker.cpp:64
+    r.n_tracked = l->n; r.av_parallax = av; r.percent_lost = pl;
+    if (av <= g->prm.parallax_thresh && (double)pl < svo_ref::KEYFRAME_PERCENT_LOST) { frame_done(li); return SVO_OK; }
+    if (l->ba_state.load(std::memory_order_acquire) != BA_NONE) { l->state = L_NEED_SOLVE; EV(li, "need_solve", l->ba_state.load()); return SVO_OK; }
+    return continue_keyframe(li);
+  };
+
+  auto start_frame = [&](int li) -> int {
+    Lane* l = g->lanes[li];
+    const int i = l->frame;
+    svo_frame_result& r = RES(li, i);
+    const int n_det = hc[li * batch + i];
+    r.n_detected = n_det;
+    if (n_det < svo_ref::MIN_DETECTED) { frame_done(li); return SVO_OK; }  // :23-25
+    if (!l->has_keyframe) {  // :30-58
+      l->first_keyframe = true;
+      l->num_inliers = 0;
+      q_tri.push_back(li); l->queued = true;
+      l->state = L_TRI_WAIT;
+      return SVO_OK;
+    }
+    if (l->n <= 0) {  // nothing to track: the kernels would see n = 0 (host/pipeline.cpp: av_parallax = 0)
+      l->n = 0; *l->h_av = 0.f;
+      return after_track(li);
+    }
+    q_track.push_back(li); l->queued = true;
+    l->state = L_TRACK_WAIT;
+    return SVO_OK;
+  };
+
+  unsigned idle_spins = 0;
+  auto last_progress = std::chrono::steady_clock::now();
+  for (;;) {
+    bool all_done = true, progressed = false;
+    // ---- advance every lane as far as the host alone can
+    for (int li = 0; li < S && !error; ++li) {
+      Lane* l = g->lanes[li];
+      bool again = true;
+      while (again && !error) {
+        again = false;
+        switch (l->state) {
+          case L_IDLE:
+            error = start_frame(li);
+            progressed = true;
+            again = l->state == L_IDLE;  // the frame ended on the host (too few corners / no keyframe gate): next frame
+            break;
+          case L_TRACK_WAIT:
+            if (!l->queued && word_ready(l, W_TRACK)) {
+              EV(li, "track_done", l->frame);
+              l->cur ^= 1; l->from_host = false;
+              l->n = *l->h_n;
+              l->last_pyr = PYR(li, l->frame);  // :66
+              error = after_track(li);
+              progressed = true; again = l->state == L_IDLE;
+            }
+            break;
+          case L_NEED_SOLVE: {
+            const int bs = l->ba_state.load(std::memory_order_acquire);
+            if ((bs == BA_INFLIGHT && svo_ba_solve_poll(l->ba)) || bs == BA_HOST_DONE) {
+              EV(li, "solve_joined_for_pnp", l->frame);
+              error = finish_solve(g, l);
+              if (!error) error = continue_keyframe(li);
+              progressed = true; again = l->state == L_IDLE;
+            }
+            break;
+          }
+          case L_PNP_HYP_WAIT:
+            if (!l->queued && word_ready(l, W_HYP)) {
+              EV(li, "hyp_done", l->frame);
+              // RANSAC bookkeeping (csrc/pnp.hip svo_k_pnp): hypotheses consumed in order with OpenCV's adaptive cap
+              int best = -1, best_cnt = 0, niters = g->pnp_iterations;
+              for (int h = 0; h < niters; ++h) {
+                if (l->h_count[h] > std::max(best_cnt, MODEL - 1)) {
+                  best = h; best_cnt = l->h_count[h];
+                  niters = svo_pnp_update_num_iters(svo_ref::PNP_CONFIDENCE, (double)(l->m_tracked - best_cnt) / l->m_tracked, MODEL, niters);
+                }
+              }
+              l->best = best;
+              progressed = true;
+              if (best < 0) after_pnp(li);
+              else { q_ref.push_back(li); l->queued = true; l->state = L_PNP_REF_WAIT; }
+            }
+            break;
+          case L_PNP_REF_WAIT:
+            if (!l->queued && word_ready(l, W_REF)) {
+              EV(li, "ref_done", l->frame);
+              double q[4] = {l->h_out[0], l->h_out[1], l->h_out[2], l->h_out[3]};
+              if (q[0] < 0) for (double& v : q) v = -v;
+              const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+              double rv[3];
+              if (vn < 1e-12) { rv[0] = 2 * q[1]; rv[1] = 2 * q[2]; rv[2] = 2 * q[3]; }
+              else {
+                const double th = 2.0 * atan2(vn, q[0]);
+                rv[0] = q[1] / vn * th; rv[1] = q[2] / vn * th; rv[2] = q[3] / vn * th;
+              }
+              for (int k = 0; k < 3; ++k) { l->rvec[k] = (float)rv[k]; l->tvec[k] = (float)l->h_out[4 + k]; }
+              l->num_inliers = *l->h_nin;
+              after_pnp(li);
+              progressed = true;
+            }
+            break;
+          case L_TRI_WAIT:
+            if (!l->queued && word_ready(l, W_TRI)) {
+              EV(li, "tri_done", l->frame);
+              error = keyframe_tail(li);
+              progressed = true; again = l->state == L_IDLE;
+            }
+            break;
+          default: break;
+        }
+      }
+      if (l->state != L_DONE) all_done = false;
+    }
+    if (error) break;
+
+    // ---- one launch per stage for the lanes that have reached it.  Launch discipline: a stage's kernels go to an in-order
+    // stream, so a launch for ONE lane right now would make the lane that is ready ten microseconds later queue behind it
+    // for a whole kernel duration (tracking: 150-200 us) — measured: 8 lanes, 110 track launches for 120 lane-frames, 3,000
+    // frames/s.  Instead a stage is launched only while none of its launches is in flight; lanes that become ready meanwhile
+    // ride the next launch together (a bus, not taxis).  Nobody waits for a lane that is not ready.
+    bool lk_busy[svo_pipeline_group::MAX_LINES] = {}, chain_busy[svo_pipeline_group::MAX_LINES] = {};
+    for (int li = 0; li < S; ++li) {
+      const Lane* l = g->lanes[li];
+      if (l->queued) continue;
+      lk_busy[li % g->n_lk] |= l->state == L_TRACK_WAIT;
+      chain_busy[li % g->n_chain] |= l->state == L_PNP_HYP_WAIT || l->state == L_PNP_REF_WAIT || l->state == L_TRI_WAIT;
+    }
+    // the lanes of `q` that ride line `line` (of `n_lines`), removed from q
+    auto take_line = [&](std::vector<int>& q, int line, int n_lines) {
+      std::vector<int> mine;
+      for (size_t k = 0; k < q.size();) {
+        if (q[k] % n_lines == line) { mine.push_back(q[k]); q.erase(q.begin() + k); } else ++k;
+      }
+      return mine;
+    };
+    for (int line = 0; line < g->n_lk && !error; ++line) {
+      if (lk_busy[line]) continue;
+      const std::vector<int> q_now = take_line(q_track, line, g->n_lk);
+      if (q_now.empty()) continue;
+      SvoLkLanes a;
+      a.w = W; a.h = H;
+      int gx = 1;
+      for (int li : q_now) gx = std::max(gx, g->lanes[li]->n);
+      int k = 0;
+      for (int li : q_now) {
+        Lane* l = g->lanes[li];
+        SvoLkLane& x = a.lane[k++];
+        const int nxt = l->cur ^ 1;
+        x.pyr_prev = l->last_pyr; x.pyr_next = PYR(li, l->frame);
+        x.xy = l->from_host ? l->h_kf_xy : l->d_xy[l->cur];
+        x.init_xy = l->from_host ? l->h_kf_xy : l->d_init[l->cur];
+        x.ids = l->from_host ? l->h_kf_ids : l->d_ids[l->cur];
+        x.n = l->n;
+        x.fwd = l->d_fwd; x.keep = l->d_keep; x.parallax = l->d_par;
+        x.kept_xy = l->d_xy[nxt]; x.init_dst = l->d_init[nxt]; x.ids_dst = l->d_ids[nxt];
+        x.host_xy = l->h_xy[nxt]; x.host_ids = l->h_ids[nxt]; x.host_n = l->h_n; x.host_av = l->h_av;
+        l->arrive_total[C_LK] += (unsigned)gx;
+        x.arrive = l->d_arrive + 16 * C_LK; x.arrive_target = l->arrive_total[C_LK];
+        x.word = &l->words[16 * W_TRACK]; x.seq = ++l->seq[W_TRACK];
+        l->queued = false;
+      }
+      if ((error = svo_kg_track(ctx, g->st_lk[line], a, k, gx))) break;
+      for (int li : q_now) EV(li, "track_launch", k);
+      g->launches[0]++; g->lanes_carried[0] += k;
+      progressed = true;
+    }
+    if (error) break;
+    for (int line = 0; line < g->n_chain && !error; ++line) {
+      if (chain_busy[line]) continue;
+      hipStream_t stc = g->st_chain[line];
+      const std::vector<int> h_now = take_line(q_hyp, line, g->n_chain), r_now = take_line(q_ref, line, g->n_chain), t_now = take_line(q_tri, line, g->n_chain);
+    if (!h_now.empty()) {
+      SvoPnpHypLanes a;
+      int k = 0;
+      for (int li : h_now) {
+        Lane* l = g->lanes[li];
+        const int m = l->m_tracked;
+        if (hipMemcpyAsync(l->d_xyz, l->h_xyz, sizeof(float) * 3 * m, hipMemcpyHostToDevice, stc) != hipSuccess) { error = SVO_ERR_HIP; ctx->err = "pipeline group: world point upload failed"; break; }
+        SvoPnpHypLane& x = a.lane[k++];
+        x.xyz = l->d_xyz; x.xy = l->d_xy[l->cur]; x.n = m;
+        x.f = (double)g->K[0]; x.cx = (double)g->K[2]; x.cy = (double)g->K[5];
+        // rvec/tvec are CV_32F in/out, the solver works in double (host/pipeline.cpp; csrc/pnp.hip svo_k_pnp)
+        const double rv[3] = {l->rvec[0], l->rvec[1], l->rvec[2]};
+        const double th = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        if (th < 1e-12) { x.q0[0] = 1; x.q0[1] = 0.5 * rv[0]; x.q0[2] = 0.5 * rv[1]; x.q0[3] = 0.5 * rv[2]; }
+        else {
+          const double sn = sin(0.5 * th) / th;
+          x.q0[0] = cos(0.5 * th); x.q0[1] = sn * rv[0]; x.q0[2] = sn * rv[1]; x.q0[3] = sn * rv[2];
+        }
+        for (int c = 0; c < 3; ++c) x.t0[c] = (double)l->tvec[c];
+        x.thr2 = (double)svo_ref::PNP_REPROJ_ERROR * (double)svo_ref::PNP_REPROJ_ERROR;
+        x.hyp_pose = l->d_hyp_pose; x.hyp_count = l->d_hyp_count; x.hyp_mask = l->d_hyp_mask; x.mask_words = svo_div_up(m, 64);
+        x.host_count = l->h_count;
+        x.pub = make_pub(l, W_HYP, C_HYP, g->pnp_iterations);
+        l->queued = false;
+      }
+      if (error) break;
+      if ((error = svo_kg_pnp_hypotheses(ctx, stc, a, k, g->pnp_iterations))) break;
+      for (int li : h_now) EV(li, "hyp_launch", k);
+      g->launches[1]++; g->lanes_carried[1] += k;
+      progressed = true;
+    }
+    if (!r_now.empty()) {
+      SvoPnpRefLanes a;
+      int k = 0;
+      for (int li : r_now) {
+        Lane* l = g->lanes[li];
+        SvoPnpRefLane& x = a.lane[k++];
+        x.xyz = l->d_xyz; x.xy = l->d_xy[l->cur]; x.n = l->m_tracked;
+        x.f = (double)g->K[0]; x.cx = (double)g->K[2]; x.cy = (double)g->K[5];
+        x.hyp_pose = l->d_hyp_pose; x.hyp_mask = l->d_hyp_mask; x.mask_words = svo_div_up(l->m_tracked, 64); x.best = l->best;
+        x.out_pose = l->d_out; x.inliers = l->d_inl; x.n_inliers = l->d_nin; x.host_pose = l->h_out; x.host_inliers = l->h_inl; x.host_nin = l->h_nin;
+        x.inlier_xy = l->d_trk_xy;
+        x.pub = make_pub(l, W_REF, -1, 1);
+        l->queued = false;
+      }
+      if ((error = svo_kg_pnp_refine(ctx, stc, a, k))) break;
+      for (int li : r_now) EV(li, "ref_launch", k);
+      g->launches[2]++; g->lanes_carried[2] += k;
+      progressed = true;
+    }
+    if (!t_now.empty()) {
+      // dedup (:113-128) for the lanes that tracked, then sparse StereoBM + triangulation (:137-142, :34-39 for frame 0)
+      SvoDedupLanes d;
+      SvoStereoTriLanes t;
+      t.w = W; t.h = H; t.stride = W; t.ndisp = svo_ref::STEREO_NUM_DISPARITIES; t.block = svo_ref::STEREO_BLOCK_SIZE;
+      int kd = 0, kt = 0, gxd = 1, gxt = 1;
+      for (int li : t_now) {
+        Lane* l = g->lanes[li];
+        const int n_det = hc[li * batch + l->frame];
+        gxt = std::max(gxt, n_det);
+        if (!l->first_keyframe) gxd = std::max(gxd, svo_div_up(n_det, 4));
+      }
+      for (int li : t_now) {
+        Lane* l = g->lanes[li];
+        const int i = l->frame, n_det = hc[li * batch + i];
+        float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        SvoStereoTriLane& x = t.lane[kt++];
+        if (l->first_keyframe) {
+          x.xy = DET(li, i); x.n_dev = nullptr;
+        } else {
+          SvoDedupLane& y = d.lane[kd++];
+          y.det = DET(li, i); y.n_det = n_det; y.trk = l->d_trk_xy; y.n_trk = l->num_inliers; y.min_d = g->prm.min_feature_distance;
+          y.keep = l->d_flags; y.kept_xy = l->d_new_xy; y.n_kept = l->d_cnt;
+          l->arrive_total[C_DEDUP] += (unsigned)gxd;
+          y.arrive = l->d_arrive + 16 * C_DEDUP; y.target = l->arrive_total[C_DEDUP];
+          // hmat = [R^T | -R^T t]  :130-134 (float Mats; the product accumulates in double)
+          memset(pose, 0, sizeof(pose));
+          for (int r = 0; r < 3; ++r) {
+            for (int c = 0; c < 3; ++c) pose[4 * r + c] = l->rmat[3 * c + r];
+            double s = 0.0;
+            for (int c = 0; c < 3; ++c) s += (double)(-l->rmat[3 * c + r]) * (double)l->tvec[c];
+            pose[4 * r + 3] = (float)s;
+          }
+          pose[15] = 1.f;
+          x.xy = l->d_new_xy; x.n_dev = l->d_cnt;
+        }
+        x.left = IMG(left, li, i); x.right = IMG(right, li, i);
+        x.n_max = n_det; x.disp = l->d_disp;
+        x.M = svo_k_reprojection_matrix(pose, g->K[0], g->K[2], g->K[5], (float)g->prm.cam.baseline);  // :178-189
+        x.kept_xy = l->h_tri_xy; x.xyz = l->h_tri_xyz; x.n_kept = l->h_tri_cnt;
+        x.pub = make_pub(l, W_TRI, C_TRI, gxt);
+        l->state = L_TRI_WAIT;
+        l->queued = false;
+      }
+      if (kd && (error = svo_kg_dedup(ctx, stc, d, kd, gxd))) break;
+      if ((error = svo_kg_stereo_triangulate(ctx, stc, t, kt, gxt))) break;
+      for (int li : t_now) EV(li, "tri_launch", kt);
+      if (kd) { g->launches[3]++; g->lanes_carried[3] += kd; }
+      g->launches[3]++; g->lanes_carried[3] += kt;
+      progressed = true;
+    }
+    }
+    if (error) break;
+    // ---- solves.  A finished solve is joined right away (its admission is handed back: lanes that are already through
+    // their frames would otherwise keep the budget while others wait for it); the results are the same whenever they are read.
+    for (int li = 0; li < S && !error; ++li) {
+      Lane* l = g->lanes[li];
+      const int bs = l->ba_state.load(std::memory_order_acquire);
+      if (l->state != L_NEED_SOLVE && ((bs == BA_INFLIGHT && svo_ba_solve_poll(l->ba)) || bs == BA_HOST_DONE)) { EV(li, "solve_joined", l->frame); error = finish_solve(g, l); progressed = true; }
+    }
+    if (error) break;
+    // everything that has been assembled goes out as one launch once no lane is still assembling
+    {
+      int assembling = 0;
+      q_ba.clear();
+      for (int li = 0; li < S; ++li) {
+        const int bs = g->lanes[li]->ba_state.load(std::memory_order_acquire);
+        assembling += bs == BA_ASSEMBLING;
+        if (bs == BA_READY) q_ba.push_back(li);
+      }
+      int ba_launches_inflight = 0;
+      bool ba_line_busy[svo_pipeline_group::MAX_LINES] = {};
+      {
+        int ids[svo_pipeline_group::MAX_LINES];
+        for (int& v : ids) v = -1;
+        for (int li = 0; li < S; ++li) {
+          const Lane* l = g->lanes[li];
+          if (l->ba_state.load(std::memory_order_acquire) != BA_INFLIGHT || svo_ba_solve_poll(l->ba)) continue;
+          ba_line_busy[l->ba_line] = true;
+          bool seen = false;
+          for (int v : ids) seen |= v == l->ba_launch;
+          if (seen) continue;
+          if (ba_launches_inflight < svo_pipeline_group::MAX_LINES) ids[ba_launches_inflight] = l->ba_launch;
+          ++ba_launches_inflight;
+        }
+      }
+      int free_line = -1;
+      for (int i = 0; i < g->n_ba; ++i) if (!ba_line_busy[i]) { free_line = i; break; }
+      if (!q_ba.empty() && assembling == 0 && free_line >= 0) {
+        svo_ba* bas[SVO_MAX_LANES];
+        std::vector<int> cand;
+        for (int li : q_ba) {
+          Lane* l = g->lanes[li];
+          if (l->ba_rc == 1) { l->ba_state.store(BA_NONE, std::memory_order_release); continue; }  // nothing to solve
+          if (l->ba_rc) { error = l->ba_rc; break; }
+          bas[cand.size()] = l->ba;
+          cand.push_back(li);
+        }
+        if (error) break;
+        if (!cand.empty()) {
+          const int launched = svo_ba_solve_launch(bas, (int)cand.size(), g->st_ba[free_line]);
+          if (launched > 0) { g->launches[4]++; g->lanes_carried[4] += launched; progressed = true; }
+          ++g->ba_launch_id;
+          for (int k = 0; k < launched; ++k) EV(cand[k], "ba_launch", launched);
+          for (int k = 0; k < launched; ++k) { g->lanes[cand[k]]->ba_launch = g->ba_launch_id; g->lanes[cand[k]]->ba_line = free_line; g->lanes[cand[k]]->ba_state.store(BA_INFLIGHT, std::memory_order_release); }
+          if (launched < (int)cand.size()) {
+            // not admitted (too many waiting workgroups on the GPU right now) or not eligible: if nothing of this group is
+            // in flight that could free the budget, the head lane is solved by the host-driven loop on a worker
+            bool inflight = false;
+            for (int li = 0; li < S; ++li) inflight |= g->lanes[li]->ba_state.load(std::memory_order_acquire) == BA_INFLIGHT;
+            if (!inflight) {
+              Lane* l = g->lanes[cand[launched]];
+              l->ba_state.store(BA_HOST_SOLVING, std::memory_order_release);
+              g->pool.post(l, 1);
+              progressed = true;
+            }
+          }
+        }
+      }
+    }
+    if (all_done) break;
+    if (!progressed) {
+      __builtin_ia32_pause();
+      if (++idle_spins > 2000u && (idle_spins & 255u) == 0) sched_yield();
+      if ((idle_spins & 0xFFFFu) == 0) {  // never hang: a launch that does not come back within seconds is reported with the lanes' states
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - last_progress).count();
+        if (waited > 5.0) {
+          std::string msg = "pipeline group: no progress for 5 s; lanes (state/frame/solve):";
+          for (int li = 0; li < S; ++li) {
+            char b[64];
+            snprintf(b, sizeof(b), " %d/%d/%d%s", g->lanes[li]->state, g->lanes[li]->frame, g->lanes[li]->ba_state.load(), g->lanes[li]->queued ? "q" : "");
+            msg += b;
+          }
+          ctx->err = msg;
+          error = SVO_ERR_HIP;
+          break;
+        }
+      }
+    } else {
+      idle_spins = 0;
+      last_progress = std::chrono::steady_clock::now();
+    }
+  }
+
+  // ---- end of the batch: join every solve, fill the poses that waited for it
+  for (int li = 0; li < S; ++li) {
+    Lane* l = g->lanes[li];
+    for (;;) {  // a lane whose assembly is still running, or whose solve is not launched yet
+      const int bs = l->ba_state.load(std::memory_order_acquire);
+      if (bs == BA_NONE || bs == BA_INFLIGHT || bs == BA_HOST_DONE) break;
+      if (bs == BA_READY) {
+        if (l->ba_rc == 1) { l->ba_state.store(BA_NONE); break; }
+        if (l->ba_rc) { if (!error) error = l->ba_rc; l->ba_state.store(BA_NONE); break; }
+        svo_ba* one = l->ba;
+        if (svo_ba_solve_launch(&one, 1, g->st_ba[0]) == 1) { l->ba_launch = ++g->ba_launch_id; l->ba_line = 0; l->ba_state.store(BA_INFLIGHT); g->launches[4]++; g->lanes_carried[4]++; }
+        else { l->ba_rc = svo_ba_solve_finish(l->ba, &l->ba_summary); l->ba_state.store(BA_HOST_DONE); }
+        break;
+      }
+      __builtin_ia32_pause();
+      if (std::chrono::duration<double>(std::chrono::steady_clock::now() - last_progress).count() > 60.0) {
+        if (!error) { error = SVO_ERR_HIP; ctx->err = "pipeline group: a bundle-adjustment worker did not come back"; }
+        break;
+      }
+    }
+    const int rcf = finish_solve(g, l);
+    if (rcf && !error) error = rcf;
+    svo_frame_result* res = &RES(li, 0);
+    if (l->pending_from < 0) l->pending_from = batch;
+    fill_pending(l, res, batch);
+  }
+  if (trace_on) {
+    for (const Ev& e : evs) fprintf(stderr, "[svo group] %10.1f lane %2d %-22s %d\n", e.us, e.lane, e.what, e.arg);
+    fprintf(stderr, "[svo group] %10.1f end\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
+  }
+  if (error) return error;
+  if (!ctx->err.empty()) return SVO_ERR_HIP;
+  return SVO_OK;
+}
