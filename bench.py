@@ -263,7 +263,7 @@ def run_kitti(args):
     ba_it = sum(r.ba_iterations for r in res)
     out = {
         "metric": "stereo frames/sec on 1241x376 KITTI pairs", "value": frames / dt, "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "n_gpus": (dist.get_world_size() if dist is not None else 1), "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/f32/f64",
         "data": "synthetic",
         "config": {"workload": "kitti_1241x376_1500corners_5kf_window (BASELINE configs[1])", "batch_per_stream": B,
@@ -374,7 +374,7 @@ def run_kitti_stream(args):
     ate = float(S.api.ate_rmse(np.array(est), np.array(gt), False)) if len(est) >= 3 else None
     path = float(np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum()) if len(gt) >= 2 else 0.0
     frames = world * n_frames
-    out = {"metric": "stereo frames/sec on 1241x376 KITTI pairs", "value": frames / dt, "unit": "frames/s", "n_gpus": world,
+    out = {"metric": "stereo frames/sec on 1241x376 KITTI pairs", "value": frames / dt, "unit": "frames/s", "n_gpus": (dist.get_world_size() if dist is not None else 1),
            "steps": steps, "warmup": max(1, args.warmup), "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
            "config": {"workload": f"kitti00_shaped_stream_{n_frames}_frames_10kf_window (BASELINE configs[2])",
@@ -449,8 +449,44 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches):
     return r
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without a launcher: this parent makes NO GPU call (never `exec` after HIP is initialised, never a
+    fork of an initialised process); it starts N ranks with torch.distributed.run and relays rank 0's JSON line."""
+    import subprocess
+    import torch  # device_count() does not initialise the runtime on this image
+    have = torch.cuda.device_count() if "SVO_BENCH_FORCE_DEVICE" not in os.environ else args.gpus
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to measure fewer ranks than asked", file=sys.stderr, flush=True)
+        return 2
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in child.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if child.returncode != 0 or line is None:
+        sys.stdout.write(child.stdout)
+        print(f"bench.py: the {args.gpus}-rank run failed (exit code {child.returncode})", file=sys.stderr, flush=True)
+        return child.returncode or 1
+    print(line, flush=True)
+    return 0
+
+
 def main():
     args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --gpus N` (it spawns the ranks) or under "
+              f"torch.distributed.run with --nproc-per-node equal to --gpus", file=sys.stderr, flush=True)
+        sys.exit(2)
     if args.workload == "kitti_cfg1":
         out = run_kitti(args)
     elif args.workload == "kitti_stream":

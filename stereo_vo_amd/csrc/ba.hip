@@ -1175,14 +1175,14 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       if (op == LMOP_ITERATE && chain) { cs.arrived_total += (unsigned)grid; cs.post_seq++; }
       cs.tag = ((unsigned long long)(unsigned)a.host_seq << 20) | (unsigned long long)(++cs.op_count & 0xFFFFFu);
       const long long tn = (long long)wall_clock64();
-      if (!a.dbg) cs.t_ctl += tn - cs.t_mark;
-      cs.t_mark = tn;
+      cs.t_ctl += tn - cs.t_mark; cs.t_mark = tn;
     }
     __syncthreads();
     return op;
   };
 
-  const int st = cs.state;  // stable: written before the barrier that ended the previous turn
+  const int st = cs.state;
+  __syncthreads();  // thread 0 rewrites cs.state further down in this very turn: every wave must have read it first
   if (st == LMS_START) {
     if (tid == 0) {
       cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, a.base_copied + (unsigned)grid, true) : 1;
@@ -1206,7 +1206,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     cs.t_body += w0 - cs.t_mark;
     cs.go = wait_until(a.cnt + LMC_ARRIVE, cs.arrive_total, true);
     cs.t_mark = (long long)wall_clock64();
-    if (!a.dbg) cs.t_wait += cs.t_mark - w0;
+    cs.t_wait += cs.t_mark - w0;
     cs.first = 0;
   }
   __syncthreads();
@@ -1277,13 +1277,6 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       if (tid == 0) { cs.cost = cP[pay1 - 2]; cs.initial_cost = cs.cost; }
       for (int q = tid; q < n; q += nt) cSc[q] = 1.0 / (1.0 + sqrt(cP[n * n + 2 * n + q]));
       act = ACT_ACCEPT_TAIL;  // the same gradient test
-      __syncthreads();
-      if (a.dbg && tid == 0) {  // diagnostics: the first payload and the scales derived from it
-        unsigned long long x = 0, y = 0;
-        for (int i = 0; i < pay1; ++i) if ((i >= n * n) || ((i % n) / 6 >= (i / n) / 6)) x = (x * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cP[i]);
-        for (int i = 0; i < n; ++i) y = (y * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cSc[i]);
-        cs.t_wait = (long long)x; cs.t_ctl = (long long)y;  // (diagnostic build: timing slots reused)
-      }
     } else if (st == LMS_RELIN) {
       if (tid == 0) cs.need_linearize = 0;
       act = ACT_SOLVE;
@@ -1347,21 +1340,6 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
     // ACT_SOLVE: scaled, damped reduced camera system (host/lm.cpp) -> Cholesky -> pose step
     const double radius = cs.radius;
-    if (a.dbg) {
-      double* img = reinterpret_cast<double*>(a.dbg + 16 * 4096) + (size_t)blockIdx.x * 1024;
-      if (pay1 + n <= 1024) {
-        for (int i = tid; i < pay1; i += nt) img[i] = cP[i];
-        for (int i = tid; i < n; i += nt) img[pay1 + i] = cSc[i];
-      }
-    }
-    if (a.dbg && tid == 0) {  // diagnostics: what this workgroup's step control is about to factorise
-      unsigned long long x = 0, y = 0;
-      for (int i = 0; i < pay1; ++i) if ((i >= n * n) || ((i % n) / 6 >= (i / n) / 6)) x = (x * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cP[i]);
-      for (int i = 0; i < n; ++i) y = (y * 1099511628211ull) ^ (unsigned long long)__double_as_longlong(cSc[i]);
-      unsigned* gdb = a.dbg + 16 * blockIdx.x + 8;
-      gdb[0] = (unsigned)(x >> 32); gdb[1] = (unsigned)x; gdb[2] = (unsigned)(y >> 32); gdb[3] = (unsigned)y;
-      gdb[4] = (unsigned)((unsigned long long)cs.t_wait >> 32); gdb[5] = (unsigned)cs.t_wait; gdb[6] = (unsigned)cs.iterations; gdb[7] = (unsigned)((unsigned long long)cs.t_ctl >> 32);
-    }
     for (int q = tid; q < n; q += nt) {
       const double sq = cSc[q];
       cDf[q] = fmin(fmax(cP[n * n + 2 * n + q] * sq * sq, MIN_DIAG), MAX_DIAG) / radius;
@@ -1485,7 +1463,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   P.flag = reinterpret_cast<int*>(a.cnt + LMC_CTL + 4);  // a word nobody reads: completion is the arrival counter itself
   P.seq = 0;
   P.ctl_dev = a.dev_pay + 2 * 8;
-  if (tid == 0) cs.state = LMS_START;
+  if (tid == 0) { cs.state = LMS_START; cs.bad = 0; }
   if (a.arena_src) {
     const double* src = reinterpret_cast<const double*>(a.arena_src);
     double* dst = reinterpret_cast<double*>(a.arena_dst);
@@ -1502,7 +1480,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (a.dbg && tid == 0) {
       unsigned* g = a.dbg + 16 * blockIdx.x;
       g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
-      g[4] = (unsigned)cs.chain; g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
+      g[4] = (unsigned)cs.chain | ((unsigned)cs.bad << 8);  // bit 8: a tagged granule never arrived g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
     }
     if (op == LMOP_ABORT || cs.bad) return;
     if (op == LMOP_EXIT) break;
@@ -1927,18 +1905,13 @@ static int ba_alloc(svo_ba* ba) {
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
-  // The payload of the device-resident solve is written by some workgroups and read by ALL workgroups of the same launch,
-  // iteration after iteration at the same addresses.  In ordinary (coarse-grained) device memory that is not coherent
-  // across the eight XCDs' L2s inside a launch: measured on MI355X under load (4+ stereo streams), a workgroup's sc1 loads
-  // returned the PREVIOUS iteration's values for whole 72-byte reduction slices written from other XCDs (lines its own L2
-  // still held), its replicated step control then took a different branch than everybody else's.  Fine-grained memory is
-  // the architected answer: not retained in L2, coherent at agent scope.  (Counters only ever see atomics; the
-  // contribution slots are written and read once per iteration at addresses a workgroup's XCD does not otherwise touch.)
-  SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_pay_fg, sizeof(double) * 2 * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)), hipDeviceMallocFinegrained));
-  SVO_HIP_CHECK(ctx, hipExtMallocWithFlags((void**)&ba->d_lmc, sizeof(unsigned) * LMC_WORDS, hipDeviceMallocFinegrained));
+  // Payload staging (tagged granules, see granule_store) and the counter block of the device-resident solve: ordinary
+  // device memory.  (Fine-grained memory was tried for both while chasing stale reads: it did not help the payload — the
+  // tags did — and the arrival counters LOST increments there: 38 workgroups had added to a counter that read 37.)
+  A(ba->d_pay_fg, double, 2 * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)));
+  A(ba->d_lmc, unsigned, LMC_WORDS);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_lane, sizeof(LmLane), hipHostMallocCoherent));
-  if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 16 * 4096 + 2 * 1024 * 128 + 8 * 256);
-  if (ba->d_lmdbg) SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmdbg, 0, sizeof(unsigned) * (16 * 4096 + 2 * 1024 * 128 + 8 * 256)));
+  if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 16 * 4096);
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned)));
   A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
@@ -2496,7 +2469,7 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out) {
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
-  a.dbg = d.C <= 256 ? ba->d_lmdbg : nullptr;
+  a.dbg = d.C <= 8192 ? ba->d_lmdbg : nullptr;
   L.lm_begin = ba->h_list_begin[nd - 1];
   L.lm_count = ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1];
   L.la = ba_list_args(ba);
@@ -2575,31 +2548,6 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
       (void)hipMemcpy(c, ba->d_lmc, sizeof(c), hipMemcpyDeviceToHost);
       fprintf(stderr, "[svo ba] device solve gave up: grid %d K %d arrive %u done %u arrived %u posted %u copied %u exited %u\n", d.C, d.K,
               c[LMC_ARRIVE], c[LMC_DONE], c[LMC_ARRIVED], c[LMC_POSTED], c[LMC_COPIED], c[LMC_EXITED]);
-      if (ba->d_lmdbg && d.C <= 256) {
-        unsigned rr[8 * 256];
-        (void)hipMemcpy(rr, ba->d_lmdbg + 16 * 4096 + 2 * 1024 * 128, sizeof(rr), hipMemcpyDeviceToHost);
-        for (int b = 0; b < 256; ++b) if (rr[8 * b]) {
-          double lds, mem; unsigned long long a_ = ((unsigned long long)rr[8 * b + 2] << 32) | rr[8 * b + 3], b_ = ((unsigned long long)rr[8 * b + 4] << 32) | rr[8 * b + 5];
-          memcpy(&lds, &a_, 8); memcpy(&mem, &b_, 8);
-          fprintf(stderr, "[svo ba]   re-read mismatch in workgroup %d: %u words, first at staging item %u (slice %u): LDS %.17g, memory now %.17g; waited for arrive %u, counter %u\n", b, rr[8 * b],
-                  rr[8 * b + 1], rr[8 * b + 1] / 16, lds, mem, rr[8 * b + 6], rr[8 * b + 7]);
-        }
-        (void)hipMemset(ba->d_lmdbg + 16 * 4096 + 2 * 1024 * 128, 0, sizeof(rr));
-        const int nwg = (d.C + 1) / 2, p1 = d.n * d.n + 3 * d.n + 2 + d.n;
-        std::vector<double> img((size_t)nwg * 1024);
-        (void)hipMemcpy(img.data(), reinterpret_cast<double*>(ba->d_lmdbg + 16 * 4096), sizeof(double) * img.size(), hipMemcpyDeviceToHost);
-        if (p1 <= 1024) for (int b = 1; b < nwg; ++b) {
-          int nd = 0, first = -1, last = -1;
-          for (int i = 0; i < p1; ++i) if (memcmp(&img[(size_t)b * 1024 + i], &img[i], 8)) {
-            const int r = i / std::max(d.n, 1), c = i % std::max(d.n, 1);
-            if (i < d.n * d.n && c / 6 < r / 6) continue;  // lower blocks: never delivered
-            if (nd < 8) fprintf(stderr, "[svo ba]   image of workgroup %d differs at word %d (row %d col %d): %.17g vs %.17g\n", b, i, r, c, img[(size_t)b * 1024 + i], img[i]);
-            if (first < 0) first = i;
-            last = i; ++nd;
-          }
-          if (nd) fprintf(stderr, "[svo ba]   workgroup %d: %d differing words of %d, first %d last %d (n %d)\n", b, nd, p1, first, last, d.n);
-        }
-      }
       if (ba->d_lmdbg && d.C <= 4096) {
         std::vector<unsigned> g(16 * (size_t)d.C);
         (void)hipMemcpy(g.data(), ba->d_lmdbg, sizeof(unsigned) * g.size(), hipMemcpyDeviceToHost);
@@ -2608,8 +2556,6 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
           if (b == 0 || memcmp(q, &g[0], 20) != 0)
             fprintf(stderr, "[svo ba]   workgroup %d: op %u state %u iterations %u need_linearize %u chain %u arrive_total %u done_total %u lin_calls %u\n", b, q[0], q[1],
                     q[2], q[3], q[4], q[5], q[6], q[7]);
-          if (b == 0 || memcmp(q, &g[0], 20) != 0)
-            fprintf(stderr, "[svo ba]     last factorised at iteration %u: payload %08x%08x scales %08x%08x | first payload %08x%08x first scales(hi) %08x\n", q[14], q[8], q[9], q[10], q[11], q[12], q[13], q[15]);
         }
       }
     }
