@@ -30,7 +30,7 @@ import time
 
 # HIP runtime knob, read when the runtime initialises: the default of 4 hardware queues makes the 2 HIP streams of
 # each stereo stream (tracker + bundle adjuster) share queues and serialise; measured +6 % at 8 streams.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "4")  # the pipeline groups need four; beyond four a launch -> completion round trip costs 30-90 us instead of 7-11 (profiles/r02_exp_launch_rate.txt)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # two pipeline groups use 2 x 7 HIP streams; with 4 hardware queues their long solve launches share queues with the tracking launches and serialise (measured 7.8 k vs 11 k frames/s)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -52,12 +52,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
-    ap.add_argument("--streams", type=int, default=8, help="independent stereo streams processed concurrently per GPU")
+    ap.add_argument("--streams", type=int, default=24, help="independent stereo streams processed concurrently per GPU")
     ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
-    ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k"])
+    ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k", "hd10k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
     ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="default line only: skip the driver-timed figures of BASELINE configs[2..4]")
     ap.add_argument("--cpu-frames", type=int, default=16)
     return ap.parse_args()
 
@@ -307,7 +308,7 @@ def run_kitti(args):
         ate = float(S.api.ate_rmse(centres(res[:m]), centres(ores[:m]), False)) if m >= 3 else 0.0
         out["parity_vs_cpu"] = {"frames": m, "index_sets_and_poses_identical": bool(same), "ate_rmse_m": ate}
     if NG > 0:
-        out["config"]["launches_per_step"] = {k: v for k, v in streams[0].pipe.last_stats().items()}
+        out["config"]["launches_per_step_of_group_0"] = {k: v for k, v in streams[0].pipe.last_stats().items()}
     for st in streams:
         st.close()
     if single_pipe is not None:
@@ -409,6 +410,115 @@ def run_kitti_stream(args):
     return out if rank == 0 else None
 
 
+HDW, HDH = 1280, 720
+
+
+def run_hd10k(args):
+    """BASELINE configs[4]: synthetic 1280x720 stereo stream (d435i focal, config/d435i.yaml:1,4), ~10 k features per frame
+    (max_corners 10000, quality 0.01, minDistance 6), 10-keyframe window, ONE stream resident in HBM, 64 frames in steps of 16."""
+    import stereo_vo_amd as S
+    torch, dist, rank, local, world = dist_setup(args.gpus)
+    B, n_frames = 16, 64
+    ctx = S.Context(HDW, HDH, device=local, max_batch=B, max_corners=10240, max_candidates=1 << 17, max_features=10240)
+    p = S.synth_default(HDW, HDH)
+    p.focal, p.cx, p.cy, p.baseline = 385.7545, 640.0, 360.0, 0.05
+    p.seed += rank
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16)) as ex:
+        fr = list(ex.map(lambda i: S.synth_render(p, i), range(n_frames)))
+    L, R = np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = HDW, HDH
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 10000, 0.01, 6.0, 10000, 10
+    pp.ba_max_time_s = 0.0
+    dev = torch.device("cuda", local)
+    dL, dR = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
+    pipe = S.Pipeline(ctx, pp)
+    istride = HDW * HDH
+
+    def one_pass():
+        pipe.reset()
+        res = []
+        for f0 in range(0, n_frames, B):
+            res += pipe.process_batch_dev(dL.data_ptr() + f0 * istride, dR.data_ptr() + f0 * istride, B)
+        return res
+    one_pass()  # warm-up
+    barrier_sync(torch, dist, ctx)
+    t0 = time.perf_counter()
+    res = one_pass()
+    ctx.sync()
+    barrier_sync(torch, dist, ctx)
+    dt = time.perf_counter() - t0
+    A = HDW * HDH
+    gbs = n_frames / dt * 6.33 * A / 1e9
+    out = {"metric": "stereo frames/sec on 1280x720 pairs, ~10k features", "value": world * n_frames / dt, "unit": "frames/s",
+           "n_gpus": (dist.get_world_size() if dist is not None else 1), "steps": n_frames // B, "warmup": 1,
+           "ms_per_step": 1e3 * dt / (n_frames // B), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8/f32/f64", "data": "synthetic",
+           "config": {"workload": "hd_1280x720_10k_features_10kf_window (BASELINE configs[4])", "frames": n_frames, "batch": B,
+                      "keyframes": int(sum(r.is_keyframe for r in res)),
+                      "mean_tracked": float(np.mean([r.n_tracked for r in res if r.n_tracked] or [0])),
+                      "mean_detected": float(np.mean([r.n_detected for r in res])),
+                      "ba_lm_iterations": int(sum(r.ba_iterations for r in res)), "fps_vs_60": n_frames / dt / 60.0},
+           "roofline": {"bound": "hbm", "kernel": "whole front end per stereo pair (6.33 A bytes, SURVEY 8d)", "achieved": gbs, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": 6.33 * A, "traffic": None}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib as O
+        cores = min(os.cpu_count() or 1, 16)
+        os.environ["OMP_NUM_THREADS"] = str(cores)
+        n = 6
+        op = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=HDW, height=HDH, max_corners=10000, quality=0.01,
+                        min_feature_distance=6.0, parallax_thresh=20.0, window_size=10, max_features=10000, ba_max_iterations=50, num_threads=cores)
+        t1 = time.perf_counter()
+        ores = [op.process(L[i], R[i]) for i in range(n)]
+        dtc = time.perf_counter() - t1
+        same = all((a.n_detected, a.n_tracked, a.n_inliers, a.n_new, a.is_keyframe, a.ba_iterations) ==
+                   (b.n_detected, b.n_tracked, b.n_inliers, b.n_new, b.is_keyframe, b.ba_iterations) and
+                   list(a.pose7) == list(b.pose7) for a, b in zip(res[:n], ores))
+        out["cpu_baseline"] = dict(value=n / dtc, unit="frames/s", cores=cores, kind="port",
+                                   sample=f"first {n} frames of the same stream, whole oracle pipeline, {dtc:.1f} s")
+        out["parity_vs_cpu"] = {"frames": n, "index_sets_and_poses_identical": bool(same)}
+    pipe.close()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+    return out if rank == 0 else None
+
+
+def other_workloads(args):
+    """Driver-timed figures of BASELINE configs[2], [3] (sparse and dense) and [4] inside the default line: each in its own
+    sub-object with its own roofline, cpu_baseline sample and parity flag; bounded so that the whole default run stays
+    within a few minutes."""
+    import copy
+    out = {}
+
+    def sub(name, fn):
+        t0 = time.perf_counter()
+        try:
+            r = fn()
+            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "parity_vs_cpu") if k in r}
+            keep["wall_s"] = round(time.perf_counter() - t0, 1)
+            out[name] = keep
+        except Exception as e:  # a sub-workload must never take the headline down with it
+            out[name] = {"error": f"{type(e).__name__}: {e}", "wall_s": round(time.perf_counter() - t0, 1)}
+
+    a = copy.copy(args)
+    a.batch, a.cpu_frames = 16, 12
+    sub("kitti_stream_4541_frames", lambda: run_kitti_stream(a))
+    from tools import bench_ba
+    b = copy.copy(args)
+    b.steps, b.warmup = 20, 3
+    os.environ.pop("SVO_BA_DENSE", None)
+    sub("ba50k_sparse", lambda: bench_ba.run(b, cpu_seconds=6.0))
+    os.environ["SVO_BA_DENSE"] = "1"
+    sub("ba50k_dense", lambda: bench_ba.run(b, cpu_seconds=6.0))
+    os.environ.pop("SVO_BA_DENSE", None)
+    sub("hd_1280x720_10k", lambda: run_hd10k(args))
+    return out
+
+
 def profile_summary():
     try:
         return json.load(open(PROFILE_SUMMARY))
@@ -489,6 +599,10 @@ def main():
         sys.exit(2)
     if args.workload == "kitti_cfg1":
         out = run_kitti(args)
+        if out is not None and world == 1 and not args.no_other_workloads:
+            out["other_workloads"] = other_workloads(args)
+    elif args.workload == "hd10k":
+        out = run_hd10k(args)
     elif args.workload == "kitti_stream":
         out = run_kitti_stream(args)
     else:

@@ -324,6 +324,12 @@ int svo_ba_set_comm(svo_ba* ba, void* nccl_comm);
 int svo_rccl_unique_id(void* id128);
 int svo_rccl_comm_create(void** nccl_comm, int n_ranks, int rank, const void* id128, int device);
 int svo_rccl_comm_destroy(void* nccl_comm);
+/* Where ceres::Solve's step control runs for window-sized, single-rank, deterministic solves (src/bundle_adjuster.cpp:140):
+ * mode 1: on the device — the whole solve is ONE launch (csrc/ba.hip ba_lm_kernel), the host only waits for its completion
+ * word; mode 0: on the host (host/lm.cpp), 1-3 launches per LM iteration; mode -1 (default): on the device while more
+ * than two pipelines are inside svo_pipeline_process_batch* (pipeline groups always solve on the device).  Results are
+ * bit-identical either way. */
+int svo_ba_set_device_lm(svo_ba* ba, int mode);
 /* counters of the last svo_ba_solve / svo_ba_solve_problem */
 int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats);
 int svo_ba_solve_problem(svo_ba* ba, svo_ba_summary* summary);

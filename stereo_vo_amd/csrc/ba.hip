@@ -1862,6 +1862,7 @@ struct svo_ba {
   double* d_pay_fg = nullptr;    // [payload2 | payload1] of ba_lm_kernel in FINE-GRAINED device memory (see ba_alloc)
   unsigned* d_lmdbg = nullptr;   // SVO_BA_TRACE: last command of every workgroup of ba_lm_kernel
   double* h_result = nullptr;    // pinned [LMR_DOUBLES | poses 7 Kmax], inside h_pin
+  int device_lm = -1;            // svo_ba_set_device_lm: -1 automatic, 0 never, 1 whenever eligible
   bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
   hipStream_t lm_stream = nullptr;  // ... on this stream
   LmLane* h_lane = nullptr;      // pinned launch record of this adjuster's solve
@@ -2035,6 +2036,12 @@ extern "C" int svo_ba_set_allreduce(svo_ba* ba, svo_allreduce_fn fn, void* user)
 extern "C" int svo_ba_set_comm(svo_ba* ba, void* nccl_comm) {
   if (!ba) return SVO_ERR_INVALID;
   ba->comm = nccl_comm;
+  return SVO_OK;
+}
+
+extern "C" int svo_ba_set_device_lm(svo_ba* ba, int mode) {
+  if (!ba || mode < -1 || mode > 1) return SVO_ERR_INVALID;
+  ba->device_lm = mode;
   return SVO_OK;
 }
 
@@ -2436,18 +2443,21 @@ inline FusedAdmission* ba_resident_admission(svo_ba* ba) { return &ba->res_admis
 
 // ---- device-resident solve (ba_lm_kernel): host side -------------------------------------------------------------
 // SVO_BA_DEVICE_LM=0 / 1 forces; default: on for every window-sized single-rank deterministic solve that is admitted.
+// Default for svo_ba_solve / svo_ba_solve_problem: on while more than two pipelines are inside process_batch (a solve that
+// never comes back to the host costs 52 us per LM iteration whatever else runs; the host-driven loop 35 us alone on the GPU,
+// 52-57 with eight streams and a host thread per stream).  A pipeline group always uses it (svo_ba_solve_launch).
 bool ba_device_lm_wanted() {
   static const char* e = getenv("SVO_BA_DEVICE_LM");
   if (e && *e) return atoi(e) != 0;
-  return true;
+  return svo_throughput_mode();
 }
 
 size_t ba_lm_lds_bytes(const BaDev& d) { return sizeof(double) * ba_lm_ctl_doubles(d.n, d.K); }
 
 // Fills the adjuster's launch record for the loaded problem; false: not eligible (use the host-driven paths).
-bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out) {
+bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   BaDev& d = ba->d;
-  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !ba_device_lm_wanted() || !ba->h_lane) return false;
+  if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !(forced || ba->device_lm == 1 || (ba->device_lm < 0 && ba_device_lm_wanted())) || !ba->h_lane) return false;
   if (ba->opt.max_time_s > 0 && ba->opt.max_time_s < LM_DEVICE_MIN_TIME_CAP_S) return false;  // see ba_lm_kernel
   const int nd = (d.K - 1) * d.K / 2 + (d.K - 1) + 1;
   if ((int)ba->h_list_begin.size() < nd || nd > 48) return false;  // the destination lists ride in the record
@@ -2481,7 +2491,7 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out) {
 // ONE launch for the solves of `n` adjusters (the lanes of a pipeline group that reached a keyframe together; n = 1: a
 // single pipeline) on stream `st`.  Returns how many of them — a prefix — were admitted and launched; the others keep
 // their loaded problem and can be offered again later, or solved by the host-driven paths.
-int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st) {
+int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced) {
   LmLanePtrs ptrs;
   int launched = 0, max_c = 0;
   size_t max_lds = 0;
@@ -2490,7 +2500,7 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st) {
     int cost = 0;
     size_t lds = 0;
     ba->lm_inflight = false;
-    if (!ba_device_lm_fill(ba, &cost, &lds)) break;
+    if (!ba_device_lm_fill(ba, &cost, &lds, forced)) break;
     if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) break;
     if (!ba_resident_admission(ba)->admit(cost)) break;
     // the counters start from zero: cleared in front of the launch (the adjuster's previous solve no longer touches them
@@ -2771,7 +2781,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
-  if (ba_device_lm_launch(&ba, 1, ba->stream) == 1) {  // the whole solve is one launch: nothing for the host to do until the completion word
+  if (ba_device_lm_launch(&ba, 1, ba->stream, false) == 1) {  // the whole solve is one launch: nothing for the host to do until the completion word
     const int rcd = ba_device_lm_end(ba, sum);
     d.flag = nullptr;
     return rcd;
@@ -2967,7 +2977,7 @@ int svo_ba_solve_prepare(svo_ba* ba) {
 int svo_ba_solve_launch(svo_ba** bas, int n, void* stream) {
   if (!bas || n < 1) return 0;
   svo_use_device(bas[0]->ctx);
-  return ba_device_lm_launch(bas, n, stream ? (hipStream_t)stream : bas[0]->stream);
+  return ba_device_lm_launch(bas, n, stream ? (hipStream_t)stream : bas[0]->stream, true);
 }
 
 // 1: the launched solve has published its completion word (svo_ba_solve_finish will not block), 0: still running

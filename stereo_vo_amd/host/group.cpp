@@ -292,8 +292,8 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
   {
     auto knob = [](const char* name, int dflt, int hi) { const char* e = getenv(name); int v = e && *e ? atoi(e) : dflt; return v < 1 ? 1 : (v > hi ? hi : v); };
     g->n_lk = knob("SVO_GROUP_LK_LINES", 1, svo_pipeline_group::MAX_LINES);
-    g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 1, svo_pipeline_group::MAX_LINES);
-    g->n_ba = knob("SVO_GROUP_BA_LINES", 2, svo_pipeline_group::MAX_LINES);
+    g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 2, svo_pipeline_group::MAX_LINES);
+    g->n_ba = knob("SVO_GROUP_BA_LINES", 4, svo_pipeline_group::MAX_LINES);
     g->st_lk[0] = ctx->stream;
     for (int i = 1; i < g->n_lk; ++i) chk(hipStreamCreateWithFlags(&g->st_lk[i], hipStreamNonBlocking), "stream");
     for (int i = 0; i < g->n_chain; ++i) chk(hipStreamCreateWithFlags(&g->st_chain[i], hipStreamNonBlocking), "stream");
@@ -368,7 +368,9 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
   if (rc) { svo_pipeline_group_destroy(g); return rc; }
   {
     const char* e = getenv("SVO_GROUP_WORKERS");
-    int nw = e ? atoi(e) : (n_lanes >= 4 ? 2 : 1);
+    // one worker per lane up to 8: lanes in phase reach their keyframes together, and a problem that waits for a worker
+    // delays its solve — measured with 2 workers for 8 lanes: 400 us from add_keyframe to the solve's launch, 90 of them assembly
+    int nw = e ? atoi(e) : (n_lanes < 8 ? n_lanes : 8);
     if (nw < 1) nw = 1;
     if (nw > 8) nw = 8;
     g->pool.start(nw, ctx->device);

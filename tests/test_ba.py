@@ -122,13 +122,14 @@ def test_hip_device_cholesky_matches_host():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("device_lm", [False, True])  # step control on the host (1-3 launches per iteration) / on the device (one launch per solve)
 @pytest.mark.parametrize("seed,K,N,dense", [(1, 5, 400, False), (2, 6, 1500, False), (4, 10, 3000, False),
                                             (5, 20, 2000, True), (6, 2, 50, False)])
-def test_hip_ba_matches_oracle(ctx, seed, K, N, dense):
+def test_hip_ba_matches_oracle(ctx, seed, K, N, dense, device_lm):
     import stereo_vo_amd as S
     p = BP.make_problem(seed, K, N, dense=dense)
     ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8,
-                  max_observations=len(p["op"]) + 8, max_time_s=0.0)
+                  max_observations=len(p["op"]) + 8, max_time_s=0.0, device_lm=device_lm)
     ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
     s = ba.solve_problem()
     poses, pts = ba.read_problem()
@@ -277,3 +278,39 @@ def test_hip_ba_read_before_solve_returns_the_loaded_problem(ctx):
     poses, pts = ba.read_problem()
     assert np.allclose(pts, pto, rtol=1e-6, atol=1e-5)
     ba.close()
+
+
+@pytest.mark.gpu
+def test_hip_device_solve_delivers_around_unobserved_landmarks(ctx):
+    """svo_ba_load_problem accepts landmarks without observations; they are skipped when wave chunks are formed, so a
+    chunk's landmark indices have gaps.  The device-resident solve delivers its landmarks by index SPAN (not by count):
+    every observed landmark must come back solved — bit-identical to the host-driven loop — and every unobserved one
+    untouched, including a gap too wide for the LDS staging."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(21, 5, 300, dense=False)
+    n0 = len(p["points0"])
+    rng = np.random.default_rng(3)
+    # new index space: gaps of 1..3 unobserved landmarks after every fifth landmark, one gap of 700 in the middle
+    new_index, pts, k = [], [], 0
+    for j in range(n0):
+        if j % 5 == 4:
+            for _ in range(int(rng.integers(1, 4))):
+                pts.append(rng.normal(size=3) * 50.0); k += 1
+        if j == n0 // 2:
+            for _ in range(700):
+                pts.append(rng.normal(size=3) * 50.0); k += 1
+        new_index.append(k); pts.append(p["points0"][j]); k += 1
+    pts = np.array(pts)
+    oj = np.array([new_index[j] for j in p["oj"]], np.int32)
+    observed = np.zeros(len(pts), bool); observed[oj] = True
+    out = {}
+    for dev in (False, True):
+        ba = S.api.BA(ctx, 5, BP.F, BP.CX, BP.CY, max_landmarks=len(pts) + 8, max_observations=len(oj) + 8, max_time_s=0.0, device_lm=dev)
+        ba.load_problem(p["poses0"], pts, p["op"], oj, p["uv"])
+        s = ba.solve_problem()
+        out[dev] = (s.iterations, *ba.read_problem())
+        ba.close()
+    assert out[True][0] == out[False][0] and out[True][0] > 3
+    assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
+    assert np.array_equal(out[True][2][~observed], pts[~observed])
+    assert not np.array_equal(out[True][2][observed], pts[observed])

@@ -105,7 +105,7 @@ def cpu_baseline(p, K, seconds=12.0):
                        f"iterations in {dt:.1f} s), rate scaled by the observation share {frac:.3f}")
 
 
-def run(args):
+def run(args, cpu_seconds=12.0):
     sys.path.insert(0, ROOT)
     import stereo_vo_amd as S
     from stereo_vo_amd import sharding
@@ -157,11 +157,11 @@ def run(args):
     fl_local = flops_per_iteration(op, oj, len(pts))
     n = 6 * (K - 1)
     out = {"metric": "BA LM iterations/sec (50k landmarks x 20 keyframes)", "value": n_it / dt, "unit": "iterations/s",
-           "n_gpus": world, "steps": n_it, "warmup": ws.iterations, "ms_per_step": 1e3 * dt / n_it, "higher_is_better": True,
+           "n_gpus": (dist.get_world_size() if dist is not None else 1), "steps": n_it, "warmup": ws.iterations, "ms_per_step": 1e3 * dt / n_it, "higher_is_better": True,
            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
            "config": {"workload": "ba_50k_landmarks_20_keyframes (BASELINE configs[3])", "observations": int(len(p["op"])),
                       "landmarks": int(len(p["points0"])), "poses": K, "final_cost": s.final_cost,
-                      "initial_cost": s.initial_cost, "accumulation": acc_mode,
+                      "initial_cost": s.initial_cost, "accumulation": acc_mode, "variant": "dense (every landmark in all 20 poses)" if os.environ.get("SVO_BA_DENSE") == "1" else "sparse (L_j ~ U{2..20})",
                       "sharding": "landmark j on rank j mod N, poses replicated",
                       "collective": ("ncclAllReduce(sum, f64) from libsvo_hip.so on the adjuster's stream" if comm is not None else
                                      "callback" if dist is not None else "none (single rank)"),
@@ -188,7 +188,7 @@ def run(args):
                                    "residual/Jacobian part issues separate f64 multiply and add (f64_muladd row), only the "
                                    "Schur products run on the matrix pipe"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
-        out["cpu_baseline"] = cpu_baseline(p, K)
+        out["cpu_baseline"] = cpu_baseline(p, K, cpu_seconds)
     ba.close()
     if comm is not None:
         from stereo_vo_amd import api
