@@ -183,3 +183,37 @@ def test_decoders_reject_malformed_files(tmp_path):
         f.write_bytes(blob)
         with pytest.raises(S.SvoError):
             S.image_read_gray(str(f))
+
+
+@pytest.mark.gpu
+def test_kitti_driver_200_frames_at_kitti_size_matches_oracle(tmp_path):
+    """BASELINE configs[0] at its stated size: the first 200 frames of a KITTI-shaped sequence (1241x376, kitti00
+    intrinsics, the reference's own constants: 300 corners, quality 0.1, 30 px, 5-keyframe window) through svo_kitti_run,
+    compared with the oracle pipeline on ALL 200 frames (camera-in-world positions, src/vo_node.cpp:149-150)."""
+    import stereo_vo_amd as S
+    n = 200
+    p, root, frames = _export(tmp_path, n=n, w=1241, h=376, focal=718.856)
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height, pp.ba_max_time_s = p.width, p.height, 0.0
+    ctx = S.Context(1241, 376, max_batch=1, max_corners=300, max_candidates=1 << 17, max_features=400)
+    traj, st = S.kitti_run(ctx, pp, root, 7, n)
+    assert st.frames == n and st.keyframes >= 20
+    o = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=p.width, height=p.height, max_corners=300,
+                   quality=0.1, min_feature_distance=30.0, parallax_thresh=20.0, window_size=5, max_features=400,
+                   ba_max_iterations=50, num_threads=8)
+    n_kf = 0
+    for i, (L, R) in enumerate(frames):
+        r = o.process(L, R)
+        n_kf += r.is_keyframe
+        q = np.array(list(r.pose7), np.float32)
+        if not q[:4].any():
+            continue
+        w, x, y, z = q[0], -q[1], -q[2], -q[3]
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], np.float32)
+        pw = Rm @ (-q[4:])
+        assert np.allclose(traj[i][:, 3], pw, rtol=0, atol=1e-4), i
+    assert n_kf == st.keyframes
+    ctx.close()
