@@ -43,7 +43,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the copy bandwidth that guide measured
 VALU_ISSUE_PEAK_GINSTR = 1228.8  # 256 CUs x 4 SIMDs x 2.4 GHz / 2 (one wave64 VALU instruction per 2 cycles per SIMD)
 FP64_VEC_PEAK_TFLOPS = 78.6  # public MI355X FP64 vector spec (not in the local guide)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r02_summary.json")  # written by tools/prof_round.sh + prof_summary.py
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03_summary.json")  # written by tools/prof_round.sh + prof_summary.py
 
 
 def parse():
@@ -52,12 +52,13 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
-    ap.add_argument("--streams", type=int, default=24, help="independent stereo streams processed concurrently per GPU")
+    ap.add_argument("--streams", type=int, default=48, help="independent stereo streams processed concurrently per GPU")
     ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k", "hd10k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
     ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-stream measurement (profiling runs)")
     ap.add_argument("--no-other-workloads", action="store_true", help="default line only: skip the driver-timed figures of BASELINE configs[2..4]")
     ap.add_argument("--cpu-frames", type=int, default=16)
     return ap.parse_args()
@@ -205,7 +206,7 @@ def run_kitti(args):
     single_pipe = None
     if NG > 0:  # pipeline groups: NG host threads, the streams dealt round-robin
         streams = [_Group(S, torch, local, seeds[gi::NG], B) for gi in range(NG)]
-        if NS > 1:
+        if NS > 1 and not args.no_single:
             single_pipe = _Stream(S, torch, local, seeds[0], B)
     else:
         streams = [_Stream(S, torch, local, sd, B) for sd in seeds]
@@ -229,7 +230,7 @@ def run_kitti(args):
     run_steps(args.warmup)
     # single-stream rate (latency-bound: one sequential VO chain) measured first, in the same run
     single = None
-    if NS > 1:
+    if NS > 1 and not args.no_single:
         one = single_pipe if single_pipe is not None else streams[0]
         for _ in range(max(1, args.warmup)):
             one.step()
@@ -281,11 +282,15 @@ def run_kitti(args):
     # roofline: (a) the SURVEY 8(d) contract figure of the whole front end, (b) the dominant kernel on the resource
     # that binds it (HIP events on the library's stream over the timed region + the committed SQ counter pass)
     avg_us = 1e3 * k_ms / k_n if k_n > 0 else None
-    out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, avg_us, res, k_n)
+    lanes_per_launch = 1.0
+    g0_stats = streams[0].pipe.last_stats() if NG else None  # of the group's last step
+    if g0_stats and g0_stats.get("track", [0, 0])[0]:
+        lanes_per_launch = g0_stats["track"][1] / g0_stats["track"][0]
+    out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, avg_us, res, k_n, lanes_per_launch, bool(NG))
     share = profile_summary()
     if share:
-        out["kernel_time_share"] = {"source": "profiles/r02_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
-                                    "8_streams_percent": share.get("kernel_time_share_8_streams"),
+        out["kernel_time_share"] = {"source": "profiles/r03_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
+                                    "default_percent": share.get("kernel_time_share_default_24_streams"),
                                     "1_stream_percent": share.get("kernel_time_share_1_stream")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, ores = cpu_baseline(streams[0].p, streams[0].L, streams[0].R, args.cpu_frames)
@@ -526,7 +531,7 @@ def profile_summary():
         return None
 
 
-def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches):
+def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches, lanes_per_launch=1.0, grouped=False):
     """one stereo pair needs 6.33 A bytes of compulsory HBM traffic (corner 1 A + stereo 4 A as a dense map
     + LK pyramid 1.33 A); achieved = pairs/s x 6.33 A.  The path is latency / instruction-issue bound, not HBM bound, so
     the dominant kernel is also reported against the resource that binds it (VALU issue)."""
@@ -542,20 +547,32 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches):
                  "the contract fraction is reported as asked, the binding resource of the dominant kernel is below"}
     if avg_us:
         n = np.mean([x.n_tracked for x in res if x.n_tracked]) if any(x.n_tracked for x in res) else 0
-        dk = {"kernel": kernel + "_kernel", "avg_launch_us": avg_us, "launches": launches,
+        dk = {"kernel": kernel + ("_group_kernel" if grouped else "_kernel"), "avg_launch_us": avg_us, "launches": launches,
               "measured": "HIP events on the library's stream around every launch in the timed region"}
         if kernel == "lk_fb":
-            byts = 2 * 1.33 * A  # both pyramids once
-            dk.update({"features_per_launch": float(n), "algorithmic_bytes_per_launch": byts,
+            # a grouped launch tracks the features of every lane that reached the stage together (one wavefront per feature)
+            byts = 2 * 1.33 * A * lanes_per_launch  # both pyramids of every lane once
+            dk.update({"lanes_per_launch": lanes_per_launch, "features_per_launch": float(n) * lanes_per_launch, "algorithmic_bytes_per_launch": byts,
                        "hbm_frac": byts / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "valu_issue"})
-            vi = prof.get("lk_fb_valu_wave_instructions_per_launch")
+            per_wave = prof.get("lk_fb_valu_instructions_per_wave")
+            vi = per_wave * float(n) * lanes_per_launch if per_wave else prof.get("lk_fb_valu_wave_instructions_per_launch")
             if vi:
                 g = vi / (avg_us * 1e-6) / 1e9
                 dk.update({"valu_wave_instructions_per_launch": vi, "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR,
                            "frac": g / VALU_ISSUE_PEAK_GINSTR,
-                           "note": "instruction count from the committed SQ pass (profiles/r02_sq_counters.txt), duration live; one "
-                                   "wavefront per feature, <= 30 iterations x 4 levels x 2 directions of a 441-pixel window"})
+                           "note": "VALU instructions per wavefront (= per feature) from the committed SQ pass (profiles/r03_sq_counters.txt) x the "
+                                   "features of a launch, duration live; <= 30 iterations x 4 levels x 2 directions of a 441-pixel window per feature"})
         r["dominant_kernel"] = dk
+    ks = prof.get("kernel_average_us_default_24_streams") or {}
+    if grouped and "ba_lm_kernel" in ks and prof.get("ba_lm_valu_wave_instructions_per_launch"):
+        # the largest share of summed kernel time: one launch = whole window solves (device-resident LM); from the committed profile, not live
+        us = ks["ba_lm_kernel"]
+        g = prof["ba_lm_valu_wave_instructions_per_launch"] / (us * 1e-6) / 1e9
+        r["largest_time_share_kernel"] = {
+            "kernel": "ba_lm_kernel", "avg_launch_us": us, "time_share_percent": (prof.get("kernel_time_share_default_24_streams") or {}).get("ba_lm_kernel"),
+            "waves_per_launch": prof.get("ba_lm_waves_per_launch"), "valu_wave_instructions_per_launch": prof["ba_lm_valu_wave_instructions_per_launch"],
+            "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": g / VALU_ISSUE_PEAK_GINSTR, "bound": "latency (device-wide meetings of a few hundred wavefronts)",
+            "source": "profiles/r03_kernel_stats_default_24_streams.csv + profiles/r03_sq_counters.txt (rocprofv3 runs of this command), not measured live"}
     return r
 
 

@@ -15,7 +15,7 @@ LIB = os.path.join(ROOT, "stereo_vo_amd", "libsvo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
              "-fno-fast-math", "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"),
-             "-I", CSRC, "-I", HOST]
+             "-I", CSRC, "-I", HOST] + os.environ.get("SVO_EXTRA_HIPFLAGS", "").split()  # developer experiments (-DSVO_EXP_...): never set for a product build
 
 
 def _newer(target, sources):

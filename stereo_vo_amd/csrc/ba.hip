@@ -299,52 +299,111 @@ __device__ __forceinline__ void store_pair_block(double* B, double* Bt, const do
   }
 }
 
-template <bool WT = false>  // WT: the slots are consumed inside this launch (see slot_store2)
-__device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius,
-                                                int first_pass, double* sS, double* sGred, double* sGc, double* sDU,
-                                                double& lcost, double& lgp2) {
-  const int lane = threadIdx.x & 63, n = P.n;
-  const bool active = R.active;
-  const int k = R.k, j = R.j, first = R.first, len = R.len, o = R.o;
-  double r[2] = {0, 0}, Jc[12], Jp[6];
+// One 6x6 Schur / U contribution (block (k, kt) = -Y Wt^T, plus Jc^T Jc on a landmark's own pair), two rows at a time:
+// rows a, a + 1 give B's words [6a, 6a + 12) and the (a, a + 1) word pair of each of Bt's six rows — twelve values live
+// instead of thirty-six (the same stores with the same values as store_pair_block of the whole block).
+template <bool WT>
+__device__ __forceinline__ void emit_pair_block(double* B, double* Bt, const double (&Y)[18], const double (&Wt)[18], const double (&Jc)[12], bool own) {
 #pragma unroll
-  for (int i = 0; i < 12; ++i) Jc[i] = 0.0;
+  for (int a = 0; a < 6; a += 2) {
+    double w0[6], w1[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
-  if (active) {
-    eval_obs(poses_ + 7 * k, R.p, R.u, R.v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
-    lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+    for (int b = 0; b < 6; ++b) {
+      const double v0 = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+      const double v1 = -(Y[3 * a + 3] * Wt[3 * b] + Y[3 * a + 4] * Wt[3 * b + 1] + Y[3 * a + 5] * Wt[3 * b + 2]);
+      w0[b] = own ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v0 : v0;
+      w1[b] = own ? (Jc[a + 1] * Jc[b] + Jc[6 + a + 1] * Jc[6 + b]) + v1 : v1;
+    }
+#ifdef SVO_EXP_NO_PAIR_STORES  // timing experiment only (results are garbage): the arithmetic without the slot stores
+    double acc = 0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) acc += w0[b] + w1[b];
+    if (acc == 1.2345e-300 && B) B[0] = acc;
+#else
+    if (B) {
+#pragma unroll
+      for (int b = 0; b < 6; b += 2) { slot_store2<WT>(B + 6 * a + b, w0[b], w0[b + 1]); slot_store2<WT>(B + 6 * (a + 1) + b, w1[b], w1[b + 1]); }
+    }
+    if (Bt) {
+#pragma unroll
+      for (int b = 0; b < 6; ++b) slot_store2<WT>(Bt + 6 * b + a, w0[b], w1[b]);
+    }
+#endif
   }
-  const double my_cost = active ? 0.5 * (r[0] * r[0] + r[1] * r[1]) : 0.0;
+}
+
+// What pass A computes before the trust-region radius enters (residual, Jacobians, the landmark's sums in observation order):
+// inside ba_lm_kernel this part runs while the accept / radius decision of the step is still on its way.
+struct LinPre { double r[2], Jc[12], Jp[6], V[9], gp[3], cost_l; int maxlen; };
+// Per-lane constants of a solve that ba_lm_kernel keeps in registers from pass to pass instead of re-loading them (two to
+// three dependent global loads per pass otherwise): destination rows of the lane's Schur pairs, the landmark's Jacobi scales
+// (fixed by the first pass A), the lane's row in its pose list.
+struct ChunkRegs { const int2* pp; int pp_stride; double s[3]; int obs_pos; bool have_pp; };  // pp: LDS, entry d of this lane at pp[d * pp_stride]
+
+__device__ __forceinline__ void linearize_prefix(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, LinPre& q, double& lcost) {
+  const bool active = R.active;
+  const int k = R.k, first = R.first, len = R.len;
+  q.r[0] = q.r[1] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) q.Jc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) q.Jp[i] = 0.0;
+  if (active) {
+    eval_obs(poses_ + 7 * k, R.p, R.u, R.v, P.f, P.cx, P.cy, k > 0, q.r, q.Jc, q.Jp);
+    lcost += 0.5 * (q.r[0] * q.r[0] + q.r[1] * q.r[1]);
+  }
+  const double my_cost = active ? 0.5 * (q.r[0] * q.r[0] + q.r[1] * q.r[1]) : 0.0;
   double cost_l = 0.0;  // landmark cost, summed in observation order (deterministic mode)
   int maxlen = len;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
   // landmark sums: every lane of a segment gathers the whole segment in observation order
-  double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) q.V[i] = 0.0;
+  q.gp[0] = q.gp[1] = q.gp[2] = 0.0;
   for (int t = 0; t < maxlen; ++t) {
     const int src = (first + t) & 63;
-    double q[6], rr[2];
+    double w[6], rr[2];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) q[i] = shfl_d(Jp[i], src);
-    rr[0] = shfl_d(r[0], src); rr[1] = shfl_d(r[1], src);
+    for (int i = 0; i < 6; ++i) w[i] = shfl_d(q.Jp[i], src);
+    rr[0] = shfl_d(q.r[0], src); rr[1] = shfl_d(q.r[1], src);
     const double ct = shfl_d(my_cost, src);
     if (t < len) {
       cost_l += ct;
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        gp[a] += q[a] * rr[0] + q[3 + a] * rr[1];
+        q.gp[a] += w[a] * rr[0] + w[3 + a] * rr[1];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) V[3 * a + b] += q[a] * q[b] + q[3 + a] * q[3 + b];
+        for (int b = 0; b < 3; ++b) q.V[3 * a + b] += w[a] * w[b] + w[3 + a] * w[3 + b];
       }
     }
   }
+  q.cost_l = cost_l;
+  q.maxlen = maxlen;
+}
+
+template <bool WT = false>  // WT: the slots are consumed inside this launch (see slot_store2)
+__device__ __forceinline__ void linearize_suffix(const BaDev& P, const ObsRec& R, const LinPre& q, double radius, int first_pass, double* sS, double* sGred,
+                                                 double* sGc, double* sDU, double& lgp2, ChunkRegs* cache = nullptr) {
+  const int lane = threadIdx.x & 63, n = P.n;
+  const bool active = R.active;
+  const int k = R.k, j = R.j, first = R.first, len = R.len, o = R.o;
+  const double (&r)[2] = q.r;
+  const double (&Jc)[12] = q.Jc;
+  const double (&Jp)[6] = q.Jp;
+  const double (&V)[9] = q.V;
+  const double (&gp)[3] = q.gp;
+  const double cost_l = q.cost_l;
+  const int maxlen = q.maxlen;
   double s[3] = {1, 1, 1};
   if (active) {
     if (first_pass) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + sqrt(V[4 * a]));
       if (lane == first) { P.sp[3 * j] = s[0]; P.sp[3 * j + 1] = s[1]; P.sp[3 * j + 2] = s[2]; }
+      if (cache) { cache->s[0] = s[0]; cache->s[1] = s[1]; cache->s[2] = s[2]; }
+    } else if (cache) {
+      s[0] = cache->s[0]; s[1] = cache->s[1]; s[2] = cache->s[2];
     } else {
       s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
     }
@@ -376,7 +435,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
 #pragma unroll
     for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
   if (freep && P.det) {
-    double* ov = P.obsV + (size_t)P.obs_pos[o] * 18;
+    double* ov = P.obsV + (size_t)(cache ? cache->obs_pos : P.obs_pos[o]) * 18;
     double w[18];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
@@ -404,9 +463,14 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
     // that the prefetched entries are indexed statically
     const int mine = freep ? first + len - lane : 0;  // pairs (lane, lane + d), d < mine
     int2 pp[8];
-    const int2* ppsrc = reinterpret_cast<const int2*>(P.pair_pos) + (freep ? P.pair_base[o] : 0);
+    if (cache && cache->have_pp) {
 #pragma unroll
-    for (int d = 0; d < 8; ++d) pp[d] = d < mine ? ppsrc[d] : int2{-1, -1};
+      for (int d = 0; d < 8; ++d) pp[d] = cache->pp[d * cache->pp_stride];
+    } else {
+      const int2* ppsrc = reinterpret_cast<const int2*>(P.pair_pos) + (freep ? P.pair_base[o] : 0);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) pp[d] = d < mine ? ppsrc[d] : int2{-1, -1};
+    }
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
       if (d >= maxlen) break;  // wave-uniform
@@ -418,15 +482,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
       if (d < mine && kt > 0) {
         double* B = pp[d].x >= 0 ? P.pairB + (size_t)pp[d].x * 36 : nullptr;   // block (k, kt) if it is an upper block
         double* Bt = pp[d].y >= 0 ? P.pairB + (size_t)pp[d].y * 36 : nullptr;  // block (kt, k) if THAT is an upper block
-        double w[36];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-            w[6 * a + b] = d == 0 ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-          }
-        store_pair_block<WT>(B, Bt, w);
+        emit_pair_block<WT>(B, Bt, Y, Wt, Jc, d == 0);
       }
     }
     return;
@@ -443,15 +499,7 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
         const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
         double* B = posA >= 0 ? P.pairB + (size_t)posA * 36 : nullptr;
         double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
-        double w[36];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < 6; ++b) {
-            const double v = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-            w[6 * a + b] = src == lane ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v : v;
-          }
-        store_pair_block<WT>(B, Bt, w);
+        emit_pair_block<WT>(B, Bt, Y, Wt, Jc, src == lane);
       } else {
         const int bt = 6 * (kt - 1);
 #pragma unroll
@@ -465,6 +513,32 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
   }
 }
 
+template <bool WT = false>
+__device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius,
+                                                int first_pass, double* sS, double* sGred, double* sGc, double* sDU,
+                                                double& lcost, double& lgp2, ChunkRegs* cache = nullptr) {
+  LinPre q;
+  linearize_prefix(P, R, poses_, q, lcost);
+  linearize_suffix<WT>(P, R, q, radius, first_pass, sS, sGred, sGc, sDU, lgp2, cache);
+}
+
+// the lane's constants of the loaded problem (ba_lm_kernel, once per solve)
+__device__ __forceinline__ void load_chunk_regs(const BaDev& P, const ObsRec& R, ChunkRegs& c, int2* pp_lds /* this lane's column */, int pp_stride) {
+  const int lane = threadIdx.x & 63;
+  const bool freep = R.active && R.k > 0;
+  int maxlen = R.len;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
+  c.have_pp = P.det && maxlen <= 8;
+  c.obs_pos = freep ? P.obs_pos[R.o] : 0;
+  const int mine = freep ? R.first + R.len - lane : 0;
+  const int2* ppsrc = reinterpret_cast<const int2*>(P.pair_pos) + (freep ? P.pair_base[R.o] : 0);
+#pragma unroll
+  for (int d = 0; d < 8; ++d) pp_lds[d * pp_stride] = (c.have_pp && d < mine) ? ppsrc[d] : int2{-1, -1};
+  c.pp = pp_lds; c.pp_stride = pp_stride;
+  c.s[0] = c.s[1] = c.s[2] = 1.0;
+}
+
 // Pass B for one wave chunk: back-substitution of the pose step dc_ at (poses_, R.p), candidate landmark (returned in
 // `cand`, valid in every active lane of the landmark's segment; written to cand_points_ by the segment's first lane),
 // candidate residual against cand_poses_.  Deterministic mode: the landmark's four scalars go to lmV2.  Otherwise
@@ -473,7 +547,7 @@ template <bool WT = false>  // WT: lmV2 is consumed inside this launch
 __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_,
                                               const double* __restrict__ cand_poses_, const double* __restrict__ dc_,
                                               double* __restrict__ cand_points_, double radius, D3& cand, double& a_cost,
-                                              double& a_mc, double& a_dp2, double& a_p2) {
+                                              double& a_mc, double& a_dp2, double& a_p2, const ChunkRegs* cache = nullptr) {
   const int lane = threadIdx.x & 63;
   const bool active = R.active;
   const int k = R.k, j = R.j, first = R.first, len = R.len;
@@ -522,7 +596,7 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
     }
   }
   if (active) {
-    const double s[3] = {P.sp[3 * j], P.sp[3 * j + 1], P.sp[3 * j + 2]};
+    const double s[3] = {cache ? cache->s[0] : P.sp[3 * j], cache ? cache->s[1] : P.sp[3 * j + 1], cache ? cache->s[2] : P.sp[3 * j + 2]};
     double Vd[9], Vi[9], De[3], rh[3];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
@@ -936,8 +1010,11 @@ struct IterShared {
 template <bool RES, int CPW = 1>
 __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, double spec_radius, const LmCtl& ctl, int with_pay1,
                                              int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy, double* sStep,
-                                             IterShared& sh, int n_blocks /* workgroups of THIS solve (a launch may hold several) */) {
+                                             IterShared& sh, int n_blocks /* workgroups of THIS solve (a launch may hold several) */,
+                                             long long* tp = nullptr /* LDS: time split of the phases, 100 MHz ticks (thread 0) */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
+  auto stamp = [&](int slot) { if (tp && tid == 0) { const long long tn = (long long)wall_clock64(); tp[slot] += tn - tmark; tmark = tn; } };
   const int my_chunk = (int)blockIdx.x * CPW + (wave < CPW ? wave : 0);
   const bool worker = (int)blockIdx.x * CPW < P.C;  // workgroups beyond the chunks only reduce
   const bool my_wave_works = wave < CPW && my_chunk < P.C;
@@ -960,6 +1037,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
     }
     if (ctl.chain) {
       __syncthreads();
+      stamp(0);
       if (tid == 0) sh.sLast = __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == sy.arrived_target;
       __syncthreads();
       if (sh.sLast) {
@@ -996,6 +1074,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
         __syncthreads();
       }
       if (!sh.sGo) return;
+      stamp(1);
       if (my_wave_works) {
         const bool accept = sh.sDec[0] != 0.0;
         if (accept) R.p = cand;
@@ -1005,6 +1084,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
     }
   }
   __syncthreads();
+  stamp(2);
   if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
   const bool sums2 = !ctl.chain && blockIdx.x == 0;  // payload2 of a same-sweep / plain step: formed here, by workgroup 0
@@ -1012,6 +1092,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
   if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
   __syncthreads();
   if (!sh.sGo) return;
+  stamp(3);
   if (sums2) {
     reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
     if (P.pay_dev) { if (tid < 4) granule_store(&P.pay2_out[2 * tid], sh.sOut[tid], P.pay_tag); }
@@ -1019,6 +1100,7 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
   }
   for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
   reduce_publish(P);
+  stamp(4);
 }
 
 __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius, double spec_radius, LmCtl ctl, int with_pay1,
@@ -1029,6 +1111,104 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
   // priority over them (measured at 8 streams: +1 %; a high-priority HIP stream instead costs 7 %)
   __builtin_amdgcn_s_setprio(3);
   iterate_body<false>(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh, (int)gridDim.x);
+}
+
+// ---- one LM step inside ba_lm_kernel -----------------------------------------------------------------------------
+// The same arithmetic as iterate_body (every slot receives the same value), arranged for a launch that lives as long as the
+// solve:
+//   * a lane's observation record, its landmark, the destination rows of its Schur pairs and the Jacobi scales stay in
+//     registers from pass to pass (LmWave): a pass starts computing at once instead of behind two or three dependent loads;
+//   * the chained decision is taken by a workgroup that owns no chunk (the launch's last one, `reducer`): it polls the
+//     arrival counter, forms payload2 in the declared order, decides and posts tagged granules — while every worker already
+//     runs the radius-free part of pass A at its candidate (linearize_prefix).  A rejected step (rare) repeats that part at
+//     the current point.
+//   * the reduction slices are spread over workers AND the reducer.
+struct LmWave { ObsRec R; ChunkRegs c; D3 cand; };
+
+template <int CPW>
+__device__ __forceinline__ bool lm_iterate(const BaDev& P, LmWave& W, bool my_wave_works, bool reducer, double radius, double spec_radius,
+                                           const LmCtl& ctl, int with_pay1, int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy,
+                                           double* sStep, IterShared& sh, int n_blocks /* workers of this solve */, long long* tp) {
+  const int tid = threadIdx.x;
+  long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
+  auto stamp = [&](int slot) { if (tp && tid == 0) { const long long tn = (long long)wall_clock64(); tp[slot] += tn - tmark; tmark = tn; } };
+  const double* dc_ = sStep;
+  const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+  const double* cur_poses_ = cand_poses_ + 7 * P.K;
+  double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
+  LinPre pre;
+  if (my_wave_works) {
+    backsub_chunk<true>(P, W.R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, W.cand, unused0, unused1, unused2, unused3, &W.c);
+    if (spec_radius > 0) {  // same sweep: pass A at the candidate with the predicted radius
+      ObsRec Rc = W.R;
+      Rc.p = W.cand;
+      linearize_chunk<true>(P, Rc, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1, &W.c);
+    }
+    stores_acknowledged();  // lmV2 (and the slots of a same sweep) are at the coherence point
+  }
+  if (ctl.chain) {
+    __syncthreads();
+    stamp(0);
+    if (!reducer) {
+      if (tid == 0) __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ObsRec Rc = W.R;
+      Rc.p = W.cand;
+      if (my_wave_works) linearize_prefix(P, Rc, cand_poses_, pre, unused0);  // the decision is on its way meanwhile
+      stamp(1);
+      if (tid == 0) {
+        double d0 = 0, d1 = 0;
+        const bool ok = granule_wait(P.ctl_dev, 0, P.pay_tag, d0) && granule_wait(P.ctl_dev, 1, P.pay_tag, d1);
+        sh.sDec[0] = d0; sh.sDec[1] = d1;
+        sh.sGo = ok;
+      }
+      __syncthreads();
+      if (!sh.sGo) return false;
+      stamp(2);
+      if (my_wave_works) {
+        const bool accept = sh.sDec[0] != 0.0;
+        if (accept) {
+          linearize_suffix<true>(P, Rc, pre, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused1, &W.c);
+        } else {
+          linearize_chunk<true>(P, W.R, cur_poses_, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1, &W.c);
+        }
+        stores_acknowledged();
+      }
+    } else {
+      if (tid == 0) sh.sGo = wait_until(sy.arrived, sy.arrived_target, true);
+      __syncthreads();
+      if (!sh.sGo) return false;
+      reduce_pay2<32, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
+      const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
+      // tagged granules: the decision for the waiting workers, payload2 + decision for everybody's step control
+      if (tid < 2) granule_store(&P.ctl_dev[2 * tid], tid == 0 ? (double)dec.accept : dec.next_radius, P.pay_tag);
+      if (tid >= 64 && tid < 70) {
+        const int t = tid - 64;
+        granule_store(&P.pay2_out[2 * t], t < 4 ? sh.sOut[t] : (t == 4 ? (double)dec.accept : dec.next_radius), P.pay_tag);
+      }
+      stores_acknowledged();
+      stamp(2);
+    }
+  }
+  __syncthreads();
+  stamp(3);
+  if (!reducer && tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
+  const bool sums2 = !ctl.chain && reducer;  // payload2 of a same-sweep / plain step: formed by the reducer, behind everybody's pass
+  // slice owners: the reducer first (it has been idle), then the workers
+  const int slot = reducer ? 0 : (int)blockIdx.x + 1;
+  if (slot >= nb && !sums2) return true;
+  if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
+  __syncthreads();
+  if (!sh.sGo) return false;
+  stamp(4);
+  if (sums2) {
+    reduce_pay2<32, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
+    if (tid < 4) granule_store(&P.pay2_out[2 * tid], sh.sOut[tid], P.pay_tag);
+  }
+  for (int sl = slot; sl < nb; sl += n_blocks + 1) reduce_slice<true>(P, la, sl, sh.sP);
+  if (slot < nb || sums2) reduce_publish(P);
+  stamp(5);
+  return true;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1073,7 +1253,7 @@ constexpr double LM_DEVICE_MIN_TIME_CAP_S = 0.02;
 enum { LMC_ARRIVE = 0, LMC_DONE = 1, LMC_ARRIVED = 2, LMC_POSTED = 3, LMC_COPIED = 4, LMC_EXITED = 5, LMC_CTL = 8, LMC_WORDS = 16 };
 enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
        LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED,
-       LMR_C_ARRIVE, LMR_C_DONE, LMR_C_ARRIVED, LMR_C_POSTED, LMR_C_COPIED, LMR_DOUBLES = 24 };
+       LMR_C_ARRIVE, LMR_C_DONE, LMR_C_ARRIVED, LMR_C_POSTED, LMR_C_COPIED, LMR_TP0, LMR_DOUBLES = LMR_TP0 + 12 };
 enum { LMS_START = 0, LMS_FIRST, LMS_RELIN, LMS_STEP, LMS_ACCEPT_RELIN, LMS_DELIVER };
 enum { LMOP_EXIT = 0, LMOP_LINEARIZE, LMOP_ITERATE, LMOP_DELIVER, LMOP_ABORT };
 
@@ -1086,6 +1266,7 @@ struct LmDevState {
   unsigned long long tag;   // of the command in flight: (solve sequence << 20) | command number
   unsigned op_count;
   long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: waiting for the reduction, step control, passes
+  long long tp[12];  // finer split (workgroup 0): pass B, decision wait, pass A, done wait, slices, payload fetch, system build, Cholesky, step tail
 };
 constexpr double LM_MIN_RADIUS = 1e-32, LM_MAX_RADIUS = 1e16;
 
@@ -1168,8 +1349,8 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   auto issue = [&](int op, int chain, int with_pay1) {
     if (tid == 0) {
       int publishers = grid;
-      if (op == LMOP_LINEARIZE) publishers = min(grid, nb);
-      else if (op == LMOP_ITERATE) publishers = with_pay1 ? min(grid, nb) : 1;
+      if (op == LMOP_LINEARIZE) publishers = min(grid + 1, nb);  // slice owners: the reducer + the workers
+      else if (op == LMOP_ITERATE) publishers = with_pay1 ? min(grid + 1, nb) : 1;
       cs.arrive_total += (unsigned)publishers;
       if (op != LMOP_DELIVER) cs.done_total += (unsigned)grid;
       if (op == LMOP_ITERATE && chain) { cs.arrived_total += (unsigned)grid; cs.post_seq++; }
@@ -1181,17 +1362,19 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     return op;
   };
 
+  auto cstamp = [&](int slot) { if (a.dbg && tid == 0) { const long long tn = (long long)wall_clock64(); cs.tp[slot] += tn - cs.tp[11]; cs.tp[11] = tn; } };
   const int st = cs.state;
   __syncthreads();  // thread 0 rewrites cs.state further down in this very turn: every wave must have read it first
   if (st == LMS_START) {
     if (tid == 0) {
-      cs.go = a.arena_src ? wait_until(a.cnt + LMC_COPIED, a.base_copied + (unsigned)grid, true) : 1;
+      cs.go = 1;
       cs.radius = opt.initial_radius; cs.df = 2.0; cs.cost = 0.0; cs.initial_cost = 0.0; cs.mcc = 0.0;
       cs.t0 = cs.t_mark = (long long)wall_clock64();
       cs.iterations = 0; cs.successful = 0; cs.termination = 1; cs.need_linearize = 0; cs.sel = 0; cs.chain = 0; cs.spec = 0.0; cs.saturated = 0;
       cs.arrived_total = a.base_arrived; cs.post_seq = a.base_posted; cs.done_total = a.base_done; cs.arrive_total = a.base_arrive;
       cs.lin_calls = 1; cs.step_calls = 0; cs.same_sweeps = 0; cs.next_used = 0; cs.bad = 0; cs.op_count = 0; cs.tag = 0;
       cs.t_wait = cs.t_ctl = cs.t_body = 0;
+      for (int i = 0; i < 12; ++i) cs.tp[i] = 0;
       cs.state = LMS_FIRST; cs.first = 1;
     }
     __syncthreads();
@@ -1211,6 +1394,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   }
   __syncthreads();
   if (!cs.go) return LMOP_ABORT;
+  if (a.dbg && tid == 0) cs.tp[11] = (long long)wall_clock64();
 
   if (st == LMS_STEP) {
     if (tid < (cs.chain ? 6 : 4) && !granule_wait(a.dev_pay, tid, cs.tag, cPay2[tid])) cs.bad = 1;  // the decision granules exist only behind a chained step
@@ -1287,6 +1471,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   }
 
   __syncthreads();
+  cstamp(6);
   if (cs.bad) return LMOP_ABORT;  // a granule's tag never showed up (bounded wait): give up, the host reports it
   for (;;) {  // uniform in the workgroup: every transition is decided by thread 0 and read between two barriers
     if (act == ACT_ACCEPT_TAIL) {
@@ -1333,6 +1518,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
           pay_store(&r[LMR_C_ARRIVE], (double)(cs.arrive_total + (unsigned)grid)); pay_store(&r[LMR_C_DONE], (double)cs.done_total);  // + the delivery's arrivals
           pay_store(&r[LMR_C_ARRIVED], (double)cs.arrived_total); pay_store(&r[LMR_C_POSTED], (double)cs.post_seq);
           pay_store(&r[LMR_C_COPIED], (double)(a.base_copied + (a.arena_src ? (unsigned)grid : 0u)));
+          for (int i = 0; i < 12; ++i) pay_store(&r[LMR_TP0 + i], (double)cs.tp[i]);
         }
         for (int i = tid; i < 7 * K; i += nt) pay_store(&a.host_result[LMR_DOUBLES + i], cPose[i]);
       }
@@ -1360,7 +1546,9 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       }
     }
     __syncthreads();
+    cstamp(7);
     const bool ok = n == 0 || svo_dev_cholesky_solve(cP, cRhs, n, cCol);
+    cstamp(8);
     if (ok) {
       for (int q = tid; q < n; q += nt) {
         const double rq = cRhs[q], sq = cSc[q];
@@ -1388,6 +1576,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
         else svo_plus_pose(&cPose[7 * tid], &cDc[6 * (tid - 1)], &cCand[7 * tid]);
       }
       __syncthreads();
+      cstamp(9);
       const int chain = cs.chain;
       return issue(LMOP_ITERATE, chain, chain || cs.spec > 0);
     }
@@ -1436,6 +1625,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __shared__ double sStep[RES_STEP_LDS_DOUBLES];  // [dc | candidate poses | current poses], built in place by the step control
   __shared__ IterShared sh;
   __shared__ LmDevState cs;
+  __shared__ int2 sPairPos[8][128];  // destination rows of every lane's Schur pairs (ChunkRegs::pp)
   __shared__ __align__(16) unsigned char sLaneRaw[sizeof(LmLane)];
   LmLane& sLane = *reinterpret_cast<LmLane*>(sLaneRaw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1449,41 +1639,42 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();
   constexpr int CPW = 2;  // both waves of a workgroup own a wave chunk
-  if ((int)blockIdx.x * CPW >= sLane.P.C) return;  // the launch is as wide as its largest solve
+  const int n_blocks = (sLane.P.C + CPW - 1) / CPW;  // workers of THIS solve; the launch is as wide as its largest solve (+ 1)
+  if ((int)blockIdx.x > n_blocks) return;
+  const bool reducer = (int)blockIdx.x == n_blocks;  // owns no chunk: takes the chained decisions, see lm_iterate
   BaDev P = sLane.P;
   const LmDevArgs& a = sLane.a;
   const ListArgs& la = sLane.la;
-  const int lm_begin = sLane.lm_begin, lm_count = sLane.lm_count, n_blocks = (P.C + CPW - 1) / CPW;
+  const int lm_begin = sLane.lm_begin, lm_count = sLane.lm_count;
   const int my_chunk = (int)blockIdx.x * CPW + wave;
-  const bool my_wave_works = my_chunk < P.C;
+  const bool my_wave_works = !reducer && my_chunk < P.C;
   __builtin_amdgcn_s_setprio(3);
-  P.step_in = nullptr;  // the step block is already in LDS (stage_step<true> then only synchronises)
+  P.step_in = nullptr;  // the step block is built in LDS by the step control
   P.pay2_out = a.dev_pay; P.pay1_out = a.dev_pay + 2 * PAY_STAGE_STRIDE; P.pay_dev = 1;  // granules: [payload2 (8) | decision (8) | 16 per reduction slice]
   P.arrive = a.cnt + LMC_ARRIVE;
   P.flag = reinterpret_cast<int*>(a.cnt + LMC_CTL + 4);  // a word nobody reads: completion is the arrival counter itself
   P.seq = 0;
   P.ctl_dev = a.dev_pay + 2 * 8;
-  if (tid == 0) { cs.state = LMS_START; cs.bad = 0; }
-  if (a.arena_src) {
-    const double* src = reinterpret_cast<const double*>(a.arena_src);
-    double* dst = reinterpret_cast<double*>(a.arena_dst);
-    const size_t n16 = a.arena_bytes / 16;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + tid; i < n16; i += (size_t)n_blocks * blockDim.x)
-      slot_store2<true>(dst + 2 * i, src[2 * i], src[2 * i + 1]);
-    stores_acknowledged();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.cnt + LMC_COPIED, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (tid == 0) { cs.state = LMS_START; cs.bad = 0; cs.accepted = 0; }
+  // this wave's observations, landmarks and destination rows: loaded ONCE (the problem image was copied in front of the launch)
+  LmWave W;
+  W.R = ObsRec{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
+  W.cand = D3{0, 0, 1};
+  if (my_wave_works) W.R = load_obs(P, my_chunk, lane, a.points_a);
+  load_chunk_regs(P, W.R, W.c, &sPairPos[0][tid], 128);
   __syncthreads();
   for (;;) {
+    const int st_before = cs.state;
     const int op = lm_controller(P, a, cs, ctl_lds, sStep);
     if (a.dbg && tid == 0) {
       unsigned* g = a.dbg + 16 * blockIdx.x;
       g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
-      g[4] = (unsigned)cs.chain | ((unsigned)cs.bad << 8);  // bit 8: a tagged granule never arrived g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
+      g[4] = (unsigned)cs.chain | ((unsigned)cs.bad << 8);  // bit 8: a tagged granule never arrived
+      g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
     }
     if (op == LMOP_ABORT || cs.bad) return;
     if (op == LMOP_EXIT) break;
+    if (st_before == LMS_STEP && cs.accepted) W.R.p = W.cand;  // the step control took the step: the candidate is the current point
     const bool sel = cs.sel != 0;
     P.points = sel ? a.points_b : a.points_a;
     P.cand_points = sel ? a.points_a : a.points_b;
@@ -1491,13 +1682,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P.pay_tag = cs.tag;
     if (op == LMOP_DELIVER) {
       if (a.export_points && my_wave_works) {
-        const ObsRec R = load_obs(P, my_chunk, lane, P.points);
+        const ObsRec R = load_obs(P, my_chunk, lane, P.points);  // the buffer the step control selected (a chained pass A may have run ahead of a step that was not taken)
         deliver_chunk_points(R, a.export_points, sStep + wave * (RES_STEP_LDS_DOUBLES / CPW), RES_STEP_LDS_DOUBLES / CPW);  // the step block is no longer needed
       }
-      // everybody's results are out; the last workgroup to arrive publishes the host's completion word
+      // everybody's results are out; the last worker to arrive publishes the host's completion word
       stores_acknowledged();
       __syncthreads();
-      if (tid == 0) {
+      if (tid == 0 && !reducer) {
         const unsigned old = __hip_atomic_fetch_add(a.cnt + LMC_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == P.arrive_target) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -1509,25 +1700,26 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     sy.posted = a.cnt + LMC_POSTED; sy.post_seq = cs.post_seq;
     sy.done = a.cnt + LMC_DONE; sy.done_target = cs.done_total;
     const double radius = cs.radius;
+    long long* tp = a.dbg ? cs.tp : nullptr;
     if (op == LMOP_ITERATE) {
       const LmCtl ctl = {cs.cost, cs.mcc, radius, cs.df, cs.chain};
-      iterate_body<true, CPW>(P, radius, cs.spec, ctl, cs.chain || cs.spec > 0, lm_begin, lm_count, la, sy, sStep, sh, n_blocks);
+      if (!lm_iterate<CPW>(P, W, my_wave_works, reducer, radius, cs.spec, ctl, cs.chain || cs.spec > 0, lm_begin, lm_count, la, sy, sStep, sh, n_blocks, tp)) return;
     } else {  // pass A alone at the current point, then the reduction
       const int first = cs.first;
       if (my_wave_works) {
-        const ObsRec R = load_obs(P, my_chunk, lane, P.points);
         double unused0 = 0, unused1 = 0;
-        linearize_chunk<true>(P, R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, first, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+        linearize_chunk<true>(P, W.R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, first, nullptr, nullptr, nullptr, nullptr, unused0, unused1, &W.c);
         stores_acknowledged();
       }
       __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!reducer && tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int nb = ba_reduce_blocks(P.K - 1);
-      if ((int)blockIdx.x < nb) {
+      const int slot = reducer ? 0 : (int)blockIdx.x + 1;  // slice owners: the reducer first, then the workers
+      if (slot < nb) {
         if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
         __syncthreads();
         if (!sh.sGo) return;
-        for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
+        for (int sl = slot; sl < nb; sl += n_blocks + 1) reduce_slice<true>(P, la, sl, sh.sP);
         reduce_publish(P);
       }
     }
@@ -1891,6 +2083,7 @@ struct svo_ba {
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
   // SVO_TIMING accumulators
+  double lm_tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double lm_t_wait = 0, lm_t_ctl = 0, lm_t_body = 0, lm_t_total = 0; long lm_n = 0, lm_iters = 0, lm_same = 0, lm_used = 0, lm_steps = 0, lm_lins = 0;
   double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0, t_prep = 0, t_read = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
 };
@@ -2015,6 +2208,11 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
     fprintf(stderr, "[svo ba] device-resident solves: %ld, %.1f LM iterations each; per solve (workgroup 0, us): total %.1f = waiting for the passes %.1f + step control %.1f "
                     "+ own share of the passes %.1f; steps %ld (same sweep %ld, next linearisation used %ld), stand-alone linearisations %ld\n", ba->lm_n, (double)ba->lm_iters / ba->lm_n, 1e-2 * ba->lm_t_total / ba->lm_n, 1e-2 * ba->lm_t_wait / ba->lm_n,
             1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n, ba->lm_steps, ba->lm_same, ba->lm_used, ba->lm_lins);
+  if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg)
+    fprintf(stderr, "[svo ba]   per LM iteration (workgroup 0, us): pass B %.2f, radius-free part of pass A %.2f, decision wait %.2f, rest of pass A %.2f, wait for all passes A %.2f, "
+                    "reduction slices %.2f | payload fetch %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
+            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters, 1e-2 * ba->lm_tp[5] / ba->lm_iters,
+            1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
   void* ptrs[] = {ba->d_pay_fg, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
@@ -2483,7 +2681,7 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   L.lm_begin = ba->h_list_begin[nd - 1];
   L.lm_count = ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1];
   L.la = ba_list_args(ba);
-  *cost = ba_lm_admission_cost((d.C + 1) / 2, lds);
+  *cost = ba_lm_admission_cost((d.C + 1) / 2 + 1, lds);
   *lds_out = lds;
   return true;
 }
@@ -2524,7 +2722,7 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced) {
   const auto t0 = now();
   {
     SvoProfScope prof(bas[0]->ctx, SVO_PROF_BA_STEP, st);
-    hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
+    hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c + 1, launched), dim3(128), max_lds, st, ptrs);  // + 1: every solve's reducer
   }
   if (hipGetLastError() != hipSuccess) {
     for (int i = 0; i < launched; ++i) ba_resident_admission(bas[i])->release();
@@ -2586,6 +2784,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   ba->stats.speculation_hits = (int)r[LMR_NEXT_USED];
   ba->stats.single_exchange = (int)r[LMR_SAME_SWEEP];
   ba->lm_same += (long)r[LMR_SAME_SWEEP]; ba->lm_used += (long)r[LMR_NEXT_USED]; ba->lm_steps += (long)r[LMR_STEP_CALLS]; ba->lm_lins += (long)r[LMR_LINEARIZE_CALLS];
+  for (int i = 0; i < 12; ++i) ba->lm_tp[i] += r[LMR_TP0 + i];
   ba->lm_t_wait += r[LMR_T_WAIT]; ba->lm_t_ctl += r[LMR_T_CTL]; ba->lm_t_body += r[LMR_T_BODY]; ba->lm_t_total += r[LMR_T_TOTAL]; ba->lm_n++; ba->lm_iters += (long)r[LMR_ITERATIONS];
   if (sum) {
     sum->iterations = (int)r[LMR_ITERATIONS]; sum->successful_steps = (int)r[LMR_SUCCESSFUL]; sum->termination = (int)r[LMR_TERMINATION];

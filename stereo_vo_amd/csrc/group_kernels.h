@@ -10,7 +10,7 @@
 #define SVO_GROUP_KERNELS_H_
 #include "kernels.h"
 
-constexpr int SVO_MAX_LANES = 16;
+constexpr int SVO_MAX_LANES = 32;
 
 // a3 + the survivor filter of FeatureTracker::track_features, forward/backward LK and the stable compaction in ONE launch:
 // the last wavefront of a lane to arrive compacts the lane (no second launch, no second round trip).

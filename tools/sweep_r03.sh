@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py sweeps of the pipeline-group knobs (streams, groups, bus lines, hardware queues); one line per run
 run() { # streams groups lk chain ba queues
-  SVO_GROUP_LK_LINES=$3 SVO_GROUP_CHAIN_LINES=$4 SVO_GROUP_BA_LINES=$5 GPU_MAX_HW_QUEUES=$6 timeout -k 10 100 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --streams $1 --groups $2 > gpurun_out/sw.json 2> gpurun_out/sw.err
+  SVO_GROUP_LK_LINES=$3 SVO_GROUP_CHAIN_LINES=$4 SVO_GROUP_BA_LINES=$5 GPU_MAX_HW_QUEUES=$6 timeout -k 10 100 python bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-other-workloads --no-single --streams $1 --groups $2 > gpurun_out/sw.json 2> gpurun_out/sw.err
   python - <<PY
 import json
 try:
