@@ -63,16 +63,20 @@ bool svo_throughput_mode();  // host/pipeline.cpp: more than two pipelines share
 
 namespace {
 int g_ba_cu_share = 32;  // CUs of every 32 the adjusters' streams may use (SVO_BA_CU_SHARE; 32 = unmasked)
-std::atomic<int> g_fused_blocks{0};  // workgroups of admitted kernels whose workgroups wait for each other (see ba_fused_budget)
-int ba_fused_budget();
+// Workgroups of admitted kernels whose workgroups wait for each other (see ba_fused_budget), per device: a process that drives
+// several GPUs (one svo_ctx each) must not let one device's adjusters draw from another device's budget.
+constexpr int SVO_MAX_DEVICES = 16;
+std::atomic<int> g_fused_blocks[SVO_MAX_DEVICES];
+int ba_fused_budget(int device);
 struct FusedAdmission {
-  int blocks = 0;
-  bool admit(int n) {
-    if (g_fused_blocks.fetch_add(n, std::memory_order_acq_rel) + n <= ba_fused_budget()) { blocks = n; return true; }
-    g_fused_blocks.fetch_sub(n, std::memory_order_acq_rel);
+  int blocks = 0, device = 0;
+  bool admit(int n, int dev) {
+    dev = dev >= 0 && dev < SVO_MAX_DEVICES ? dev : 0;
+    if (g_fused_blocks[dev].fetch_add(n, std::memory_order_acq_rel) + n <= ba_fused_budget(dev)) { blocks = n; device = dev; return true; }
+    g_fused_blocks[dev].fetch_sub(n, std::memory_order_acq_rel);
     return false;
   }
-  void release() { if (blocks) g_fused_blocks.fetch_sub(blocks, std::memory_order_acq_rel); blocks = 0; }
+  void release() { if (blocks) g_fused_blocks[device].fetch_sub(blocks, std::memory_order_acq_rel); blocks = 0; }
   ~FusedAdmission() { release(); }
 };
 constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
@@ -185,11 +189,16 @@ __device__ __forceinline__ unsigned granule_load8(const double* base, const int 
 __device__ __forceinline__ bool granule_wait(const double* base, int idx, unsigned long long tag, double& out) {
   const int only[8] = {idx, -1, -1, -1, -1, -1, -1, -1};
   double v[8];
-  for (unsigned spins = 0; spins < (1u << 22); ++spins) {
+  long long t0 = 0;
+  for (unsigned spins = 0;; ++spins) {
     if (granule_load8(base, only, tag, v) & 1u) { out = v[0]; return true; }
     __builtin_amdgcn_s_sleep(2);
+    if ((spins & 255u) == 255u) {  // the launch-wide deadline, see wait_until
+      const long long tn = (long long)wall_clock64();
+      if (!t0) t0 = tn;
+      else if (tn - t0 > 300000000ll) return false;
+    }
   }
-  return false;
 }
 
 // The decision for the summed payload2 -> ctl_dev (for the pass-A launch queued behind) and payload slots 4 / 5 (for the host).
@@ -986,13 +995,21 @@ struct IterSync {
   unsigned done_target;
 };
 
+// Every wait inside a launch is bounded by ONE wall-clock deadline (the 100 MHz constant clock, not a spin count whose
+// duration depends on what is polled): a workgroup gives up LM_WAIT_TICKS after it started waiting — far beyond any
+// solve, well inside the host's own 10 s limit on the completion word (ba_wait_flag) — and the host reports the solve.
+constexpr long long LM_WAIT_TICKS = 300000000ll;  // 3 s
 __device__ __forceinline__ bool wait_until(const unsigned* word, unsigned target, bool monotone) {
-  unsigned spins = 0;
-  for (;;) {
+  long long t0 = 0;
+  for (unsigned spins = 0;; ++spins) {
     const unsigned v = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (monotone ? (int)(v - target) >= 0 : v == target) return true;
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1u << 24)) return false;  // ~seconds: something is badly wrong; never hang the GPU
+    if ((spins & 255u) == 255u) {
+      const long long tn = (long long)wall_clock64();
+      if (!t0) t0 = tn;
+      else if (tn - t0 > LM_WAIT_TICKS) return false;  // something is badly wrong; never hang the GPU
+    }
   }
 }
 
@@ -1288,8 +1305,14 @@ __device__ __forceinline__ bool lm_fetch_staged(double* cP, const double* stage,
     }
     double v[8];
     unsigned ok = granule_load8(stage, gi, tag, v);
-    for (unsigned spins = 0; ok != 0xFFu && spins < (1u << 20); ++spins) {
+    long long t0 = 0;
+    for (unsigned spins = 0; ok != 0xFFu; ++spins) {
       __builtin_amdgcn_s_sleep(2);
+      if ((spins & 255u) == 255u) {  // the launch-wide deadline, see wait_until
+        const long long tn = (long long)wall_clock64();
+        if (!t0) t0 = tn;
+        else if (tn - t0 > LM_WAIT_TICKS) break;
+      }
       int again[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) again[u] = (ok >> u) & 1u ? -1 : gi[u];
@@ -2142,7 +2165,7 @@ static int ba_alloc(svo_ba* ba) {
       uint32_t mask[8];
       for (int i = 0; i < 8; ++i) mask[i] = (1u << nres) - 1u;
       SVO_HIP_CHECK(ctx, hipExtStreamCreateWithCUMask(&ba->stream, 8, mask));
-      g_ba_cu_share = nres;  // process-wide like the environment variable; read by ba_fused_budget() at the first admission
+      g_ba_cu_share = nres;  // process-wide like the environment variable; ba_fused_budget() recomputes a device's budget when it changes
     } else {
       SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
     }
@@ -2254,7 +2277,7 @@ extern "C" int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats) {
 // Destination index of pose-pair block (ka <= kb) among the F (F + 1) / 2 upper blocks, row-major.
 static inline int ba_upper_index(int ka, int kb, int F) { return ka * F - ka * (ka - 1) / 2 + (kb - ka); }
 
-static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const double* points3, int M,
+static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, const double* points3, int M,
                      const int32_t* op, const int32_t* oj, const double* uv) {
   svo_ctx* ctx = ba->ctx;
   SVO_REQUIRE(ctx, K >= 1 && K <= ba->max_poses, "ba: pose count outside the window capacity");
@@ -2446,6 +2469,21 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   return SVO_OK;
 }
 
+// A rejected problem must not leave a half-committed one behind (dimensions of the new problem over the chunk layout and
+// the host copies of the old one): after a failed load the adjuster holds NO problem — svo_ba_solve_problem refuses,
+// svo_ba_read_problem copies nothing.
+static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const double* points3, int M,
+                     const int32_t* op, const int32_t* oj, const double* uv) {
+  const int rc = ba_upload_checked(ba, K, poses7, npts, points3, M, op, oj, uv);
+  if (rc != SVO_OK) {
+    ba->d.K = 0; ba->d.n = 0; ba->d.M = 0; ba->d.L = 0; ba->d.C = 0;
+    ba->n_points = 0;
+    ba->host_points_valid = false;
+    ba->arena_dirty = false;
+  }
+  return rc;
+}
+
 // The problem image -> device by one H2D copy on the adjuster's stream (every path but the resident kernel's).
 static int ba_flush_arena(svo_ba* ba) {
   if (!ba->arena_dirty) return SVO_OK;
@@ -2591,25 +2629,28 @@ bool ba_fused_reduce() {
 // budgets of 1/2, 3/4 and 1/1 of the capacity give 6,630 / 6,690 / 6,780 frames/s at 8 streams).  A launch that is not admitted takes the
 // separate-launch path for that iteration — same arithmetic, same results.  (Other PROCESSES on the GPU are not
 // counted; the kernel's bounded spin turns that unlikely pile-up into a reported error, never a hang.)
-int g_fused_per_cu = 0;  // workgroups per CU the budget is counted in
-int ba_fused_budget() {
-  static const int budget = [] {
-    int per_cu = 0, per_cu_res = 0, cus = 0, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_lm_kernel, 128, 8192) != hipSuccess) return 0;
-    per_cu = std::min(per_cu, per_cu_res);  // one budget for both kernels whose workgroups wait: the tighter occupancy counts
-    g_fused_per_cu = per_cu;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
-  }();
-  return budget;
+int g_fused_per_cu = 0;  // workgroups per CU the budget is counted in (a property of the two kernels: the same on every gfx950 device)
+int ba_fused_budget(int device) {
+  static std::mutex mu;
+  static int budget[SVO_MAX_DEVICES], share_of[SVO_MAX_DEVICES];  // 0: not computed yet; recomputed when SVO_BA_CU_SHARE changes
+  device = device >= 0 && device < SVO_MAX_DEVICES ? device : 0;
+  std::lock_guard<std::mutex> g(mu);
+  if (budget[device] && share_of[device] == g_ba_cu_share) return budget[device];
+  int per_cu = 0, per_cu_res = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_lm_kernel, 128, 8192) != hipSuccess) return 0;
+  per_cu = std::min(per_cu, per_cu_res);  // one budget for both kernels whose workgroups wait: the tighter occupancy counts
+  g_fused_per_cu = per_cu;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+  share_of[device] = g_ba_cu_share;
+  budget[device] = per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
+  return budget[device];
 }
 
 // What `grid` workgroups of ba_lm_kernel with `lds` bytes of step-control workspace cost in the units of that budget: a
 // larger reduced camera system (10-keyframe windows) lowers the kernel's occupancy, its workgroups then count for more.
-int ba_lm_admission_cost(int grid, size_t lds) {
-  (void)ba_fused_budget();
+int ba_lm_admission_cost(int grid, size_t lds, int device) {
+  (void)ba_fused_budget(device);
   static std::mutex mu;
   static size_t cached_lds[8];
   static int cached_per_cu[8], n_cached = 0;
@@ -2681,7 +2722,7 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   L.lm_begin = ba->h_list_begin[nd - 1];
   L.lm_count = ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1];
   L.la = ba_list_args(ba);
-  *cost = ba_lm_admission_cost((d.C + 1) / 2 + 1, lds);
+  *cost = ba_lm_admission_cost((d.C + 1) / 2 + 1, lds, ba->ctx->device);
   *lds_out = lds;
   return true;
 }
@@ -2700,7 +2741,7 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced) {
     ba->lm_inflight = false;
     if (!ba_device_lm_fill(ba, &cost, &lds, forced)) break;
     if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) break;
-    if (!ba_resident_admission(ba)->admit(cost)) break;
+    if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) break;
     // the counters start from zero: cleared in front of the launch (the adjuster's previous solve no longer touches them
     // once its completion word is out; a reset by the finishing kernel itself raced with this launch's first arrivals)
     if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
@@ -2868,7 +2909,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     bool fused = false;
     FusedAdmission admission;  // released when this call returns: the completion word has arrived by then
     const int grid1 = std::max(d.C, next ? nb : 1);
-    const bool one_launch = !sharded && d.C > 0 && ba_fused_reduce() && admission.admit(grid1);
+    const bool one_launch = !sharded && d.C > 0 && ba_fused_reduce() && admission.admit(grid1, ctx->device);
     if (one_launch) {
       // the whole iteration — pass B, [decision,] pass A, reduction — in ONE launch
       ba_aim_reduce(ba, next ? nb : 1, true);

@@ -104,22 +104,22 @@ int svo_k_gather_track(svo_ctx* ctx, const int* idx, const int* n_dev, int n_max
   return SVO_OK;
 }
 
-__global__ void tracker_init_kernel(const float* __restrict__ h_xy, const long long* __restrict__ h_ids, int n,
+__global__ void tracker_init_kernel(const float* __restrict__ h_xy, const float* __restrict__ h_init, const long long* __restrict__ h_ids, int n,
                                     float* __restrict__ d_xy, float* __restrict__ d_init, long long* __restrict__ d_ids,
                                     SvoPublish pub) {
   svo_latency_critical();
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     const float x = h_xy[2 * i], y = h_xy[2 * i + 1];
     d_xy[2 * i] = x; d_xy[2 * i + 1] = y;
-    d_init[2 * i] = x; d_init[2 * i + 1] = y;
+    d_init[2 * i] = h_init[2 * i]; d_init[2 * i + 1] = h_init[2 * i + 1];  // = (x, y) unless init() saw duplicate ids
     d_ids[i] = h_ids[i];
   }
   svo_publish_block(pub);
 }
 
-int svo_k_tracker_init(svo_ctx* ctx, const float* h_xy, const long long* h_ids, int n, float* d_xy, float* d_init,
+int svo_k_tracker_init(svo_ctx* ctx, const float* h_xy, const float* h_init, const long long* h_ids, int n, float* d_xy, float* d_init,
                        long long* d_ids, const SvoPublish* pub) {
-  hipLaunchKernelGGL(tracker_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, h_xy, h_ids, n, d_xy, d_init, d_ids,
+  hipLaunchKernelGGL(tracker_init_kernel, dim3(1), dim3(1024), 0, ctx->stream, h_xy, h_init, h_ids, n, d_xy, d_init, d_ids,
                      pub ? *pub : SvoPublish{});
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;

@@ -45,7 +45,7 @@ int svo_k_lk(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, int
 int svo_k_gather_track(svo_ctx* ctx, const int* idx, const int* n_dev, int n_max, const float* init_src,
                        const long long* ids_src, float* init_dst, long long* ids_dst);
 // tracker (re)initialisation from pinned host arrays: d_xy = d_init = h_xy, d_ids = h_ids (one launch, no H2D blits)
-int svo_k_tracker_init(svo_ctx* ctx, const float* h_xy, const long long* h_ids, int n, float* d_xy, float* d_init,
+int svo_k_tracker_init(svo_ctx* ctx, const float* h_xy, const float* h_init, const long long* h_ids, int n, float* d_xy, float* d_init,
                        long long* d_ids, const SvoPublish* pub);
 int svo_k_gather_xy_ids(svo_ctx* ctx, const int* idx, int n, const float* xy_src, const long long* ids_src,
                         float* xy_dst, long long* ids_dst);

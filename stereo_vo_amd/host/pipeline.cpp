@@ -269,6 +269,7 @@ FeatureTracker::~FeatureTracker() {
                   d_host_img_, d_host_pyr_};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   if (h_mirror_) (void)hipHostFree(h_mirror_);
+  if (h_init_dup_) (void)hipHostFree(h_init_dup_);
 }
 
 void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const std::vector<Point2f>& features,
@@ -286,12 +287,37 @@ void FeatureTracker::init(const uint8_t* pyramid, int width, int height, const s
   for (int i = 0; i < n; ++i) h_ids_[i] = (long long)ids[i];
   init_xy_.assign(features.begin(), features.begin() + n);  // initial_features (src/feature_tracker.cpp:9-12), host side
   init_ids_.assign(h_ids_, h_ids_ + n);
+  // initial_features is a map (src/feature_tracker.hpp:49): insert() keeps the FIRST feature of an id (:10-12), the parallax
+  // of every feature carrying that id is measured from it (:47) and percent_lost counts the map's entries (:64).  The
+  // pipeline's ids ascend strictly (tracked survivors in order, then new ids): only a caller of the public init() can
+  // hand over duplicates, and only then is the id -> first feature table built.
+  bool ascending = true;
+  for (int i = 1; i < n && ascending; ++i) ascending = ids[i] > ids[i - 1];
+  int n_ids = n;
+  const float* init_src = h_xy_;
+  if (!ascending) {
+    std::unordered_map<size_t, int> first;
+    first.reserve((size_t)n * 2);
+    std::vector<int> first_of((size_t)n);
+    for (int i = 0; i < n; ++i) first_of[i] = first.emplace(ids[i], i).first->second;
+    n_ids = (int)first.size();
+    if (n_ids != n) {
+      if (!h_init_dup_ && hipHostMalloc((void**)&h_init_dup_, sizeof(float) * 2 * (size_t)cap_, hipHostMallocDefault) != hipSuccess) {
+        h_init_dup_ = nullptr;
+        ctx_->err = "FeatureTracker::init: pinned allocation failed";
+        return;
+      }
+      for (int i = 0; i < n; ++i) { h_init_dup_[2 * i] = features[first_of[i]].x; h_init_dup_[2 * i + 1] = features[first_of[i]].y; }
+      init_src = h_init_dup_;
+    }
+  }
   const SvoPublish pub = svo_publish_next(ctx_, SVO_W_INIT);
   pending_init_seq_ = pub.seq;
-  if (svo_k_tracker_init(ctx_, h_xy_, h_ids_, n, d_xy_[cur_], d_init_[cur_], d_ids_[cur_], &pub)) return;
+  if (svo_k_tracker_init(ctx_, h_xy_, init_src, h_ids_, n, d_xy_[cur_], d_init_[cur_], d_ids_[cur_], &pub)) return;
   remember(pyramid, width, height);  // clone, :14
   if (!borrow_) SVO_TRY(hipStreamSynchronize(st));  // the caller may reuse `pyramid` right away
-  n_ = n_initial_ = n;
+  n_ = n;
+  n_initial_ = n_ids;
   has_image_ = true;
 }
 

@@ -185,6 +185,7 @@ class FeatureTracker {  // src/feature_tracker.hpp:20-54 (draw_track/get_drawing
   uint8_t* d_last_pyr_ = nullptr;
   const uint8_t* last_pyr_ = nullptr;  // d_last_pyr_ or a borrowed pyramid
   uint8_t* h_mirror_ = nullptr;        // pinned: ids | xy | n | av_parallax, written by the kernels in place
+  float* h_init_dup_ = nullptr;        // pinned, allocated on first need: initial positions when init() was handed duplicate ids
   long long* h_ids_ = nullptr; float* h_xy_ = nullptr; int* h_n_ = nullptr; float* h_av_ = nullptr;
   int pending_init_seq_ = 0;           // completion word value of an init launch that may still read the mirrors (0: none)
   int last_w_ = 0, last_h_ = 0;

@@ -134,6 +134,23 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < oid.size(); ++i) printf(" %zu:%08x:%08x", oid[i], fbits(out[i].x), fbits(out[i].y));
     printf("\n");
 
+    // duplicate ids (src/feature_tracker.cpp:10-12: map::insert keeps the FIRST feature of an id; :47,64 then read that entry
+    // for the parallax of every feature carrying the id and count the map's entries): features 2m and 2m+1 share id 500+m
+    {
+      FeatureTracker dup;
+      vector<size_t> ids2;
+      for (int i = 0; i < n; ++i) ids2.push_back(500 + i / 2);
+      dup.init(l0, pts, ids2);
+      float av2 = 0, lost2 = 0;
+      dup.track_features(av2, lost2, l1, true);
+      vector<cv::Point2f> out2;
+      vector<size_t> oid2;
+      dup.get_tracked_features(out2, oid2);
+      printf("dup-tracker init %d kept %zu par %08x lost %08x", n, oid2.size(), fbits(av2), fbits(lost2));
+      for (size_t i = 0; i < oid2.size(); ++i) printf(" %zu:%08x:%08x", oid2[i], fbits(out2[i].x), fbits(out2[i].y));
+      printf("\n");
+    }
+
     BundleAdjuster adjuster(3, info);  // src/bundle_adjuster.hpp:86-126
     vector<cv::Point2f> n2;
     vector<cv::Point3f> n3;

@@ -164,6 +164,22 @@ def test_hip_adapters_match_the_cabi_pipeline(ctx):
     exp = [(100 + int(kidx[j]), int(kxy[j, 0].view(np.uint32)), int(kxy[j, 1].view(np.uint32))) for j in range(len(kidx))]
     assert got == exp
 
+    # duplicate ids handed to the public init(): the parallax of every feature is measured from the FIRST feature of its id
+    # and percent_lost counts distinct ids (src/feature_tracker.cpp:10-12,47,64; features 2m, 2m+1 share id 500+m)
+    t = [ln for ln in lines if ln.startswith("dup-tracker ")][0].split()
+    assert int(t[2]) == n0
+    first = np.arange(n0) // 2 * 2
+    kxy, kidx, av = ctx.track_features(fr[0][0], fr[1][0], c0, c0[first])
+    import oracle_lib as O
+    oxy, oidx, oav = O.track_features(fr[0][0], fr[1][0], c0, c0[first])
+    assert np.array_equal(kidx, oidx) and np.array_equal(kxy.view(np.uint32), oxy.view(np.uint32)) and _f32bits(av) == _f32bits(oav)
+    assert int(t[4]) == len(kidx) and int(t[6], 16) == _f32bits(av)
+    assert int(t[8], 16) == _f32bits(np.float32(1.0 - float(np.float32(len(kidx)) / np.float32((n0 + 1) // 2))))
+    got = [tuple(int(v, 16) if j else int(v) for j, v in enumerate(e.split(":"))) for e in t[9:]]
+    exp = [(500 + int(kidx[j]) // 2, int(kxy[j, 0].view(np.uint32)), int(kxy[j, 1].view(np.uint32))) for j in range(len(kidx))]
+    assert got == exp
+    assert any(c0[i, 0] != c0[first[i], 0] or c0[i, 1] != c0[first[i], 1] for i in kidx), "no surviving duplicate: the case tests nothing"
+
     a = [ln for ln in lines if ln.startswith("direct-adjuster ")][0].split()
     # 450 new features offered, max_features = 400 kept (src/bundle_adjuster.cpp:85-90), ids sequential from 0
     assert a[1:15] == ["new2d", "400", "new3d", "400", "ids", "400", "first", "0", "last", "399", "same_kf", "1", "wp", "400"]

@@ -146,6 +146,30 @@ def test_hip_ba_matches_oracle(ctx, seed, K, N, dense, device_lm):
 
 
 @pytest.mark.gpu
+def test_hip_rejected_load_leaves_no_problem(ctx):
+    """A load that fails its validation must not leave the new dimensions over the old chunk layout: afterwards the adjuster
+    holds NO problem (solve refuses), and a later good load solves as if nothing had happened."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(21, 5, 300)
+    ba = S.api.BA(ctx, 6, BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0)
+    ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s0 = ba.solve_problem()
+    poses0, pts0 = ba.read_problem()
+    bad = p["oj"].copy()
+    bad[len(bad) // 2] = len(p["points0"]) + 3  # a landmark index out of range, found after the dimensions were taken
+    with pytest.raises(S.api.SvoError):
+        ba.load_problem(p["poses0"][:4], p["points0"], np.minimum(p["op"], 3), bad, p["uv"])
+    with pytest.raises(S.api.SvoError):
+        ba.solve_problem()
+    ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s1 = ba.solve_problem()
+    poses1, pts1 = ba.read_problem()
+    assert (s1.iterations, s1.final_cost) == (s0.iterations, s0.final_cost)
+    assert np.array_equal(poses0, poses1) and np.array_equal(pts0, pts1)
+    ba.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["atomics", "mfma"])
 @pytest.mark.parametrize("seed,K,N,dense", [(11, 5, 700, False), (12, 12, 2500, False), (13, 20, 1500, True),
                                             (14, 22, 3000, False), (15, 2, 80, False)])
