@@ -290,7 +290,7 @@ def run_kitti(args):
     share = profile_summary()
     if share:
         out["kernel_time_share"] = {"source": "profiles/r03_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
-                                    "default_percent": share.get("kernel_time_share_default_24_streams"),
+                                    "default_percent": share.get("kernel_time_share_default"),
                                     "1_stream_percent": share.get("kernel_time_share_1_stream")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cb, ores = cpu_baseline(streams[0].p, streams[0].L, streams[0].R, args.cpu_frames)
@@ -563,16 +563,16 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches, lanes
                            "note": "VALU instructions per wavefront (= per feature) from the committed SQ pass (profiles/r03_sq_counters.txt) x the "
                                    "features of a launch, duration live; <= 30 iterations x 4 levels x 2 directions of a 441-pixel window per feature"})
         r["dominant_kernel"] = dk
-    ks = prof.get("kernel_average_us_default_24_streams") or {}
+    ks = prof.get("kernel_average_us_default") or {}
     if grouped and "ba_lm_kernel" in ks and prof.get("ba_lm_valu_wave_instructions_per_launch"):
         # the largest share of summed kernel time: one launch = whole window solves (device-resident LM); from the committed profile, not live
         us = ks["ba_lm_kernel"]
         g = prof["ba_lm_valu_wave_instructions_per_launch"] / (us * 1e-6) / 1e9
         r["largest_time_share_kernel"] = {
-            "kernel": "ba_lm_kernel", "avg_launch_us": us, "time_share_percent": (prof.get("kernel_time_share_default_24_streams") or {}).get("ba_lm_kernel"),
+            "kernel": "ba_lm_kernel", "avg_launch_us": us, "time_share_percent": (prof.get("kernel_time_share_default") or {}).get("ba_lm_kernel"),
             "waves_per_launch": prof.get("ba_lm_waves_per_launch"), "valu_wave_instructions_per_launch": prof["ba_lm_valu_wave_instructions_per_launch"],
             "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": g / VALU_ISSUE_PEAK_GINSTR, "bound": "latency (device-wide meetings of a few hundred wavefronts)",
-            "source": "profiles/r03_kernel_stats_default_24_streams.csv + profiles/r03_sq_counters.txt (rocprofv3 runs of this command), not measured live"}
+            "source": "profiles/r03_kernel_stats_default.csv + profiles/r03_sq_counters.txt (rocprofv3 runs of this command), not measured live"}
     return r
 
 

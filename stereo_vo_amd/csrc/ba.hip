@@ -531,19 +531,73 @@ __device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R,
   linearize_suffix<WT>(P, R, q, radius, first_pass, sS, sGred, sGc, sDU, lgp2, cache);
 }
 
-// the lane's constants of the loaded problem (ba_lm_kernel, once per solve)
-__device__ __forceinline__ void load_chunk_regs(const BaDev& P, const ObsRec& R, ChunkRegs& c, int2* pp_lds /* this lane's column */, int pp_stride) {
+
+// One-time reads of the problem image by ba_lm_kernel.  The image stays in PINNED HOST memory (no H2D copy launch in front of
+// every solve: that copy was a 45 us blit kernel and a stream dependency per keyframe): `shift` leads from a device-arena
+// address to the same word of the host image (0: the device arena is complete, a re-solve).  System-scope loads: the XCD's
+// L2 may hold lines of the previous problem at these addresses.
+template <typename T>
+__device__ __forceinline__ T sys_load(const T* p, ptrdiff_t shift) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "word loads");
+  return __hip_atomic_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(p) + shift), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// 16 bytes per lane at system scope (sc0 sc1): consecutive lanes read consecutive records, so one instruction is a run of
+// whole 64-byte PCIe reads — word-sized loads of the same records would fetch every line four times.
+__device__ __forceinline__ uint4 sys_load16(const void* p, ptrdiff_t shift) {
+  uint4 v;
+  const char* q = reinterpret_cast<const char*>(p) + shift;
+  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");
+  return v;
+}
+__device__ __forceinline__ ObsRec load_obs_image(const BaDev& P, int chunk, int lane, const double* __restrict__ points, ptrdiff_t shift) {
+  ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
+  R.o = chunk * 64 + lane;
+  const uint4 rc = sys_load16(&P.rec[R.o], shift);
+  const uint4 uv = sys_load16(&P.obs_uv[2 * R.o], shift);
+  R.u = __hiloint2double((int)uv.y, (int)uv.x); R.v = __hiloint2double((int)uv.w, (int)uv.z);
+  R.active = (int)rc.x >= 0;
+  if (R.active) {
+    R.k = (int)rc.x; R.j = (int)rc.y; R.first = (int)rc.z; R.len = (int)rc.w;
+    R.p = D3{sys_load(&points[3 * R.j], shift), sys_load(&points[3 * R.j + 1], shift), sys_load(&points[3 * R.j + 2], shift)};
+  }
+  return R;
+}
+
+// the lane's constants of the loaded problem (ba_lm_kernel, once per solve).  `stage`: LDS scratch of this wavefront,
+// >= 512 eight-byte words: the wavefront's pair rows are ONE contiguous run of the image (pair_base ascends with the lanes),
+// fetched by consecutive lanes and then picked apart — per-lane reads of its own 1-5 rows would fetch every line once per row index.
+__device__ __forceinline__ void load_chunk_regs(const BaDev& P, const ObsRec& R, ChunkRegs& c, int2* pp_lds /* this lane's column */, int pp_stride,
+                                                ptrdiff_t shift, long long* stage) {
   const int lane = threadIdx.x & 63;
   const bool freep = R.active && R.k > 0;
   int maxlen = R.len;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
   c.have_pp = P.det && maxlen <= 8;
-  c.obs_pos = freep ? P.obs_pos[R.o] : 0;
+  c.obs_pos = freep ? sys_load(&P.obs_pos[R.o], shift) : 0;
   const int mine = freep ? R.first + R.len - lane : 0;
-  const int2* ppsrc = reinterpret_cast<const int2*>(P.pair_pos) + (freep ? P.pair_base[R.o] : 0);
+  const int pb = freep ? sys_load(&P.pair_base[R.o], shift) : 0;
+  int lo = (c.have_pp && mine > 0) ? pb : 0x7fffffff, hi = (c.have_pp && mine > 0) ? pb + min(mine, 8) : 0;
 #pragma unroll
-  for (int d = 0; d < 8; ++d) pp_lds[d * pp_stride] = (c.have_pp && d < mine) ? ppsrc[d] : int2{-1, -1};
+  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
+  const bool run = hi > lo && hi - lo <= 512;  // wave-uniform
+  if (run) {
+    const long long* src = reinterpret_cast<const long long*>(P.pair_pos) + lo;
+    for (int i = lane; i < hi - lo; i += 64) stage[i] = sys_load(src + i, shift);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  const long long* ppsrc = reinterpret_cast<const long long*>(P.pair_pos) + pb;
+#pragma unroll
+  for (int d = 0; d < 8; ++d) {
+    int2 v = int2{-1, -1};
+    if (c.have_pp && d < mine) {
+      const long long w = run ? stage[pb - lo + d] : sys_load(ppsrc + d, shift);
+      v = int2{(int)(w & 0xFFFFFFFFll), (int)(w >> 32)};
+    }
+    pp_lds[d * pp_stride] = v;
+  }
   c.pp = pp_lds; c.pp_stride = pp_stride;
   c.s[0] = c.s[1] = c.s[2] = 1.0;
 }
@@ -1402,7 +1456,10 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
     __syncthreads();
     if (!cs.go) return LMOP_ABORT;
-    lm_fetch(cPose, P.poses, 7 * K);
+    {
+      const ptrdiff_t shift = a.arena_src ? reinterpret_cast<const char*>(a.arena_src) - reinterpret_cast<const char*>(a.arena_dst) : 0;
+      for (int i = tid; i < 7 * K; i += nt) cPose[i] = sys_load(&P.poses[i], shift);
+    }
     return issue(LMOP_LINEARIZE, 0, 1);
   }
   if (st == LMS_DELIVER) return LMOP_EXIT;
@@ -1683,8 +1740,13 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   LmWave W;
   W.R = ObsRec{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
   W.cand = D3{0, 0, 1};
-  if (my_wave_works) W.R = load_obs(P, my_chunk, lane, a.points_a);
-  load_chunk_regs(P, W.R, W.c, &sPairPos[0][tid], 128);
+  const ptrdiff_t shift = a.arena_src ? reinterpret_cast<const char*>(a.arena_src) - reinterpret_cast<const char*>(a.arena_dst) : 0;
+  if (my_wave_works) {
+    W.R = load_obs_image(P, my_chunk, lane, a.points_a, shift);
+    // the device copy of the current landmarks (DELIVER exports from the buffer the step control selected; pass B fills the other one)
+    if (shift && W.R.active && lane == W.R.first) { a.points_a[3 * W.R.j] = W.R.p.x; a.points_a[3 * W.R.j + 1] = W.R.p.y; a.points_a[3 * W.R.j + 2] = W.R.p.z; }
+  }
+  load_chunk_regs(P, W.R, W.c, &sPairPos[0][tid], 128, shift, reinterpret_cast<long long*>(sStep + wave * (RES_STEP_LDS_DOUBLES / CPW)));  // the step block is built later
   __syncthreads();
   for (;;) {
     const int st_before = cs.state;
@@ -1705,7 +1767,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     P.pay_tag = cs.tag;
     if (op == LMOP_DELIVER) {
       if (a.export_points && my_wave_works) {
-        const ObsRec R = load_obs(P, my_chunk, lane, P.points);  // the buffer the step control selected (a chained pass A may have run ahead of a step that was not taken)
+        ObsRec R = W.R;  // the landmarks of the buffer the step control selected (a chained pass A may have run ahead of a step that was not taken)
+        if (R.active) R.p = D3{P.points[3 * R.j], P.points[3 * R.j + 1], P.points[3 * R.j + 2]};
         deliver_chunk_points(R, a.export_points, sStep + wave * (RES_STEP_LDS_DOUBLES / CPW), RES_STEP_LDS_DOUBLES / CPW);  // the step block is no longer needed
       }
       // everybody's results are out; the last worker to arrive publishes the host's completion word
@@ -2083,6 +2146,9 @@ struct svo_ba {
   LmLane* h_lane = nullptr;      // pinned launch record of this adjuster's solve
   unsigned lm_base[5] = {0, 0, 0, 0, 0};  // where the last solve left the device counters (arrive, done, arrived, posted, copied)
   bool lm_counters_dirty = false;  // the last kernel did not leave through its clean exit: zero the counters before the next launch
+  bool lm_have_base = false;       // lm_base describes the counters (false until the first clean solve)
+  bool arena_partial = false;      // the last solve read the problem image from h_arena in place: d_arena lacks the tables, h_arena the solved state
+  size_t arena_cpts_off = 0, arena_p0_off = 0, arena_p1_off = 0;
   std::chrono::steady_clock::time_point lm_t0;
   double* h_pay = nullptr;
   // current / candidate buffers of the running solve (swapped on every accepted step)
@@ -2462,6 +2528,8 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   // of it), or by one H2D copy (ba_flush_arena)
   ba->arena_bytes = (total + 15) & ~(size_t)15;
   ba->arena_dirty = true;
+  ba->arena_partial = false;
+  ba->arena_cpts_off = o_cpts; ba->arena_p0_off = o_p0; ba->arena_p1_off = o_p1;
   if (d.det && has_empty_landmark && npts) {
     SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
     SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV2, 0, sizeof(double) * 4 * npts, st));
@@ -2484,8 +2552,45 @@ static int ba_upload(svo_ba* ba, int K, const double* poses7, int npts, const do
   return rc;
 }
 
+// After a solve that read the problem image from pinned memory in place, the device arena holds only the landmark buffers and
+// the host image still holds the INITIAL landmarks and poses.  Before anything else uses the loaded problem again (a second
+// solve, a host-driven path), the host image takes the solved state and counts as not uploaded.
+static int ba_refresh_arena_image(svo_ba* ba) {
+  svo_ctx* ctx = ba->ctx;
+  const size_t npts = (size_t)ba->n_points;
+  if (npts) {
+    double* img = reinterpret_cast<double*>(ba->h_arena + ba->arena_pts_off);
+    if (ba->host_points_valid) {
+      const std::vector<int32_t>& lm = ba->u_lm_start;
+      for (size_t j = 0; j < npts; ++j) {
+        if (j + 1 < lm.size() && lm[j + 1] == lm[j]) continue;  // never observed: keeps its uploaded value
+        img[3 * j] = ba->h_out_points[3 * j]; img[3 * j + 1] = ba->h_out_points[3 * j + 1]; img[3 * j + 2] = ba->h_out_points[3 * j + 2];
+      }
+    } else {
+      std::vector<double> tmp(3 * npts);
+      SVO_HIP_CHECK(ctx, hipMemcpy(tmp.data(), ba->d.points, sizeof(double) * 3 * npts, hipMemcpyDeviceToHost));
+      const std::vector<int32_t>& lm = ba->u_lm_start;
+      for (size_t j = 0; j < npts; ++j) {
+        if (j + 1 < lm.size() && lm[j + 1] == lm[j]) continue;
+        img[3 * j] = tmp[3 * j]; img[3 * j + 1] = tmp[3 * j + 1]; img[3 * j + 2] = tmp[3 * j + 2];
+      }
+    }
+    memcpy(ba->h_arena + ba->arena_cpts_off, img, sizeof(double) * 3 * npts);
+  }
+  memcpy(ba->h_arena + ba->arena_p0_off, ba->h_poses.data(), sizeof(double) * 7 * (size_t)ba->d.K);
+  memcpy(ba->h_arena + ba->arena_p1_off, ba->h_poses.data(), sizeof(double) * 7 * (size_t)ba->d.K);
+  uint8_t* D = ba->d_arena;
+  ba->cur_points = (double*)(D + ba->arena_pts_off); ba->cand_points = (double*)(D + ba->arena_cpts_off);
+  ba->cur_poses = (double*)(D + ba->arena_p0_off); ba->cand_poses = (double*)(D + ba->arena_p1_off);
+  ba->d.points = ba->cur_points; ba->d.cand_points = ba->cand_points; ba->d.poses = ba->cur_poses; ba->d.cand_poses = ba->cand_poses;
+  ba->arena_partial = false;
+  ba->arena_dirty = true;
+  return SVO_OK;
+}
+
 // The problem image -> device by one H2D copy on the adjuster's stream (every path but the resident kernel's).
 static int ba_flush_arena(svo_ba* ba) {
+  if (ba->arena_partial) { const int rc = ba_refresh_arena_image(ba); if (rc) return rc; }
   if (!ba->arena_dirty) return SVO_OK;
   svo_ctx* ctx = ba->ctx;
   SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_arena, ba->h_arena, ba->arena_bytes, hipMemcpyHostToDevice, ba->stream));
@@ -2708,13 +2813,19 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   L.P = d;
   LmDevArgs& a = L.a;
   a.cnt = ba->d_lmc;
-  a.arena_src = nullptr; a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;  // copied in front of the launch (ba_device_lm_launch)
+  if (ba->arena_partial && ba_refresh_arena_image(ba)) return false;  // a re-solve after a zero-copy solve: the host image takes the solved state first
+  a.arena_src = ba->arena_dirty ? ba->h_arena : nullptr;  // read in place by the kernel (zero copy); null: the device arena is complete
+  a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;
   a.points_a = ba->cur_points; a.points_b = ba->cand_points;
   a.export_points = ba->n_points ? ba->h_out_points : nullptr;
   a.dev_pay = ba->d_pay_fg;
   a.host_result = ba->h_result;
   a.host_flag = ba->h_flag; a.host_seq = ba->seq + 1;  // committed by the launch
-  a.base_arrive = a.base_done = a.base_arrived = a.base_posted = a.base_copied = 0;  // cleared in front of the launch
+  // the device counters run on from solve to solve (monotone, wrap-safe compares): no clearing launch in front of a solve
+  // unless the last one did not leave cleanly
+  const bool fresh = ba->lm_counters_dirty || !ba->lm_have_base;
+  a.base_arrive = fresh ? 0 : ba->lm_base[0]; a.base_done = fresh ? 0 : ba->lm_base[1]; a.base_arrived = fresh ? 0 : ba->lm_base[2];
+  a.base_posted = fresh ? 0 : ba->lm_base[3]; a.base_copied = fresh ? 0 : ba->lm_base[4];
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
@@ -2744,16 +2855,10 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced) {
     if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) break;
     // the counters start from zero: cleared in front of the launch (the adjuster's previous solve no longer touches them
     // once its completion word is out; a reset by the finishing kernel itself raced with this launch's first arrivals)
-    if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
-    ba->lm_counters_dirty = false;
-    // The problem image goes up by a copy IN FRONT of the launch (stream order + kernel boundary).  Round 2's resident kernel —
-    // and this one at first — fetched it itself, every workgroup a share, write-through, then an arrival counter: under load
-    // a workgroup could pass the counter and still read the previous solve's records (a late store again, see
-    // granule_store), i.e. garbage indices.
-    if (ba->arena_dirty && hipMemcpyAsync(ba->d_arena, ba->h_arena, ba->arena_bytes, hipMemcpyHostToDevice, st) != hipSuccess) {
-      ba_resident_admission(ba)->release();
-      break;
+    if (ba->lm_counters_dirty || !ba->lm_have_base) {
+      if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
     }
+    ba->lm_counters_dirty = false;
     ptrs.p[i] = ba->h_lane;
     max_c = std::max(max_c, (ba->d.C + 1) / 2);
     max_lds = std::max(max_lds, lds);
@@ -2773,7 +2878,8 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced) {
     svo_ba* ba = bas[i];
     ++ba->seq;  // = a.host_seq
     ba->lm_t0 = t0;
-    ba->arena_dirty = false;  // the kernel fetches it
+    if (ba->arena_dirty) ba->arena_partial = true;  // the kernel reads the host image in place: the device arena holds the landmark buffers only
+    ba->arena_dirty = false;
     ba->lm_inflight = true;
     ba->lm_stream = st;
     ba->res_export = ba->h_lane->a.export_points != nullptr;
@@ -2815,6 +2921,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   const double* r = ba->h_result;
   ba->lm_base[0] = (unsigned)r[LMR_C_ARRIVE]; ba->lm_base[1] = (unsigned)r[LMR_C_DONE]; ba->lm_base[2] = (unsigned)r[LMR_C_ARRIVED];
   ba->lm_base[3] = (unsigned)r[LMR_C_POSTED]; ba->lm_base[4] = (unsigned)r[LMR_C_COPIED];
+  ba->lm_have_base = true;
   memcpy(ba->h_poses.data(), r + LMR_DOUBLES, sizeof(double) * 7 * (size_t)d.K);
   if (r[LMR_SEL] != 0.0) { std::swap(ba->cur_points, ba->cand_points); std::swap(ba->cur_poses, ba->cand_poses); }
   ba->host_points_valid = ba->res_export;

@@ -28,7 +28,7 @@ def stats(path):
 
 
 summary = {}
-for key, sub in (("default_24_streams", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
+for key, sub in (("default", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
     f = os.path.join(src, sub, "p_kernel_stats.csv")
     if not os.path.exists(f):
         continue
@@ -90,8 +90,15 @@ for c, key in (("FETCH_SIZE", "fetch_kb_per_launch"), ("WRITE_SIZE", "write_kb_p
         traffic[k][key] = a[k][c] / n[k]
         launches[k] = n[k]
 if traffic:
-    # the counter passes ran `bench.py --steps 3 --warmup 1 --streams 8 --groups 1 --no-single`: 4 steps of 16 frames on 8 lanes
-    frames = 4 * 16 * 8
+    # the counter passes ran `bench.py --steps 3 --warmup 1 --streams 24 --groups 1 --no-single`: frames = (steps + warmup) x batch x lanes, from the run's own line
+    frames = 4 * 16 * 24
+    try:
+        for ln in open(os.path.join(src, "bench_FETCH_SIZE.log")):
+            if ln.startswith('{"metric"'):
+                b = json.loads(ln)
+                frames = (b["steps"] + b["warmup"]) * b["config"]["batch_per_stream"] * b["config"]["streams_per_gpu"]
+    except Exception:
+        pass
     front = ("corner_response_kernel", "corner_nms_kernel", "corner_select_kernel", "pyr_copy_kernel", "pyr_down_kernel", "lk_fb_kernel",
              "lk_fb_group_kernel", "track_compact_kernel", "stereo_at_kernel", "stereo_triangulate_kernel", "stereo_triangulate_group_kernel",
              "dedup_group_kernel", "dedup_kernel")
