@@ -60,7 +60,20 @@ inline double texture(uint64_t seed, int plane, double a, double b) {
   return 30.0 + 120.0 * c1 + 55.0 * c2 + 35.0 * c3;
 }
 
-inline double shade(const svo_synth_params* p, const double* O, const double* d) {
+// The billboards a ray from height/depth O[2] can meet: their four hashed parameters depend on the index alone, so they are
+// tabulated once per image (same values, same order of evaluation per ray as hashing them per sample: bit-identical images,
+// 5 hashes per visited billboard and sample saved).
+struct Board { double z, xc, hw, top; };
+inline Board board_at(const svo_synth_params* p, int64_t i) {
+  Board b;
+  b.z = kFirstZ + (double)i * kSpacing + 0.85 * kSpacing * unit(hash3(p->seed, 11, i, 0));
+  b.xc = -6.0 + 12.0 * unit(hash3(p->seed, 12, i, 0));
+  b.hw = 0.7 + 1.6 * unit(hash3(p->seed, 13, i, 0));
+  b.top = kCamHeight - (1.2 + 2.8 * unit(hash3(p->seed, 14, i, 0)));
+  return b;
+}
+
+inline double shade(const svo_synth_params* p, const double* O, const double* d, const Board* boards) {
   double best = 1e30, val = 205.0 - 40.0 * (d[1] < 0 ? -d[1] : 0);  // sky
   if (d[1] > 1e-9) {  // ground Y = kCamHeight
     const double l = (kCamHeight - O[1]) / d[1];
@@ -77,13 +90,12 @@ inline double shade(const svo_synth_params* p, const double* O, const double* d)
     int64_t i0 = (int64_t)std::floor((O[2] - kFirstZ) / kSpacing);
     if (i0 < 0) i0 = 0;
     for (int64_t i = i0; i < i0 + p->n_billboards; ++i) {
-      const double z = kFirstZ + (double)i * kSpacing + 0.85 * kSpacing * unit(hash3(p->seed, 11, i, 0));
+      const Board& bd = boards[i - i0];
+      const double z = bd.z;
       const double l = (z - O[2]) / d[2];
       if (l <= 0) continue;
       if (l >= best) break;
-      const double xc = -6.0 + 12.0 * unit(hash3(p->seed, 12, i, 0));
-      const double hw = 0.7 + 1.6 * unit(hash3(p->seed, 13, i, 0));
-      const double top = kCamHeight - (1.2 + 2.8 * unit(hash3(p->seed, 14, i, 0)));
+      const double xc = bd.xc, hw = bd.hw, top = bd.top;
       const double X = O[0] + l * d[0], Y = O[1] + l * d[1];
       if (X > xc - hw && X < xc + hw && Y > top && Y < kCamHeight) {
         best = l;
@@ -104,6 +116,12 @@ void render_one(const svo_synth_params* p, const Cam& cam, double ox, uint8_t* i
   const int W = p->width, H = p->height;
   const double O[3] = {cam.C[0] + cam.R[0] * ox, cam.C[1] + cam.R[3] * ox, cam.C[2] + cam.R[6] * ox};
   const double inv_f = 1.0 / p->focal;
+  std::vector<Board> boards((size_t)(p->n_billboards > 0 ? p->n_billboards : 0));
+  {
+    int64_t i0 = (int64_t)std::floor((O[2] - kFirstZ) / kSpacing);  // as in shade(): a function of the camera centre alone
+    if (i0 < 0) i0 = 0;
+    for (int k = 0; k < p->n_billboards; ++k) boards[(size_t)k] = board_at(p, i0 + k);
+  }
   auto rows = [&](int v0, int v1) {
   for (int v = v0; v < v1; ++v)
     for (int u = 0; u < W; ++u) {
@@ -115,7 +133,7 @@ void render_one(const svo_synth_params* p, const Cam& cam, double ox, uint8_t* i
           const double d[3] = {cam.R[0] * dc[0] + cam.R[1] * dc[1] + cam.R[2] * dc[2],
                                cam.R[3] * dc[0] + cam.R[4] * dc[1] + cam.R[5] * dc[2],
                                cam.R[6] * dc[0] + cam.R[7] * dc[1] + cam.R[8] * dc[2]};
-          acc += shade(p, O, d);
+          acc += shade(p, O, d, boards.data());
         }
       const double m = acc * 0.25;
       const int q = (int)std::floor(m + 0.5);
