@@ -78,6 +78,7 @@ enum Word { W_TRACK = 0, W_HYP, W_REF, W_TRI, W_COUNT };
 enum Counter { C_LK = 0, C_HYP, C_DEDUP, C_TRI, C_COUNT };
 
 struct Lane {
+  int lk_line = 0;  // the tracking line (stream) its launch in flight went to
   // ---- tracker state (FeatureTracker): feature set double-buffered on the device, mirrored in pinned memory
   float* d_xy[2] = {nullptr, nullptr}; float* d_init[2] = {nullptr, nullptr}; long long* d_ids[2] = {nullptr, nullptr};
   float* d_fwd = nullptr; float* d_par = nullptr; uint8_t* d_keep = nullptr;
@@ -179,6 +180,8 @@ struct svo_pipeline_group {
   // consecutive stages coherent), solves take whichever solve line is free
   static constexpr int MAX_LINES = 8;
   int n_lk = 1, n_chain = 1, n_ba = 2;
+  double lk_overlap_us = 0.0;  // > 0: a second tracking line may depart once every launch in flight is at least this old (it is in its tail then)
+  double lk_t0[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // departure time of the launch in flight on each tracking line (us since the call began)
   hipStream_t st_lk[MAX_LINES] = {}, st_chain[MAX_LINES] = {}, st_ba[MAX_LINES] = {};
   int ba_launch_id = 0;
   // batch-wide front-end outputs
@@ -292,6 +295,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
   {
     auto knob = [](const char* name, int dflt, int hi) { const char* e = getenv(name); int v = e && *e ? atoi(e) : dflt; return v < 1 ? 1 : (v > hi ? hi : v); };
     g->n_lk = knob("SVO_GROUP_LK_LINES", 1, svo_pipeline_group::MAX_LINES);
+    { const char* e = getenv("SVO_GROUP_LK_OVERLAP_US"); g->lk_overlap_us = e && *e ? std::max(0.0, atof(e)) : 0.0; }
     g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 2, svo_pipeline_group::MAX_LINES);
     g->n_ba = knob("SVO_GROUP_BA_LINES", 4, svo_pipeline_group::MAX_LINES);
     g->st_lk[0] = ctx->stream;
@@ -696,7 +700,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     for (int li = 0; li < S; ++li) {
       const Lane* l = g->lanes[li];
       if (l->queued) continue;
-      lk_busy[li % g->n_lk] |= l->state == L_TRACK_WAIT;
+      lk_busy[g->lk_overlap_us > 0 ? l->lk_line : li % g->n_lk] |= l->state == L_TRACK_WAIT;
       chain_busy[li % g->n_chain] |= l->state == L_PNP_HYP_WAIT || l->state == L_PNP_REF_WAIT || l->state == L_TRI_WAIT;
     }
     // the lanes of `q` that ride line `line` (of `n_lines`), removed from q
@@ -707,10 +711,21 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       }
       return mine;
     };
+    const double t_now_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    bool tails_only = true;  // every tracking launch in flight is old enough to be in its tail (a few straggling wavefronts)
+    for (int line = 0; line < g->n_lk; ++line) tails_only = tails_only && (!lk_busy[line] || t_now_us - g->lk_t0[line] >= g->lk_overlap_us);
     for (int line = 0; line < g->n_lk && !error; ++line) {
       if (lk_busy[line]) continue;
-      const std::vector<int> q_now = take_line(q_track, line, g->n_lk);
+      std::vector<int> q_now;
+      if (g->lk_overlap_us > 0) {  // dynamic lines: the whole queue departs on a free line, but only next to tails
+        if (!tails_only) break;
+        q_now.swap(q_track);
+      } else {
+        q_now = take_line(q_track, line, g->n_lk);
+      }
       if (q_now.empty()) continue;
+      g->lk_t0[line] = t_now_us;
+      for (int li : q_now) g->lanes[li]->lk_line = line;
       SvoLkLanes a;
       a.w = W; a.h = H;
       int gx = 1;

@@ -146,6 +146,30 @@ def test_hip_ba_matches_oracle(ctx, seed, K, N, dense, device_lm):
 
 
 @pytest.mark.gpu
+def test_hip_device_solve_twice_on_one_load_continues_from_the_solved_state(ctx):
+    """The device-resident solve reads the problem image from pinned memory in place (no upload in front of it).  A second
+    solve of the SAME load must start from the solved landmarks and poses (the host image is refreshed first), exactly as
+    the host-driven loop does from its device copies; a host-driven solve after a device one must work too."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(31, 5, 600)
+    out = {}
+    for name, modes in (("host", (False, False)), ("device", (True, True)), ("mixed", (True, False))):
+        ba = S.api.BA(ctx, 6, BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0,
+                      max_iterations=4, device_lm=modes[0])
+        ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+        s1 = ba.solve_problem()
+        ba.L.svo_ba_set_device_lm(ba.h, 1 if modes[1] else 0)
+        s2 = ba.solve_problem()
+        poses, pts = ba.read_problem()
+        out[name] = (s1.iterations, s1.final_cost, s2.iterations, s2.initial_cost, s2.final_cost, poses.copy(), pts.copy())
+        assert s2.initial_cost == s1.final_cost, name  # the second solve starts where the first ended
+        ba.close()
+    for name in ("device", "mixed"):
+        assert out[name][:5] == out["host"][:5], name
+        assert np.array_equal(out[name][5], out["host"][5]) and np.array_equal(out[name][6], out["host"][6]), name
+
+
+@pytest.mark.gpu
 def test_hip_rejected_load_leaves_no_problem(ctx):
     """A load that fails its validation must not leave the new dimensions over the old chunk layout: afterwards the adjuster
     holds NO problem (solve refuses), and a later good load solves as if nothing had happened."""

@@ -100,9 +100,29 @@ def cpu_baseline(p, K, seconds=12.0):
     dt = time.perf_counter() - t0
     frac = len(op) / len(p["op"])
     # iterations/s of the FULL problem: work is linear in the observations, so the sample's rate scales by its share
-    return dict(value=its / dt * frac, unit="iterations/s", cores=cores, kind="port",
-                sample=f"oracle ba_solve on the first {n_lm} landmarks ({len(op)} of {len(p['op'])} observations, {its} LM "
-                       f"iterations in {dt:.1f} s), rate scaled by the observation share {frac:.3f}")
+    cb = dict(value=its / dt * frac, unit="iterations/s", cores=cores, kind="port",
+              sample=f"oracle ba_solve on the first {n_lm} landmarks ({len(op)} of {len(p['op'])} observations, {its} LM "
+                     f"iterations in {dt:.1f} s), rate scaled by the observation share {frac:.3f}")
+    return cb, dict(pts=pts, op=op, oj=oj, uv=uv, oracle=so)
+
+
+def parity_vs_cpu(S, ctx, p, K, sub, acc_mode):
+    """The SAME 3-iteration solve of the cpu_baseline sample on the GPU: in the deterministic accumulation mode (declared summation
+    order: the oracle's numbers) and in the mode the bench line was measured in (hardware-order sums: tolerance level)."""
+    out = {"sample": f"3 LM iterations on the cpu_baseline sample ({len(sub['pts'])} landmarks, {len(sub['op'])} observations)"}
+    so = sub["oracle"]
+    for mode in dict.fromkeys(("deterministic", acc_mode)):
+        ba = S.BA(ctx, K, F, CX, CY, max_landmarks=len(sub["pts"]) + 8, max_observations=len(sub["op"]) + 8, max_iterations=3, max_time_s=0.0,
+                  accumulation=mode)
+        ba.load_problem(p["poses0"], sub["pts"], sub["op"], sub["oj"], sub["uv"])
+        s = ba.solve_problem()
+        ba.close()
+        out[mode] = {"iterations_identical": bool(s.iterations == so["iterations"]),
+                     "initial_cost_rel_diff": abs(s.initial_cost - so["initial_cost"]) / so["initial_cost"],
+                     "final_cost_rel_diff": abs(s.final_cost - so["final_cost"]) / so["final_cost"],
+                     "final_cost_bits_identical": bool(s.final_cost == so["final_cost"])}
+    out["identical"] = bool(out["deterministic"]["iterations_identical"] and out["deterministic"]["final_cost_rel_diff"] <= 1e-12)
+    return out
 
 
 def run(args, cpu_seconds=12.0):
@@ -188,7 +208,8 @@ def run(args, cpu_seconds=12.0):
                                    "residual/Jacobian part issues separate f64 multiply and add (f64_muladd row), only the "
                                    "Schur products run on the matrix pipe"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not emu:
-        out["cpu_baseline"] = cpu_baseline(p, K, cpu_seconds)
+        out["cpu_baseline"], sub = cpu_baseline(p, K, cpu_seconds)
+        out["parity_vs_cpu"] = parity_vs_cpu(S, ctx, p, K, sub, acc_mode)
     ba.close()
     if comm is not None:
         from stereo_vo_amd import api
