@@ -2,7 +2,12 @@
 // reference src/image_processor.cpp:22 (semantics: SURVEY.md Appendix A.1; the exact float
 // operation order is the one declared in oracle/ora_corner.cpp and repeated here bit for bit).
 //
-// Three launches per batch of frames (grid.z / blockIdx.x = frame):
+// Three launches per batch of frames (grid.z / blockIdx.x = frame).  The detection path (round 3) does not write the f32
+// response map at all: corner_response_nms_kernel keeps a three-row window of responses in registers, takes the 3x3
+// non-maximum test there and appends only local maxima above a running lower bound of the threshold (4A bytes written and
+// 4A read per image become a list of a few thousand 8-byte entries); corner_threshold_kernel then applies the exact
+// threshold quality * max.  The two-launch form below (response map + NMS over the map) remains for the response tap
+// (svo_corner_response) and as SVO_CORNER_TWO_PASS=1:
 //   corner_response_kernel : streaming, wavefront = 62-column strip, lane = column: Sobel -> products -> 3x3 box
 //                            (double, DPP neighbour moves + 3-row register window) -> min eigenvalue map (f32) +
 //                            per-image max (order-preserving uint atomicMax).  HBM: reads ~1.1 A bytes, writes 4A.
@@ -173,6 +178,202 @@ __global__ __launch_bounds__(256) void corner_response_kernel(const uint8_t* __r
     lmax = o > lmax ? o : lmax;
   }
   if (lane == 0 && lmax) atomicMax(&maxkey[b], lmax);
+}
+
+
+// ---- response + non-maximum suppression in one streaming pass -----------------------------------------------------------
+// The NMS predicate of corner_nms_kernel — v = (c > thr ? c : 0) equals the maximum of the thresholded 3x3 neighbourhood,
+// for 1 <= x <= W-2, 1 <= y <= H-2 — holds exactly when c > thr and c >= every one of its eight RAW neighbours (a neighbour
+// at or below the threshold is below c anyway), so the local-maximum test does not need the threshold, and the threshold
+// quality * max (known only when the whole image is done) is applied afterwards to the few candidates that survive.  While
+// streaming, a candidate is dropped early when it is not above quality * (the image's maximum SO FAR): that bound only grows
+// towards the final threshold, so nothing the final test would keep is lost (which raw candidates are recorded depends on
+// timing; the thresholded SET does not, and corner_select_kernel orders by key).
+// Geometry: as corner_response_kernel with two halo columns per side (responses are valid on lanes 1..62, the test needs
+// lanes +-1: 60 output columns per wavefront) and one extra response row above and below the strip.
+constexpr int RN_HALO = 2, RN_COLS = 64 - 2 * RN_HALO;
+constexpr int RN_BUF = 320;   // raw candidates a wavefront collects in LDS before it claims list space (one atomic per flush)
+constexpr int NC_RAW = 16;    // word of an image's counter line that counts its raw candidates
+
+__global__ __launch_bounds__(256) void corner_response_nms_kernel(const uint8_t* __restrict__ imgs, int W, int H, int row_stride,
+                                                                  size_t image_stride, unsigned* __restrict__ maxkey, double quality,
+                                                                  unsigned long long* __restrict__ raw, size_t raw_stride /* entries per image */,
+                                                                  int* __restrict__ ncand, int* __restrict__ status) {
+  __shared__ unsigned long long sBuf[4][RN_BUF];
+  const int b = blockIdx.z;
+  const uint8_t* img = imgs + (size_t)b * image_stride;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ncs = (W + RN_COLS - 1) / RN_COLS, nrs = (H + RS_ROWS - 1) / RS_ROWS;
+  const int wid = blockIdx.x * 4 + wave;
+  if (wid >= ncs * nrs) return;  // whole wavefront
+  const int cs = wid % ncs, rs = wid / ncs;
+  const int x = cs * RN_COLS - RN_HALO + lane;      // image column of this lane (may be < 0 or >= W)
+  const int y0 = rs * RS_ROWS, y1 = min(y0 + RS_ROWS, H);               // rows this wavefront decides
+  const int ey0 = y0 > 0 ? y0 - 1 : 0, ey1 = y1 < H ? y1 + 1 : H;       // response rows it computes: [ey0, ey1)
+  const int xr = reflect101(x, W);
+  const int xe = reflect101(lane == 0 ? x - 1 : x + 1, W);
+  const bool edge = lane == 0 || lane == 63;
+  const bool fix_lo = x == -1, fix_hi = x == W;
+  const bool border_wave = cs == 0 || cs * RN_COLS - RN_HALO + 63 >= W;
+  const double scale = 1.0 / (4.0 * 3.0 * 255.0);
+  const float k1 = (float)(1.0 * scale), k0 = (float)(2.0 * scale);
+  const bool test_lane = lane >= RN_HALO && lane < RN_HALO + RN_COLS && x >= 1 && x <= W - 2;
+  unsigned long long* list = raw + (size_t)b * raw_stride;
+  int* count = &ncand[b * NC_STRIDE + NC_RAW];
+  unsigned long long* buf = sBuf[wave];
+  int nbuf = 0;  // wave-uniform
+  auto flush = [&]() {
+    if (nbuf == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    int base = 0;
+    if (lane == 0) base = atomicAdd(count, nbuf);
+    base = __builtin_amdgcn_readfirstlane(base);
+    for (int i = lane; i < nbuf; i += 64) {
+      if ((size_t)(base + i) < raw_stride) list[base + i] = buf[i];
+      else atomicOr(status, 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    nbuf = 0;
+  };
+
+  const int j0 = ey0 > 0 ? ey0 - 1 : 0, j1 = ey1 < H ? ey1 : H - 1;
+  auto load_row = [&](int py, int& c, int& e) {
+    const uint8_t* row = img + (size_t)reflect101(py, H) * row_stride;
+    c = row[xr];
+    e = edge ? (int)row[xe] : 0;
+  };
+  auto row_terms = [&](int c, int e, float& rdx, float& rdy) {
+    int l = wave_from_lower(c), r = wave_from_upper(c);
+    if (lane == 0) l = e;
+    if (lane == 63) r = e;
+    rdx = (float)(r - l);
+    rdy = (float)c * k0 + (float)(l + r) * k1;
+  };
+  const int p_first = j0 - 1, p_last = j1 + 1;
+  unsigned lmax = 0u;
+  float thr_lb = (float)((double)key_f32(ld_l2(&maxkey[b])) * quality);  // maxkey starts at 0: key_f32(0) is a NaN pattern
+  if (!(thr_lb >= 0.0f)) thr_lb = 0.0f;
+  float eA = 0.f, eB = 0.f;  // responses of the two rows above the one being emitted
+  auto emit = [&](int y, const double* top, const double* mid, const double* bot) {
+    const float a = (float)((top[0] + mid[0]) + bot[0]) * 0.5f;
+    const float bq = (float)((top[1] + mid[1]) + bot[1]);
+    const float c = (float)((top[2] + mid[2]) + bot[2]) * 0.5f;
+    const float d = a - c;
+    const float e = (a + c) - sqrtf(d * d + bq * bq);
+    if (lane >= 1 && lane <= 62 && x >= 0 && x < W && y >= y0 && y < y1) {  // every pixel belongs to exactly one wavefront's (rows, lanes 2..61) — lanes 1 / 62 only feed the tests
+      if (lane >= RN_HALO && lane < RN_HALO + RN_COLS) { const unsigned k = f32_key(e); lmax = k > lmax ? k : lmax; }
+    }
+    // row y - 1 can be decided now: its 3x3 neighbourhood is (eA, eB, e) x lanes -1 / 0 / +1
+    const int yt = y - 1;
+    if (yt >= y0 && yt < y1 && yt >= 1 && yt <= H - 2) {  // wave-uniform
+      const float m0 = fmaxf(fmaxf(wave_from_lower(eA), eA), wave_from_upper(eA));
+      const float m2 = fmaxf(fmaxf(wave_from_lower(e), e), wave_from_upper(e));
+      const float m1 = fmaxf(wave_from_lower(eB), wave_from_upper(eB));
+      const bool cand = test_lane && eB > thr_lb && eB >= fmaxf(fmaxf(m0, m1), m2);
+      const unsigned long long mask = __ballot(cand);
+      if (mask) {
+        if (cand) buf[nbuf + __popcll(mask & ((1ull << lane) - 1ull))] = ((unsigned long long)f32_key(eB) << 32) | pack_xy(x, yt);
+        nbuf += __popcll(mask);
+        if (nbuf > RN_BUF - 64) {
+          flush();
+          // a fresher lower bound of the threshold (the image's maximum so far, this wavefront's included)
+          unsigned wm = lmax;
+          for (int off = 32; off > 0; off >>= 1) { const unsigned o = __shfl_xor(wm, off); wm = o > wm ? o : wm; }
+          const unsigned gm = ld_l2(&maxkey[b]);
+          const float lb = (float)((double)key_f32(gm > wm ? gm : wm) * quality);
+          if (lb > thr_lb) thr_lb = lb;
+        }
+      }
+    }
+    eA = eB; eB = e;
+  };
+  auto step = [&](int p, int& c, int& e, float& dxA, float& dyA, float& dxB, float& dyB, float& dxC, float& dyC, double* HA,
+                  double* HB, double* HC) {
+    const int cc = c, ee = e;
+    if (p + RS_PF <= p_last) load_row(p + RS_PF, c, e);
+    row_terms(cc, ee, dxC, dyC);
+    const int j = p - 1;
+    if (j < j0) return;
+    const float dx = (dxA + dxC) * k1 + dxB * k0;
+    const float dy = dyC - dyA;
+    float xx = dx * dx, xy = dx * dy, yy = dy * dy;
+    if (border_wave) {
+      const int src = fix_lo ? lane + 2 : lane - 2;
+      const float x2 = __shfl(xx, src), y2 = __shfl(xy, src), z2 = __shfl(yy, src);
+      if (fix_lo || fix_hi) { xx = x2; xy = y2; yy = z2; }
+    }
+    HC[0] = ((double)wave_from_lower(xx) + (double)xx) + (double)wave_from_upper(xx);
+    HC[1] = ((double)wave_from_lower(xy) + (double)xy) + (double)wave_from_upper(xy);
+    HC[2] = ((double)wave_from_lower(yy) + (double)yy) + (double)wave_from_upper(yy);
+    const int y = j - 1;
+    if (y < ey0) return;
+    if (y == 0) emit(0, HC, HB, HC);
+    else emit(y, HA, HB, HC);
+  };
+  int c0, e0, c1, e1, c2, e2;
+  load_row(p_first, c0, e0); load_row(p_first + 1, c1, e1); load_row(p_first + 2, c2, e2);
+  float dx0 = 0.f, dy0 = 0.f, dx1 = 0.f, dy1 = 0.f, dx2 = 0.f, dy2 = 0.f;
+  double h0[3] = {0, 0, 0}, h1[3] = {0, 0, 0}, h2[3] = {0, 0, 0};
+  int p = p_first;
+  for (; p + 2 <= p_last; p += 3) {
+    step(p, c0, e0, dx1, dy1, dx2, dy2, dx0, dy0, h1, h2, h0);
+    step(p + 1, c1, e1, dx2, dy2, dx0, dy0, dx1, dy1, h2, h0, h1);
+    step(p + 2, c2, e2, dx0, dy0, dx1, dy1, dx2, dy2, h0, h1, h2);
+  }
+  double hp[3] = {h1[0], h1[1], h1[2]}, hl[3] = {h2[0], h2[1], h2[2]};
+  if (p <= p_last) {
+    step(p, c0, e0, dx1, dy1, dx2, dy2, dx0, dy0, h1, h2, h0);
+    for (int q = 0; q < 3; ++q) { hp[q] = h2[q]; hl[q] = h0[q]; }
+    ++p;
+    if (p <= p_last) {
+      step(p, c1, e1, dx2, dy2, dx0, dy0, dx1, dy1, h2, h0, h1);
+      for (int q = 0; q < 3; ++q) { hp[q] = h0[q]; hl[q] = h1[q]; }
+    }
+  }
+  if (j1 == H - 1 && ey1 == H && H - 1 >= ey0) emit(H - 1, hp, hl, hp);
+  flush();
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned o = __shfl_xor(lmax, off);
+    lmax = o > lmax ? o : lmax;
+  }
+  if (lane == 0 && lmax) atomicMax(&maxkey[b], lmax);
+}
+
+// The exact threshold on the raw local maxima: keeps c > (float)(max * quality), as corner_nms_kernel does.
+__global__ __launch_bounds__(256) void corner_threshold_kernel(const unsigned long long* __restrict__ raw, size_t raw_stride,
+                                                               const unsigned* __restrict__ maxkey, double quality,
+                                                               unsigned long long* __restrict__ cand, int* __restrict__ ncand, int cap,
+                                                               int* __restrict__ status) {
+  const int b = blockIdx.z;
+  const int n = min(ncand[b * NC_STRIDE + NC_RAW], (int)raw_stride);
+  const float thr = (float)((double)key_f32(maxkey[b]) * quality);
+  __shared__ int sCount, sBase;
+  for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {  // workgroup-uniform trip count
+    if (threadIdx.x == 0) sCount = 0;
+    __syncthreads();
+    const int i = i0 + (int)threadIdx.x;
+    unsigned long long e = 0;
+    bool keep = false;
+    if (i < n) {
+      e = raw[(size_t)b * raw_stride + i];
+      keep = key_f32((unsigned)(e >> 32)) > thr;
+    }
+    int local = 0;
+    if (keep) local = atomicAdd(&sCount, 1);
+    __syncthreads();
+    if (threadIdx.x == 0 && sCount > 0) sBase = atomicAdd(&ncand[b * NC_STRIDE], sCount);
+    __syncthreads();
+    if (keep) {
+      const int pos = sBase + local;
+      if (pos < cap) cand[(size_t)b * cap + pos] = e;
+      else atomicOr(status, 1);
+    }
+    __syncthreads();
+  }
 }
 
 constexpr int NMS_ROWS = 8;   // pixel rows per thread: a workgroup covers 64 x 32 pixels (one pixel per thread left the
@@ -477,16 +678,29 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned) * batch, st));
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * NC_STRIDE * batch, st));
-  {
-    SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
-    hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(svo_div_up(W, RS_COLS) * svo_div_up(H, RS_ROWS), 4), 1, batch), dim3(256), 0, st,
-                       imgs, W, H, row_stride, image_stride, ctx->d_eig, ctx->d_maxkey);
-  }
-  {
-  SvoProfScope prof(ctx, SVO_PROF_CORNER_NMS);
-  hipLaunchKernelGGL(corner_nms_kernel, dim3(svo_div_up(W, 64), svo_div_up(H, 4 * NMS_ROWS), batch), dim3(256), 0, st,
-                     ctx->d_eig, W, H, ctx->d_maxkey, quality, ctx->d_cand, ctx->d_ncand, ctx->lim.max_candidates,
-                     ctx->d_status);
+  static const bool two_pass = [] { const char* e = getenv("SVO_CORNER_TWO_PASS"); return e && *e && atoi(e) != 0; }();
+  if (two_pass) {
+    {
+      SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
+      hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(svo_div_up(W, RS_COLS) * svo_div_up(H, RS_ROWS), 4), 1, batch), dim3(256), 0, st,
+                         imgs, W, H, row_stride, image_stride, ctx->d_eig, ctx->d_maxkey);
+    }
+    SvoProfScope prof(ctx, SVO_PROF_CORNER_NMS);
+    hipLaunchKernelGGL(corner_nms_kernel, dim3(svo_div_up(W, 64), svo_div_up(H, 4 * NMS_ROWS), batch), dim3(256), 0, st,
+                       ctx->d_eig, W, H, ctx->d_maxkey, quality, ctx->d_cand, ctx->d_ncand, ctx->lim.max_candidates,
+                       ctx->d_status);
+  } else {
+    // the raw local maxima of an image go where its response map would have gone (4 W H bytes = W H / 2 entries per image)
+    unsigned long long* raw = reinterpret_cast<unsigned long long*>(ctx->d_eig);
+    const size_t raw_stride = (size_t)W * H / 2;
+    {
+      SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
+      hipLaunchKernelGGL(corner_response_nms_kernel, dim3(svo_div_up(svo_div_up(W, RN_COLS) * svo_div_up(H, RS_ROWS), 4), 1, batch), dim3(256), 0, st,
+                         imgs, W, H, row_stride, image_stride, ctx->d_maxkey, quality, raw, raw_stride, ctx->d_ncand, ctx->d_status);
+    }
+    SvoProfScope prof(ctx, SVO_PROF_CORNER_NMS);
+    hipLaunchKernelGGL(corner_threshold_kernel, dim3(32, 1, batch), dim3(256), 0, st, raw, raw_stride, ctx->d_maxkey, quality, ctx->d_cand,
+                       ctx->d_ncand, ctx->lim.max_candidates, ctx->d_status);
   }
   static bool attr_set = false;
   if (!attr_set) {
