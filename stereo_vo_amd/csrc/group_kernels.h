@@ -16,6 +16,7 @@ constexpr int SVO_MAX_LANES = 32;
 // the last wavefront of a lane to arrive compacts the lane (no second launch, no second round trip).
 struct SvoLkLane {
   const uint8_t* pyr_prev; const uint8_t* pyr_next;
+  const uint8_t* l0_prev; const uint8_t* l0_next;                  // level 0 of the two pyramids when it is read from the caller's images in place (null: inside the pyramid)
   const float* xy; const float* init_xy; const long long* ids;   // current features (device, or the pinned arrays a keyframe left)
   int n;
   float* fwd; uint8_t* keep; float* parallax;                      // per-feature scratch (device)

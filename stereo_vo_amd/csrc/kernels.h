@@ -24,7 +24,9 @@ int svo_k_dedup(svo_ctx* ctx, const float* det_xy, const int* n_det_dev, int n_d
 // a3: pyramid of `batch` images. levels buffer: per image svo_k_pyramid_bytes(w,h) bytes, level 0 first.
 size_t svo_k_pyramid_bytes(int w, int h);
 int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride,
-                        size_t image_stride, uint8_t* pyr, size_t pyr_stride);
+                        size_t image_stride, uint8_t* pyr, size_t pyr_stride, bool level0_in_place = false);
+int svo_k_pyramid_level0(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride, size_t image_stride, uint8_t* pyr,
+                         size_t pyr_stride, hipStream_t st);
 // forward+backward LK and the survivor filter of FeatureTracker::track_features.
 // optional extras of the compaction step: per-feature state carried along with the kept features, and pinned
 // host words that receive (n_kept, av_parallax) directly

@@ -36,12 +36,14 @@ constexpr float FLT_EPS = 1.1920928955078125e-7f;
 // pointers would live in scratch memory (measured: 136 B/lane of scratch, 30 MB of spill writes per launch).
 struct Pyr {
   const uint8_t* base;
+  const uint8_t* l0;  // level 0: the pyramid buffer's own copy, or the caller's image read in place (tight rows)
   int w0, h0;
 };
 
-__device__ __forceinline__ Pyr make_pyr(const uint8_t* base, int w, int h) { return Pyr{base, w, h}; }
+__device__ __forceinline__ Pyr make_pyr(const uint8_t* base, int w, int h, const uint8_t* l0 = nullptr) { return Pyr{base, l0 ? l0 : base, w, h}; }
 
 __device__ __forceinline__ void pyr_level(const Pyr& P, int level, const uint8_t*& p, int& w, int& h) {
+  if (level == 0) { p = P.l0; w = P.w0; h = P.h0; return; }
   size_t off = 0;
   w = P.w0; h = P.h0;
   for (int l = 0; l < level; ++l) {
@@ -538,16 +540,18 @@ __global__ __launch_bounds__(256) void pyr_copy_kernel(const uint8_t* __restrict
   pyr[(size_t)blockIdx.z * pyr_stride + (size_t)y * w + x] = imgs[(size_t)blockIdx.z * image_stride + (size_t)y * row_stride + x];
 }
 
+// src_imgs != null (level 1 of a pyramid whose level 0 stays in the caller's images): the source is image z of that array
 __global__ __launch_bounds__(256) void pyr_down_kernel(uint8_t* __restrict__ pyr, size_t pyr_stride, size_t src_off, int sw,
-                                                       int sh, size_t dst_off, int dw, int dh) {
+                                                       int sh, size_t dst_off, int dw, int dh, const uint8_t* __restrict__ src_imgs,
+                                                       size_t src_image_stride, int src_row_stride) {
   const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (x >= dw || y >= dh) return;
-  const uint8_t* src = pyr + (size_t)blockIdx.z * pyr_stride + src_off;
+  const uint8_t* src = src_imgs ? src_imgs + (size_t)blockIdx.z * src_image_stride : pyr + (size_t)blockIdx.z * pyr_stride + src_off;
   const int k[5] = {1, 4, 6, 4, 1};
   int s = 0;
 #pragma unroll
   for (int j = 0; j < 5; ++j) {
-    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, sh) * sw;
+    const uint8_t* row = src + (size_t)reflect101(2 * y + j - 2, sh) * (src_imgs ? src_row_stride : sw);
     int r = 0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) r += k[i] * row[reflect101(2 * x + i - 2, sw)];
@@ -614,7 +618,7 @@ __global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
   const SvoLkLane& a = g.lane[blockIdx.y];
   const int n = a.n, f = blockIdx.x, lane = threadIdx.x;
   if (f < n) {
-    const Pyr A = make_pyr(a.pyr_prev, g.w, g.h), B = make_pyr(a.pyr_next, g.w, g.h);
+    const Pyr A = make_pyr(a.pyr_prev, g.w, g.h, a.l0_prev), B = make_pyr(a.pyr_next, g.w, g.h, a.l0_next);
     const float x0 = a.xy[2 * f], y0 = a.xy[2 * f + 1];
     float fx, fy, bx = 0.f, by = 0.f;
     const uint8_t s1 = lk_point(A, B, x0, y0, &fx, &fy, S);
@@ -748,21 +752,34 @@ size_t svo_k_pyramid_bytes(int w, int h) {
   return s;
 }
 
+// level0_in_place: the pyramid's level-0 slot is left unwritten (the tracker reads the caller's image instead, see Pyr::l0);
+// levels 1.. are the same bytes either way.
 int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride, size_t image_stride,
-                        uint8_t* pyr, size_t pyr_stride) {
+                        uint8_t* pyr, size_t pyr_stride, bool level0_in_place) {
   hipStream_t st = ctx->stream;
-  hipLaunchKernelGGL(pyr_copy_kernel, dim3(svo_div_up(w, 64), svo_div_up(h, 4), batch), dim3(256), 0, st, imgs, w, h,
-                     row_stride, image_stride, pyr, pyr_stride);
+  if (!level0_in_place)
+    hipLaunchKernelGGL(pyr_copy_kernel, dim3(svo_div_up(w, 64), svo_div_up(h, 4), batch), dim3(256), 0, st, imgs, w, h,
+                       row_stride, image_stride, pyr, pyr_stride);
   size_t src_off = 0;
   int sw = w, sh = h;
   for (int l = 1; l < LEVELS; ++l) {
     const size_t dst_off = src_off + (size_t)sw * sh;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     SvoProfScope prof(ctx, SVO_PROF_PYR_DOWN);
+    const bool from_images = level0_in_place && l == 1;
     hipLaunchKernelGGL(pyr_down_kernel, dim3(svo_div_up(dw, 64), svo_div_up(dh, 4), batch), dim3(256), 0, st, pyr, pyr_stride,
-                       src_off, sw, sh, dst_off, dw, dh);
+                       src_off, sw, sh, dst_off, dw, dh, from_images ? imgs : (const uint8_t*)nullptr, image_stride, row_stride);
     src_off = dst_off; sw = dw; sh = dh;
   }
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  return SVO_OK;
+}
+
+// level 0 of `batch` pyramids from their images (what svo_k_build_pyramid skips with level0_in_place)
+int svo_k_pyramid_level0(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int h, int row_stride, size_t image_stride, uint8_t* pyr,
+                         size_t pyr_stride, hipStream_t st) {
+  hipLaunchKernelGGL(pyr_copy_kernel, dim3(svo_div_up(w, 64), svo_div_up(h, 4), batch), dim3(256), 0, st, imgs, w, h, row_stride, image_stride,
+                     pyr, pyr_stride);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

@@ -88,6 +88,7 @@ struct Lane {
   int cur = 0, n = 0, n_initial = 0;
   bool from_host = false;           // the next track reads its features from h_kf_* (tracker (re)initialised by a keyframe)
   const uint8_t* last_pyr = nullptr;
+  const uint8_t* last_l0 = nullptr;  // level 0 of last_pyr: inside it, or (within the batch that produced it) the caller's image read in place
   // ---- PnP
   float* d_xyz = nullptr; double* d_hyp_pose = nullptr; int* d_hyp_count = nullptr; unsigned long long* d_hyp_mask = nullptr;
   double* d_out = nullptr; int* d_nin = nullptr; int* d_inl = nullptr; float* d_trk_xy = nullptr;
@@ -389,7 +390,7 @@ extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
   for (Lane* l : g->lanes) {
     (void)finish_solve(g, l);
     svo_ba_reset(l->ba);
-    l->has_keyframe = false; l->n = l->n_initial = 0; l->from_host = false; l->last_pyr = nullptr; l->cur = 0;
+    l->has_keyframe = false; l->n = l->n_initial = 0; l->from_host = false; l->last_pyr = nullptr; l->last_l0 = nullptr; l->cur = 0;
     l->rvec[0] = l->rvec[1] = l->rvec[2] = l->tvec[0] = l->tvec[1] = l->tvec[2] = 0.f;
     l->state = L_IDLE; l->queued = false; l->pending_from = -1; l->last_iterations = 0;
     const double id7[7] = {1, 0, 0, 0, 0, 0, 0};
@@ -438,12 +439,18 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   int rc = SVO_OK;
   if (lane_stride == istride * (size_t)batch) {
     rc = svo_corner_detect_batch_dev(ctx, left, S * batch, W, H, W, istride, mc, g->prm.quality, (double)g->prm.min_feature_distance, g->d_corners, g->d_ncorners);
-    if (!rc) rc = svo_k_build_pyramid(ctx, left, S * batch, W, H, W, istride, pyr, g->pyr_stride);
+    // level 0 of the pyramids is NOT copied: the tracker reads the caller's images in place (Pyr::l0) — except every lane's
+    // last frame, which the next batch tracks from when the caller's buffer may hold other frames
+    if (!rc) rc = svo_k_build_pyramid(ctx, left, S * batch, W, H, W, istride, pyr, g->pyr_stride, true);
+    if (!rc) rc = svo_k_pyramid_level0(ctx, left + (size_t)(batch - 1) * istride, S, W, H, W, lane_stride, pyr + (size_t)(batch - 1) * g->pyr_stride,
+                                       (size_t)batch * g->pyr_stride, st);
   } else {
     for (int l = 0; l < S && !rc; ++l) {
       rc = svo_corner_detect_batch_dev(ctx, left + l * lane_stride, batch, W, H, W, istride, mc, g->prm.quality, (double)g->prm.min_feature_distance,
                                        g->d_corners + (size_t)l * batch * 2 * mc, g->d_ncorners + (size_t)l * batch);
-      if (!rc) rc = svo_k_build_pyramid(ctx, left + l * lane_stride, batch, W, H, W, istride, pyr + (size_t)l * batch * g->pyr_stride, g->pyr_stride);
+      if (!rc) rc = svo_k_build_pyramid(ctx, left + l * lane_stride, batch, W, H, W, istride, pyr + (size_t)l * batch * g->pyr_stride, g->pyr_stride, true);
+      if (!rc) rc = svo_k_pyramid_level0(ctx, left + l * lane_stride + (size_t)(batch - 1) * istride, 1, W, H, W, istride,
+                                         pyr + ((size_t)l * batch + (size_t)(batch - 1)) * g->pyr_stride, g->pyr_stride, st);
     }
   }
   if (rc) return rc;
@@ -461,6 +468,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   auto RES = [&](int lane, int f) -> svo_frame_result& { return results[(size_t)lane * batch + f]; };
   auto IMG = [&](const uint8_t* base, int lane, int f) { return base + lane * lane_stride + (size_t)f * istride; };
   auto PYR = [&](int lane, int f) { return pyr + ((size_t)lane * batch + f) * g->pyr_stride; };
+  // level 0 of frame f's pyramid: the caller's image, except the batch's last frame (copied into the pyramid above)
+  auto L0 = [&](int lane, int f) -> const uint8_t* { return f == batch - 1 ? PYR(lane, f) : IMG(left, lane, f); };
   auto DET = [&](int lane, int f) { return g->d_corners + ((size_t)lane * batch + f) * 2 * mc; };
   for (int li = 0; li < S; ++li) {
     Lane* l = g->lanes[li];
@@ -527,6 +536,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     l->n = l->n_initial = n;
     l->from_host = true;
     l->last_pyr = PYR(li, i);  // clone of the image, :14 (the batch buffers are double-buffered: it stays valid through the next batch)
+    l->last_l0 = L0(li, i);
     if (l->first_keyframe) { l->tvec[0] = l->tvec[1] = l->tvec[2] = 0.f; l->rvec[0] = l->rvec[1] = l->rvec[2] = 0.f; }  // :54-55
     res[i].is_keyframe = 1;
     res[i].n_new = kept;
@@ -628,6 +638,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
               l->cur ^= 1; l->from_host = false;
               l->n = *l->h_n;
               l->last_pyr = PYR(li, l->frame);  // :66
+              l->last_l0 = L0(li, l->frame);
               error = after_track(li);
               progressed = true; again = l->state == L_IDLE;
             }
@@ -736,6 +747,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         SvoLkLane& x = a.lane[k++];
         const int nxt = l->cur ^ 1;
         x.pyr_prev = l->last_pyr; x.pyr_next = PYR(li, l->frame);
+        x.l0_prev = l->last_l0; x.l0_next = L0(li, l->frame);
         x.xy = l->from_host ? l->h_kf_xy : l->d_xy[l->cur];
         x.init_xy = l->from_host ? l->h_kf_xy : l->d_init[l->cur];
         x.ids = l->from_host ? l->h_kf_ids : l->d_ids[l->cur];
@@ -977,6 +989,23 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     svo_frame_result* res = &RES(li, 0);
     if (l->pending_from < 0) l->pending_from = batch;
     fill_pending(l, res, batch);
+  }
+  // A lane whose last tracked image is NOT the batch's last frame (its later frames had too few corners to track, C-7)
+  // still reads that image's level 0 from the caller's buffer: clone it into its pyramid now (src/feature_tracker.cpp:14,66),
+  // before the caller may reuse the buffer.
+  {
+    bool copied = false;
+    for (int li = 0; li < S && !error; ++li) {
+      Lane* l = g->lanes[li];
+      if (!l->last_pyr || l->last_l0 == l->last_pyr || !l->last_l0) continue;
+#ifdef SVO_EXP_NO_L0_CLONE  // test-the-test build only
+      continue;
+#endif
+      if (svo_k_pyramid_level0(ctx, l->last_l0, 1, W, H, W, istride, const_cast<uint8_t*>(l->last_pyr), g->pyr_stride, st)) { error = SVO_ERR_HIP; break; }
+      l->last_l0 = l->last_pyr;
+      copied = true;
+    }
+    if (copied && hipStreamSynchronize(st) != hipSuccess && !error) { error = SVO_ERR_HIP; ctx->err = "pipeline group: pyramid clone failed"; }
   }
   if (trace_on) {
     for (const Ev& e : evs) fprintf(stderr, "[svo group] %10.1f lane %2d %-22s %d\n", e.us, e.lane, e.what, e.arg);

@@ -95,3 +95,44 @@ def test_hip_group_equals_separate_pipelines_on_identical_streams():
     single.close()
     g.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_group_tracks_across_batches_from_a_frame_that_was_not_the_batch_s_last():
+    """The tracker reads level 0 of its pyramids from the caller's images in place; the image a lane will track FROM in the next
+    batch is cloned (src/feature_tracker.cpp:14,66).  Usually that is the batch's last frame — here the last frames of the first
+    batch are blank (fewer than 4 corners: the frame is skipped, SURVEY C-7), so the clone must be made of an earlier frame, and
+    the caller then overwrites its buffer with the next batch."""
+    import torch
+    import stereo_vo_amd as S
+    n, lanes, batch = 12, 3, 6
+    seqs = [_seq(n, seed=0x5EED0400 + 17 * i) for i in range(lanes)]
+    p0 = seqs[0][0]
+    Ls = np.stack([s[1] for s in seqs]).copy()
+    Rs = np.stack([s[2] for s in seqs]).copy()
+    Ls[1, 4:6] = 128; Rs[1, 4:6] = 128  # lane 1: frames 4 and 5 (the end of batch 0) are blank
+    Ls[2, 5:8] = 90; Rs[2, 5:8] = 90    # lane 2: blank across the batch boundary
+    ctx = S.Context(p0.width, p0.height, max_batch=lanes * batch, max_corners=300, max_candidates=1 << 16, max_features=400)
+    g = _group(S, ctx, p0, 300, 12.0, 400, lanes)
+    buf_l = torch.empty((lanes, batch, p0.height, p0.width), dtype=torch.uint8, device="cuda")
+    buf_r = torch.empty_like(buf_l)
+    got = [[] for _ in range(lanes)]
+    for b0 in range(0, n, batch):
+        buf_l.copy_(torch.from_numpy(Ls[:, b0:b0 + batch]))  # the SAME device buffer for every batch
+        buf_r.copy_(torch.from_numpy(Rs[:, b0:b0 + batch]))
+        torch.cuda.synchronize()
+        res = g.process_batch_dev(buf_l.data_ptr(), buf_r.data_ptr(), batch * p0.width * p0.height, batch)
+        torch.cuda.synchronize()
+        for l in range(lanes):
+            got[l] += res[l]
+    for l in range(lanes):
+        o = _ora_pipe(seqs[l][0], min_feature_distance=12.0, max_corners=300, max_features=400)
+        ref = [o.process(Ls[l, k], Rs[l, k]) for k in range(n)]
+        for k in range(n):
+            assert KEY(got[l][k]) == KEY(ref[k]), (l, k, KEY(got[l][k]), KEY(ref[k]))
+        ig, xg = g.get_tracked(l)
+        io, xo = o.tracked()
+        assert np.array_equal(ig, io) and np.array_equal(xg.view(np.uint32), xo.view(np.uint32)), l
+    assert got[1][4].n_detected < 4 and got[1][6].n_tracked > 0  # the blank frames were skipped, tracking went on from frame 3
+    g.close()
+    ctx.close()
