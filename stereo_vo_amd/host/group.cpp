@@ -300,7 +300,20 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 2, svo_pipeline_group::MAX_LINES);
     g->n_ba = knob("SVO_GROUP_BA_LINES", 4, svo_pipeline_group::MAX_LINES);
     g->st_lk[0] = ctx->stream;
-    for (int i = 1; i < g->n_lk; ++i) chk(hipStreamCreateWithFlags(&g->st_lk[i], hipStreamNonBlocking), "stream");
+    // experiment knob: the tracker's launches on `keep` of every 32 CUs only (the rest stays free for the short kernels of the
+    // keyframe chains and the solves)
+    int keep = 32;
+    { const char* e = getenv("SVO_GROUP_LK_CU_KEEP"); if (e && *e) keep = std::max(4, std::min(32, atoi(e))); }
+    for (int i = 0; i < g->n_lk; ++i) {
+      if (i == 0 && keep == 32) continue;
+      if (keep < 32) {
+        uint32_t mask[8];
+        for (int w = 0; w < 8; ++w) mask[w] = (uint32_t)((1ull << keep) - 1ull);
+        chk(hipExtStreamCreateWithCUMask(&g->st_lk[i], 8, mask), "stream");
+      } else {
+        chk(hipStreamCreateWithFlags(&g->st_lk[i], hipStreamNonBlocking), "stream");
+      }
+    }
     for (int i = 0; i < g->n_chain; ++i) chk(hipStreamCreateWithFlags(&g->st_chain[i], hipStreamNonBlocking), "stream");
     for (int i = 0; i < g->n_ba; ++i) chk(hipStreamCreateWithFlags(&g->st_ba[i], hipStreamNonBlocking), "stream");
   }
