@@ -934,7 +934,8 @@ __device__ __forceinline__ int pay_stage_index(int b, int t, int F, int n) {
 
 // One slice of payload1: destination d, elements [e_lo, e_lo + width).  Any workgroup size; ends with a barrier.
 template <bool SAME_LAUNCH>  // the slots were written by this very launch (fused): read them at the coherence point
-__device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la, int b, double (*sP)[RED_SLICE]) {
+__device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la, int b, double (*sP)[RED_SLICE], long long* t_items = nullptr /* trace: ticks spent in the list walk */) {
+  const long long t_in = t_items && threadIdx.x == 0 ? (long long)wall_clock64() : 0;
   const int F = P.K - 1, n = P.n, tid = threadIdx.x;
   const int nU = F * (F + 1) / 2, nd = nU + F + 1;
   int d, e_lo, width, stride;
@@ -962,6 +963,7 @@ __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la,
     sP[seg][e] = acc;
   }
   __syncthreads();
+  if (t_items && tid == 0) *t_items += (long long)wall_clock64() - t_in;
   if (tid < width) {
     double acc = 0.0;
     for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
@@ -1276,7 +1278,7 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, LmWave& W, bool my_wa
     reduce_pay2<32, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
     if (tid < 4) granule_store(&P.pay2_out[2 * tid], sh.sOut[tid], P.pay_tag);
   }
-  for (int sl = slot; sl < nb; sl += n_blocks + 1) reduce_slice<true>(P, la, sl, sh.sP);
+  for (int sl = slot; sl < nb; sl += n_blocks + 1) reduce_slice<true>(P, la, sl, sh.sP, tp ? tp + 10 : nullptr);
   if (slot < nb || sums2) reduce_publish(P);
   stamp(5);
   return true;
@@ -2299,9 +2301,9 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
             1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n, ba->lm_steps, ba->lm_same, ba->lm_used, ba->lm_lins);
   if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg)
     fprintf(stderr, "[svo ba]   per LM iteration (workgroup 0, us): pass B %.2f, radius-free part of pass A %.2f, decision wait %.2f, rest of pass A %.2f, wait for all passes A %.2f, "
-                    "reduction slices %.2f | payload fetch %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
+                    "reduction slices %.2f (of which walking the lists %.2f) | payload fetch %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
             1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters, 1e-2 * ba->lm_tp[5] / ba->lm_iters,
-            1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
+            1e-2 * ba->lm_tp[10] / ba->lm_iters, 1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
   void* ptrs[] = {ba->d_pay_fg, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
