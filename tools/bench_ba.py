@@ -114,14 +114,24 @@ def parity_vs_cpu(S, ctx, p, K, sub, acc_mode):
     for mode in dict.fromkeys(("deterministic", acc_mode)):
         ba = S.BA(ctx, K, F, CX, CY, max_landmarks=len(sub["pts"]) + 8, max_observations=len(sub["op"]) + 8, max_iterations=3, max_time_s=0.0,
                   accumulation=mode)
-        ba.load_problem(p["poses0"], sub["pts"], sub["op"], sub["oj"], sub["uv"])
-        s = ba.solve_problem()
-        ba.close()
+        try:
+            ba.load_problem(p["poses0"], sub["pts"], sub["op"], sub["oj"], sub["uv"])
+            s = ba.solve_problem()
+        except S.api.SvoError as e:  # the dense variant's contribution slots (210 pose pairs per landmark) exceed the deterministic mode's store
+            out[mode] = {"not_run": str(e)[-120:]}
+            continue
+        finally:
+            ba.close()
         out[mode] = {"iterations_identical": bool(s.iterations == so["iterations"]),
                      "initial_cost_rel_diff": abs(s.initial_cost - so["initial_cost"]) / so["initial_cost"],
                      "final_cost_rel_diff": abs(s.final_cost - so["final_cost"]) / so["final_cost"],
                      "final_cost_bits_identical": bool(s.final_cost == so["final_cost"])}
-    out["identical"] = bool(out["deterministic"]["iterations_identical"] and out["deterministic"]["final_cost_rel_diff"] <= 1e-12)
+    det, acc = out.get("deterministic", {}), out.get(acc_mode, {})
+    if "final_cost_rel_diff" in det:
+        out["identical"] = bool(det["iterations_identical"] and det["final_cost_rel_diff"] <= 1e-12)
+    else:  # tolerance level only (hardware-order sums): the bound tests/test_ba_config4.py uses for the first iterations
+        out["identical"] = None
+        out["within_tolerance"] = bool(acc.get("iterations_identical") and acc.get("final_cost_rel_diff", 1.0) <= 1e-9)
     return out
 
 
