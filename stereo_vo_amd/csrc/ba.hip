@@ -714,17 +714,8 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
 
 // [dc | candidate poses] -> LDS (the source may be pinned host memory: ONE PCIe round trip per workgroup instead of one
 // per use); the first workgroup also leaves the device copy of the candidate poses that later launches linearise at.
-// RES (resident kernel: no kernel boundary since the block was written): [dc | candidate poses | current poses], read at the
-// coherence point — a plain load could be served from a cache line of an earlier iteration.
-template <bool RES = false>
 __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
-  const int nn = P.n > 0 ? P.n : 1, tot = nn + (RES ? 14 : 7) * P.K;
-  if (RES) {
-    if (P.step_in)  // null: the step control of ba_lm_kernel built the block in place
-      for (int i = threadIdx.x; i < tot; i += blockDim.x) sStep[i] = slot_load(&P.step_in[i]);  // the device copy workgroup 0 made of the host's block
-    __syncthreads();
-    return;
-  }
+  const int nn = P.n > 0 ? P.n : 1, tot = nn + 7 * P.K;
   // the first two rounds as ONE round trip (window problems: 72-124 words on 64 or 128 threads): both loads are issued,
   // unconditionally and at clamped addresses, before either is stored — the plain loop waits for each PCIe read in turn
   const int i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
@@ -739,7 +730,7 @@ __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
   __syncthreads();
 }
 constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
-constexpr int RES_STEP_LDS_DOUBLES = 6 * 63 + 14 * 64;  // + the current poses
+constexpr int RES_STEP_LDS_DOUBLES = 6 * 63 + 14 * 64;  // ba_lm_kernel's step block: + the current poses
 
 // payload2 = R(landmark list) over the four per-landmark scalars of pass B (lmV2), in the declared order, by ANY workgroup
 // size: item = (segment, element), 112 items.  sP: RSEG * 4 doubles of LDS, sOut: 4.  Ends with a barrier: every thread
@@ -1076,28 +1067,22 @@ struct IterShared {
   int sGo, sLast;
 };
 
-// RES: inside the resident kernel — the step block (with the current poses) is read coherently, see stage_step<true>.
-// CPW: wave chunks per workgroup.  1: wave 0 works, the second wave only helps with the sums (ba_iterate_kernel: spreads the
-// chunks over the CUs).  2: both waves own a chunk (ba_lm_kernel: a solve then holds half as many wave slots — and, at 256
-// VGPRs a wave, half as many SIMD register files — for its whole duration).
-template <bool RES, int CPW = 1>
+// One workgroup per wave chunk: wave 0 works, the second wave only helps with the sums (spreads the chunks over the CUs).
+// (The solve that lives in ONE launch, ba_lm_kernel, has its own step function: lm_iterate.)
 __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, double spec_radius, const LmCtl& ctl, int with_pay1,
                                              int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy, double* sStep,
-                                             IterShared& sh, int n_blocks /* workgroups of THIS solve (a launch may hold several) */,
-                                             long long* tp = nullptr /* LDS: time split of the phases, 100 MHz ticks (thread 0) */) {
+                                             IterShared& sh, int n_blocks) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-  long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
-  auto stamp = [&](int slot) { if (tp && tid == 0) { const long long tn = (long long)wall_clock64(); tp[slot] += tn - tmark; tmark = tn; } };
-  const int my_chunk = (int)blockIdx.x * CPW + (wave < CPW ? wave : 0);
-  const bool worker = (int)blockIdx.x * CPW < P.C;  // workgroups beyond the chunks only reduce
-  const bool my_wave_works = wave < CPW && my_chunk < P.C;
+  const int my_chunk = (int)blockIdx.x;
+  const bool worker = (int)blockIdx.x < P.C;  // workgroups beyond the chunks only reduce
+  const bool my_wave_works = wave == 0 && my_chunk < P.C;
   if (worker) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
     if (my_wave_works) R = load_obs(P, my_chunk, lane, P.points);  // requested before the step is staged: HBM and PCIe round trips overlap
-    stage_step<RES>(P, sStep);
+    stage_step(P, sStep);
     const double* dc_ = sStep;
     const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
-    const double* cur_poses_ = RES ? cand_poses_ + 7 * P.K : P.poses;
+    const double* cur_poses_ = P.poses;
     D3 cand = D3{0, 0, 1};
     double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
     if (my_wave_works) {
@@ -1110,21 +1095,15 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
     }
     if (ctl.chain) {
       __syncthreads();
-      stamp(0);
       if (tid == 0) sh.sLast = __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == sy.arrived_target;
       __syncthreads();
       if (sh.sLast) {
         reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
         const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
-        if (P.pay_dev) {  // tagged granules: payload2 + decision for the replicated step control, the decision for the waiting workgroups
-          if (tid < 6) granule_store(&P.pay2_out[2 * tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius), P.pay_tag);
-          if (tid == 0) { granule_store(&P.ctl_dev[0], (double)dec.accept, P.pay_tag); granule_store(&P.ctl_dev[2], dec.next_radius, P.pay_tag); }
-        } else {
-          if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
-          if (tid == 0) {
-            __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
+        if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
+        if (tid == 0) {
+          __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid == 0) { sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius; }
         stores_acknowledged();  // the decision (device) and payload2 (host) have arrived before anybody can see the post
@@ -1134,20 +1113,13 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
         __syncthreads();
       } else {
         if (tid == 0) {
-          bool ok = wait_until(sy.posted, sy.post_seq, false);
-          if (P.pay_dev) {
-            double d0 = 0, d1 = 0;
-            ok = ok && granule_wait(P.ctl_dev, 0, P.pay_tag, d0) && granule_wait(P.ctl_dev, 1, P.pay_tag, d1);
-            sh.sDec[0] = d0; sh.sDec[1] = d1;
-          } else {
-            sh.sDec[0] = slot_load(&P.ctl_dev[0]); sh.sDec[1] = slot_load(&P.ctl_dev[1]);
-          }
+          const bool ok = wait_until(sy.posted, sy.post_seq, false);
+          sh.sDec[0] = slot_load(&P.ctl_dev[0]); sh.sDec[1] = slot_load(&P.ctl_dev[1]);
           sh.sGo = ok;
         }
         __syncthreads();
       }
       if (!sh.sGo) return;
-      stamp(1);
       if (my_wave_works) {
         const bool accept = sh.sDec[0] != 0.0;
         if (accept) R.p = cand;
@@ -1157,7 +1129,6 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
     }
   }
   __syncthreads();
-  stamp(2);
   if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
   const bool sums2 = !ctl.chain && blockIdx.x == 0;  // payload2 of a same-sweep / plain step: formed here, by workgroup 0
@@ -1165,15 +1136,12 @@ __device__ __forceinline__ void iterate_body(const BaDev& P, double radius, doub
   if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
   __syncthreads();
   if (!sh.sGo) return;
-  stamp(3);
   if (sums2) {
     reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-    if (P.pay_dev) { if (tid < 4) granule_store(&P.pay2_out[2 * tid], sh.sOut[tid], P.pay_tag); }
-    else if (tid < 4) pay_store(&P.pay2_out[tid], sh.sOut[tid]);
+    if (tid < 4) pay_store(&P.pay2_out[tid], sh.sOut[tid]);
   }
   for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
   reduce_publish(P);
-  stamp(4);
 }
 
 __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius, double spec_radius, LmCtl ctl, int with_pay1,
@@ -1183,7 +1151,7 @@ __global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius,
   // these few waves are some stream's critical path and share their SIMDs with other streams' long tracker waves: issue
   // priority over them (measured at 8 streams: +1 %; a high-priority HIP stream instead costs 7 %)
   __builtin_amdgcn_s_setprio(3);
-  iterate_body<false>(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh, (int)gridDim.x);
+  iterate_body(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh, (int)gridDim.x);
 }
 
 // ---- one LM step inside ba_lm_kernel -----------------------------------------------------------------------------
@@ -1424,7 +1392,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   const LmDevOpt& opt = a.opt;
   enum { ACT_NONE = 0, ACT_LOOPTOP, ACT_FINISH, ACT_ACCEPT_TAIL, ACT_SOLVE };
   int act = ACT_NONE;
-  // a command's bookkeeping, as the host keeps it for the resident kernel (op_linearize / op_step / ba_resident_end)
+  // a pass' bookkeeping: how many arrivals complete it
   auto issue = [&](int op, int chain, int with_pay1) {
     if (tid == 0) {
       int publishers = grid;
@@ -2238,9 +2206,9 @@ static int ba_alloc(svo_ba* ba) {
       SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
     }
   }
-  // pinned block: [completion word 64 B | resident-kernel command header 128 B | step: dc, candidate poses (, current poses) | payload]
+  // pinned block: [completion word 64 B | 128 B reserved | step: dc, candidate poses (, current poses) | payload]
   const size_t pin_step_doubles = step_doubles + 7 * (size_t)Kmax;
-  // ... | landmarks delivered by the resident kernel (written by the GPU only: the CPU never holds these lines dirty)]
+  // ... | landmarks delivered by ba_lm_kernel (written by the GPU only: the CPU never holds these lines dirty)]
   ba->pin_bytes = 64 + 128 + sizeof(double) * (pin_step_doubles + PAY2_SLOTS + ba->cap_pay1 + 8 + 3 * ba->cap_points + LMR_DOUBLES + 7 * (size_t)Kmax + 8);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_pin, ba->pin_bytes, hipHostMallocCoherent));  // fine-grained: see reduce_publish
   memset(ba->h_pin, 0, ba->pin_bytes);  // the flag word is compared by equality with a sequence number: never start from recycled bytes
@@ -2526,8 +2494,8 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
   d.poses = (double*)(D + o_p0);
   d.cand_poses = (double*)(D + o_p1);
-  // the image goes up when the solve knows how: fetched by the resident LM kernel itself (no blit, no extra launch in front
-  // of it), or by one H2D copy (ba_flush_arena)
+  // the image goes up when the solve knows how: read in place by ba_lm_kernel (no blit, no extra launch in front of it), or
+  // by one H2D copy (ba_flush_arena)
   ba->arena_bytes = (total + 15) & ~(size_t)15;
   ba->arena_dirty = true;
   ba->arena_partial = false;
@@ -2590,7 +2558,7 @@ static int ba_refresh_arena_image(svo_ba* ba) {
   return SVO_OK;
 }
 
-// The problem image -> device by one H2D copy on the adjuster's stream (every path but the resident kernel's).
+// The problem image -> device by one H2D copy on the adjuster's stream (every path but ba_lm_kernel's).
 static int ba_flush_arena(svo_ba* ba) {
   if (ba->arena_partial) { const int rc = ba_refresh_arena_image(ba); if (rc) return rc; }
   if (!ba->arena_dirty) return SVO_OK;
@@ -3174,7 +3142,7 @@ extern "C" int svo_ba_read_problem(svo_ba* ba, double* poses7, double* points3) 
   svo_ctx* ctx = ba->ctx;
   if (poses7) memcpy(poses7, ba->h_poses.data(), sizeof(double) * 7 * (size_t)ba->d.K);
   if (points3 && ba->n_points && ba->host_points_valid) {
-    // delivered by the resident kernel; a landmark without observations was never touched: it keeps its uploaded value
+    // delivered by ba_lm_kernel; a landmark without observations was never touched: it keeps its uploaded value
     memcpy(points3, ba->h_out_points, sizeof(double) * 3 * (size_t)ba->n_points);
     const double* in = reinterpret_cast<const double*>(ba->h_arena + ba->arena_pts_off);
     const std::vector<int32_t>& lm = ba->u_lm_start;

@@ -311,7 +311,7 @@ def test_hip_sharded_callback_equals_unsharded(ctx):
 
 @pytest.mark.gpu
 def test_hip_ba_read_before_solve_returns_the_loaded_problem(ctx):
-    """The problem image goes to the device only when a solve knows how (fetched by the resident kernel, or one H2D copy):
+    """The problem image goes to the device only when a solve knows how (read in place by the one-launch solve, or one H2D copy):
     reading a problem that was loaded but never solved must hand back exactly what was loaded, and a solve afterwards
     must still see it."""
     import stereo_vo_amd as S
