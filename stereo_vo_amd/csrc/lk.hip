@@ -611,10 +611,10 @@ __global__ __launch_bounds__(LKT * FPB) void lk_fb_kernel(const uint8_t* __restr
 // a running sum that is >= +0 bit-identical), 64 scalar lane reads per round.  Per-feature results cross workgroups
 // inside the launch: written through, read at the coherence point (tail_device.h); the compacted set goes out with plain
 // stores behind ONE system-scope release fence of the compacting wavefront, then the completion word.
-// Register budget: 80 VGPRs (six wavefronts per SIMD; 22 values of the per-level set-up spill).  At the natural 123 a SIMD that
-// hosts one 256-VGPR wavefront of a resident solve (about every SIMD of the chip does under the default load) has room for two
-// tracker wavefronts, at 80 for three: 16.1-16.4 k -> 16.6-16.7 k frames/s although the launch itself gets 6 % longer.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void lk_fb_group_kernel(SvoLkLanes g) {
+// Register budget: the natural 123 VGPRs.  Measured with 80 (amdgpu_waves_per_eu(6, 6): three tracker wavefronts instead of two
+// fit next to a 256-VGPR wavefront of a resident solve): +1.5 % frames/s, but the 22 spilled values of the per-level set-up
+// cost 9 MB of scratch traffic per stereo pair (3.7 -> 12.8 MB for this kernel, profiles/r03_traffic.json of that build).
+__global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
   static_assert(LKT == 64 && FPB == 1, "the stream-batched tracker is written for one wavefront per feature");
   __shared__ LkShared S;
   __shared__ int sLast;
