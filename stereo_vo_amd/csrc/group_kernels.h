@@ -32,6 +32,7 @@ int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_la
 // a5: hypotheses (100 workgroups per lane), then refinement of the hypothesis the host's RANSAC bookkeeping chose
 struct SvoPnpHypLane {
   const float* xyz; const float* xy; int n; double f, cx, cy; double q0[4], t0[3]; double thr2;
+  const float* host_xyz;  // pinned source of xyz (get_world_points, src/image_processor.cpp:72); null: xyz is already on the device
   double* hyp_pose; int* hyp_count; unsigned long long* hyp_mask; int mask_words; int* host_count;
   SvoPublish pub;
 };

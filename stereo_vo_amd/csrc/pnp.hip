@@ -498,7 +498,28 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, i
 int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters) { return update_num_iters(p, ep, model_points, max_iters); }
 int svo_pnp_model_points() { return MODEL; }
 
+// The world points of every lane of a hypotheses launch, pinned host -> device, as ONE small launch in front of it (a
+// hipMemcpyAsync per lane was a blit kernel each: 0.5 per processed frame, 47 us on average under the group load).
+__global__ __launch_bounds__(256) void pnp_xyz_upload_group_kernel(SvoPnpHypLanes g) {
+  const SvoPnpHypLane& a = g.lane[blockIdx.y];
+  if (!a.host_xyz) return;
+  const int nfl = 3 * a.n, i = blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk i = floats [4 i, 4 i + 4)
+  if (4 * i >= nfl) return;
+  float* dst = const_cast<float*>(a.xyz);
+  if (4 * i + 4 <= nfl) {
+    uint4 v;
+    const float* q = a.host_xyz + 4 * i;
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");  // system scope: never a stale L2 line of the last keyframe's points
+    *reinterpret_cast<uint4*>(dst + 4 * i) = v;
+  } else {
+    for (int j = 4 * i; j < nfl; ++j) dst[j] = __hip_atomic_load(&a.host_xyz[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 int svo_kg_pnp_hypotheses(svo_ctx* ctx, hipStream_t st, const SvoPnpHypLanes& lanes, int n_lanes, int iterations) {
+  int max_n = 0;
+  for (int i = 0; i < n_lanes; ++i) if (lanes.lane[i].host_xyz) max_n = std::max(max_n, lanes.lane[i].n);
+  if (max_n > 0) hipLaunchKernelGGL(pnp_xyz_upload_group_kernel, dim3(svo_div_up(svo_div_up(3 * max_n, 4), 256), n_lanes), dim3(256), 0, st, lanes);
   SvoProfScope prof(ctx, SVO_PROF_PNP_HYP, st);
   hipLaunchKernelGGL(pnp_hypotheses_group_kernel, dim3(iterations, n_lanes), dim3(64), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());

@@ -789,9 +789,9 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       for (int li : h_now) {
         Lane* l = g->lanes[li];
         const int m = l->m_tracked;
-        if (hipMemcpyAsync(l->d_xyz, l->h_xyz, sizeof(float) * 3 * m, hipMemcpyHostToDevice, stc) != hipSuccess) { error = SVO_ERR_HIP; ctx->err = "pipeline group: world point upload failed"; break; }
         SvoPnpHypLane& x = a.lane[k++];
         x.xyz = l->d_xyz; x.xy = l->d_xy[l->cur]; x.n = m;
+        x.host_xyz = l->h_xyz;  // uploaded by the launch itself (one small kernel for all its lanes: svo_kg_pnp_hypotheses)
         x.f = (double)g->K[0]; x.cx = (double)g->K[2]; x.cy = (double)g->K[5];
         // rvec/tvec are CV_32F in/out, the solver works in double (host/pipeline.cpp; csrc/pnp.hip svo_k_pnp)
         const double rv[3] = {l->rvec[0], l->rvec[1], l->rvec[2]};
