@@ -181,6 +181,8 @@ struct svo_pipeline_group {
   // consecutive stages coherent), solves take whichever solve line is free
   static constexpr int MAX_LINES = 8;
   int n_lk = 1, n_chain = 1, n_ba = 2;
+  // SVO_TIMING: host time of the group thread inside the per-keyframe graph calls (ns), and keyframes seen
+  double t_get_points = 0, t_add_keyframe = 0, t_finish = 0, t_loop = 0; long n_kf = 0; bool timing = false;
   double lk_overlap_us = 0.0;  // > 0: a second tracking line may depart once every launch in flight is at least this old (it is in its tail then)
   double lk_t0[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // departure time of the launch in flight on each tracking line (us since the call began)
   hipStream_t st_lk[MAX_LINES] = {}, st_chain[MAX_LINES] = {}, st_ba[MAX_LINES] = {};
@@ -238,8 +240,10 @@ int finish_solve(svo_pipeline_group* g, Lane* l) {
   const int st = l->ba_state.load(std::memory_order_acquire);
   if (st == BA_NONE) return SVO_OK;
   int rc = SVO_OK;
+  const auto tf0 = std::chrono::steady_clock::now();
   if (st == BA_INFLIGHT) rc = svo_ba_solve_finish(l->ba, &l->ba_summary);
   else rc = l->ba_rc;  // BA_HOST_DONE
+  if (g->timing) g->t_finish += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tf0).count();
   l->ba_state.store(BA_NONE, std::memory_order_release);
   if (rc) return rc;
   l->last_iterations = l->ba_summary.iterations;
@@ -259,6 +263,9 @@ extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
   for (Lane* l : g->lanes) {
     if (l->ba_state.load() == BA_INFLIGHT) { svo_ba_summary s; (void)svo_ba_solve_finish(l->ba, &s); }
   }
+  if (g->timing && g->n_kf)
+    fprintf(stderr, "[svo group] %d lanes, %ld keyframes; group thread per keyframe (us): get_world_points %.1f, add_keyframe %.1f, join + write-back of the solve %.1f\n",
+            g->n_lanes, g->n_kf, 1e-3 * g->t_get_points / g->n_kf, 1e-3 * g->t_add_keyframe / g->n_kf, 1e-3 * g->t_finish / g->n_kf);
   (void)hipStreamSynchronize(g->ctx->stream);
   for (int i = 0; i < svo_pipeline_group::MAX_LINES; ++i) {
     if (g->st_lk[i] && g->st_lk[i] != g->ctx->stream) { (void)hipStreamSynchronize(g->st_lk[i]); (void)hipStreamDestroy(g->st_lk[i]); }
@@ -296,6 +303,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
   {
     auto knob = [](const char* name, int dflt, int hi) { const char* e = getenv(name); int v = e && *e ? atoi(e) : dflt; return v < 1 ? 1 : (v > hi ? hi : v); };
     g->n_lk = knob("SVO_GROUP_LK_LINES", 1, svo_pipeline_group::MAX_LINES);
+    g->timing = getenv("SVO_TIMING") != nullptr;
     { const char* e = getenv("SVO_GROUP_LK_OVERLAP_US"); g->lk_overlap_us = e && *e ? std::max(0.0, atof(e)) : 0.0; }
     g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 2, svo_pipeline_group::MAX_LINES);
     g->n_ba = knob("SVO_GROUP_BA_LINES", 4, svo_pipeline_group::MAX_LINES);
@@ -532,7 +540,9 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     l->new_ids.assign((size_t)(m_new > 0 ? m_new : 1), 0);
     int kept = 0;
     std::vector<int64_t> tid(l->kf_tracked_ids.begin(), l->kf_tracked_ids.end());
+    const auto ta0 = std::chrono::steady_clock::now();
     int rc2 = svo_ba_add_keyframe(l->ba, pose7, tid.data(), l->kf_tracked_xy.data(), nt, l->h_tri_xy, l->h_tri_xyz, m_new, l->new_ids.data(), &kept);  // :144
+    if (g->timing) { g->t_add_keyframe += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ta0).count(); g->n_kf++; }
     if (rc2) return rc2;
     // the previous solve was joined before the graph was edited: its poses are final now
     fill_pending(l, res, i);
@@ -586,7 +596,9 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     if (m > 0) {
       l->ids64.assign(l->h_ids[l->cur], l->h_ids[l->cur] + m);
       std::vector<int64_t> id64(l->ids64.begin(), l->ids64.end());
+      const auto tg0 = std::chrono::steady_clock::now();
       const int rc2 = svo_ba_get_points(l->ba, id64.data(), m, l->h_xyz);  // :72 get_world_points
+      if (g->timing) g->t_get_points += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tg0).count();
       if (rc2) return rc2;
     }
     if (m >= MODEL) { q_hyp.push_back(li); l->queued = true; l->state = L_PNP_HYP_WAIT; }
