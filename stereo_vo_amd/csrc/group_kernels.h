@@ -57,9 +57,12 @@ struct SvoDedupLanes { SvoDedupLane lane[SVO_MAX_LANES]; };
 // grid_x = ceil(largest n_det / 4); every lane's target counts grid_x workgroups
 int svo_kg_dedup(svo_ctx* ctx, hipStream_t st, const SvoDedupLanes& lanes, int n_lanes, int grid_x);
 
-// a7 (sparse) + a8: disparities at the lane's features, triangulation / compaction by the lane's last workgroup
+// a6 + a7 (sparse) + a8: every workgroup first applies the dedup predicate to its detected corner (a duplicate takes disparity 0
+// and is dropped by the triangulation's own validity test, in the same index order as the separate dedup launch gave), then the
+// disparity at the corner; triangulation / compaction by the lane's last workgroup
 struct SvoStereoTriLane {
   const uint8_t* left; const uint8_t* right; const float* xy; const int* n_dev; int n_max; float* disp; SvoMat4 M;
+  const float* trk; int n_trk; float min_d;  // a6 folded in: the tracked inliers a detected corner must keep min_d away from (null: no dedup, frame 0)
   float* kept_xy; float* xyz; int* n_kept; SvoPublish pub;
 };
 struct SvoStereoTriLanes { int w, h, stride, ndisp, block; SvoStereoTriLane lane[SVO_MAX_LANES]; };

@@ -196,11 +196,49 @@ __global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* 
   stereo_triangulate_body(L, R, W, H, stride, ndisp, block, xy, n_dev, n_host, disp, M, kept_xy, xyz, kept_index, n_kept, pub);
 }
 
-// stream-batched form (group_kernels.h): blockIdx.y = lane, the same body
+// stream-batched form (group_kernels.h): blockIdx.y = lane.  The dedup of src/image_processor.cpp:113-128 is folded in (one
+// launch and one wait for wavefront slots less per keyframe; under the group load the separate dedup launch took 128 us for
+// 15 us of work): wavefront 0 of a corner's workgroup tests it against the tracked inliers exactly as dedup_body does
+// (sqrtf(dx^2 + dy^2) < min_d); a duplicate gets disparity 0, which the triangulation's validity test (d > 0, :194) drops —
+// the surviving corners keep their detection order, as after the separate, order-preserving dedup compaction.
 __global__ __launch_bounds__(256) void stereo_triangulate_group_kernel(SvoStereoTriLanes g) {
   const SvoStereoTriLane& a = g.lane[blockIdx.y];
-  stereo_triangulate_body(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, a.xy, a.n_dev, a.n_max, a.disp, a.M, a.kept_xy, a.xyz,
-                          nullptr, a.n_kept, a.pub);
+  if (!a.trk) {
+    stereo_triangulate_body(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, a.xy, a.n_dev, a.n_max, a.disp, a.M, a.kept_xy, a.xyz,
+                            nullptr, a.n_kept, a.pub);
+    return;
+  }
+  svo_latency_critical();
+  __shared__ int sWaveT[4];
+  __shared__ int sLast, sHit;
+  const int n = a.n_max, f = blockIdx.x;
+  if (f < n) {
+    const float x = a.xy[2 * f], y = a.xy[2 * f + 1];
+    if (threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      bool hit = false;
+      for (int j0 = 0; j0 < a.n_trk && !hit; j0 += 64) {
+        const int j = j0 + lane;
+        bool h = false;
+        if (j < a.n_trk) {
+          const float dx = x - a.trk[2 * j], dy = y - a.trk[2 * j + 1];
+          h = sqrtf(dx * dx + dy * dy) < a.min_d;  // src/image_processor.cpp:118-123
+        }
+        hit = __any(h);
+      }
+      if (lane == 0) sHit = hit ? 1 : 0;
+    }
+    __syncthreads();
+    const bool dup = sHit != 0;  // workgroup-uniform
+    float d = 0.f;
+    if (!dup) d = stereo_at_block(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, (int)x, (int)y);
+    if (threadIdx.x == 0) svo_wt_store(&a.disp[f], d);
+  }
+  if (!svo_last_arrival(a.pub.arrive, a.pub.target, &sLast)) return;
+  svo_triangulate_block<256, true>(a.xy, a.disp, n, a.M, a.kept_xy, a.xyz, nullptr, a.n_kept, sWaveT);
+  SvoPublish one = a.pub;
+  one.arrive = nullptr;  // the arrivals have been counted: this workgroup publishes alone
+  svo_publish_block(one);
 }
 
 int svo_kg_stereo_triangulate(svo_ctx* ctx, hipStream_t st, const SvoStereoTriLanes& lanes, int n_lanes, int grid_x) {

@@ -858,29 +858,25 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     }
     if (!t_now.empty()) {
       // dedup (:113-128) for the lanes that tracked, then sparse StereoBM + triangulation (:137-142, :34-39 for frame 0)
-      SvoDedupLanes d;
       SvoStereoTriLanes t;
       t.w = W; t.h = H; t.stride = W; t.ndisp = svo_ref::STEREO_NUM_DISPARITIES; t.block = svo_ref::STEREO_BLOCK_SIZE;
-      int kd = 0, kt = 0, gxd = 1, gxt = 1;
+      int kt = 0, gxt = 1;
       for (int li : t_now) {
         Lane* l = g->lanes[li];
         const int n_det = hc[li * batch + l->frame];
         gxt = std::max(gxt, n_det);
-        if (!l->first_keyframe) gxd = std::max(gxd, svo_div_up(n_det, 4));
       }
       for (int li : t_now) {
         Lane* l = g->lanes[li];
         const int i = l->frame, n_det = hc[li * batch + i];
         float pose[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
         SvoStereoTriLane& x = t.lane[kt++];
-        if (l->first_keyframe) {
-          x.xy = DET(li, i); x.n_dev = nullptr;
-        } else {
-          SvoDedupLane& y = d.lane[kd++];
-          y.det = DET(li, i); y.n_det = n_det; y.trk = l->d_trk_xy; y.n_trk = l->num_inliers; y.min_d = g->prm.min_feature_distance;
-          y.keep = l->d_flags; y.kept_xy = l->d_new_xy; y.n_kept = l->d_cnt;
-          l->arrive_total[C_DEDUP] += (unsigned)gxd;
-          y.arrive = l->d_arrive + 16 * C_DEDUP; y.target = l->arrive_total[C_DEDUP];
+        x.xy = DET(li, i); x.n_dev = nullptr;
+        x.trk = nullptr; x.n_trk = 0; x.min_d = 0.f;
+        if (!l->first_keyframe) {
+          // dedup (:113-128) inside the same launch: every corner's workgroup tests it against the tracked inliers first
+          x.trk = l->d_trk_xy; x.n_trk = l->num_inliers; x.min_d = g->prm.min_feature_distance;
+          if (x.n_trk <= 0) x.trk = nullptr;  // no inliers (C-9): nothing to keep away from
           // hmat = [R^T | -R^T t]  :130-134 (float Mats; the product accumulates in double)
           memset(pose, 0, sizeof(pose));
           for (int r = 0; r < 3; ++r) {
@@ -890,7 +886,6 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             pose[4 * r + 3] = (float)s;
           }
           pose[15] = 1.f;
-          x.xy = l->d_new_xy; x.n_dev = l->d_cnt;
         }
         x.left = IMG(left, li, i); x.right = IMG(right, li, i);
         x.n_max = n_det; x.disp = l->d_disp;
@@ -900,10 +895,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         l->state = L_TRI_WAIT;
         l->queued = false;
       }
-      if (kd && (error = svo_kg_dedup(ctx, stc, d, kd, gxd))) break;
       if ((error = svo_kg_stereo_triangulate(ctx, stc, t, kt, gxt))) break;
       for (int li : t_now) EV(li, "tri_launch", kt);
-      if (kd) { g->launches[3]++; g->lanes_carried[3] += kd; }
       g->launches[3]++; g->lanes_carried[3] += kt;
       progressed = true;
     }
