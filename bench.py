@@ -1,18 +1,20 @@
 #!/usr/bin/env python3
 """bench.py — stereo frames/s of the MI355X-native stereo-VO hot path (BASELINE.json metric).
 
-Default line = "8 concurrent streams, inputs resident in HBM": a compute rate.  The same 16 frames per stream are
-re-processed every step from a reset pipeline (identical work per step, no upload in the timed region);
+Default line = "48 concurrent streams as 2 pipeline groups, inputs resident in HBM": a compute rate.  The same 16 frames per
+stream are re-processed every step from a reset pipeline (identical work per step, no upload in the timed region);
 `--workload kitti_stream` is the streaming figure (BASELINE configs[2]: 4541 frames through the host-pointer entry,
-upload included, 10-keyframe window, nothing reset).
+upload included, 10-keyframe window, nothing reset).  The default line also carries `other_workloads` (kitti_stream, ba50k
+sparse and dense, hd_1280x720_10k), each with its own roofline / cpu_baseline / parity record.
 
-A "step" = one pass of the whole hot path, on every one of `--streams` (default 8) independent stereo streams
-that share the GPU (own HIP stream, pipeline and BA worker each; exactly how ranks are used across GPUs), i.e. one pass (ImageProcessor::process + BundleAdjuster::bundle_adjust per
-frame: corner detection, pyramids, forward/backward LK + survivor filter, PnP-RANSAC, dedup, stereo
-disparity at the features, triangulation, sliding-window bundle adjustment) over one batch of B
-consecutive synthetic KITTI-shaped stereo pairs that are already resident in HBM, starting from a reset
-pipeline (so every step does identical work).  Workload = BASELINE.json configs[1]:
-1241x376, ~1.5k corners per frame (max_corners 1500, quality 0.02, minDistance 10), 5-keyframe BA window.
+A "step" = one pass of the whole hot path on every one of `--streams` (default 48) independent stereo streams that share the
+GPU — as `--groups` (default 2) pipeline groups (svo_pipeline_group_*: one host thread per group, one kernel launch per stage
+for the lanes that are ready, their bundle adjustments one device-resident launch), or with `--groups 0` as one svo_pipeline
+and one host thread per stream (round 2's form) — i.e. one pass (ImageProcessor::process + BundleAdjuster::bundle_adjust per
+frame: corner detection, pyramids, forward/backward LK + survivor filter, PnP-RANSAC, dedup, stereo disparity at the features,
+triangulation, sliding-window bundle adjustment) over one batch of B consecutive synthetic KITTI-shaped stereo pairs that are
+already resident in HBM, starting from a reset pipeline (so every step does identical work).  Workload = BASELINE.json
+configs[1]: 1241x376, ~1.5k corners per frame (max_corners 1500, quality 0.02, minDistance 10), 5-keyframe BA window.
 
 N GPUs: the frame stream shards across ranks (rank r processes its own sequence chunk; weak scaling, no
 data-path collective — SURVEY §8e "front end / frames").  value = frames all ranks processed / max-over-
@@ -28,9 +30,8 @@ import os
 import sys
 import time
 
-# HIP runtime knob, read when the runtime initialises: the default of 4 hardware queues makes the 2 HIP streams of
-# each stereo stream (tracker + bundle adjuster) share queues and serialise; measured +6 % at 8 streams.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # two pipeline groups use 2 x 7 HIP streams; with 4 hardware queues their long solve launches share queues with the tracking launches and serialise (measured 7.8 k vs 11 k frames/s)
+# HIP runtime knob, read when the runtime initialises (profiles/r03_group_sweep.txt has 4 / 8 / 12 / 16 / 20 / 24):
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # two pipeline groups use 2 x 7 HIP streams; with 4 hardware queues their long solve launches share queues with the tracking launches and serialise (measured 9.9 k vs 16 k frames/s)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
