@@ -27,6 +27,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import re
 import sys
 import time
 
@@ -577,14 +578,54 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches, lanes
     return r
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT the HIP runtime (the parent must stay a process that never mapped
+    libamdhip64: on this pool an exec / fork+exec from a HIP-initialised process can take the machine down).  Order:
+    SVO_BENCH_GPU_COUNT (tests / rehearsals) -> the *_VISIBLE_DEVICES lists the runtime itself honours -> the KFD
+    topology in sysfs (nodes with simd_count > 0 are GPUs)."""
+    forced = os.environ.get("SVO_BENCH_GPU_COUNT")
+    if forced is not None:
+        return int(forced)
+    kfd = 0
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, "properties")).read()
+            except OSError:
+                continue
+            m = re.search(r"^simd_count\s+(\d+)", props, re.M)
+            if m and int(m.group(1)) > 0:
+                kfd += 1
+    except OSError:
+        kfd = 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([x for x in v.split(",") if x.strip() != ""])
+            kfd = min(kfd, listed) if kfd else listed
+    return kfd
+
+
+def hip_runtime_mapped():
+    """True when this process has libamdhip64 mapped (importing torch is enough for that)."""
+    try:
+        return "libamdhip64" in open("/proc/self/maps").read()
+    except OSError:
+        return False
+
+
 def spawn_ranks(args):
-    """`bench.py --gpus N` without a launcher: this parent makes NO GPU call (never `exec` after HIP is initialised, never a
-    fork of an initialised process); it starts N ranks with torch.distributed.run and relays rank 0's JSON line."""
+    """`bench.py --gpus N` without a launcher: this parent makes NO GPU call and never maps the HIP runtime (no torch import:
+    never an `exec` after HIP is initialised, never a fork of an initialised process); it counts the GPUs from the
+    environment / sysfs, starts N ranks with torch.distributed.run and relays rank 0's JSON line."""
     import subprocess
-    import torch  # device_count() does not initialise the runtime on this image
-    have = torch.cuda.device_count() if "SVO_BENCH_FORCE_DEVICE" not in os.environ else args.gpus
+    have = visible_gpu_count()
     if have < args.gpus:
         print(f"bench.py: --gpus {args.gpus} asked for, {have} GPU(s) visible: refusing to measure fewer ranks than asked", file=sys.stderr, flush=True)
+        return 2
+    if hip_runtime_mapped():
+        print("bench.py: the launching process has the HIP runtime mapped; refusing to fork + exec the ranks from it", file=sys.stderr, flush=True)
         return 2
     import socket
     with socket.socket() as sk:

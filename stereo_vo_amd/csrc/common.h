@@ -39,7 +39,10 @@ struct svo_ctx {
   uint8_t* d_ws = nullptr;   // generic scratch for host-pointer entry points
   size_t ws_bytes = 0;
   // front-end buffers, sized for max_batch frames
-  float* d_eig = nullptr;              // batch * W*H
+  float* d_eig = nullptr;              // f32 response map, eig_images * W*H: allocated on first use only (svo_ensure_eig: the
+  size_t eig_images = 0;               // response tap svo_corner_response and the two-pass form SVO_CORNER_TWO_PASS=1)
+  unsigned long long* d_raw = nullptr; // batch * raw_cap raw local maxima of the streaming detection pass (key<<32 | y<<16|x)
+  size_t raw_cap = 0;
   unsigned* d_maxkey = nullptr;        // batch
   unsigned long long* d_cand = nullptr;  // batch * max_candidates  (key<<32 | raster idx)
   int* d_ncand = nullptr;              // batch
@@ -93,6 +96,7 @@ inline SvoPublish svo_arrive_next(svo_ctx* c, int nblocks) {
   return p;
 }
 int svo_wait_word(svo_ctx* c, const SvoPublish& p);  // ctx.hip: bounded spin, falls back to a stream wait
+int svo_ensure_eig(svo_ctx* c, size_t images);       // ctx.hip: the f32 response map, on first use
 
 #if defined(__HIPCC__)
 // First statement of every small kernel that sits on a stereo stream's serial path (the keyframe chain, the adjuster's

@@ -680,6 +680,7 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_ncand, 0, sizeof(int) * NC_STRIDE * batch, st));
   static const bool two_pass = [] { const char* e = getenv("SVO_CORNER_TWO_PASS"); return e && *e && atoi(e) != 0; }();
   if (two_pass) {
+    { const int rce = svo_ensure_eig(ctx, (size_t)ctx->lim.max_batch); if (rce) return rce; }
     {
       SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
       hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(svo_div_up(W, RS_COLS) * svo_div_up(H, RS_ROWS), 4), 1, batch), dim3(256), 0, st,
@@ -690,9 +691,9 @@ static int corner_launch(svo_ctx* ctx, const uint8_t* imgs, int batch, int W, in
                        ctx->d_eig, W, H, ctx->d_maxkey, quality, ctx->d_cand, ctx->d_ncand, ctx->lim.max_candidates,
                        ctx->d_status);
   } else {
-    // the raw local maxima of an image go where its response map would have gone (4 W H bytes = W H / 2 entries per image)
-    unsigned long long* raw = reinterpret_cast<unsigned long long*>(ctx->d_eig);
-    const size_t raw_stride = (size_t)W * H / 2;
+    // the raw local maxima of an image: their own list (ctx->raw_cap entries per image; an overflow sets status bit 1)
+    unsigned long long* raw = ctx->d_raw;
+    const size_t raw_stride = ctx->raw_cap;
     {
       SvoProfScope prof(ctx, SVO_PROF_CORNER_RESPONSE);
       hipLaunchKernelGGL(corner_response_nms_kernel, dim3(svo_div_up(svo_div_up(W, RN_COLS) * svo_div_up(H, RS_ROWS), 4), 1, batch), dim3(256), 0, st,
@@ -786,6 +787,7 @@ extern "C" int svo_corner_response(svo_ctx* ctx, const uint8_t* img, int width, 
   if (!d_img) { ctx->err = "corner_response: workspace too small"; return SVO_ERR_CAPACITY; }
   hipStream_t st = ctx->stream;
   SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(d_img, width, img, row_stride, width, height, hipMemcpyHostToDevice, st));
+  { const int rce = svo_ensure_eig(ctx, 1); if (rce) return rce; }
   SVO_HIP_CHECK(ctx, hipMemsetAsync(ctx->d_maxkey, 0, sizeof(unsigned), st));
   hipLaunchKernelGGL(corner_response_kernel, dim3(svo_div_up(svo_div_up(width, RS_COLS) * svo_div_up(height, RS_ROWS), 4), 1, 1), dim3(256), 0,
                      st, d_img, width, height, width, (size_t)width * height, ctx->d_eig, ctx->d_maxkey);

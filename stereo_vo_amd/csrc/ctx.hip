@@ -1,4 +1,5 @@
 // Context lifetime and workspace (svo.h: svo_create / svo_destroy / svo_stream / svo_sync).
+#include <algorithm>
 #include <chrono>
 #include <sched.h>
 
@@ -90,7 +91,12 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
 #define ALLOC(ptr, bytes) \
   if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return fail(#ptr, e)
   ALLOC(c->d_ws, c->ws_bytes);
-  ALLOC(c->d_eig, B * px * sizeof(float));
+  // raw local maxima of the streaming detection pass: at most one 3x3 maximum per 2x2 pixels could exist (px / 4; ties on
+  // plateaus aside), but what counts is what survives "above quality x the running maximum": twice the candidate bound;
+  // an overflow is reported like a candidate overflow (status bit 1).  The f32 response map of rounds 1-2 (4 px bytes per
+  // frame: 717 MB for a 384-frame context) is no longer allocated here, see svo_ensure_eig.
+  c->raw_cap = std::min(px / 2, (size_t)2 * (size_t)c->lim.max_candidates);
+  ALLOC(c->d_raw, B * c->raw_cap * sizeof(unsigned long long));
   ALLOC(c->d_maxkey, B * sizeof(unsigned));
   ALLOC(c->d_cand, B * c->lim.max_candidates * sizeof(unsigned long long));
   ALLOC(c->d_sorted, B * c->lim.max_candidates * sizeof(unsigned long long));
@@ -105,6 +111,16 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
   if ((e = hipMemsetAsync(c->d_status, 0, 64, c->stream)) != hipSuccess) return fail("memset", e);
   if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail("sync", e);
   *out = c;
+  return SVO_OK;
+}
+
+// the f32 response map for `images` frames (response tap / two-pass detection only)
+int svo_ensure_eig(svo_ctx* c, size_t images) {
+  if (c->d_eig && c->eig_images >= images) return SVO_OK;
+  if (c->d_eig) { SVO_HIP_CHECK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_eig); c->d_eig = nullptr; c->eig_images = 0; }
+  const size_t px = (size_t)c->lim.max_width * c->lim.max_height;
+  SVO_HIP_CHECK(c, hipMalloc((void**)&c->d_eig, images * px * sizeof(float)));
+  c->eig_images = images;
   return SVO_OK;
 }
 
@@ -127,7 +143,7 @@ extern "C" void svo_destroy(svo_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->d_ws, c->d_eig, c->d_maxkey, c->d_cand, c->d_sorted, c->d_state, c->d_ncand,
+  void* ptrs[] = {c->d_ws, c->d_eig, c->d_raw, c->d_maxkey, c->d_cand, c->d_sorted, c->d_state, c->d_ncand,
                   c->d_cell_count, c->d_cell_start, c->d_status};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

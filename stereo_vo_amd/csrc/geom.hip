@@ -71,17 +71,6 @@ __global__ __launch_bounds__(256) void dedup_kernel(const float* __restrict__ de
   dedup_body(det, n_det_dev, n_det_host, trk, n_trk_dev, n_trk_host, min_d, keep, kept_xy, n_kept, arrive, target);
 }
 
-// stream-batched form (group_kernels.h): blockIdx.y = lane, the same body
-__global__ __launch_bounds__(256) void dedup_group_kernel(SvoDedupLanes g) {
-  const SvoDedupLane& a = g.lane[blockIdx.y];
-  dedup_body(a.det, nullptr, a.n_det, a.trk, nullptr, a.n_trk, a.min_d, a.keep, a.kept_xy, a.n_kept, a.arrive, a.target);
-}
-
-int svo_kg_dedup(svo_ctx* ctx, hipStream_t st, const SvoDedupLanes& lanes, int n_lanes, int grid_x) {
-  hipLaunchKernelGGL(dedup_group_kernel, dim3(grid_x, n_lanes), dim3(256), 0, st, lanes);
-  SVO_HIP_CHECK(ctx, hipGetLastError());
-  return SVO_OK;
-}
 
 __global__ void gather_track_kernel(const int* __restrict__ idx, const int* __restrict__ n_dev, int n_host,
                                     const float* __restrict__ init_src, const long long* __restrict__ ids_src,

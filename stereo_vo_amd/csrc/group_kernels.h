@@ -48,15 +48,6 @@ int svo_kg_pnp_refine(svo_ctx* ctx, hipStream_t st, const SvoPnpRefLanes& lanes,
 int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters);  // OpenCV's RANSACUpdateNumIters (csrc/pnp.hip)
 int svo_pnp_model_points();
 
-// a6: dedup of the detected corners against the tracked inliers
-struct SvoDedupLane {
-  const float* det; int n_det; const float* trk; int n_trk; float min_d; uint8_t* keep; float* kept_xy; int* n_kept;
-  unsigned* arrive; unsigned target;
-};
-struct SvoDedupLanes { SvoDedupLane lane[SVO_MAX_LANES]; };
-// grid_x = ceil(largest n_det / 4); every lane's target counts grid_x workgroups
-int svo_kg_dedup(svo_ctx* ctx, hipStream_t st, const SvoDedupLanes& lanes, int n_lanes, int grid_x);
-
 // a6 + a7 (sparse) + a8: every workgroup first applies the dedup predicate to its detected corner (a duplicate takes disparity 0
 // and is dropped by the triangulation's own validity test, in the same index order as the separate dedup launch gave), then the
 // disparity at the corner; triangulation / compaction by the lane's last workgroup

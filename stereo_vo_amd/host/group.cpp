@@ -75,7 +75,7 @@ void quat_from_R(const float* m, float* q /*wxyz*/) {
 enum LaneState { L_IDLE = 0, L_TRACK_WAIT, L_NEED_SOLVE, L_PNP_HYP_WAIT, L_PNP_REF_WAIT, L_TRI_WAIT, L_DONE };
 enum BaState { BA_NONE = 0, BA_ASSEMBLING, BA_READY, BA_INFLIGHT, BA_HOST_SOLVING, BA_HOST_DONE };
 enum Word { W_TRACK = 0, W_HYP, W_REF, W_TRI, W_COUNT };
-enum Counter { C_LK = 0, C_HYP, C_DEDUP, C_TRI, C_COUNT };
+enum Counter { C_LK = 0, C_HYP, C_TRI, C_COUNT };
 
 struct Lane {
   int lk_line = 0;  // the tracking line (stream) its launch in flight went to
@@ -89,19 +89,19 @@ struct Lane {
   bool from_host = false;           // the next track reads its features from h_kf_* (tracker (re)initialised by a keyframe)
   const uint8_t* last_pyr = nullptr;
   const uint8_t* last_l0 = nullptr;  // level 0 of last_pyr: inside it, or (within the batch that produced it) the caller's image read in place
+  uint8_t* d_own_pyr = nullptr;      // the lane's private clone of its last image's pyramid, used when a whole batch went by without tracking (see process_batch)
   // ---- PnP
   float* d_xyz = nullptr; double* d_hyp_pose = nullptr; int* d_hyp_count = nullptr; unsigned long long* d_hyp_mask = nullptr;
   double* d_out = nullptr; int* d_nin = nullptr; int* d_inl = nullptr; float* d_trk_xy = nullptr;
   float* h_xyz = nullptr; int* h_count = nullptr; double* h_out = nullptr; int* h_nin = nullptr; int* h_inl = nullptr;
   // ---- dedup / sparse stereo / triangulation
-  uint8_t* d_flags = nullptr; float* d_new_xy = nullptr; int* d_cnt = nullptr; float* d_disp = nullptr;
-  float* d_kept_xy = nullptr; float* d_kept_xyz = nullptr;
+  float* d_disp = nullptr;
   int* h_tri_cnt = nullptr; float* h_tri_xy = nullptr; float* h_tri_xyz = nullptr;
   // ---- hand-over words and arrival counters
   int* words = nullptr;             // pinned, W_COUNT words 64 bytes apart
   int seq[W_COUNT] = {0, 0, 0, 0};
   unsigned* d_arrive = nullptr;     // device, C_COUNT counters 64 bytes apart (monotone)
-  unsigned arrive_total[C_COUNT] = {0, 0, 0, 0};
+  unsigned arrive_total[C_COUNT] = {0, 0, 0};
   // ---- graph + solve (BundleAdjuster)
   svo_ba* ba = nullptr;
   std::atomic<int> ba_state{BA_NONE};
@@ -254,6 +254,23 @@ int finish_solve(svo_pipeline_group* g, Lane* l) {
   return SVO_OK;
 }
 
+// After a failed batch: launches of other lanes may still be in flight (they read the caller's images and write the pinned
+// mirrors and completion words), and arrive_total[] / seq[] were advanced for launches that may never have run.  Drain every
+// line, then bring device counters, host totals and completion words back to a common zero.
+void quiesce_after_error(svo_pipeline_group* g) {
+  for (int i = 0; i < svo_pipeline_group::MAX_LINES; ++i) {
+    if (g->st_lk[i]) (void)hipStreamSynchronize(g->st_lk[i]);
+    if (g->st_chain[i]) (void)hipStreamSynchronize(g->st_chain[i]);
+    if (g->st_ba[i]) (void)hipStreamSynchronize(g->st_ba[i]);
+  }
+  for (Lane* l : g->lanes) {
+    (void)hipMemset(l->d_arrive, 0, sizeof(unsigned) * 16 * C_COUNT);
+    for (int c = 0; c < C_COUNT; ++c) l->arrive_total[c] = 0;
+    for (int w = 0; w < W_COUNT; ++w) { l->seq[w] = 0; l->words[16 * w] = 0; }
+    l->queued = false;
+  }
+}
+
 }  // namespace
 
 extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
@@ -289,6 +306,17 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
                        p->max_features <= ctx->lim.max_features, "pipeline_group_create: feature counts outside the context limits");
   SVO_REQUIRE(ctx, p->window_size >= 1 && p->window_size <= 63, "pipeline_group_create: window size must be 1..63");
   SVO_REQUIRE(ctx, ctx->lim.max_batch >= n_lanes, "pipeline_group_create: svo_limits.max_batch must hold lanes x frames per call");
+  {
+    // A group drives 1 + chain + solve lines (HIP streams); the runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues
+    // (default 4, read when the runtime initialises).  With fewer queues than lines a 1 ms solve launch shares a queue with
+    // tracking launches and serialises them: measured 9.9 k against 16+ k frames/s for 48 lanes.
+    static std::atomic<bool> warned{false};
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    const int nq = q && *q ? atoi(q) : 4;
+    if (n_lanes > 4 && nq < 8 && !warned.exchange(true))
+      fprintf(stderr, "[svo] pipeline group of %d lanes with GPU_MAX_HW_QUEUES=%d: its launches will share hardware queues and serialise; "
+                      "export GPU_MAX_HW_QUEUES=16 before the first HIP call (INTEGRATION.md)\n", n_lanes, nq);
+  }
   svo_pipeline_group* g = new svo_pipeline_group();
   g->ctx = ctx; g->prm = *p; g->n_lanes = n_lanes;
   g->max_batch = ctx->lim.max_batch / n_lanes;
@@ -365,12 +393,8 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     if (!rc) rc = dev_alloc(g, &l->d_nin, 16);
     if (!rc) rc = dev_alloc(g, &l->d_inl, mf);
     if (!rc) rc = dev_alloc(g, &l->d_trk_xy, 2 * mf);
-    if (!rc) rc = dev_alloc(g, &l->d_flags, mc);
-    if (!rc) rc = dev_alloc(g, &l->d_new_xy, 2 * mc);
-    if (!rc) rc = dev_alloc(g, &l->d_cnt, 16);
     if (!rc) rc = dev_alloc(g, &l->d_disp, mc);
-    if (!rc) rc = dev_alloc(g, &l->d_kept_xy, 2 * mc);
-    if (!rc) rc = dev_alloc(g, &l->d_kept_xyz, 3 * mc);
+    if (!rc) rc = dev_alloc(g, &l->d_own_pyr, g->pyr_stride);
     if (!rc) rc = dev_alloc(g, &l->d_arrive, 16 * C_COUNT);
     if (!rc) chk(hipMemset(l->d_arrive, 0, sizeof(unsigned) * 16 * C_COUNT), "hipMemset");
     if (rc) break;
@@ -419,8 +443,10 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
 extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
   if (!g) return SVO_ERR_INVALID;
   (void)hipSetDevice(g->ctx->device);
+  int rc_join = SVO_OK;
   for (Lane* l : g->lanes) {
-    (void)finish_solve(g, l);
+    const int rcf = finish_solve(g, l);
+    if (rcf && !rc_join) rc_join = rcf;
     svo_ba_reset(l->ba);
     l->has_keyframe = false; l->n = l->n_initial = 0; l->from_host = false; l->last_pyr = nullptr; l->last_l0 = nullptr; l->cur = 0;
     l->rvec[0] = l->rvec[1] = l->rvec[2] = l->tvec[0] = l->tvec[1] = l->tvec[2] = 0.f;
@@ -428,6 +454,7 @@ extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
     const double id7[7] = {1, 0, 0, 0, 0, 0, 0};
     memcpy(l->solved_pose, id7, sizeof(id7));
   }
+  if (rc_join) { quiesce_after_error(g); return rc_join; }  // a solve that was in flight did not come back cleanly
   return SVO_OK;
 }
 
@@ -469,6 +496,20 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   g->pyr_cur ^= 1;  // the previous batch's pyramids stay valid: a lane's last tracked image lives there (src/feature_tracker.cpp:66)
   uint8_t* pyr = g->d_pyr[g->pyr_cur];
   int rc = SVO_OK;
+  // ... but a lane that neither tracked nor made a keyframe during the WHOLE previous batch (every frame below MIN_DETECTED
+  // corners, C-7; with batch = 1 one blank frame is enough) still holds its last image in the buffer that is rebuilt now:
+  // the reference keeps a clone of it (src/feature_tracker.cpp:14,66), so the lane takes a private copy first (same stream
+  // as the rebuild: ordered in front of it).
+  {
+    const uint8_t* lo = pyr;
+    const uint8_t* hi = pyr + g->pyr_stride * (size_t)g->n_lanes * (size_t)g->max_batch;
+    for (Lane* l : g->lanes) {
+      if (!l->last_pyr || l->last_pyr < lo || l->last_pyr >= hi) continue;
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(l->d_own_pyr, l->last_pyr, g->pyr_stride, hipMemcpyDeviceToDevice, ctx->stream));
+      l->last_pyr = l->d_own_pyr;  // level 0 was cloned into the pyramid at the end of the batch that produced it
+      l->last_l0 = l->d_own_pyr;
+    }
+  }
   if (lane_stride == istride * (size_t)batch) {
     rc = svo_corner_detect_batch_dev(ctx, left, S * batch, W, H, W, istride, mc, g->prm.quality, (double)g->prm.min_feature_distance, g->d_corners, g->d_ncorners);
     // level 0 of the pyramids is NOT copied: the tracker reads the caller's images in place (Pyr::l0) — except every lane's
@@ -919,21 +960,10 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         assembling += bs == BA_ASSEMBLING;
         if (bs == BA_READY) q_ba.push_back(li);
       }
-      int ba_launches_inflight = 0;
       bool ba_line_busy[svo_pipeline_group::MAX_LINES] = {};
-      {
-        int ids[svo_pipeline_group::MAX_LINES];
-        for (int& v : ids) v = -1;
-        for (int li = 0; li < S; ++li) {
-          const Lane* l = g->lanes[li];
-          if (l->ba_state.load(std::memory_order_acquire) != BA_INFLIGHT || svo_ba_solve_poll(l->ba)) continue;
-          ba_line_busy[l->ba_line] = true;
-          bool seen = false;
-          for (int v : ids) seen |= v == l->ba_launch;
-          if (seen) continue;
-          if (ba_launches_inflight < svo_pipeline_group::MAX_LINES) ids[ba_launches_inflight] = l->ba_launch;
-          ++ba_launches_inflight;
-        }
+      for (int li = 0; li < S; ++li) {
+        const Lane* l = g->lanes[li];
+        if (l->ba_state.load(std::memory_order_acquire) == BA_INFLIGHT && !svo_ba_solve_poll(l->ba)) ba_line_busy[l->ba_line] = true;
       }
       int free_line = -1;
       for (int i = 0; i < g->n_ba; ++i) if (!ba_line_busy[i]) { free_line = i; break; }
@@ -1027,9 +1057,6 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     for (int li = 0; li < S && !error; ++li) {
       Lane* l = g->lanes[li];
       if (!l->last_pyr || l->last_l0 == l->last_pyr || !l->last_l0) continue;
-#ifdef SVO_EXP_NO_L0_CLONE  // test-the-test build only
-      continue;
-#endif
       if (svo_k_pyramid_level0(ctx, l->last_l0, 1, W, H, W, istride, const_cast<uint8_t*>(l->last_pyr), g->pyr_stride, st)) { error = SVO_ERR_HIP; break; }
       l->last_l0 = l->last_pyr;
       copied = true;
@@ -1040,7 +1067,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     for (const Ev& e : evs) fprintf(stderr, "[svo group] %10.1f lane %2d %-22s %d\n", e.us, e.lane, e.what, e.arg);
     fprintf(stderr, "[svo group] %10.1f end\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   }
-  if (error) return error;
+  if (error) { quiesce_after_error(g); return error; }
   if (!ctx->err.empty()) return SVO_ERR_HIP;
   return SVO_OK;
 }

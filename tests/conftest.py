@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the HIP runtime reads this when it initialises: the GPU tests run with the hardware-queue count bench.py measures with
+# (two pipeline groups = 2 x 7 HIP streams; with the default 4 their launches share queues — slower, same results)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 # torch bundles its own libamdhip64; load it BEFORE libsvo_hip.so so that the process holds exactly one HIP
 # runtime (same soname => the loader reuses the first one).  Tests that hand torch tensors / RCCL buffers to
 # the library need that; the library itself does not depend on torch.

@@ -136,3 +136,123 @@ def test_hip_group_tracks_across_batches_from_a_frame_that_was_not_the_batch_s_l
     assert got[1][4].n_detected < 4 and got[1][6].n_tracked > 0  # the blank frames were skipped, tracking went on from frame 3
     g.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 3])
+def test_hip_group_keeps_its_last_image_through_a_whole_blank_batch(batch):
+    """A lane that neither tracks nor makes a keyframe during a WHOLE batch (every frame of it blank: fewer than 4 corners, C-7;
+    with batch = 1 one blank frame is enough) still tracks its next frame from the image it tracked last: the reference holds a
+    clone (src/feature_tracker.cpp:14,66).  The group's batch pyramids are double-buffered, so without a private copy that
+    image would be overwritten by the batch after the blank one."""
+    import torch
+    import stereo_vo_amd as S
+    n, lanes = 12, 3
+    seqs = [_seq(n, seed=0x5EED0500 + 13 * i) for i in range(lanes)]
+    p0 = seqs[0][0]
+    Ls = np.stack([s[1] for s in seqs]).copy()
+    Rs = np.stack([s[2] for s in seqs]).copy()
+    b0_blank = 2 * batch  # the third batch of lane 1 is blank from its first to its last frame
+    Ls[1, b0_blank:b0_blank + batch] = 77; Rs[1, b0_blank:b0_blank + batch] = 77
+    Ls[2, 5:5 + 2 * batch] = 140; Rs[2, 5:5 + 2 * batch] = 140  # lane 2: blank over (at least) two consecutive batches
+    ctx = S.Context(p0.width, p0.height, max_batch=lanes * batch, max_corners=300, max_candidates=1 << 16, max_features=400)
+    g = _group(S, ctx, p0, 300, 12.0, 400, lanes)
+    buf_l = torch.empty((lanes, batch, p0.height, p0.width), dtype=torch.uint8, device="cuda")
+    buf_r = torch.empty_like(buf_l)
+    got = [[] for _ in range(lanes)]
+    for b0 in range(0, n - n % batch, batch):
+        buf_l.copy_(torch.from_numpy(Ls[:, b0:b0 + batch]))
+        buf_r.copy_(torch.from_numpy(Rs[:, b0:b0 + batch]))
+        torch.cuda.synchronize()
+        res = g.process_batch_dev(buf_l.data_ptr(), buf_r.data_ptr(), batch * p0.width * p0.height, batch)
+        torch.cuda.synchronize()
+        for l in range(lanes):
+            got[l] += res[l]
+    m = len(got[0])
+    for l in range(lanes):
+        o = _ora_pipe(seqs[l][0], min_feature_distance=12.0, max_corners=300, max_features=400)
+        ref = [o.process(Ls[l, k], Rs[l, k]) for k in range(m)]
+        for k in range(m):
+            assert KEY(got[l][k]) == KEY(ref[k]), (l, k, KEY(got[l][k]), KEY(ref[k]))
+    assert got[1][b0_blank].n_detected < 4 and any(r.n_tracked > 0 for r in got[1][b0_blank + batch:])
+    g.close()
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_headline_load_24_lanes_full_size_two_groups_concurrently():
+    """The configuration the bench's headline is quoted on, under its own load: a 24-lane group at 1241x376 / 1,500 corners /
+    5-keyframe window / 16 frames, 5 repetitions from a reset group in one process WHILE a second group runs the same load on
+    another thread (two groups = the bench's default shape: 48 lanes, the device-resident solves of both sharing the GPU).
+    Every lane of the checked group must equal its oracle bit for bit in every repetition; the second group must reproduce
+    itself.  (The cross-workgroup hand-overs of the solve kernel are exercised here at the load they are used at.)"""
+    import threading
+    import torch
+    import stereo_vo_amd as S
+    W, H, lanes, n, reps = 1241, 376, 24, 16, 5
+    maxc, md, mf = 1500, 10.0, 2000
+    p = S.synth_default(W, H)
+    seeds = [0x5EED0001 + i for i in range(2 * lanes)]  # the bench's seeds
+
+    def render(seed):
+        q = S.synth_default(W, H)
+        q.seed = seed
+        fr = [S.synth_render(q, i) for i in range(n)]
+        return q, np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        data = list(ex.map(render, seeds))
+    groups = []
+    for gi in range(2):
+        ctx = S.Context(W, H, max_batch=lanes * n, max_corners=maxc, max_candidates=1 << 16, max_features=mf)
+        pp = S.pipeline_default_params()
+        pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+        pp.width, pp.height = W, H
+        pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = maxc, 0.02, md, mf, 5
+        pp.ba_max_time_s = 0.0
+        g = S.PipelineGroup(ctx, pp, lanes)
+        mine = data[gi::2]  # dealt round-robin as bench.py does
+        L = torch.from_numpy(np.stack([d[1] for d in mine])).cuda()
+        R = torch.from_numpy(np.stack([d[2] for d in mine])).cuda()
+        groups.append(dict(ctx=ctx, g=g, L=L, R=R, data=mine, out=[], err=None))
+    torch.cuda.synchronize()
+
+    def work(G):
+        try:
+            for _ in range(reps):
+                G["g"].reset()
+                G["out"].append(G["g"].process_batch_dev(G["L"].data_ptr(), G["R"].data_ptr(), n * W * H, n))
+        except Exception as e:  # noqa: BLE001
+            G["err"] = e
+
+    th = [threading.Thread(target=work, args=(G,)) for G in groups]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    torch.cuda.synchronize()
+    for G in groups:
+        assert G["err"] is None, G["err"]
+        assert len(G["out"]) == reps
+    # group 0: every lane against its oracle, every repetition
+    G = groups[0]
+
+    def oracle_lane(d):
+        q, Lh, Rh = d
+        o = O.Pipeline(focal=q.focal, cx=q.cx, cy=q.cy, baseline=q.baseline, width=W, height=H, max_corners=maxc, quality=0.02,
+                       min_feature_distance=md, parallax_thresh=20.0, window_size=5, max_features=mf, ba_max_iterations=50, num_threads=2)
+        return [KEY(o.process(Lh[k], Rh[k])) for k in range(n)]
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        refs = list(ex.map(oracle_lane, G["data"]))
+    for rep in range(reps):
+        for l in range(lanes):
+            got = [KEY(r) for r in G["out"][rep][l]]
+            assert got == refs[l], (rep, l, [k for k in range(n) if got[k] != refs[l][k]][:3])
+    # group 1: identical frames every repetition => identical bits
+    G1 = groups[1]
+    for rep in range(1, reps):
+        for l in range(lanes):
+            assert [KEY(r) for r in G1["out"][rep][l]] == [KEY(r) for r in G1["out"][0][l]], (rep, l)
+    for G in groups:
+        G["g"].close()
+        G["ctx"].close()

@@ -198,7 +198,11 @@ def run(args, cpu_seconds=12.0):
                       "doubles_per_exchange": {"payload2": 8, "payload1": n * n + 3 * n + 2},
                       "lm_stats": {"stand_alone_pass_A": st.linearize_calls, "steps": st.step_calls,
                                    "next_linearisation_with_the_step": st.speculations, "usable": st.speculation_hits,
-                                   "payloads_in_one_collective": st.single_exchange}}}
+                                   "payloads_in_one_collective": st.single_exchange},
+                      # all-reduces the LM loop issued (or would issue on N ranks): a stand-alone pass A = 1, a same-sweep step = 1
+                      # (both payloads in one buffer), a chained step = 2 (payload2, decision, payload1), a plain step = 1
+                      "collectives_per_iteration": (st.linearize_calls + st.single_exchange + 2 * (st.speculations - st.single_exchange) +
+                                                    (st.step_calls - st.speculations)) / n_it}}
     if k_n:
         # roofline of the dominant kernel.  achieved = SURVEY 8d algorithmic f64 flops of one linearisation / launch time,
         # HIP events on the adjuster's stream.  peak = the f64 MFMA rate MEASURED on this card (svo_measure_peak).
