@@ -12,13 +12,30 @@
 // (Round 1 also took the candidate step when the function tolerance fired; Ceres' FunctionToleranceReached()
 // returns before the step is accepted, and so does this restatement now.)
 //
-// Declared summation order (what makes the HIP solver bit-identical to this one, and this one independent
-// of its thread count): every sum over observations of ONE landmark runs sequentially in observation
-// order; every sum ACROSS landmarks / observations / pose pairs is R(list) = "28 consecutive
-// segments of ceil(len/28) entries, each summed sequentially, then the 28 segment sums added
-// sequentially" over the contribution list in landmark order.  Per pose pair the 6x6 Schur contribution of
-// observations i <= t of a landmark is B = -(Y_i (W_t s)^T) (+ J_c^T J_c when i == t); it enters block
-// (k_i,k_t) as B and, when i != t, block (k_t,k_i) as B^T.
+// Declared summation order (what makes the HIP solver bit-identical to this one, and this one independent of its
+// thread count).  Ceres' own order is unspecified (4 threads, src/bundle_adjuster.cpp:12): this restatement DEFINES one,
+// chosen (round 4) so that it is cheap on the GPU — sums stay inside a wavefront's registers / LDS as long as possible:
+//   observations are landmark-major; CHUNKS are formed greedily from whole landmarks, a chunk closes when the next
+//     landmark would take it beyond 64 observations (landmarks without observations are skipped);
+//   level 0  every sum over the observations of ONE landmark runs sequentially in observation order (V, g_p, the
+//            landmark's cost); a chunk's partial P_c[e] of payload element e is the sequential sum, from +0.0, of the
+//            chunk's contributions to e in (landmark, observation i, observation t) order;
+//   level 1  GROUPS of G consecutive chunks, G = 1 for C <= 128 chunks, else ceil(C / 128): Q_g[e] = P_c0[e] + P_c1[e] + ...
+//            sequentially in chunk order (starting FROM the first partial);
+//   level 2  total[e] = Q_0[e] + Q_1[e] + ... sequentially in group order (starting from Q_0[e]).
+// Elements e ("wire format", E = 36 F(F+1)/2 + 33 F + 2 with F = K - 1 free poses):
+//   Schur part of every UPPER pose-pair block (ka <= kb), 36 each: pair (i, t >= i) of a landmark contributes
+//     B = -(Y_i (W_t s)^T) to block (k_i, k_t) when k_i <= k_t, and B^T to block (k_t, k_i) when t != i and k_t <= k_i
+//     (two observations of one landmark in one pose: both, the direct entry first);
+//   per free pose 33: g_c (6) | the -Y g_p part of the reduced gradient (6) | the upper triangle of U = J_c^T J_c (21),
+//     one contribution per observation of that pose;
+//   cost | sum g_p^2, one contribution per landmark.
+// Assembly (after the totals): S[(k,a),(k,b)] = U_k[min(a,b)][max(a,b)] + Schur_(k,k)[a][b]; S[(ka,a),(kb,b)] =
+// Schur_(ka,kb)[a][b] for ka < kb and its exact transpose below the diagonal blocks; diag U[6k+a] = U_k[a][a].
+// payload2 (pass B's four scalars per landmark) goes through the same three levels.
+// (Rounds 1-3 declared "28 strided segments over destination-ordered per-pair 6x6 slots": every pair block had to be
+// written through to memory and read back.  ora_ba_set_order(1) still selects that order — only for the comparison
+// tests/test_ba.py::test_declared_orders_agree and profiles/r04_order_comparison.txt.)
 //
 // Sharded form: a rank holds all poses and a subset of landmarks.  Per LM iteration it sums
 //   payload1 = [ U - sum_j W_j Vd_j^-1 W_j^T  (n x n) | g_c - sum_j W_j Vd_j^-1 g_pj (n) | g_c (n) |
@@ -172,7 +189,14 @@ void reduce_list(int count, int width, Get get, double* out) {
 // Stateful form: one object holds the problem, the current point (poses, points), the candidate and the Jacobi scales.
 // ora_ba_solve below drives it with the plain (non-speculative) LM loop; tests also drive it through the PRODUCT's
 // step control (svo_lm_solve in libsvo_hip.so) to check that host logic without a GPU.
+static int g_order = 2;  // 2: chunk order (declared above); 1: rounds 1-3's 28-segment order (comparison only)
+extern "C" void ora_ba_set_order(int order) { g_order = order == 1 ? 1 : 2; }
+
 struct ora_ba_state {
+  int order = 2;
+  // chunk order: landmarks (indices into P.lm_start) of every chunk, groups of chunks, wire-format sizes
+  std::vector<int> chunk_lm;   // chunk c = landmarks [chunk_lm[c], chunk_lm[c + 1])
+  int C = 0, G = 1, NG = 0, nU = 0, E = 0;
   Problem P;
   std::vector<double> poses, points;            // current point (owned copies)
   std::vector<double> cand_poses, cand_points;  // candidate
@@ -202,7 +226,25 @@ extern "C" ora_ba_state* ora_ba_open(int n_poses, const double* poses7, int n_po
   S->num_threads = num_threads < 1 ? 1 : num_threads;
   const int L = S->L, F = S->F, n = P.n;
   S->pay1 = (size_t)n * n + 3 * (size_t)n + 2;
-  // contribution slots and destination lists (landmark order)
+  S->order = g_order;
+  {
+    // chunks: whole landmarks, greedily, at most 64 observations each
+    S->chunk_lm.push_back(0);
+    int cur = 0;
+    for (int l = 0; l < L; ++l) {
+      const int len = P.lm_start[l + 1] - P.lm_start[l];
+      if (cur + len > 64) { S->chunk_lm.push_back(l); cur = 0; }
+      cur += len;
+    }
+    if (L > 0) S->chunk_lm.push_back(L);
+    S->C = (int)S->chunk_lm.size() - 1;
+    S->G = S->C <= 128 ? 1 : (S->C + 127) / 128;
+    S->NG = S->C > 0 ? (S->C + S->G - 1) / S->G : 0;
+    S->nU = F * (F + 1) / 2;
+    S->E = 36 * S->nU + 33 * F + 2;
+  }
+  if (S->order == 2) return S;
+  // ---- order 1 only: contribution slots and destination lists (landmark order)
   S->pair_base.assign((size_t)n_obs + 1, 0);
   for (int l = 0; l < L; ++l)
     for (int o = P.lm_start[l]; o < P.lm_start[l + 1]; ++o) S->pair_base[o + 1] = S->pair_base[o] + (P.lm_start[l + 1] - o);
@@ -236,9 +278,212 @@ extern "C" void ora_ba_read(const ora_ba_state* S, double* poses7, double* point
   if (points3) std::memcpy(points3, S->points.data(), sizeof(double) * S->points.size());
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Chunk order (the declared order, see the head of this file).
+namespace {
+inline int upper_index(int ka, int kb, int F) { return ka * F - ka * (ka - 1) / 2 + (kb - ka); }
+
+// levels 1 and 2 over per-chunk partials part[c * width + e] -> out[e]
+void sum_partials(const ora_ba_state* S, const std::vector<double>& part, int width, double* out) {
+  const int C = S->C, G = S->G, NG = S->NG;
+  for (int e = 0; e < width; ++e) {
+    double tot = 0.0;
+    for (int g = 0; g < NG; ++g) {
+      const int c0 = g * G, c1 = std::min(C, c0 + G);
+      double q = part[(size_t)c0 * width + e];                                   // level 1 starts FROM the first partial
+      for (int c = c0 + 1; c < c1; ++c) q += part[(size_t)c * width + e];
+      tot = g == 0 ? q : tot + q;                                                // level 2 starts from Q_0
+    }
+    out[e] = tot;
+  }
+}
+
+// pass A in chunk order: the wire-format totals, then the assembled payload1 [S | g_red | g_c | diag U | cost | sum g_p^2]
+void linearize_v2(ora_ba_state* S, int at_candidate, double rad, int first, double* pay) {
+  const Problem& P = S->P;
+  const double* poses = at_candidate ? S->cand_poses.data() : S->poses.data();
+  const double* points = at_candidate ? S->cand_points.data() : S->points.data();
+  const int F = S->F, n = P.n, nU = S->nU, E = S->E, C = S->C;
+  const double min_diag = 1e-6, max_diag = 1e32;
+  std::vector<double>& sp = S->sp;
+  if (sp.size() < (size_t)S->L * 3) sp.assign((size_t)S->L * 3, 0.0);
+  std::vector<double> part((size_t)C * E, 0.0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(S->num_threads)
+  for (int c = 0; c < C; ++c) {
+    double* Pc = &part[(size_t)c * E];  // level 0: every element starts at +0.0, contributions in (landmark, i, t) order
+    double* Pv = Pc + 36 * (size_t)nU;  // per pose 33
+    double* Ps = Pv + 33 * (size_t)F;   // cost, sum g_p^2
+    for (int l = S->chunk_lm[c]; l < S->chunk_lm[c + 1]; ++l) {
+      const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1], len = o1 - o0;
+      std::vector<double> R((size_t)len * 2), JC((size_t)len * 12, 0.0), JP((size_t)len * 6), WS((size_t)len * 18), YY((size_t)len * 18);
+      double V[9] = {0}, gp[3] = {0}, cost_l = 0.0;
+      for (int o = o0; o < o1; ++o) {
+        double* r = &R[2 * (o - o0)];
+        double* Jc = &JC[12 * (o - o0)];
+        double* Jp = &JP[6 * (o - o0)];
+        eval_obs(P, poses, points, o, r, P.op[o] > 0 ? Jc : nullptr, Jp);
+        cost_l += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+        for (int a = 0; a < 3; ++a) {
+          gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+          for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+        }
+      }
+      double* s = &sp[(size_t)l * 3];
+      if (first) for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + std::sqrt(V[4 * a]));
+      double Vd[9], gps[3], Vi[9] = {0};
+      for (int a = 0; a < 3; ++a) {
+        gps[a] = gp[a] * s[a];
+        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+      }
+      for (int a = 0; a < 3; ++a) Vd[4 * a] += std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad;
+      inv3_sym(Vd, Vi);
+      Ps[0] += cost_l;
+      Ps[1] += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+      for (int o = o0; o < o1; ++o) {
+        if (P.op[o] <= 0) continue;
+        const double* r = &R[2 * (o - o0)];
+        const double* Jc = &JC[12 * (o - o0)];
+        const double* Jp = &JP[6 * (o - o0)];
+        double* Ws = &WS[18 * (o - o0)];
+        double* Y = &YY[18 * (o - o0)];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 3; ++b) Ws[3 * a + b] = (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b];
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
+        double* pv = Pv + 33 * (size_t)(P.op[o] - 1);
+        for (int a = 0; a < 6; ++a) {
+          pv[a] += Jc[a] * r[0] + Jc[6 + a] * r[1];
+          pv[6 + a] += -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+        }
+        int u = 12;
+        for (int a = 0; a < 6; ++a)
+          for (int b = a; b < 6; ++b) pv[u++] += Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
+      }
+      for (int i = o0; i < o1; ++i) {
+        if (P.op[i] <= 0) continue;
+        const int ki = P.op[i] - 1;
+        const double* Y = &YY[18 * (i - o0)];
+        for (int t = i; t < o1; ++t) {
+          if (P.op[t] <= 0) continue;
+          const int kt = P.op[t] - 1;
+          const double* Wt = &WS[18 * (t - o0)];
+          double B[36];
+          for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) B[6 * a + b] = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
+          if (ki <= kt) {
+            double* d = Pc + 36 * (size_t)upper_index(ki, kt, F);
+            for (int e = 0; e < 36; ++e) d[e] += B[e];
+          }
+          if (t != i && kt <= ki) {
+            double* d = Pc + 36 * (size_t)upper_index(kt, ki, F);
+            for (int a = 0; a < 6; ++a)
+              for (int b = 0; b < 6; ++b) d[6 * b + a] += B[6 * a + b];
+          }
+        }
+      }
+    }
+  }
+  if (first) S->have_scale = true;
+  std::vector<double> tot(E > 0 ? E : 1, 0.0);
+  if (C > 0) sum_partials(S, part, E, tot.data());
+  // assembly
+  std::fill(pay, pay + S->pay1, 0.0);
+  double* Sx = pay;
+  double* gred = Sx + (size_t)n * n;
+  double* gc = gred + n;
+  double* dU = gc + n;
+  for (int ka = 0; ka < F; ++ka)
+    for (int kb = ka; kb < F; ++kb) {
+      const double* blk = &tot[36 * (size_t)upper_index(ka, kb, F)];
+      const double* U = &tot[36 * (size_t)nU + 33 * (size_t)ka + 12];
+      for (int a = 0; a < 6; ++a)
+        for (int b = 0; b < 6; ++b) {
+          double v = blk[6 * a + b];
+          if (ka == kb) {
+            const int lo = std::min(a, b), hi = std::max(a, b);
+            v = U[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)] + v;
+          }
+          Sx[(size_t)(6 * ka + a) * n + 6 * kb + b] = v;
+          if (ka != kb) Sx[(size_t)(6 * kb + b) * n + 6 * ka + a] = v;
+        }
+    }
+  for (int k = 0; k < F; ++k) {
+    const double* pv = &tot[36 * (size_t)nU + 33 * (size_t)k];
+    for (int a = 0; a < 6; ++a) {
+      gc[6 * k + a] = pv[a];
+      gred[6 * k + a] = pv[6 + a];
+      dU[6 * k + a] = pv[12 + a * 6 - a * (a - 1) / 2];
+    }
+  }
+  pay[S->pay1 - 2] = tot[E - 2];
+  pay[S->pay1 - 1] = tot[E - 1];
+}
+
+void backsub_v2(ora_ba_state* S, const double* dc, const double* cand_poses7, double rad, double* pay2) {
+  const Problem& P = S->P;
+  const int C = S->C;
+  const double min_diag = 1e-6, max_diag = 1e32;
+  std::memcpy(S->cand_poses.data(), cand_poses7, sizeof(double) * S->cand_poses.size());
+  S->cand_points = S->points;
+  std::vector<double>&sp = S->sp, &cand_points = S->cand_points;
+  std::vector<double> part((size_t)C * 4, 0.0);
+#pragma omp parallel for schedule(dynamic, 1) num_threads(S->num_threads)
+  for (int c = 0; c < C; ++c) {
+    double* Pc = &part[(size_t)c * 4];
+    for (int l = S->chunk_lm[c]; l < S->chunk_lm[c + 1]; ++l) {
+      const int o0 = P.lm_start[l], o1 = P.lm_start[l + 1];
+      double V[9] = {0}, gp[3] = {0}, wd[3] = {0};
+      for (int o = o0; o < o1; ++o) {
+        double r[2], Jc[12], Jp[6];
+        const int k = P.op[o];
+        eval_obs(P, S->poses.data(), S->points.data(), o, r, k > 0 ? Jc : nullptr, Jp);
+        double jd[2] = {0, 0};
+        if (k > 0)
+          for (int a = 0; a < 6; ++a) { jd[0] += Jc[a] * dc[6 * (k - 1) + a]; jd[1] += Jc[6 + a] * dc[6 * (k - 1) + a]; }
+        for (int a = 0; a < 3; ++a) {
+          gp[a] += Jp[a] * r[0] + Jp[3 + a] * r[1];
+          wd[a] += Jp[a] * jd[0] + Jp[3 + a] * jd[1];
+          for (int b = 0; b < 3; ++b) V[3 * a + b] += Jp[a] * Jp[b] + Jp[3 + a] * Jp[3 + b];
+        }
+      }
+      const double* s = &sp[(size_t)l * 3];
+      double Vd[9], De[3], rh[3], Vi[9] = {0};
+      for (int a = 0; a < 3; ++a) {
+        rh[a] = -(gp[a] + wd[a]) * s[a];
+        for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+      }
+      for (int a = 0; a < 3; ++a) { De[a] = std::min(std::max(Vd[4 * a], min_diag), max_diag) / rad; Vd[4 * a] += De[a]; }
+      inv3_sym(Vd, Vi);
+      const double* p0 = &S->points[3 * (size_t)P.lm_id[l]];
+      double* pt = &cand_points[3 * (size_t)P.lm_id[l]];
+      double mc = 0, dp2 = 0, p2 = 0;
+      for (int a = 0; a < 3; ++a) {
+        const double y = Vi[3 * a] * rh[0] + Vi[3 * a + 1] * rh[1] + Vi[3 * a + 2] * rh[2];
+        mc += 0.5 * y * (De[a] * y - gp[a] * s[a]);
+        const double d = y * s[a];
+        dp2 += d * d;
+        p2 += p0[a] * p0[a];
+        pt[a] = p0[a] + d;
+      }
+      double cn = 0;
+      for (int o = o0; o < o1; ++o) {
+        double r[2];
+        eval_obs(P, S->cand_poses.data(), cand_points.data(), o, r, nullptr, nullptr);
+        cn += 0.5 * (r[0] * r[0] + r[1] * r[1]);
+      }
+      Pc[0] += cn; Pc[1] += mc; Pc[2] += dp2; Pc[3] += p2;
+    }
+  }
+  pay2[0] = pay2[1] = pay2[2] = pay2[3] = 0.0;
+  if (C > 0) sum_partials(S, part, 4, pay2);
+}
+}  // namespace
+
 // pass A: linearise at the current point (at_candidate = 0) or at the candidate (1), fill the slots, reduce into
 // this rank's payload1 for `rad`.  `first` fixes the Jacobi scales of the landmarks from this Jacobian.
 extern "C" void ora_ba_linearize(ora_ba_state* S, int at_candidate, double rad, int first, double* pay) {
+  if (S->order == 2) { linearize_v2(S, at_candidate, rad, first, pay); return; }
   const Problem& P = S->P;
   const double* poses = at_candidate ? S->cand_poses.data() : S->poses.data();
   const double* points = at_candidate ? S->cand_points.data() : S->points.data();
@@ -344,6 +589,7 @@ extern "C" void ora_ba_linearize(ora_ba_state* S, int at_candidate, double rad, 
 // pass B: back-substitute at the current point with the pose step dc (unscaled tangent) and the candidate poses the
 // caller formed from it; builds the candidate landmarks and this rank's payload2.
 extern "C" void ora_ba_backsub(ora_ba_state* S, const double* dc, const double* cand_poses7, double rad, double* pay2) {
+  if (S->order == 2) { backsub_v2(S, dc, cand_poses7, rad, pay2); return; }
   const Problem& P = S->P;
   const int L = S->L, num_threads = S->num_threads;
   const double min_diag = 1e-6, max_diag = 1e32;

@@ -14,25 +14,25 @@
 //           -> payload2 = [cost_new | model-change(points) | sum dp^2 | sum p^2].
 // One exchange per LM iteration (host/lm.cpp): pass B of iteration i and pass A of iteration i+1 (at the candidate,
 // with the radius an accepted step produces) run back to back and their payloads leave together:
-//   deterministic mode (window-sized problems, everything the pipeline solves): the passes write per-pair 6x6 blocks,
-//     per-observation vectors and per-landmark scalars to DESTINATION-ORDERED contribution slots, and every destination is
-//     summed in the DECLARED order "28 consecutive segments of ceil(len/28) entries summed sequentially, then the 28
-//     segment sums added sequentially" (lane = (segment, element)); [payload2 | decision | payload1] goes straight into
-//     pinned host memory behind a completion word the host polls: 1 host round trip, no copy kernel, no stream wait per
-//     LM iteration.  Three forms of the same arithmetic, chosen per solve:
-//       alone on the GPU      3 launches  ba_step_kernel -> ba_decide_linearize_kernel -> ba_reduce_kernel
-//       default, kernel admitted
-//                             1 launch per SOLVE  ba_lm_kernel: the step control (host/lm.cpp's arithmetic) runs on the
+//   deterministic mode (window-sized problems, everything the pipeline solves): every sum follows the DECLARED order of
+//     oracle/ora_ba.cpp (round 4: "chunk order") — landmark sums in observation order; per wave chunk of <= 64
+//     observations a partial of every payload element, its contributions added sequentially in (landmark, pair) order —
+//     formed INSIDE the wavefront (per-observation Y / W s rows staged in LDS, one owner lane per destination row walks the
+//     chunk's destination-ordered pair list); chunk partials added sequentially in chunk order (groups of G chunks first
+//     when a problem has more than 128).  What crosses workgroups is E = 36 F(F+1)/2 + 33 F + 2 doubles per chunk (the
+//     "wire format": Schur part of the upper pose-pair blocks | per pose g_c, -Y g_p, upper triangle of U | cost, sum g_p^2)
+//     instead of rounds 1-3's per-pair 6x6 slots (7 MB written through and read back per LM iteration of a window).
+//     [payload2 | decision | wire totals] goes straight into pinned host memory behind a completion word the host polls.
+//     Two forms of the same arithmetic, chosen per solve:
+//       host-driven           3 launches per LM iteration  ba_step_kernel -> ba_decide_linearize_kernel -> ba_reduce_kernel
+//       device-resident       1 launch per SOLVE  ba_lm_kernel: the step control (host/lm.cpp's arithmetic) runs on the
 //                                         device too, replicated in every workgroup; several solves (the lanes of a
-//                                         pipeline group) share one launch, blockIdx.y = solve
-//       not admitted / SVO_BA_DEVICE_LM=0, several stereo streams
-//                             1 launch per iteration  ba_iterate_kernel (workgroups meet at device-wide arrivals)
-//     No cache maintenance instruction (buffer_wbl2 / buffer_inv) inside any of them: payload and slots that cross
-//     workgroups are written through and read at the coherence point.  The oracle performs the same
-//     sums in the same order, so the whole LM trajectory — and therefore every later PnP inlier set — is bit-identical
-//     between CPU and GPU and independent of grid size.  (Needed because the reference's problem has a scale gauge:
-//     with one fixed pose and only reprojection factors the iterates slide along a flat direction and amplify any
-//     summation-order difference; measured 3e-2 pose drift otherwise.)
+//                                         pipeline group) share one launch, blockIdx.y = solve; workgroups hand over
+//                                         TAGGED granules only (no counters, no cache maintenance)
+//     The oracle performs the same sums in the same order, so the whole LM trajectory — and therefore every later PnP
+//     inlier set — is bit-identical between CPU and GPU and independent of grid size.  (Needed because the reference's
+//     problem has a scale gauge: with one fixed pose and only reprojection factors the iterates slide along a flat
+//     direction and amplify any summation-order difference; measured 3e-2 pose drift otherwise.)
 //   bulk modes (config 4; svo_ba_options.accumulation): hardware-order sums with a tolerance-level result.
 //     ba_backsub_kernel, then ba_linearize_mfma_kernel (each landmark's Schur contribution as a rank-3 update of S on
 //     the f64 matrix cores, <= 22 poses) or the LDS-atomic ba_linearize_kernel, both accumulating into ONE device
@@ -79,7 +79,6 @@ struct FusedAdmission {
   void release() { if (blocks) g_fused_blocks[device].fetch_sub(blocks, std::memory_order_acq_rel); blocks = 0; }
   ~FusedAdmission() { release(); }
 };
-constexpr int RSEG = 28;  // segments of the declared reduction order R(list)
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32;
 constexpr int PAY2_SLOTS = 8;  // payload2 (4 doubles) is padded to 8 so that payload1 starts 64-byte aligned behind it
 
@@ -97,18 +96,14 @@ struct BaDev {
   double* pay1 = nullptr;          // device payload1 (bulk kernels accumulate here with atomics)
   double* pay2 = nullptr;          // device payload2
   double f = 0, cx = 0, cy = 0;
-  // deterministic mode: contribution slots + destination lists
+  // deterministic mode (chunk order): per-chunk destination tables + the partial store
   int det = 0;
-  // Contributions are stored DESTINATION-ORDERED so the reduce kernel streams contiguous memory:
-  int32_t* pair_base = nullptr;   // per observation slot: first pair slot (pairs (o, t>=o) of its landmark)
-  int32_t* pair_pos = nullptr;    // per pair slot: [position in its block list, position in the mirrored list or -1]
-  int32_t* obs_pos = nullptr;     // per observation slot: position in its pose list or -1
-  double* pairB = nullptr;        // (sum of block-list lengths) x 36, block lists back to back
-  double* obsV = nullptr;         // (free observations) x 18  (g_c | g_red part | diag U), pose lists back to back
-  double* lmV = nullptr;          // Npts x 4, by landmark index: pass A's (cost, g_p^2) (zero for landmarks without observations)
-  double* lmV2 = nullptr;         // Npts x 4, by landmark index: pass B's (cost_new, model change, dp^2, p^2)
-  int32_t* list_start = nullptr;  // F*F + F + 1 entries (+1): offsets into pairB / obsV / lmV rows
-  double* pay1_out = nullptr;     // where the reduce kernel writes (pinned host memory when single-rank)
+  int G = 1, NG = 0, NGpad = 0, E = 0;   // chunks per group, groups, granules per element row, wire-format elements
+  const uint16_t* tab = nullptr;   // chunk tables back to back (u16 words), see ba_build_tables
+  const uint32_t* tab_off = nullptr;  // C + 1 offsets into tab
+  double* part1 = nullptr;         // granules {value, tag}: element e of group g at part1[2 * (e * NGpad + g)]
+  double* part2 = nullptr;         // granules: pass B's four sums of group g at part2[2 * ((parity * NG + g) * 4 + i)]
+  double* pay1_out = nullptr;      // where ba_reduce_kernel writes the wire totals (pinned host memory when single-rank)
   double* pay2_out = nullptr;
   const double* step_in = nullptr;  // [dc (max(n,1)) | candidate poses (7K)]: pinned host memory (read in place, no H2D blit) or device
   // completion flag in pinned host memory (single-rank deterministic mode): the reduce kernel publishes `seq` after its
@@ -118,8 +113,8 @@ struct BaDev {
   unsigned arrive_target = 0;
   int seq = 0;
   double* ctl_dev = nullptr;    // device [accept (0/1) | next radius]: the chained decision, read by the next pass A
-  int pay_dev = 0;              // the payload stays on the device for the other workgroups of THIS launch (ba_lm_kernel): tagged granules, see granule_store
-  unsigned long long pay_tag = 0;  // ... the tag of the command in flight (unique per solve and command)
+  unsigned long long pay_tag = 0;  // tag of the command in flight (unique per adjuster and command): every partial carries it, a reader takes a value only under the awaited tag
+  int pay_parity = 0;           // which half of part2 the command in flight uses
 };
 
 // Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
@@ -291,63 +286,12 @@ __device__ __forceinline__ ObsRec load_obs(const BaDev& P, int chunk, int lane, 
   return R;
 }
 
-// Pass A for one wave chunk at (poses_, R.p).  Deterministic mode: contributions go to the slots.  Otherwise into the
-// workgroup's LDS image of payload1 (ds_add_f64), lcost / lgp2 accumulate this lane's share of the two scalars.
-// One 6x6 Schur / U contribution into its slot(s): block (k, kt) row-major, and/or its transpose into the mirrored pair's slot.
-template <bool WT>
-__device__ __forceinline__ void store_pair_block(double* B, double* Bt, const double (&w)[36]) {
-  if (B) {
-#pragma unroll
-    for (int i = 0; i < 36; i += 2) slot_store2<WT>(B + i, w[i], w[i + 1]);
-  }
-  if (Bt) {
-#pragma unroll
-    for (int b = 0; b < 6; ++b)
-#pragma unroll
-      for (int a = 0; a < 6; a += 2) slot_store2<WT>(Bt + 6 * b + a, w[6 * a + b], w[6 * (a + 1) + b]);
-  }
-}
-
-// One 6x6 Schur / U contribution (block (k, kt) = -Y Wt^T, plus Jc^T Jc on a landmark's own pair), two rows at a time:
-// rows a, a + 1 give B's words [6a, 6a + 12) and the (a, a + 1) word pair of each of Bt's six rows — twelve values live
-// instead of thirty-six (the same stores with the same values as store_pair_block of the whole block).
-template <bool WT>
-__device__ __forceinline__ void emit_pair_block(double* B, double* Bt, const double (&Y)[18], const double (&Wt)[18], const double (&Jc)[12], bool own) {
-#pragma unroll
-  for (int a = 0; a < 6; a += 2) {
-    double w0[6], w1[6];
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const double v0 = -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]);
-      const double v1 = -(Y[3 * a + 3] * Wt[3 * b] + Y[3 * a + 4] * Wt[3 * b + 1] + Y[3 * a + 5] * Wt[3 * b + 2]);
-      w0[b] = own ? (Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]) + v0 : v0;
-      w1[b] = own ? (Jc[a + 1] * Jc[b] + Jc[6 + a + 1] * Jc[6 + b]) + v1 : v1;
-    }
-#ifdef SVO_EXP_NO_PAIR_STORES  // timing experiment only (results are garbage): the arithmetic without the slot stores
-    double acc = 0;
-#pragma unroll
-    for (int b = 0; b < 6; ++b) acc += w0[b] + w1[b];
-    if (acc == 1.2345e-300 && B) B[0] = acc;
-#else
-    if (B) {
-#pragma unroll
-      for (int b = 0; b < 6; b += 2) { slot_store2<WT>(B + 6 * a + b, w0[b], w0[b + 1]); slot_store2<WT>(B + 6 * (a + 1) + b, w1[b], w1[b + 1]); }
-    }
-    if (Bt) {
-#pragma unroll
-      for (int b = 0; b < 6; ++b) slot_store2<WT>(Bt + 6 * b + a, w0[b], w1[b]);
-    }
-#endif
-  }
-}
-
 // What pass A computes before the trust-region radius enters (residual, Jacobians, the landmark's sums in observation order):
 // inside ba_lm_kernel this part runs while the accept / radius decision of the step is still on its way.
 struct LinPre { double r[2], Jc[12], Jp[6], V[9], gp[3], cost_l; int maxlen; };
-// Per-lane constants of a solve that ba_lm_kernel keeps in registers from pass to pass instead of re-loading them (two to
-// three dependent global loads per pass otherwise): destination rows of the lane's Schur pairs, the landmark's Jacobi scales
-// (fixed by the first pass A), the lane's row in its pose list.
-struct ChunkRegs { const int2* pp; int pp_stride; double s[3]; int obs_pos; bool have_pp; };  // pp: LDS, entry d of this lane at pp[d * pp_stride]
+// Per-lane constants of a solve that ba_lm_kernel keeps in registers from pass to pass: the landmark's Jacobi scales
+// (fixed by the first pass A).
+struct ChunkRegs { double s[3]; };
 
 __device__ __forceinline__ void linearize_prefix(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, LinPre& q, double& lcost) {
   const bool active = R.active;
@@ -391,19 +335,156 @@ __device__ __forceinline__ void linearize_prefix(const BaDev& P, const ObsRec& R
   q.maxlen = maxlen;
 }
 
-template <bool WT = false>  // WT: the slots are consumed inside this launch (see slot_store2)
-__device__ __forceinline__ void linearize_suffix(const BaDev& P, const ObsRec& R, const LinPre& q, double radius, int first_pass, double* sS, double* sGred,
-                                                 double* sGc, double* sDU, double& lgp2, ChunkRegs* cache = nullptr) {
+// Pass A behind the prefix, bulk modes (hardware-order sums): into the workgroup's LDS image of payload1 (ds_add_f64),
+// lgp2 accumulates this lane's share of sum g_p^2.
+__device__ __forceinline__ void linearize_suffix_bulk(const BaDev& P, const ObsRec& R, const LinPre& q, double radius, int first_pass, double* sS, double* sGred,
+                                                      double* sGc, double* sDU, double& lgp2) {
   const int lane = threadIdx.x & 63, n = P.n;
   const bool active = R.active;
-  const int k = R.k, j = R.j, first = R.first, len = R.len, o = R.o;
+  const int k = R.k, j = R.j, first = R.first, len = R.len;
   const double (&r)[2] = q.r;
   const double (&Jc)[12] = q.Jc;
   const double (&Jp)[6] = q.Jp;
   const double (&V)[9] = q.V;
   const double (&gp)[3] = q.gp;
-  const double cost_l = q.cost_l;
   const int maxlen = q.maxlen;
+  double s[3] = {1, 1, 1};
+  if (active) {
+    if (first_pass) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a) s[a] = 1.0 / (1.0 + sqrt(V[4 * a]));
+      if (lane == first) { P.sp[3 * j] = s[0]; P.sp[3 * j + 1] = s[1]; P.sp[3 * j + 2] = s[2]; }
+    } else {
+      s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
+    }
+    if (lane == first) lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
+  }
+  double Vd[9], Vi[9], gps[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    gps[a] = gp[a] * s[a];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Vd[3 * a + b] = V[3 * a + b] * s[a] * s[b];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) Vd[4 * a] += fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius;
+  inv3_sym(Vd, Vi);
+  double Ws[18], Y[18];
+  const bool freep = active && k > 0;
+  const int base = 6 * (k - 1);
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Ws[3 * a + b] = freep ? (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b] : 0.0;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
+  if (freep) {
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+      atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
+      atomicAdd(&sDU[base + a], Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]);
+      atomicAdd(&sGred[base + a], -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]));
+#pragma unroll
+      for (int b = 0; b < 6; ++b) atomicAdd(&sS[(base + a) * n + base + b], Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+    }
+  }
+  for (int t = 0; t < maxlen; ++t) {
+    const int src = (first + t) & 63;
+    const int kt = __shfl(k, src);
+    double Wt[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
+    if (freep && t < len && kt > 0 && src >= lane) {
+      const int bt = 6 * (kt - 1);
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+          atomicAdd(&sS[(base + a) * n + bt + b],
+                    -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Deterministic mode: the declared "chunk order" (oracle/ora_ba.cpp).  A wave chunk forms the partial of EVERY payload element
+// it contributes to inside the wavefront; what leaves it is E doubles per chunk (group), not one 6x6 block per observation pair.
+//   level 0  lanes stage their per-observation rows (W s, Y = W s Vd^-1: 36 doubles) in LDS; one OWNER lane per
+//            destination row (upper pose-pair block q, row a) walks the chunk's destination-ordered pair list and adds
+//            -(Y_i[a] . (W_t s)[b]) for b = 0..5 sequentially — (landmark, i, t) order, every element from +0.0.  Then the
+//            lanes stage their 33 per-pose values (g_c | -Y g_p | upper triangle of J_c^T J_c) in the same LDS rows and the
+//            owners of (pose, value) add them in lane order; the landmark scalars go through a small LDS list.
+//   level 1  (only problems with more than 128 chunks) a wavefront walks the G chunks of its group and adds every new
+//            partial to the group's running sum, kept in the partial store itself;
+//   level 2  reduce_elements: thread = element, the NG group sums added sequentially.
+// Partials travel as tagged granules {value, tag} (granule_store): a reader takes a value only under the awaited tag.
+constexpr int REC_STRIDE = 38;        // doubles per lane of the staging rows (36 used; even: 16-byte alignment)
+constexpr int LMS_STRIDE = 4;         // landmark scalars per landmark of a chunk (pass A uses 2)
+constexpr int WAVE_LDS_DOUBLES = 64 * REC_STRIDE + 64 * LMS_STRIDE;  // staging rows + landmark scalars of one wavefront
+constexpr int TAB_LDS_WORDS = 1024;   // u16 words of a chunk table ba_lm_kernel keeps in LDS (larger tables: host-driven path)
+
+// A chunk's destination table (host: ba_build_tables), u16 words:
+//   bstart[nU + 1]  entry range of every upper pose-pair block (bstart[nU] = number of entries)
+//   pstart[F + 1]   range of every free pose in the pose-lane list
+//   ent[n_ent]      lane i | transposed << 7 | lane t << 8; destination-ordered, inside a destination in (landmark, i, t) order
+//   plane[n_free]   bytes: lanes of the free observations, pose-ordered, ascending inside a pose
+struct ChunkTab {
+  const uint16_t* w; int nU, F;
+  __device__ __forceinline__ int bstart(int q) const { return w[q]; }
+  __device__ __forceinline__ int pstart(int k) const { return w[nU + 1 + k]; }
+  __device__ __forceinline__ int ent(int e) const { return w[nU + F + 2 + e]; }
+  __device__ __forceinline__ int plane(int x) const {
+    const int at = 2 * (nU + F + 2 + (int)w[nU]) + x;  // byte offset
+    return (w[at >> 1] >> (8 * (at & 1))) & 0xFF;
+  }
+};
+
+// Where a chunk's partials go: group g of the partial store.  `first`: the group's first chunk (its partial starts the
+// group's sum); otherwise the partial is added to what the group holds so far (same wavefront, acknowledged stores).
+struct PartSink { double* part1; double* part2; int NGpad, NG, g, first, parity; unsigned long long tag; };
+__device__ __forceinline__ void emit1(const PartSink& k, int e, double v) {
+  double* slot = k.part1 + 2 * ((size_t)e * k.NGpad + k.g);
+  if (!k.first) v = slot_load(slot) + v;
+  granule_store(slot, v, k.tag);
+}
+__device__ __forceinline__ void emit2(const PartSink& k, int i, double v) {
+  double* slot = k.part2 + 2 * (((size_t)k.parity * k.NG + k.g) * 4 + i);
+  if (!k.first) v = slot_load(slot) + v;
+  granule_store(slot, v, k.tag);
+}
+
+// "my stores have been acknowledged" (write-through stores: they are at the coherence point / in host memory)
+__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// LDS traffic of ONE wavefront is ordered; the fence only keeps the compiler from moving accesses across it
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// rank of the lane's landmark inside its chunk and the number of landmarks of the chunk
+__device__ __forceinline__ void landmark_rank(const ObsRec& R, int& rank, int& nlm) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long firsts = __ballot(R.active && lane == R.first);
+  nlm = __popcll(firsts);
+  rank = __popcll(firsts & ((1ull << R.first) - 1ull));  // R.first <= lane < 64
+}
+
+// Pass A behind the prefix, deterministic mode.  rec / lms: this wavefront's LDS (WAVE_LDS_DOUBLES).
+__device__ __forceinline__ void linearize_suffix_det(const BaDev& P, const ObsRec& R, const LinPre& q, double radius, int first_pass, const ChunkTab& T,
+                                                     double* rec, double* lms, const PartSink& sink, ChunkRegs* cache) {
+  const int lane = threadIdx.x & 63;
+  const bool active = R.active;
+  const int k = R.k, j = R.j, first = R.first;
+  const double (&r)[2] = q.r;
+  const double (&Jc)[12] = q.Jc;
+  const double (&Jp)[6] = q.Jp;
+  const double (&V)[9] = q.V;
+  const double (&gp)[3] = q.gp;
+  int rank, nlm;
+  landmark_rank(R, rank, nlm);
   double s[3] = {1, 1, 1};
   if (active) {
     if (first_pass) {
@@ -416,10 +497,7 @@ __device__ __forceinline__ void linearize_suffix(const BaDev& P, const ObsRec& R
     } else {
       s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
     }
-    if (lane == first) {
-      lgp2 += gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2];
-      if (P.det) slot_store2<WT>(&P.lmV[4 * (size_t)j], cost_l, gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]);
-    }
+    if (lane == first) { lms[LMS_STRIDE * rank] = q.cost_l; lms[LMS_STRIDE * rank + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
   }
   double Vd[9], Vi[9], gps[3];
 #pragma unroll
@@ -431,106 +509,87 @@ __device__ __forceinline__ void linearize_suffix(const BaDev& P, const ObsRec& R
 #pragma unroll
   for (int a = 0; a < 3; ++a) Vd[4 * a] += fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius;
   inv3_sym(Vd, Vi);
-  // W s and Y = (W s) Vd^-1 for free poses
-  double Ws[18], Y[18];
   const bool freep = active && k > 0;
-  const int base = 6 * (k - 1);
+  double* mine = rec + lane * REC_STRIDE;
+  double ov[33];
+  {
+    // W s and Y = (W s) Vd^-1 -> this lane's staging row [W s (18) | Y (18)]; then the 33 per-pose values
+    double Ws[18], Y[18];
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) Ws[3 * a + b] = freep ? (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b] : 0.0;
+      for (int b = 0; b < 3; ++b) Ws[3 * a + b] = freep ? (Jc[a] * Jp[b] + Jc[6 + a] * Jp[3 + b]) * s[b] : 0.0;
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
-  if (freep && P.det) {
-    double* ov = P.obsV + (size_t)(cache ? cache->obs_pos : P.obs_pos[o]) * 18;
-    double w[18];
+      for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-      w[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
-      w[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
-      w[12 + a] = Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a];
-    }
-#pragma unroll
-    for (int a = 0; a < 18; a += 2) slot_store2<WT>(ov + a, w[a], w[a + 1]);
-  }
-  if (freep && !P.det) {
+    for (int i = 0; i < 18; ++i) { mine[i] = Ws[i]; mine[18 + i] = Y[i]; }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      atomicAdd(&sGc[base + a], Jc[a] * r[0] + Jc[6 + a] * r[1]);
-      atomicAdd(&sDU[base + a], Jc[a] * Jc[a] + Jc[6 + a] * Jc[6 + a]);
-      atomicAdd(&sGred[base + a], -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]));
-#pragma unroll
-      for (int b = 0; b < 6; ++b) atomicAdd(&sS[(base + a) * n + base + b], Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b]);
+      ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+      ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
     }
+    int u = 12;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = a; b < 6; ++b) ov[u++] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
   }
-  // Schur pairs: lane (pose k) x every later-or-equal member of its segment
-  if (P.det && maxlen <= 8) {
-    // window-sized landmarks (<= 8 observations): the destination rows of all of this lane's pairs are fetched up front
-    // (contiguous int2 entries) instead of one dependent load per pair, and the loop runs over the lane distance d so
-    // that the prefetched entries are indexed statically
-    const int mine = freep ? first + len - lane : 0;  // pairs (lane, lane + d), d < mine
-    int2 pp[8];
-    if (cache && cache->have_pp) {
+  wave_lds_fence();
+  // ---- Schur part: owner = (upper block q, row a), six elements, the block's pair list in order
+  const int nU = T.nU, F = T.F;
+  for (int row = lane; row < 6 * nU; row += 64) {
+    const int qb = row / 6, a = row - 6 * qb;
+    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    const int e1 = T.bstart(qb + 1);
+    for (int e = T.bstart(qb); e < e1; ++e) {
+      const int en = T.ent(e);
+      const double* ri = rec + (en & 63) * REC_STRIDE;
+      const double* rt = rec + ((en >> 8) & 63) * REC_STRIDE;
+      if (!(en & 0x80)) {
+        const double y0 = ri[18 + 3 * a], y1 = ri[18 + 3 * a + 1], y2 = ri[18 + 3 * a + 2];
 #pragma unroll
-      for (int d = 0; d < 8; ++d) pp[d] = cache->pp[d * cache->pp_stride];
-    } else {
-      const int2* ppsrc = reinterpret_cast<const int2*>(P.pair_pos) + (freep ? P.pair_base[o] : 0);
+        for (int b = 0; b < 6; ++b) acc[b] += -(y0 * rt[3 * b] + y1 * rt[3 * b + 1] + y2 * rt[3 * b + 2]);
+      } else {  // the transpose of the pair's block: element (a, b) of the destination is B[b][a]
+        const double w0 = rt[3 * a], w1 = rt[3 * a + 1], w2 = rt[3 * a + 2];
 #pragma unroll
-      for (int d = 0; d < 8; ++d) pp[d] = d < mine ? ppsrc[d] : int2{-1, -1};
-    }
-#pragma unroll
-    for (int d = 0; d < 8; ++d) {
-      if (d >= maxlen) break;  // wave-uniform
-      const int src = (lane + d) & 63;
-      const int kt = __shfl(k, src);
-      double Wt[18];
-#pragma unroll
-      for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
-      if (d < mine && kt > 0) {
-        double* B = pp[d].x >= 0 ? P.pairB + (size_t)pp[d].x * 36 : nullptr;   // block (k, kt) if it is an upper block
-        double* Bt = pp[d].y >= 0 ? P.pairB + (size_t)pp[d].y * 36 : nullptr;  // block (kt, k) if THAT is an upper block
-        emit_pair_block<WT>(B, Bt, Y, Wt, Jc, d == 0);
+        for (int b = 0; b < 6; ++b) acc[b] += -(ri[18 + 3 * b] * w0 + ri[18 + 3 * b + 1] * w1 + ri[18 + 3 * b + 2] * w2);
       }
     }
-    return;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) emit1(sink, 36 * qb + 6 * a + b, acc[b]);
   }
-  for (int t = 0; t < maxlen; ++t) {
-    const int src = (first + t) & 63;
-    const int kt = __shfl(k, src);
-    double Wt[18];
+  wave_lds_fence();
+  // ---- per-pose values: the rows now carry the 33 values of every free observation
+  if (freep) {
 #pragma unroll
-    for (int i = 0; i < 18; ++i) Wt[i] = shfl_d(Ws[i], src);
-    if (freep && t < len && kt > 0 && src >= lane) {
-      if (P.det) {
-        const int slot = P.pair_base[o] + (src - lane);
-        const int posA = P.pair_pos[2 * slot], posB = P.pair_pos[2 * slot + 1];
-        double* B = posA >= 0 ? P.pairB + (size_t)posA * 36 : nullptr;
-        double* Bt = posB >= 0 ? P.pairB + (size_t)posB * 36 : nullptr;
-        emit_pair_block<WT>(B, Bt, Y, Wt, Jc, src == lane);
-      } else {
-        const int bt = 6 * (kt - 1);
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int b = 0; b < 6; ++b)
-            atomicAdd(&sS[(base + a) * n + bt + b],
-                      -(Y[3 * a] * Wt[3 * b] + Y[3 * a + 1] * Wt[3 * b + 1] + Y[3 * a + 2] * Wt[3 * b + 2]));
-      }
-    }
+    for (int i = 0; i < 33; ++i) mine[i] = ov[i];
   }
+  wave_lds_fence();
+  for (int idx = lane; idx < 33 * F; idx += 64) {
+    const int kp = idx / 33, el = idx - 33 * kp;
+    double acc = 0.0;
+    const int x1 = T.pstart(kp + 1);
+    for (int x = T.pstart(kp); x < x1; ++x) acc += rec[T.plane(x) * REC_STRIDE + el];
+    emit1(sink, 36 * nU + idx, acc);
+  }
+  // ---- cost, sum g_p^2: landmark order
+  if (lane < 2) {
+    double acc = 0.0;
+    for (int l = 0; l < nlm; ++l) acc += lms[LMS_STRIDE * l + lane];
+    emit1(sink, 36 * nU + 33 * F + lane, acc);
+  }
+  wave_lds_fence();  // the next pass of this wavefront reuses rows and scalars
 }
 
-template <bool WT = false>
-__device__ __forceinline__ void linearize_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius,
-                                                int first_pass, double* sS, double* sGred, double* sGc, double* sDU,
-                                                double& lcost, double& lgp2, ChunkRegs* cache = nullptr) {
+__device__ __forceinline__ void linearize_chunk_det(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius, int first_pass,
+                                                    const ChunkTab& T, double* rec, double* lms, const PartSink& sink, ChunkRegs* cache = nullptr) {
   LinPre q;
-  linearize_prefix(P, R, poses_, q, lcost);
-  linearize_suffix<WT>(P, R, q, radius, first_pass, sS, sGred, sGc, sDU, lgp2, cache);
+  double unused = 0.0;
+  linearize_prefix(P, R, poses_, q, unused);
+  linearize_suffix_det(P, R, q, radius, first_pass, T, rec, lms, sink, cache);
 }
-
 
 // One-time reads of the problem image by ba_lm_kernel.  The image stays in PINNED HOST memory (no H2D copy launch in front of
 // every solve: that copy was a 45 us blit kernel and a stream dependency per keyframe): `shift` leads from a device-arena
@@ -563,56 +622,29 @@ __device__ __forceinline__ ObsRec load_obs_image(const BaDev& P, int chunk, int 
   return R;
 }
 
-// the lane's constants of the loaded problem (ba_lm_kernel, once per solve).  `stage`: LDS scratch of this wavefront,
-// >= 512 eight-byte words: the wavefront's pair rows are ONE contiguous run of the image (pair_base ascends with the lanes),
-// fetched by consecutive lanes and then picked apart — per-lane reads of its own 1-5 rows would fetch every line once per row index.
-__device__ __forceinline__ void load_chunk_regs(const BaDev& P, const ObsRec& R, ChunkRegs& c, int2* pp_lds /* this lane's column */, int pp_stride,
-                                                ptrdiff_t shift, long long* stage) {
+// this wavefront's chunk table -> LDS (ba_lm_kernel, once per solve): consecutive lanes read consecutive words of the image
+__device__ __forceinline__ void load_chunk_table(const BaDev& P, int chunk, uint16_t* dst, ptrdiff_t shift) {
   const int lane = threadIdx.x & 63;
-  const bool freep = R.active && R.k > 0;
-  int maxlen = R.len;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
-  c.have_pp = P.det && maxlen <= 8;
-  c.obs_pos = freep ? sys_load(&P.obs_pos[R.o], shift) : 0;
-  const int mine = freep ? R.first + R.len - lane : 0;
-  const int pb = freep ? sys_load(&P.pair_base[R.o], shift) : 0;
-  int lo = (c.have_pp && mine > 0) ? pb : 0x7fffffff, hi = (c.have_pp && mine > 0) ? pb + min(mine, 8) : 0;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { lo = min(lo, __shfl_xor(lo, off)); hi = max(hi, __shfl_xor(hi, off)); }
-  const bool run = hi > lo && hi - lo <= 512;  // wave-uniform
-  if (run) {
-    const long long* src = reinterpret_cast<const long long*>(P.pair_pos) + lo;
-    for (int i = lane; i < hi - lo; i += 64) stage[i] = sys_load(src + i, shift);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-  const long long* ppsrc = reinterpret_cast<const long long*>(P.pair_pos) + pb;
-#pragma unroll
-  for (int d = 0; d < 8; ++d) {
-    int2 v = int2{-1, -1};
-    if (c.have_pp && d < mine) {
-      const long long w = run ? stage[pb - lo + d] : sys_load(ppsrc + d, shift);
-      v = int2{(int)(w & 0xFFFFFFFFll), (int)(w >> 32)};
-    }
-    pp_lds[d * pp_stride] = v;
-  }
-  c.pp = pp_lds; c.pp_stride = pp_stride;
-  c.s[0] = c.s[1] = c.s[2] = 1.0;
+  const uint32_t o0 = sys_load(&P.tab_off[chunk], shift), o1 = sys_load(&P.tab_off[chunk + 1], shift);
+  const int words32 = (int)((o1 - o0 + 1) >> 1);  // tables start on even u16 offsets
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tab + o0);
+  uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
+  for (int i = lane; i < words32 && 2 * i < TAB_LDS_WORDS; i += 64) d32[i] = sys_load(src + i, shift);
+  wave_lds_fence();
 }
 
 // Pass B for one wave chunk: back-substitution of the pose step dc_ at (poses_, R.p), candidate landmark (returned in
 // `cand`, valid in every active lane of the landmark's segment; written to cand_points_ by the segment's first lane),
-// candidate residual against cand_poses_.  Deterministic mode: the landmark's four scalars go to lmV2.  Otherwise
+// candidate residual against cand_poses_.  Deterministic mode (lms != null): the chunk's four sums go to `sink`.  Otherwise
 // a_* accumulate this lane's share of payload2.
-template <bool WT = false>  // WT: lmV2 is consumed inside this launch
 __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_,
                                               const double* __restrict__ cand_poses_, const double* __restrict__ dc_,
                                               double* __restrict__ cand_points_, double radius, D3& cand, double& a_cost,
-                                              double& a_mc, double& a_dp2, double& a_p2, const ChunkRegs* cache = nullptr) {
+                                              double& a_mc, double& a_dp2, double& a_p2, const ChunkRegs* cache = nullptr,
+                                              double* lms = nullptr, const PartSink* sink = nullptr) {
   const int lane = threadIdx.x & 63;
   const bool active = R.active;
+  const bool det = lms != nullptr;
   const int k = R.k, j = R.j, first = R.first, len = R.len;
   double r[2] = {0, 0}, Jc[12], Jp[6], jd[2] = {0, 0};
   double det_c = 0.0, det_mc = 0.0, det_dp2 = 0.0, det_p2 = 0.0;
@@ -632,7 +664,7 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, off));
   double V[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, gp[3] = {0, 0, 0}, wd[3] = {0, 0, 0};
-  if (!P.det) {
+  if (!det) {
     double t[12] = {Jp[0] * Jp[0] + Jp[3] * Jp[3], Jp[0] * Jp[1] + Jp[3] * Jp[4], Jp[0] * Jp[2] + Jp[3] * Jp[5],
                     Jp[1] * Jp[1] + Jp[4] * Jp[4], Jp[1] * Jp[2] + Jp[4] * Jp[5], Jp[2] * Jp[2] + Jp[5] * Jp[5],
                     Jp[0] * r[0] + Jp[3] * r[1], Jp[1] * r[0] + Jp[4] * r[1], Jp[2] * r[0] + Jp[5] * r[1],
@@ -641,7 +673,7 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
     V[0] = t[0]; V[1] = V[3] = t[1]; V[2] = V[6] = t[2]; V[4] = t[3]; V[5] = V[7] = t[4]; V[8] = t[5];
     gp[0] = t[6]; gp[1] = t[7]; gp[2] = t[8]; wd[0] = t[9]; wd[1] = t[10]; wd[2] = t[11];
   }
-  for (int t = 0; t < (P.det ? maxlen : 0); ++t) {
+  for (int t = 0; t < (det ? maxlen : 0); ++t) {
     const int src = (first + t) & 63;
     double q[6], rr[2], dd[2];
 #pragma unroll
@@ -699,16 +731,25 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
       det_p2 += pv[a] * pv[a];
     }
   }
-  if (P.det) {  // candidate cost of the landmark in observation order, then the landmark's slot
+  if (det) {  // candidate cost of the landmark in observation order, then the chunk's sums in landmark order
     double cn = 0.0;
     for (int t = 0; t < maxlen; ++t) {
       const double ct = shfl_d(det_c, (first + t) & 63);
       if (t < len) cn += ct;
     }
+    int rank, nlm;
+    landmark_rank(R, rank, nlm);
     if (active && lane == first) {
-      double* lv = P.lmV2 + 4 * (size_t)j;
-      slot_store2<WT>(lv, cn, det_mc); slot_store2<WT>(lv + 2, det_dp2, det_p2);
+      double* lv = lms + LMS_STRIDE * rank;
+      lv[0] = cn; lv[1] = det_mc; lv[2] = det_dp2; lv[3] = det_p2;
     }
+    wave_lds_fence();
+    if (lane < 4) {
+      double acc = 0.0;
+      for (int l = 0; l < nlm; ++l) acc += lms[LMS_STRIDE * l + lane];
+      emit2(*sink, lane, acc);
+    }
+    wave_lds_fence();
   }
 }
 
@@ -730,61 +771,147 @@ __device__ __forceinline__ void stage_step(const BaDev& P, double* sStep) {
   __syncthreads();
 }
 constexpr int STEP_LDS_DOUBLES = 6 * 63 + 7 * 64;
-constexpr int RES_STEP_LDS_DOUBLES = 6 * 63 + 14 * 64;  // ba_lm_kernel's step block: + the current poses
 
-// payload2 = R(landmark list) over the four per-landmark scalars of pass B (lmV2), in the declared order, by ANY workgroup
-// size: item = (segment, element), 112 items.  sP: RSEG * 4 doubles of LDS, sOut: 4.  Ends with a barrier: every thread
-// may read sOut afterwards.
-template <int DEPTH, bool SAME_LAUNCH = false>  // SAME_LAUNCH: lmV2 was written by this very launch, read it at the coherence point
-__device__ __forceinline__ void reduce_pay2(const BaDev& P, int e0, int len, double* sP, double* sOut) {
-  const int seglen = (len + RSEG - 1) / RSEG;
-  for (int item = threadIdx.x; item < RSEG * 4; item += (int)blockDim.x) {
-    const int seg = item >> 2, e = item & 3;
-    double acc = 0.0;
-    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-    const double* src = P.lmV2 + 4 * ((size_t)e0 + (size_t)b0) + e;
-    for (int q0 = b0; q0 < b1; q0 += DEPTH, src += 4 * DEPTH) {  // DEPTH loads in flight, adds in list order
-      double v[DEPTH];
+// Every wait inside a launch is bounded by ONE wall-clock deadline (the 100 MHz constant clock, not a spin count whose
+// duration depends on what is polled): a workgroup gives up LM_WAIT_TICKS after it started waiting — far beyond any
+// solve, well inside the host's own 10 s limit on the completion word (ba_wait_flag) — and the host reports the solve.
+constexpr long long LM_WAIT_TICKS = 300000000ll;  // 3 s
+
+// `count` consecutive granules under `tag` -> dst (LDS), values only; up to 8 per thread in flight; a granule whose tag is
+// not the awaited one is read again (bounded).  Any workgroup size; no barrier.  false: a tag never showed up.
+__device__ __forceinline__ bool fetch_granules(double* dst, const double* src, int count, unsigned long long tag) {
+  bool good = true;
+  for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
+    int gi[8];
 #pragma unroll
-      for (int u = 0; u < DEPTH; ++u) v[u] = q0 + u < b1 ? (SAME_LAUNCH ? slot_load(src + 4 * u) : src[4 * u]) : 0.0;
-#pragma unroll
-      for (int u = 0; u < DEPTH; ++u)
-        if (q0 + u < b1) acc += v[u];
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+      gi[u] = i < count ? i : -1;
     }
-    sP[4 * seg + e] = acc;
+    double v[8];
+    unsigned ok = granule_load8(src, gi, tag, v);
+    long long t0 = 0;
+    for (unsigned spins = 0; ok != 0xFFu; ++spins) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((spins & 255u) == 255u) {
+        const long long tn = (long long)wall_clock64();
+        if (!t0) t0 = tn;
+        else if (tn - t0 > LM_WAIT_TICKS) break;
+      }
+      int again[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) again[u] = (ok >> u) & 1u ? -1 : gi[u];
+      double w[8];
+      const unsigned ok2 = granule_load8(src, again, tag, w);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (!((ok >> u) & 1u) && ((ok2 >> u) & 1u)) { v[u] = w[u]; ok |= 1u << u; }
+    }
+    good = good && ok == 0xFFu;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (gi[u] >= 0) dst[gi[u]] = v[u];
   }
+  return good;
+}
+
+// Level 2 for the wire elements [e0, e1): the NG group sums of every element (granules under `tag`) added sequentially,
+// starting from the first.  sm: >= sm_doubles doubles of LDS; out(e, total).  Any workgroup size, block-uniform arguments;
+// ends with a barrier.  false (block-uniform): a tag never showed up.
+template <typename Out>
+__device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, unsigned long long tag, double* sm, int sm_doubles, int* s_flag, Out out) {
+  const int NG = P.NG, NGpad = P.NGpad;
+  const int per_round = max(1, sm_doubles / NGpad);
+  if (threadIdx.x == 0) *s_flag = 1;
+  __syncthreads();
+  for (int eb = e0; eb < e1; eb += per_round) {  // block-uniform trip count
+    const int ne = min(per_round, e1 - eb);
+    // the rows of consecutive elements are consecutive in the store: ne * NGpad granules in one run (the padding granules
+    // of a row are never written: they are skipped, not waited for)
+    bool good = true;
+    for (int base = 0; base < ne * NGpad; base += 8 * (int)blockDim.x) {
+      int gi[8], at[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
+        const bool use = i < ne * NGpad && (i % NGpad) < NG;
+        at[u] = use ? i : -1;
+        gi[u] = use ? eb * NGpad + i : -1;
+      }
+      double v[8];
+      unsigned ok = granule_load8(P.part1, gi, tag, v);
+      long long t0 = 0;
+      for (unsigned spins = 0; ok != 0xFFu; ++spins) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 255u) {
+          const long long tn = (long long)wall_clock64();
+          if (!t0) t0 = tn;
+          else if (tn - t0 > LM_WAIT_TICKS) break;
+        }
+        int again[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) again[u] = (ok >> u) & 1u ? -1 : gi[u];
+        double w[8];
+        const unsigned ok2 = granule_load8(P.part1, again, tag, w);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (!((ok >> u) & 1u) && ((ok2 >> u) & 1u)) { v[u] = w[u]; ok |= 1u << u; }
+      }
+      good = good && ok == 0xFFu;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (at[u] >= 0) sm[at[u]] = v[u];
+    }
+    if (!good) *s_flag = 0;
+    __syncthreads();
+    for (int el = threadIdx.x; el < ne; el += (int)blockDim.x) {
+      const double* row = sm + el * NGpad;
+      double acc = row[0];
+      for (int g = 1; g < NG; ++g) acc += row[g];
+      out(eb + el, acc);
+    }
+    __syncthreads();
+  }
+  return *s_flag != 0;
+}
+
+// payload2: the NG group sums of pass B's four scalars (granules under `tag`, half `parity` of the store) added
+// sequentially from the first.  sm: >= 4 * NG doubles of LDS, sOut: 4.  Ends with a barrier; false: a tag never showed up.
+__device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned long long tag, double* sm, double* sOut, int* s_flag) {
+  const int NG = P.NG;
+  if (threadIdx.x == 0) *s_flag = 1;
+  __syncthreads();
+  if (!fetch_granules(sm, P.part2 + 2 * ((size_t)parity * NG * 4), 4 * NG, tag)) *s_flag = 0;
   __syncthreads();
   if (threadIdx.x < 4) {
-    double acc = 0.0;
-    for (int sg = 0; sg < RSEG; ++sg) acc += sP[4 * sg + threadIdx.x];
+    double acc = sm[threadIdx.x];
+    for (int g = 1; g < NG; ++g) acc += sm[4 * g + threadIdx.x];
     sOut[threadIdx.x] = acc;
   }
   __syncthreads();
+  return *s_flag != 0;
 }
 
-// ---- pass A alone (first linearisation of a solve, re-linearisation after a rejected step or a missed speculation)
+// ---- pass A alone, bulk modes (first linearisation of a solve, re-linearisation after a rejected step or a missed speculation)
 __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
   svo_latency_critical();
   apply_ctl(P, radius, ctl);
-  extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2  (bulk mode only)
+  extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2
   const int n = P.n;
   const int pay1 = n * n + 3 * n + 2;
   double* sS = lds;
   double* sGred = sS + n * n;
   double* sGc = sGred + n;
   double* sDU = sGc + n;
-  if (!P.det) {
-    for (int i = threadIdx.x; i < pay1; i += blockDim.x) lds[i] = 0.0;
-  }
+  for (int i = threadIdx.x; i < pay1; i += blockDim.x) lds[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double lcost = 0.0, lgp2 = 0.0;
   const int wpb = blockDim.x >> 6;
   for (int chunk = blockIdx.x * wpb + wave; chunk < P.C; chunk += gridDim.x * wpb) {
     const ObsRec R = load_obs(P, chunk, lane, P.points);
-    linearize_chunk(P, R, P.poses, radius, first_pass, sS, sGred, sGc, sDU, lcost, lgp2);
+    LinPre q;
+    linearize_prefix(P, R, P.poses, q, lcost);
+    linearize_suffix_bulk(P, R, q, radius, first_pass, sS, sGred, sGc, sDU, lgp2);
   }
-  if (P.det) return;  // sums are formed by ba_reduce_kernel in the declared order
   // block totals of cost / gp2
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { lcost += __shfl_xor(lcost, off); lgp2 += __shfl_xor(lgp2, off); }
@@ -796,32 +923,54 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
   }
 }
 
-// ---- single rank, deterministic mode, chained iteration: pass A that FIRST forms payload2 from pass B's per-landmark
-// scalars (every workgroup redundantly, in the declared order: 32 KB of L2 reads instead of a launch boundary), takes
-// Ceres' accept / radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
-__global__ __launch_bounds__(128) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl, int lm_begin, int lm_count) {
+// ---- deterministic mode, host-driven: one wavefront per workgroup, workgroup = group of chunks (window problems: one chunk)
+__device__ __forceinline__ PartSink make_sink(const BaDev& P, int g, int first) {
+  return PartSink{P.part1, P.part2, P.NGpad, P.NG, g, first, P.pay_parity, P.pay_tag};
+}
+__device__ __forceinline__ ChunkTab global_tab(const BaDev& P, int chunk) { return ChunkTab{P.tab + P.tab_off[chunk], (P.K - 1) * P.K / 2, P.K - 1}; }
+
+__global__ __launch_bounds__(64) void ba_linearize_det_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
   svo_latency_critical();
-  __shared__ double sP[RSEG * 4];
+  apply_ctl(P, radius, ctl);
+  extern __shared__ double lds[];  // WAVE_LDS_DOUBLES
+  double* rec = lds;
+  double* lms = lds + 64 * REC_STRIDE;
+  const int lane = threadIdx.x & 63, g = blockIdx.x;
+  const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
+  for (int chunk = c0; chunk < c1; ++chunk) {
+    const ObsRec R = load_obs(P, chunk, lane, P.points);
+    linearize_chunk_det(P, R, P.poses, radius, first_pass, global_tab(P, chunk), rec, lms, make_sink(P, g, chunk == c0));
+    stores_acknowledged();  // the group's running sums are read back by the next chunk
+  }
+}
+
+// ---- single rank, deterministic mode, chained iteration: pass A that FIRST forms payload2 from pass B's group sums (every
+// workgroup redundantly, in the declared order: a few KB of L2 reads instead of a launch boundary), takes Ceres' accept /
+// radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
+__global__ __launch_bounds__(64) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
+  svo_latency_critical();
+  extern __shared__ double lds[];  // WAVE_LDS_DOUBLES, the staging rows double as scratch of the sums
   __shared__ double sOut[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // wave 0 requests its chunk's records before the sums (both candidate landing points: the decision is not known yet)
-  const int chunk0 = blockIdx.x < P.C ? blockIdx.x : 0;
-  ObsRec Rc = load_obs(P, chunk0, lane, P.points);
+  __shared__ int sFlag;
+  double* rec = lds;
+  double* lms = lds + 64 * REC_STRIDE;
+  const int lane = threadIdx.x & 63, g = blockIdx.x;
+  const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
+  // the first chunk's records are requested before the sums (both candidate landing points: the decision is not known yet)
+  ObsRec Rc = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   D3 pc = Rc.p;
   if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
-  // 112 (segment, element) items on 128 lanes, 64 loads in flight each: one dependent round trip
-  reduce_pay2<64>(P, lm_begin, lm_count, sP, sOut);
+  (void)sum_pay2(P, P.pay_parity, P.pay_tag, rec, sOut, &sFlag);  // pass B's launch is complete: the tags are there
   const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
   if (blockIdx.x == 0 && threadIdx.x < 6)
     pay_store(&P.pay2_out[threadIdx.x], threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius));
-  if (wave != 0) return;
   const double* points_ = dec.accept ? P.cand_points : P.points;
   const double* poses_ = dec.accept ? P.cand_poses : P.poses;
   if (dec.accept) Rc.p = pc;
-  double unused0 = 0, unused1 = 0;
-  for (int chunk = blockIdx.x; chunk < P.C; chunk += gridDim.x) {
-    if (chunk != (int)blockIdx.x) Rc = load_obs(P, chunk, lane, points_);
-    linearize_chunk(P, Rc, poses_, dec.next_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+  for (int chunk = c0; chunk < c1; ++chunk) {
+    if (chunk != c0) Rc = load_obs(P, chunk, lane, points_);
+    linearize_chunk_det(P, Rc, poses_, dec.next_radius, 0, global_tab(P, chunk), rec, lms, make_sink(P, g, chunk == c0));
+    stores_acknowledged();
   }
 }
 
@@ -841,7 +990,6 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
     D3 cand;
     backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, a_cost, a_mc, a_dp2, a_p2);
   }
-  if (P.det) return;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     a_cost += __shfl_xor(a_cost, off); a_mc += __shfl_xor(a_mc, off);
@@ -858,126 +1006,33 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
 __global__ __launch_bounds__(64) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
   svo_latency_critical();
   __shared__ double sStep[STEP_LDS_DOUBLES];
-  const int lane = threadIdx.x & 63;
-  int chunk = blockIdx.x;
+  extern __shared__ double lds[];  // WAVE_LDS_DOUBLES
+  double* rec = lds;
+  double* lms = lds + 64 * REC_STRIDE;
+  const int lane = threadIdx.x & 63, g = blockIdx.x;
+  const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
   // the observation records are requested BEFORE the step is staged: the HBM round trip and the PCIe round trip overlap
-  ObsRec R = load_obs(P, chunk < P.C ? chunk : 0, lane, P.points);
+  ObsRec R = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   stage_step(P, sStep);
   const double* dc_ = sStep;
   const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
   double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
-  while (chunk < P.C) {
+  for (int chunk = c0; chunk < c1; ++chunk) {
+    if (chunk != c0) R = load_obs(P, chunk, lane, P.points);
+    const PartSink sink = make_sink(P, g, chunk == c0);
     D3 cand;
-    backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
+    backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3, nullptr, lms, &sink);
     if (spec_radius > 0) {
       R.p = cand;
-      linearize_chunk(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
+      linearize_chunk_det(P, R, cand_poses_, spec_radius, 0, global_tab(P, chunk), rec, lms, sink);
     }
-    chunk += gridDim.x;
-    if (chunk < P.C) R = load_obs(P, chunk, lane, P.points);
+    stores_acknowledged();
   }
 }
 
 // sharded runs: the decision is taken from the ALL-REDUCED payload2 (device buffer [payload2 | payload1])
 __global__ __launch_bounds__(64) void ba_decide_kernel(LmCtl ctl, double* paybuf, double* ctl_dev) {
   if (threadIdx.x == 0 && blockIdx.x == 0) decide_device(ctl, paybuf[0], paybuf[1], ctl_dev, paybuf);
-}
-
-// R(list): 28 consecutive segments summed sequentially, then the segment sums added sequentially
-// (the declared order; see oracle/ora_ba.cpp).  One workgroup per destination: with payload1, the F (F + 1) / 2 upper
-// pose-pair blocks (36 values; the lower ones are their exact transposes, mirrored on the host), F pose vectors
-// (18 values), 1 scalar pair from lmV; with payload2, one more workgroup for the four scalars of lmV2;
-// lane = (segment, element).  The last workgroup to arrive publishes the completion word.
-struct ListArgs { int n; int begin[48], end[48]; };  // destination lists of window-sized problems ride in the kernel arguments (n = 0: read P.list_start)
-
-// Workgroups of 256 threads (a 1024-thread workgroup needs half a CU's wave slots at once and queues behind other
-// streams' kernels when several stereo streams share the GPU): a 36-wide pose-pair destination is cut into four
-// independent 9-element slices, an 18-wide pose destination into two — every (segment, element) sum and every
-// 28-term final sum stays inside one workgroup, so the declared order is untouched.
-constexpr int RED_SLICE = 9;
-__host__ __device__ inline int ba_reduce_blocks(int F) { return 4 * (F * (F + 1) / 2) + 2 * F + 1; }
-// Payload that stays on the device for the other workgroups of the SAME launch (ba_lm_kernel) is staged slice by slice,
-// each slice in its own 128-byte line: writers on different XCDs never share a cache line.  Measured on MI355X with the
-// slices packed into the logical payload1 layout (72-byte slices, two or three writers per line): under load, readers
-// saw earlier versions of whole slices — and of words nobody had written for several solves — although every store had
-// been acknowledged before the arrival counter moved; partial-line write-through from two L2s does not merge reliably.
-constexpr int PAY_STAGE_STRIDE = 16;
-// logical payload1 index of element t of slice b (-1: t is beyond the slice's width)
-__device__ __forceinline__ int pay_stage_index(int b, int t, int F, int n) {
-  const int nU = F * (F + 1) / 2;
-  if (b < 4 * nU) {
-    if (t >= RED_SLICE) return -1;
-    const int d = b >> 2, el = RED_SLICE * (b & 3) + t;
-    int ka = 0, rest = d;
-    while (rest >= F - ka) { rest -= F - ka; ++ka; }
-    const int kb = ka + rest;
-    return (6 * ka + el / 6) * n + 6 * kb + el % 6;
-  }
-  if (b < 4 * nU + 2 * F) {
-    if (t >= RED_SLICE) return -1;
-    const int k = (b - 4 * nU) >> 1, el = RED_SLICE * ((b - 4 * nU) & 1) + t;
-    if (el < 6) return n * n + n + 6 * k + el;            // g_c
-    if (el < 12) return n * n + 6 * k + (el - 6);         // g_red (the -Y g_p part)
-    return n * n + 2 * n + 6 * k + (el - 12);             // diag U
-  }
-  return t < 2 ? n * n + 3 * n + t : -1;
-}
-
-// One slice of payload1: destination d, elements [e_lo, e_lo + width).  Any workgroup size; ends with a barrier.
-template <bool SAME_LAUNCH>  // the slots were written by this very launch (fused): read them at the coherence point
-__device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la, int b, double (*sP)[RED_SLICE], long long* t_items = nullptr /* trace: ticks spent in the list walk */) {
-  const long long t_in = t_items && threadIdx.x == 0 ? (long long)wall_clock64() : 0;
-  const int F = P.K - 1, n = P.n, tid = threadIdx.x;
-  const int nU = F * (F + 1) / 2, nd = nU + F + 1;
-  int d, e_lo, width, stride;
-  const double* base;
-  if (b < 4 * nU) { d = b >> 2; e_lo = RED_SLICE * (b & 3); width = RED_SLICE; stride = 36; base = P.pairB; }
-  else if (b < 4 * nU + 2 * F) { d = nU + ((b - 4 * nU) >> 1); e_lo = RED_SLICE * ((b - 4 * nU) & 1); width = RED_SLICE; stride = 18; base = P.obsV; }
-  else { d = nU + F; e_lo = 0; width = 2; stride = 4; base = P.lmV; }
-  const int e0 = la.n ? la.begin[d] : P.list_start[d], len = (la.n ? la.end[d] : P.list_start[nd + 1 + d]) - e0;
-  const int seglen = (len + RSEG - 1) / RSEG;
-  for (int item = tid; item < RSEG * width; item += (int)blockDim.x) {
-    const int seg = item / width, e = item % width;
-    double acc = 0.0;
-    const int b0 = seg * seglen, b1 = min(len, (seg + 1) * seglen);
-    // 16 independent loads in flight, adds strictly in list order.  The row pointer advances by addition: a
-    // per-element 64-bit index multiply is a quarter-rate instruction and was most of this loop's ALU time.
-    const double* pq = base + ((size_t)e0 + (size_t)b0) * stride + e_lo + e;
-    for (int q0 = b0; q0 < b1; q0 += 16, pq += 16 * stride) {
-      double v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = q0 + u < b1 ? (SAME_LAUNCH ? slot_load(pq + u * stride) : pq[u * stride]) : 0.0;
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (q0 + u < b1) acc += v[u];
-    }
-    sP[seg][e] = acc;
-  }
-  __syncthreads();
-  if (t_items && tid == 0) *t_items += (long long)wall_clock64() - t_in;
-  if (tid < width) {
-    double acc = 0.0;
-    for (int sg = 0; sg < RSEG; ++sg) acc += sP[sg][tid];
-    double* out = P.pay1_out;
-    const int el = e_lo + tid;  // element of the destination
-    if (P.pay_dev) {
-      // payload for the other workgroups of this launch: every slice owns one 128-byte line (see PAY_STAGE_STRIDE)
-      granule_store(&out[2 * (PAY_STAGE_STRIDE * b + tid)], acc, P.pay_tag);
-    } else if (d < nU) {
-      int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
-      while (rest >= F - ka) { rest -= F - ka; ++ka; }
-      const int kb = ka + rest;
-      pay_store(&out[(size_t)(6 * ka + el / 6) * n + 6 * kb + el % 6], acc);
-    } else if (d < nU + F) {
-      const int k = d - nU;
-      if (el < 6) pay_store(&out[(size_t)n * n + n + 6 * k + el], acc);                 // g_c
-      else if (el < 12) pay_store(&out[(size_t)n * n + 6 * k + (el - 6)], acc);         // g_red (the -Y g_p part)
-      else pay_store(&out[(size_t)n * n + 2 * n + 6 * k + (el - 12)], acc);             // diag U
-    } else {
-      pay_store(&out[(size_t)n * n + 3 * n + el], acc);
-    }
-  }
-  __syncthreads();
 }
 
 // Publishing without cache maintenance.  A compiler fence at agent or system scope is `buffer_wbl2` + `buffer_inv`: it
@@ -987,8 +1042,6 @@ __device__ __forceinline__ void reduce_slice(const BaDev& P, const ListArgs& la,
 // side, every store is written through), so `s_waitcnt vmcnt(0)` alone says "my payload stores are acknowledged"; the
 // arrival counter and the completion word are relaxed atomics (performed at the device's / system's coherence point).
 // The last workgroup to arrive has, transitively, seen every payload store acknowledged before it writes the word.
-__device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 __device__ __forceinline__ void reduce_publish(const BaDev& P) {
   if (!P.flag) return;
   stores_acknowledged();
@@ -999,21 +1052,24 @@ __device__ __forceinline__ void reduce_publish(const BaDev& P) {
   }
 }
 
-__global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, int with_pay2, LmCtl ctl, ListArgs la) {
+// Level 2 of the declared order, host-driven form: workgroup b < nb1 sums RED_EPB wire elements -> pay1_out (pinned host
+// memory, or the device buffer an all-reduce follows on); one more workgroup sums payload2 (and, single rank with a chained
+// step, takes the decision for the pass-A launch queued behind).  The last workgroup to arrive publishes the completion word.
+constexpr int RED_EPB = 64, RED_LDS_DOUBLES = 4096;
+__host__ __device__ inline int ba_reduce_blocks(int E) { return (E + RED_EPB - 1) / RED_EPB; }
+
+__global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, int with_pay2, LmCtl ctl) {
   svo_latency_critical();
-  __shared__ double sP[RSEG][RED_SLICE];
+  __shared__ double sm[RED_LDS_DOUBLES];
   __shared__ double sOut[4];
-  const int F = P.K - 1, tid = threadIdx.x, b = blockIdx.x;
-  const int nU = F * (F + 1) / 2, nd = nU + F + 1;
-  const int nb1 = with_pay1 ? ba_reduce_blocks(F) : 0;
+  __shared__ int sFlag;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int nb1 = with_pay1 ? ba_reduce_blocks(P.E) : 0;
   if (b < nb1) {
-    reduce_slice<false>(P, la, b, sP);
+    double* out = P.pay1_out;
+    (void)reduce_elements(P, b * RED_EPB, min(P.E, (b + 1) * RED_EPB), P.pay_tag, sm, RED_LDS_DOUBLES, &sFlag, [out](int e, double v) { pay_store(&out[e], v); });
   } else if (with_pay2) {
-    {
-      const int dl = nU + F;  // the landmark list
-      const int e0 = la.n ? la.begin[dl] : P.list_start[dl], e1 = la.n ? la.end[dl] : P.list_start[nd + 1 + dl];
-      reduce_pay2<16>(P, e0, e1 - e0, &sP[0][0], sOut);
-    }
+    (void)sum_pay2(P, P.pay_parity, P.pay_tag, sm, sOut, &sFlag);
     if (tid < 4) pay_store(&P.pay2_out[tid], sOut[tid]);
     if (ctl.chain) {  // single rank: these ARE the global sums; decide here, pass A is queued right behind this launch
       if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
@@ -1022,30 +1078,6 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
   reduce_publish(P);
 }
 
-// ---- single rank, deterministic mode: a WHOLE LM iteration in ONE launch.  Every kernel boundary costs an L2 write-back
-// at its end and an L2 invalidate at its start on all eight XCDs — for every stream on the GPU — so with several stereo
-// streams the number of launches per iteration, not their arithmetic, sets the pace.  Workgroup = one chunk (wave 0 works,
-// the second wave only helps with the sums):
-//   pass B  ->  [chained: device-wide arrival; the LAST workgroup to arrive forms payload2 in the declared order, takes
-//   Ceres' decision and posts it; the others wait for the post]  ->  pass A (at the candidate kept in registers, or at the
-//   current point)  ->  device-wide arrival  ->  the first ba_reduce_blocks() workgroups reduce payload1  ->  publish.
-// Same sweep (spec_radius > 0): pass A follows pass B directly, payload2 is reduced behind the second arrival.
-// with_pay1 = 0: pass B alone (the last iteration of a solve).
-// Cross-workgroup data moves by write-through stores (slot_store2<true>) and loads at the coherence point (slot_load):
-// no L2 write-back, no L2 invalidate anywhere inside the launch.  Waiting is bounded; admission (FusedAdmission) keeps all waiting workgroups resident.
-struct IterSync {
-  unsigned* arrived;   // pass B finished (monotone, target = total so far)
-  unsigned arrived_target;
-  unsigned* posted;    // the decision of launch `post_seq` is in ctl_dev
-  unsigned post_seq;
-  unsigned* done;      // pass A finished
-  unsigned done_target;
-};
-
-// Every wait inside a launch is bounded by ONE wall-clock deadline (the 100 MHz constant clock, not a spin count whose
-// duration depends on what is polled): a workgroup gives up LM_WAIT_TICKS after it started waiting — far beyond any
-// solve, well inside the host's own 10 s limit on the completion word (ba_wait_flag) — and the host reports the solve.
-constexpr long long LM_WAIT_TICKS = 300000000ll;  // 3 s
 __device__ __forceinline__ bool wait_until(const unsigned* word, unsigned target, bool monotone) {
   long long t0 = 0;
   for (unsigned spins = 0;; ++spins) {
@@ -1060,279 +1092,94 @@ __device__ __forceinline__ bool wait_until(const unsigned* word, unsigned target
   }
 }
 
-struct IterShared {
-  double sP[RSEG][RED_SLICE];
-  double sOut[4];
-  double sDec[2];
-  int sGo, sLast;
-};
-
-// One workgroup per wave chunk: wave 0 works, the second wave only helps with the sums (spreads the chunks over the CUs).
-// (The solve that lives in ONE launch, ba_lm_kernel, has its own step function: lm_iterate.)
-__device__ __forceinline__ void iterate_body(const BaDev& P, double radius, double spec_radius, const LmCtl& ctl, int with_pay1,
-                                             int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy, double* sStep,
-                                             IterShared& sh, int n_blocks) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
-  const int my_chunk = (int)blockIdx.x;
-  const bool worker = (int)blockIdx.x < P.C;  // workgroups beyond the chunks only reduce
-  const bool my_wave_works = wave == 0 && my_chunk < P.C;
-  if (worker) {
-    ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
-    if (my_wave_works) R = load_obs(P, my_chunk, lane, P.points);  // requested before the step is staged: HBM and PCIe round trips overlap
-    stage_step(P, sStep);
-    const double* dc_ = sStep;
-    const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
-    const double* cur_poses_ = P.poses;
-    D3 cand = D3{0, 0, 1};
-    double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
-    if (my_wave_works) {
-      backsub_chunk<true>(P, R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3);
-      if (spec_radius > 0) {
-        R.p = cand;
-        linearize_chunk<true>(P, R, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
-      }
-      stores_acknowledged();  // lmV2 (and the slots of a same sweep) are at the coherence point
-    }
-    if (ctl.chain) {
-      __syncthreads();
-      if (tid == 0) sh.sLast = __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == sy.arrived_target;
-      __syncthreads();
-      if (sh.sLast) {
-        reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-        const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
-        if (tid < 6) pay_store(&P.pay2_out[tid], tid < 4 ? sh.sOut[tid] : (tid == 4 ? (double)dec.accept : dec.next_radius));
-        if (tid == 0) {
-          __hip_atomic_store(&P.ctl_dev[0], (double)dec.accept, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&P.ctl_dev[1], dec.next_radius, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (tid == 0) { sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius; }
-        stores_acknowledged();  // the decision (device) and payload2 (host) have arrived before anybody can see the post
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(sy.posted, sy.post_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid == 0) sh.sGo = 1;
-        __syncthreads();
-      } else {
-        if (tid == 0) {
-          const bool ok = wait_until(sy.posted, sy.post_seq, false);
-          sh.sDec[0] = slot_load(&P.ctl_dev[0]); sh.sDec[1] = slot_load(&P.ctl_dev[1]);
-          sh.sGo = ok;
-        }
-        __syncthreads();
-      }
-      if (!sh.sGo) return;
-      if (my_wave_works) {
-        const bool accept = sh.sDec[0] != 0.0;
-        if (accept) R.p = cand;
-        linearize_chunk<true>(P, R, accept ? cand_poses_ : cur_poses_, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1);
-        stores_acknowledged();
-      }
-    }
-  }
-  __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
-  const bool sums2 = !ctl.chain && blockIdx.x == 0;  // payload2 of a same-sweep / plain step: formed here, by workgroup 0
-  if ((int)blockIdx.x >= nb && !sums2) return;
-  if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
-  __syncthreads();
-  if (!sh.sGo) return;
-  if (sums2) {
-    reduce_pay2<64, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-    if (tid < 4) pay_store(&P.pay2_out[tid], sh.sOut[tid]);
-  }
-  for (int sl = blockIdx.x; sl < nb; sl += n_blocks) reduce_slice<true>(P, la, sl, sh.sP);
-  reduce_publish(P);
-}
-
-__global__ __launch_bounds__(128) void ba_iterate_kernel(BaDev P, double radius, double spec_radius, LmCtl ctl, int with_pay1,
-                                                         int lm_begin, int lm_count, ListArgs la, IterSync sy) {
-  __shared__ double sStep[STEP_LDS_DOUBLES];
-  __shared__ IterShared sh;
-  // these few waves are some stream's critical path and share their SIMDs with other streams' long tracker waves: issue
-  // priority over them (measured at 8 streams: +1 %; a high-priority HIP stream instead costs 7 %)
-  __builtin_amdgcn_s_setprio(3);
-  iterate_body(P, radius, spec_radius, ctl, with_pay1, lm_begin, lm_count, la, sy, sStep, sh, (int)gridDim.x);
-}
-
-// ---- one LM step inside ba_lm_kernel -----------------------------------------------------------------------------
-// The same arithmetic as iterate_body (every slot receives the same value), arranged for a launch that lives as long as the
-// solve:
-//   * a lane's observation record, its landmark, the destination rows of its Schur pairs and the Jacobi scales stay in
-//     registers from pass to pass (LmWave): a pass starts computing at once instead of behind two or three dependent loads;
-//   * the chained decision is taken by a workgroup that owns no chunk (the launch's last one, `reducer`): it polls the
-//     arrival counter, forms payload2 in the declared order, decides and posts tagged granules — while every worker already
-//     runs the radius-free part of pass A at its candidate (linearize_prefix).  A rejected step (rare) repeats that part at
-//     the current point.
-//   * the reduction slices are spread over workers AND the reducer.
-struct LmWave { ObsRec R; ChunkRegs c; D3 cand; };
-
-template <int CPW>
-__device__ __forceinline__ bool lm_iterate(const BaDev& P, LmWave& W, bool my_wave_works, bool reducer, double radius, double spec_radius,
-                                           const LmCtl& ctl, int with_pay1, int lm_begin, int lm_count, const ListArgs& la, const IterSync& sy,
-                                           double* sStep, IterShared& sh, int n_blocks /* workers of this solve */, long long* tp) {
-  const int tid = threadIdx.x;
-  long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
-  auto stamp = [&](int slot) { if (tp && tid == 0) { const long long tn = (long long)wall_clock64(); tp[slot] += tn - tmark; tmark = tn; } };
-  const double* dc_ = sStep;
-  const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
-  const double* cur_poses_ = cand_poses_ + 7 * P.K;
-  double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
-  LinPre pre;
-  if (my_wave_works) {
-    backsub_chunk<true>(P, W.R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, W.cand, unused0, unused1, unused2, unused3, &W.c);
-    if (spec_radius > 0) {  // same sweep: pass A at the candidate with the predicted radius
-      ObsRec Rc = W.R;
-      Rc.p = W.cand;
-      linearize_chunk<true>(P, Rc, cand_poses_, spec_radius, 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1, &W.c);
-    }
-    stores_acknowledged();  // lmV2 (and the slots of a same sweep) are at the coherence point
-  }
-  if (ctl.chain) {
-    __syncthreads();
-    stamp(0);
-    if (!reducer) {
-      if (tid == 0) __hip_atomic_fetch_add(sy.arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      ObsRec Rc = W.R;
-      Rc.p = W.cand;
-      if (my_wave_works) linearize_prefix(P, Rc, cand_poses_, pre, unused0);  // the decision is on its way meanwhile
-      stamp(1);
-      if (tid == 0) {
-        double d0 = 0, d1 = 0;
-        const bool ok = granule_wait(P.ctl_dev, 0, P.pay_tag, d0) && granule_wait(P.ctl_dev, 1, P.pay_tag, d1);
-        sh.sDec[0] = d0; sh.sDec[1] = d1;
-        sh.sGo = ok;
-      }
-      __syncthreads();
-      if (!sh.sGo) return false;
-      stamp(2);
-      if (my_wave_works) {
-        const bool accept = sh.sDec[0] != 0.0;
-        if (accept) {
-          linearize_suffix<true>(P, Rc, pre, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused1, &W.c);
-        } else {
-          linearize_chunk<true>(P, W.R, cur_poses_, sh.sDec[1], 0, nullptr, nullptr, nullptr, nullptr, unused0, unused1, &W.c);
-        }
-        stores_acknowledged();
-      }
-    } else {
-      if (tid == 0) sh.sGo = wait_until(sy.arrived, sy.arrived_target, true);
-      __syncthreads();
-      if (!sh.sGo) return false;
-      reduce_pay2<32, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-      const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sh.sOut[0], sh.sOut[1]);
-      // tagged granules: the decision for the waiting workers, payload2 + decision for everybody's step control
-      if (tid < 2) granule_store(&P.ctl_dev[2 * tid], tid == 0 ? (double)dec.accept : dec.next_radius, P.pay_tag);
-      if (tid >= 64 && tid < 70) {
-        const int t = tid - 64;
-        granule_store(&P.pay2_out[2 * t], t < 4 ? sh.sOut[t] : (t == 4 ? (double)dec.accept : dec.next_radius), P.pay_tag);
-      }
-      stores_acknowledged();
-      stamp(2);
-    }
-  }
-  __syncthreads();
-  stamp(3);
-  if (!reducer && tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int nb = with_pay1 ? ba_reduce_blocks(P.K - 1) : 0;
-  const bool sums2 = !ctl.chain && reducer;  // payload2 of a same-sweep / plain step: formed by the reducer, behind everybody's pass
-  // slice owners: the reducer first (it has been idle), then the workers
-  const int slot = reducer ? 0 : (int)blockIdx.x + 1;
-  if (slot >= nb && !sums2) return true;
-  if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
-  __syncthreads();
-  if (!sh.sGo) return false;
-  stamp(4);
-  if (sums2) {
-    reduce_pay2<32, true>(P, lm_begin, lm_count, &sh.sP[0][0], sh.sOut);
-    if (tid < 4) granule_store(&P.pay2_out[2 * tid], sh.sOut[tid], P.pay_tag);
-  }
-  for (int sl = slot; sl < nb; sl += n_blocks + 1) reduce_slice<true>(P, la, sl, sh.sP, tp ? tp + 10 : nullptr);
-  if (slot < nb || sums2) reduce_publish(P);
-  stamp(5);
-  return true;
-}
-
 // ---------------------------------------------------------------------------------------------------
-// The WHOLE solve as one launch: ba_lm_kernel.  Every other path has the host in every LM iteration (Cholesky of the
+// The WHOLE solve as one launch: ba_lm_kernel.  The host-driven path has the host in every LM iteration (Cholesky of the
 // reduced camera system + Ceres' step control: 13 us of PCIe turnaround for 1.3-4.4 us of arithmetic, and one host thread
-// per stereo stream; round 2's resident kernel took commands from the host over PCIe and is gone).  Here the step control
-// runs on the device, REPLICATED: when the reduction of
-// an iteration is complete (one device-wide arrival counter), every workgroup reads the summed payload at the coherence
-// point and runs host/lm.cpp's step control itself — the SAME functions (host/lm_math.h, host/lm_decide.h; the Cholesky
-// of csrc/lm_device.h applies host/linalg.cpp's operations in its order), hence the same bits and the same decision in
-// every workgroup — and goes straight on to its share of the next pass.  No command block, no post / poll hop, no
-// controller to wait for: an iteration is pass B -> arrival (the last workgroup forms payload2, decides, posts) ->
-// pass A -> arrival -> reduction slices -> arrival -> step control.  The host launches, and later finds poses,
-// landmarks, summary and ONE completion word in pinned memory.  Bit-identical to the host-driven loop
-// (tests/test_ba.py, tests/test_pipeline.py): every deciding operation is the same IEEE operation wherever it runs.
-// Steps take host/lm.cpp's two forms: chained (decision inside the launch, pass A behind it) or, after a saturated step,
-// same sweep (pass A at the candidate with the predicted radius right behind pass B: one device-wide meeting less).
-// The wall-clock cap of src/bundle_adjuster.cpp:11 cannot be evaluated consistently by replicated controllers:
-// solves with a cap below LM_DEVICE_MIN_TIME_CAP_S stay on the host-driven paths, larger caps (the reference's 0.1 s is
-// 30x the longest 50-iteration window solve) can never fire and are ignored.
-struct LmDevOpt { int max_iterations; double function_tolerance, gradient_tolerance, parameter_tolerance, initial_radius; };
+// per stereo stream).  Here the step control runs on the device, REPLICATED: every workgroup reads the summed payload and
+// runs host/lm.cpp's step control itself — the SAME functions (host/lm_math.h, host/lm_decide.h; the Cholesky of
+// csrc/lm_device.h applies host/linalg.cpp's operations in its order), hence the same bits and the same decision in every
+// workgroup — and goes straight on to its share of the next pass.  Workgroups hand over nothing but TAGGED GRANULES:
+//   pass B -> every wavefront posts its chunk's four sums -> EVERY workgroup collects all of them, adds them in the
+//   declared order and takes Ceres' decision itself (the radius-free part of pass A runs before the collection) ->
+//   pass A -> every wavefront posts its chunk's E partials -> every workgroup sums its slice of the elements over the
+//   chunks (level 2) and posts the totals -> every workgroup collects the E totals and runs the step control.
+// No arrival counter, no controller or reducer workgroup, no post / poll hop: a reader simply reads a granule again until
+// it carries the tag of the command it is waiting for.  Three hand-overs per chained iteration, two per same-sweep
+// iteration (after a saturated step pass A follows pass B directly with the predicted radius).
+// The host launches, and later finds poses, landmarks, summary and ONE completion word in pinned memory.  Bit-identical to
+// the host-driven loop (tests/test_ba.py, tests/test_pipeline.py): every deciding operation is the same IEEE operation
+// wherever it runs.
+// The wall-clock cap of src/bundle_adjuster.cpp:11: replicated controllers cannot each read a clock and agree, so
+// workgroup 0 posts the time elapsed since its first pass with every reduction it takes part in (one more granule) and
+// every controller tests THAT value at the top of the loop, where host/lm.cpp tests its clock.
+struct LmDevOpt { int max_iterations; double function_tolerance, gradient_tolerance, parameter_tolerance, initial_radius, max_time_s; };
 struct LmDevArgs {
-  unsigned* cnt;            // device counter block (LMC_*): all zero at entry, zeroed again by the last workgroup to leave
-  const void* arena_src;    // pinned problem image to fetch first (null: already on the device)
+  unsigned* cnt;            // device counter block (LMC_*)
+  const void* arena_src;    // pinned problem image to read in place (null: already on the device)
   void* arena_dst;
   size_t arena_bytes;
   double* points_a;         // the two landmark buffers (current / candidate, swapped by every accepted step)
   double* points_b;
   double* export_points;    // pinned: the solved landmarks, by landmark index (null: none)
-  double* dev_pay;          // device [payload2 (PAY2_SLOTS) | payload1] of the running iteration
-  double* host_result;      // pinned: [LMR_* summary (16 doubles) | poses 7 K]
+  double* dev_res;          // device granules: the E wire totals of the running iteration | elapsed seconds
+  double* host_result;      // pinned: [LMR_* summary | poses 7 K]
   int* host_flag;           // pinned completion word of the solve
   int host_seq;
-  // The counters are never reset: they run on from solve to solve (a reset by the finishing launch raced with the first
-  // arrivals of the adjuster's next launch on another stream — stores can land late, see granule_store); the finishing
-  // solve reports where it left them (LMR_C_*), the host hands that to the next one.
-  unsigned base_arrive, base_done, base_arrived, base_posted, base_copied;
+  unsigned base_arrive;     // the delivery counter runs on from solve to solve (monotone, wrap-safe compares)
   LmDevOpt opt;
-  unsigned* dbg;            // per workgroup 8 words: its last command (diagnostics of a solve that gave up; null: none)
+  unsigned* dbg;            // per workgroup 16 words: its last command (diagnostics of a solve that gave up; null: none)
 };
-constexpr double LM_DEVICE_MIN_TIME_CAP_S = 0.02;
-enum { LMC_ARRIVE = 0, LMC_DONE = 1, LMC_ARRIVED = 2, LMC_POSTED = 3, LMC_COPIED = 4, LMC_EXITED = 5, LMC_CTL = 8, LMC_WORDS = 16 };
+enum { LMC_ARRIVE = 0, LMC_WORDS = 16 };
 enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
-       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED,
-       LMR_C_ARRIVE, LMR_C_DONE, LMR_C_ARRIVED, LMR_C_POSTED, LMR_C_COPIED, LMR_TP0, LMR_DOUBLES = LMR_TP0 + 12 };
+       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED, LMR_C_ARRIVE, LMR_TP0, LMR_DOUBLES = LMR_TP0 + 12 };
 enum { LMS_START = 0, LMS_FIRST, LMS_RELIN, LMS_STEP, LMS_ACCEPT_RELIN, LMS_DELIVER };
 enum { LMOP_EXIT = 0, LMOP_LINEARIZE, LMOP_ITERATE, LMOP_DELIVER, LMOP_ABORT };
 
 struct LmDevState {
   double radius, df, cost, initial_cost, mcc, spec;  // spec: radius of the same-sweep pass A of the step in flight (0: none)
+  double elapsed;                                    // seconds since workgroup 0's first pass, as posted with the last reduction
+  double pay2[6];                                    // payload2 (+ accept, next radius) of a chained step, formed by lm_iterate
   int iterations, successful, termination, need_linearize, state, sel, chain, first, saturated;
-  unsigned arrived_total, post_seq, done_total, arrive_total;
+  unsigned arrive_total;
   int lin_calls, step_calls, same_sweeps, next_used;
-  int go, act, use_next, accepted, relin, bad;
-  unsigned long long tag;   // of the command in flight: (solve sequence << 20) | command number
+  int go, act, use_next, accepted, relin, bad, flag;
+  unsigned long long tag;   // of the command in flight: bit 62 | (solve sequence << 20) | command number
   unsigned op_count;
-  long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: waiting for the reduction, step control, passes
-  long long tp[12];  // finer split (workgroup 0): pass B, decision wait, pass A, done wait, slices, payload fetch, system build, Cholesky, step tail
+  long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: collecting the totals, step control, passes
+  long long tp[12];  // finer split (workgroup 0): pass B, radius-free part of pass A, collecting payload2, rest of pass A, own slice of level 2 (incl. waiting for the partials), -, collecting the totals, system build, Cholesky, step tail
 };
 constexpr double LM_MIN_RADIUS = 1e-32, LM_MAX_RADIUS = 1e16;
 
-// controller workspace (doubles): payload1 image, 4 vectors of n, payload2, term scratch
-static inline size_t ba_lm_ctl_doubles(int n, int K) { return (size_t)n * n + 3 * (size_t)n + 2 + 5 * (size_t)(n > 0 ? n : 1) + 8 + 14 * (size_t)K + 8; }
+// controller workspace (doubles) — it lives in the LDS of the staging rows (a pass and a controller turn never overlap):
+// payload image, 4 vectors of n, term scratch, U staging
+__host__ __device__ static inline size_t ba_lm_ctl_doubles(int n, int K) { return (size_t)n * n + 3 * (size_t)n + 2 + 4 * (size_t)(n > 0 ? n : 1) + (size_t)(n > 0 ? n : 1) + 14 * (size_t)K + 21 * (size_t)(K > 1 ? K - 1 : 1) + 8; }
+// dynamic LDS of ba_lm_kernel (doubles): [staging rows + landmark scalars of CPW wavefronts | controller workspace] (union) |
+// chunk tables | Jacobi scales of the pose columns | step block [dc | candidate poses | current poses]
+constexpr int LM_CPW = 2;
+__host__ __device__ static inline size_t ba_lm_union_doubles(int n, int K) { const size_t a = (size_t)LM_CPW * WAVE_LDS_DOUBLES, b = ba_lm_ctl_doubles(n, K); return a > b ? a : b; }
+__host__ __device__ static inline size_t ba_lm_lds_doubles(int n, int K) {
+  return ba_lm_union_doubles(n, K) + (size_t)LM_CPW * TAB_LDS_WORDS / 4 + 2 * (size_t)(n > 0 ? n : 1) + 14 * (size_t)K;
+}
 
-// payload1 out of its staging (16 tagged granules per reduction slice) into the logical layout in LDS; up to 8 granules
-// per thread are in flight; a granule whose tag is not the awaited one is read again.  false: a tag never showed up.
-__device__ __forceinline__ bool lm_fetch_staged(double* cP, const double* stage, int F, int n, unsigned long long tag) {
-  const int count = PAY_STAGE_STRIDE * ba_reduce_blocks(F);
+// The E wire totals (granules under `tag`) -> the payload image [S | g_red | g_c | diag U | cost | sum g_p^2] in LDS, assembled as
+// the oracle does: S[(k,a),(k,b)] = U_k[min][max] + Schur_(k,k)[a][b]; upper blocks as summed; the step control reads the
+// lower triangle through the mirror (see the system build).  cU: 21 F doubles of scratch.  false: a tag never showed up.
+__device__ __forceinline__ bool lm_fetch_totals(double* cP, double* cU, const double* res, int F, int n, unsigned long long tag, double* elapsed) {
+  const int nU = F * (F + 1) / 2, E = 36 * nU + 33 * F + 2;
   bool good = true;
-  for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
-    int gi[8], at[8];
+  for (int base = 0; base < E + 1; base += 8 * (int)blockDim.x) {
+    int gi[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
-      at[u] = i < count ? pay_stage_index(i / PAY_STAGE_STRIDE, i % PAY_STAGE_STRIDE, F, n) : -1;
-      gi[u] = at[u] >= 0 ? i : -1;
+      gi[u] = i < E + 1 ? i : -1;
     }
     double v[8];
-    unsigned ok = granule_load8(stage, gi, tag, v);
+    unsigned ok = granule_load8(res, gi, tag, v);
     long long t0 = 0;
     for (unsigned spins = 0; ok != 0xFFu; ++spins) {
       __builtin_amdgcn_s_sleep(2);
-      if ((spins & 255u) == 255u) {  // the launch-wide deadline, see wait_until
+      if ((spins & 255u) == 255u) {
         const long long tn = (long long)wall_clock64();
         if (!t0) t0 = tn;
         else if (tn - t0 > LM_WAIT_TICKS) break;
@@ -1341,67 +1188,70 @@ __device__ __forceinline__ bool lm_fetch_staged(double* cP, const double* stage,
 #pragma unroll
       for (int u = 0; u < 8; ++u) again[u] = (ok >> u) & 1u ? -1 : gi[u];
       double w[8];
-      const unsigned ok2 = granule_load8(stage, again, tag, w);
+      const unsigned ok2 = granule_load8(res, again, tag, w);
 #pragma unroll
       for (int u = 0; u < 8; ++u) if (!((ok >> u) & 1u) && ((ok2 >> u) & 1u)) { v[u] = w[u]; ok |= 1u << u; }
     }
     good = good && ok == 0xFFu;
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (at[u] >= 0) cP[at[u]] = v[u];
+    for (int u = 0; u < 8; ++u) {
+      const int e = gi[u];
+      if (e < 0) continue;
+      if (e < 36 * nU) {
+        const int d = e / 36, el = e - 36 * d;
+        int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
+        while (rest >= F - ka) { rest -= F - ka; ++ka; }
+        const int kb = ka + rest;
+        cP[(6 * ka + el / 6) * n + 6 * kb + el % 6] = v[u];
+      } else if (e < 36 * nU + 33 * F) {
+        const int k = (e - 36 * nU) / 33, el = (e - 36 * nU) - 33 * k;
+        if (el < 6) cP[n * n + n + 6 * k + el] = v[u];            // g_c
+        else if (el < 12) cP[n * n + 6 * k + (el - 6)] = v[u];    // g_red (the -Y g_p part)
+        else cU[21 * k + (el - 12)] = v[u];
+      } else if (e < E) {
+        cP[n * n + 3 * n + (e - 36 * nU - 33 * F)] = v[u];
+      } else {
+        *elapsed = v[u];
+      }
+    }
   }
+  __syncthreads();
+  // diagonal pose blocks take U; diag U
+  for (int i = threadIdx.x; i < 36 * F; i += (int)blockDim.x) {
+    const int k = i / 36, a = (i % 36) / 6, b = i % 6;
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const double uu = cU[21 * k + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    double* s = &cP[(6 * k + a) * n + 6 * k + b];
+    *s = uu + *s;
+    if (a == b) cP[n * n + 2 * n + 6 * k + a] = uu;
+  }
+  __syncthreads();
   return good;
-}
-
-// `count` doubles from device memory (written by other workgroups of this launch) into LDS: all loads of a thread are
-// issued before the first is stored (one memory round trip for up to 8 x blockDim words, then the next batch)
-__device__ __forceinline__ void lm_fetch(double* dst, const double* src, int count) {
-  for (int base = 0; base < count; base += 8 * (int)blockDim.x) {
-    double v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
-      v[u] = slot_load(&src[i < count ? i : count - 1]);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
-      if (i < count) dst[i] = v[u];
-    }
-  }
 }
 
 // Controller turn (every thread of every workgroup; identical inputs -> identical state everywhere): consume the
 // finished pass, run host/lm.cpp's step control up to the next pass.  Leaves the next pass' step block
 // [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
-__device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* sStep) {
+__device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* cSc, double* sStep, double* sOut4) {
   const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
-  const int grid = (P.C + 1) / 2, nb = ba_reduce_blocks(K - 1);  // workgroups of THIS solve: two wave chunks each (the launch may hold several solves)
+  const int grid = (P.C + LM_CPW - 1) / LM_CPW;  // workgroups of THIS solve (the launch may hold several solves)
   const int pay1 = n * n + 3 * n + 2;
-  double* cP = cl;             // payload1 image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
-  double* cSc = cP + pay1;     // Jacobi scales of the pose columns
-  double* cDf = cSc + nn;
+  double* cP = cl;             // payload image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
+  double* cDf = cP + pay1;
   double* cRhs = cDf + nn;
   double* cCol = cRhs + nn;
   double* cTerm = cCol + nn;   // nn + 14 K: per-element terms of the sequential sums
-  double* cPay2 = cTerm + nn + 14 * K;  // 8
+  double* cU = cTerm + nn + 14 * K;  // 21 F: the U triangles on their way into the diagonal blocks
   double* cDc = sStep;         // the step block is built in place
   double* cCand = sStep + nn;
   double* cPose = cCand + 7 * K;
-  const double* dpay1 = a.dev_pay + 2 * PAY_STAGE_STRIDE;  // granules: payload2 owns the first 8, the decision the next 8
   const LmDevOpt& opt = a.opt;
   enum { ACT_NONE = 0, ACT_LOOPTOP, ACT_FINISH, ACT_ACCEPT_TAIL, ACT_SOLVE };
   int act = ACT_NONE;
-  // a pass' bookkeeping: how many arrivals complete it
-  auto issue = [&](int op, int chain, int with_pay1) {
+  auto issue = [&](int op) {
     if (tid == 0) {
-      int publishers = grid;
-      if (op == LMOP_LINEARIZE) publishers = min(grid + 1, nb);  // slice owners: the reducer + the workers
-      else if (op == LMOP_ITERATE) publishers = with_pay1 ? min(grid + 1, nb) : 1;
-      cs.arrive_total += (unsigned)publishers;
-      if (op != LMOP_DELIVER) cs.done_total += (unsigned)grid;
-      if (op == LMOP_ITERATE && chain) { cs.arrived_total += (unsigned)grid; cs.post_seq++; }
-      cs.tag = ((unsigned long long)(unsigned)a.host_seq << 20) | (unsigned long long)(++cs.op_count & 0xFFFFFu);
+      if (op == LMOP_DELIVER) cs.arrive_total += (unsigned)grid;
+      cs.tag = (1ull << 62) | ((unsigned long long)(unsigned)a.host_seq << 20) | (unsigned long long)(++cs.op_count & 0xFFFFFu);
       const long long tn = (long long)wall_clock64();
       cs.t_ctl += tn - cs.t_mark; cs.t_mark = tn;
     }
@@ -1415,39 +1265,40 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   if (st == LMS_START) {
     if (tid == 0) {
       cs.go = 1;
-      cs.radius = opt.initial_radius; cs.df = 2.0; cs.cost = 0.0; cs.initial_cost = 0.0; cs.mcc = 0.0;
+      cs.radius = opt.initial_radius; cs.df = 2.0; cs.cost = 0.0; cs.initial_cost = 0.0; cs.mcc = 0.0; cs.elapsed = 0.0;
       cs.t0 = cs.t_mark = (long long)wall_clock64();
       cs.iterations = 0; cs.successful = 0; cs.termination = 1; cs.need_linearize = 0; cs.sel = 0; cs.chain = 0; cs.spec = 0.0; cs.saturated = 0;
-      cs.arrived_total = a.base_arrived; cs.post_seq = a.base_posted; cs.done_total = a.base_done; cs.arrive_total = a.base_arrive;
+      cs.arrive_total = a.base_arrive;
       cs.lin_calls = 1; cs.step_calls = 0; cs.same_sweeps = 0; cs.next_used = 0; cs.bad = 0; cs.op_count = 0; cs.tag = 0;
       cs.t_wait = cs.t_ctl = cs.t_body = 0;
       for (int i = 0; i < 12; ++i) cs.tp[i] = 0;
       cs.state = LMS_FIRST; cs.first = 1;
     }
     __syncthreads();
-    if (!cs.go) return LMOP_ABORT;
     {
       const ptrdiff_t shift = a.arena_src ? reinterpret_cast<const char*>(a.arena_src) - reinterpret_cast<const char*>(a.arena_dst) : 0;
       for (int i = tid; i < 7 * K; i += nt) cPose[i] = sys_load(&P.poses[i], shift);
     }
-    return issue(LMOP_LINEARIZE, 0, 1);
+    return issue(LMOP_LINEARIZE);
   }
   if (st == LMS_DELIVER) return LMOP_EXIT;
 
-  if (tid == 0) {  // the pass in flight is complete when all of its publishers have arrived
+  if (tid == 0) {
     const long long w0 = (long long)wall_clock64();
     cs.t_body += w0 - cs.t_mark;
-    cs.go = wait_until(a.cnt + LMC_ARRIVE, cs.arrive_total, true);
-    cs.t_mark = (long long)wall_clock64();
-    cs.t_wait += cs.t_mark - w0;
+    cs.t_mark = w0;
     cs.first = 0;
   }
   __syncthreads();
-  if (!cs.go) return LMOP_ABORT;
   if (a.dbg && tid == 0) cs.tp[11] = (long long)wall_clock64();
 
   if (st == LMS_STEP) {
-    if (tid < (cs.chain ? 6 : 4) && !granule_wait(a.dev_pay, tid, cs.tag, cPay2[tid])) cs.bad = 1;  // the decision granules exist only behind a chained step
+    // payload2: a chained step formed it (and the decision) inside the pass; otherwise collect the group sums now
+    if (!cs.chain) {
+      if (!sum_pay2(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+      if (tid < 4) cs.pay2[tid] = sOut4[tid];
+      __syncthreads();
+    }
     for (int i = tid; i < 7 * K; i += nt) {  // terms of the pose part of |step|^2 and |x|^2 (host/lm.cpp after ops->step)
       const double dd = cCand[i] - cPose[i];
       cTerm[i] = dd * dd;
@@ -1455,6 +1306,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
     __syncthreads();
     if (tid == 0) {
+      const double* cPay2 = cs.pay2;
       const double cost_new = cPay2[0], model_change = cs.mcc + cPay2[1];
       double step2 = cPay2[2], x2 = cPay2[3];
       for (int i = 7; i < 7 * K; ++i) { step2 += cTerm[i]; x2 += cTerm[7 * K + i]; }
@@ -1495,17 +1347,27 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     }
     __syncthreads();
     if (cs.accepted) for (int i = tid; i < 7 * K; i += nt) cPose[i] = cCand[i];
-    if (cs.use_next && !lm_fetch_staged(cP, dpay1, K - 1, n, cs.tag)) cs.bad = 1;
+    // the totals of the pass A that rode along are collected even when they are not used: every slice owner has posted
+    // them under this command's tag, and the elapsed time travels with them
+    const bool with_pay1 = cs.chain != 0 || cs.spec > 0;
+    if (with_pay1) {
+      if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
+      if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed)) { if (tid == 0) cs.bad = 1; }
+      if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
+    }
+    __syncthreads();
     act = cs.act;
     const bool relin = act == ACT_ACCEPT_TAIL && cs.relin;
     __syncthreads();  // thread 0 writes cs.act again below
-    if (relin) {  // the chained pass A did not run for this outcome (last iteration): linearise now
+    if (relin) {  // the pass A that rode along did not run for this outcome: linearise now
       if (tid == 0) { ++cs.lin_calls; cs.state = LMS_ACCEPT_RELIN; }
-      return issue(LMOP_LINEARIZE, 0, 1);
+      return issue(LMOP_LINEARIZE);
     }
   } else {
-    // a stand-alone pass A has finished: its payload is the linearisation in use
-    if (!lm_fetch_staged(cP, dpay1, K - 1, n, cs.tag)) cs.bad = 1;
+    // a stand-alone pass A has finished: its totals are the linearisation in use
+    if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
+    if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed)) { if (tid == 0) cs.bad = 1; }
+    if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
     __syncthreads();
     if (st == LMS_FIRST) {
       if (tid == 0) { cs.cost = cP[pay1 - 2]; cs.initial_cost = cs.cost; }
@@ -1540,6 +1402,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       if (tid == 0) {
         int a_ = ACT_SOLVE;
         if (cs.iterations >= opt.max_iterations) { cs.termination = 1; a_ = ACT_FINISH; }
+        else if (opt.max_time_s > 0 && cs.elapsed >= opt.max_time_s) { cs.termination = 1; a_ = ACT_FINISH; }  // src/bundle_adjuster.cpp:11, on workgroup 0's posted clock
         else if (cs.radius <= LM_MIN_RADIUS) { cs.termination = 0; a_ = ACT_FINISH; }
         else {
           ++cs.iterations;
@@ -1550,7 +1413,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       __syncthreads();
       act = cs.act;
       __syncthreads();
-      if (act == ACT_NONE) return issue(LMOP_LINEARIZE, 0, 1);
+      if (act == ACT_NONE) return issue(LMOP_LINEARIZE);
     }
     if (act == ACT_FINISH) {
       if (tid == 0) cs.state = LMS_DELIVER;
@@ -1565,14 +1428,12 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
           pay_store(&r[LMR_T_WAIT], (double)cs.t_wait); pay_store(&r[LMR_T_CTL], (double)(cs.t_ctl + (tn - cs.t_mark)));
           pay_store(&r[LMR_T_BODY], (double)cs.t_body); pay_store(&r[LMR_T_TOTAL], (double)(tn - cs.t0));
           pay_store(&r[LMR_SAME_SWEEP], (double)cs.same_sweeps); pay_store(&r[LMR_NEXT_USED], (double)cs.next_used);
-          pay_store(&r[LMR_C_ARRIVE], (double)(cs.arrive_total + (unsigned)grid)); pay_store(&r[LMR_C_DONE], (double)cs.done_total);  // + the delivery's arrivals
-          pay_store(&r[LMR_C_ARRIVED], (double)cs.arrived_total); pay_store(&r[LMR_C_POSTED], (double)cs.post_seq);
-          pay_store(&r[LMR_C_COPIED], (double)(a.base_copied + (a.arena_src ? (unsigned)grid : 0u)));
+          pay_store(&r[LMR_C_ARRIVE], (double)(cs.arrive_total + (unsigned)grid));  // + the delivery's arrivals
           for (int i = 0; i < 12; ++i) pay_store(&r[LMR_TP0 + i], (double)cs.tp[i]);
         }
         for (int i = tid; i < 7 * K; i += nt) pay_store(&a.host_result[LMR_DOUBLES + i], cPose[i]);
       }
-      return issue(LMOP_DELIVER, 0, 0);
+      return issue(LMOP_DELIVER);
     }
     // ACT_SOLVE: scaled, damped reduced camera system (host/lm.cpp) -> Cholesky -> pose step
     const double radius = cs.radius;
@@ -1582,7 +1443,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       cRhs[q] = -(cP[n * n + q] + cP[n * n + n + q]) * sq;
     }
     __syncthreads();
-    // lower triangle of S' = S sc_a sc_b (+ Df on the diagonal).  The reduction wrote the upper pose-pair blocks; a lower
+    // lower triangle of S' = S sc_a sc_b (+ Df on the diagonal).  The totals hold the upper pose-pair blocks; a lower
     // block is the exact transpose of its mirror, diagonal blocks are complete.  A lower element of
     // an off-diagonal block never serves as the SOURCE of another element (sources are upper-block or diagonal-block
     // words), so the in-place write is race free.
@@ -1613,8 +1474,8 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
         cs.chain = 0; cs.spec = 0.0;
         if (cs.iterations < opt.max_iterations) {  // the last iteration cannot use a new linearisation
           // after a saturated step (Ceres' update is exactly radius / (1/3) for rho >= 0.9368) the next one is predicted
-          // saturated too: pass A at the candidate runs with that radius in the SAME sweep as pass B — no device-wide
-          // meeting for the decision; a misprediction costs one stand-alone pass A (host/lm.cpp, "same sweep")
+          // saturated too: pass A at the candidate runs with that radius in the SAME sweep as pass B — no hand-over
+          // for the decision; a misprediction costs one stand-alone pass A (host/lm.cpp, "same sweep")
           if (cs.saturated) { cs.spec = fmin(LM_MAX_RADIUS, cs.radius / (1.0 / 3.0)); ++cs.same_sweeps; }
           else cs.chain = 1;
         }
@@ -1627,8 +1488,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       }
       __syncthreads();
       cstamp(9);
-      const int chain = cs.chain;
-      return issue(LMOP_ITERATE, chain, chain || cs.spec > 0);
+      return issue(LMOP_ITERATE);
     }
     // not positive definite: invalid step, linearise again with the reduced radius
     if (tid == 0) { cs.radius /= cs.df; cs.df *= 2; cs.need_linearize = 1; }
@@ -1655,27 +1515,86 @@ __device__ __forceinline__ void deliver_chunk_points(const ObsRec& R, double* ou
     return;
   }
   for (int i = lane; i < 3 * span; i += 64) stage[i] = 0.0;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  wave_lds_fence();
   if (first) { stage[3 * (R.j - j0)] = R.p.x; stage[3 * (R.j - j0) + 1] = R.p.y; stage[3 * (R.j - j0) + 2] = R.p.z; }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  wave_lds_fence();
   for (int i = lane; i < 3 * span; i += 64) pay_store(&out[3 * (size_t)j0 + i], stage[i]);
 }
 
 // One solve of a launch: everything the kernel needs, in pinned host memory owned by the adjuster (stable while its solve
 // is in flight); the launch carries one pointer per solve, blockIdx.y selects it.
-struct LmLane { BaDev P; LmDevArgs a; int lm_begin, lm_count; ListArgs la; };
+struct LmLane { BaDev P; LmDevArgs a; };
 struct LmLanePtrs { const LmLane* p[SVO_MAX_LANES]; };
 
+struct LmWave { ObsRec R; ChunkRegs c; D3 cand; };
+struct LmShared { double sOut[4]; double sDec[2]; double sPay2[4 * 128]; int sGo; };
+
+// One LM step inside ba_lm_kernel (LMOP_ITERATE): pass B, [the decision,] pass A, this workgroup's slice of level 2.
+__device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, LmWave& W, bool my_wave_works, const ChunkTab& T, double* rec, double* lms,
+                                           double* union_lds, int union_doubles, LmDevState& cs, double* sStep, LmShared& sh, int n_blocks, long long t_first, long long* tp) {
+  const int tid = threadIdx.x, wave = tid >> 6;
+  long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
+  auto stamp = [&](int slot) { if (tp && tid == 0) { const long long tn = (long long)wall_clock64(); tp[slot] += tn - tmark; tmark = tn; } };
+  const double* dc_ = sStep;
+  const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+  const double* cur_poses_ = cand_poses_ + 7 * P.K;
+  const double radius = cs.radius, spec_radius = cs.spec;
+  const int chain = cs.chain;
+  const int with_pay1 = chain || spec_radius > 0;
+  const int my_chunk = (int)blockIdx.x * LM_CPW + wave;
+  double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
+  const PartSink sink = make_sink(P, my_chunk, 1);  // window problems: group = chunk
+  LinPre pre;
+  if (my_wave_works) {
+    backsub_chunk(P, W.R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, W.cand, unused0, unused1, unused2, unused3, &W.c, lms, &sink);
+    if (spec_radius > 0) {  // same sweep: pass A at the candidate with the predicted radius
+      ObsRec Rc = W.R;
+      Rc.p = W.cand;
+      linearize_chunk_det(P, Rc, cand_poses_, spec_radius, 0, T, rec, lms, sink, &W.c);
+    }
+  }
+  stamp(0);
+  if (chain) {
+    ObsRec Rc = W.R;
+    Rc.p = W.cand;
+    if (my_wave_works) linearize_prefix(P, Rc, cand_poses_, pre, unused0);  // the other wavefronts' sums are on their way meanwhile
+    stamp(1);
+    // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits
+    const bool ok = sum_pay2(P, P.pay_parity, P.pay_tag, sh.sPay2, sh.sOut, &sh.sGo);
+    if (!ok) return false;
+    if (tid == 0) {
+      const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, sh.sOut[0], sh.sOut[1]);
+      sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius;
+      cs.pay2[0] = sh.sOut[0]; cs.pay2[1] = sh.sOut[1]; cs.pay2[2] = sh.sOut[2]; cs.pay2[3] = sh.sOut[3];
+      cs.pay2[4] = (double)dec.accept; cs.pay2[5] = dec.next_radius;
+    }
+    __syncthreads();
+    stamp(2);
+    if (my_wave_works) {
+      const bool accept = sh.sDec[0] != 0.0;
+      if (accept) linearize_suffix_det(P, Rc, pre, sh.sDec[1], 0, T, rec, lms, sink, &W.c);
+      else linearize_chunk_det(P, W.R, cur_poses_, sh.sDec[1], 0, T, rec, lms, sink, &W.c);
+    }
+  }
+  stamp(3);
+  if (!with_pay1) return true;
+  __syncthreads();  // both wavefronts are through their passes: the staging rows become the scratch of level 2
+  // level 2: this workgroup's slice of the wire elements
+  const int per = (P.E + n_blocks - 1) / n_blocks;
+  const int e0 = min(P.E, (int)blockIdx.x * per), e1 = min(P.E, e0 + per);
+  double* res = a.dev_res;
+  const unsigned long long tag = P.pay_tag;
+  const bool ok = reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); });
+  if (blockIdx.x == 0 && tid == 0)  // the clock every controller tests (see the kernel's header): seconds since this workgroup's first pass
+    granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
+  stamp(4);
+  return ok;
+}
+
 __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_lm_kernel(LmLanePtrs lanes) {
-  extern __shared__ double ctl_lds[];  // the step control's workspace
-  __shared__ double sStep[RES_STEP_LDS_DOUBLES];  // [dc | candidate poses | current poses], built in place by the step control
-  __shared__ IterShared sh;
+  extern __shared__ double lds[];  // ba_lm_lds_doubles(n, K)
+  __shared__ LmShared sh;
   __shared__ LmDevState cs;
-  __shared__ int2 sPairPos[8][128];  // destination rows of every lane's Schur pairs (ChunkRegs::pp)
   __shared__ __align__(16) unsigned char sLaneRaw[sizeof(LmLane)];
   LmLane& sLane = *reinterpret_cast<LmLane*>(sLaneRaw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1688,96 +1607,87 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = tid; i < (int)(sizeof(LmLane) / 4); i += blockDim.x) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   __syncthreads();
-  constexpr int CPW = 2;  // both waves of a workgroup own a wave chunk
-  const int n_blocks = (sLane.P.C + CPW - 1) / CPW;  // workers of THIS solve; the launch is as wide as its largest solve (+ 1)
-  if ((int)blockIdx.x > n_blocks) return;
-  const bool reducer = (int)blockIdx.x == n_blocks;  // owns no chunk: takes the chained decisions, see lm_iterate
+  const int n_blocks = (sLane.P.C + LM_CPW - 1) / LM_CPW;  // workgroups of THIS solve; the launch is as wide as its largest solve
+  if ((int)blockIdx.x >= n_blocks) return;
   BaDev P = sLane.P;
   const LmDevArgs& a = sLane.a;
-  const ListArgs& la = sLane.la;
-  const int lm_begin = sLane.lm_begin, lm_count = sLane.lm_count;
-  const int my_chunk = (int)blockIdx.x * CPW + wave;
-  const bool my_wave_works = !reducer && my_chunk < P.C;
+  const int n = P.n, K = P.K, nn = n > 0 ? n : 1;
+  const int union_doubles = (int)ba_lm_union_doubles(n, K);
+  double* union_lds = lds;                                         // staging rows + landmark scalars | controller workspace
+  double* rec = lds + wave * WAVE_LDS_DOUBLES;
+  double* lms = rec + 64 * REC_STRIDE;
+  uint16_t* tabs = reinterpret_cast<uint16_t*>(lds + union_doubles) + wave * TAB_LDS_WORDS;
+  double* cSc = lds + union_doubles + LM_CPW * TAB_LDS_WORDS / 4;  // persistent: Jacobi scales of the pose columns
+  double* sStep = cSc + 2 * nn;                                    // [dc | candidate poses | current poses] (the second nn: spare)
+  const int my_chunk = (int)blockIdx.x * LM_CPW + wave;
+  const bool my_wave_works = my_chunk < P.C;
   __builtin_amdgcn_s_setprio(3);
   P.step_in = nullptr;  // the step block is built in LDS by the step control
-  P.pay2_out = a.dev_pay; P.pay1_out = a.dev_pay + 2 * PAY_STAGE_STRIDE; P.pay_dev = 1;  // granules: [payload2 (8) | decision (8) | 16 per reduction slice]
-  P.arrive = a.cnt + LMC_ARRIVE;
-  P.flag = reinterpret_cast<int*>(a.cnt + LMC_CTL + 4);  // a word nobody reads: completion is the arrival counter itself
-  P.seq = 0;
-  P.ctl_dev = a.dev_pay + 2 * 8;
+  P.flag = nullptr;
   if (tid == 0) { cs.state = LMS_START; cs.bad = 0; cs.accepted = 0; }
-  // this wave's observations, landmarks and destination rows: loaded ONCE (the problem image was copied in front of the launch)
+  // this wave's observations, landmarks and chunk table: loaded ONCE, read in place from the pinned problem image
   LmWave W;
   W.R = ObsRec{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
   W.cand = D3{0, 0, 1};
+  W.c.s[0] = W.c.s[1] = W.c.s[2] = 1.0;
   const ptrdiff_t shift = a.arena_src ? reinterpret_cast<const char*>(a.arena_src) - reinterpret_cast<const char*>(a.arena_dst) : 0;
   if (my_wave_works) {
     W.R = load_obs_image(P, my_chunk, lane, a.points_a, shift);
     // the device copy of the current landmarks (DELIVER exports from the buffer the step control selected; pass B fills the other one)
     if (shift && W.R.active && lane == W.R.first) { a.points_a[3 * W.R.j] = W.R.p.x; a.points_a[3 * W.R.j + 1] = W.R.p.y; a.points_a[3 * W.R.j + 2] = W.R.p.z; }
+    load_chunk_table(P, my_chunk, tabs, shift);
   }
-  load_chunk_regs(P, W.R, W.c, &sPairPos[0][tid], 128, shift, reinterpret_cast<long long*>(sStep + wave * (RES_STEP_LDS_DOUBLES / CPW)));  // the step block is built later
+  const ChunkTab T{tabs, (K - 1) * K / 2, K - 1};
+  long long t_first = 0;
   __syncthreads();
   for (;;) {
     const int st_before = cs.state;
-    const int op = lm_controller(P, a, cs, ctl_lds, sStep);
+    const int op = lm_controller(P, a, cs, union_lds, cSc, sStep, sh.sOut);
     if (a.dbg && tid == 0) {
       unsigned* g = a.dbg + 16 * blockIdx.x;
       g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
       g[4] = (unsigned)cs.chain | ((unsigned)cs.bad << 8);  // bit 8: a tagged granule never arrived
-      g[5] = cs.arrive_total; g[6] = cs.done_total; g[7] = (unsigned)cs.lin_calls;
+      g[5] = cs.arrive_total; g[6] = cs.op_count; g[7] = (unsigned)cs.lin_calls;
     }
     if (op == LMOP_ABORT || cs.bad) return;
     if (op == LMOP_EXIT) break;
     if (st_before == LMS_STEP && cs.accepted) W.R.p = W.cand;  // the step control took the step: the candidate is the current point
+    if (!t_first) t_first = (long long)wall_clock64();
     const bool sel = cs.sel != 0;
     P.points = sel ? a.points_b : a.points_a;
     P.cand_points = sel ? a.points_a : a.points_b;
-    P.arrive_target = cs.arrive_total;
     P.pay_tag = cs.tag;
+    P.pay_parity = (int)(cs.op_count & 1u);
     if (op == LMOP_DELIVER) {
       if (a.export_points && my_wave_works) {
         ObsRec R = W.R;  // the landmarks of the buffer the step control selected (a chained pass A may have run ahead of a step that was not taken)
         if (R.active) R.p = D3{P.points[3 * R.j], P.points[3 * R.j + 1], P.points[3 * R.j + 2]};
-        deliver_chunk_points(R, a.export_points, sStep + wave * (RES_STEP_LDS_DOUBLES / CPW), RES_STEP_LDS_DOUBLES / CPW);  // the step block is no longer needed
+        deliver_chunk_points(R, a.export_points, rec, 64 * REC_STRIDE);  // the staging rows are idle
       }
-      // everybody's results are out; the last worker to arrive publishes the host's completion word
+      // everybody's results are out; the last workgroup to arrive publishes the host's completion word
       stores_acknowledged();
       __syncthreads();
-      if (tid == 0 && !reducer) {
+      if (tid == 0) {
         const unsigned old = __hip_atomic_fetch_add(a.cnt + LMC_ARRIVE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old + 1u == P.arrive_target) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (old + 1u == cs.arrive_total) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       __syncthreads();
       continue;  // the next controller turn answers "delivered": everybody leaves
     }
-    IterSync sy;
-    sy.arrived = a.cnt + LMC_ARRIVED; sy.arrived_target = cs.arrived_total;
-    sy.posted = a.cnt + LMC_POSTED; sy.post_seq = cs.post_seq;
-    sy.done = a.cnt + LMC_DONE; sy.done_target = cs.done_total;
-    const double radius = cs.radius;
     long long* tp = a.dbg ? cs.tp : nullptr;
     if (op == LMOP_ITERATE) {
-      const LmCtl ctl = {cs.cost, cs.mcc, radius, cs.df, cs.chain};
-      if (!lm_iterate<CPW>(P, W, my_wave_works, reducer, radius, cs.spec, ctl, cs.chain || cs.spec > 0, lm_begin, lm_count, la, sy, sStep, sh, n_blocks, tp)) return;
-    } else {  // pass A alone at the current point, then the reduction
+      if (!lm_iterate(P, a, W, my_wave_works, T, rec, lms, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, tp)) return;
+    } else {  // pass A alone at the current point, then level 2
       const int first = cs.first;
-      if (my_wave_works) {
-        double unused0 = 0, unused1 = 0;
-        linearize_chunk<true>(P, W.R, sStep + (P.n > 0 ? P.n : 1) + 7 * P.K, radius, first, nullptr, nullptr, nullptr, nullptr, unused0, unused1, &W.c);
-        stores_acknowledged();
-      }
+      const double radius = cs.radius;
+      if (my_wave_works) linearize_chunk_det(P, W.R, sStep + nn + 7 * K, radius, first, T, rec, lms, make_sink(P, my_chunk, 1), &W.c);
       __syncthreads();
-      if (!reducer && tid == 0) __hip_atomic_fetch_add(sy.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int nb = ba_reduce_blocks(P.K - 1);
-      const int slot = reducer ? 0 : (int)blockIdx.x + 1;  // slice owners: the reducer first, then the workers
-      if (slot < nb) {
-        if (tid == 0) sh.sGo = wait_until(sy.done, sy.done_target, true);
-        __syncthreads();
-        if (!sh.sGo) return;
-        for (int sl = slot; sl < nb; sl += n_blocks + 1) reduce_slice<true>(P, la, sl, sh.sP);
-        reduce_publish(P);
-      }
+      const int per = (P.E + n_blocks - 1) / n_blocks;
+      const int e0 = min(P.E, (int)blockIdx.x * per), e1 = min(P.E, e0 + per);
+      double* res = a.dev_res;
+      const unsigned long long tag = P.pay_tag;
+      if (!reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); })) return;
+      if (blockIdx.x == 0 && tid == 0) granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
     }
     __syncthreads();
   }
@@ -2084,7 +1994,11 @@ struct svo_ba {
   void* comm = nullptr;                   // ncclComm_t of a sharded run (svo_ba_set_comm)
   // device problem
   BaDev d;
-  size_t cap_points = 0, cap_obs = 0, cap_pay1 = 0, cap_pairs = 0;
+  size_t cap_points = 0, cap_obs = 0, cap_pay1 = 0;
+  size_t cap_part1 = 0, cap_part2 = 0, cap_res = 0;   // granules of the partial store / of ba_lm_kernel's totals
+  double* d_res = nullptr;          // ba_lm_kernel: the E wire totals of the running iteration (+ the posted clock), tagged granules
+  unsigned long long tag_seq = 0;   // host-driven launches: one tag per op (ba_next_tag)
+  int tab_max_words = 0;            // largest chunk table of the loaded problem (u16 words)
   std::vector<double> h_poses;            // K x 7 current poses (updated in place by svo_lm_solve)
   int n_points = 0;
   uint8_t* d_arena = nullptr;     // all per-solve inputs in one allocation: one H2D per solve
@@ -2107,16 +2021,15 @@ struct svo_ba {
   FusedAdmission res_admission;  // ba_lm_kernel's workgroups, admitted for the duration of a solve
   // device-resident solve (ba_lm_kernel): counter block, pinned result block, state of the launch in flight
   unsigned* d_lmc = nullptr;
-  double* d_pay_fg = nullptr;    // [payload2 | payload1] of ba_lm_kernel in FINE-GRAINED device memory (see ba_alloc)
   unsigned* d_lmdbg = nullptr;   // SVO_BA_TRACE: last command of every workgroup of ba_lm_kernel
   double* h_result = nullptr;    // pinned [LMR_DOUBLES | poses 7 Kmax], inside h_pin
   int device_lm = -1;            // svo_ba_set_device_lm: -1 automatic, 0 never, 1 whenever eligible
   bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
   hipStream_t lm_stream = nullptr;  // ... on this stream
   LmLane* h_lane = nullptr;      // pinned launch record of this adjuster's solve
-  unsigned lm_base[5] = {0, 0, 0, 0, 0};  // where the last solve left the device counters (arrive, done, arrived, posted, copied)
-  bool lm_counters_dirty = false;  // the last kernel did not leave through its clean exit: zero the counters before the next launch
-  bool lm_have_base = false;       // lm_base describes the counters (false until the first clean solve)
+  unsigned lm_base = 0;            // where the last solve left the delivery counter
+  bool lm_counters_dirty = false;  // the last kernel did not leave through its clean exit: zero the counter before the next launch
+  bool lm_have_base = false;       // lm_base describes the counter (false until the first clean solve)
   bool arena_partial = false;      // the last solve read the problem image from h_arena in place: d_arena lacks the tables, h_arena the solved state
   size_t arena_cpts_off = 0, arena_p0_off = 0, arena_p1_off = 0;
   std::chrono::steady_clock::time_point lm_t0;
@@ -2134,10 +2047,9 @@ struct svo_ba {
   std::vector<int64_t> solve_lm_ids;
   std::vector<double> s_poses, s_points, s_uv, s_out_pts;   // per-solve scratch of svo_ba_solve (kept: no allocation per keyframe)
   std::vector<int32_t> s_op, s_oj;
-  std::vector<int32_t> u_lm_start, u_chunks, u_pair_base, u_pair_pos, u_obs_pos, u_ls, u_cnt, u_fill;  // scratch of ba_upload
-  std::vector<int32_t> h_list_begin, h_list_end;
-  size_t n_pair_rows = 0;
-  unsigned* d_arrive = nullptr; unsigned arrive_total = 0, done_total = 0, arrived_total = 0, post_seq = 0; int seq = 0;
+  std::vector<int32_t> u_lm_start, u_chunks, u_cnt;  // scratch of ba_upload
+  std::vector<uint16_t> u_tab; std::vector<uint32_t> u_tab_off;  // the chunk tables of the loaded problem
+  unsigned* d_arrive = nullptr; unsigned arrive_total = 0; int seq = 0;
   bool upload_pending = false;  // H2D of the problem image enqueued, not yet known complete
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
@@ -2152,43 +2064,51 @@ static int ba_alloc(svo_ba* ba) {
   BaDev& d = ba->d;
   const int Kmax = ba->max_poses, nmax = 6 * (Kmax - 1);
   ba->cap_points = ba->max_landmarks; ba->cap_obs = ba->max_obs;
-  ba->cap_pay1 = (size_t)nmax * nmax + 3 * (size_t)nmax + 2;
+  ba->cap_pay1 = std::max((size_t)nmax * nmax + 3 * (size_t)nmax + 2, (size_t)(18 * (Kmax - 1) * Kmax + 33 * (Kmax - 1) + 2));  // payload1, or the wire totals
   const size_t step_doubles = (size_t)(nmax > 0 ? nmax : 1) + 7 * (size_t)Kmax;
 #define A(ptr, T, cnt) SVO_HIP_CHECK(ctx, hipMalloc((void**)&(ptr), sizeof(T) * (size_t)(cnt)))
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
-  // Payload staging (tagged granules, see granule_store) and the counter block of the device-resident solve: ordinary
-  // device memory.  (Fine-grained memory was tried for both while chasing stale reads: it did not help the payload — the
-  // tags did — and the arrival counters LOST increments there: 38 workgroups had added to a counter that read 37.)
-  A(ba->d_pay_fg, double, 2 * PAY_STAGE_STRIDE * (1 + (size_t)ba_reduce_blocks(Kmax - 1)));
+  // The counter block of the device-resident solve: ordinary device memory (fine-grained memory LOST atomic increments
+  // when it was tried in round 3: 38 workgroups had added to a counter that read 37).  The granule stores (partials, totals)
+  // are sized by the problem: ba_ensure_partials.
   A(ba->d_lmc, unsigned, LMC_WORDS);
   SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_lane, sizeof(LmLane), hipHostMallocCoherent));
   if (getenv("SVO_BA_TRACE")) A(ba->d_lmdbg, unsigned, 16 * 4096);
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned)));
   A(ba->d_arrive, unsigned, 16);  // [arrival counter | pad | chained decision: 2 doubles at +8 bytes | +32 bytes: pass-A done counter, pass-B arrival counter, decision post]
   SVO_HIP_CHECK(ctx, hipMemset(ba->d_arrive, 0, 16 * sizeof(unsigned)));
-  A(d.obsV, double, 18 * ba->cap_obs);
-  A(d.lmV, double, 4 * ba->cap_points);
-  A(d.lmV2, double, 4 * ba->cap_points);
 #undef A
   {
     // pre-size the per-solve input arena and the pair-block store for window-shaped problems (every landmark seen
     // at most once per pose) so that the hot path never allocates; bulk problems beyond this grow lazily
     const size_t M = ba->cap_obs, Kc = (size_t)Kmax;
-    const size_t pairs = M * (Kc + 1) / 2 + 64;
+    const size_t pairs = M * (Kc + 1) / 2 + 64;  // upper bound of the chunk tables' pair entries (2 bytes each)
     // per-slot arrays are padded to whole waves: a chunk closes when the next landmark would not fit, i.e. it holds more
     // than 64 - max(landmark length) observations; 2 M + 64 slots bound it for landmark lengths <= 32
     const size_t slots = 2 * M + 64;
-    const size_t est = 16 * 3 * ba->cap_points + (16 + 16 + 4 + 4) * slots + 8 * pairs + 8 * (Kc * Kc + Kc + 2) + 2 * 56 * Kc + 16 * 256;
+    const size_t est = 16 * 3 * ba->cap_points + (16 + 16) * slots + 2 * pairs + (slots / 64 + 2) * (2 * (Kc * Kc + 2 * Kc + 4) + 64 + 4) + 2 * 56 * Kc + 16 * 256;
     if (est < ((size_t)512 << 20)) {
       ba->arena_cap = est;
       SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_arena, ba->arena_cap));
       SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_arena, ba->arena_cap, hipHostMallocDefault));
     }
-    if (2 * pairs * 288 < ((size_t)512 << 20)) {
-      ba->cap_pairs = 2 * pairs;
-      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
+  }
+  {
+    // the granule stores for window-shaped problems up front (<= 128 chunks: one group per chunk), so that the hot path never
+    // allocates; larger problems grow them in ba_ensure_partials
+    const size_t Fm = (size_t)Kmax - 1, Em = 18 * Fm * (Fm + 1) + 33 * Fm + 2;
+    if (Em * 128 * 16 <= ((size_t)64 << 20)) {
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part1, 16 * Em * 128));
+      SVO_HIP_CHECK(ctx, hipMemset(d.part1, 0, 16 * Em * 128));
+      ba->cap_part1 = Em * 128;
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part2, 16 * 2 * 4 * 128));
+      SVO_HIP_CHECK(ctx, hipMemset(d.part2, 0, 16 * 2 * 4 * 128));
+      ba->cap_part2 = 2 * 4 * 128;
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_res, 16 * (Em + 1)));
+      SVO_HIP_CHECK(ctx, hipMemset(ba->d_res, 0, 16 * (Em + 1)));
+      ba->cap_res = Em + 1;
     }
   }
   {
@@ -2268,12 +2188,12 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
                     "+ own share of the passes %.1f; steps %ld (same sweep %ld, next linearisation used %ld), stand-alone linearisations %ld\n", ba->lm_n, (double)ba->lm_iters / ba->lm_n, 1e-2 * ba->lm_t_total / ba->lm_n, 1e-2 * ba->lm_t_wait / ba->lm_n,
             1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n, ba->lm_steps, ba->lm_same, ba->lm_used, ba->lm_lins);
   if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg)
-    fprintf(stderr, "[svo ba]   per LM iteration (workgroup 0, us): pass B %.2f, radius-free part of pass A %.2f, decision wait %.2f, rest of pass A %.2f, wait for all passes A %.2f, "
-                    "reduction slices %.2f (of which walking the lists %.2f) | payload fetch %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
-            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters, 1e-2 * ba->lm_tp[5] / ba->lm_iters,
-            1e-2 * ba->lm_tp[10] / ba->lm_iters, 1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
+    fprintf(stderr, "[svo ba]   per LM iteration (workgroup 0, us): pass B %.2f, radius-free part of pass A %.2f, collecting payload2 + decision %.2f, rest of pass A %.2f, "
+                    "own slice of level 2 incl. waiting for the partials %.2f | collecting the totals + assembly %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
+            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters,
+            1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
-  void* ptrs[] = {ba->d_pay_fg, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.pairB, d.obsV, d.lmV, d.lmV2, ba->d_arena};
+  void* ptrs[] = {ba->d_res, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.part1, d.part2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2313,6 +2233,29 @@ extern "C" int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats) {
 // Destination index of pose-pair block (ka <= kb) among the F (F + 1) / 2 upper blocks, row-major.
 static inline int ba_upper_index(int ka, int kb, int F) { return ka * F - ka * (ka - 1) / 2 + (kb - ka); }
 
+// The granule stores of the loaded problem: partials of pass A (E x NGpad), of pass B (2 x NG x 4), ba_lm_kernel's totals
+// (E + 1).  Window-sized problems reach their sizes within a few keyframes; nothing is allocated per solve afterwards.
+// Fresh stores are zeroed: no command ever carries tag 0.
+static int ba_ensure_partials(svo_ba* ba) {
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  auto grow = [&](double** p, size_t* cap, size_t granules) -> int {
+    if (granules <= *cap) return SVO_OK;
+    if (ba->upload_pending || ba->lm_inflight) SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+    if (*p) SVO_HIP_CHECK(ctx, hipFree(*p));
+    *p = nullptr;
+    const size_t want = granules + granules / 2 + 64;
+    SVO_HIP_CHECK(ctx, hipMalloc((void**)p, 16 * want));
+    SVO_HIP_CHECK(ctx, hipMemset(*p, 0, 16 * want));
+    *cap = want;
+    return SVO_OK;
+  };
+  int rc = grow(&d.part1, &ba->cap_part1, (size_t)d.E * (size_t)(d.NGpad > 0 ? d.NGpad : 8));
+  if (!rc) rc = grow(&d.part2, &ba->cap_part2, 2 * 4 * (size_t)(d.NG > 0 ? d.NG : 1));
+  if (!rc) rc = grow(&ba->d_res, &ba->cap_res, (size_t)d.E + 1);
+  return rc;
+}
+
 static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, const double* points3, int M,
                      const int32_t* op, const int32_t* oj, const double* uv) {
   svo_ctx* ctx = ba->ctx;
@@ -2350,88 +2293,87 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   d.C = (int)chunks.size() - 1;
   d.L = npts;
   hipStream_t st = ba->stream;
-  std::vector<int32_t>&pair_base_v = ba->u_pair_base, &pair_pos_v = ba->u_pair_pos, &obs_pos_v = ba->u_obs_pos, &ls = ba->u_ls;
-  pair_pos_v.clear(); ls.clear();
-  // deterministic mode: pair slots + destination lists (landmark order) if they fit
+  std::vector<uint16_t>& tab = ba->u_tab;
+  std::vector<uint32_t>& tab_off = ba->u_tab_off;
+  tab.clear(); tab_off.clear();
+  ba->tab_max_words = 0;
   {
     const int F = K - 1;
-    pair_base_v.assign((size_t)M + 1, 0);
     bool dup = false;
     for (int j = 0; j < npts; ++j) {
       uint64_t seen = 0;
       for (int o = lm_start[j]; o < lm_start[j + 1]; ++o) {
-        pair_base_v[o + 1] = pair_base_v[o] + (lm_start[j + 1] - o);
         const uint64_t bit = 1ull << op[o];
         dup |= (seen & bit) != 0;
         seen |= bit;
       }
     }
-    const size_t n_pairs = (size_t)pair_base_v[M];
-    d.det = n_pairs <= ((size_t)1 << 21) ? 1 : 0;  // <= 604 MB of pair blocks
+    // deterministic mode ("chunk order"): G chunks per group, NG groups, E wire elements; the partial store holds E x NG granules
+    const int nU = F * (F + 1) / 2;
+    d.G = d.C <= 128 ? 1 : (d.C + 127) / 128;
+    d.NG = d.C > 0 ? (d.C + d.G - 1) / d.G : 0;
+    d.NGpad = (d.NG + 7) & ~7;
+    d.E = 36 * nU + 33 * F + 2;
+    d.det = (size_t)d.E * (size_t)(d.NGpad > 0 ? d.NGpad : 8) * 16 <= ((size_t)512 << 20) ? 1 : 0;
     if (ba->opt.accumulation == SVO_BA_ACC_ATOMICS || ba->opt.accumulation == SVO_BA_ACC_MFMA) d.det = 0;
     SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_DETERMINISTIC && !d.det), "ba: problem too large for deterministic accumulation");
     ba->mfma_ok = !dup && d.n <= 128 && d.n > 0 && ba->opt.accumulation != SVO_BA_ACC_ATOMICS;
     SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_MFMA && !ba->mfma_ok), "ba: MFMA accumulation needs <= 22 poses and one observation per (landmark, pose)");
-    ba->h_list_begin.clear(); ba->h_list_end.clear();
     if (d.det) {
-      // Destination lists in landmark order.  S is symmetric and the list of block (kb, ka) holds the transposes of the
-      // list of (ka, kb) in the same order, so its sums are the exact transpose: only the F (F + 1) / 2 blocks ka <= kb
-      // are stored and reduced, the host mirrors them.  Then F pose lists; the landmark list is the identity over [0, npts).
-      const int nU = F * (F + 1) / 2, nd = nU + F + 1;
-      std::vector<int32_t>&cnt = ba->u_cnt, &fill = ba->u_fill;
-      cnt.assign(nd, 0);
-      pair_pos_v.assign(2 * n_pairs + 2, -1);
-      obs_pos_v.assign((size_t)M + 1, -1);
-      for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) {
-          // block lists are back to back in pairB, pose lists back to back in obsV, the landmark list is
-          // rows [0, npts) of lmV
-          ba->h_list_begin.assign(nd, 0); ba->h_list_end.assign(nd, 0);
-          int32_t acc = 0;
-          for (int q = 0; q < nU; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
-          ba->n_pair_rows = (size_t)acc;
-          acc = 0;
-          for (int q = nU; q < nU + F; ++q) { ba->h_list_begin[q] = acc; acc += cnt[q]; ba->h_list_end[q] = acc; }
-          ba->h_list_begin[nU + F] = 0; ba->h_list_end[nU + F] = npts;
-        }
-        fill.assign(nd, 0);
-        for (int j = 0; j < npts; ++j) {
-          const int o1 = lm_start[j + 1];
-          for (int i = lm_start[j]; i < o1; ++i) {
-            const int ki = op[i] - 1;
-            if (ki < 0) continue;
-            if (pass == 0) cnt[nU + ki]++;
-            else obs_pos_v[i] = ba->h_list_begin[nU + ki] + fill[nU + ki]++;
-            for (int t = i; t < o1; ++t) {
-              const int kt = op[t] - 1;
-              if (kt < 0) continue;
-              // B enters block (ki, kt), its transpose block (kt, ki): whichever of them is an upper block is stored
-              // (both when ki == kt for t != i: two observations of one landmark in one pose)
-              const int slot = pair_base_v[i] + (t - i);
-              const bool fwd = ki <= kt, rev = t != i && kt <= ki;
-              const int da = fwd ? ba_upper_index(ki, kt, F) : 0, db = rev ? ba_upper_index(kt, ki, F) : 0;
-              if (pass == 0) { if (fwd) cnt[da]++; if (rev) cnt[db]++; }
-              else {
-                if (fwd) pair_pos_v[2 * slot] = ba->h_list_begin[da] + fill[da]++;
-                if (rev) pair_pos_v[2 * slot + 1] = ba->h_list_begin[db] + fill[db]++;
-              }
-            }
+      // Chunk tables (ChunkTab): per chunk the pair entries of every UPPER pose-pair block in (landmark, i, t) order — pair
+      // (i, t >= i) enters block (k_i, k_t) when k_i <= k_t and, transposed, block (k_t, k_i) when t != i and k_t <= k_i (two
+      // observations of one landmark in one pose: both, the direct entry first) — and the lanes of every free pose.
+      std::vector<int32_t>& cur = ba->u_cnt;  // fill cursors: nU block lists, then F pose lists
+      tab_off.reserve((size_t)d.C + 1);
+      tab.reserve((size_t)M * 3 + (size_t)d.C * (size_t)(nU + F + 4));
+      for (int c = 0; c < d.C; ++c) {
+        const int c0 = chunks[c], c1 = chunks[c + 1];
+        cur.assign((size_t)nU + (size_t)F + 2, 0);
+        // pass 1: list lengths
+        for (int i = c0; i < c1; ++i) {
+          const int ki = op[i] - 1;
+          if (ki < 0) continue;
+          cur[nU + ki]++;
+          const int o1 = lm_start[oj[i] + 1];
+          for (int t = i; t < o1; ++t) {
+            const int kt = op[t] - 1;
+            if (kt < 0) continue;
+            if (ki <= kt) cur[ba_upper_index(ki, kt, F)]++;
+            if (t != i && kt <= ki) cur[ba_upper_index(kt, ki, F)]++;
           }
         }
+        tab_off.push_back((uint32_t)tab.size());
+        const size_t t0 = tab.size();
+        int n_ent = 0, n_free = 0;
+        for (int q = 0; q < nU; ++q) { const int len = cur[q]; cur[q] = n_ent; tab.push_back((uint16_t)n_ent); n_ent += len; }
+        tab.push_back((uint16_t)n_ent);
+        for (int k = 0; k < F; ++k) { const int len = cur[nU + k]; cur[nU + k] = n_free; tab.push_back((uint16_t)n_free); n_free += len; }
+        tab.push_back((uint16_t)n_free);
+        const size_t e_at = tab.size();
+        tab.resize(e_at + (size_t)n_ent + (size_t)((n_free + 1) / 2), 0);
+        uint16_t* ent = tab.data() + e_at;
+        uint8_t* plane = reinterpret_cast<uint8_t*>(ent + n_ent);
+        // pass 2: fill, every list in (landmark, i, t) / lane order
+        for (int i = c0; i < c1; ++i) {
+          const int ki = op[i] - 1;
+          if (ki < 0) continue;
+          plane[cur[nU + ki]++] = (uint8_t)(i - c0);
+          const int o1 = lm_start[oj[i] + 1];
+          for (int t = i; t < o1; ++t) {
+            const int kt = op[t] - 1;
+            if (kt < 0) continue;
+            if (ki <= kt) ent[cur[ba_upper_index(ki, kt, F)]++] = (uint16_t)((i - c0) | ((t - c0) << 8));
+            if (t != i && kt <= ki) ent[cur[ba_upper_index(kt, ki, F)]++] = (uint16_t)((i - c0) | 0x80 | ((t - c0) << 8));
+          }
+        }
+        if ((tab.size() - t0) & 1) tab.push_back(0);  // tables start on even u16 offsets (read as 32-bit words)
+        ba->tab_max_words = std::max(ba->tab_max_words, (int)(tab.size() - t0));
       }
-      const size_t rows = ba->n_pair_rows;
-      if (rows > ba->cap_pairs) {
-        if (d.pairB) (void)hipFree(d.pairB);
-        d.pairB = nullptr;
-        ba->cap_pairs = rows + rows / 4 + 1024;
-        SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.pairB, sizeof(double) * 36 * ba->cap_pairs));
-      }
-      ls.assign(2 * (size_t)nd + 2, 0);  // list_start[q] = begin(q), list_start[nd + 1 + q] = end(q)
-      for (int q = 0; q < nd; ++q) { ls[q] = ba->h_list_begin[q]; ls[nd + 1 + q] = ba->h_list_end[q]; }
+      tab_off.push_back((uint32_t)tab.size());
     }
   }
   // ---- one pinned staging image, one H2D: [points | points (candidate copy) | per-slot records | per-slot uv |
-  //      per-slot pair_base | per-slot obs_pos | pair_pos | list_start | poses x 2]
+  //      chunk tables | table offsets | poses x 2]
   const size_t nslots = (size_t)d.C * 64;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   size_t off = 0;
@@ -2440,10 +2382,8 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   const size_t o_cpts = off; off = al(off + sizeof(double) * 3 * (size_t)npts);
   const size_t o_rec = off; off = al(off + sizeof(int4) * nslots);
   const size_t o_uv = off; off = al(off + sizeof(double) * 2 * nslots);
-  const size_t o_pb = off; off = al(off + sizeof(int32_t) * (d.det ? nslots : 0));
-  const size_t o_ob = off; off = al(off + sizeof(int32_t) * (d.det ? nslots : 0));
-  const size_t o_pp = off; off = al(off + sizeof(int32_t) * pair_pos_v.size());
-  const size_t o_ls = off; off = al(off + sizeof(int32_t) * ls.size());
+  const size_t o_tab = off; off = al(off + sizeof(uint16_t) * tab.size());
+  const size_t o_toff = off; off = al(off + sizeof(uint32_t) * tab_off.size());
   const size_t o_p0 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
   const size_t o_p1 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
   const size_t total = off;
@@ -2460,8 +2400,6 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   {
     int4* rec = reinterpret_cast<int4*>(h + o_rec);
     double* suv = reinterpret_cast<double*>(h + o_uv);
-    int32_t* spb = reinterpret_cast<int32_t*>(h + o_pb);
-    int32_t* sob = reinterpret_cast<int32_t*>(h + o_ob);
     for (int c = 0; c < d.C; ++c) {
       const int c0 = chunks[c], c1 = chunks[c + 1];
       for (int lane = 0; lane < 64; ++lane) {
@@ -2471,24 +2409,21 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
           const int j = oj[o];
           rec[slot] = int4{op[o], j, lm_start[j] - c0, lm_start[j + 1] - lm_start[j]};
           suv[2 * slot] = uv[2 * (size_t)o]; suv[2 * slot + 1] = uv[2 * (size_t)o + 1];
-          if (d.det) { spb[slot] = pair_base_v[o]; sob[slot] = obs_pos_v[o]; }
         } else {
           rec[slot] = int4{-1, 0, lane, 0};
           suv[2 * slot] = 0.0; suv[2 * slot + 1] = 0.0;
-          if (d.det) { spb[slot] = 0; sob[slot] = -1; }
         }
       }
     }
   }
-  if (!pair_pos_v.empty()) memcpy(h + o_pp, pair_pos_v.data(), sizeof(int32_t) * pair_pos_v.size());
-  if (!ls.empty()) memcpy(h + o_ls, ls.data(), sizeof(int32_t) * ls.size());
+  if (!tab.empty()) memcpy(h + o_tab, tab.data(), sizeof(uint16_t) * tab.size());
+  if (!tab_off.empty()) memcpy(h + o_toff, tab_off.data(), sizeof(uint32_t) * tab_off.size());
   uint8_t* D = ba->d_arena;
   d.points = (double*)(D + o_pts); d.cand_points = (double*)(D + o_cpts);
   ba->cur_points = (double*)(D + o_pts); ba->cand_points = (double*)(D + o_cpts);
   ba->cur_poses = (double*)(D + o_p0); ba->cand_poses = (double*)(D + o_p1);
   d.rec = (const int4*)(D + o_rec); d.obs_uv = (const double*)(D + o_uv);
-  d.pair_base = (int32_t*)(D + o_pb); d.obs_pos = (int32_t*)(D + o_ob);
-  d.pair_pos = (int32_t*)(D + o_pp); d.list_start = (int32_t*)(D + o_ls);
+  d.tab = (const uint16_t*)(D + o_tab); d.tab_off = (const uint32_t*)(D + o_toff);
   memcpy(h + o_p0, poses7, sizeof(double) * 7 * (size_t)K);
   memcpy(h + o_p1, poses7, sizeof(double) * 7 * (size_t)K);
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
@@ -2500,10 +2435,8 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   ba->arena_dirty = true;
   ba->arena_partial = false;
   ba->arena_cpts_off = o_cpts; ba->arena_p0_off = o_p0; ba->arena_p1_off = o_p1;
-  if (d.det && has_empty_landmark && npts) {
-    SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV, 0, sizeof(double) * 4 * npts, st));
-    SVO_HIP_CHECK(ctx, hipMemsetAsync(d.lmV2, 0, sizeof(double) * 4 * npts, st));
-  }
+  (void)has_empty_landmark; (void)st;
+  if (d.det) { const int rcp = ba_ensure_partials(ba); if (rcp) return rcp; }
   return SVO_OK;
 }
 
@@ -2624,20 +2557,47 @@ int ba_fetch(svo_ba* ba, size_t off, size_t cnt) {
   return SVO_OK;
 }
 
-// payload1 as the step control wants it: S full.  The deterministic reduce writes every pose-pair block; the bulk kernels
-// write each unordered pose pair once, mirrored here.
+// payload1 as the step control wants it: [S full | g_red | g_c | diag U | cost | sum g_p^2].  Deterministic mode: `src` holds
+// the E wire totals (Schur part of the upper pose-pair blocks | per pose g_c, -Y g_p, U triangle | cost, sum g_p^2), assembled
+// exactly as the oracle does: S[(k,a),(k,b)] = U_k[min][max] + Schur_(k,k)[a][b]; the lower blocks are exact transposes.
+// Bulk modes: `src` is payload1 with each unordered pose pair written once, mirrored here.
 void ba_payload1_out(svo_ba* ba, const double* src, double* dst) {
   const BaDev& d = ba->d;
-  const int n = d.n, K = d.K;
+  const int n = d.n, K = d.K, F = K - 1;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
-  memcpy(dst, src, sizeof(double) * pay1);
-  if (d.det) {  // upper pose-pair blocks were reduced; the lower ones are their exact transposes
-    for (int a = 0; a < K - 1; ++a)
-      for (int b = a + 1; b < K - 1; ++b)
-        for (int i = 0; i < 6; ++i)
-          for (int j = 0; j < 6; ++j) dst[(size_t)(6 * b + j) * n + 6 * a + i] = src[(size_t)(6 * a + i) * n + 6 * b + j];
+  if (d.det) {
+    const int nU = F * (F + 1) / 2;
+    double* gred = dst + (size_t)n * n;
+    double* gc = gred + n;
+    double* dU = gc + n;
+    for (int ka = 0; ka < F; ++ka)
+      for (int kb = ka; kb < F; ++kb) {
+        const double* blk = src + 36 * (size_t)ba_upper_index(ka, kb, F);
+        const double* U = src + 36 * (size_t)nU + 33 * (size_t)ka + 12;
+        for (int a = 0; a < 6; ++a)
+          for (int b = 0; b < 6; ++b) {
+            double v = blk[6 * a + b];
+            if (ka == kb) {
+              const int lo = a < b ? a : b, hi = a < b ? b : a;
+              v = U[lo * 6 - lo * (lo - 1) / 2 + (hi - lo)] + v;
+            }
+            dst[(size_t)(6 * ka + a) * n + 6 * kb + b] = v;
+            if (ka != kb) dst[(size_t)(6 * kb + b) * n + 6 * ka + a] = v;
+          }
+      }
+    for (int k = 0; k < F; ++k) {
+      const double* pv = src + 36 * (size_t)nU + 33 * (size_t)k;
+      for (int a = 0; a < 6; ++a) {
+        gc[6 * k + a] = pv[a];
+        gred[6 * k + a] = pv[6 + a];
+        dU[6 * k + a] = pv[12 + a * 6 - a * (a - 1) / 2];
+      }
+    }
+    dst[pay1 - 2] = src[d.E - 2];
+    dst[pay1 - 1] = src[d.E - 1];
     return;
   }
+  memcpy(dst, src, sizeof(double) * pay1);
   for (int a = 0; a < K - 1; ++a)
     for (int b = 0; b < K - 1; ++b) {
       if (a == b) continue;
@@ -2687,34 +2647,26 @@ void ba_aim_reduce(svo_ba* ba, int n_blocks, bool publish) {
 
 const LmCtl kNoCtl = {0, 0, 0, 0, 0};
 
-// The whole LM iteration as ONE launch (ba_iterate_kernel) or as three (pass B, decision + pass A, reduction).  Measured
-// on MI355X: alone on the GPU the two device-wide waits cost more than the two launches they save (≈1,590 vs ≈1,700
-// frames/s); with 8 stereo streams the single launch wins (7,400 vs 6,250 frames/s).  Default: one launch when more than
-// two pipelines are inside process_batch (svo_throughput_mode, host/pipeline.cpp); SVO_BA_FUSED_REDUCE=0 / 1 forces either.
-bool ba_fused_reduce() {
-  static const char* e = getenv("SVO_BA_FUSED_REDUCE");
-  if (e && *e) return atoi(e) != 0;
-  return svo_throughput_mode();
-}
+// one tag per host-driven op (pass B / pass A launches of one step-control call share it; every slot of the partial
+// store is written at most once per op) — never 0, never in ba_lm_kernel's tag space (bit 62)
+unsigned long long ba_next_tag(svo_ba* ba) { ba->d.pay_tag = ++ba->tag_seq; ba->d.pay_parity = (int)(ba->tag_seq & 1ull); return ba->d.pay_tag; }
 
-// Workgroups of the fused launch WAIT for each other, so all of one launch must be able to become resident while the
-// waiting workgroups of every other adjuster's launch hold their wave slots: the process admits fused launches only
-// while their workgroups together fit in 7/8 of what the device can hold of this kernel (occupancy x CUs; kernels that
-// never wait always drain and hand their slots over, so the sum of the WAITING workgroups is what has to fit; measured:
-// budgets of 1/2, 3/4 and 1/1 of the capacity give 6,630 / 6,690 / 6,780 frames/s at 8 streams).  A launch that is not admitted takes the
-// separate-launch path for that iteration — same arithmetic, same results.  (Other PROCESSES on the GPU are not
-// counted; the kernel's bounded spin turns that unlikely pile-up into a reported error, never a hang.)
-int g_fused_per_cu = 0;  // workgroups per CU the budget is counted in (a property of the two kernels: the same on every gfx950 device)
+// Workgroups of ba_lm_kernel WAIT for each other (they collect each other's granules), so all of one launch must be able
+// to become resident while the waiting workgroups of every other adjuster's launch hold their wave slots: the process
+// admits such launches only while their workgroups together fit in 7/8 of what the device can hold of this kernel
+// (occupancy x CUs; kernels that never wait always drain and hand their slots over, so the sum of the WAITING workgroups
+// is what has to fit).  A solve that is not admitted takes the host-driven path — same arithmetic, same results.  (Other
+// PROCESSES on the GPU are not counted; the kernel's bounded waits turn that unlikely pile-up into a reported error,
+// never a hang.)
+int g_fused_per_cu = 0;  // workgroups per CU the budget is counted in (window-5 problems' occupancy)
 int ba_fused_budget(int device) {
   static std::mutex mu;
   static int budget[SVO_MAX_DEVICES], share_of[SVO_MAX_DEVICES];  // 0: not computed yet; recomputed when SVO_BA_CU_SHARE changes
   device = device >= 0 && device < SVO_MAX_DEVICES ? device : 0;
   std::lock_guard<std::mutex> g(mu);
   if (budget[device] && share_of[device] == g_ba_cu_share) return budget[device];
-  int per_cu = 0, per_cu_res = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_iterate_kernel, 128, 0) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_res, ba_lm_kernel, 128, 8192) != hipSuccess) return 0;
-  per_cu = std::min(per_cu, per_cu_res);  // one budget for both kernels whose workgroups wait: the tighter occupancy counts
+  int per_cu = 0, cus = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_lm_kernel, 128, sizeof(double) * ba_lm_lds_doubles(24, 5)) != hipSuccess) return 0;
   g_fused_per_cu = per_cu;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   share_of[device] = g_ba_cu_share;
@@ -2722,7 +2674,7 @@ int ba_fused_budget(int device) {
   return budget[device];
 }
 
-// What `grid` workgroups of ba_lm_kernel with `lds` bytes of step-control workspace cost in the units of that budget: a
+// What `grid` workgroups of ba_lm_kernel with `lds` bytes of dynamic LDS cost in the units of that budget: a
 // larger reduced camera system (10-keyframe windows) lowers the kernel's occupancy, its workgroups then count for more.
 int ba_lm_admission_cost(int grid, size_t lds, int device) {
   (void)ba_fused_budget(device);
@@ -2742,17 +2694,6 @@ int ba_lm_admission_cost(int grid, size_t lds, int device) {
   return (grid * g_fused_per_cu + per_cu - 1) / per_cu;
 }
 
-// destination lists as kernel arguments when they fit (every window-sized problem: K <= 6 free... F*F + F + 1 <= 48)
-ListArgs ba_list_args(const svo_ba* ba) {
-  ListArgs la;
-  la.n = 0;
-  const size_t nd = ba->h_list_begin.size();
-  if (!ba->d.det || nd == 0 || nd > 48) return la;
-  la.n = (int)nd;
-  for (size_t q = 0; q < nd; ++q) { la.begin[q] = ba->h_list_begin[q]; la.end[q] = ba->h_list_end[q]; }
-  return la;
-}
-
 inline FusedAdmission* ba_resident_admission(svo_ba* ba) { return &ba->res_admission; }
 
 // ---- device-resident solve (ba_lm_kernel): host side -------------------------------------------------------------
@@ -2766,86 +2707,87 @@ bool ba_device_lm_wanted() {
   return svo_throughput_mode();
 }
 
-size_t ba_lm_lds_bytes(const BaDev& d) { return sizeof(double) * ba_lm_ctl_doubles(d.n, d.K); }
+size_t ba_lm_lds_bytes(const BaDev& d) { return sizeof(double) * ba_lm_lds_doubles(d.n, d.K); }
 
-// Fills the adjuster's launch record for the loaded problem; false: not eligible (use the host-driven paths).
+// Fills the adjuster's launch record for the loaded problem; false: not eligible (use the host-driven path).
 bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   BaDev& d = ba->d;
   if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !(forced || ba->device_lm == 1 || (ba->device_lm < 0 && ba_device_lm_wanted())) || !ba->h_lane) return false;
-  if (ba->opt.max_time_s > 0 && ba->opt.max_time_s < LM_DEVICE_MIN_TIME_CAP_S) return false;  // see ba_lm_kernel
-  const int nd = (d.K - 1) * d.K / 2 + (d.K - 1) + 1;
-  if ((int)ba->h_list_begin.size() < nd || nd > 48) return false;  // the destination lists ride in the record
+  if (d.C > 128 || ba->tab_max_words > TAB_LDS_WORDS) return false;  // one group per chunk, every chunk table in LDS: window-sized problems
   const size_t lds = ba_lm_lds_bytes(d);
-  if (lds > 96 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
+  if (lds > 120 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   d.flag = nullptr;
+  if (ba->arena_partial && ba_refresh_arena_image(ba)) return false;  // a re-solve after a zero-copy solve: the host image takes the solved state first
   LmLane& L = *ba->h_lane;
   L.P = d;
   LmDevArgs& a = L.a;
   a.cnt = ba->d_lmc;
-  if (ba->arena_partial && ba_refresh_arena_image(ba)) return false;  // a re-solve after a zero-copy solve: the host image takes the solved state first
   a.arena_src = ba->arena_dirty ? ba->h_arena : nullptr;  // read in place by the kernel (zero copy); null: the device arena is complete
   a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;
   a.points_a = ba->cur_points; a.points_b = ba->cand_points;
   a.export_points = ba->n_points ? ba->h_out_points : nullptr;
-  a.dev_pay = ba->d_pay_fg;
+  a.dev_res = ba->d_res;
   a.host_result = ba->h_result;
   a.host_flag = ba->h_flag; a.host_seq = ba->seq + 1;  // committed by the launch
-  // the device counters run on from solve to solve (monotone, wrap-safe compares): no clearing launch in front of a solve
+  // the delivery counter runs on from solve to solve (monotone, wrap-safe compares): no clearing launch in front of a solve
   // unless the last one did not leave cleanly
   const bool fresh = ba->lm_counters_dirty || !ba->lm_have_base;
-  a.base_arrive = fresh ? 0 : ba->lm_base[0]; a.base_done = fresh ? 0 : ba->lm_base[1]; a.base_arrived = fresh ? 0 : ba->lm_base[2];
-  a.base_posted = fresh ? 0 : ba->lm_base[3]; a.base_copied = fresh ? 0 : ba->lm_base[4];
+  a.base_arrive = fresh ? 0 : ba->lm_base;
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
+  a.opt.max_time_s = ba->opt.max_time_s;  // src/bundle_adjuster.cpp:11, tested on workgroup 0's posted clock
   a.dbg = d.C <= 8192 ? ba->d_lmdbg : nullptr;
-  L.lm_begin = ba->h_list_begin[nd - 1];
-  L.lm_count = ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1];
-  L.la = ba_list_args(ba);
-  *cost = ba_lm_admission_cost((d.C + 1) / 2 + 1, lds, ba->ctx->device);
+  *cost = ba_lm_admission_cost((d.C + LM_CPW - 1) / LM_CPW, lds, ba->ctx->device);
   *lds_out = lds;
   return true;
 }
 
 // ONE launch for the solves of `n` adjusters (the lanes of a pipeline group that reached a keyframe together; n = 1: a
-// single pipeline) on stream `st`.  Returns how many of them — a prefix — were admitted and launched; the others keep
-// their loaded problem and can be offered again later, or solved by the host-driven paths.
-int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced) {
+// single pipeline) on stream `st`.  Returns how many were admitted and launched; `launched_mask` says which (an ineligible
+// or not admitted adjuster is skipped, not a barrier for those behind it).  The others keep their loaded problem and can be
+// offered again later, or solved by the host-driven path.
+int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsigned long long* launched_mask) {
   LmLanePtrs ptrs;
   int launched = 0, max_c = 0;
   size_t max_lds = 0;
+  svo_ba* took[SVO_MAX_LANES];
+  if (launched_mask) *launched_mask = 0;
   for (int i = 0; i < n && i < SVO_MAX_LANES; ++i) {
     svo_ba* ba = bas[i];
     int cost = 0;
     size_t lds = 0;
     ba->lm_inflight = false;
-    if (!ba_device_lm_fill(ba, &cost, &lds, forced)) break;
-    if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) break;
-    if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) break;
-    // the counters start from zero: cleared in front of the launch (the adjuster's previous solve no longer touches them
-    // once its completion word is out; a reset by the finishing kernel itself raced with this launch's first arrivals)
+    if (!ba_device_lm_fill(ba, &cost, &lds, forced)) continue;
+    if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) continue;
+    if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) continue;
+    // the counter starts from zero: cleared in front of the launch (the adjuster's previous solve no longer touches it
+    // once its completion word is out)
     if (ba->lm_counters_dirty || !ba->lm_have_base) {
-      if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); break; }
+      if (hipMemsetAsync(ba->d_lmc, 0, LMC_WORDS * sizeof(unsigned), st) != hipSuccess) { ba_resident_admission(ba)->release(); continue; }
     }
     ba->lm_counters_dirty = false;
-    ptrs.p[i] = ba->h_lane;
-    max_c = std::max(max_c, (ba->d.C + 1) / 2);
+    ptrs.p[launched] = ba->h_lane;
+    took[launched] = ba;
+    if (launched_mask) *launched_mask |= 1ull << i;
+    max_c = std::max(max_c, (ba->d.C + LM_CPW - 1) / LM_CPW);
     max_lds = std::max(max_lds, lds);
     ++launched;
   }
   if (!launched) return 0;
   const auto t0 = now();
   {
-    SvoProfScope prof(bas[0]->ctx, SVO_PROF_BA_STEP, st);
-    hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c + 1, launched), dim3(128), max_lds, st, ptrs);  // + 1: every solve's reducer
+    SvoProfScope prof(took[0]->ctx, SVO_PROF_BA_STEP, st);
+    hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
   }
   if (hipGetLastError() != hipSuccess) {
-    for (int i = 0; i < launched; ++i) ba_resident_admission(bas[i])->release();
+    for (int i = 0; i < launched; ++i) ba_resident_admission(took[i])->release();
+    if (launched_mask) *launched_mask = 0;
     return 0;
   }
   for (int i = 0; i < launched; ++i) {
-    svo_ba* ba = bas[i];
+    svo_ba* ba = took[i];
     ++ba->seq;  // = a.host_seq
     ba->lm_t0 = t0;
     if (ba->arena_dirty) ba->arena_partial = true;  // the kernel reads the host image in place: the device arena holds the landmark buffers only
@@ -2866,20 +2808,19 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   const int rc = ba_wait_flag(ba, ba->seq);
   ba_resident_admission(ba)->release();
   if (rc) {
-    // a wait inside the kernel gave up (or the launch never ran): drain, and never trust the counters again
+    // a wait inside the kernel gave up (or the launch never ran): drain, and never trust the counter again
     (void)hipStreamSynchronize(ba->lm_stream);
-    if (getenv("SVO_BA_TRACE")) {  // which meeting was never complete
+    if (getenv("SVO_BA_TRACE")) {  // who stopped where
       unsigned c[LMC_WORDS] = {0};
       (void)hipMemcpy(c, ba->d_lmc, sizeof(c), hipMemcpyDeviceToHost);
-      fprintf(stderr, "[svo ba] device solve gave up: grid %d K %d arrive %u done %u arrived %u posted %u copied %u exited %u\n", d.C, d.K,
-              c[LMC_ARRIVE], c[LMC_DONE], c[LMC_ARRIVED], c[LMC_POSTED], c[LMC_COPIED], c[LMC_EXITED]);
+      fprintf(stderr, "[svo ba] device solve gave up: chunks %d K %d delivered %u\n", d.C, d.K, c[LMC_ARRIVE]);
       if (ba->d_lmdbg && d.C <= 4096) {
         std::vector<unsigned> g(16 * (size_t)d.C);
         (void)hipMemcpy(g.data(), ba->d_lmdbg, sizeof(unsigned) * g.size(), hipMemcpyDeviceToHost);
-        for (int b = 0; b < d.C; ++b) {
+        for (int b = 0; b < (d.C + LM_CPW - 1) / LM_CPW; ++b) {
           const unsigned* q = &g[16 * (size_t)b];
           if (b == 0 || memcmp(q, &g[0], 20) != 0)
-            fprintf(stderr, "[svo ba]   workgroup %d: op %u state %u iterations %u need_linearize %u chain %u arrive_total %u done_total %u lin_calls %u\n", b, q[0], q[1],
+            fprintf(stderr, "[svo ba]   workgroup %d: op %u state %u iterations %u need_linearize %u chain/bad %x arrive_total %u commands %u lin_calls %u\n", b, q[0], q[1],
                     q[2], q[3], q[4], q[5], q[6], q[7]);
         }
       }
@@ -2889,8 +2830,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
     return rc;
   }
   const double* r = ba->h_result;
-  ba->lm_base[0] = (unsigned)r[LMR_C_ARRIVE]; ba->lm_base[1] = (unsigned)r[LMR_C_DONE]; ba->lm_base[2] = (unsigned)r[LMR_C_ARRIVED];
-  ba->lm_base[3] = (unsigned)r[LMR_C_POSTED]; ba->lm_base[4] = (unsigned)r[LMR_C_COPIED];
+  ba->lm_base = (unsigned)r[LMR_C_ARRIVE];
   ba->lm_have_base = true;
   memcpy(ba->h_poses.data(), r + LMR_DOUBLES, sizeof(double) * 7 * (size_t)d.K);
   if (r[LMR_SEL] != 0.0) { std::swap(ba->cur_points, ba->cand_points); std::swap(ba->cur_poses, ba->cand_poses); }
@@ -2914,25 +2854,35 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   return SVO_OK;
 }
 
+constexpr size_t WAVE_LDS_BYTES = sizeof(double) * WAVE_LDS_DOUBLES;
+
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
   svo_ba* ba = static_cast<svo_ba*>(user);
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   hipStream_t st = ba->stream;
   const auto t0 = now();
-  const int n = d.n, K = d.K;
+  const int n = d.n;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  const size_t wire = d.det ? (size_t)d.E : pay1;  // what travels: the wire totals, or payload1 itself (bulk modes)
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   if (d.det) {
-    if (d.C > 0) {
+    (void)ba_next_tag(ba);
+    if (d.NG > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
+      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
     }
-    const int nb = ba_reduce_blocks(K - 1);
-    ba_aim_reduce(ba, nb, true);
-    hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl, ba_list_args(ba));
-    SVO_HIP_CHECK(ctx, hipGetLastError());
-    if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
+    const int nb = d.NG > 0 ? ba_reduce_blocks(d.E) : 0;
+    if (nb > 0) {
+      ba_aim_reduce(ba, nb, true);
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl);
+      SVO_HIP_CHECK(ctx, hipGetLastError());
+      if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
+    } else {  // no observations at all: every total is zero
+      SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+      memset(ba->h_pay, 0, sizeof(double) * (PAY2_SLOTS + wire));
+      if (!ba_zero_copy(ba)) SVO_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pay, 0, sizeof(double) * (PAY2_SLOTS + wire), st));
+    }
   } else {
     SVO_HIP_CHECK(ctx, hipMemsetAsync(d.pay1, 0, sizeof(double) * pay1, st));
     const int rc = ba_launch_bulk_linearize(ba, radius, first, nullptr);
@@ -2940,8 +2890,8 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
     SVO_HIP_CHECK(ctx, hipGetLastError());
   }
   if (!ba_zero_copy(ba)) {
-    int rc = ba_allreduce(ba, PAY2_SLOTS, pay1);
-    if (!rc) rc = ba_fetch(ba, PAY2_SLOTS, pay1);
+    int rc = ba_allreduce(ba, PAY2_SLOTS, wire);
+    if (!rc) rc = ba_fetch(ba, PAY2_SLOTS, wire);
     if (rc) return rc;
   }
   ba_payload1_out(ba, ba->h_pay + PAY2_SLOTS, pay1_out);
@@ -2961,6 +2911,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
   const auto t0 = now();
   const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
   const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2;
+  const size_t wire = d.det ? (size_t)d.E : pay1;
   const double spec_radius = ctl->spec_radius;
   const bool same_sweep = spec_radius > 0, chain = !same_sweep && ctl->chain != 0;
   const bool sharded = ba->comm || ba->allreduce;
@@ -2979,65 +2930,47 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     d.step_in = ba->d_step;
   }
   const bool next = same_sweep || chain;
-  if (d.det) {
-    const int nd = (K - 1) * K / 2 + (K - 1) + 1;  // upper pose-pair blocks + pose vectors + the landmark scalars
-    const int nb = ba_reduce_blocks(K - 1);
-    const int lm_b = ba->h_list_begin[nd - 1], lm_n = ba->h_list_end[nd - 1] - lm_b;
-    bool fused = false;
-    FusedAdmission admission;  // released when this call returns: the completion word has arrived by then
-    const int grid1 = std::max(d.C, next ? nb : 1);
-    const bool one_launch = !sharded && d.C > 0 && ba_fused_reduce() && admission.admit(grid1, ctx->device);
-    if (one_launch) {
-      // the whole iteration — pass B, [decision,] pass A, reduction — in ONE launch
-      ba_aim_reduce(ba, next ? nb : 1, true);
-      IterSync sy;
-      sy.arrived = ba->d_arrive + 9;
-      if (chain) ba->arrived_total += (unsigned)d.C;
-      sy.arrived_target = ba->arrived_total;
-      sy.posted = ba->d_arrive + 10;
-      sy.post_seq = chain ? ++ba->post_seq : 0u;
-      sy.done = ba->d_arrive + 8;
-      ba->done_total += (unsigned)grid1;
-      sy.done_target = ba->done_total;
+  if (d.det && d.NG > 0) {
+    (void)ba_next_tag(ba);
+    const int nb = ba_reduce_blocks(d.E);
+    {
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
-      hipLaunchKernelGGL(ba_iterate_kernel, dim3(grid1), dim3(128), 0, st, d, radius, same_sweep ? spec_radius : 0.0, lc, next ? 1 : 0,
-                         lm_b, lm_n, ba_list_args(ba), sy);
-      fused = true;
-    } else if (d.C > 0) {
-      SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
-      hipLaunchKernelGGL(ba_step_kernel, dim3(d.C), dim3(64), 0, st, d, radius, same_sweep ? spec_radius : 0.0);
+      hipLaunchKernelGGL(ba_step_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, radius, same_sweep ? spec_radius : 0.0);
     }
-    if (one_launch) {
-      // nothing more to queue
-    } else if (!chain) {
+    if (!chain) {
       const int blocks = (same_sweep ? nb : 0) + 1;
       ba_aim_reduce(ba, blocks, true);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, same_sweep ? 1 : 0, 1, kNoCtl, ba_list_args(ba));
-    } else if (!sharded && d.C > 0) {
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, same_sweep ? 1 : 0, 1, kNoCtl);
+    } else if (!sharded) {
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.C), dim3(128), 0, st, d, lc, ba->h_list_begin[nd - 1], ba->h_list_end[nd - 1] - ba->h_list_begin[nd - 1]);
+      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, lc);
     } else {
       ba_aim_reduce(ba, 1, false);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, st, d, 0, 1, lc, ba_list_args(ba));
-      if (sharded) {
-        int rc = ba_allreduce(ba, 0, PAY2_SLOTS);
-        if (rc) return rc;
-        const LmCtl lcs = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 1};
-        hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, lcs, ba->d_pay, d.ctl_dev);
-      }
-      if (d.C > 0) {
-        SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-        hipLaunchKernelGGL(ba_linearize_kernel, dim3(d.C), dim3(64), 64, st, d, 0.0, 0, (const double*)d.ctl_dev);
-      }
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, st, d, 0, 1, lc);
+      int rc = ba_allreduce(ba, 0, PAY2_SLOTS);
+      if (rc) return rc;
+      const LmCtl lcs = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 1};
+      hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, lcs, ba->d_pay, d.ctl_dev);
+      SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
+      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, 0.0, 0, (const double*)d.ctl_dev);
     }
-    if (chain && !fused) {
+    if (chain) {
       ba_aim_reduce(ba, nb, true);
-      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl, ba_list_args(ba));
+      hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl);
     }
     SVO_HIP_CHECK(ctx, hipGetLastError());
     if (d.flag) { const int rc = ba_wait_flag(ba, d.seq); if (rc) return rc; }
+  } else if (d.det) {  // no observations: zero sums, nothing to launch
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    memset(ba->h_pay, 0, sizeof(double) * (PAY2_SLOTS + wire));
+    if (!zc) SVO_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pay, 0, sizeof(double) * (PAY2_SLOTS + wire), st));
+    if (chain) {  // the decision of the chained step, as the kernels would take it
+      const SvoLmDecision dec = svo_lm_decide(ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 0.0, 0.0);
+      ba->h_pay[4] = (double)dec.accept; ba->h_pay[5] = dec.next_radius;
+      if (!zc) SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_pay, ba->h_pay, sizeof(double) * PAY2_SLOTS, hipMemcpyHostToDevice, st));
+    }
   } else {
     SVO_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pay, 0, sizeof(double) * (next ? PAY2_SLOTS + pay1 : PAY2_SLOTS), st));
     if (d.C > 0) {
@@ -3062,10 +2995,10 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
   if (!zc) {
     // same sweep: ONE collective for both payloads; chained: payload2 was summed before the decision, payload1 now
     int rc = SVO_OK;
-    if (same_sweep) rc = ba_allreduce(ba, 0, PAY2_SLOTS + pay1);
-    else if (chain) rc = ba_allreduce(ba, PAY2_SLOTS, pay1);
+    if (same_sweep) rc = ba_allreduce(ba, 0, PAY2_SLOTS + wire);
+    else if (chain) rc = ba_allreduce(ba, PAY2_SLOTS, wire);
     else rc = ba_allreduce(ba, 0, PAY2_SLOTS);
-    if (!rc) rc = ba_fetch(ba, 0, next ? PAY2_SLOTS + pay1 : PAY2_SLOTS);
+    if (!rc) rc = ba_fetch(ba, 0, next ? PAY2_SLOTS + wire : PAY2_SLOTS);
     if (rc) return rc;
   }
   memcpy(pay2_out, ba->h_pay, sizeof(double) * 4);
@@ -3098,7 +3031,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
-  if (ba_device_lm_launch(&ba, 1, ba->stream, false) == 1) {  // the whole solve is one launch: nothing for the host to do until the completion word
+  if (ba_device_lm_launch(&ba, 1, ba->stream, false, nullptr) == 1) {  // the whole solve is one launch: nothing for the host to do until the completion word
     const int rcd = ba_device_lm_end(ba, sum);
     d.flag = nullptr;
     return rcd;
@@ -3291,10 +3224,11 @@ int svo_ba_solve_prepare(svo_ba* ba) {
 
 // launch: the prepared problems of `n` adjusters as ONE ba_lm_kernel launch on `stream`; returns how many (a prefix) were
 // eligible and admitted.  The others: offer them again, or svo_ba_solve_finish runs the host-driven loop for them.
-int svo_ba_solve_launch(svo_ba** bas, int n, void* stream) {
+int svo_ba_solve_launch(svo_ba** bas, int n, void* stream, unsigned long long* launched_mask) {
+  if (launched_mask) *launched_mask = 0;
   if (!bas || n < 1) return 0;
   svo_use_device(bas[0]->ctx);
-  return ba_device_lm_launch(bas, n, stream ? (hipStream_t)stream : bas[0]->stream, true);
+  return ba_device_lm_launch(bas, n, stream ? (hipStream_t)stream : bas[0]->stream, true, launched_mask);
 }
 
 // 1: the launched solve has published its completion word (svo_ba_solve_finish will not block), 0: still running

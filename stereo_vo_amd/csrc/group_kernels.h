@@ -62,7 +62,7 @@ int svo_kg_stereo_triangulate(svo_ctx* ctx, hipStream_t st, const SvoStereoTriLa
 
 // a12 in steps (csrc/ba.hip): assemble on any thread, launch the solves of several adjusters as ONE kernel, join later
 int svo_ba_solve_prepare(svo_ba* ba);                          // 1: nothing to solve, 0: a problem is loaded, < 0: svo_status
-int svo_ba_solve_launch(svo_ba** bas, int n, void* stream);    // number launched (a prefix of bas)
+int svo_ba_solve_launch(svo_ba** bas, int n, void* stream, unsigned long long* launched_mask);  // number launched; bit i of the mask: bas[i] was (an ineligible or not admitted adjuster is skipped)
 int svo_ba_solve_poll(svo_ba* ba);                             // 1: finish will not block
 int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary);  // join (or solve host-driven) + write back into the graph
 

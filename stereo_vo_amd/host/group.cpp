@@ -979,18 +979,25 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         }
         if (error) break;
         if (!cand.empty()) {
-          const int launched = svo_ba_solve_launch(bas, (int)cand.size(), g->st_ba[free_line]);
+          unsigned long long mask = 0;
+          const int launched = svo_ba_solve_launch(bas, (int)cand.size(), g->st_ba[free_line], &mask);
           if (launched > 0) { g->launches[4]++; g->lanes_carried[4] += launched; progressed = true; }
           ++g->ba_launch_id;
-          for (int k = 0; k < launched; ++k) EV(cand[k], "ba_launch", launched);
-          for (int k = 0; k < launched; ++k) { g->lanes[cand[k]]->ba_launch = g->ba_launch_id; g->lanes[cand[k]]->ba_line = free_line; g->lanes[cand[k]]->ba_state.store(BA_INFLIGHT, std::memory_order_release); }
-          if (launched < (int)cand.size()) {
-            // not admitted (too many waiting workgroups on the GPU right now) or not eligible: if nothing of this group is
-            // in flight that could free the budget, the head lane is solved by the host-driven loop on a worker
+          int not_taken = -1;  // the first lane the launch skipped: not eligible, or not admitted right now
+          for (int k = 0; k < (int)cand.size(); ++k) {
+            if (!((mask >> k) & 1ull)) { if (not_taken < 0) not_taken = cand[k]; continue; }
+            Lane* l = g->lanes[cand[k]];
+            EV(cand[k], "ba_launch", launched);
+            l->ba_launch = g->ba_launch_id; l->ba_line = free_line; l->ba_state.store(BA_INFLIGHT, std::memory_order_release);
+          }
+          if (not_taken >= 0) {
+            // if nothing of this group is in flight that could free the admission budget (or the problem is simply not
+            // eligible for the device-resident solve), the lane is solved by the host-driven loop on a worker; otherwise it
+            // is offered again when a solve of this group has been joined
             bool inflight = false;
             for (int li = 0; li < S; ++li) inflight |= g->lanes[li]->ba_state.load(std::memory_order_acquire) == BA_INFLIGHT;
             if (!inflight) {
-              Lane* l = g->lanes[cand[launched]];
+              Lane* l = g->lanes[not_taken];
               l->ba_state.store(BA_HOST_SOLVING, std::memory_order_release);
               g->pool.post(l, 1);
               progressed = true;
@@ -1033,7 +1040,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         if (l->ba_rc == 1) { l->ba_state.store(BA_NONE); break; }
         if (l->ba_rc) { if (!error) error = l->ba_rc; l->ba_state.store(BA_NONE); break; }
         svo_ba* one = l->ba;
-        if (svo_ba_solve_launch(&one, 1, g->st_ba[0]) == 1) { l->ba_launch = ++g->ba_launch_id; l->ba_line = 0; l->ba_state.store(BA_INFLIGHT); g->launches[4]++; g->lanes_carried[4]++; }
+        if (svo_ba_solve_launch(&one, 1, g->st_ba[0], nullptr) == 1) { l->ba_launch = ++g->ba_launch_id; l->ba_line = 0; l->ba_state.store(BA_INFLIGHT); g->launches[4]++; g->lanes_carried[4]++; }
         else { l->ba_rc = svo_ba_solve_finish(l->ba, &l->ba_summary); l->ba_state.store(BA_HOST_DONE); }
         break;
       }

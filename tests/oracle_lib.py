@@ -204,6 +204,12 @@ def ba_solve(poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, max_it
                             initial_cost=summ[3], final_cost=summ[4])
 
 
+def ba_set_order(order):
+    """2 (default): the declared chunk order; 1: rounds 1-3's 28-segment order (comparison only).  Process-wide: takes effect
+    for solvers opened afterwards."""
+    oracle().ora_ba_set_order(int(order))
+
+
 class Pipeline:
     def __init__(self, **kw):
         L = oracle()
