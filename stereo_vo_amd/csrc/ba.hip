@@ -98,10 +98,10 @@ struct BaDev {
   double f = 0, cx = 0, cy = 0;
   // deterministic mode (chunk order): per-chunk destination tables + the partial store
   int det = 0;
-  int G = 1, NG = 0, NGpad = 0, E = 0;   // chunks per group, groups, granules per element row, wire-format elements
+  int G = 1, NG = 0, Epad = 0, E = 0;    // chunks per group, groups, granules per group row (E rounded up), wire-format elements
   const uint16_t* tab = nullptr;   // chunk tables back to back (u16 words), see ba_build_tables
   const uint32_t* tab_off = nullptr;  // C + 1 offsets into tab
-  double* part1 = nullptr;         // granules {value, tag}: element e of group g at part1[2 * (e * NGpad + g)]
+  double* part1 = nullptr;         // granules {value, tag}: element e of group g at part1[2 * (g * Epad + e)] — a wavefront's partials are one contiguous run
   double* part2 = nullptr;         // granules: pass B's four sums of group g at part2[2 * ((parity * NG + g) * 4 + i)]
   double* pay1_out = nullptr;      // where ba_reduce_kernel writes the wire totals (pinned host memory when single-rank)
   double* pay2_out = nullptr;
@@ -194,6 +194,33 @@ __device__ __forceinline__ bool granule_wait(const double* base, int idx, unsign
       else if (tn - t0 > 300000000ll) return false;
     }
   }
+}
+
+// One "sentinel" granule per producer (granule first + i * stride, i < count), polled by the calling workgroup until it
+// carries `tag`.  A producer writes its sentinel LAST, so a reader that has seen every sentinel finds (almost always)
+// everything else in place on its first read — and reads again what is not: every granule carries the tag, the sentinel is
+// only a hint that keeps the polling traffic at one load per producer and round instead of one per granule.  Ends with a
+// barrier; false (block-uniform through *s_flag): a tag never showed up.
+__device__ __forceinline__ bool wait_sentinels(const double* base, int first, int stride, int count, unsigned long long tag, int* s_flag) {
+  if (threadIdx.x == 0) *s_flag = 1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < count; i += (int)blockDim.x) {
+    const double* p = base + 2 * ((size_t)first + (size_t)i * stride);
+    long long t0 = 0;
+    for (unsigned spins = 0;; ++spins) {
+      svo_d2 v;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+      if ((unsigned long long)__double_as_longlong(v.y) == tag) break;
+      __builtin_amdgcn_s_sleep(4);
+      if ((spins & 255u) == 255u) {
+        const long long tn = (long long)wall_clock64();
+        if (!t0) t0 = tn;
+        else if (tn - t0 > 300000000ll) { *s_flag = 0; break; }
+      }
+    }
+  }
+  __syncthreads();
+  return *s_flag != 0;
 }
 
 // The decision for the summed payload2 -> ctl_dev (for the pass-A launch queued behind) and payload slots 4 / 5 (for the host).
@@ -421,8 +448,22 @@ __device__ __forceinline__ void linearize_suffix_bulk(const BaDev& P, const ObsR
 //   level 2  reduce_elements: thread = element, the NG group sums added sequentially.
 // Partials travel as tagged granules {value, tag} (granule_store): a reader takes a value only under the awaited tag.
 constexpr int REC_STRIDE = 38;        // doubles per lane of the staging rows (36 used; even: 16-byte alignment)
-constexpr int LMS_STRIDE = 4;         // landmark scalars per landmark of a chunk (pass A uses 2)
-constexpr int WAVE_LDS_DOUBLES = 64 * REC_STRIDE + 64 * LMS_STRIDE;  // staging rows + landmark scalars of one wavefront
+constexpr int LMS_STRIDE = 4;         // pass B: four scalars per landmark of a chunk, in the (idle) staging rows
+constexpr int LMS_COL = 36;           // pass A: cost and g_p^2 of the landmark of rank r in the spare columns 36, 37 of row r
+constexpr int PST_MAX = 2048;         // wire elements a wavefront stages in LDS before it posts them (larger E: posted one by one)
+// LDS of an owner set (doubles): the staging rows (their two spare columns carry pass A's landmark scalars; pass B, which does
+// not stage, keeps its four scalars per landmark in the rows themselves) | the E partials of the chunk on their way out
+// (consecutive threads then post consecutive granules: whole lines) | 4 ints
+__host__ __device__ static inline int wg_lds_doubles(int E) { return 64 * REC_STRIDE + (E <= PST_MAX ? ((E + 1) & ~1) : 0) + 2; }
+struct WgLds { double* rec; double* pst; int* s_ne; };
+__device__ __forceinline__ WgLds wg_lds(double* base, int E) {
+  WgLds L;
+  const int pst_doubles = E <= PST_MAX ? ((E + 1) & ~1) : 0;
+  L.rec = base;
+  L.pst = pst_doubles ? base + 64 * REC_STRIDE : nullptr;
+  L.s_ne = reinterpret_cast<int*>(base + 64 * REC_STRIDE + pst_doubles);
+  return L;
+}
 constexpr int TAB_LDS_WORDS = 1024;   // u16 words of a chunk table ba_lm_kernel keeps in LDS (larger tables: host-driven path)
 
 // A chunk's destination table (host: ba_build_tables), u16 words:
@@ -443,11 +484,14 @@ struct ChunkTab {
 
 // Where a chunk's partials go: group g of the partial store.  `first`: the group's first chunk (its partial starts the
 // group's sum); otherwise the partial is added to what the group holds so far (same wavefront, acknowledged stores).
-struct PartSink { double* part1; double* part2; int NGpad, NG, g, first, parity; unsigned long long tag; };
-__device__ __forceinline__ void emit1(const PartSink& k, int e, double v) {
-  double* slot = k.part1 + 2 * ((size_t)e * k.NGpad + k.g);
+struct PartSink { double* part1; double* part2; double* pst; int Epad, E, NG, g, first, parity; unsigned long long tag; };
+__device__ __forceinline__ void post1(const PartSink& k, int e, double v) {
+  double* slot = k.part1 + 2 * ((size_t)k.g * k.Epad + e);
   if (!k.first) v = slot_load(slot) + v;
   granule_store(slot, v, k.tag);
+}
+__device__ __forceinline__ void emit1(const PartSink& k, int e, double v) {
+  if (k.pst) k.pst[e] = v; else post1(k, e, v);
 }
 __device__ __forceinline__ void emit2(const PartSink& k, int i, double v) {
   double* slot = k.part2 + 2 * (((size_t)k.parity * k.NG + k.g) * 4 + i);
@@ -457,6 +501,26 @@ __device__ __forceinline__ void emit2(const PartSink& k, int i, double v) {
 
 // "my stores have been acknowledged" (write-through stores: they are at the coherence point / in host memory)
 __device__ __forceinline__ void stores_acknowledged() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// acc += x[0], x[stride], ..., x[(count - 1) stride] in THAT order (count may differ per lane), eight LDS loads in flight:
+// a plain loop pays one LDS round trip per term (a lone wavefront: ~100 cycles each)
+__device__ __forceinline__ double lds_seq_sum(double acc, const double* x, int count, int stride) {
+  int i = 0;
+  for (; i + 8 <= count; i += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[(i + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  if (i < count) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[min(i + u, count - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) if (i + u < count) acc += v[u];
+  }
+  return acc;
+}
 // LDS traffic of ONE wavefront is ordered; the fence only keeps the compiler from moving accesses across it
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -472,9 +536,55 @@ __device__ __forceinline__ void landmark_rank(const ObsRec& R, int& rank, int& n
   rank = __popcll(firsts & ((1ull << R.first) - 1ull));  // R.first <= lane < 64
 }
 
-// Pass A behind the prefix, deterministic mode.  rec / lms: this wavefront's LDS (WAVE_LDS_DOUBLES).
-__device__ __forceinline__ void linearize_suffix_det(const BaDev& P, const ObsRec& R, const LinPre& q, double radius, int first_pass, const ChunkTab& T,
-                                                     double* rec, double* lms, const PartSink& sink, ChunkRegs* cache) {
+// The Schur owners of a chunk: item = (block slot, row a, column group of WIDTH), dealt over the threads of the workgroup;
+// `nonempty` (bit q: block q has entries; 0: every block, slot = q) lists the `nb` blocks that are walked.  Every element
+// receives the same operations in the same order whatever WIDTH is: -(Y_i[a] . (W_t s)[b]) per pair, added in list order
+// from +0.0.
+template <int WIDTH>
+__device__ __forceinline__ void schur_owners(const ChunkTab& T, const double* rec, const PartSink& sink, unsigned long long nonempty, int nb, int tid, int nt) {
+  constexpr int SPLIT = 6 / WIDTH;
+  for (int item = tid; item < nb * 6 * SPLIT; item += nt) {
+    const int slot = item / (6 * SPLIT), rem = item - slot * (6 * SPLIT), a = rem / SPLIT, b0 = (rem - a * SPLIT) * WIDTH;
+    int qb = slot;
+    if (nonempty) {  // the slot-th set bit
+      unsigned long long m = nonempty;
+      for (int i = 0; i < slot; ++i) m &= m - 1ull;
+      qb = __ffsll((long long)m) - 1;
+    }
+    double acc[WIDTH];
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) acc[j] = 0.0;
+    const int e0 = T.bstart(qb), e1 = T.bstart(qb + 1);
+    int en_next = e0 < e1 ? T.ent(e0) : 0;  // the next entry is fetched one iteration ahead: entry -> rows is a dependent LDS chain
+    for (int e = e0; e < e1; ++e) {
+      const int en = en_next;
+      if (e + 1 < e1) en_next = T.ent(e + 1);
+      const double* ri = rec + (en & 63) * REC_STRIDE;
+      const double* rt = rec + ((en >> 8) & 63) * REC_STRIDE;
+      if (!(en & 0x80)) {
+        const double y0 = ri[18 + 3 * a], y1 = ri[18 + 3 * a + 1], y2 = ri[18 + 3 * a + 2];
+        double w[3 * WIDTH];
+#pragma unroll
+        for (int i = 0; i < 3 * WIDTH; ++i) w[i] = rt[3 * b0 + i];
+#pragma unroll
+        for (int j = 0; j < WIDTH; ++j) acc[j] += -(y0 * w[3 * j] + y1 * w[3 * j + 1] + y2 * w[3 * j + 2]);
+      } else {  // the transpose of the pair's block: element (a, b) of the destination is B[b][a]
+        const double w0 = rt[3 * a], w1 = rt[3 * a + 1], w2 = rt[3 * a + 2];
+#pragma unroll
+        for (int j = 0; j < WIDTH; ++j) acc[j] += -(ri[18 + 3 * (b0 + j)] * w0 + ri[18 + 3 * (b0 + j) + 1] * w1 + ri[18 + 3 * (b0 + j) + 2] * w2);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WIDTH; ++j) emit1(sink, 36 * qb + 6 * a + b0 + j, acc[j]);
+  }
+}
+
+// What a lane carries from its own arithmetic behind the prefix into the workgroup's owner phases.
+struct SufRegs { double ov[33]; bool freep; };  // (W s and Y go straight into the lane's staging row: holding them too spilled 1.3 KB per lane in ba_lm_kernel)
+
+// Pass A behind the prefix, one lane's arithmetic (registers; the landmark's cost and g_p^2 go to the spare columns of `rec`):
+// W s, Y = (W s) Vd^-1 -> the lane's staging row; the 33 per-pose values (g_c | -Y g_p | upper triangle of J_c^T J_c) -> o.
+__device__ __forceinline__ void suffix_math(const BaDev& P, const ObsRec& R, const LinPre& q, double radius, int first_pass, double* rec, ChunkRegs* cache, SufRegs& o) {
   const int lane = threadIdx.x & 63;
   const bool active = R.active;
   const int k = R.k, j = R.j, first = R.first;
@@ -497,7 +607,7 @@ __device__ __forceinline__ void linearize_suffix_det(const BaDev& P, const ObsRe
     } else {
       s[0] = P.sp[3 * j]; s[1] = P.sp[3 * j + 1]; s[2] = P.sp[3 * j + 2];
     }
-    if (lane == first) { lms[LMS_STRIDE * rank] = q.cost_l; lms[LMS_STRIDE * rank + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
+    if (lane == first) { rec[REC_STRIDE * rank + LMS_COL] = q.cost_l; rec[REC_STRIDE * rank + LMS_COL + 1] = gp[0] * gp[0] + gp[1] * gp[1] + gp[2] * gp[2]; }
   }
   double Vd[9], Vi[9], gps[3];
 #pragma unroll
@@ -510,10 +620,8 @@ __device__ __forceinline__ void linearize_suffix_det(const BaDev& P, const ObsRe
   for (int a = 0; a < 3; ++a) Vd[4 * a] += fmin(fmax(Vd[4 * a], MIN_DIAG), MAX_DIAG) / radius;
   inv3_sym(Vd, Vi);
   const bool freep = active && k > 0;
-  double* mine = rec + lane * REC_STRIDE;
-  double ov[33];
+  o.freep = freep;
   {
-    // W s and Y = (W s) Vd^-1 -> this lane's staging row [W s (18) | Y (18)]; then the 33 per-pose values
     double Ws[18], Y[18];
 #pragma unroll
     for (int a = 0; a < 6; ++a)
@@ -523,72 +631,110 @@ __device__ __forceinline__ void linearize_suffix_det(const BaDev& P, const ObsRe
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < 3; ++b) Y[3 * a + b] = Ws[3 * a] * Vi[b] + Ws[3 * a + 1] * Vi[3 + b] + Ws[3 * a + 2] * Vi[6 + b];
+    double* row = rec + lane * REC_STRIDE;  // this lane's staging row [W s (18) | Y (18)]
 #pragma unroll
-    for (int i = 0; i < 18; ++i) { mine[i] = Ws[i]; mine[18 + i] = Y[i]; }
+    for (int i = 0; i < 18; ++i) { row[i] = Ws[i]; row[18 + i] = Y[i]; }
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
-      ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
-      ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
+      o.ov[a] = Jc[a] * r[0] + Jc[6 + a] * r[1];
+      o.ov[6 + a] = -(Y[3 * a] * gps[0] + Y[3 * a + 1] * gps[1] + Y[3 * a + 2] * gps[2]);
     }
-    int u = 12;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int b = a; b < 6; ++b) ov[u++] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
   }
-  wave_lds_fence();
-  // ---- Schur part: owner = (upper block q, row a), six elements, the block's pair list in order
-  const int nU = T.nU, F = T.F;
-  for (int row = lane; row < 6 * nU; row += 64) {
-    const int qb = row / 6, a = row - 6 * qb;
-    double acc[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    const int e1 = T.bstart(qb + 1);
-    for (int e = T.bstart(qb); e < e1; ++e) {
-      const int en = T.ent(e);
-      const double* ri = rec + (en & 63) * REC_STRIDE;
-      const double* rt = rec + ((en >> 8) & 63) * REC_STRIDE;
-      if (!(en & 0x80)) {
-        const double y0 = ri[18 + 3 * a], y1 = ri[18 + 3 * a + 1], y2 = ri[18 + 3 * a + 2];
+  int u = 12;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) acc[b] += -(y0 * rt[3 * b] + y1 * rt[3 * b + 1] + y2 * rt[3 * b + 2]);
-      } else {  // the transpose of the pair's block: element (a, b) of the destination is B[b][a]
-        const double w0 = rt[3 * a], w1 = rt[3 * a + 1], w2 = rt[3 * a + 2];
+  for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) acc[b] += -(ri[18 + 3 * b] * w0 + ri[18 + 3 * b + 1] * w1 + ri[18 + 3 * b + 2] * w2);
-      }
-    }
-#pragma unroll
-    for (int b = 0; b < 6; ++b) emit1(sink, 36 * qb + 6 * a + b, acc[b]);
-  }
-  wave_lds_fence();
-  // ---- per-pose values: the rows now carry the 33 values of every free observation
-  if (freep) {
-#pragma unroll
-    for (int i = 0; i < 33; ++i) mine[i] = ov[i];
-  }
-  wave_lds_fence();
-  for (int idx = lane; idx < 33 * F; idx += 64) {
-    const int kp = idx / 33, el = idx - 33 * kp;
-    double acc = 0.0;
-    const int x1 = T.pstart(kp + 1);
-    for (int x = T.pstart(kp); x < x1; ++x) acc += rec[T.plane(x) * REC_STRIDE + el];
-    emit1(sink, 36 * nU + idx, acc);
-  }
-  // ---- cost, sum g_p^2: landmark order
-  if (lane < 2) {
-    double acc = 0.0;
-    for (int l = 0; l < nlm; ++l) acc += lms[LMS_STRIDE * l + lane];
-    emit1(sink, 36 * nU + 33 * F + lane, acc);
-  }
-  wave_lds_fence();  // the next pass of this wavefront reuses rows and scalars
+    for (int b = a; b < 6; ++b) o.ov[u++] = Jc[a] * Jc[b] + Jc[6 + a] * Jc[6 + b];
 }
 
-__device__ __forceinline__ void linearize_chunk_det(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius, int first_pass,
-                                                    const ChunkTab& T, double* rec, double* lms, const PartSink& sink, ChunkRegs* cache = nullptr) {
-  LinPre q;
-  double unused = 0.0;
-  linearize_prefix(P, R, poses_, q, unused);
-  linearize_suffix_det(P, R, q, radius, first_pass, T, rec, lms, sink, cache);
+// The owner phases of ONE chunk: its lanes stage their rows, then every thread of the owner set takes destination rows.
+//   WG = false: the owner set is the chunk's own wavefront (ba_lm_kernel: both wavefronts of a workgroup run their chunks'
+//               phases side by side, each in its own LDS; hand-overs are wave-level fences);
+//   WG = true : the owner set is the whole workgroup (the one-wavefront workgroups of the host-driven kernels).
+//   (Tried in round 4: ONE staging area per 128-thread workgroup, its two wavefronts taking turns with all 128 lanes as
+//   owners — 36 KB of LDS instead of 49, but the turns and their ten barriers took pass A from 10 to 22 us.)
+//   rec: 64 x REC_STRIDE (spare columns: the chunk's landmark scalars), sink.pst: E or null, s_ne: 4 ints — LDS of the owner set.
+template <bool WG>
+__device__ __forceinline__ void chunk_owner_phases(const ObsRec& R, const ChunkTab& T, const SufRegs& o, double* rec, const PartSink& sink, int* s_ne) {
+  const int lane = threadIdx.x & 63;
+  const int tid = WG ? (int)threadIdx.x : lane, nt = WG ? (int)blockDim.x : 64;
+  const bool mine = WG ? (threadIdx.x >> 6) == 0 : true;
+  auto sync = [&]() { if (WG) __syncthreads(); else wave_lds_fence(); };
+  const int nU = T.nU, F = T.F;
+  unsigned long long nonempty = 0ull;
+  int nlm = 0;
+  if (mine) {  // (its lanes' rows were staged by suffix_math)
+    int rank;
+    landmark_rank(R, rank, nlm);
+    if (nU <= 64) nonempty = __ballot(lane < nU && T.bstart(lane + 1) > T.bstart(lane));
+    if (WG && lane == 0) { s_ne[0] = (int)(nonempty & 0xFFFFFFFFull); s_ne[1] = (int)(nonempty >> 32); s_ne[2] = nlm; }
+  }
+  if (sink.pst) for (int e = tid; e < 36 * nU; e += nt) sink.pst[e] = 0.0;  // blocks the chunk does not touch: +0.0
+  sync();
+  if (WG) { nonempty = ((unsigned long long)(unsigned)s_ne[1] << 32) | (unsigned long long)(unsigned)s_ne[0]; nlm = s_ne[2]; }
+  // ---- Schur part.  How many columns an owner takes depends on how many blocks the chunk touches at all: a chunk of new
+  // landmarks (one observation each, all in the newest pose) has ONE block with 64 entries — six row owners would walk it
+  // while the other lanes idle (measured: that chunk's pass took 19 us against a mean of 10 and everybody waited for it).
+  if (nU <= 64) {
+    const int nb_ne = __popcll(nonempty);
+    if (!sink.pst) {  // posted straight from the owners: every element of every block must be written
+      for (int e = tid; e < 36 * nU; e += nt) if (!((nonempty >> (e / 36)) & 1ull)) post1(sink, e, 0.0);
+    }
+    if (nb_ne * 36 <= nt) schur_owners<1>(T, rec, sink, nonempty, nb_ne, tid, nt);
+    else if (nb_ne * 18 <= nt) schur_owners<2>(T, rec, sink, nonempty, nb_ne, tid, nt);
+    else if (nb_ne * 12 <= nt) schur_owners<3>(T, rec, sink, nonempty, nb_ne, tid, nt);
+    else schur_owners<6>(T, rec, sink, nonempty, nb_ne, tid, nt);
+  } else {
+    schur_owners<6>(T, rec, sink, 0ull, nU, tid, nt);
+  }
+  sync();
+  // ---- per-pose values: the rows now carry the 33 values of every free observation
+  if (mine && o.freep) {
+    double* row = rec + lane * REC_STRIDE;
+#pragma unroll
+    for (int i = 0; i < 33; ++i) row[i] = o.ov[i];
+  }
+  sync();
+  for (int idx = tid; idx < 33 * F; idx += nt) {
+    const int kp = idx / 33, el = idx - 33 * kp;
+    double acc = 0.0;
+    const int x0 = T.pstart(kp), x1 = T.pstart(kp + 1);
+    for (int x = x0; x < x1; x += 8) {  // eight lanes' rows in flight (lane list -> row is a dependent LDS chain), added in list order
+      int ln[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ln[u] = T.plane(min(x + u, x1 - 1));
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = rec[ln[u] * REC_STRIDE + el];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (x + u < x1) acc += v[u];
+    }
+    emit1(sink, 36 * nU + idx, acc);
+  }
+  // ---- cost, sum g_p^2: landmark order.  LAST: sum g_p^2 is the readers' sentinel.
+  sync();
+  if (sink.pst) {  // the chunk's partials leave as one contiguous run
+    for (int e = tid; e < sink.E - 2; e += nt) post1(sink, e, sink.pst[e]);
+  }
+  if (tid < 2) post1(sink, 36 * nU + 33 * F + tid, lds_seq_sum(0.0, rec + LMS_COL + tid, nlm, REC_STRIDE));
+  sync();  // rows, scalars and the outgoing partials are reused by the next chunk
+}
+
+// pass A of one chunk by a workgroup of the host-driven kernels (DET_THREADS threads): the first wavefront does the lanes'
+// arithmetic (lane = observation), every thread of the workgroup then owns destination rows — the owner phases are half of a
+// chunk's pass and run twice as wide (measured on the single-stream bench: the pass-A launch is its slowest chunk)
+constexpr int DET_THREADS = 128;
+__device__ __forceinline__ void linearize_chunk_wg1(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius, int first_pass,
+                                                    const ChunkTab& T, const WgLds& L, const PartSink& sink) {
+  SufRegs o;
+  o.freep = false;
+  if (threadIdx.x < 64) {
+    LinPre q;
+    double unused = 0.0;
+    linearize_prefix(P, R, poses_, q, unused);
+    suffix_math(P, R, q, radius, first_pass, L.rec, nullptr, o);
+  }
+  chunk_owner_phases<true>(R, T, o, L.rec, sink, L.s_ne);
 }
 
 // One-time reads of the problem image by ba_lm_kernel.  The image stays in PINNED HOST memory (no H2D copy launch in front of
@@ -629,7 +775,7 @@ __device__ __forceinline__ void load_chunk_table(const BaDev& P, int chunk, uint
   const int words32 = (int)((o1 - o0 + 1) >> 1);  // tables start on even u16 offsets
   const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tab + o0);
   uint32_t* d32 = reinterpret_cast<uint32_t*>(dst);
-  for (int i = lane; i < words32 && 2 * i < TAB_LDS_WORDS; i += 64) d32[i] = sys_load(src + i, shift);
+  for (int i = lane; i < words32; i += 64) d32[i] = sys_load(src + i, shift);  // the host sized the LDS for the problem's largest table
   wave_lds_fence();
 }
 
@@ -744,11 +890,7 @@ __device__ __forceinline__ void backsub_chunk(const BaDev& P, const ObsRec& R, c
       lv[0] = cn; lv[1] = det_mc; lv[2] = det_dp2; lv[3] = det_p2;
     }
     wave_lds_fence();
-    if (lane < 4) {
-      double acc = 0.0;
-      for (int l = 0; l < nlm; ++l) acc += lms[LMS_STRIDE * l + lane];
-      emit2(*sink, lane, acc);
-    }
+    if (lane < 4) emit2(*sink, lane, lds_seq_sum(0.0, lms + lane, nlm, LMS_STRIDE));
     wave_lds_fence();
   }
 }
@@ -818,24 +960,26 @@ __device__ __forceinline__ bool fetch_granules(double* dst, const double* src, i
 // starting from the first.  sm: >= sm_doubles doubles of LDS; out(e, total).  Any workgroup size, block-uniform arguments;
 // ends with a barrier.  false (block-uniform): a tag never showed up.
 template <typename Out>
-__device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, unsigned long long tag, double* sm, int sm_doubles, int* s_flag, Out out) {
-  const int NG = P.NG, NGpad = P.NGpad;
-  const int per_round = max(1, sm_doubles / NGpad);
-  if (threadIdx.x == 0) *s_flag = 1;
-  __syncthreads();
+__device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, unsigned long long tag, double* sm, int sm_doubles, int* s_flag, Out out, long long* t_waited = nullptr) {
+  const int NG = P.NG, Epad = P.Epad;
+  const int per_round = max(1, sm_doubles / NG);
+  // every group's last-posted element (sum g_p^2) first: one load per group and polling round
+  const long long t_in = t_waited && threadIdx.x == 0 ? (long long)wall_clock64() : 0;
+  if (!wait_sentinels(P.part1, P.E - 1, Epad, NG, tag, s_flag)) return false;
+  if (t_waited && threadIdx.x == 0) *t_waited += (long long)wall_clock64() - t_in;
   for (int eb = e0; eb < e1; eb += per_round) {  // block-uniform trip count
     const int ne = min(per_round, e1 - eb);
-    // the rows of consecutive elements are consecutive in the store: ne * NGpad granules in one run (the padding granules
-    // of a row are never written: they are skipped, not waited for)
+    // item i = (group i / ne, element i % ne): consecutive threads read consecutive granules of a group's run
     bool good = true;
-    for (int base = 0; base < ne * NGpad; base += 8 * (int)blockDim.x) {
+    for (int base = 0; base < ne * NG; base += 8 * (int)blockDim.x) {
       int gi[8], at[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int i = base + u * (int)blockDim.x + (int)threadIdx.x;
-        const bool use = i < ne * NGpad && (i % NGpad) < NG;
-        at[u] = use ? i : -1;
-        gi[u] = use ? eb * NGpad + i : -1;
+        const bool use = i < ne * NG;
+        const int g = use ? i / ne : 0, el = use ? i - g * ne : 0;
+        at[u] = use ? el * NG + g : -1;
+        gi[u] = use ? g * Epad + eb + el : -1;
       }
       double v[8];
       unsigned ok = granule_load8(P.part1, gi, tag, v);
@@ -863,10 +1007,8 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
     if (!good) *s_flag = 0;
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += (int)blockDim.x) {
-      const double* row = sm + el * NGpad;
-      double acc = row[0];
-      for (int g = 1; g < NG; ++g) acc += row[g];
-      out(eb + el, acc);
+      const double* row = sm + el * NG;
+      out(eb + el, lds_seq_sum(row[0], row + 1, NG - 1, 1));
     }
     __syncthreads();
   }
@@ -877,15 +1019,10 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
 // sequentially from the first.  sm: >= 4 * NG doubles of LDS, sOut: 4.  Ends with a barrier; false: a tag never showed up.
 __device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned long long tag, double* sm, double* sOut, int* s_flag) {
   const int NG = P.NG;
-  if (threadIdx.x == 0) *s_flag = 1;
-  __syncthreads();
+  if (!wait_sentinels(P.part2 + 2 * ((size_t)parity * NG * 4), 3, 4, NG, tag, s_flag)) return false;
   if (!fetch_granules(sm, P.part2 + 2 * ((size_t)parity * NG * 4), 4 * NG, tag)) *s_flag = 0;
   __syncthreads();
-  if (threadIdx.x < 4) {
-    double acc = sm[threadIdx.x];
-    for (int g = 1; g < NG; ++g) acc += sm[4 * g + threadIdx.x];
-    sOut[threadIdx.x] = acc;
-  }
+  if (threadIdx.x < 4) sOut[threadIdx.x] = lds_seq_sum(sm[threadIdx.x], sm + 4 + threadIdx.x, NG - 1, 4);
   __syncthreads();
   return *s_flag != 0;
 }
@@ -924,22 +1061,22 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 }
 
 // ---- deterministic mode, host-driven: one wavefront per workgroup, workgroup = group of chunks (window problems: one chunk)
-__device__ __forceinline__ PartSink make_sink(const BaDev& P, int g, int first) {
-  return PartSink{P.part1, P.part2, P.NGpad, P.NG, g, first, P.pay_parity, P.pay_tag};
+__device__ __forceinline__ PartSink make_sink(const BaDev& P, int g, int first, double* pst) {
+  return PartSink{P.part1, P.part2, pst, P.Epad, P.E, P.NG, g, first, P.pay_parity, P.pay_tag};
 }
 __device__ __forceinline__ ChunkTab global_tab(const BaDev& P, int chunk) { return ChunkTab{P.tab + P.tab_off[chunk], (P.K - 1) * P.K / 2, P.K - 1}; }
 
-__global__ __launch_bounds__(64) void ba_linearize_det_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+__global__ __launch_bounds__(DET_THREADS) void ba_linearize_det_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
   svo_latency_critical();
   apply_ctl(P, radius, ctl);
-  extern __shared__ double lds[];  // WAVE_LDS_DOUBLES
-  double* rec = lds;
-  double* lms = lds + 64 * REC_STRIDE;
+  extern __shared__ double lds[];  // wg_lds_doubles(E)
+  const WgLds L = wg_lds(lds, P.E);
   const int lane = threadIdx.x & 63, g = blockIdx.x;
   const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
   for (int chunk = c0; chunk < c1; ++chunk) {
-    const ObsRec R = load_obs(P, chunk, lane, P.points);
-    linearize_chunk_det(P, R, P.poses, radius, first_pass, global_tab(P, chunk), rec, lms, make_sink(P, g, chunk == c0));
+    ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
+    if (threadIdx.x < 64) R = load_obs(P, chunk, lane, P.points);
+    linearize_chunk_wg1(P, R, P.poses, radius, first_pass, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
     stores_acknowledged();  // the group's running sums are read back by the next chunk
   }
 }
@@ -947,13 +1084,13 @@ __global__ __launch_bounds__(64) void ba_linearize_det_kernel(BaDev P, double ra
 // ---- single rank, deterministic mode, chained iteration: pass A that FIRST forms payload2 from pass B's group sums (every
 // workgroup redundantly, in the declared order: a few KB of L2 reads instead of a launch boundary), takes Ceres' accept /
 // radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
-__global__ __launch_bounds__(64) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
+__global__ __launch_bounds__(DET_THREADS) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
   svo_latency_critical();
-  extern __shared__ double lds[];  // WAVE_LDS_DOUBLES, the staging rows double as scratch of the sums
+  extern __shared__ double lds[];  // wg_lds_doubles(E), the staging rows double as scratch of the sums
   __shared__ double sOut[4];
   __shared__ int sFlag;
-  double* rec = lds;
-  double* lms = lds + 64 * REC_STRIDE;
+  const WgLds L = wg_lds(lds, P.E);
+  double* rec = L.rec;
   const int lane = threadIdx.x & 63, g = blockIdx.x;
   const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
   // the first chunk's records are requested before the sums (both candidate landing points: the decision is not known yet)
@@ -969,7 +1106,7 @@ __global__ __launch_bounds__(64) void ba_decide_linearize_kernel(BaDev P, LmCtl 
   if (dec.accept) Rc.p = pc;
   for (int chunk = c0; chunk < c1; ++chunk) {
     if (chunk != c0) Rc = load_obs(P, chunk, lane, points_);
-    linearize_chunk_det(P, Rc, poses_, dec.next_radius, 0, global_tab(P, chunk), rec, lms, make_sink(P, g, chunk == c0));
+    linearize_chunk_wg1(P, Rc, poses_, dec.next_radius, 0, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
     stores_acknowledged();
   }
 }
@@ -1003,12 +1140,12 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
 // ---- deterministic mode, one LM iteration in one sweep: pass B at the current point, then (spec_radius > 0) pass A at
 // the candidate it just formed, with the radius an accepted step will have.  One wave per workgroup (spreads the
 // chunks over the CUs); the candidate landmark stays in registers between the passes.
-__global__ __launch_bounds__(64) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
+__global__ __launch_bounds__(DET_THREADS) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
   svo_latency_critical();
   __shared__ double sStep[STEP_LDS_DOUBLES];
-  extern __shared__ double lds[];  // WAVE_LDS_DOUBLES
-  double* rec = lds;
-  double* lms = lds + 64 * REC_STRIDE;
+  extern __shared__ double lds[];  // wg_lds_doubles(E)
+  const WgLds L = wg_lds(lds, P.E);
+  double* lms = L.rec;  // pass B's landmark scalars live in the idle staging rows
   const int lane = threadIdx.x & 63, g = blockIdx.x;
   const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
   // the observation records are requested BEFORE the step is staged: the HBM round trip and the PCIe round trip overlap
@@ -1019,12 +1156,13 @@ __global__ __launch_bounds__(64) void ba_step_kernel(BaDev P, double radius, dou
   double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
   for (int chunk = c0; chunk < c1; ++chunk) {
     if (chunk != c0) R = load_obs(P, chunk, lane, P.points);
-    const PartSink sink = make_sink(P, g, chunk == c0);
-    D3 cand;
-    backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3, nullptr, lms, &sink);
+    const PartSink sink = make_sink(P, g, chunk == c0, L.pst);
+    D3 cand = R.p;
+    if (threadIdx.x < 64) backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3, nullptr, lms, &sink);
     if (spec_radius > 0) {
+      __syncthreads();  // pass B kept its landmark scalars in the staging rows
       R.p = cand;
-      linearize_chunk_det(P, R, cand_poses_, spec_radius, 0, global_tab(P, chunk), rec, lms, sink);
+      linearize_chunk_wg1(P, R, cand_poses_, spec_radius, 0, global_tab(P, chunk), L, sink);
     }
     stores_acknowledged();
   }
@@ -1126,6 +1264,7 @@ struct LmDevArgs {
   int* host_flag;           // pinned completion word of the solve
   int host_seq;
   unsigned base_arrive;     // the delivery counter runs on from solve to solve (monotone, wrap-safe compares)
+  int tab_words;            // u16 words of LDS per wavefront for its chunk table (a multiple of 4)
   LmDevOpt opt;
   unsigned* dbg;            // per workgroup 16 words: its last command (diagnostics of a solve that gave up; null: none)
 };
@@ -1156,16 +1295,23 @@ __host__ __device__ static inline size_t ba_lm_ctl_doubles(int n, int K) { retur
 // dynamic LDS of ba_lm_kernel (doubles): [staging rows + landmark scalars of CPW wavefronts | controller workspace] (union) |
 // chunk tables | Jacobi scales of the pose columns | step block [dc | candidate poses | current poses]
 constexpr int LM_CPW = 2;
-__host__ __device__ static inline size_t ba_lm_union_doubles(int n, int K) { const size_t a = (size_t)LM_CPW * WAVE_LDS_DOUBLES, b = ba_lm_ctl_doubles(n, K); return a > b ? a : b; }
-__host__ __device__ static inline size_t ba_lm_lds_doubles(int n, int K) {
-  return ba_lm_union_doubles(n, K) + (size_t)LM_CPW * TAB_LDS_WORDS / 4 + 2 * (size_t)(n > 0 ? n : 1) + 14 * (size_t)K;
+__host__ __device__ static inline int ba_wire_elements(int K) { const int F = K - 1; return 18 * F * (F + 1) + 33 * F + 2; }
+__host__ __device__ static inline size_t ba_lm_union_doubles(int n, int K) { const size_t a = (size_t)LM_CPW * (size_t)wg_lds_doubles(ba_wire_elements(K)), b = ba_lm_ctl_doubles(n, K); return a > b ? a : b; }
+__host__ __device__ static inline size_t ba_lm_lds_doubles(int n, int K, int tab_words /* per wavefront, a multiple of 4, <= TAB_LDS_WORDS */) {
+  return ba_lm_union_doubles(n, K) + (size_t)LM_CPW * (size_t)tab_words / 4 + 2 * (size_t)(n > 0 ? n : 1) + 14 * (size_t)K;
 }
 
 // The E wire totals (granules under `tag`) -> the payload image [S | g_red | g_c | diag U | cost | sum g_p^2] in LDS, assembled as
 // the oracle does: S[(k,a),(k,b)] = U_k[min][max] + Schur_(k,k)[a][b]; upper blocks as summed; the step control reads the
 // lower triangle through the mirror (see the system build).  cU: 21 F doubles of scratch.  false: a tag never showed up.
-__device__ __forceinline__ bool lm_fetch_totals(double* cP, double* cU, const double* res, int F, int n, unsigned long long tag, double* elapsed) {
+__device__ __forceinline__ bool lm_fetch_totals(double* cP, double* cU, const double* res, int F, int n, unsigned long long tag, double* elapsed, int n_blocks, int* s_flag) {
   const int nU = F * (F + 1) / 2, E = 36 * nU + 33 * F + 2;
+  {
+    // the last element of every workgroup's slice, and the clock granule workgroup 0 writes behind its slice
+    const int per = (E + n_blocks - 1) / n_blocks, slices = (E + per - 1) / per;
+    if (!wait_sentinels(res, per - 1, per, slices - 1, tag, s_flag)) return false;
+    if (!wait_sentinels(res, E - 1, 1, 2, tag, s_flag)) return false;
+  }
   bool good = true;
   for (int base = 0; base < E + 1; base += 8 * (int)blockDim.x) {
     int gi[8];
@@ -1352,7 +1498,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
     const bool with_pay1 = cs.chain != 0 || cs.spec > 0;
     if (with_pay1) {
       if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
-      if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed)) { if (tid == 0) cs.bad = 1; }
+      if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
       if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
     }
     __syncthreads();
@@ -1366,7 +1512,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   } else {
     // a stand-alone pass A has finished: its totals are the linearisation in use
     if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
-    if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed)) { if (tid == 0) cs.bad = 1; }
+    if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
     if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
     __syncthreads();
     if (st == LMS_FIRST) {
@@ -1527,10 +1673,18 @@ struct LmLane { BaDev P; LmDevArgs a; };
 struct LmLanePtrs { const LmLane* p[SVO_MAX_LANES]; };
 
 struct LmWave { ObsRec R; ChunkRegs c; D3 cand; };
-struct LmShared { double sOut[4]; double sDec[2]; double sPay2[4 * 128]; int sGo; };
+struct LmShared { double sOut[4]; double sDec[2]; int sGo; };
+
+// The owner phases of this wavefront's chunk, in its own LDS (chunk_owner_phases<false>).
+__device__ __forceinline__ void lm_owner_phases(const BaDev& P, const LmWave& W, bool my_wave_works, const SufRegs& o, const uint16_t* tabs, const WgLds& L) {
+  if (!my_wave_works) return;
+  const int wave = threadIdx.x >> 6;
+  const ChunkTab T{tabs, (P.K - 1) * P.K / 2, P.K - 1};
+  chunk_owner_phases<false>(W.R, T, o, L.rec, make_sink(P, (int)blockIdx.x * LM_CPW + wave, 1, L.pst), L.s_ne);
+}
 
 // One LM step inside ba_lm_kernel (LMOP_ITERATE): pass B, [the decision,] pass A, this workgroup's slice of level 2.
-__device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, LmWave& W, bool my_wave_works, const ChunkTab& T, double* rec, double* lms,
+__device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, LmWave& W, bool my_wave_works, const uint16_t* tabs, const WgLds& L,
                                            double* union_lds, int union_doubles, LmDevState& cs, double* sStep, LmShared& sh, int n_blocks, long long t_first, long long* tp) {
   const int tid = threadIdx.x, wave = tid >> 6;
   long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
@@ -1542,25 +1696,31 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
   const int chain = cs.chain;
   const int with_pay1 = chain || spec_radius > 0;
   const int my_chunk = (int)blockIdx.x * LM_CPW + wave;
+  double* lms = L.rec;  // this wavefront's own LDS: pass B's landmark scalars live in the idle staging rows
   double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
-  const PartSink sink = make_sink(P, my_chunk, 1);  // window problems: group = chunk
+  const PartSink sink = make_sink(P, my_chunk, 1, L.pst);  // window problems: group = chunk
   LinPre pre;
+  SufRegs o;
+  o.freep = false;
   if (my_wave_works) {
     backsub_chunk(P, W.R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, W.cand, unused0, unused1, unused2, unused3, &W.c, lms, &sink);
     if (spec_radius > 0) {  // same sweep: pass A at the candidate with the predicted radius
       ObsRec Rc = W.R;
       Rc.p = W.cand;
-      linearize_chunk_det(P, Rc, cand_poses_, spec_radius, 0, T, rec, lms, sink, &W.c);
+      linearize_prefix(P, Rc, cand_poses_, pre, unused0);
+      suffix_math(P, Rc, pre, spec_radius, 0, L.rec, &W.c, o);
     }
   }
   stamp(0);
+  if (spec_radius > 0) lm_owner_phases(P, W, my_wave_works, o, tabs, L);
   if (chain) {
     ObsRec Rc = W.R;
     Rc.p = W.cand;
     if (my_wave_works) linearize_prefix(P, Rc, cand_poses_, pre, unused0);  // the other wavefronts' sums are on their way meanwhile
     stamp(1);
-    // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits
-    const bool ok = sum_pay2(P, P.pay_parity, P.pay_tag, sh.sPay2, sh.sOut, &sh.sGo);
+    // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits (the staging
+    // rows are idle between the passes: they are the scratch of the collection)
+    const bool ok = sum_pay2(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
     if (!ok) return false;
     if (tid == 0) {
       const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, sh.sOut[0], sh.sOut[1]);
@@ -1572,19 +1732,23 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
     stamp(2);
     if (my_wave_works) {
       const bool accept = sh.sDec[0] != 0.0;
-      if (accept) linearize_suffix_det(P, Rc, pre, sh.sDec[1], 0, T, rec, lms, sink, &W.c);
-      else linearize_chunk_det(P, W.R, cur_poses_, sh.sDec[1], 0, T, rec, lms, sink, &W.c);
+      if (!accept) linearize_prefix(P, W.R, cur_poses_, pre, unused0);  // rejected: the radius-free part again, at the current point
+      suffix_math(P, accept ? Rc : W.R, pre, sh.sDec[1], 0, L.rec, &W.c, o);
     }
+    lm_owner_phases(P, W, my_wave_works, o, tabs, L);
   }
   stamp(3);
   if (!with_pay1) return true;
-  __syncthreads();  // both wavefronts are through their passes: the staging rows become the scratch of level 2
-  // level 2: this workgroup's slice of the wire elements
+  __syncthreads();  // both wavefronts are through their passes: their LDS becomes the scratch of level 2
+  // level 2: this workgroup's slice of the wire elements.  A workgroup WITHOUT a slice must not wait for anybody's partials:
+  // nobody waits for it in return, so the fast workgroups may already be posting the next command's (the hang of the first
+  // version: E = 2 for a one-keyframe window, 494 elements over 47 workgroups leave two of them without a slice)
   const int per = (P.E + n_blocks - 1) / n_blocks;
   const int e0 = min(P.E, (int)blockIdx.x * per), e1 = min(P.E, e0 + per);
   double* res = a.dev_res;
   const unsigned long long tag = P.pay_tag;
-  const bool ok = reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); });
+  bool ok = true;
+  if (e0 < e1) ok = reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); }, tp ? tp + 5 : nullptr);
   if (blockIdx.x == 0 && tid == 0)  // the clock every controller tests (see the kernel's header): seconds since this workgroup's first pass
     granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
   stamp(4);
@@ -1614,10 +1778,9 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int n = P.n, K = P.K, nn = n > 0 ? n : 1;
   const int union_doubles = (int)ba_lm_union_doubles(n, K);
   double* union_lds = lds;                                         // staging rows + landmark scalars | controller workspace
-  double* rec = lds + wave * WAVE_LDS_DOUBLES;
-  double* lms = rec + 64 * REC_STRIDE;
-  uint16_t* tabs = reinterpret_cast<uint16_t*>(lds + union_doubles) + wave * TAB_LDS_WORDS;
-  double* cSc = lds + union_doubles + LM_CPW * TAB_LDS_WORDS / 4;  // persistent: Jacobi scales of the pose columns
+  const WgLds L = wg_lds(lds + wave * wg_lds_doubles(P.E), P.E);  // this wavefront's own staging rows and outgoing partials
+  uint16_t* tabs = reinterpret_cast<uint16_t*>(lds + union_doubles) + wave * a.tab_words;
+  double* cSc = lds + union_doubles + LM_CPW * a.tab_words / 4;  // persistent: Jacobi scales of the pose columns
   double* sStep = cSc + 2 * nn;                                    // [dc | candidate poses | current poses] (the second nn: spare)
   const int my_chunk = (int)blockIdx.x * LM_CPW + wave;
   const bool my_wave_works = my_chunk < P.C;
@@ -1637,7 +1800,6 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (shift && W.R.active && lane == W.R.first) { a.points_a[3 * W.R.j] = W.R.p.x; a.points_a[3 * W.R.j + 1] = W.R.p.y; a.points_a[3 * W.R.j + 2] = W.R.p.z; }
     load_chunk_table(P, my_chunk, tabs, shift);
   }
-  const ChunkTab T{tabs, (K - 1) * K / 2, K - 1};
   long long t_first = 0;
   __syncthreads();
   for (;;) {
@@ -1662,7 +1824,12 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       if (a.export_points && my_wave_works) {
         ObsRec R = W.R;  // the landmarks of the buffer the step control selected (a chained pass A may have run ahead of a step that was not taken)
         if (R.active) R.p = D3{P.points[3 * R.j], P.points[3 * R.j + 1], P.points[3 * R.j + 2]};
-        deliver_chunk_points(R, a.export_points, rec, 64 * REC_STRIDE);  // the staging rows are idle
+        deliver_chunk_points(R, a.export_points, union_lds + wave * ((64 * REC_STRIDE) / LM_CPW), (64 * REC_STRIDE) / LM_CPW);  // the staging rows are idle
+      }
+      if (a.dbg && tid == 0) {  // SVO_BA_TRACE: this workgroup's own split (ticks), for the spread over the workgroups of a solve
+        unsigned* g = a.dbg + 16 * blockIdx.x;
+        for (int i = 0; i < 6; ++i) g[8 + i] = (unsigned)cs.tp[i];
+        g[14] = (unsigned)cs.tp[6];
       }
       // everybody's results are out; the last workgroup to arrive publishes the host's completion word
       stores_acknowledged();
@@ -1676,17 +1843,25 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     long long* tp = a.dbg ? cs.tp : nullptr;
     if (op == LMOP_ITERATE) {
-      if (!lm_iterate(P, a, W, my_wave_works, T, rec, lms, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, tp)) return;
+      if (!lm_iterate(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, tp)) return;
     } else {  // pass A alone at the current point, then level 2
       const int first = cs.first;
       const double radius = cs.radius;
-      if (my_wave_works) linearize_chunk_det(P, W.R, sStep + nn + 7 * K, radius, first, T, rec, lms, make_sink(P, my_chunk, 1), &W.c);
+      SufRegs o;
+      o.freep = false;
+      if (my_wave_works) {
+        LinPre pre;
+        double unused = 0.0;
+        linearize_prefix(P, W.R, sStep + nn + 7 * K, pre, unused);
+        suffix_math(P, W.R, pre, radius, first, L.rec, &W.c, o);
+      }
+      lm_owner_phases(P, W, my_wave_works, o, tabs, L);
       __syncthreads();
       const int per = (P.E + n_blocks - 1) / n_blocks;
       const int e0 = min(P.E, (int)blockIdx.x * per), e1 = min(P.E, e0 + per);
       double* res = a.dev_res;
       const unsigned long long tag = P.pay_tag;
-      if (!reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); })) return;
+      if (e0 < e1 && !reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); })) return;
       if (blockIdx.x == 0 && tid == 0) granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
     }
     __syncthreads();
@@ -2055,6 +2230,7 @@ struct svo_ba {
   svo_lm_stats stats{};
   // SVO_TIMING accumulators
   double lm_tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double lm_wg_min[7] = {0, 0, 0, 0, 0, 0, 0}, lm_wg_mean[7] = {0, 0, 0, 0, 0, 0, 0}, lm_wg_max[7] = {0, 0, 0, 0, 0, 0, 0};  // SVO_BA_TRACE: spread of the per-workgroup split
   double lm_t_wait = 0, lm_t_ctl = 0, lm_t_body = 0, lm_t_total = 0; long lm_n = 0, lm_iters = 0, lm_same = 0, lm_used = 0, lm_steps = 0, lm_lins = 0;
   double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0, t_prep = 0, t_read = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
 };
@@ -2098,7 +2274,7 @@ static int ba_alloc(svo_ba* ba) {
   {
     // the granule stores for window-shaped problems up front (<= 128 chunks: one group per chunk), so that the hot path never
     // allocates; larger problems grow them in ba_ensure_partials
-    const size_t Fm = (size_t)Kmax - 1, Em = 18 * Fm * (Fm + 1) + 33 * Fm + 2;
+    const size_t Fm = (size_t)Kmax - 1, Em = ((18 * Fm * (Fm + 1) + 33 * Fm + 2) + 7) & ~(size_t)7;
     if (Em * 128 * 16 <= ((size_t)64 << 20)) {
       SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part1, 16 * Em * 128));
       SVO_HIP_CHECK(ctx, hipMemset(d.part1, 0, 16 * Em * 128));
@@ -2189,9 +2365,15 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
             1e-2 * ba->lm_t_ctl / ba->lm_n, 1e-2 * ba->lm_t_body / ba->lm_n, ba->lm_steps, ba->lm_same, ba->lm_used, ba->lm_lins);
   if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg)
     fprintf(stderr, "[svo ba]   per LM iteration (workgroup 0, us): pass B %.2f, radius-free part of pass A %.2f, collecting payload2 + decision %.2f, rest of pass A %.2f, "
-                    "own slice of level 2 incl. waiting for the partials %.2f | collecting the totals + assembly %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
-            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters,
+                    "own slice of level 2 %.2f (of which waiting for everybody's partials %.2f) | collecting the totals + assembly %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
+            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters, 1e-2 * ba->lm_tp[5] / ba->lm_iters,
             1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
+  if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg) {
+    static const char* nm[7] = {"pass B", "radius-free part of pass A", "collecting payload2", "rest of pass A", "own slice of level 2", "waiting for the partials", "collecting the totals"};
+    for (int sl = 0; sl < 7; ++sl)
+      fprintf(stderr, "[svo ba]   over the workgroups of a solve, per LM iteration (us): %-28s min %.2f mean %.2f max %.2f\n", nm[sl], 1e-2 * ba->lm_wg_min[sl] / ba->lm_iters,
+              1e-2 * ba->lm_wg_mean[sl] / ba->lm_iters, 1e-2 * ba->lm_wg_max[sl] / ba->lm_iters);
+  }
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
   void* ptrs[] = {ba->d_res, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.part1, d.part2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
@@ -2233,7 +2415,7 @@ extern "C" int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats) {
 // Destination index of pose-pair block (ka <= kb) among the F (F + 1) / 2 upper blocks, row-major.
 static inline int ba_upper_index(int ka, int kb, int F) { return ka * F - ka * (ka - 1) / 2 + (kb - ka); }
 
-// The granule stores of the loaded problem: partials of pass A (E x NGpad), of pass B (2 x NG x 4), ba_lm_kernel's totals
+// The granule stores of the loaded problem: partials of pass A (NG x Epad), of pass B (2 x NG x 4), ba_lm_kernel's totals
 // (E + 1).  Window-sized problems reach their sizes within a few keyframes; nothing is allocated per solve afterwards.
 // Fresh stores are zeroed: no command ever carries tag 0.
 static int ba_ensure_partials(svo_ba* ba) {
@@ -2250,7 +2432,7 @@ static int ba_ensure_partials(svo_ba* ba) {
     *cap = want;
     return SVO_OK;
   };
-  int rc = grow(&d.part1, &ba->cap_part1, (size_t)d.E * (size_t)(d.NGpad > 0 ? d.NGpad : 8));
+  int rc = grow(&d.part1, &ba->cap_part1, (size_t)d.Epad * (size_t)(d.NG > 0 ? d.NG : 1));
   if (!rc) rc = grow(&d.part2, &ba->cap_part2, 2 * 4 * (size_t)(d.NG > 0 ? d.NG : 1));
   if (!rc) rc = grow(&ba->d_res, &ba->cap_res, (size_t)d.E + 1);
   return rc;
@@ -2312,9 +2494,9 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
     const int nU = F * (F + 1) / 2;
     d.G = d.C <= 128 ? 1 : (d.C + 127) / 128;
     d.NG = d.C > 0 ? (d.C + d.G - 1) / d.G : 0;
-    d.NGpad = (d.NG + 7) & ~7;
     d.E = 36 * nU + 33 * F + 2;
-    d.det = (size_t)d.E * (size_t)(d.NGpad > 0 ? d.NGpad : 8) * 16 <= ((size_t)512 << 20) ? 1 : 0;
+    d.Epad = (d.E + 7) & ~7;
+    d.det = (size_t)d.Epad * (size_t)(d.NG > 0 ? d.NG : 1) * 16 <= ((size_t)512 << 20) ? 1 : 0;
     if (ba->opt.accumulation == SVO_BA_ACC_ATOMICS || ba->opt.accumulation == SVO_BA_ACC_MFMA) d.det = 0;
     SVO_REQUIRE(ctx, !(ba->opt.accumulation == SVO_BA_ACC_DETERMINISTIC && !d.det), "ba: problem too large for deterministic accumulation");
     ba->mfma_ok = !dup && d.n <= 128 && d.n > 0 && ba->opt.accumulation != SVO_BA_ACC_ATOMICS;
@@ -2666,11 +2848,14 @@ int ba_fused_budget(int device) {
   std::lock_guard<std::mutex> g(mu);
   if (budget[device] && share_of[device] == g_ba_cu_share) return budget[device];
   int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_lm_kernel, 128, sizeof(double) * ba_lm_lds_doubles(24, 5)) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ba_lm_kernel, 128, sizeof(double) * ba_lm_lds_doubles(24, 5, 256)) != hipSuccess) return 0;
   g_fused_per_cu = per_cu;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
   share_of[device] = g_ba_cu_share;
-  budget[device] = per_cu * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
+  // LDS is handed out in contiguous pieces: between the tracker's small workgroups a CU may not have room for the last
+  // workgroup the occupancy query promises, so one per CU is left out of the count
+  const int usable = per_cu >= 3 ? per_cu - 1 : (per_cu >= 1 ? 1 : 0);
+  budget[device] = usable * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
   return budget[device];
 }
 
@@ -2707,14 +2892,15 @@ bool ba_device_lm_wanted() {
   return svo_throughput_mode();
 }
 
-size_t ba_lm_lds_bytes(const BaDev& d) { return sizeof(double) * ba_lm_lds_doubles(d.n, d.K); }
+int ba_lm_tab_words(const svo_ba* ba) { return std::max(64, (ba->tab_max_words + 63) & ~63); }
+size_t ba_lm_lds_bytes(const svo_ba* ba) { return sizeof(double) * ba_lm_lds_doubles(ba->d.n, ba->d.K, ba_lm_tab_words(ba)); }
 
 // Fills the adjuster's launch record for the loaded problem; false: not eligible (use the host-driven path).
 bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   BaDev& d = ba->d;
   if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !(forced || ba->device_lm == 1 || (ba->device_lm < 0 && ba_device_lm_wanted())) || !ba->h_lane) return false;
   if (d.C > 128 || ba->tab_max_words > TAB_LDS_WORDS) return false;  // one group per chunk, every chunk table in LDS: window-sized problems
-  const size_t lds = ba_lm_lds_bytes(d);
+  const size_t lds = ba_lm_lds_bytes(ba);
   if (lds > 120 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   d.flag = nullptr;
@@ -2734,6 +2920,7 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   // unless the last one did not leave cleanly
   const bool fresh = ba->lm_counters_dirty || !ba->lm_have_base;
   a.base_arrive = fresh ? 0 : ba->lm_base;
+  a.tab_words = ba_lm_tab_words(ba);
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
@@ -2843,6 +3030,17 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   ba->stats.single_exchange = (int)r[LMR_SAME_SWEEP];
   ba->lm_same += (long)r[LMR_SAME_SWEEP]; ba->lm_used += (long)r[LMR_NEXT_USED]; ba->lm_steps += (long)r[LMR_STEP_CALLS]; ba->lm_lins += (long)r[LMR_LINEARIZE_CALLS];
   for (int i = 0; i < 12; ++i) ba->lm_tp[i] += r[LMR_TP0 + i];
+  if (ba->d_lmdbg && getenv("SVO_TIMING")) {
+    const int nb = (d.C + LM_CPW - 1) / LM_CPW;
+    std::vector<unsigned> g(16 * (size_t)nb);
+    if (hipMemcpy(g.data(), ba->d_lmdbg, sizeof(unsigned) * g.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int sl = 0; sl < 7; ++sl) {
+        double mn = 1e300, mx = 0, sum = 0;
+        for (int b = 0; b < nb; ++b) { const double v = g[16 * (size_t)b + 8 + sl]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
+        ba->lm_wg_min[sl] += mn; ba->lm_wg_max[sl] += mx; ba->lm_wg_mean[sl] += sum / nb;
+      }
+    }
+  }
   ba->lm_t_wait += r[LMR_T_WAIT]; ba->lm_t_ctl += r[LMR_T_CTL]; ba->lm_t_body += r[LMR_T_BODY]; ba->lm_t_total += r[LMR_T_TOTAL]; ba->lm_n++; ba->lm_iters += (long)r[LMR_ITERATIONS];
   if (sum) {
     sum->iterations = (int)r[LMR_ITERATIONS]; sum->successful_steps = (int)r[LMR_SUCCESSFUL]; sum->termination = (int)r[LMR_TERMINATION];
@@ -2854,7 +3052,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   return SVO_OK;
 }
 
-constexpr size_t WAVE_LDS_BYTES = sizeof(double) * WAVE_LDS_DOUBLES;
+inline size_t wave_lds_bytes(const BaDev& d) { return sizeof(double) * (size_t)wg_lds_doubles(d.E); }
 
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
   svo_ba* ba = static_cast<svo_ba*>(user);
@@ -2870,7 +3068,7 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
     (void)ba_next_tag(ba);
     if (d.NG > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
+      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
     }
     const int nb = d.NG > 0 ? ba_reduce_blocks(d.E) : 0;
     if (nb > 0) {
@@ -2935,7 +3133,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     const int nb = ba_reduce_blocks(d.E);
     {
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
-      hipLaunchKernelGGL(ba_step_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, radius, same_sweep ? spec_radius : 0.0);
+      hipLaunchKernelGGL(ba_step_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, radius, same_sweep ? spec_radius : 0.0);
     }
     if (!chain) {
       const int blocks = (same_sweep ? nb : 0) + 1;
@@ -2945,7 +3143,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, lc);
+      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, lc);
     } else {
       ba_aim_reduce(ba, 1, false);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, st, d, 0, 1, lc);
@@ -2954,7 +3152,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       const LmCtl lcs = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 1};
       hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, lcs, ba->d_pay, d.ctl_dev);
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(64), WAVE_LDS_BYTES, st, d, 0.0, 0, (const double*)d.ctl_dev);
+      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, 0.0, 0, (const double*)d.ctl_dev);
     }
     if (chain) {
       ba_aim_reduce(ba, nb, true);
