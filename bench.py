@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-stream measurement (profiling runs)")
+    ap.add_argument("--no-streaming", action="store_true", help="default line only: skip the host-fed (PCIe upload timed) variant of the same lanes")
     ap.add_argument("--no-other-workloads", action="store_true", help="default line only: skip the driver-timed figures of BASELINE configs[2..4]")
     ap.add_argument("--cpu-frames", type=int, default=16)
     return ap.parse_args()
@@ -138,6 +139,54 @@ def cpu_baseline(p, L, R, frames):
                 value_4_threads=n / dt4), res
 
 
+RES_KEY = lambda r: (r.n_detected, r.n_tracked, r.n_inliers, r.n_new, r.is_keyframe, r.ba_iterations, list(r.pose7))
+
+
+def group_self_parity(groups, B):
+    """Every lane of every group, every timed step: the SAME frames from a reset group must give the SAME result records, bit for
+    bit (a stale or late hand-over inside a solve would show here on whatever lane and step it hits)."""
+    lanes = steps = bad = 0
+    first_bad = None
+    for gi, g in enumerate(groups):
+        if not g.raws:
+            continue
+        rec = len(g.raws[0]) // (g.n * B)
+        ref = g.raws[0]
+        steps = max(steps, len(g.raws))
+        lanes += g.n
+        for si, raw in enumerate(g.raws[1:], 1):
+            if raw == ref:
+                continue
+            for l in range(g.n):
+                if raw[l * B * rec:(l + 1) * B * rec] != ref[l * B * rec:(l + 1) * B * rec]:
+                    bad += 1
+                    first_bad = first_bad or {"group": gi, "lane": l, "step": si}
+    return {"lanes_checked": lanes, "steps_checked": steps, "lane_steps_that_differ_from_step_0": bad, "first": first_bad,
+            "what": "raw svo_frame_result records of every lane, every timed step against the first timed step"}
+
+
+def group_parity_vs_cpu(groups, B, lane0_oracle, per_group=4):
+    """The CPU oracle on `per_group` lanes of every group (lane 0 of group 0 comes from the cpu_baseline leg): counts, keyframe
+    decisions, LM iteration counts and poses must be identical."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = [(gi, l) for gi, g in enumerate(groups) for l in range(min(per_group, g.n)) if (gi, l) != (0, 0)]
+
+    def run(job):
+        gi, l = job
+        p, L, R = groups[gi].data[l]
+        pipe = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=MAXC, quality=QUALITY,
+                          min_feature_distance=MIN_DIST, parallax_thresh=20.0, window_size=WINDOW, max_features=MAX_FEAT, ba_max_iterations=50, num_threads=2)
+        return [RES_KEY(pipe.process(L[i], R[i])) for i in range(B)]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        refs = list(ex.map(run, jobs))
+    bad = [job for job, ref in zip(jobs, refs) if [RES_KEY(r) for r in groups[job[0]].all_res[job[1]]] != ref]
+    ok0 = [RES_KEY(r) for r in groups[0].all_res[0][:len(lane0_oracle)]] == [RES_KEY(r) for r in lane0_oracle]
+    return {"lanes_checked": len(jobs) + 1, "lanes_that_differ": len(bad) + (0 if ok0 else 1), "lanes": [[0, 0]] + [list(j) for j in jobs],
+            "frames_per_lane": B}
+
+
 class _Stream:
     """One independent stereo stream: its own svo_ctx (HIP stream), pipeline and BA worker, its own frames."""
 
@@ -187,11 +236,42 @@ class _Group:
         self.B, self.n = B, n
         self.res = None
         self.all_res = None
+        self.data = data             # (params, left, right) per lane: the parity legs render nothing again
+        self.raws = []               # per step: every lane's raw result records (identical frames => identical bits, checked after the timed region)
+        self.stats_sum = {}          # launches / lane-stages per stage, summed over the steps since clear_counters()
+
+    def clear_counters(self):
+        self.raws, self.stats_sum = [], {}
 
     def step(self):
         self.pipe.reset()
         self.all_res = self.pipe.process_batch_dev(self.dL.data_ptr(), self.dR.data_ptr(), self.B * W * H, self.B)
         self.res = self.all_res[0]
+        self.raws.append(self.pipe.last_raw)
+        for k, v in self.pipe.last_stats().items():
+            a = self.stats_sum.setdefault(k, [0, 0])
+            a[0] += v[0]; a[1] += v[1]
+
+    def fill_staging(self):
+        """The lanes' frames into BOTH pinned staging slots (what an image callback would do for every batch; the frames
+        are the same every step, so it is done once, outside the timed region)."""
+        for slot in (0, 1):
+            sl, sr = self.pipe.staging(slot)
+            for l, (_, Lh, Rh) in enumerate(self.data):
+                sl[l, :self.B], sr[l, :self.B] = Lh, Rh
+        self.slot = 0
+        self.pipe.upload(0, self.B)
+
+    def step_streaming(self):
+        """One step fed from HOST memory: the upload of the next step's batch is started first (copy stream), then the batch
+        uploaded during the previous step is processed."""
+        self.pipe.reset()
+        nxt = self.slot ^ 1
+        self.pipe.upload(nxt, self.B)
+        self.all_res = self.pipe.process_uploaded(self.slot, self.B)
+        self.res = self.all_res[0]
+        self.raws.append(self.pipe.last_raw)
+        self.slot = nxt
 
     def close(self):
         self.pipe.close()
@@ -245,6 +325,11 @@ def run_kitti(args):
         single = {"value": B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps,
                   "note": "one stream alone on the GPU (per rank)"}
     ctx.profile_select(args.profile_kernel)
+    if NG > 1:
+        streams[1].ctx.profile_select("ba_step")  # the solve launches of the second group, timed live as well (HIP events on its solve lines)
+    for st in streams:
+        if hasattr(st, "clear_counters"):
+            st.clear_counters()
     barrier_sync(torch, dist, ctx)
     cpu0 = time.process_time()
     t0 = time.perf_counter()
@@ -256,6 +341,10 @@ def run_kitti(args):
     host_cores = (time.process_time() - cpu0) / dt  # CPU time of all threads of this rank over the timed region
     k_ms, k_n = ctx.profile_read()
     ctx.profile_select(None)
+    ba_ms, ba_n = (0.0, 0)
+    if NG > 1:
+        ba_ms, ba_n = streams[1].ctx.profile_read()
+        streams[1].ctx.profile_select(None)
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -285,7 +374,7 @@ def run_kitti(args):
     # that binds it (HIP events on the library's stream over the timed region + the committed SQ counter pass)
     avg_us = 1e3 * k_ms / k_n if k_n > 0 else None
     lanes_per_launch = 1.0
-    g0_stats = streams[0].pipe.last_stats() if NG else None  # of the group's last step
+    g0_stats = streams[0].stats_sum if NG else None  # summed over the timed region
     if g0_stats and g0_stats.get("track", [0, 0])[0]:
         lanes_per_launch = g0_stats["track"][1] / g0_stats["track"][0]
     out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, avg_us, res, k_n, lanes_per_launch, bool(NG))
@@ -314,8 +403,48 @@ def run_kitti(args):
             return np.array(c)
         ate = float(S.api.ate_rmse(centres(res[:m]), centres(ores[:m]), False)) if m >= 3 else 0.0
         out["parity_vs_cpu"] = {"frames": m, "index_sets_and_poses_identical": bool(same), "ate_rmse_m": ate}
+        if NG > 0:
+            out["parity_vs_cpu"].update(group_parity_vs_cpu(streams, B, ores))
     if NG > 0:
-        out["config"]["launches_per_step_of_group_0"] = {k: v for k, v in streams[0].pipe.last_stats().items()}
+        out["parity_self"] = group_self_parity(streams, B)
+        launches_sum = {k: list(v) for k, v in streams[0].stats_sum.items()}
+    if NG > 0 and not args.no_streaming:
+        # the same lanes fed from host memory: every step uploads its batch over PCIe (pinned staging slots of the groups,
+        # the upload of step s+1 overlapped with the processing of step s); results must equal the resident ones bit for bit
+        resident_raw = [g.raws[0] if g.raws else None for g in streams]
+        for g in streams:
+            g.fill_staging()
+            g.clear_counters()
+
+        def swork(st, k):
+            for _ in range(k):
+                st.step_streaming()
+        def run_streaming(k):
+            th = [threading.Thread(target=swork, args=(st, k)) for st in streams]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        run_streaming(max(1, args.warmup))
+        for g in streams:
+            g.clear_counters()
+        barrier_sync(torch, dist, ctx)
+        t1 = time.perf_counter()
+        run_streaming(args.steps)
+        for st in streams:
+            st.ctx.sync()
+        barrier_sync(torch, dist, ctx)
+        dts = time.perf_counter() - t1
+        same = all(r is not None and all(raw == r for raw in g.raws) for g, r in zip(streams, resident_raw))
+        out["streaming"] = {"value": NS * B * args.steps / dts, "unit": "frames/s", "ms_per_step": 1e3 * dts / args.steps,
+                            "fraction_of_resident": (NS * B * args.steps / dts) / (frames / world / dt),
+                            "pcie_gbs": 2.0 * NS * B * W * H * args.steps / dts / 1e9,
+                            "bit_identical_to_resident": bool(same),
+                            "note": "per rank; svo_pipeline_group_upload / _process_uploaded: host images in the groups' pinned staging slots, H2D of "
+                                    "step s+1 on a copy stream while step s is processed"}
+    if NG > 0:
+        out["config"]["launches_per_step_of_group_0"] = {k: [round(v[0] / args.steps, 1), round(v[1] / args.steps, 1)] for k, v in launches_sum.items()}
+        if ba_n:
+            out["roofline"]["solve_launches_live"] = {"kernel": "ba_lm_kernel", "avg_launch_us": 1e3 * ba_ms / ba_n, "launches": ba_n,
+                                                       "measured": "HIP events on the solve lines of the second pipeline group over the timed region"}
     for st in streams:
         st.close()
     if single_pipe is not None:

@@ -392,6 +392,23 @@ int svo_pipeline_group_lanes(const svo_pipeline_group* g);
  * after lane l-1's.  results: n_lanes x batch, lane-major. */
 int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const uint8_t* left, const uint8_t* right, size_t lane_stride,
                                          int batch, svo_frame_result* results);
+/* Host-pointer / streaming entry.  The reference hands over HOST images frame by frame (cv::Mat copies made in the image
+ * callback, src/vo_node.cpp:70-73, consumed at :141-143): a group takes them through TWO pinned staging slots it owns.
+ *   svo_pipeline_group_staging   the slot's buffers: n_lanes x max_batch x height x width bytes each, lane_stride =
+ *                                max_batch x width x height.  The caller writes the next batch there in place (the
+ *                                callback's copy lands where the DMA engine reads it: no second host copy);
+ *   svo_pipeline_group_upload    starts the H2D copy of the slot's first `batch` frames per lane on the group's copy stream
+ *                                and returns at once: the upload of batch b+1 overlaps the processing of batch b;
+ *   svo_pipeline_group_process_uploaded  waits for the slot's upload, then processes it exactly as
+ *                                svo_pipeline_group_process_batch_dev does (bit-identical results);
+ *   svo_pipeline_group_process_batch     convenience, nothing overlapped: caller-owned host images are copied into slot 0,
+ *                                uploaded and processed (what ImageProcessor::process(const StereoPair&) does, for every lane).
+ * Streaming loop: fill(0); upload(0); for b: { fill((b+1)&1); upload((b+1)&1); process_uploaded(b&1); }. */
+int svo_pipeline_group_staging(svo_pipeline_group* g, int slot, uint8_t** left, uint8_t** right, size_t* lane_stride);
+int svo_pipeline_group_upload(svo_pipeline_group* g, int slot, int batch);
+int svo_pipeline_group_process_uploaded(svo_pipeline_group* g, int slot, svo_frame_result* results);
+int svo_pipeline_group_process_batch(svo_pipeline_group* g, const uint8_t* left, const uint8_t* right, size_t lane_stride,
+                                     int batch, svo_frame_result* results);
 int svo_pipeline_group_get_tracked(svo_pipeline_group* g, int lane, int64_t* ids, float* xy, int capacity, int* n);
 /* Launch statistics of the last process_batch call, by stage: 0 track (LK + compaction), 1 PnP hypotheses, 2 PnP
  * refinement, 3 dedup / stereo + triangulation, 4 bundle-adjustment solves, 5 corner detection + pyramids;

@@ -165,6 +165,7 @@ SYMBOLS = [
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_pipeline_group_create", "svo_pipeline_group_destroy", "svo_pipeline_group_reset", "svo_pipeline_group_lanes",
     "svo_pipeline_group_process_batch_dev", "svo_pipeline_group_get_tracked", "svo_pipeline_group_last_stats",
+    "svo_pipeline_group_staging", "svo_pipeline_group_upload", "svo_pipeline_group_process_uploaded", "svo_pipeline_group_process_batch",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
     "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve", "svo_cholesky_solve_dev", "svo_draw_track", "svo_pipeline_draw_track",
 ]
@@ -630,6 +631,39 @@ class PipelineGroup:
         res = (FrameResult * (self.n_lanes * batch))()
         self.ctx._chk(self.L.svo_pipeline_group_process_batch_dev(self.h, C.c_void_p(left_ptr), C.c_void_p(right_ptr), C.c_size_t(lane_stride),
                                                                   batch, res), "svo_pipeline_group_process_batch_dev")
+        self.last_raw = bytes(res)  # every lane's results as the library wrote them (it zeroes the records first): bench.py's bit-for-bit checks
+        return [list(res[l * batch:(l + 1) * batch]) for l in range(self.n_lanes)]
+
+    def staging(self, slot):
+        """The slot's pinned staging buffers as numpy views (n_lanes, max_batch, H, W): the caller fills them in place."""
+        lp, rp, stride = C.POINTER(C.c_uint8)(), C.POINTER(C.c_uint8)(), C.c_size_t(0)
+        self.L.svo_pipeline_group_staging.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.ctx._chk(self.L.svo_pipeline_group_staging(self.h, slot, C.byref(lp), C.byref(rp), C.byref(stride)), "svo_pipeline_group_staging")
+        h, w = self.prm.height, self.prm.width
+        mb = stride.value // (h * w)
+        shape = (self.n_lanes, mb, h, w)
+        n = self.n_lanes * mb * h * w
+        return (np.ctypeslib.as_array(lp, shape=(n,)).reshape(shape), np.ctypeslib.as_array(rp, shape=(n,)).reshape(shape))
+
+    def upload(self, slot, batch):
+        self.ctx._chk(self.L.svo_pipeline_group_upload(self.h, slot, batch), "svo_pipeline_group_upload")
+
+    def process_uploaded(self, slot, batch):
+        res = (FrameResult * (self.n_lanes * batch))()
+        self.L.svo_pipeline_group_process_uploaded.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        self.ctx._chk(self.L.svo_pipeline_group_process_uploaded(self.h, slot, res), "svo_pipeline_group_process_uploaded")
+        self.last_raw = bytes(res)
+        return [list(res[l * batch:(l + 1) * batch]) for l in range(self.n_lanes)]
+
+    def process_batch(self, left, right):
+        """left/right: (n_lanes, B, H, W) uint8 HOST arrays (the convenience entry: copy into slot 0, upload, process)."""
+        left, right = _u8(left), _u8(right)
+        batch = left.shape[1]
+        res = (FrameResult * (self.n_lanes * batch))()
+        self.L.svo_pipeline_group_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+        self.ctx._chk(self.L.svo_pipeline_group_process_batch(self.h, _p(left), _p(right), C.c_size_t(batch * left.shape[2] * left.shape[3]), batch, res),
+                      "svo_pipeline_group_process_batch")
+        self.last_raw = bytes(res)
         return [list(res[l * batch:(l + 1) * batch]) for l in range(self.n_lanes)]
 
     def get_tracked(self, lane, capacity=8192):

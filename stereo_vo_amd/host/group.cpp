@@ -195,6 +195,12 @@ struct svo_pipeline_group {
   int pnp_iterations = 0, mask_words_cap = 0;
   // statistics of the last batch (launches by kind and the lanes they carried)
   long launches[6] = {0, 0, 0, 0, 0, 0}, lanes_carried[6] = {0, 0, 0, 0, 0, 0};
+  // host-pointer / streaming entry: two pinned staging slots, their device twins, a copy stream (allocated on first use)
+  uint8_t* h_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};  // [slot][left / right]
+  uint8_t* d_stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  hipStream_t st_copy = nullptr;
+  hipEvent_t ev_up[2] = {nullptr, nullptr};
+  int up_batch[2] = {0, 0};  // frames per lane of the upload in flight / completed in the slot (0: none)
 };
 
 namespace {
@@ -288,6 +294,11 @@ extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
     if (g->st_lk[i] && g->st_lk[i] != g->ctx->stream) { (void)hipStreamSynchronize(g->st_lk[i]); (void)hipStreamDestroy(g->st_lk[i]); }
     if (g->st_chain[i]) { (void)hipStreamSynchronize(g->st_chain[i]); (void)hipStreamDestroy(g->st_chain[i]); }
     if (g->st_ba[i]) { (void)hipStreamSynchronize(g->st_ba[i]); (void)hipStreamDestroy(g->st_ba[i]); }
+  }
+  if (g->st_copy) { (void)hipStreamSynchronize(g->st_copy); (void)hipStreamDestroy(g->st_copy); }
+  for (int sl = 0; sl < 2; ++sl) {
+    if (g->ev_up[sl]) (void)hipEventDestroy(g->ev_up[sl]);
+    for (int e = 0; e < 2; ++e) { if (g->h_stage[sl][e]) (void)hipHostFree(g->h_stage[sl][e]); if (g->d_stage[sl][e]) (void)hipFree(g->d_stage[sl][e]); }
   }
   for (Lane* l : g->lanes) { if (l->ba) svo_ba_destroy(l->ba); delete l; }
   for (void* p : g->dev_allocs) (void)hipFree(p);
@@ -1077,4 +1088,83 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   if (error) { quiesce_after_error(g); return error; }
   if (!ctx->err.empty()) return SVO_ERR_HIP;
   return SVO_OK;
+}
+
+// ---- host-pointer / streaming entry (include/svo.h): the reference's images are host cv::Mat copies made in the image
+// callback (src/vo_node.cpp:70-73) and consumed frame by frame (:141-143)
+namespace {
+int ensure_staging(svo_pipeline_group* g) {
+  if (g->st_copy) return SVO_OK;
+  svo_ctx* ctx = g->ctx;
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)g->n_lanes * (size_t)g->max_batch * (size_t)g->prm.width * (size_t)g->prm.height;
+  for (int sl = 0; sl < 2; ++sl) {
+    for (int e = 0; e < 2; ++e) {
+      SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&g->h_stage[sl][e], bytes, hipHostMallocDefault));
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&g->d_stage[sl][e], bytes));
+    }
+    SVO_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->ev_up[sl], hipEventDisableTiming));
+  }
+  SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&g->st_copy, hipStreamNonBlocking));
+  return SVO_OK;
+}
+}  // namespace
+
+extern "C" int svo_pipeline_group_staging(svo_pipeline_group* g, int slot, uint8_t** left, uint8_t** right, size_t* lane_stride) {
+  if (!g || slot < 0 || slot > 1 || !left || !right) return SVO_ERR_INVALID;
+  const int rc = ensure_staging(g);
+  if (rc) return rc;
+  *left = g->h_stage[slot][0]; *right = g->h_stage[slot][1];
+  if (lane_stride) *lane_stride = (size_t)g->max_batch * (size_t)g->prm.width * (size_t)g->prm.height;
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_group_upload(svo_pipeline_group* g, int slot, int batch) {
+  if (!g || slot < 0 || slot > 1) return SVO_ERR_INVALID;
+  svo_ctx* ctx = g->ctx;
+  SVO_REQUIRE(ctx, batch >= 1 && batch <= g->max_batch, "pipeline_group_upload: batch outside 1..max_batch");
+  int rc = ensure_staging(g);
+  if (rc) return rc;
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t istride = (size_t)g->prm.width * (size_t)g->prm.height, lane_bytes = (size_t)g->max_batch * istride;
+  for (int e = 0; e < 2; ++e) {
+    if (batch == g->max_batch)  // one contiguous run
+      SVO_HIP_CHECK(ctx, hipMemcpyAsync(g->d_stage[slot][e], g->h_stage[slot][e], lane_bytes * (size_t)g->n_lanes, hipMemcpyHostToDevice, g->st_copy));
+    else                        // the first `batch` frames of every lane
+      SVO_HIP_CHECK(ctx, hipMemcpy2DAsync(g->d_stage[slot][e], lane_bytes, g->h_stage[slot][e], lane_bytes, (size_t)batch * istride, (size_t)g->n_lanes,
+                                          hipMemcpyHostToDevice, g->st_copy));
+  }
+  SVO_HIP_CHECK(ctx, hipEventRecord(g->ev_up[slot], g->st_copy));
+  g->up_batch[slot] = batch;
+  return SVO_OK;
+}
+
+extern "C" int svo_pipeline_group_process_uploaded(svo_pipeline_group* g, int slot, svo_frame_result* results) {
+  if (!g || slot < 0 || slot > 1) return SVO_ERR_INVALID;
+  svo_ctx* ctx = g->ctx;
+  SVO_REQUIRE(ctx, g->st_copy && g->up_batch[slot] > 0, "pipeline_group_process_uploaded: nothing was uploaded into this slot");
+  SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  SVO_HIP_CHECK(ctx, hipEventSynchronize(g->ev_up[slot]));  // started a whole batch ago in a streaming loop: long complete
+  const int batch = g->up_batch[slot];
+  g->up_batch[slot] = 0;
+  const size_t lane_stride = (size_t)g->max_batch * (size_t)g->prm.width * (size_t)g->prm.height;
+  return svo_pipeline_group_process_batch_dev(g, g->d_stage[slot][0], g->d_stage[slot][1], lane_stride, batch, results);
+}
+
+extern "C" int svo_pipeline_group_process_batch(svo_pipeline_group* g, const uint8_t* left, const uint8_t* right, size_t lane_stride,
+                                                int batch, svo_frame_result* results) {
+  if (!g) return SVO_ERR_INVALID;
+  svo_ctx* ctx = g->ctx;
+  SVO_REQUIRE(ctx, left && right && results && batch >= 1 && batch <= g->max_batch, "pipeline_group_process_batch: bad arguments");
+  const size_t istride = (size_t)g->prm.width * (size_t)g->prm.height;
+  SVO_REQUIRE(ctx, lane_stride >= istride * (size_t)batch, "pipeline_group_process_batch: lanes overlap");
+  int rc = ensure_staging(g);
+  if (rc) return rc;
+  const size_t stage_stride = (size_t)g->max_batch * istride;
+  for (int l = 0; l < g->n_lanes; ++l) {
+    memcpy(g->h_stage[0][0] + (size_t)l * stage_stride, left + (size_t)l * lane_stride, (size_t)batch * istride);
+    memcpy(g->h_stage[0][1] + (size_t)l * stage_stride, right + (size_t)l * lane_stride, (size_t)batch * istride);
+  }
+  if ((rc = svo_pipeline_group_upload(g, 0, batch))) return rc;
+  return svo_pipeline_group_process_uploaded(g, 0, results);
 }

@@ -256,3 +256,63 @@ def test_hip_headline_load_24_lanes_full_size_two_groups_concurrently():
     for G in groups:
         G["g"].close()
         G["ctx"].close()
+
+
+@pytest.mark.gpu
+def test_hip_group_streaming_entry_equals_the_device_pointer_entry():
+    """The host-pointer entries (pinned staging slots, upload of batch b+1 overlapped with the processing of batch b; and the
+    copying convenience call) give every lane the results of svo_pipeline_group_process_batch_dev, bit for bit
+    (reference: the images are host cv::Mat copies handed over frame by frame, src/vo_node.cpp:70-73,141-143)."""
+    import torch
+    import stereo_vo_amd as S
+    n, lanes, batch = 12, 4, 4
+    seqs = [_seq(n, seed=0x5EED0600 + 7 * i) for i in range(lanes)]
+    p0 = seqs[0][0]
+    Ls = np.stack([s[1] for s in seqs])
+    Rs = np.stack([s[2] for s in seqs])
+    ctx = S.Context(p0.width, p0.height, max_batch=lanes * batch, max_corners=300, max_candidates=1 << 16, max_features=400)
+    g = _group(S, ctx, p0, 300, 12.0, 400, lanes)
+    # (1) device-pointer entry
+    want = [[] for _ in range(lanes)]
+    for b0 in range(0, n, batch):
+        dl, dr = torch.from_numpy(Ls[:, b0:b0 + batch].copy()).cuda(), torch.from_numpy(Rs[:, b0:b0 + batch].copy()).cuda()
+        res = g.process_batch_dev(dl.data_ptr(), dr.data_ptr(), batch * p0.width * p0.height, batch)
+        torch.cuda.synchronize()
+        for l in range(lanes):
+            want[l] += res[l]
+    # (2) streaming: fill slot, upload, process the previous one
+    g.reset()
+    got = [[] for _ in range(lanes)]
+    nb = n // batch
+    sl, sr = g.staging(0)
+    sl[:, :batch], sr[:, :batch] = Ls[:, 0:batch], Rs[:, 0:batch]
+    g.upload(0, batch)
+    for b in range(nb):
+        if b + 1 < nb:
+            nl, nr = g.staging((b + 1) & 1)
+            nl[:, :batch], nr[:, :batch] = Ls[:, (b + 1) * batch:(b + 2) * batch], Rs[:, (b + 1) * batch:(b + 2) * batch]
+            g.upload((b + 1) & 1, batch)
+        res = g.process_uploaded(b & 1, batch)
+        for l in range(lanes):
+            got[l] += res[l]
+    for l in range(lanes):
+        assert [KEY(r) for r in got[l]] == [KEY(r) for r in want[l]], l
+    # (3) the copying convenience entry, with a batch shorter than the slots (strided upload)
+    g.reset()
+    got = [[] for _ in range(lanes)]
+    for b0 in range(0, n, 3):
+        res = g.process_batch(Ls[:, b0:b0 + 3], Rs[:, b0:b0 + 3])
+        for l in range(lanes):
+            got[l] += res[l]
+    g.reset()
+    want3 = [[] for _ in range(lanes)]
+    for b0 in range(0, n, 3):
+        dl, dr = torch.from_numpy(Ls[:, b0:b0 + 3].copy()).cuda(), torch.from_numpy(Rs[:, b0:b0 + 3].copy()).cuda()
+        res = g.process_batch_dev(dl.data_ptr(), dr.data_ptr(), 3 * p0.width * p0.height, 3)
+        torch.cuda.synchronize()
+        for l in range(lanes):
+            want3[l] += res[l]
+    for l in range(lanes):
+        assert [KEY(r) for r in got[l]] == [KEY(r) for r in want3[l]], l
+    g.close()
+    ctx.close()
