@@ -454,6 +454,19 @@ def run_kitti(args):
     return out if rank == 0 else None
 
 
+def window_load(kfs, window):
+    """Observations and live landmarks of the sliding window behind every keyframe (steady state: full windows only): a keyframe
+    adds n_inliers observations of known landmarks and n_new new ones (src/bundle_adjuster.cpp:72-121)."""
+    obs = [k.n_inliers + k.n_new for k in kfs]
+    o, l = [], []
+    for i in range(window - 1, len(kfs)):
+        w = range(i - window + 1, i + 1)
+        o.append(sum(obs[j] for j in w))
+        l.append(kfs[i - window + 1].n_inliers + sum(kfs[j].n_new for j in w))
+    return {"mean_observations_per_window": float(np.mean(o)) if o else 0.0, "mean_live_landmarks_per_window": float(np.mean(l)) if l else 0.0,
+            "mean_detected": 0.0 if not kfs else float(np.mean([k.n_detected for k in kfs]))}
+
+
 def run_kitti_stream(args):
     """BASELINE configs[2]: one KITTI-00-shaped stream (default 4541 frames) through ONE pipeline with a 10-keyframe
     window, handed over as HOST buffers batch by batch (svo_pipeline_process_batch: the PCIe upload is inside the timed
@@ -517,6 +530,7 @@ def run_kitti_stream(args):
            "config": {"workload": f"kitti00_shaped_stream_{n_frames}_frames_10kf_window (BASELINE configs[2])",
                       "label": "ONE stream per GPU, host buffers in (PCIe upload timed), nothing reset", "batch": B, "window": window,
                       "keyframes": n_kf, "mean_tracked": float(np.mean([r.n_tracked for r in res_all if r.n_tracked] or [0])),
+                      **window_load([r for r in res_all if r.is_keyframe], window),
                       "ba_lm_iterations": int(sum(r.ba_iterations for r in res_all)),
                       "ate_rmse_m_at_keyframes_vs_generator": ate, "path_length_m": path,
                       "pcie_bytes_per_step": 2 * B * W * H}}
@@ -551,7 +565,7 @@ HDW, HDH = 1280, 720
 
 def run_hd10k(args):
     """BASELINE configs[4]: synthetic 1280x720 stereo stream (d435i focal, config/d435i.yaml:1,4), ~10 k features per frame
-    (max_corners 10000, quality 0.01, minDistance 6), 10-keyframe window, ONE stream resident in HBM, 64 frames in steps of 16."""
+    (max_corners 10000, quality 0.001, minDistance 4: the cap is reached on the synthetic scene), 10-keyframe window, ONE stream resident in HBM, 64 frames in steps of 16."""
     import stereo_vo_amd as S
     torch, dist, rank, local, world = dist_setup(args.gpus)
     B, n_frames = 16, 64
@@ -566,7 +580,7 @@ def run_hd10k(args):
     pp = S.pipeline_default_params()
     pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
     pp.width, pp.height = HDW, HDH
-    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 10000, 0.01, 6.0, 10000, 10
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 10000, 0.001, 4.0, 10000, 10
     pp.ba_max_time_s = 0.0
     dev = torch.device("cuda", local)
     dL, dR = torch.from_numpy(L).to(dev), torch.from_numpy(R).to(dev)
@@ -596,6 +610,7 @@ def run_hd10k(args):
                       "keyframes": int(sum(r.is_keyframe for r in res)),
                       "mean_tracked": float(np.mean([r.n_tracked for r in res if r.n_tracked] or [0])),
                       "mean_detected": float(np.mean([r.n_detected for r in res])),
+                      **{k: v for k, v in window_load([r for r in res if r.is_keyframe], 10).items() if k != "mean_detected"},
                       "ba_lm_iterations": int(sum(r.ba_iterations for r in res)), "fps_vs_60": n_frames / dt / 60.0},
            "roofline": {"bound": "hbm", "kernel": "whole front end per stereo pair (6.33 A bytes, SURVEY 8d)", "achieved": gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": 6.33 * A, "traffic": None}}
@@ -605,8 +620,8 @@ def run_hd10k(args):
         cores = min(os.cpu_count() or 1, 16)
         os.environ["OMP_NUM_THREADS"] = str(cores)
         n = 6
-        op = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=HDW, height=HDH, max_corners=10000, quality=0.01,
-                        min_feature_distance=6.0, parallax_thresh=20.0, window_size=10, max_features=10000, ba_max_iterations=50, num_threads=cores)
+        op = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=HDW, height=HDH, max_corners=10000, quality=0.001,
+                        min_feature_distance=4.0, parallax_thresh=20.0, window_size=10, max_features=10000, ba_max_iterations=50, num_threads=cores)
         t1 = time.perf_counter()
         ores = [op.process(L[i], R[i]) for i in range(n)]
         dtc = time.perf_counter() - t1

@@ -28,11 +28,21 @@ inline double unit(uint64_t h) { return (double)(h >> 11) * (1.0 / 9007199254740
 
 struct Cam { double R[9]; double C[3]; };
 
+// The camera WEAVES along the street: the yaw rate keeps its magnitude and changes sign in the pattern + - - + every
+// kYawSwing frames, so the heading swings between -kYawSwing * yaw and +kYawSwing * yaw and the lateral offset returns to
+// zero every 4 kYawSwing frames (about +-2 m for the defaults: inside the walls at +-7.5 m).  Rounds 1-3 kept the sign: a
+// circle of radius step / yaw = 200 m that had left the street — walls, billboards — after a few hundred frames; what the
+// 4,541-frame stream of BASELINE configs[2] then saw was the ground plane alone (StereoBM accepted 12 % of the corners,
+// src/image_processor.cpp:173-176,193-194).  Frames 0 .. kYawSwing are what they were.
+constexpr int kYawSwing = 25;
+
 void cam_at(const svo_synth_params* p, int frame, Cam* cam) {
   const double a = 0.5 * p->yaw_per_frame;  // half-tangent of the per-frame yaw
-  const double c = (1.0 - a * a) / (1.0 + a * a), s = 2.0 * a / (1.0 + a * a);
+  const double c = (1.0 - a * a) / (1.0 + a * a), s_abs = 2.0 * a / (1.0 + a * a);
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, C[3] = {0, 0, 0};
   for (int i = 0; i < frame; ++i) {
+    const int phase = (i / kYawSwing) & 3;
+    const double s = (phase == 0 || phase == 3) ? s_abs : -s_abs;
     // C += R * (step_x, 0, step_z)
     C[0] += R[0] * p->step_x + R[2] * p->step_z;
     C[1] += R[3] * p->step_x + R[5] * p->step_z;

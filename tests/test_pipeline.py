@@ -215,8 +215,9 @@ def test_hip_pipeline_config3_ten_keyframe_window(ctx):
 
 @pytest.mark.gpu
 def test_hip_pipeline_config5_hd_many_features():
-    """BASELINE configs[4] shape: 1280x720, ~10k features per frame (d435i intrinsics).  Exercises the
-    candidate counts beyond the LDS tables of corner_select, >8k-feature LK launches and a ~10k-landmark window solve."""
+    """BASELINE configs[4] at its stated load: 1280x720, 10,000 corners detected per frame (d435i intrinsics; quality 0.001 /
+    minDistance 4 — the values bench.py's hd10k workload uses — reach the 10,000 cap on the synthetic scene).  Exercises candidate
+    counts beyond the LDS tables of corner_select, LK launches of 8,000+ features and a window solve over them."""
     import stereo_vo_amd as S
     c = S.Context(1280, 720, max_batch=2, max_corners=10240, max_candidates=1 << 17, max_features=10240)
     p = S.synth_default(1280, 720)
@@ -226,13 +227,13 @@ def test_hip_pipeline_config5_hd_many_features():
     pp = S.pipeline_default_params()
     pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
     pp.width, pp.height = 1280, 720
-    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 10000, 0.01, 6.0, 10000, 10
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = 10000, 0.001, 4.0, 10000, 10
     pp.ba_max_time_s = 0.0
     g = S.Pipeline(c, pp)
-    o = _ora_pipe(p, min_feature_distance=6.0, max_corners=10000, quality=0.01, max_features=10000, window_size=10)
+    o = _ora_pipe(p, min_feature_distance=4.0, max_corners=10000, quality=0.001, max_features=10000, window_size=10)
     _run_pair(g, o, L, R, 2)
     ids, _ = g.tracked()
-    assert len(ids) > 3000
+    assert len(ids) > 6000
     g.close()
     c.close()
 
