@@ -477,13 +477,17 @@ def run_kitti_stream(args):
     B, window = args.batch, 10
     n_frames = max(B, args.frames)
     steps = (n_frames + B - 1) // B
-    ctx = S.Context(W, H, device=local, max_batch=B, max_corners=MAXC, max_candidates=1 << 16, max_features=MAX_FEAT)
+    # BASELINE configs[2] asks for ~5k live landmarks in a 10-keyframe window (~15k observations): on the synthetic
+    # street that takes 2,500 corners at quality 0.005 / minDistance 8 (measured with the oracle: 7.5k landmarks, 14k observations
+    # per window; configs[1]'s 1500 / 0.02 / 10 give 4.5k / 8.6k)
+    SMAXC, SQUAL, SMIND, SMAXF = 2500, 0.005, 8.0, 3000
+    ctx = S.Context(W, H, device=local, max_batch=B, max_corners=SMAXC, max_candidates=1 << 16, max_features=SMAXF)
     p = S.synth_default(W, H)
     p.seed += rank  # the default scene of the generator (the one tools/soak_long_stream.py and the KITTI driver test use)
     pp = S.pipeline_default_params()
     pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
     pp.width, pp.height = W, H
-    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = MAXC, QUALITY, MIN_DIST, MAX_FEAT, window
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = SMAXC, SQUAL, SMIND, SMAXF, window
     pp.ba_max_time_s = 0.0
     pipe = S.Pipeline(ctx, pp)
     # the whole stream is rendered up front into host memory (the synthetic renderer is test input, not the path)
@@ -529,6 +533,7 @@ def run_kitti_stream(args):
            "vs_baseline": None, "dtype": "u8/f32/f64", "data": "synthetic",
            "config": {"workload": f"kitti00_shaped_stream_{n_frames}_frames_10kf_window (BASELINE configs[2])",
                       "label": "ONE stream per GPU, host buffers in (PCIe upload timed), nothing reset", "batch": B, "window": window,
+                      "max_corners": SMAXC, "quality": SQUAL, "min_distance": SMIND,
                       "keyframes": n_kf, "mean_tracked": float(np.mean([r.n_tracked for r in res_all if r.n_tracked] or [0])),
                       **window_load([r for r in res_all if r.is_keyframe], window),
                       "ba_lm_iterations": int(sum(r.ba_iterations for r in res_all)),
@@ -541,8 +546,8 @@ def run_kitti_stream(args):
         cores = min(os.cpu_count() or 1, 16)
         os.environ["OMP_NUM_THREADS"] = str(cores)
         n = min(args.cpu_frames * 2, n_frames)
-        op = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=MAXC, quality=QUALITY,
-                        min_feature_distance=MIN_DIST, parallax_thresh=20.0, window_size=window, max_features=MAX_FEAT,
+        op = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=SMAXC, quality=SQUAL,
+                        min_feature_distance=SMIND, parallax_thresh=20.0, window_size=window, max_features=SMAXF,
                         ba_max_iterations=50, num_threads=cores)
         t1 = time.perf_counter()
         ores = [op.process(L[i], R[i]) for i in range(n)]
@@ -572,6 +577,7 @@ def run_hd10k(args):
     ctx = S.Context(HDW, HDH, device=local, max_batch=B, max_corners=10240, max_candidates=1 << 17, max_features=10240)
     p = S.synth_default(HDW, HDH)
     p.focal, p.cx, p.cy, p.baseline = 385.7545, 640.0, 360.0, 0.05
+    p.step_z = 0.25  # 60 frames/s x 0.25 m = 15 m/s (the generator's default 0.8 m per frame is KITTI's 10 Hz)
     p.seed += rank
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16)) as ex:

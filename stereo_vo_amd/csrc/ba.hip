@@ -2272,22 +2272,6 @@ static int ba_alloc(svo_ba* ba) {
     }
   }
   {
-    // the granule stores for window-shaped problems up front (<= 128 chunks: one group per chunk), so that the hot path never
-    // allocates; larger problems grow them in ba_ensure_partials
-    const size_t Fm = (size_t)Kmax - 1, Em = ((18 * Fm * (Fm + 1) + 33 * Fm + 2) + 7) & ~(size_t)7;
-    if (Em * 128 * 16 <= ((size_t)64 << 20)) {
-      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part1, 16 * Em * 128));
-      SVO_HIP_CHECK(ctx, hipMemset(d.part1, 0, 16 * Em * 128));
-      ba->cap_part1 = Em * 128;
-      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part2, 16 * 2 * 4 * 128));
-      SVO_HIP_CHECK(ctx, hipMemset(d.part2, 0, 16 * 2 * 4 * 128));
-      ba->cap_part2 = 2 * 4 * 128;
-      SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_res, 16 * (Em + 1)));
-      SVO_HIP_CHECK(ctx, hipMemset(ba->d_res, 0, 16 * (Em + 1)));
-      ba->cap_res = Em + 1;
-    }
-  }
-  {
     // SVO_BA_CU_SHARE=n (n = 8 on MI355X: one shader engine of every XCD; see include/svo.h): window-sized adjusters
     // run on their own n CUs of every 32 and the context's stream on the others, so that the LM loop's small dependent
     // kernels never queue behind other stereo streams' wide LK launches.  Bulk-sized adjusters keep the whole GPU.
@@ -2301,6 +2285,24 @@ static int ba_alloc(svo_ba* ba) {
     } else {
       SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking));
     }
+  }
+  {
+    // the granule stores for window-shaped problems up front (<= 128 chunks: one group per chunk), so that the hot path never
+    // allocates; larger problems grow them in ba_ensure_partials
+    const size_t Fm = (size_t)Kmax - 1, Em = ((18 * Fm * (Fm + 1) + 33 * Fm + 2) + 7) & ~(size_t)7;
+    if (Em * 128 * 16 <= ((size_t)64 << 20)) {
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part1, 16 * Em * 128));
+      SVO_HIP_CHECK(ctx, hipMemsetAsync(d.part1, 0, 16 * Em * 128, ba->stream));
+      ba->cap_part1 = Em * 128;
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&d.part2, 16 * 2 * 4 * 128));
+      SVO_HIP_CHECK(ctx, hipMemsetAsync(d.part2, 0, 16 * 2 * 4 * 128, ba->stream));
+      ba->cap_part2 = 2 * 4 * 128;
+      SVO_HIP_CHECK(ctx, hipMalloc((void**)&ba->d_res, 16 * (Em + 1)));
+      SVO_HIP_CHECK(ctx, hipMemsetAsync(ba->d_res, 0, 16 * (Em + 1), ba->stream));
+      ba->cap_res = Em + 1;
+    }
+    // every fill of this function is complete before the adjuster is handed out (its streams are non-blocking: see ba_ensure_partials)
+    SVO_HIP_CHECK(ctx, hipDeviceSynchronize());
   }
   // pinned block: [completion word 64 B | 128 B reserved | step: dc, candidate poses (, current poses) | payload]
   const size_t pin_step_doubles = step_doubles + 7 * (size_t)Kmax;
@@ -2428,7 +2430,11 @@ static int ba_ensure_partials(svo_ba* ba) {
     *p = nullptr;
     const size_t want = granules + granules / 2 + 64;
     SVO_HIP_CHECK(ctx, hipMalloc((void**)p, 16 * want));
-    SVO_HIP_CHECK(ctx, hipMemset(*p, 0, 16 * want));
+    // the fill must be COMPLETE before any solve posts into the store: the adjuster's streams are non-blocking streams, which
+    // a hipMemset on the null stream is not ordered with (a fill that landed behind the first pass wiped its tags: the
+    // reduction then waited three seconds for them and the solve returned zeros — seen once in a full test run)
+    SVO_HIP_CHECK(ctx, hipMemsetAsync(*p, 0, 16 * want, ba->stream));
+    SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
     *cap = want;
     return SVO_OK;
   };

@@ -102,6 +102,10 @@ __device__ __forceinline__ float wave_sum_f32(int v) {
 #ifndef SVO_LK_THREADS
 #define SVO_LK_THREADS 64
 #endif
+typedef short lk_s2 __attribute__((ext_vector_type(2)));
+// (lo, hi) as two int16 in one register
+__device__ __forceinline__ lk_s2 pack_s2(int lo, int hi) { return __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm((unsigned)hi, (unsigned)lo, 0x05040100u)); }
+
 // Threads per feature.  64 (default): ONE wavefront owns a feature — 7 window pixels per lane, all sums by DPP, no
 // workgroup barrier anywhere (LDS traffic of a single wave is ordered; a wave-level fence replaces s_barrier), one
 // feature per 64-thread workgroup.  256 / 128: the wavefronts of a workgroup share one feature and meet at a barrier
@@ -448,6 +452,13 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
         }
       }
     }
+    // the template gradients as 16-bit pairs for the iteration's packed dot products (zero in the idle lane)
+    lk_s2 tXp[4], tYp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      tXp[q] = pack_s2(act ? tX[2 * q] : 0, act && 2 * q + 1 < 7 ? tX[2 * q + 1] : 0);
+      tYp[q] = pack_s2(act ? tY[2 * q] : 0, act && 2 * q + 1 < 7 ? tY[2 * q + 1] : 0);
+    }
     long long sA[3];
     block_sum_split<3>(pA, sA, S, phase);
     const float A11 = (float)(double)sA[0] * FLT_SCALE;
@@ -493,20 +504,25 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
       const uint32_t v0 = jw[wi + RS / 4], v1 = jw[wi + RS / 4 + 1], v2 = jw[wi + RS / 4 + 2];
       const uint32_t tl = __builtin_amdgcn_alignbyte(u1, u0, sh), th = __builtin_amdgcn_alignbyte(u2, u1, sh);
       const uint32_t bl = __builtin_amdgcn_alignbyte(v1, v0, sh), bh = __builtin_amdgcn_alignbyte(v2, v1, sh);
-      int tt[8], bb[8];
+      // Packed 16-bit dot products (v_dot2c_i32_i16: a.lo b.lo + a.hi b.hi + c, exact in int32): the bilinear value of a pixel
+      // is two of them over (pixel, right neighbour) x (weight pair), the two mismatch sums four each over pixel pairs —
+      // 14 + 8 + 4 packs instead of 7 x 14 multiplies and adds, and the 16 byte extracts become 14 byte permutes.  Integer
+      // arithmetic: the same numbers in any grouping (weights <= 2^14, |diff| <= 8160, |gradient| <= 4080 all fit int16).
+      const lk_s2 wtop = pack_s2(iw00, iw01), wbot = pack_s2(iw10, iw11);
+      int diff[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        tt[k] = (int)((tl >> (8 * k)) & 255u); tt[4 + k] = (int)((th >> (8 * k)) & 255u);
-        bb[k] = (int)((bl >> (8 * k)) & 255u); bb[4 + k] = (int)((bh >> (8 * k)) & 255u);
+      for (int p = 0; p < 7; ++p) {
+        const uint32_t sel = 0x0c000c00u | ((uint32_t)(p + 1) << 16) | (uint32_t)p;  // (byte p, 0, byte p + 1, 0) of the 8-byte row
+        const lk_s2 tp = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(th, tl, sel)), bp = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(bh, bl, sel));
+        diff[p] = descale(__builtin_amdgcn_sdot2(tp, wtop, __builtin_amdgcn_sdot2(bp, wbot, 0, false), false), 9) - tI[p];
       }
+      diff[7] = 0;
       int pb[2] = {0, 0};
-      if (act) {
 #pragma unroll
-        for (int p = 0; p < 7; ++p) {
-          const int diff = descale(__mul24(tt[p], iw00) + __mul24(tt[p + 1], iw01) + __mul24(bb[p], iw10) + __mul24(bb[p + 1], iw11), 9) - tI[p];
-          pb[0] += __mul24(diff, tX[p]);   // |diff| <= 8160, |gradient| <= 4080
-          pb[1] += __mul24(diff, tY[p]);
-        }
+      for (int q = 3; q >= 0; --q) {
+        const lk_s2 d = pack_s2(diff[2 * q], diff[2 * q + 1]);
+        pb[0] = __builtin_amdgcn_sdot2(d, tXp[q], pb[0], false);   // the template pairs of the idle 64th lane are zero
+        pb[1] = __builtin_amdgcn_sdot2(d, tYp[q], pb[1], false);
       }
       const float b1 = wave_sum_f32(pb[0]) * FLT_SCALE;
       const float b2 = wave_sum_f32(pb[1]) * FLT_SCALE;

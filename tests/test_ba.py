@@ -1,6 +1,8 @@
 """a12 bundle adjustment — BundleAdjuster::bundle_adjust -> ceres::Solve (reference
 src/bundle_adjuster.cpp:137-157) restated as LM + Schur (oracle/ora_ba.cpp).
 Floating point: converged poses must agree to 1e-6 m / 1e-6 rad, costs to 1e-9 rel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -362,3 +364,36 @@ def test_hip_device_solve_delivers_around_unobserved_landmarks(ctx):
     assert np.array_equal(out[True][1], out[False][1]) and np.array_equal(out[True][2], out[False][2])
     assert np.array_equal(out[True][2][~observed], pts[~observed])
     assert not np.array_equal(out[True][2][observed], pts[observed])
+
+
+def test_declared_orders_agree():
+    """Round 4 re-declared the oracle's summation order (per-chunk partials in (landmark, pair) order, chunk partials added in chunk
+    order) so that the GPU can form the sums inside a wavefront; rounds 1-3 declared 28 strided segments over per-pair slots.
+    Ceres' own order is unspecified (4 threads, src/bundle_adjuster.cpp:12): both are restatements of the same solve.  They must
+    agree to rounding: same iteration counts, final costs within 1e-9 relative, poses within 1e-7 m / rad (the scale gauge of the
+    problem — one fixed pose, reprojection factors only — amplifies rounding along its flat direction; CPU only)."""
+    rows = []
+    for seed, K, N in ((11, 5, 700), (12, 10, 1500), (13, 20, 2500), (14, 3, 120)):
+        p = BP.make_problem(seed, K, N)
+        out = {}
+        for order in (1, 2):
+            O.ba_set_order(order)
+            try:
+                out[order] = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, max_iterations=50, num_threads=2)
+            finally:
+                O.ba_set_order(2)
+        (p1, x1, s1), (p2, x2, s2) = out[1], out[2]
+        assert s1["iterations"] == s2["iterations"] and s1["termination"] == s2["termination"]
+        rel = abs(s1["final_cost"] - s2["final_cost"]) / s2["final_cost"]
+        dt, da = BP.pose_error(p1, p2)
+        assert rel <= 1e-9 and dt <= 1e-7 and da <= 1e-7, (K, N, rel, dt, da)
+        # thread independence of the declared order
+        p3, x3, s3 = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, max_iterations=50, num_threads=1)
+        assert np.array_equal(p3, p2) and np.array_equal(x3, x2)
+        rows.append((K, len(p["points0"]), len(p["op"]), s2["iterations"], rel, dt))
+    if os.environ.get("SVO_WRITE_ORDER_COMPARISON"):
+        with open(os.environ["SVO_WRITE_ORDER_COMPARISON"], "w") as f:
+            f.write("declared summation order: rounds 1-3 (28 strided segments over per-pair slots) vs round 4 (chunk order), CPU oracle, 50-iteration cap\n")
+            f.write("poses  landmarks  observations  LM iterations (both)  |final cost difference| / cost  max translation difference (m)\n")
+            for r in rows:
+                f.write("%5d  %9d  %12d  %20d  %30.3e  %30.3e\n" % r)
