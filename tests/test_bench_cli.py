@@ -29,3 +29,35 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"], env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
     assert r.returncode != 0
     assert "WORLD_SIZE" in r.stderr and '"metric"' not in r.stdout
+
+
+def test_bench_spawner_counts_gpus_without_hip_and_starts_the_ranks():
+    """`bench.py --gpus N` without a launcher: the parent counts GPUs WITHOUT the HIP runtime (here: the stub
+    SVO_BENCH_GPU_COUNT, on a box: *_VISIBLE_DEVICES / the KFD topology in sysfs), refuses to fork + exec from a process that
+    has libamdhip64 mapped, and starts the ranks with torch.distributed.run.  In this GPU-less container the two ranks come
+    up, rendezvous over gloo and then fail at svo_create (no device): what is checked is that the spawner got that far and
+    relayed the failure, never a line measured on fewer ranks."""
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "ba50k"],
+             env={"SVO_BENCH_GPU_COUNT": "2", "SVO_BENCH_BACKEND": "gloo", "SVO_BENCH_FORCE_DEVICE": "0"})
+    assert r.returncode != 0
+    assert "2-rank run failed" in r.stderr and '"metric"' not in r.stdout
+    assert "HIP runtime mapped" not in r.stderr
+
+
+def test_bench_gpu_count_reads_the_environment_not_the_runtime():
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    old = {k: os.environ.pop(k, None) for k in ("SVO_BENCH_GPU_COUNT", "ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+    try:
+        os.environ["SVO_BENCH_GPU_COUNT"] = "5"
+        assert bench.visible_gpu_count() == 5
+        del os.environ["SVO_BENCH_GPU_COUNT"]
+        base = bench.visible_gpu_count()      # the KFD topology of this machine (0 in the build container)
+        os.environ["HIP_VISIBLE_DEVICES"] = "0,1"
+        assert bench.visible_gpu_count() == (min(base, 2) if base else 2)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v

@@ -382,7 +382,9 @@ def test_hip_config3_full_4541_frame_stream_properties():
             gt.append(S.synth_pose(p, i)[:, 3])
     path = float(np.linalg.norm(np.diff(np.array(gt), axis=0), axis=1).sum())
     ate = S.api.ate_rmse(np.array(est), np.array(gt), False)
-    assert path > 3000 and ate < 0.01 * path, (ate, path)
+    # (rigid alignment, no scale: open-loop VO over 3.6 km through scene changes — the camera drives through billboards, some
+    # frames have a few hundred corners — drifts by a few per cent; the degenerate ground-only circle of rounds 1-3 stayed below 1 %)
+    assert path > 3000 and ate < 0.08 * path, (ate, path)
     # the head of the stream against the oracle (bit-exact counters and poses)
     o = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=1500, quality=0.02,
                    min_feature_distance=10.0, parallax_thresh=20.0, window_size=10, max_features=2000, ba_max_iterations=50,
