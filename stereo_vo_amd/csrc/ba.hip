@@ -1755,7 +1755,10 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
   return ok;
 }
 
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(2, 2))) void ba_lm_kernel(LmLanePtrs lanes) {
+#ifndef SVO_LM_WAVES_PER_EU  // developer experiments only (SVO_EXTRA_HIPFLAGS): the register budget of the solve kernel's wavefronts
+#define SVO_LM_WAVES_PER_EU 2
+#endif
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVES_PER_EU, SVO_LM_WAVES_PER_EU))) void ba_lm_kernel(LmLanePtrs lanes) {
   extern __shared__ double lds[];  // ba_lm_lds_doubles(n, K)
   __shared__ LmShared sh;
   __shared__ LmDevState cs;

@@ -124,8 +124,11 @@ constexpr int RS = G + 2 * RM;   // 32
 struct LkShared {
   alignas(4) uint8_t raw[RP * RP];      // source patch of the template image (reflect-101 staged)
   alignas(4) uint8_t jreg[RS * RS + 8];  // target-image region; restaged only when the window leaves it (+8: the aligned-dword reads of the last row)
-  short Iw[WIN * WIN], dIx[WIN * WIN], dIy[WIN * WIN];
-  short gx[G * G], gy[G * G];
+  // template / gradient patches and cross-wave partials of the variants that share a feature between wavefronts; the
+  // one-wavefront form keeps its template in registers (1.6 KB instead of 6.2 KB of LDS per feature: sixteen resident
+  // tracker wavefronts no longer hold 100 KB of a CU's LDS that the solve kernel's workgroups are waiting for)
+  short Iw[LKT == 64 ? 2 : WIN * WIN], dIx[LKT == 64 ? 2 : WIN * WIN], dIy[LKT == 64 ? 2 : WIN * WIN];
+  short gx[LKT == 64 ? 2 : G * G], gy[LKT == 64 ? 2 : G * G];
   long long red[2][3][NW];   // cross-wave partials (double-buffered: one barrier per reduction point); unused with one wave
 };
 

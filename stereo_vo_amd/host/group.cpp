@@ -78,7 +78,7 @@ enum Word { W_TRACK = 0, W_HYP, W_REF, W_TRI, W_COUNT };
 enum Counter { C_LK = 0, C_HYP, C_TRI, C_COUNT };
 
 struct Lane {
-  int lk_line = 0;  // the tracking line (stream) its launch in flight went to
+  int lk_line = 0, chain_line = 0;  // the tracking / keyframe-chain line (stream) its launch in flight went to
   // ---- tracker state (FeatureTracker): feature set double-buffered on the device, mirrored in pinned memory
   float* d_xy[2] = {nullptr, nullptr}; float* d_init[2] = {nullptr, nullptr}; long long* d_ids[2] = {nullptr, nullptr};
   float* d_fwd = nullptr; float* d_par = nullptr; uint8_t* d_keep = nullptr;
@@ -185,7 +185,8 @@ struct svo_pipeline_group {
   double t_get_points = 0, t_add_keyframe = 0, t_finish = 0, t_loop = 0; long n_kf = 0; bool timing = false;
   double lk_overlap_us = 0.0;  // > 0: a second tracking line may depart once every launch in flight is at least this old (it is in its tail then)
   double lk_t0[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // departure time of the launch in flight on each tracking line (us since the call began)
-  hipStream_t st_lk[MAX_LINES] = {}, st_chain[MAX_LINES] = {}, st_ba[MAX_LINES] = {};
+  hipStream_t st_lk[MAX_LINES + 1] = {}, st_chain[MAX_LINES + 1] = {}, st_ba[MAX_LINES] = {};  // [MAX_LINES]: the express lines (see process_batch)
+  bool express = false;
   int ba_launch_id = 0;
   // batch-wide front-end outputs
   float* d_corners = nullptr; int* d_ncorners = nullptr; uint8_t* d_pyr[2] = {nullptr, nullptr}; int pyr_cur = 0;
@@ -264,10 +265,10 @@ int finish_solve(svo_pipeline_group* g, Lane* l) {
 // mirrors and completion words), and arrive_total[] / seq[] were advanced for launches that may never have run.  Drain every
 // line, then bring device counters, host totals and completion words back to a common zero.
 void quiesce_after_error(svo_pipeline_group* g) {
-  for (int i = 0; i < svo_pipeline_group::MAX_LINES; ++i) {
+  for (int i = 0; i <= svo_pipeline_group::MAX_LINES; ++i) {
     if (g->st_lk[i]) (void)hipStreamSynchronize(g->st_lk[i]);
     if (g->st_chain[i]) (void)hipStreamSynchronize(g->st_chain[i]);
-    if (g->st_ba[i]) (void)hipStreamSynchronize(g->st_ba[i]);
+    if (i < svo_pipeline_group::MAX_LINES && g->st_ba[i]) (void)hipStreamSynchronize(g->st_ba[i]);
   }
   for (Lane* l : g->lanes) {
     (void)hipMemset(l->d_arrive, 0, sizeof(unsigned) * 16 * C_COUNT);
@@ -290,10 +291,10 @@ extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
     fprintf(stderr, "[svo group] %d lanes, %ld keyframes; group thread per keyframe (us): get_world_points %.1f, add_keyframe %.1f, join + write-back of the solve %.1f\n",
             g->n_lanes, g->n_kf, 1e-3 * g->t_get_points / g->n_kf, 1e-3 * g->t_add_keyframe / g->n_kf, 1e-3 * g->t_finish / g->n_kf);
   (void)hipStreamSynchronize(g->ctx->stream);
-  for (int i = 0; i < svo_pipeline_group::MAX_LINES; ++i) {
+  for (int i = 0; i <= svo_pipeline_group::MAX_LINES; ++i) {
     if (g->st_lk[i] && g->st_lk[i] != g->ctx->stream) { (void)hipStreamSynchronize(g->st_lk[i]); (void)hipStreamDestroy(g->st_lk[i]); }
     if (g->st_chain[i]) { (void)hipStreamSynchronize(g->st_chain[i]); (void)hipStreamDestroy(g->st_chain[i]); }
-    if (g->st_ba[i]) { (void)hipStreamSynchronize(g->st_ba[i]); (void)hipStreamDestroy(g->st_ba[i]); }
+    if (i < svo_pipeline_group::MAX_LINES && g->st_ba[i]) { (void)hipStreamSynchronize(g->st_ba[i]); (void)hipStreamDestroy(g->st_ba[i]); }
   }
   if (g->st_copy) { (void)hipStreamSynchronize(g->st_copy); (void)hipStreamDestroy(g->st_copy); }
   for (int sl = 0; sl < 2; ++sl) {
@@ -374,6 +375,11 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
       else chk(hipStreamCreateWithFlags(&g->st_chain[i], hipStreamNonBlocking), "stream");
     }
     for (int i = 0; i < g->n_ba; ++i) chk(hipStreamCreateWithFlags(&g->st_ba[i], hipStreamNonBlocking), "stream");
+    { const char* e = getenv("SVO_GROUP_EXPRESS"); g->express = e && *e && atoi(e) != 0; }  // off by default: measured 17.1 k against 18.3 k frames/s on the bench
+    if (g->express) {
+      chk(hipStreamCreateWithFlags(&g->st_lk[svo_pipeline_group::MAX_LINES], hipStreamNonBlocking), "stream");
+      chk(hipStreamCreateWithFlags(&g->st_chain[svo_pipeline_group::MAX_LINES], hipStreamNonBlocking), "stream");
+    }
   }
   g->pyr_stride = svo_k_pyramid_bytes(p->width, p->height);
   if (!rc) rc = dev_alloc(g, &g->d_corners, 2 * mc * S * B);
@@ -795,35 +801,48 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     // for a whole kernel duration (tracking: 150-200 us) — measured: 8 lanes, 110 track launches for 120 lane-frames, 3,000
     // frames/s.  Instead a stage is launched only while none of its launches is in flight; lanes that become ready meanwhile
     // ride the next launch together (a bus, not taxis).  Nobody waits for a lane that is not ready.
-    bool lk_busy[svo_pipeline_group::MAX_LINES] = {}, chain_busy[svo_pipeline_group::MAX_LINES] = {};
+    // EXPRESS lines (experiment, SVO_GROUP_EXPRESS=1; off by default): a call ends when its slowest lane ends, and lanes differ
+    // (a stream whose windows take 11 LM iterations per solve next to streams that take 4: the other lanes of the group idle for
+    // a fifth of the call).  A lane that has fallen behind the group departs at once on an express line of its stage (one more
+    // stream each for tracking and the keyframe chain) instead of waiting for the bus.  Lanes are independent and every stage
+    // starts only after the host has seen the previous one complete, so which stream carries a launch changes no result.
+    // Measured: no gain (17.1 k against 18.3 k frames/s) — what holds a late lane back is the start of its SOLVES, see below.
+    constexpr int XL = svo_pipeline_group::MAX_LINES;
+    bool lk_busy[XL + 1] = {}, chain_busy[XL + 1] = {};
+    double mean_frame = 0.0;
+    int n_running = 0;
     for (int li = 0; li < S; ++li) {
       const Lane* l = g->lanes[li];
+      if (l->state != L_DONE) { mean_frame += l->frame; ++n_running; }
       if (l->queued) continue;
-      lk_busy[g->lk_overlap_us > 0 ? l->lk_line : li % g->n_lk] |= l->state == L_TRACK_WAIT;
-      chain_busy[li % g->n_chain] |= l->state == L_PNP_HYP_WAIT || l->state == L_PNP_REF_WAIT || l->state == L_TRI_WAIT;
+      lk_busy[l->lk_line] |= l->state == L_TRACK_WAIT;
+      chain_busy[l->chain_line] |= l->state == L_PNP_HYP_WAIT || l->state == L_PNP_REF_WAIT || l->state == L_TRI_WAIT;
     }
-    // the lanes of `q` that ride line `line` (of `n_lines`), removed from q
+    mean_frame = n_running ? mean_frame / n_running : 0.0;
+    auto laggard = [&](int li) { return g->express && n_running > 2 && (double)g->lanes[li]->frame + 1.0 < mean_frame; };
+    // the lanes of `q` that ride line `line` (of `n_lines`; XL: the express line takes the laggards), removed from q
     auto take_line = [&](std::vector<int>& q, int line, int n_lines) {
       std::vector<int> mine;
       for (size_t k = 0; k < q.size();) {
-        if (q[k] % n_lines == line) { mine.push_back(q[k]); q.erase(q.begin() + k); } else ++k;
+        if (line == XL ? laggard(q[k]) : q[k] % n_lines == line) { mine.push_back(q[k]); q.erase(q.begin() + k); } else ++k;
       }
       return mine;
     };
     const double t_now_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
     bool tails_only = true;  // every tracking launch in flight is old enough to be in its tail (a few straggling wavefronts)
     for (int line = 0; line < g->n_lk; ++line) tails_only = tails_only && (!lk_busy[line] || t_now_us - g->lk_t0[line] >= g->lk_overlap_us);
-    for (int line = 0; line < g->n_lk && !error; ++line) {
+    for (int pass = g->express ? -1 : 0; pass < g->n_lk && !error; ++pass) {
+      const int line = pass < 0 ? XL : pass;  // the express line first: what it takes no longer waits for a regular line
       if (lk_busy[line]) continue;
       std::vector<int> q_now;
-      if (g->lk_overlap_us > 0) {  // dynamic lines: the whole queue departs on a free line, but only next to tails
+      if (g->lk_overlap_us > 0 && line != XL) {  // dynamic lines: the whole queue departs on a free line, but only next to tails
         if (!tails_only) break;
         q_now.swap(q_track);
       } else {
         q_now = take_line(q_track, line, g->n_lk);
       }
       if (q_now.empty()) continue;
-      g->lk_t0[line] = t_now_us;
+      if (line != XL) g->lk_t0[line] = t_now_us;
       for (int li : q_now) g->lanes[li]->lk_line = line;
       SvoLkLanes a;
       a.w = W; a.h = H;
@@ -854,10 +873,14 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       progressed = true;
     }
     if (error) break;
-    for (int line = 0; line < g->n_chain && !error; ++line) {
+    for (int pass = g->express ? -1 : 0; pass < g->n_chain && !error; ++pass) {
+      const int line = pass < 0 ? XL : pass;
       if (chain_busy[line]) continue;
       hipStream_t stc = g->st_chain[line];
       const std::vector<int> h_now = take_line(q_hyp, line, g->n_chain), r_now = take_line(q_ref, line, g->n_chain), t_now = take_line(q_tri, line, g->n_chain);
+      for (int li : h_now) g->lanes[li]->chain_line = line;
+      for (int li : r_now) g->lanes[li]->chain_line = line;
+      for (int li : t_now) g->lanes[li]->chain_line = line;
     if (!h_now.empty()) {
       SvoPnpHypLanes a;
       int k = 0;
@@ -978,7 +1001,11 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       }
       int free_line = -1;
       for (int i = 0; i < g->n_ba; ++i) if (!ba_line_busy[i]) { free_line = i; break; }
-      if (!q_ba.empty() && assembling == 0 && free_line >= 0) {
+      // (rounds 3-4 held ready solves back while ANY lane was still assembling, to launch them together: measured in round 4,
+      // a solve then left 1.1 ms after its assembly was posted on average — as long as it runs — and 3 ms at the 90th
+      // percentile; SVO_GROUP_BA_WAIT_ASSEMBLY=1 restores that)
+      static const bool wait_assembly = [] { const char* e = getenv("SVO_GROUP_BA_WAIT_ASSEMBLY"); return e && *e && atoi(e) != 0; }();
+      if (!q_ba.empty() && (assembling == 0 || !wait_assembly) && free_line >= 0) {
         svo_ba* bas[SVO_MAX_LANES];
         std::vector<int> cand;
         for (int li : q_ba) {
