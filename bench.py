@@ -45,7 +45,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the copy bandwidth that guide measured
 VALU_ISSUE_PEAK_GINSTR = 1228.8  # 256 CUs x 4 SIMDs x 2.4 GHz / 2 (one wave64 VALU instruction per 2 cycles per SIMD)
 FP64_VEC_PEAK_TFLOPS = 78.6  # public MI355X FP64 vector spec (not in the local guide)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r03_summary.json")  # written by tools/prof_round.sh + prof_summary.py
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r04_summary.json")  # written by tools/prof_round.sh + prof_summary.py
 
 
 def parse():
@@ -330,6 +330,8 @@ def run_kitti(args):
     for st in streams:
         if hasattr(st, "clear_counters"):
             st.clear_counters()
+    if NG > 1:
+        streams[1].pipe.solve_work(reset=True)
     barrier_sync(torch, dist, ctx)
     cpu0 = time.process_time()
     t0 = time.perf_counter()
@@ -341,10 +343,11 @@ def run_kitti(args):
     host_cores = (time.process_time() - cpu0) / dt  # CPU time of all threads of this rank over the timed region
     k_ms, k_n = ctx.profile_read()
     ctx.profile_select(None)
-    ba_ms, ba_n = (0.0, 0)
+    ba_ms, ba_n, ba_work = 0.0, 0, None
     if NG > 1:
         ba_ms, ba_n = streams[1].ctx.profile_read()
         streams[1].ctx.profile_select(None)
+        ba_work = streams[1].pipe.solve_work()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -380,7 +383,7 @@ def run_kitti(args):
     out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, avg_us, res, k_n, lanes_per_launch, bool(NG))
     share = profile_summary()
     if share:
-        out["kernel_time_share"] = {"source": "profiles/r03_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
+        out["kernel_time_share"] = {"source": "profiles/r04_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
                                     "default_percent": share.get("kernel_time_share_default"),
                                     "1_stream_percent": share.get("kernel_time_share_1_stream")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -442,9 +445,27 @@ def run_kitti(args):
                                     "step s+1 on a copy stream while step s is processed"}
     if NG > 0:
         out["config"]["launches_per_step_of_group_0"] = {k: [round(v[0] / args.steps, 1), round(v[1] / args.steps, 1)] for k, v in launches_sum.items()}
-        if ba_n:
-            out["roofline"]["solve_launches_live"] = {"kernel": "ba_lm_kernel", "avg_launch_us": 1e3 * ba_ms / ba_n, "launches": ba_n,
-                                                       "measured": "HIP events on the solve lines of the second pipeline group over the timed region"}
+        if ba_n and ba_work:
+            # the kernel with the largest share of summed kernel time: whole window solves, one launch for the lanes that are ready.
+            # achieved = SURVEY 8(d) algorithmic f64 flops (and bytes) of the solves the launches carried / their summed duration
+            # (HIP events on the solve lines of the second group); traffic = FETCH_SIZE + WRITE_SIZE per launch from the committed
+            # counter pass of this command (profiles/r04_traffic.json)
+            fl, by, n_solves, n_its = ba_work
+            us = 1e3 * ba_ms / ba_n
+            tf = fl / (ba_ms * 1e-3) / 1e12
+            prof = profile_summary() or {}
+            tr = (prof.get("ba_lm_traffic_bytes_per_launch") or None)
+            dk = {"kernel": "ba_lm_kernel", "bound": "latency (tagged hand-overs between the workgroups of a solve; FP64 VALU inside a pass)",
+                  "avg_launch_us": us, "launches": ba_n, "solves": n_solves, "lm_iterations": n_its,
+                  "algorithmic_flops_per_launch": fl / ba_n, "algorithmic_bytes_per_launch": by / ba_n,
+                  "achieved": tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VEC_PEAK_TFLOPS,
+                  "hbm_frac_algorithmic": by / (ba_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+                  "traffic_over_algorithmic": (tr / (by / ba_n)) if tr else None,
+                  "time_share_percent": (prof.get("kernel_time_share_default") or {}).get("ba_lm_kernel"),
+                  "measured": "HIP events on the solve lines of the second pipeline group over the timed region; per launch = per "
+                              "%.1f solves of %.1f LM iterations" % (n_solves / ba_n, n_its / max(n_solves, 1))}
+            out["roofline"]["tracker_kernel"] = out["roofline"].pop("dominant_kernel", None)
+            out["roofline"]["dominant_kernel"] = dk
     for st in streams:
         st.close()
     if single_pipe is not None:
@@ -712,19 +733,9 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches, lanes
                 g = vi / (avg_us * 1e-6) / 1e9
                 dk.update({"valu_wave_instructions_per_launch": vi, "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR,
                            "frac": g / VALU_ISSUE_PEAK_GINSTR,
-                           "note": "VALU instructions per wavefront (= per feature) from the committed SQ pass (profiles/r03_sq_counters.txt) x the "
+                           "note": "VALU instructions per wavefront (= per feature) from the committed SQ pass (profiles/r04_sq_counters.txt) x the "
                                    "features of a launch, duration live; <= 30 iterations x 4 levels x 2 directions of a 441-pixel window per feature"})
         r["dominant_kernel"] = dk
-    ks = prof.get("kernel_average_us_default") or {}
-    if grouped and "ba_lm_kernel" in ks and prof.get("ba_lm_valu_wave_instructions_per_launch"):
-        # the largest share of summed kernel time: one launch = whole window solves (device-resident LM); from the committed profile, not live
-        us = ks["ba_lm_kernel"]
-        g = prof["ba_lm_valu_wave_instructions_per_launch"] / (us * 1e-6) / 1e9
-        r["largest_time_share_kernel"] = {
-            "kernel": "ba_lm_kernel", "avg_launch_us": us, "time_share_percent": (prof.get("kernel_time_share_default") or {}).get("ba_lm_kernel"),
-            "waves_per_launch": prof.get("ba_lm_waves_per_launch"), "valu_wave_instructions_per_launch": prof["ba_lm_valu_wave_instructions_per_launch"],
-            "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": g / VALU_ISSUE_PEAK_GINSTR, "bound": "latency (device-wide meetings of a few hundred wavefronts)",
-            "source": "profiles/r03_kernel_stats_default.csv + profiles/r03_sq_counters.txt (rocprofv3 runs of this command), not measured live"}
     return r
 
 

@@ -414,6 +414,10 @@ int svo_pipeline_group_get_tracked(svo_pipeline_group* g, int lane, int64_t* ids
  * refinement, 3 dedup / stereo + triangulation, 4 bundle-adjustment solves, 5 corner detection + pyramids;
  * launches6[i] launches carried lanes6[i] lane-stages in total. */
 int svo_pipeline_group_last_stats(const svo_pipeline_group* g, long* launches6, long* lanes6);
+/* Algorithmic work (SURVEY 8(d) per-iteration figures: 466 flops per observation + 50 + 144 L + 216 L (L + 1) / 2 per landmark;
+ * 24 B per observation + 48 B per landmark + 56 B per pose) of the bundle adjustments all lanes have finished since the last
+ * reset: out4 = [f64 flops, bytes, solves, LM iterations].  Measurement aid (bench.py's roofline of the solve kernel). */
+int svo_pipeline_group_solve_work(svo_pipeline_group* g, double* out4, int reset);
 
 /* FeatureTracker::draw_track + get_drawing (src/feature_tracker.cpp:74-91; used by src/vo_node.cpp:137,188):
  * the keyframe image as RGB (3 bytes per pixel, width*height*3 output) with one green arrow of thickness 4 per feature

@@ -165,7 +165,7 @@ SYMBOLS = [
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
     "svo_pipeline_group_create", "svo_pipeline_group_destroy", "svo_pipeline_group_reset", "svo_pipeline_group_lanes",
     "svo_pipeline_group_process_batch_dev", "svo_pipeline_group_get_tracked", "svo_pipeline_group_last_stats",
-    "svo_pipeline_group_staging", "svo_pipeline_group_upload", "svo_pipeline_group_process_uploaded", "svo_pipeline_group_process_batch",
+    "svo_pipeline_group_solve_work", "svo_pipeline_group_staging", "svo_pipeline_group_upload", "svo_pipeline_group_process_uploaded", "svo_pipeline_group_process_batch",
     "svo_synth_default_params", "svo_synth_render", "svo_synth_pose",
     "svo_image_read_gray", "svo_kitti_read_poses", "svo_ate_rmse", "svo_kitti_run", "svo_cholesky_solve", "svo_cholesky_solve_dev", "svo_draw_track", "svo_pipeline_draw_track",
 ]
@@ -672,6 +672,12 @@ class PipelineGroup:
         n = C.c_int(0)
         self.ctx._chk(self.L.svo_pipeline_group_get_tracked(self.h, lane, _p(ids), _p(xy), capacity, C.byref(n)), "svo_pipeline_group_get_tracked")
         return ids[:n.value].copy(), xy[:n.value].copy()
+
+    def solve_work(self, reset=False):
+        """Algorithmic [f64 flops, bytes, solves, LM iterations] of the bundle adjustments finished since the last reset."""
+        out = (C.c_double * 4)()
+        self.ctx._chk(self.L.svo_pipeline_group_solve_work(self.h, out, int(reset)), "svo_pipeline_group_solve_work")
+        return list(out)
 
     def last_stats(self):
         """{stage: (launches, lane-stages carried)} of the last process_batch_dev call."""

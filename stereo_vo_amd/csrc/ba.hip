@@ -2177,6 +2177,8 @@ struct svo_ba {
   double* d_res = nullptr;          // ba_lm_kernel: the E wire totals of the running iteration (+ the posted clock), tagged granules
   unsigned long long tag_seq = 0;   // host-driven launches: one tag per op (ba_next_tag)
   int tab_max_words = 0;            // largest chunk table of the loaded problem (u16 words)
+  double flops_iter = 0, bytes_iter = 0;                       // SURVEY 8(d) algorithmic f64 flops / bytes of ONE LM iteration of the loaded problem
+  double acc_flops = 0, acc_bytes = 0, acc_solves = 0, acc_iters = 0;  // ... summed over the solves since the last svo_ba_work(reset)
   std::vector<double> h_poses;            // K x 7 current poses (updated in place by svo_lm_solve)
   int n_points = 0;
   uint8_t* d_arena = nullptr;     // all per-solve inputs in one allocation: one H2D per solve
@@ -2483,6 +2485,17 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   chunks.push_back(M);
   d.C = (int)chunks.size() - 1;
   d.L = npts;
+  {
+    // 466 flops per observation + per landmark 50 + 144 L + 216 L (L + 1) / 2; 24 B per observation, 48 B per landmark, 56 B per pose
+    double fl = 466.0 * M;
+    int n_seen = 0;
+    for (int j = 0; j < npts; ++j) {
+      const double Lj = lm_start[j + 1] - lm_start[j];
+      if (Lj > 0) { fl += 50.0 + 144.0 * Lj + 108.0 * Lj * (Lj + 1.0); ++n_seen; }
+    }
+    ba->flops_iter = fl;
+    ba->bytes_iter = 24.0 * M + 48.0 * n_seen + 56.0 * K;
+  }
   hipStream_t st = ba->stream;
   std::vector<uint16_t>& tab = ba->u_tab;
   std::vector<uint32_t>& tab_off = ba->u_tab_off;
@@ -3461,6 +3474,10 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   ba->n_solves++;
   if (rc) return rc;
+  if (summary) {
+    const double its = summary->iterations + 1;  // + the first linearisation
+    ba->acc_flops += its * ba->flops_iter; ba->acc_bytes += its * ba->bytes_iter; ba->acc_solves += 1; ba->acc_iters += summary->iterations;
+  }
   const auto tr0 = std::chrono::steady_clock::now();
   std::vector<double>& out_pts = ba->s_out_pts;
   out_pts.resize(points.size());
@@ -3472,6 +3489,12 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   ba->new_frame_added = false;  // :155
   ba->t_read += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
   return SVO_OK;
+}
+
+// algorithmic work (SURVEY 8d figures) of the solves finished since the last reset: [f64 flops, bytes, solves, LM iterations]
+void svo_ba_work(svo_ba* ba, double* out4, int reset) {
+  out4[0] = ba->acc_flops; out4[1] = ba->acc_bytes; out4[2] = ba->acc_solves; out4[3] = ba->acc_iters;
+  if (reset) ba->acc_flops = ba->acc_bytes = ba->acc_solves = ba->acc_iters = 0;
 }
 
 extern "C" int svo_ba_solve(svo_ba* ba, svo_ba_summary* summary) {

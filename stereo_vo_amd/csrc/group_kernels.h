@@ -65,5 +65,6 @@ int svo_ba_solve_prepare(svo_ba* ba);                          // 1: nothing to 
 int svo_ba_solve_launch(svo_ba** bas, int n, void* stream, unsigned long long* launched_mask);  // number launched; bit i of the mask: bas[i] was (an ineligible or not admitted adjuster is skipped)
 int svo_ba_solve_poll(svo_ba* ba);                             // 1: finish will not block
 int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary);  // join (or solve host-driven) + write back into the graph
+void svo_ba_work(svo_ba* ba, double* out4, int reset);          // algorithmic [flops, bytes, solves, LM iterations] of the finished solves
 
 #endif

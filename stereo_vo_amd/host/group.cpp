@@ -490,6 +490,17 @@ extern "C" int svo_pipeline_group_get_tracked(svo_pipeline_group* g, int lane, i
   return SVO_OK;
 }
 
+extern "C" int svo_pipeline_group_solve_work(svo_pipeline_group* g, double* out4, int reset) {
+  if (!g || !out4) return SVO_ERR_INVALID;
+  out4[0] = out4[1] = out4[2] = out4[3] = 0.0;
+  for (Lane* l : g->lanes) {
+    double w[4];
+    svo_ba_work(l->ba, w, reset);
+    for (int i = 0; i < 4; ++i) out4[i] += w[i];
+  }
+  return SVO_OK;
+}
+
 extern "C" int svo_pipeline_group_last_stats(const svo_pipeline_group* g, long* launches6, long* lanes6) {
   if (!g || !launches6 || !lanes6) return SVO_ERR_INVALID;
   for (int i = 0; i < 6; ++i) { launches6[i] = g->launches[i]; lanes6[i] = g->lanes_carried[i]; }

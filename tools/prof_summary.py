@@ -34,12 +34,15 @@ for key, sub in (("default", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
         continue
     st = stats(f)
     with open(os.path.join(out, f"{tag}_kernel_stats_{key}.csv"), "w") as w:
+        w.write("# " + stamp + "\n")
         w.write("kernel,calls,total_ms,average_us,percent\n")
         for n, c, t, a, p in st:
             w.write(f"{n},{c},{t / 1e6:.3f},{a / 1e3:.2f},{p:.2f}\n")
     summary["kernel_time_share_" + key] = {n: round(p, 2) for n, c, t, a, p in st if p >= 0.3}
     summary["kernel_average_us_" + key] = {n: round(a / 1e3, 2) for n, c, t, a, p in st if p >= 0.3}
-for name in ("bench_s8.json", "bench_s1.json", "bench_ba.json", "gpu_busy_s8.txt"):
+stamp = open(os.path.join(src, "STAMP.txt")).read().strip() if os.path.exists(os.path.join(src, "STAMP.txt")) else "unknown"
+summary["stamp"] = stamp
+for name in ("bench_s8.json", "bench_s1.json", "bench_ba.json", "gpu_busy_s8.txt", "STAMP.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(out, f"{tag}_{name}"))
 
@@ -64,6 +67,7 @@ def counters(sub):
 agg, calls = counters("sq")
 if agg:
     with open(os.path.join(out, f"{tag}_sq_counters.txt"), "w") as w:
+        w.write("# " + stamp + "\n")
         for k in sorted(agg, key=lambda k: -agg[k]["SQ_WAVE_CYCLES"])[:12]:
             a, c = agg[k], calls[k]
             wc = max(a["SQ_WAVE_CYCLES"], 1.0)
@@ -113,12 +117,15 @@ if traffic:
     summary["front_end_hbm_bytes_per_pair_pmc"] = per_pair
     for k in traffic:
         traffic[k]["launches"] = launches[k]
-    json.dump(dict(unit="KB per launch, raw FETCH_SIZE / WRITE_SIZE (no 2x correction: byte-granular gathers)", frames=frames,
+    if "ba_lm_kernel" in traffic:  # the solve kernel's own HBM traffic per launch (bench.py sets it against the algorithmic bytes)
+        summary["ba_lm_traffic_bytes_per_launch"] = (traffic["ba_lm_kernel"].get("fetch_kb_per_launch", 0) + traffic["ba_lm_kernel"].get("write_kb_per_launch", 0)) * 1024.0
+    json.dump(dict(stamp=stamp, unit="KB per launch, raw FETCH_SIZE / WRITE_SIZE (no 2x correction: byte-granular gathers)", frames=frames,
                    front_end_bytes_per_pair=per_pair, kernels=traffic), open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 
 agg, calls = counters("ba_pmc")
 if agg:
     with open(os.path.join(out, f"{tag}_ba50k_mfma_pmc.txt"), "w") as w:
+        w.write("# " + stamp + "\n")
         for k in agg:
             w.write(k + " calls=%d " % calls[k] + " ".join("%s=%.0f" % (c, v / calls[k]) for c, v in sorted(agg[k].items())) + "  (per launch)\n")
 json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
