@@ -294,6 +294,30 @@ __device__ __forceinline__ void eval_obs(const double* __restrict__ pose, D3 p, 
     }
   }
 }
+// the same with FMA contraction (bulk kernels only: hardware-ordered sums, tolerance-level parity)
+#pragma clang fp contract(fast)
+__device__ __forceinline__ void eval_obs_contract(const double* __restrict__ pose, D3 p, double u, double v, double f, double cx,
+                                         double cy, bool want_jc, double* r, double* Jc, double* Jp) {
+  double Jq[14];
+  reproj_full_c(pose, p, u, v, f, cx, cy, r, want_jc ? Jq : nullptr, Jp);
+  if (want_jc) {
+    const double w = pose[0], x = pose[1], y = pose[2], z = pose[3];
+    const double T[4][3] = {{-x, -y, -z}, {w, z, -y}, {-z, w, x}, {y, -x, w}};
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += Jq[7 * row + k] * T[k][c];
+        Jc[6 * row + c] = s;
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Jc[6 * row + 3 + c] = Jq[7 * row + 4 + c];
+    }
+  }
+}
+#pragma clang fp contract(off)
 }  // namespace
 
 // One lane's observation: indices, its landmark's lane segment [first, first + len) inside the chunk, the landmark
@@ -1971,7 +1995,7 @@ __global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double 
 #pragma unroll
       for (int i = 0; i < 6; ++i) Jp[i] = 0.0;
       if (active) {
-        eval_obs(P.poses + 7 * k, cur.p, cur.u, cur.v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
+        eval_obs_contract(P.poses + 7 * k, cur.p, cur.u, cur.v, P.f, P.cx, P.cy, k > 0, r, Jc, Jp);
         lcost += 0.5 * (r[0] * r[0] + r[1] * r[1]);
       }
       int maxlen = len;
