@@ -28,6 +28,8 @@ def stats(path):
 
 
 summary = {}
+stamp = open(os.path.join(src, "STAMP.txt")).read().strip() if os.path.exists(os.path.join(src, "STAMP.txt")) else "unknown"
+summary["stamp"] = stamp
 for key, sub in (("default", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
     f = os.path.join(src, sub, "p_kernel_stats.csv")
     if not os.path.exists(f):
@@ -40,8 +42,6 @@ for key, sub in (("default", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
             w.write(f"{n},{c},{t / 1e6:.3f},{a / 1e3:.2f},{p:.2f}\n")
     summary["kernel_time_share_" + key] = {n: round(p, 2) for n, c, t, a, p in st if p >= 0.3}
     summary["kernel_average_us_" + key] = {n: round(a / 1e3, 2) for n, c, t, a, p in st if p >= 0.3}
-stamp = open(os.path.join(src, "STAMP.txt")).read().strip() if os.path.exists(os.path.join(src, "STAMP.txt")) else "unknown"
-summary["stamp"] = stamp
 for name in ("bench_s8.json", "bench_s1.json", "bench_ba.json", "gpu_busy_s8.txt", "STAMP.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(out, f"{tag}_{name}"))
