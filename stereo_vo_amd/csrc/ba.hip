@@ -747,7 +747,7 @@ __device__ __forceinline__ void chunk_owner_phases(const ObsRec& R, const ChunkT
 // pass A of one chunk by a workgroup of the host-driven kernels (DET_THREADS threads): the first wavefront does the lanes'
 // arithmetic (lane = observation), every thread of the workgroup then owns destination rows — the owner phases are half of a
 // chunk's pass and run twice as wide (measured on the single-stream bench: the pass-A launch is its slowest chunk)
-constexpr int DET_THREADS = 128;
+template <int NT>
 __device__ __forceinline__ void linearize_chunk_wg1(const BaDev& P, const ObsRec& R, const double* __restrict__ poses_, double radius, int first_pass,
                                                     const ChunkTab& T, const WgLds& L, const PartSink& sink) {
   SufRegs o;
@@ -758,7 +758,7 @@ __device__ __forceinline__ void linearize_chunk_wg1(const BaDev& P, const ObsRec
     linearize_prefix(P, R, poses_, q, unused);
     suffix_math(P, R, q, radius, first_pass, L.rec, nullptr, o);
   }
-  chunk_owner_phases<true>(R, T, o, L.rec, sink, L.s_ne);
+  chunk_owner_phases<(NT > 64)>(R, T, o, L.rec, sink, L.s_ne);
 }
 
 // One-time reads of the problem image by ba_lm_kernel.  The image stays in PINNED HOST memory (no H2D copy launch in front of
@@ -1090,7 +1090,8 @@ __device__ __forceinline__ PartSink make_sink(const BaDev& P, int g, int first, 
 }
 __device__ __forceinline__ ChunkTab global_tab(const BaDev& P, int chunk) { return ChunkTab{P.tab + P.tab_off[chunk], (P.K - 1) * P.K / 2, P.K - 1}; }
 
-__global__ __launch_bounds__(DET_THREADS) void ba_linearize_det_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+template <int NT>
+__global__ __launch_bounds__(NT) void ba_linearize_det_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
   svo_latency_critical();
   apply_ctl(P, radius, ctl);
   extern __shared__ double lds[];  // wg_lds_doubles(E)
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(DET_THREADS) void ba_linearize_det_kernel(BaDev P, 
   for (int chunk = c0; chunk < c1; ++chunk) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
     if (threadIdx.x < 64) R = load_obs(P, chunk, lane, P.points);
-    linearize_chunk_wg1(P, R, P.poses, radius, first_pass, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
+    linearize_chunk_wg1<NT>(P, R, P.poses, radius, first_pass, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
     stores_acknowledged();  // the group's running sums are read back by the next chunk
   }
 }
@@ -1108,7 +1109,8 @@ __global__ __launch_bounds__(DET_THREADS) void ba_linearize_det_kernel(BaDev P, 
 // ---- single rank, deterministic mode, chained iteration: pass A that FIRST forms payload2 from pass B's group sums (every
 // workgroup redundantly, in the declared order: a few KB of L2 reads instead of a launch boundary), takes Ceres' accept /
 // radius decision and linearises for it.  Workgroup 0 also delivers payload2 and the decision.
-__global__ __launch_bounds__(DET_THREADS) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
+template <int NT>
+__global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl ctl) {
   svo_latency_critical();
   extern __shared__ double lds[];  // wg_lds_doubles(E), the staging rows double as scratch of the sums
   __shared__ double sOut[4];
@@ -1130,7 +1132,7 @@ __global__ __launch_bounds__(DET_THREADS) void ba_decide_linearize_kernel(BaDev 
   if (dec.accept) Rc.p = pc;
   for (int chunk = c0; chunk < c1; ++chunk) {
     if (chunk != c0) Rc = load_obs(P, chunk, lane, points_);
-    linearize_chunk_wg1(P, Rc, poses_, dec.next_radius, 0, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
+    linearize_chunk_wg1<NT>(P, Rc, poses_, dec.next_radius, 0, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
     stores_acknowledged();
   }
 }
@@ -1164,7 +1166,8 @@ __global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius)
 // ---- deterministic mode, one LM iteration in one sweep: pass B at the current point, then (spec_radius > 0) pass A at
 // the candidate it just formed, with the radius an accepted step will have.  One wave per workgroup (spreads the
 // chunks over the CUs); the candidate landmark stays in registers between the passes.
-__global__ __launch_bounds__(DET_THREADS) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
+template <int NT>
+__global__ __launch_bounds__(NT) void ba_step_kernel(BaDev P, double radius, double spec_radius) {
   svo_latency_critical();
   __shared__ double sStep[STEP_LDS_DOUBLES];
   extern __shared__ double lds[];  // wg_lds_doubles(E)
@@ -1186,7 +1189,7 @@ __global__ __launch_bounds__(DET_THREADS) void ba_step_kernel(BaDev P, double ra
     if (spec_radius > 0) {
       __syncthreads();  // pass B kept its landmark scalars in the staging rows
       R.p = cand;
-      linearize_chunk_wg1(P, R, cand_poses_, spec_radius, 0, global_tab(P, chunk), L, sink);
+      linearize_chunk_wg1<NT>(P, R, cand_poses_, spec_radius, 0, global_tab(P, chunk), L, sink);
     }
     stores_acknowledged();
   }
@@ -3099,6 +3102,16 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
 }
 
 inline size_t wave_lds_bytes(const BaDev& d) { return sizeof(double) * (size_t)wg_lds_doubles(d.E); }
+// workgroup width of the host-driven deterministic kernels (experiment knob)
+inline int det_threads() {
+  static const int v = [] { const char* e = getenv("SVO_BA_DET_THREADS"); return e && atoi(e) == 64 ? 64 : 128; }();
+  return v;
+}
+#define SVO_DET_LAUNCH(kernel, grid, lds, st, ...)                                                        \
+  do {                                                                                                    \
+    if (det_threads() == 64) hipLaunchKernelGGL(kernel<64>, grid, dim3(64), lds, st, __VA_ARGS__);        \
+    else hipLaunchKernelGGL(kernel<128>, grid, dim3(128), lds, st, __VA_ARGS__);                          \
+  } while (0)
 
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
   svo_ba* ba = static_cast<svo_ba*>(user);
@@ -3114,7 +3127,7 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
     (void)ba_next_tag(ba);
     if (d.NG > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
+      SVO_DET_LAUNCH(ba_linearize_det_kernel, dim3(d.NG), wave_lds_bytes(d), st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
     }
     const int nb = d.NG > 0 ? ba_reduce_blocks(d.E) : 0;
     if (nb > 0) {
@@ -3179,7 +3192,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     const int nb = ba_reduce_blocks(d.E);
     {
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
-      hipLaunchKernelGGL(ba_step_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, radius, same_sweep ? spec_radius : 0.0);
+      SVO_DET_LAUNCH(ba_step_kernel, dim3(d.NG), wave_lds_bytes(d), st, d, radius, same_sweep ? spec_radius : 0.0);
     }
     if (!chain) {
       const int blocks = (same_sweep ? nb : 0) + 1;
@@ -3189,7 +3202,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       // pass A forms payload2 and takes the decision itself: 3 launches per LM iteration
       ba_aim_reduce(ba, 1, false);
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_decide_linearize_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, lc);
+      SVO_DET_LAUNCH(ba_decide_linearize_kernel, dim3(d.NG), wave_lds_bytes(d), st, d, lc);
     } else {
       ba_aim_reduce(ba, 1, false);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(1), dim3(256), 0, st, d, 0, 1, lc);
@@ -3198,7 +3211,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
       const LmCtl lcs = {ctl->cost, ctl->mcc, radius, ctl->decrease_factor, 1};
       hipLaunchKernelGGL(ba_decide_kernel, dim3(1), dim3(64), 0, st, lcs, ba->d_pay, d.ctl_dev);
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
-      hipLaunchKernelGGL(ba_linearize_det_kernel, dim3(d.NG), dim3(DET_THREADS), wave_lds_bytes(d), st, d, 0.0, 0, (const double*)d.ctl_dev);
+      SVO_DET_LAUNCH(ba_linearize_det_kernel, dim3(d.NG), wave_lds_bytes(d), st, d, 0.0, 0, (const double*)d.ctl_dev);
     }
     if (chain) {
       ba_aim_reduce(ba, nb, true);
