@@ -101,16 +101,14 @@ def test_hip_pipeline_degenerate_frames(ctx):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("env", [{"SVO_BA_CU_SHARE": "8"}, {"SVO_BA_NO_POLL": "1"}, {"SVO_LM_NO_SPECULATION": "1"},
-                                 {"SVO_BA_FUSED_REDUCE": "1", "SVO_BA_DEVICE_LM": "0"}, {"SVO_BA_FUSED_REDUCE": "0", "SVO_SPIN": "50"},
-                                 {"SVO_BA_FUSED_REDUCE": "1", "SVO_BA_DEVICE_LM": "0", "SVO_BA_CU_SHARE": "4"},
+                                 {"SVO_BA_DEVICE_LM": "0"}, {"SVO_BA_DEVICE_LM": "0", "SVO_SPIN": "50"},
                                  {"SVO_BA_DEVICE_LM": "1"}, {"SVO_BA_DEVICE_LM": "1", "SVO_BA_CU_SHARE": "4"},
                                  {"SVO_BA_DEVICE_LM": "1", "SVO_BA_CU_SHARE": "24"}, {"SVO_CORNER_TWO_PASS": "1"}])
 def test_hip_pipeline_optional_paths_keep_parity(env):
     """Deployment knobs must not change results: CU-partitioned streams, the stream-wait (non-polling) host loop, the
-    LM loop without chained / same-sweep linearisation (two host round trips per iteration), the whole LM iteration
-    in one launch (workgroups meeting at device-wide arrivals), sleeping host waits, the one-launch iteration on a
-    CU mask too small to hold its waiting workgroups (admission must send it down the separate-launch path instead of
-    letting it time out), the device-resident solve (one launch per solve, LM step control on the device; also on CU masks)
+    LM loop without chained / same-sweep linearisation (two host round trips per iteration), the host-driven loop forced,
+    sleeping host waits, the device-resident solve (one launch per solve, LM step control on the device; also on CU masks,
+    one of them too small to hold its waiting workgroups: admission must send the solve down the host-driven path)
     and corner detection through the f32 response map (two passes) instead of the fused response + non-maximum pass all
     have to reproduce the oracle's index sets and poses exactly.  The knobs are read from the environment, hence one child process each."""
     import os
