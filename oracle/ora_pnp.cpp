@@ -19,6 +19,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <cstdint>
 #include <vector>
 
 #include "svo_oracle.h"
@@ -177,17 +178,47 @@ Pose lm_solve(Pose P, const float* xyz, const float* xy, const int* idx, int m, 
   return P;
 }
 
+// RANSACUpdateNumIters with DECLARED arithmetic (the product restates the same in stereo_vo_amd/host/pnp_iters.h so that the
+// cut-off can be taken on the device): (1 - ep)^k by k - 1 multiplications left to right; log(x) = e ln2 + 2 s (1 + z/3 +
+// ... + z^12/25) with x = m 2^e, m in [sqrt(1/2), sqrt(2)), s = (m - 1)/(m + 1), z = s s, Horner from the highest term,
+// every operation rounded separately; round-half-even of the quotient.  (libm's log / pow are not bit-portable.)
+double det_log(double x) {
+  uint64_t bits;
+  std::memcpy(&bits, &x, 8);
+  int e = (int)((bits >> 52) & 0x7ffu) - 1022;
+  bits = (bits & 0x000fffffffffffffull) | 0x3fe0000000000000ull;
+  double m;
+  std::memcpy(&m, &bits, 8);
+  if (m < 0.70710678118654757) { m = m * 2.0; e -= 1; }
+  const double s = (m - 1.0) / (m + 1.0), z = s * s;
+  double p = 1.0 / 25.0;
+  for (int k = 23; k >= 3; k -= 2) p = p * z + 1.0 / (double)k;
+  p = p * z + 1.0;
+  const double t1 = (double)e * 0.6931471805599453, t2 = 2.0 * s, t3 = t2 * p;
+  return t1 + t3;
+}
+
 int update_num_iters(double p, double ep, int model_points, int max_iters) {
   p = std::max(p, 0.0); p = std::min(p, 1.0);
   ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
   double num = std::max(1.0 - p, DBL_MIN);
-  double denom = 1.0 - std::pow(1.0 - ep, model_points);
+  double pw = 1.0;
+  for (int i = 0; i < model_points; ++i) pw = pw * (1.0 - ep);
+  double denom = 1.0 - pw;
   if (denom < DBL_MIN) return 0;
-  num = std::log(num);
-  denom = std::log(denom);
-  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+  num = det_log(num);
+  denom = det_log(denom);
+  if (denom >= 0 || -num >= max_iters * (-denom)) return max_iters;
+  const double v = num / denom, f = std::fabs(v);
+  long long i = (long long)f;
+  const double frac = f - (double)i;
+  if (frac > 0.5 || (frac == 0.5 && (i & 1))) ++i;
+  return (int)(v < 0 ? -i : i);
 }
 }  // namespace
+
+extern "C" int ora_pnp_update_num_iters(double p, double ep, int model_points, int max_iters) { return update_num_iters(p, ep, model_points, max_iters); }
+extern "C" double ora_pnp_det_log(double x) { return det_log(x); }
 
 extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float focal, float cxf,
                               float cyf, double* rvec3, double* tvec3, int iterations,

@@ -101,6 +101,7 @@ struct BaDev {
   int G = 1, NG = 0, Epad = 0, E = 0;    // chunks per group, groups, granules per group row (E rounded up), wire-format elements
   const uint16_t* tab = nullptr;   // chunk tables back to back (u16 words), see ba_build_tables
   const uint32_t* tab_off = nullptr;  // C + 1 offsets into tab
+  const unsigned* lm_key = nullptr;   // per landmark: low 32 bits of its feature id (null: the problem has none — bulk loads); the key of its landmark-store entry
   double* part1 = nullptr;         // granules {value, tag}: element e of group g at part1[2 * (g * Epad + e)] — a wavefront's partials are one contiguous run
   double* part2 = nullptr;         // granules: pass B's four sums of group g at part2[2 * ((parity * NG + g) * 4 + i)]
   double* pay1_out = nullptr;      // where ba_reduce_kernel writes the wire totals (pinned host memory when single-rank)
@@ -1286,6 +1287,8 @@ struct LmDevArgs {
   double* points_a;         // the two landmark buffers (current / candidate, swapped by every accepted step)
   double* points_b;
   double* export_points;    // pinned: the solved landmarks, by landmark index (null: none)
+  float4* store;            // device-resident landmark store (null: none): entry (key & store_mask) = {x, y, z, key} of every landmark of the solve, key = P.lm_key[j]
+  unsigned store_mask;
   double* dev_res;          // device granules: the E wire totals of the running iteration | elapsed seconds
   double* host_result;      // pinned: [LMR_* summary | poses 7 K]
   int* host_flag;           // pinned completion word of the solve
@@ -1856,6 +1859,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
         if (R.active) R.p = D3{P.points[3 * R.j], P.points[3 * R.j + 1], P.points[3 * R.j + 2]};
         deliver_chunk_points(R, a.export_points, union_lds + wave * ((64 * REC_STRIDE) / LM_CPW), (64 * REC_STRIDE) / LM_CPW);  // the staging rows are idle
       }
+      if (a.store && my_wave_works && W.R.active && lane == W.R.first) {
+        // get_world_points (src/bundle_adjuster.cpp:159-163: double -> float) for the next keyframe's PnP, served from the device:
+        // one write-through 16-byte store per landmark, acknowledged before the completion word like everything else
+        const int j = W.R.j;
+        const unsigned key = sys_load(&P.lm_key[j], shift);
+        const float x = (float)P.points[3 * j], y = (float)P.points[3 * j + 1], z = (float)P.points[3 * j + 2];
+        const unsigned long long lo = ((unsigned long long)__float_as_uint(y) << 32) | __float_as_uint(x), hi = ((unsigned long long)key << 32) | __float_as_uint(z);
+        slot_store2<true>(reinterpret_cast<double*>(a.store + (key & a.store_mask)), __longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
+      }
       if (a.dbg && tid == 0) {  // SVO_BA_TRACE: this workgroup's own split (ticks), for the spread over the workgroups of a solve
         unsigned* g = a.dbg + 16 * blockIdx.x;
         for (int i = 0; i < 6; ++i) g[8 + i] = (unsigned)cs.tp[i];
@@ -2252,6 +2264,9 @@ struct svo_ba {
   std::vector<double> feat_pos;  // 3 per feature id
   bool new_frame_added = false;
   std::vector<int64_t> solve_lm_ids;
+  bool upload_has_ids = false;   // solve_lm_ids describes the landmarks of the problem being uploaded (svo_ba_solve_prepare)
+  float4* store = nullptr; unsigned store_mask = 0;  // device-resident landmark store of the stream (svo_ba_attach_store), keyed by feature id
+  float4* h_store_stage = nullptr; unsigned* h_store_slot = nullptr; size_t store_stage_cap = 0;  // pinned staging of the scatter behind a host-driven solve
   std::vector<double> s_poses, s_points, s_uv, s_out_pts;   // per-solve scratch of svo_ba_solve (kept: no allocation per keyframe)
   std::vector<int32_t> s_op, s_oj;
   std::vector<int32_t> u_lm_start, u_chunks, u_cnt;  // scratch of ba_upload
@@ -2411,6 +2426,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
   void* ptrs[] = {ba->d_res, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.part1, d.part2, ba->d_arena};
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
+  if (ba->h_store_stage) (void)hipHostFree(ba->h_store_stage);
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
@@ -2615,6 +2631,8 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   const size_t o_uv = off; off = al(off + sizeof(double) * 2 * nslots);
   const size_t o_tab = off; off = al(off + sizeof(uint16_t) * tab.size());
   const size_t o_toff = off; off = al(off + sizeof(uint32_t) * tab_off.size());
+  const bool with_keys = ba->upload_has_ids && ba->store && (int)ba->solve_lm_ids.size() == npts;
+  const size_t o_key = off; if (with_keys) off = al(off + sizeof(unsigned) * (size_t)npts);
   const size_t o_p0 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
   const size_t o_p1 = off; off = al(off + sizeof(double) * 7 * (size_t)K);
   const size_t total = off;
@@ -2649,12 +2667,14 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   }
   if (!tab.empty()) memcpy(h + o_tab, tab.data(), sizeof(uint16_t) * tab.size());
   if (!tab_off.empty()) memcpy(h + o_toff, tab_off.data(), sizeof(uint32_t) * tab_off.size());
+  if (with_keys) { unsigned* k = reinterpret_cast<unsigned*>(h + o_key); for (int j = 0; j < npts; ++j) k[j] = (unsigned)ba->solve_lm_ids[(size_t)j]; }
   uint8_t* D = ba->d_arena;
   d.points = (double*)(D + o_pts); d.cand_points = (double*)(D + o_cpts);
   ba->cur_points = (double*)(D + o_pts); ba->cand_points = (double*)(D + o_cpts);
   ba->cur_poses = (double*)(D + o_p0); ba->cand_poses = (double*)(D + o_p1);
   d.rec = (const int4*)(D + o_rec); d.obs_uv = (const double*)(D + o_uv);
   d.tab = (const uint16_t*)(D + o_tab); d.tab_off = (const uint32_t*)(D + o_toff);
+  d.lm_key = with_keys ? (const unsigned*)(D + o_key) : nullptr;
   memcpy(h + o_p0, poses7, sizeof(double) * 7 * (size_t)K);
   memcpy(h + o_p1, poses7, sizeof(double) * 7 * (size_t)K);
   ba->h_poses.assign(poses7, poses7 + 7 * (size_t)K);
@@ -2962,6 +2982,7 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   a.arena_dst = ba->d_arena; a.arena_bytes = ba->arena_bytes;
   a.points_a = ba->cur_points; a.points_b = ba->cand_points;
   a.export_points = ba->n_points ? ba->h_out_points : nullptr;
+  a.store = d.lm_key ? ba->store : nullptr; a.store_mask = ba->store_mask;
   a.dev_res = ba->d_res;
   a.host_result = ba->h_result;
   a.host_flag = ba->h_flag; a.host_seq = ba->seq + 1;  // committed by the launch
@@ -3416,6 +3437,44 @@ extern "C" int svo_ba_get_points(svo_ba* ba, const int64_t* ids, int n, float* x
   return SVO_OK;
 }
 
+// The landmark store behind a HOST-DRIVEN solve (a lane whose window was not eligible or not admitted for ba_lm_kernel): the
+// solved landmarks as store entries in pinned memory, one scatter launch, joined before the caller goes on (the next PnP of
+// the lane is launched on another stream).  Rare; the device-resident solve writes its entries itself.
+__global__ __launch_bounds__(256) void ba_store_scatter_kernel(const float4* __restrict__ stage, int n, float4* __restrict__ store, unsigned mask) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 e = stage[i];
+  store[__float_as_uint(e.w) & mask] = e;
+}
+
+static int ba_store_scatter(svo_ba* ba, const std::vector<int64_t>& ids, const std::vector<double>& pts) {
+  svo_ctx* ctx = ba->ctx;
+  const size_t n = ids.size();
+  if (n > ba->store_stage_cap) {
+    if (ba->h_store_stage) (void)hipHostFree(ba->h_store_stage);
+    ba->h_store_stage = nullptr;
+    ba->store_stage_cap = n + n / 2 + 256;
+    SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_store_stage, sizeof(float4) * ba->store_stage_cap, hipHostMallocDefault));
+  }
+  for (size_t j = 0; j < n; ++j) {
+    float4 e;
+    e.x = (float)pts[3 * j]; e.y = (float)pts[3 * j + 1]; e.z = (float)pts[3 * j + 2];  // src/bundle_adjuster.cpp:159-163 (double -> float)
+    const unsigned key = (unsigned)ids[j];
+    memcpy(&e.w, &key, 4);
+    ba->h_store_stage[j] = e;
+  }
+  hipLaunchKernelGGL(ba_store_scatter_kernel, dim3(svo_div_up((int)n, 256)), dim3(256), 0, ba->stream, (const float4*)ba->h_store_stage, (int)n, ba->store, ba->store_mask);
+  SVO_HIP_CHECK(ctx, hipGetLastError());
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(ba->stream));
+  return SVO_OK;
+}
+
+int svo_ba_attach_store(svo_ba* ba, float4* store, unsigned mask) {
+  if (!ba || (store && (mask & (mask + 1)) != 0)) return SVO_ERR_INVALID;
+  ba->store = store; ba->store_mask = mask;
+  return SVO_OK;
+}
+
 // BundleAdjuster::bundle_adjust in three steps, so that a driver of several stereo streams (host/group.cpp) can assemble
 // on worker threads, launch the solves of several adjusters as ONE kernel and join them later; svo_ba_solve = all three.
 // prepare: host only (no launch) — the window's observations as a landmark-major problem image in pinned memory.
@@ -3473,7 +3532,9 @@ int svo_ba_solve_prepare(svo_ba* ba) {
   }
   const auto tu0 = std::chrono::steady_clock::now();
   ba->t_prep += std::chrono::duration<double, std::milli>(tu0 - tp0).count();
+  ba->upload_has_ids = true;   // the landmark-store keys of this problem = lm_ids
   int rc = ba_upload(ba, K, poses.data(), (int)lm_ids.size(), points.data(), (int)op.size(), op.data(), oj.data(), uv.data());
+  ba->upload_has_ids = false;
   if (rc) return rc;
   ba->t_upload += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   return SVO_OK;
@@ -3505,6 +3566,7 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   std::vector<double>& poses = ba->s_poses; std::vector<double>& points = ba->s_points;
   std::vector<int64_t>& lm_ids = ba->solve_lm_ids;
   int rc;
+  const bool on_device = ba->lm_inflight;
   if (ba->lm_inflight) { rc = ba_device_lm_end(ba, summary); ba->d.flag = nullptr; }
   else rc = ba_lm(ba, summary);
   if (!rc) ba->upload_pending = false;
@@ -3524,6 +3586,10 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   for (size_t l = 0; l < lm_ids.size(); ++l)
     for (int a = 0; a < 3; ++a) ba->feat_pos[3 * lm_ids[l] + a] = out_pts[3 * l + a];
   ba->new_frame_added = false;  // :155
+  if (ba->store && !on_device && !lm_ids.empty()) {  // the device-resident solve wrote the landmark store itself
+    rc = ba_store_scatter(ba, lm_ids, out_pts);
+    if (rc) return rc;
+  }
   ba->t_read += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
   return SVO_OK;
 }

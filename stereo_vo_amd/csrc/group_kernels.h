@@ -29,23 +29,23 @@ struct SvoLkLanes { int w, h; SvoLkLane lane[SVO_MAX_LANES]; };
 // grid_x = the largest lane's feature count; every lane's arrive_target counts grid_x workgroups
 int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_lanes, int grid_x);
 
-// a5: hypotheses (100 workgroups per lane), then refinement of the hypothesis the host's RANSAC bookkeeping chose
-struct SvoPnpHypLane {
-  const float* xyz; const float* xy; int n; double f, cx, cy; double q0[4], t0[3]; double thr2;
-  const float* host_xyz;  // pinned source of xyz (get_world_points, src/image_processor.cpp:72); null: xyz is already on the device
-  double* hyp_pose; int* hyp_count; unsigned long long* hyp_mask; int mask_words; int* host_count;
-  SvoPublish pub;
+// a5: the whole cv::solvePnPRansac of a lane (src/image_processor.cpp:72-80) as ONE launch: hypotheses (four per workgroup),
+// RANSAC bookkeeping and refinement by the lane's last workgroup to arrive; the world points (get_world_points,
+// src/bundle_adjuster.cpp:159-163) come from the lane's device-resident landmark store, keyed by feature id
+// store entry (id mod capacity) = float4 {x, y, z, bits of the low 32 bits of the id}
+struct SvoPnpLane {
+  const long long* ids; const float4* store; unsigned store_mask;  // tracked features' ids (device) -> store entries
+  const float* xy; int n; double f, cx, cy; double q0[4], t0[3]; double thr2, confidence; int iterations;
+  double* hyp_pose; int* hyp_count; unsigned long long* hyp_mask; int mask_words;   // per-hypothesis scratch (device)
+  double* out_pose; int* inliers; int* n_inliers; float* inlier_xy;                // device results (inlier_xy: the dedup stage's input)
+  double* host_pose; int* host_inliers; int* host_nin; int* host_best; int* host_bad;  // pinned mirrors; host_best < 0: no model, host_bad != 0: a store entry under a foreign id
+  unsigned* arrive; unsigned arrive_target;                                         // device arrival counter of the lane (monotone)
+  int* word; int seq;                                                               // pinned completion word
 };
-struct SvoPnpHypLanes { SvoPnpHypLane lane[SVO_MAX_LANES]; };
-int svo_kg_pnp_hypotheses(svo_ctx* ctx, hipStream_t st, const SvoPnpHypLanes& lanes, int n_lanes, int iterations);
-struct SvoPnpRefLane {
-  const float* xyz; const float* xy; int n; double f, cx, cy; const double* hyp_pose; const unsigned long long* hyp_mask;
-  int mask_words; int best; double* out_pose; int* inliers; int* n_inliers; double* host_pose; int* host_inliers; int* host_nin;
-  float* inlier_xy; SvoPublish pub;
-};
-struct SvoPnpRefLanes { SvoPnpRefLane lane[SVO_MAX_LANES]; };
-int svo_kg_pnp_refine(svo_ctx* ctx, hipStream_t st, const SvoPnpRefLanes& lanes, int n_lanes);
-int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters);  // OpenCV's RANSACUpdateNumIters (csrc/pnp.hip)
+struct SvoPnpLanes { SvoPnpLane lane[SVO_MAX_LANES]; };
+int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes, int iterations);
+int svo_kg_pnp_workgroups(int iterations);  // workgroups per lane of that launch (what arrive_target counts)
+int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters);  // OpenCV's RANSACUpdateNumIters (host/pnp_iters.h)
 int svo_pnp_model_points();
 
 // a6 + a7 (sparse) + a8: every workgroup first applies the dedup predicate to its detected corner (a duplicate takes disparity 0
@@ -65,6 +65,9 @@ int svo_ba_solve_prepare(svo_ba* ba);                          // 1: nothing to 
 int svo_ba_solve_launch(svo_ba** bas, int n, void* stream, unsigned long long* launched_mask);  // number launched; bit i of the mask: bas[i] was (an ineligible or not admitted adjuster is skipped)
 int svo_ba_solve_poll(svo_ba* ba);                             // 1: finish will not block
 int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary);  // join (or solve host-driven) + write back into the graph
-void svo_ba_work(svo_ba* ba, double* out4, int reset);          // algorithmic [flops, bytes, solves, LM iterations] of the finished solves
+void svo_ba_work(svo_ba* ba, double* out4, int reset);
+// device-resident landmark store of the adjuster's stream (capacity = mask + 1 entries, a power of two): every solve writes the
+// landmarks it optimised into it — ba_lm_kernel with its delivery, a host-driven solve through one scatter launch at its finish
+int svo_ba_attach_store(svo_ba* ba, float4* store, unsigned mask);          // algorithmic [flops, bytes, solves, LM iterations] of the finished solves
 
 #endif

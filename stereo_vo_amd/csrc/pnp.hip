@@ -17,6 +17,8 @@
 
 #include "kernels.h"
 #include "group_kernels.h"
+#include "pnp_iters.h"
+#include "tail_device.h"
 
 namespace {
 constexpr int MODEL = 5;
@@ -38,10 +40,41 @@ __device__ __forceinline__ void quat_to_R(const double* q, double* R) {
   R[6] = 2 * (x * z - w * y); R[7] = 2 * (y * z + w * x); R[8] = 1 - 2 * (x * x + y * y);
 }
 
+// Where a tracked feature's world point comes from (get_world_points, src/bundle_adjuster.cpp:159-163, called at
+// src/image_processor.cpp:72):
+//   XyzArray : a float3 array in feature order (the single pipeline: gathered on the host, uploaded);
+//   XyzStore : the pipeline group's DEVICE-RESIDENT landmark store, keyed by feature id — entry (id mod capacity) =
+//              {x, y, z, low 32 bits of the id}, written by the solve that last optimised the landmark (ba_lm_kernel's delivery,
+//              or the scatter behind a host-driven solve).  An entry under another id is reported (`bad`), never used silently.
+struct XyzArray {
+  const float* xyz;
+  __device__ __forceinline__ void get(int i, float& X, float& Y, float& Z) const { X = xyz[3 * i]; Y = xyz[3 * i + 1]; Z = xyz[3 * i + 2]; }
+};
+struct XyzStore {
+  const long long* ids; const float4* store; unsigned mask; int* bad;
+  __device__ __forceinline__ void get(int i, float& X, float& Y, float& Z) const {
+    const unsigned key = (unsigned)ids[i];
+    const float4 e = store[key & mask];
+    if (__float_as_uint(e.w) != key) svo_host_store(bad, 1);
+    X = e.x; Y = e.y; Z = e.z;
+  }
+};
+// LDS traffic of ONE wavefront is ordered; the fence only keeps the compiler from moving accesses across it
+__device__ __forceinline__ void pnp_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <bool WAVE>
+__device__ __forceinline__ void pnp_sync() { if (WAVE) pnp_wave_fence(); else __syncthreads(); }
+
 // residual (and 2x6 Jacobian) of one point; returns ex^2+ey^2
-__device__ __forceinline__ double pnp_term(const double* R, const double* t, const float* xyz, const float* xy, int i,
+template <typename Xyz>
+__device__ __forceinline__ double pnp_term(const double* R, const double* t, const Xyz& src, const float* xy, int i,
                                            double f, double cx, double cy, double* e, double* J /*12 or null*/) {
-  const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+  float Xf, Yf, Zf;
+  src.get(i, Xf, Yf, Zf);
+  const double X = Xf, Y = Yf, Z = Zf;
   const double rx = R[0] * X + R[1] * Y + R[2] * Z;
   const double ry = R[3] * X + R[4] * Y + R[5] * Z;
   const double rz = R[6] * X + R[7] * Y + R[8] * Z;
@@ -144,18 +177,20 @@ struct LmShared {
   int ok;
 };
 
-template <typename Acc>
+// WAVE: the owner set is ONE wavefront (a hypothesis), hand-overs are wave-level fences; otherwise the whole workgroup.
+template <bool WAVE, typename Acc>
 __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
+  const int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
   double lambda = 1e-3;
   double cost = acc(S.cur, S.H, S.g);
   for (int it = 0; it < max_it; ++it) {
-    if (threadIdx.x < 64) {
+    if (t < 64) {
       const bool ok = solve6_retract_wave(S.H, S.g, lambda, S.cur, S.d, S.cand);
-      if (threadIdx.x == 0) S.ok = ok ? 1 : 0;
+      if (t == 0) S.ok = ok ? 1 : 0;
     }
-    __syncthreads();
+    pnp_sync<WAVE>();
     const int ok = S.ok;
-    if (!ok) { lambda *= 10; __syncthreads(); continue; }
+    if (!ok) { lambda *= 10; pnp_sync<WAVE>(); continue; }
     const double c2 = acc(S.cand, S.Hc, S.gc);
     if (c2 < cost) {
       const double* d = S.d;
@@ -163,11 +198,11 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
       // CvLevMarq's stop: relative parameter change below FLT_EPSILON, against the pose before the step (oracle/ora_pnp.cpp)
       const double x2 = ((S.cur.t[0] * S.cur.t[0] + S.cur.t[1] * S.cur.t[1]) + S.cur.t[2] * S.cur.t[2]) +
                         4.0 * ((S.cur.q[1] * S.cur.q[1] + S.cur.q[2] * S.cur.q[2]) + S.cur.q[3] * S.cur.q[3]);
-      __syncthreads();
-      if (threadIdx.x == 0) S.cur = S.cand;
-      if (threadIdx.x < 36) S.H[threadIdx.x] = S.Hc[threadIdx.x];
-      if (threadIdx.x < 6) S.g[threadIdx.x] = S.gc[threadIdx.x];
-      __syncthreads();
+      pnp_sync<WAVE>();
+      if (t == 0) S.cur = S.cand;
+      if (t < 36) S.H[t] = S.Hc[t];
+      if (t < 6) S.g[t] = S.gc[t];
+      pnp_sync<WAVE>();
       lambda *= 0.1;
       if (lambda < 1e-9) lambda = 1e-9;
       cost = c2;
@@ -180,57 +215,62 @@ __device__ void lm_solve(LmShared& S, int max_it, Acc acc) {
 }
 }  // namespace
 
-__device__ __forceinline__ void pnp_hypotheses_body(const float* __restrict__ xyz, const float* __restrict__ xy,
-                                                    int n, double f, double cx, double cy, PnpPose P0,
-                                                    double thr2, double* __restrict__ hyp_pose,
-                                                    int* __restrict__ hyp_count,
-                                                    unsigned long long* __restrict__ hyp_mask, int mask_words,
-                                                    int* __restrict__ host_count, SvoPublish pub) {
-  svo_latency_critical();
-  __shared__ LmShared S;
-  __shared__ int sIdx[MODEL];
-  __shared__ double sJ[MODEL][12], sE[MODEL][2];
-  const int h = blockIdx.x, lane = threadIdx.x;
+// LDS of one hypothesis (one wavefront)
+struct HypLds {
+  LmShared S;
+  double sJ[MODEL][12], sE[MODEL][2];
+  int sIdx[MODEL];
+};
+
+// Hypothesis `h` by the calling WAVEFRONT (64 lanes; any workgroup shape).  WT: count / mask / pose are consumed by another
+// workgroup of this launch (the bookkeeping of pnp_group_kernel) and are written through.
+template <typename Xyz, bool WT>
+__device__ __forceinline__ void pnp_hypothesis_wave(const Xyz& src, const float* __restrict__ xy, int n, double f, double cx, double cy,
+                                                    const PnpPose& P0, double thr2, int h, HypLds& L, double* __restrict__ hyp_pose,
+                                                    int* __restrict__ hyp_count, unsigned long long* __restrict__ hyp_mask, int mask_words,
+                                                    int* __restrict__ host_count) {
+  const int lane = threadIdx.x & 63;
+  LmShared& S = L.S;
   if (lane == 0) {
     unsigned long long s = SEED + (unsigned long long)h * STRIDE;
     for (int k = 0; k < MODEL; ++k) {
       for (;;) {
         const int c = (int)(splitmix(s) % (unsigned long long)n);
         bool dup = false;
-        for (int j = 0; j < k; ++j) dup |= sIdx[j] == c;
-        if (!dup) { sIdx[k] = c; break; }
+        for (int j = 0; j < k; ++j) dup |= L.sIdx[j] == c;
+        if (!dup) { L.sIdx[k] = c; break; }
       }
     }
     S.cur = P0;
   }
-  __syncthreads();
+  pnp_wave_fence();
   auto acc = [&](const PnpPose& P, double* H, double* g) -> double {
     double R[9];
     quat_to_R(P.q, R);
-    if (lane < MODEL) pnp_term(R, P.t, xyz, xy, sIdx[lane], f, cx, cy, sE[lane], sJ[lane]);
-    __syncthreads();
+    if (lane < MODEL) pnp_term(R, P.t, src, xy, L.sIdx[lane], f, cx, cy, L.sE[lane], L.sJ[lane]);
+    pnp_wave_fence();
     if (lane < 27) {
       if (lane < 21) {  // upper-triangular entry (r,c)
         int r = 0, e = lane;
         while (e >= 6 - r) { e -= 6 - r; ++r; }
         const int c = r + e;
         double s = 0.0;
-        for (int k = 0; k < MODEL; ++k) s += sJ[k][r] * sJ[k][c] + sJ[k][6 + r] * sJ[k][6 + c];
+        for (int k = 0; k < MODEL; ++k) s += L.sJ[k][r] * L.sJ[k][c] + L.sJ[k][6 + r] * L.sJ[k][6 + c];
         H[6 * r + c] = s;
       } else {
         const int r = lane - 21;
         double s = 0.0;
-        for (int k = 0; k < MODEL; ++k) s += sJ[k][r] * sE[k][0] + sJ[k][6 + r] * sE[k][1];
+        for (int k = 0; k < MODEL; ++k) s += L.sJ[k][r] * L.sE[k][0] + L.sJ[k][6 + r] * L.sE[k][1];
         g[r] = s;
       }
     }
     double cost = 0.0;
-    for (int k = 0; k < MODEL; ++k) cost += sE[k][0] * sE[k][0] + sE[k][1] * sE[k][1];
-    __syncthreads();
+    for (int k = 0; k < MODEL; ++k) cost += L.sE[k][0] * L.sE[k][0] + L.sE[k][1] * L.sE[k][1];
+    pnp_wave_fence();
     return cost;
   };
-  lm_solve(S, 12, acc);
-  __syncthreads();
+  lm_solve<true>(S, 12, acc);
+  pnp_wave_fence();
   const PnpPose P = S.cur;
   double R[9];
   quat_to_R(P.q, R);
@@ -239,7 +279,9 @@ __device__ __forceinline__ void pnp_hypotheses_body(const float* __restrict__ xy
     const int i = w * 64 + lane;
     bool in = false;
     if (i < n) {
-      const double X = xyz[3 * i], Y = xyz[3 * i + 1], Z = xyz[3 * i + 2];
+      float Xf, Yf, Zf;
+      src.get(i, Xf, Yf, Zf);
+      const double X = Xf, Y = Yf, Z = Zf;
       const double px = R[0] * X + R[1] * Y + R[2] * Z + P.t[0];
       const double py = R[3] * X + R[4] * Y + R[5] * Z + P.t[1];
       const double pz = R[6] * X + R[7] * Y + R[8] * Z + P.t[2];
@@ -252,34 +294,38 @@ __device__ __forceinline__ void pnp_hypotheses_body(const float* __restrict__ xy
     }
     const unsigned long long m = __ballot(in);
     cnt += __popcll(m);
-    if (lane == 0) hyp_mask[(size_t)h * mask_words + w] = m;
+    if (lane == 0) {
+      if (WT) svo_wt_store(&hyp_mask[(size_t)h * mask_words + w], m);
+      else hyp_mask[(size_t)h * mask_words + w] = m;
+    }
   }
   if (lane == 0) {
-    hyp_count[h] = cnt;
+    if (WT) svo_wt_store(&hyp_count[h], cnt); else hyp_count[h] = cnt;
     if (host_count) svo_host_store(&host_count[h], cnt);  // pinned: the host's RANSAC bookkeeping reads the counts in place
-    for (int k = 0; k < 4; ++k) hyp_pose[7 * h + k] = P.q[k];
-    for (int k = 0; k < 3; ++k) hyp_pose[7 * h + 4 + k] = P.t[k];
+    for (int k = 0; k < 7; ++k) {
+      const double v = k < 4 ? P.q[k] : P.t[k - 4];
+      if (WT) svo_wt_store(&hyp_pose[7 * h + k], v); else hyp_pose[7 * h + k] = v;
+    }
   }
-  svo_publish_block_wt(pub);  // the only host payload is host_count (written through above): no write-back per workgroup
 }
 
-__device__ __forceinline__ void pnp_refine_body(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
-                                                double f, double cx, double cy, const double* __restrict__ hyp_pose,
-                                                const unsigned long long* __restrict__ hyp_mask, int mask_words,
+// Refinement over the inliers of hypothesis `best` by the calling workgroup (256 threads).  COHERENT: mask and pose of the
+// hypothesis were written by other workgroups of this very launch (read at the coherence point).
+template <typename Xyz, bool COHERENT>
+__device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __restrict__ xy, int n,
+                                                double f, double cx, double cy, const double* hyp_pose,
+                                                const unsigned long long* hyp_mask, int mask_words,
                                                 int best, double* __restrict__ out_pose, int* __restrict__ inliers,
                                                 int* __restrict__ n_inliers, double* __restrict__ host_pose,
                                                 int* __restrict__ host_inliers, int* __restrict__ host_nin,
-                                                float* __restrict__ inlier_xy, SvoPublish pub) {
+                                                float* __restrict__ inlier_xy, SvoPublish pub, LmShared& S, double (*sPart)[28], int* sBase) {
   svo_latency_critical();
-  __shared__ LmShared S;
-  __shared__ double sPart[256][28];
-  __shared__ int sBase;
   const int tid = threadIdx.x;
   // inlier list of the best hypothesis, ascending (one wave builds it)
   if (tid < 64) {
     int base = 0;
     for (int w = 0; w < mask_words; ++w) {
-      const unsigned long long m = hyp_mask[(size_t)best * mask_words + w];
+      const unsigned long long m = COHERENT ? svo_coherent_load(&hyp_mask[(size_t)best * mask_words + w]) : hyp_mask[(size_t)best * mask_words + w];
       if ((m >> tid) & 1ull) {
         const int slot = base + __popcll(m & ((1ull << tid) - 1ull));
         inliers[slot] = w * 64 + tid;
@@ -289,13 +335,13 @@ __device__ __forceinline__ void pnp_refine_body(const float* __restrict__ xyz, c
       base += __popcll(m);
     }
     if (tid == 0) {
-      sBase = base;
-      for (int k = 0; k < 4; ++k) S.cur.q[k] = hyp_pose[7 * best + k];
-      for (int k = 0; k < 3; ++k) S.cur.t[k] = hyp_pose[7 * best + 4 + k];
+      *sBase = base;
+      for (int k = 0; k < 4; ++k) S.cur.q[k] = COHERENT ? svo_coherent_load(&hyp_pose[7 * best + k]) : hyp_pose[7 * best + k];
+      for (int k = 0; k < 3; ++k) S.cur.t[k] = COHERENT ? svo_coherent_load(&hyp_pose[7 * best + 4 + k]) : hyp_pose[7 * best + 4 + k];
     }
   }
   __syncthreads();
-  const int m = sBase;
+  const int m = *sBase;
   auto acc = [&](const PnpPose& P, double* H, double* g) -> double {
     double R[9];
     quat_to_R(P.q, R);
@@ -305,7 +351,7 @@ __device__ __forceinline__ void pnp_refine_body(const float* __restrict__ xyz, c
     for (int k = tid; k < m; k += 256) {
       double e2[2], J[12];
       const int pi = __hip_atomic_load(&inliers[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // written by wave 0 above
-      v[27] += pnp_term(R, P.t, xyz, xy, pi, f, cx, cy, e2, J);
+      v[27] += pnp_term(R, P.t, src, xy, pi, f, cx, cy, e2, J);
       int o = 0;
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
@@ -336,7 +382,7 @@ __device__ __forceinline__ void pnp_refine_body(const float* __restrict__ xyz, c
     __syncthreads();
     return cost;
   };
-  lm_solve(S, 20, acc);
+  lm_solve<false>(S, 20, acc);
   __syncthreads();
   if (tid == 0) {
     for (int k = 0; k < 4; ++k) out_pose[k] = S.cur.q[k];
@@ -357,7 +403,10 @@ __global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restr
                                                             int* __restrict__ hyp_count,
                                                             unsigned long long* __restrict__ hyp_mask, int mask_words,
                                                             int* __restrict__ host_count, SvoPublish pub) {
-  pnp_hypotheses_body(xyz, xy, n, f, cx, cy, P0, thr2, hyp_pose, hyp_count, hyp_mask, mask_words, host_count, pub);
+  svo_latency_critical();
+  __shared__ HypLds L;
+  pnp_hypothesis_wave<XyzArray, false>(XyzArray{xyz}, xy, n, f, cx, cy, P0, thr2, blockIdx.x, L, hyp_pose, hyp_count, hyp_mask, mask_words, host_count);
+  svo_publish_block_wt(pub);  // the only host payload is host_count (written through above): no write-back per workgroup
 }
 
 __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
@@ -367,35 +416,63 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict
                                                          int* __restrict__ n_inliers, double* __restrict__ host_pose,
                                                          int* __restrict__ host_inliers, int* __restrict__ host_nin,
                                                          float* __restrict__ inlier_xy, SvoPublish pub) {
-  pnp_refine_body(xyz, xy, n, f, cx, cy, hyp_pose, hyp_mask, mask_words, best, out_pose, inliers, n_inliers, host_pose, host_inliers,
-                  host_nin, inlier_xy, pub);
+  __shared__ LmShared S;
+  __shared__ double sPart[256][28];
+  __shared__ int sBase;
+  pnp_refine_body<XyzArray, false>(XyzArray{xyz}, xy, n, f, cx, cy, hyp_pose, hyp_mask, mask_words, best, out_pose, inliers, n_inliers, host_pose,
+                                   host_inliers, host_nin, inlier_xy, pub, S, sPart, &sBase);
 }
 
-// stream-batched forms (group_kernels.h): blockIdx.y = lane, the same bodies
-__global__ __launch_bounds__(64) void pnp_hypotheses_group_kernel(SvoPnpHypLanes g) {
-  const SvoPnpHypLane& a = g.lane[blockIdx.y];
-  PnpPose P0;
-  for (int k = 0; k < 4; ++k) P0.q[k] = a.q0[k];
-  for (int k = 0; k < 3; ++k) P0.t[k] = a.t0[k];
-  pnp_hypotheses_body(a.xyz, a.xy, a.n, a.f, a.cx, a.cy, P0, a.thr2, a.hyp_pose, a.hyp_count, a.hyp_mask, a.mask_words, a.host_count, a.pub);
-}
-
-__global__ __launch_bounds__(256) void pnp_refine_group_kernel(SvoPnpRefLanes g) {
-  const SvoPnpRefLane& a = g.lane[blockIdx.y];
-  pnp_refine_body(a.xyz, a.xy, a.n, a.f, a.cx, a.cy, a.hyp_pose, a.hyp_mask, a.mask_words, a.best, a.out_pose, a.inliers, a.n_inliers,
-                  a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, a.pub);
+// ---- stream-batched form (group_kernels.h): the WHOLE solvePnPRansac of a lane as one launch.  blockIdx.y = lane; every
+// workgroup runs four hypotheses (one per wavefront, wave-level hand-overs) with the world points read from the lane's
+// device-resident landmark store; the LAST workgroup of the lane to arrive does OpenCV's bookkeeping (hypotheses consumed in
+// order, strictly more inliers replaces the best, RANSACUpdateNumIters with the declared arithmetic of host/pnp_iters.h) and
+// refines the winner — the same bodies, the same operations in the same order as the two single-stream kernels and the host
+// loop between them, hence the same bits (tests/test_group.py).  One launch and one completion word per keyframe where
+// round 3 had a world-point upload kernel, two launches and a host round trip between them.
+__global__ __launch_bounds__(256) void pnp_group_kernel(SvoPnpLanes g) {
+  svo_latency_critical();
+  const SvoPnpLane& a = g.lane[blockIdx.y];
+  __shared__ double sPart[256][28];  // first the four hypotheses' LDS, then the refinement's partial sums
+  __shared__ LmShared S;
+  __shared__ int sBase, sLast, sBest;
+  static_assert(4 * sizeof(HypLds) <= sizeof(double) * 256 * 28, "the hypotheses' LDS must fit the refinement's");
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const XyzStore src{a.ids, a.store, a.store_mask, a.host_bad};
+  const int h = blockIdx.x * 4 + wave;
+  if (h < a.iterations) {
+    PnpPose P0;
+    for (int k = 0; k < 4; ++k) P0.q[k] = a.q0[k];
+    for (int k = 0; k < 3; ++k) P0.t[k] = a.t0[k];
+    HypLds& L = reinterpret_cast<HypLds*>(&sPart[0][0])[wave];
+    pnp_hypothesis_wave<XyzStore, true>(src, a.xy, a.n, a.f, a.cx, a.cy, P0, a.thr2, h, L, a.hyp_pose, a.hyp_count, a.hyp_mask, a.mask_words, nullptr);
+  }
+  if (!svo_last_arrival(a.arrive, a.arrive_target, &sLast)) return;
+  if (tid == 0) {
+    int best = -1, best_cnt = 0, niters = a.iterations;
+    for (int hh = 0; hh < niters; ++hh) {
+      const int c = svo_coherent_load(&a.hyp_count[hh]);
+      if (c > (best_cnt > MODEL - 1 ? best_cnt : MODEL - 1)) {
+        best = hh; best_cnt = c;
+        niters = svo_pnp_update_num_iters_det(a.confidence, (double)(a.n - best_cnt) / a.n, MODEL, niters);
+      }
+    }
+    sBest = best;
+    *a.host_best = best;
+    if (best < 0) *a.host_nin = 0;
+  }
+  __syncthreads();
+  const int best = sBest;
+  SvoPublish pub;
+  pub.word = a.word; pub.seq = a.seq;
+  if (best < 0) { svo_publish_block(pub); return; }
+  pnp_refine_body<XyzStore, true>(src, a.xy, a.n, a.f, a.cx, a.cy, a.hyp_pose, a.hyp_mask, a.mask_words, best, a.out_pose, a.inliers, a.n_inliers,
+                                  a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, pub, S, sPart, &sBase);
 }
 
 // ----------------------------------------------------------------------------- host side
 static int update_num_iters(double p, double ep, int model_points, int max_iters) {
-  p = std::max(p, 0.0); p = std::min(p, 1.0);
-  ep = std::max(ep, 0.0); ep = std::min(ep, 1.0);
-  double num = std::max(1.0 - p, DBL_MIN);
-  double denom = 1.0 - pow(1.0 - ep, model_points);
-  if (denom < DBL_MIN) return 0;
-  num = log(num);
-  denom = log(denom);
-  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
+  return svo_pnp_update_num_iters_det(p, ep, model_points, max_iters);  // OpenCV's RANSACUpdateNumIters, declared arithmetic (host/pnp_iters.h)
 }
 
 // Device-pointer form used by the pipeline: xyz/xy on the device, n known on the host.
@@ -498,37 +575,10 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, i
 int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters) { return update_num_iters(p, ep, model_points, max_iters); }
 int svo_pnp_model_points() { return MODEL; }
 
-// The world points of every lane of a hypotheses launch, pinned host -> device, as ONE small launch in front of it (a
-// hipMemcpyAsync per lane was a blit kernel each: 0.5 per processed frame, 47 us on average under the group load).
-__global__ __launch_bounds__(256) void pnp_xyz_upload_group_kernel(SvoPnpHypLanes g) {
-  const SvoPnpHypLane& a = g.lane[blockIdx.y];
-  if (!a.host_xyz) return;
-  const int nfl = 3 * a.n, i = blockIdx.x * 256 + threadIdx.x;  // 16-byte chunk i = floats [4 i, 4 i + 4)
-  if (4 * i >= nfl) return;
-  float* dst = const_cast<float*>(a.xyz);
-  if (4 * i + 4 <= nfl) {
-    uint4 v;
-    const float* q = a.host_xyz + 4 * i;
-    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(q) : "memory");  // system scope: never a stale L2 line of the last keyframe's points
-    *reinterpret_cast<uint4*>(dst + 4 * i) = v;
-  } else {
-    for (int j = 4 * i; j < nfl; ++j) dst[j] = __hip_atomic_load(&a.host_xyz[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-int svo_kg_pnp_hypotheses(svo_ctx* ctx, hipStream_t st, const SvoPnpHypLanes& lanes, int n_lanes, int iterations) {
-  int max_n = 0;
-  for (int i = 0; i < n_lanes; ++i) if (lanes.lane[i].host_xyz) max_n = std::max(max_n, lanes.lane[i].n);
-  if (max_n > 0) hipLaunchKernelGGL(pnp_xyz_upload_group_kernel, dim3(svo_div_up(svo_div_up(3 * max_n, 4), 256), n_lanes), dim3(256), 0, st, lanes);
+int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes, int iterations) {
   SvoProfScope prof(ctx, SVO_PROF_PNP_HYP, st);
-  hipLaunchKernelGGL(pnp_hypotheses_group_kernel, dim3(iterations, n_lanes), dim3(64), 0, st, lanes);
+  hipLaunchKernelGGL(pnp_group_kernel, dim3(svo_div_up(iterations, 4), n_lanes), dim3(256), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }
-
-int svo_kg_pnp_refine(svo_ctx* ctx, hipStream_t st, const SvoPnpRefLanes& lanes, int n_lanes) {
-  SvoProfScope prof(ctx, SVO_PROF_PNP_REFINE, st);
-  hipLaunchKernelGGL(pnp_refine_group_kernel, dim3(1, n_lanes), dim3(256), 0, st, lanes);
-  SVO_HIP_CHECK(ctx, hipGetLastError());
-  return SVO_OK;
-}
+int svo_kg_pnp_workgroups(int iterations) { return svo_div_up(iterations, 4); }

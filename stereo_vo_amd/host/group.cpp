@@ -72,10 +72,10 @@ void quat_from_R(const float* m, float* q /*wxyz*/) {
   }
 }
 
-enum LaneState { L_IDLE = 0, L_TRACK_WAIT, L_NEED_SOLVE, L_PNP_HYP_WAIT, L_PNP_REF_WAIT, L_TRI_WAIT, L_DONE };
+enum LaneState { L_IDLE = 0, L_TRACK_WAIT, L_NEED_SOLVE, L_PNP_WAIT, L_TRI_WAIT, L_DONE };
 enum BaState { BA_NONE = 0, BA_ASSEMBLING, BA_READY, BA_INFLIGHT, BA_HOST_SOLVING, BA_HOST_DONE };
-enum Word { W_TRACK = 0, W_HYP, W_REF, W_TRI, W_COUNT };
-enum Counter { C_LK = 0, C_HYP, C_TRI, C_COUNT };
+enum Word { W_TRACK = 0, W_PNP, W_TRI, W_COUNT };
+enum Counter { C_LK = 0, C_PNP, C_TRI, C_COUNT };
 
 struct Lane {
   int lk_line = 0, chain_line = 0;  // the tracking / keyframe-chain line (stream) its launch in flight went to
@@ -91,15 +91,16 @@ struct Lane {
   const uint8_t* last_l0 = nullptr;  // level 0 of last_pyr: inside it, or (within the batch that produced it) the caller's image read in place
   uint8_t* d_own_pyr = nullptr;      // the lane's private clone of its last image's pyramid, used when a whole batch went by without tracking (see process_batch)
   // ---- PnP
-  float* d_xyz = nullptr; double* d_hyp_pose = nullptr; int* d_hyp_count = nullptr; unsigned long long* d_hyp_mask = nullptr;
+  float4* d_store = nullptr; unsigned store_mask = 0;  // device-resident landmark store of the lane, keyed by feature id (get_world_points, src/bundle_adjuster.cpp:159-163)
+  double* d_hyp_pose = nullptr; int* d_hyp_count = nullptr; unsigned long long* d_hyp_mask = nullptr;
   double* d_out = nullptr; int* d_nin = nullptr; int* d_inl = nullptr; float* d_trk_xy = nullptr;
-  float* h_xyz = nullptr; int* h_count = nullptr; double* h_out = nullptr; int* h_nin = nullptr; int* h_inl = nullptr;
+  int* h_best = nullptr; int* h_bad = nullptr; double* h_out = nullptr; int* h_nin = nullptr; int* h_inl = nullptr;
   // ---- dedup / sparse stereo / triangulation
   float* d_disp = nullptr;
   int* h_tri_cnt = nullptr; float* h_tri_xy = nullptr; float* h_tri_xyz = nullptr;
   // ---- hand-over words and arrival counters
   int* words = nullptr;             // pinned, W_COUNT words 64 bytes apart
-  int seq[W_COUNT] = {0, 0, 0, 0};
+  int seq[W_COUNT] = {};
   unsigned* d_arrive = nullptr;     // device, C_COUNT counters 64 bytes apart (monotone)
   unsigned arrive_total[C_COUNT] = {0, 0, 0};
   // ---- graph + solve (BundleAdjuster)
@@ -402,7 +403,15 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     if (!rc) rc = dev_alloc(g, &l->d_fwd, 2 * mf);
     if (!rc) rc = dev_alloc(g, &l->d_par, mf);
     if (!rc) rc = dev_alloc(g, &l->d_keep, mf);
-    if (!rc) rc = dev_alloc(g, &l->d_xyz, 3 * mf);
+    {
+      // ids advance by at most max_features per keyframe: room for 256 keyframes of survival, power of two; an entry found
+      // under another id is reported by the PnP launch (never used silently)
+      size_t cap = 1;
+      while (cap < 256 * mf) cap <<= 1;
+      l->store_mask = (unsigned)(cap - 1);
+      if (!rc) rc = dev_alloc(g, &l->d_store, cap);
+      if (!rc) chk(hipMemset(l->d_store, 0xFF, sizeof(float4) * cap), "hipMemset");
+    }
     if (!rc) rc = dev_alloc(g, &l->d_hyp_pose, 7 * (size_t)g->pnp_iterations);
     if (!rc) rc = dev_alloc(g, &l->d_hyp_count, (size_t)g->pnp_iterations);
     if (!rc) rc = dev_alloc(g, &l->d_hyp_mask, (size_t)g->pnp_iterations * words);
@@ -420,7 +429,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 127) & ~(size_t)127; return o; };
     const size_t o_xy0 = take(f2), o_xy1 = take(f2), o_id0 = take(i8), o_id1 = take(i8), o_kxy = take(f2), o_kid = take(i8), o_n = take(64),
-                 o_xyz = take(sizeof(float) * 3 * mf), o_cnt = take(sizeof(int) * (size_t)g->pnp_iterations), o_out = take(64), o_nin = take(64),
+                 o_cnt = take(64), o_out = take(64), o_nin = take(64),
                  o_inl = take(sizeof(int) * mf), o_tc = take(64), o_txy = take(sizeof(float) * 2 * mc), o_txyz = take(sizeof(float) * 3 * mc),
                  o_words = take(64 * W_COUNT);
     void* hp = nullptr;
@@ -432,7 +441,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     l->h_xy[0] = (float*)(h + o_xy0); l->h_xy[1] = (float*)(h + o_xy1); l->h_ids[0] = (long long*)(h + o_id0); l->h_ids[1] = (long long*)(h + o_id1);
     l->h_kf_xy = (float*)(h + o_kxy); l->h_kf_ids = (long long*)(h + o_kid);
     l->h_n = (int*)(h + o_n); l->h_av = (float*)(h + o_n + 16);
-    l->h_xyz = (float*)(h + o_xyz); l->h_count = (int*)(h + o_cnt); l->h_out = (double*)(h + o_out); l->h_nin = (int*)(h + o_nin);
+    l->h_best = (int*)(h + o_cnt); l->h_bad = (int*)(h + o_cnt) + 1; l->h_out = (double*)(h + o_out); l->h_nin = (int*)(h + o_nin);
     l->h_inl = (int*)(h + o_inl); l->h_tri_cnt = (int*)(h + o_tc); l->h_tri_xy = (float*)(h + o_txy); l->h_tri_xyz = (float*)(h + o_txyz);
     l->words = (int*)(h + o_words);
     svo_ba_options opt;
@@ -442,6 +451,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     opt.max_time_s = p->ba_max_time_s;        // src/bundle_adjuster.cpp:11
     const int max_obs = (p->window_size + 1) * p->max_features + 64;
     rc = svo_ba_create(ctx, &l->ba, p->window_size, &p->cam, &opt, max_obs, max_obs);
+    if (!rc) rc = svo_ba_attach_store(l->ba, l->d_store, l->store_mask);
   }
   if (rc) { svo_pipeline_group_destroy(g); return rc; }
   {
@@ -579,7 +589,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   }
 
   // per-pass submission lists
-  std::vector<int> q_track, q_hyp, q_ref, q_tri, q_ba;
+  std::vector<int> q_track, q_pnp, q_tri, q_ba;
   int error = SVO_OK;
   const int MODEL = svo_pnp_model_points();
   // SVO_GROUP_TRACE=1: (microseconds, lane, event) of this call on stderr — where a lane's time goes
@@ -673,15 +683,9 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     const int m = l->n;
     l->m_tracked = m;
     l->num_inliers = 0; l->best = -1;
-    if (m > 0) {
-      l->ids64.assign(l->h_ids[l->cur], l->h_ids[l->cur] + m);
-      std::vector<int64_t> id64(l->ids64.begin(), l->ids64.end());
-      const auto tg0 = std::chrono::steady_clock::now();
-      const int rc2 = svo_ba_get_points(l->ba, id64.data(), m, l->h_xyz);  // :72 get_world_points
-      if (g->timing) g->t_get_points += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - tg0).count();
-      if (rc2) return rc2;
-    }
-    if (m >= MODEL) { q_hyp.push_back(li); l->queued = true; l->state = L_PNP_HYP_WAIT; }
+    // :72 get_world_points: nothing to do on the host — the PnP launch reads the tracked features' world points from the lane's
+    // device-resident landmark store, which the (joined) solve of the previous keyframe has written
+    if (m >= MODEL) { q_pnp.push_back(li); l->queued = true; l->state = L_PNP_WAIT; }
     else after_pnp(li);
     return SVO_OK;
   };
@@ -758,39 +762,30 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             }
             break;
           }
-          case L_PNP_HYP_WAIT:
-            if (!l->queued && word_ready(l, W_HYP)) {
-              EV(li, "hyp_done", l->frame);
-              // RANSAC bookkeeping (csrc/pnp.hip svo_k_pnp): hypotheses consumed in order with OpenCV's adaptive cap
-              int best = -1, best_cnt = 0, niters = g->pnp_iterations;
-              for (int h = 0; h < niters; ++h) {
-                if (l->h_count[h] > std::max(best_cnt, MODEL - 1)) {
-                  best = h; best_cnt = l->h_count[h];
-                  niters = svo_pnp_update_num_iters(svo_ref::PNP_CONFIDENCE, (double)(l->m_tracked - best_cnt) / l->m_tracked, MODEL, niters);
+          case L_PNP_WAIT:
+            if (!l->queued && word_ready(l, W_PNP)) {
+              EV(li, "pnp_done", l->frame);
+              progressed = true;
+              if (*l->h_bad) {
+                ctx->err = "pipeline group: a tracked feature's entry of the landmark store belongs to another id (store capacity exceeded?)";
+                error = SVO_ERR_CAPACITY;
+                break;
+              }
+              l->best = *l->h_best;  // the launch's own RANSAC bookkeeping (csrc/pnp.hip pnp_group_kernel); < 0: no model
+              if (l->best >= 0) {
+                double q[4] = {l->h_out[0], l->h_out[1], l->h_out[2], l->h_out[3]};
+                if (q[0] < 0) for (double& v : q) v = -v;
+                const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                double rv[3];
+                if (vn < 1e-12) { rv[0] = 2 * q[1]; rv[1] = 2 * q[2]; rv[2] = 2 * q[3]; }
+                else {
+                  const double th = 2.0 * atan2(vn, q[0]);
+                  rv[0] = q[1] / vn * th; rv[1] = q[2] / vn * th; rv[2] = q[3] / vn * th;
                 }
+                for (int k = 0; k < 3; ++k) { l->rvec[k] = (float)rv[k]; l->tvec[k] = (float)l->h_out[4 + k]; }
+                l->num_inliers = *l->h_nin;
               }
-              l->best = best;
-              progressed = true;
-              if (best < 0) after_pnp(li);
-              else { q_ref.push_back(li); l->queued = true; l->state = L_PNP_REF_WAIT; }
-            }
-            break;
-          case L_PNP_REF_WAIT:
-            if (!l->queued && word_ready(l, W_REF)) {
-              EV(li, "ref_done", l->frame);
-              double q[4] = {l->h_out[0], l->h_out[1], l->h_out[2], l->h_out[3]};
-              if (q[0] < 0) for (double& v : q) v = -v;
-              const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-              double rv[3];
-              if (vn < 1e-12) { rv[0] = 2 * q[1]; rv[1] = 2 * q[2]; rv[2] = 2 * q[3]; }
-              else {
-                const double th = 2.0 * atan2(vn, q[0]);
-                rv[0] = q[1] / vn * th; rv[1] = q[2] / vn * th; rv[2] = q[3] / vn * th;
-              }
-              for (int k = 0; k < 3; ++k) { l->rvec[k] = (float)rv[k]; l->tvec[k] = (float)l->h_out[4 + k]; }
-              l->num_inliers = *l->h_nin;
               after_pnp(li);
-              progressed = true;
             }
             break;
           case L_TRI_WAIT:
@@ -827,7 +822,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       if (l->state != L_DONE) { mean_frame += l->frame; ++n_running; }
       if (l->queued) continue;
       lk_busy[l->lk_line] |= l->state == L_TRACK_WAIT;
-      chain_busy[l->chain_line] |= l->state == L_PNP_HYP_WAIT || l->state == L_PNP_REF_WAIT || l->state == L_TRI_WAIT;
+      chain_busy[l->chain_line] |= l->state == L_PNP_WAIT || l->state == L_TRI_WAIT;
     }
     mean_frame = n_running ? mean_frame / n_running : 0.0;
     auto laggard = [&](int li) { return g->express && n_running > 2 && (double)g->lanes[li]->frame + 1.0 < mean_frame; };
@@ -888,19 +883,19 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       const int line = pass < 0 ? XL : pass;
       if (chain_busy[line]) continue;
       hipStream_t stc = g->st_chain[line];
-      const std::vector<int> h_now = take_line(q_hyp, line, g->n_chain), r_now = take_line(q_ref, line, g->n_chain), t_now = take_line(q_tri, line, g->n_chain);
+      const std::vector<int> h_now = take_line(q_pnp, line, g->n_chain), t_now = take_line(q_tri, line, g->n_chain);
       for (int li : h_now) g->lanes[li]->chain_line = line;
-      for (int li : r_now) g->lanes[li]->chain_line = line;
       for (int li : t_now) g->lanes[li]->chain_line = line;
     if (!h_now.empty()) {
-      SvoPnpHypLanes a;
+      SvoPnpLanes a;
+      const int wgs = svo_kg_pnp_workgroups(g->pnp_iterations);
       int k = 0;
       for (int li : h_now) {
         Lane* l = g->lanes[li];
         const int m = l->m_tracked;
-        SvoPnpHypLane& x = a.lane[k++];
-        x.xyz = l->d_xyz; x.xy = l->d_xy[l->cur]; x.n = m;
-        x.host_xyz = l->h_xyz;  // uploaded by the launch itself (one small kernel for all its lanes: svo_kg_pnp_hypotheses)
+        SvoPnpLane& x = a.lane[k++];
+        x.ids = l->d_ids[l->cur]; x.store = l->d_store; x.store_mask = l->store_mask;
+        x.xy = l->d_xy[l->cur]; x.n = m;
         x.f = (double)g->K[0]; x.cx = (double)g->K[2]; x.cy = (double)g->K[5];
         // rvec/tvec are CV_32F in/out, the solver works in double (host/pipeline.cpp; csrc/pnp.hip svo_k_pnp)
         const double rv[3] = {l->rvec[0], l->rvec[1], l->rvec[2]};
@@ -912,34 +907,17 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         }
         for (int c = 0; c < 3; ++c) x.t0[c] = (double)l->tvec[c];
         x.thr2 = (double)svo_ref::PNP_REPROJ_ERROR * (double)svo_ref::PNP_REPROJ_ERROR;
+        x.confidence = svo_ref::PNP_CONFIDENCE; x.iterations = g->pnp_iterations;
         x.hyp_pose = l->d_hyp_pose; x.hyp_count = l->d_hyp_count; x.hyp_mask = l->d_hyp_mask; x.mask_words = svo_div_up(m, 64);
-        x.host_count = l->h_count;
-        x.pub = make_pub(l, W_HYP, C_HYP, g->pnp_iterations);
+        x.out_pose = l->d_out; x.inliers = l->d_inl; x.n_inliers = l->d_nin; x.inlier_xy = l->d_trk_xy;
+        x.host_pose = l->h_out; x.host_inliers = l->h_inl; x.host_nin = l->h_nin; x.host_best = l->h_best; x.host_bad = l->h_bad;
+        const SvoPublish pb = make_pub(l, W_PNP, C_PNP, wgs);
+        x.arrive = pb.arrive; x.arrive_target = pb.target; x.word = pb.word; x.seq = pb.seq;
         l->queued = false;
       }
-      if (error) break;
-      if ((error = svo_kg_pnp_hypotheses(ctx, stc, a, k, g->pnp_iterations))) break;
-      for (int li : h_now) EV(li, "hyp_launch", k);
+      if ((error = svo_kg_pnp(ctx, stc, a, k, g->pnp_iterations))) break;
+      for (int li : h_now) EV(li, "pnp_launch", k);
       g->launches[1]++; g->lanes_carried[1] += k;
-      progressed = true;
-    }
-    if (!r_now.empty()) {
-      SvoPnpRefLanes a;
-      int k = 0;
-      for (int li : r_now) {
-        Lane* l = g->lanes[li];
-        SvoPnpRefLane& x = a.lane[k++];
-        x.xyz = l->d_xyz; x.xy = l->d_xy[l->cur]; x.n = l->m_tracked;
-        x.f = (double)g->K[0]; x.cx = (double)g->K[2]; x.cy = (double)g->K[5];
-        x.hyp_pose = l->d_hyp_pose; x.hyp_mask = l->d_hyp_mask; x.mask_words = svo_div_up(l->m_tracked, 64); x.best = l->best;
-        x.out_pose = l->d_out; x.inliers = l->d_inl; x.n_inliers = l->d_nin; x.host_pose = l->h_out; x.host_inliers = l->h_inl; x.host_nin = l->h_nin;
-        x.inlier_xy = l->d_trk_xy;
-        x.pub = make_pub(l, W_REF, -1, 1);
-        l->queued = false;
-      }
-      if ((error = svo_kg_pnp_refine(ctx, stc, a, k))) break;
-      for (int li : r_now) EV(li, "ref_launch", k);
-      g->launches[2]++; g->lanes_carried[2] += k;
       progressed = true;
     }
     if (!t_now.empty()) {

@@ -186,6 +186,16 @@ def pnp_ransac(xyz, xy, focal, cx, cy, rvec, tvec, iterations=100, reproj_err=8.
     return rv, tv, inl[:m].copy()
 
 
+def pnp_update_num_iters(p, ep, model_points, max_iters):
+    return int(oracle().ora_pnp_update_num_iters(C.c_double(p), C.c_double(ep), int(model_points), int(max_iters)))
+
+
+def pnp_det_log(x):
+    f = oracle().ora_pnp_det_log
+    f.restype = C.c_double
+    return float(f(C.c_double(x)))
+
+
 def ba_solve(poses7, points3, obs_pose, obs_point, obs_uv, focal, cx, cy, max_iterations=50,
              function_tol=1e-6, gradient_tol=1e-10, parameter_tol=1e-8, initial_radius=1e4,
              num_threads=1, allreduce=None):

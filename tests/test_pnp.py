@@ -43,6 +43,31 @@ def test_oracle_degenerate_inputs():
     assert len(inl) < 12
 
 
+def test_iteration_cap_with_declared_arithmetic_equals_the_libm_formula():
+    """RANSACUpdateNumIters with the declared logarithm / power (so that the kernels can take the cut-off themselves, bit for
+    bit) against the libm formula OpenCV uses: the logarithm within 5e-16 relative, the cap identical for every inlier count
+    of every set size the pipelines see."""
+    import math
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([rng.uniform(1e-300, 1.0, 2000), 10.0 ** rng.uniform(-300, 0, 2000), [1.0, 0.5, 0.01, 2.2250738585072014e-308]])
+    for x in xs:
+        assert abs(O.pnp_det_log(float(x)) - math.log(x)) <= 5e-16 * abs(math.log(x)) + 1e-300
+
+    def libm_cap(p, ep, k, mx):
+        p = min(max(p, 0.0), 1.0); ep = min(max(ep, 0.0), 1.0)
+        num = max(1.0 - p, 2.2250738585072014e-308)
+        den = 1.0 - (1.0 - ep) ** k
+        if den < 2.2250738585072014e-308:
+            return 0
+        num, den = math.log(num), math.log(den)
+        return mx if den >= 0 or -num >= mx * (-den) else int(round(num / den))  # Python rounds half to even, like lrint
+    for n in (5, 7, 64, 300, 731, 1500, 3000):
+        for cnt in range(5, n + 1, max(1, n // 97)):
+            for mx in (100, 37, 3):
+                assert O.pnp_update_num_iters(0.99, (n - cnt) / n, 5, mx) == libm_cap(0.99, (n - cnt) / n, 5, mx), (n, cnt, mx)
+    assert O.pnp_update_num_iters(0.99, 0.0, 5, 100) == 0 and O.pnp_update_num_iters(0.99, 1.0, 5, 100) == 100
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,n,of", [(1, 300, 0.2), (4, 1500, 0.35), (5, 64, 0.0), (6, 7, 0.1), (7, 2000, 0.6)])
 def test_hip_pnp_bit_exact(ctx, seed, n, of):
