@@ -1,15 +1,17 @@
 // a5 — cv::solvePnPRansac(obj, img, K, 0, rvec, tvec, true, 100, 8.0, 0.99, inliers), reference call site
 // src/image_processor.cpp:76-80.  OpenCV's sample sequence / EPnP are version specific;
 // the deterministic RANSAC implemented here is the one DEFINED in oracle/ora_pnp.cpp and DESIGN.md §PnP:
-//   pnp_hypotheses_kernel : one wavefront per hypothesis (all `iterations` hypotheses in one launch).
-//       splitmix64 sampling of 5 distinct points, LM minimal solve from the extrinsic guess with a
-//       trig-free quaternion retraction, then every lane tests its share of the n points and the inlier
-//       set is emitted as a 64-bit ballot mask per 64 points.  The 5-term normal-equation sums are
-//       evaluated entry-per-lane in the oracle's k = 0..4 order => bit-identical to the CPU.
-//   (host)                : consumes the counts in order h = 0,1,.. with OpenCV's adaptive iteration cap.
-//   pnp_refine_kernel     : LM over the best model's inliers; reductions use the declared order
-//       "per-thread strided partials (stride 256), then binary tree" so the refined pose is bit-identical
-//       to the oracle as well.
+//   pnp_ransac_kernel / pnp_group_kernel : ONE launch per solvePnPRansac call.
+//       hypotheses  — one wavefront per hypothesis, four per workgroup (all `iterations` hypotheses in the launch): splitmix64
+//                     sampling of 5 distinct points, LM minimal solve from the extrinsic guess with a trig-free quaternion
+//                     retraction, then every lane tests its share of the n points and the inlier set is emitted as a 64-bit
+//                     ballot mask per 64 points.  The 5-term normal-equation sums are evaluated entry-per-lane in the
+//                     oracle's k = 0..4 order => bit-identical to the CPU.
+//       bookkeeping — by the last workgroup to arrive: the counts consumed in order h = 0,1,.. with OpenCV's adaptive
+//                     iteration cap (RANSACUpdateNumIters, declared arithmetic: host/pnp_iters.h).
+//       refinement  — by the same workgroup: LM over the best model's inliers; reductions use the declared order "per-thread
+//                     strided partials (stride 256), then binary tree" so the refined pose is bit-identical to the oracle.
+//   (Rounds 1-3: two launches with the bookkeeping on the host between them.)
 #include <math.h>
 
 #include <algorithm>
@@ -397,55 +399,27 @@ __device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __r
   svo_publish_block(pub);
 }
 
-__global__ __launch_bounds__(64) void pnp_hypotheses_kernel(const float* __restrict__ xyz, const float* __restrict__ xy,
-                                                            int n, double f, double cx, double cy, PnpPose P0,
-                                                            double thr2, double* __restrict__ hyp_pose,
-                                                            int* __restrict__ hyp_count,
-                                                            unsigned long long* __restrict__ hyp_mask, int mask_words,
-                                                            int* __restrict__ host_count, SvoPublish pub) {
+// ---- the WHOLE solvePnPRansac of a stream as one launch.  Every workgroup runs four hypotheses (one per wavefront, wave-level
+// hand-overs); the LAST workgroup of the stream to arrive does OpenCV's bookkeeping (hypotheses consumed in order, strictly
+// more inliers replaces the best, RANSACUpdateNumIters with the declared arithmetic of host/pnp_iters.h) and refines the
+// winner — the operations of oracle/ora_pnp.cpp in its order, hence the same bits (tests/test_pnp.py, tests/test_group.py).
+// One launch and one completion word per keyframe where round 3 had a world-point upload kernel (group), two launches and a
+// host round trip between them.  Src: where the world points come from (XyzArray / XyzStore above).
+template <typename Src>
+__device__ __forceinline__ void pnp_fused_body(const SvoPnpLane& a, const Src& src) {
   svo_latency_critical();
-  __shared__ HypLds L;
-  pnp_hypothesis_wave<XyzArray, false>(XyzArray{xyz}, xy, n, f, cx, cy, P0, thr2, blockIdx.x, L, hyp_pose, hyp_count, hyp_mask, mask_words, host_count);
-  svo_publish_block_wt(pub);  // the only host payload is host_count (written through above): no write-back per workgroup
-}
-
-__global__ __launch_bounds__(256) void pnp_refine_kernel(const float* __restrict__ xyz, const float* __restrict__ xy, int n,
-                                                         double f, double cx, double cy, const double* __restrict__ hyp_pose,
-                                                         const unsigned long long* __restrict__ hyp_mask, int mask_words,
-                                                         int best, double* __restrict__ out_pose, int* __restrict__ inliers,
-                                                         int* __restrict__ n_inliers, double* __restrict__ host_pose,
-                                                         int* __restrict__ host_inliers, int* __restrict__ host_nin,
-                                                         float* __restrict__ inlier_xy, SvoPublish pub) {
-  __shared__ LmShared S;
-  __shared__ double sPart[256][28];
-  __shared__ int sBase;
-  pnp_refine_body<XyzArray, false>(XyzArray{xyz}, xy, n, f, cx, cy, hyp_pose, hyp_mask, mask_words, best, out_pose, inliers, n_inliers, host_pose,
-                                   host_inliers, host_nin, inlier_xy, pub, S, sPart, &sBase);
-}
-
-// ---- stream-batched form (group_kernels.h): the WHOLE solvePnPRansac of a lane as one launch.  blockIdx.y = lane; every
-// workgroup runs four hypotheses (one per wavefront, wave-level hand-overs) with the world points read from the lane's
-// device-resident landmark store; the LAST workgroup of the lane to arrive does OpenCV's bookkeeping (hypotheses consumed in
-// order, strictly more inliers replaces the best, RANSACUpdateNumIters with the declared arithmetic of host/pnp_iters.h) and
-// refines the winner — the same bodies, the same operations in the same order as the two single-stream kernels and the host
-// loop between them, hence the same bits (tests/test_group.py).  One launch and one completion word per keyframe where
-// round 3 had a world-point upload kernel, two launches and a host round trip between them.
-__global__ __launch_bounds__(256) void pnp_group_kernel(SvoPnpLanes g) {
-  svo_latency_critical();
-  const SvoPnpLane& a = g.lane[blockIdx.y];
   __shared__ double sPart[256][28];  // first the four hypotheses' LDS, then the refinement's partial sums
   __shared__ LmShared S;
   __shared__ int sBase, sLast, sBest;
   static_assert(4 * sizeof(HypLds) <= sizeof(double) * 256 * 28, "the hypotheses' LDS must fit the refinement's");
   const int tid = threadIdx.x, wave = tid >> 6;
-  const XyzStore src{a.ids, a.store, a.store_mask, a.host_bad};
   const int h = blockIdx.x * 4 + wave;
   if (h < a.iterations) {
     PnpPose P0;
     for (int k = 0; k < 4; ++k) P0.q[k] = a.q0[k];
     for (int k = 0; k < 3; ++k) P0.t[k] = a.t0[k];
     HypLds& L = reinterpret_cast<HypLds*>(&sPart[0][0])[wave];
-    pnp_hypothesis_wave<XyzStore, true>(src, a.xy, a.n, a.f, a.cx, a.cy, P0, a.thr2, h, L, a.hyp_pose, a.hyp_count, a.hyp_mask, a.mask_words, nullptr);
+    pnp_hypothesis_wave<Src, true>(src, a.xy, a.n, a.f, a.cx, a.cy, P0, a.thr2, h, L, a.hyp_pose, a.hyp_count, a.hyp_mask, a.mask_words, nullptr);
   }
   if (!svo_last_arrival(a.arrive, a.arrive_target, &sLast)) return;
   if (tid == 0) {
@@ -466,8 +440,17 @@ __global__ __launch_bounds__(256) void pnp_group_kernel(SvoPnpLanes g) {
   SvoPublish pub;
   pub.word = a.word; pub.seq = a.seq;
   if (best < 0) { svo_publish_block(pub); return; }
-  pnp_refine_body<XyzStore, true>(src, a.xy, a.n, a.f, a.cx, a.cy, a.hyp_pose, a.hyp_mask, a.mask_words, best, a.out_pose, a.inliers, a.n_inliers,
-                                  a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, pub, S, sPart, &sBase);
+  pnp_refine_body<Src, true>(src, a.xy, a.n, a.f, a.cx, a.cy, a.hyp_pose, a.hyp_mask, a.mask_words, best, a.out_pose, a.inliers, a.n_inliers,
+                             a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, pub, S, sPart, &sBase);
+}
+
+// single stream: the world points as a float3 array in feature order (gathered by the host: get_world_points)
+__global__ __launch_bounds__(256) void pnp_ransac_kernel(SvoPnpLane a, const float* __restrict__ xyz) { pnp_fused_body(a, XyzArray{xyz}); }
+
+// stream-batched form (group_kernels.h): blockIdx.y = lane, world points from the lane's device-resident landmark store
+__global__ __launch_bounds__(256) void pnp_group_kernel(SvoPnpLanes g) {
+  const SvoPnpLane& a = g.lane[blockIdx.y];
+  pnp_fused_body(a, XyzStore{a.ids, a.store, a.store_mask, a.host_bad});
 }
 
 // ----------------------------------------------------------------------------- host side
@@ -500,39 +483,32 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   int* d_nin = s.take<int>(1);
   if (!d_pose || !d_count || !d_mask || !d_out || !d_nin) { ctx->err = "pnp: workspace too small"; return SVO_ERR_CAPACITY; }
   hipStream_t st = ctx->stream;
-  const double thr2 = (double)reproj_err * (double)reproj_err;
-  // both kernels write what the host needs straight into pinned memory and publish a completion word:
-  // no D2H blits, no stream waits
-  int* h_count = (int*)ctx->h_pinned;
-  if ((size_t)iterations * sizeof(int) + 64 > 4096) { ctx->err = "pnp: too many iterations"; return SVO_ERR_CAPACITY; }
-  const SvoPublish pub1 = svo_publish_next(ctx, SVO_W_PNP_HYP, iterations);
-  {
-  SvoProfScope prof(ctx, SVO_PROF_PNP_HYP);
-  hipLaunchKernelGGL(pnp_hypotheses_kernel, dim3(iterations), dim3(64), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf,
-                     (double)cyf, P0, thr2, d_pose, d_count, d_mask, words, h_count, pub1);
-  }
-  SVO_HIP_CHECK(ctx, hipGetLastError());
-  int rc = svo_wait_word(ctx, pub1);
-  if (rc) return rc;
-  int best = -1, best_cnt = 0, niters = iterations;
-  for (int h = 0; h < niters; ++h) {
-    if (h_count[h] > std::max(best_cnt, MODEL - 1)) {
-      best = h; best_cnt = h_count[h];
-      niters = update_num_iters(confidence, (double)(n - best_cnt) / n, MODEL, niters);
-    }
-  }
-  if (best < 0) return SVO_OK;
+  // ONE launch (pnp_ransac_kernel); what the host needs comes back in pinned memory behind one completion word: no D2H
+  // blits, no stream waits
   double* h_out = (double*)((char*)ctx->h_pinned + 4096);
   int* h_nin = (int*)((char*)ctx->h_pinned + 4096 + 64);
-  const SvoPublish pub2 = svo_publish_next(ctx, SVO_W_PNP_REF);
+  int* h_best = (int*)((char*)ctx->h_pinned + 4096 + 128);
+  const int wgs = svo_div_up(iterations, 4);
+  const SvoPublish pub = svo_publish_next(ctx, SVO_W_PNP_REF);   // the word the last workgroup publishes
+  const SvoPublish arr = svo_arrive_next(ctx, wgs);               // the arrival counter the workgroups meet at
+  SvoPnpLane a;
+  memset(&a, 0, sizeof(a));
+  a.xy = d_xy; a.n = n; a.f = (double)focal; a.cx = (double)cxf; a.cy = (double)cyf;
+  for (int k = 0; k < 4; ++k) a.q0[k] = P0.q[k];
+  for (int k = 0; k < 3; ++k) a.t0[k] = P0.t[k];
+  a.thr2 = (double)reproj_err * (double)reproj_err; a.confidence = confidence; a.iterations = iterations;
+  a.hyp_pose = d_pose; a.hyp_count = d_count; a.hyp_mask = d_mask; a.mask_words = words;
+  a.out_pose = d_out; a.inliers = d_inliers; a.n_inliers = d_nin; a.inlier_xy = d_inlier_xy;
+  a.host_pose = h_out; a.host_inliers = h_inliers; a.host_nin = h_nin; a.host_best = h_best; a.host_bad = nullptr;
+  a.arrive = arr.arrive; a.arrive_target = arr.target; a.word = pub.word; a.seq = pub.seq;
   {
-  SvoProfScope prof(ctx, SVO_PROF_PNP_REFINE);
-  hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, st, d_xyz, d_xy, n, (double)focal, (double)cxf, (double)cyf,
-                     d_pose, d_mask, words, best, d_out, d_inliers, d_nin, h_out, h_inliers, h_nin, d_inlier_xy, pub2);
+  SvoProfScope prof(ctx, SVO_PROF_PNP_HYP);
+  hipLaunchKernelGGL(pnp_ransac_kernel, dim3(wgs), dim3(256), 0, st, a, d_xyz);
   }
   SVO_HIP_CHECK(ctx, hipGetLastError());
-  rc = svo_wait_word(ctx, pub2);
+  int rc = svo_wait_word(ctx, pub);
   if (rc) return rc;
+  if (*h_best < 0) return SVO_OK;
   double q[4] = {h_out[0], h_out[1], h_out[2], h_out[3]};
   if (q[0] < 0) for (double& v : q) v = -v;
   const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
