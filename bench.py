@@ -501,7 +501,7 @@ def run_kitti_stream(args):
     # BASELINE configs[2] asks for ~5k live landmarks in a 10-keyframe window (~15k observations): on the synthetic
     # street that takes 2,500 corners at quality 0.005 / minDistance 8 (measured with the oracle: 7.5k landmarks, 14k observations
     # per window; configs[1]'s 1500 / 0.02 / 10 give 4.5k / 8.6k)
-    SMAXC, SQUAL, SMIND, SMAXF = 2500, 0.005, 8.0, 3000
+    SMAXC, SQUAL, SMIND, SMAXF = 2800, 0.004, 7.0, 3300
     ctx = S.Context(W, H, device=local, max_batch=B, max_corners=SMAXC, max_candidates=1 << 16, max_features=SMAXF)
     p = S.synth_default(W, H)
     p.seed += rank  # the default scene of the generator (the one tools/soak_long_stream.py and the KITTI driver test use)

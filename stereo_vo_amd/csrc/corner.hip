@@ -482,6 +482,56 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   unsigned long long* S = sorted + (size_t)b * cap;
   uint8_t* st = state_g + (size_t)b * cap;
   if (ncell > max_cells) { if (tid == 0) { atomicOr(status, 4); out_n[b] = 0; } return; }
+  // The rounds below re-read keys, states and the cell table many times; from L2 every read is a ~0.7 us
+  // round trip (measured 950 us for this kernel), so when they fit they live in LDS.
+  unsigned long long* keysL = reinterpret_cast<unsigned long long*>(lds_raw);
+  unsigned short* cellL = reinterpret_cast<unsigned short*>(lds_raw + (size_t)SEL_CAP_K * 8);  // positions <= n <= 12288
+  uint8_t* stateL = lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 2;
+  unsigned short* blkL = reinterpret_cast<unsigned short*>(lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 2 + SEL_CAP_K);
+  const bool use_lds = n <= SEL_CAP_K && ncell + 1 <= SEL_CAP_C;
+  if (use_lds) {
+    // Binning entirely in LDS (round 4): histogram, exclusive scan and scatter never touch HBM — the global form below wrote
+    // every key and state byte through to memory as a scattered partial line (475 KB per frame for a result of <= 12 KB).
+    // The per-cell counters borrow the state + blocker arrays (3 SEL_CAP_K bytes >= 4 SEL_CAP_C), which are initialised afterwards.
+    static_assert(3 * SEL_CAP_K >= 4 * SEL_CAP_C, "the cell counters must fit the state + blocker arrays");
+    int* cntL = reinterpret_cast<int*>(stateL);
+    for (int i = tid; i < ncell; i += SEL_THREADS) cntL[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      const unsigned idx = (unsigned)(C[i] & 0xffffffffu);
+      atomicAdd(&cntL[(key_y(idx) / cell) * gw + key_x(idx) / cell], 1);
+    }
+    __syncthreads();
+    {
+      const int chunk = (ncell + SEL_THREADS - 1) / SEL_THREADS;
+      const int lo = tid * chunk, hi = (lo + chunk < ncell) ? lo + chunk : ncell;
+      int s = 0;
+      for (int i = lo; i < hi; ++i) s += cntL[i];
+      sPart[tid] = s;
+      __syncthreads();
+      for (int off = 1; off < SEL_THREADS; off <<= 1) {
+        int v = tid >= off ? sPart[tid - off] : 0;
+        __syncthreads();
+        sPart[tid] += v;
+        __syncthreads();
+      }
+      int run = sPart[tid] - s;
+      for (int i = lo; i < hi; ++i) { cellL[i] = (unsigned short)run; run += cntL[i]; }
+      if (tid == 0) cellL[ncell] = (unsigned short)n;
+    }
+    __syncthreads();
+    // scatter into cell order (order inside a cell is irrelevant: every decision below uses the key)
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      const unsigned long long k = C[i];
+      const unsigned idx = (unsigned)(k & 0xffffffffu);
+      const int cid = (key_y(idx) / cell) * gw + key_x(idx) / cell;
+      const int slot = atomicSub(&cntL[cid], 1) - 1;
+      keysL[(int)cellL[cid] + slot] = k;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += SEL_THREADS) { stateL[i] = 0; blkL[i] = 0xFFFFu; }
+    __syncthreads();
+  } else {
   // (a) histogram of candidates per cell
   for (int i = tid; i < ncell; i += SEL_THREADS) st_l2(&cc[i], 0);
   __syncthreads();
@@ -521,17 +571,6 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
     st_l2(&st[pos], (uint8_t)0);
   }
   __syncthreads();
-  // The rounds below re-read keys, states and the cell table many times; from L2 every read is a ~0.7 us
-  // round trip (measured 950 us for this kernel), so when they fit they are cached in LDS first.
-  unsigned long long* keysL = reinterpret_cast<unsigned long long*>(lds_raw);
-  unsigned short* cellL = reinterpret_cast<unsigned short*>(lds_raw + (size_t)SEL_CAP_K * 8);  // positions <= n <= 12288
-  uint8_t* stateL = lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 2;
-  unsigned short* blkL = reinterpret_cast<unsigned short*>(lds_raw + (size_t)SEL_CAP_K * 8 + (size_t)SEL_CAP_C * 2 + SEL_CAP_K);
-  const bool use_lds = n <= SEL_CAP_K && ncell + 1 <= SEL_CAP_C;
-  if (use_lds) {
-    for (int i = tid; i < n; i += SEL_THREADS) { keysL[i] = ld_l2(&S[i]); stateL[i] = 0; blkL[i] = 0xFFFFu; }
-    for (int i = tid; i <= ncell; i += SEL_THREADS) cellL[i] = (unsigned short)ld_l2(&cs[i]);
-    __syncthreads();
   }
   auto KEY = [&](int i) -> unsigned long long { return use_lds ? keysL[i] : ld_l2(&S[i]); };
   auto STATE = [&](int i) -> uint8_t { return use_lds ? ((volatile uint8_t*)stateL)[i] : ld_l2(&st[i]); };
@@ -637,19 +676,44 @@ __global__ __launch_bounds__(SEL_THREADS) void corner_select_kernel(
   if (tid == 0) sCount = 0;
   __syncthreads();
   // accepted keys go through the (now idle) candidate buffer: sKeys aliases the LDS key cache
-  unsigned long long* Cw = const_cast<unsigned long long*>(C);
-  for (int i = tid; i < n; i += SEL_THREADS) {
-    if (STATE(i) == 1) {
-      const int p = atomicAdd(&sCount, 1);
-      if (p < SEL_MAX_ACCEPT) st_l2(&Cw[p], KEY(i));
+  int A, np2 = 1;
+  if (use_lds) {
+    // in LDS: every thread takes its accepted keys into registers, then the list is rebuilt at the front of the key cache
+    // (sKeys aliases it) — no trip through the candidate buffer in HBM
+    constexpr int PER = SEL_CAP_K / SEL_THREADS;
+    unsigned long long mine[PER];
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) {
+      const int i = tid + r * SEL_THREADS;
+      const bool acc = i < n && stateL[i] == 1;
+      mine[r] = acc ? keysL[i] : 0ull;
+      cnt += acc;
     }
+    __syncthreads();
+    int pos = cnt ? atomicAdd(&sCount, cnt) : 0;
+    __syncthreads();
+    A = sCount;
+    while (np2 < A) np2 <<= 1;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) if (mine[r]) sKeys[pos++] = mine[r];  // a key is never 0: its response is above the threshold
+    for (int i = A + tid; i < np2; i += SEL_THREADS) sKeys[i] = 0ull;
+    __syncthreads();
+  } else {
+    unsigned long long* Cw = const_cast<unsigned long long*>(C);
+    for (int i = tid; i < n; i += SEL_THREADS) {
+      if (STATE(i) == 1) {
+        const int p = atomicAdd(&sCount, 1);
+        if (p < SEL_MAX_ACCEPT) st_l2(&Cw[p], KEY(i));
+      }
+    }
+    __syncthreads();
+    A = sCount;
+    if (A > SEL_MAX_ACCEPT) { if (tid == 0) { atomicOr(status, 2); out_n[b] = 0; } return; }
+    while (np2 < A) np2 <<= 1;
+    for (int i = tid; i < np2; i += SEL_THREADS) sKeys[i] = i < A ? ld_l2(&Cw[i]) : 0ull;
+    __syncthreads();
   }
-  __syncthreads();
-  int A = sCount;
-  if (A > SEL_MAX_ACCEPT) { if (tid == 0) { atomicOr(status, 2); out_n[b] = 0; } return; }
-  int np2 = 1; while (np2 < A) np2 <<= 1;
-  for (int i = tid; i < np2; i += SEL_THREADS) sKeys[i] = i < A ? ld_l2(&Cw[i]) : 0ull;
-  __syncthreads();
   for (int k = 2; k <= np2; k <<= 1)
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int i = tid; i < np2; i += SEL_THREADS) {
