@@ -111,15 +111,20 @@ bool cholesky_solve(std::vector<double>& A, std::vector<double>& b, int n) {
       A[(size_t)i * n + j] = v / l;
     }
   }
+  // substitutions: the pivots' reciprocals are formed ONCE (r_i = 1 / l_ii) and every row is scaled by multiplication — on the
+  // device the 2 n divisions of the plain form were a dependent chain of ~100 cycles each (declared in round 4, together with
+  // stereo_vo_amd/host/linalg.cpp and csrc/lm_device.h)
+  std::vector<double> r(n > 0 ? n : 1);
+  for (int i = 0; i < n; ++i) r[i] = 1.0 / A[(size_t)i * n + i];
   for (int i = 0; i < n; ++i) {
     double v = b[i];
     for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
-    b[i] = v / A[(size_t)i * n + i];
+    b[i] = v * r[i];
   }
   for (int i = n - 1; i >= 0; --i) {  // inner index DESCENDING: the order a parallel column sweep produces
     double v = b[i];
     for (int k = n - 1; k > i; --k) v -= A[(size_t)k * n + i] * b[k];
-    b[i] = v / A[(size_t)i * n + i];
+    b[i] = v * r[i];
   }
   return true;
 }

@@ -580,6 +580,33 @@ __device__ __forceinline__ void schur_owners(const ChunkTab& T, const double* re
 #pragma unroll
     for (int j = 0; j < WIDTH; ++j) acc[j] = 0.0;
     const int e0 = T.bstart(qb), e1 = T.bstart(qb + 1);
+    if (WIDTH == 1) {
+      // One element per owner: the chunks that get here touch one or two blocks with LONG lists (64 brand-new landmarks = one
+      // block of 64 entries) and were the slowest chunks of every pass — everybody waits for them.  Four entries' rows are in
+      // flight at once (entry -> rows is a dependent LDS chain), the additions stay in list order.  A transposed entry is the same
+      // expression with the roles of (a, b) swapped: element (a, b) of B^T is  sum_c Y_i[b][c] (W_t s)[a][c]  — same products, same
+      // order of the three-term sum, no branch.
+      for (int e = e0; e < e1; e += 4) {
+        int en[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) en[u] = T.ent(min(e + u, e1 - 1));
+        double y[4][3], w[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double* ri = rec + (en[u] & 63) * REC_STRIDE;
+          const double* rt = rec + ((en[u] >> 8) & 63) * REC_STRIDE;
+          const bool tr = (en[u] & 0x80) != 0;
+          const int ra = tr ? b0 : a, rb = tr ? a : b0;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { y[u][c] = ri[18 + 3 * ra + c]; w[u][c] = rt[3 * rb + c]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e + u < e1) acc[0] += -(y[u][0] * w[u][0] + y[u][1] * w[u][1] + y[u][2] * w[u][2]);
+      }
+      emit1(sink, 36 * qb + 6 * a + b0, acc[0]);
+      continue;
+    }
     int en_next = e0 < e1 ? T.ent(e0) : 0;  // the next entry is fetched one iteration ahead: entry -> rows is a dependent LDS chain
     for (int e = e0; e < e1; ++e) {
       const int en = en_next;
@@ -680,7 +707,7 @@ __device__ __forceinline__ void suffix_math(const BaDev& P, const ObsRec& R, con
 //   owners — 36 KB of LDS instead of 49, but the turns and their ten barriers took pass A from 10 to 22 us.)
 //   rec: 64 x REC_STRIDE (spare columns: the chunk's landmark scalars), sink.pst: E or null, s_ne: 4 ints — LDS of the owner set.
 template <bool WG>
-__device__ __forceinline__ void chunk_owner_phases(const ObsRec& R, const ChunkTab& T, const SufRegs& o, double* rec, const PartSink& sink, int* s_ne) {
+__device__ __forceinline__ void chunk_owner_phases(const ObsRec& R, const ChunkTab& T, const SufRegs& o, double* rec, const PartSink& sink, int* s_ne, long long* t_schur = nullptr) {
   const int lane = threadIdx.x & 63;
   const int tid = WG ? (int)threadIdx.x : lane, nt = WG ? (int)blockDim.x : 64;
   const bool mine = WG ? (threadIdx.x >> 6) == 0 : true;
@@ -713,6 +740,7 @@ __device__ __forceinline__ void chunk_owner_phases(const ObsRec& R, const ChunkT
     schur_owners<6>(T, rec, sink, 0ull, nU, tid, nt);
   }
   sync();
+  if (t_schur && threadIdx.x == 0) *t_schur += (long long)wall_clock64();  // (diagnostics: the caller subtracts its own stamp)
   // ---- per-pose values: the rows now carry the 33 values of every free observation
   if (mine && o.freep) {
     double* row = rec + lane * REC_STRIDE;
@@ -1300,7 +1328,7 @@ struct LmDevArgs {
 };
 enum { LMC_ARRIVE = 0, LMC_WORDS = 16 };
 enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
-       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED, LMR_C_ARRIVE, LMR_TP0, LMR_DOUBLES = LMR_TP0 + 12 };
+       LMR_T_WAIT, LMR_T_CTL, LMR_T_BODY, LMR_T_TOTAL, LMR_SAME_SWEEP, LMR_NEXT_USED, LMR_C_ARRIVE, LMR_TP0, LMR_DOUBLES = LMR_TP0 + 14 };
 enum { LMS_START = 0, LMS_FIRST, LMS_RELIN, LMS_STEP, LMS_ACCEPT_RELIN, LMS_DELIVER };
 enum { LMOP_EXIT = 0, LMOP_LINEARIZE, LMOP_ITERATE, LMOP_DELIVER, LMOP_ABORT };
 
@@ -1315,7 +1343,7 @@ struct LmDevState {
   unsigned long long tag;   // of the command in flight: bit 62 | (solve sequence << 20) | command number
   unsigned op_count;
   long long t0, t_wait, t_ctl, t_body, t_mark;  // 100 MHz ticks: collecting the totals, step control, passes
-  long long tp[12];  // finer split (workgroup 0): pass B, radius-free part of pass A, collecting payload2, rest of pass A, own slice of level 2 (incl. waiting for the partials), -, collecting the totals, system build, Cholesky, step tail
+  long long tp[14];  // (slot 11: the controller's running mark; 10, 12: see lm_iterate) finer split (workgroup 0): pass B, radius-free part of pass A, collecting payload2, rest of pass A, own slice of level 2 (incl. waiting for the partials), -, collecting the totals, system build, Cholesky, step tail
 };
 constexpr double LM_MIN_RADIUS = 1e-32, LM_MAX_RADIUS = 1e16;
 
@@ -1447,7 +1475,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
       cs.arrive_total = a.base_arrive;
       cs.lin_calls = 1; cs.step_calls = 0; cs.same_sweeps = 0; cs.next_used = 0; cs.bad = 0; cs.op_count = 0; cs.tag = 0;
       cs.t_wait = cs.t_ctl = cs.t_body = 0;
-      for (int i = 0; i < 12; ++i) cs.tp[i] = 0;
+      for (int i = 0; i < 14; ++i) cs.tp[i] = 0;
       cs.state = LMS_FIRST; cs.first = 1;
     }
     __syncthreads();
@@ -1605,7 +1633,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
           pay_store(&r[LMR_T_BODY], (double)cs.t_body); pay_store(&r[LMR_T_TOTAL], (double)(tn - cs.t0));
           pay_store(&r[LMR_SAME_SWEEP], (double)cs.same_sweeps); pay_store(&r[LMR_NEXT_USED], (double)cs.next_used);
           pay_store(&r[LMR_C_ARRIVE], (double)(cs.arrive_total + (unsigned)grid));  // + the delivery's arrivals
-          for (int i = 0; i < 12; ++i) pay_store(&r[LMR_TP0 + i], (double)cs.tp[i]);
+          for (int i = 0; i < 14; ++i) pay_store(&r[LMR_TP0 + i], (double)cs.tp[i]);
         }
         for (int i = tid; i < 7 * K; i += nt) pay_store(&a.host_result[LMR_DOUBLES + i], cPose[i]);
       }
@@ -1706,11 +1734,11 @@ struct LmWave { ObsRec R; ChunkRegs c; D3 cand; };
 struct LmShared { double sOut[4]; double sDec[2]; int sGo; };
 
 // The owner phases of this wavefront's chunk, in its own LDS (chunk_owner_phases<false>).
-__device__ __forceinline__ void lm_owner_phases(const BaDev& P, const LmWave& W, bool my_wave_works, const SufRegs& o, const uint16_t* tabs, const WgLds& L) {
+__device__ __forceinline__ void lm_owner_phases(const BaDev& P, const LmWave& W, bool my_wave_works, const SufRegs& o, const uint16_t* tabs, const WgLds& L, long long* t_schur = nullptr) {
   if (!my_wave_works) return;
   const int wave = threadIdx.x >> 6;
   const ChunkTab T{tabs, (P.K - 1) * P.K / 2, P.K - 1};
-  chunk_owner_phases<false>(W.R, T, o, L.rec, make_sink(P, (int)blockIdx.x * LM_CPW + wave, 1, L.pst), L.s_ne);
+  chunk_owner_phases<false>(W.R, T, o, L.rec, make_sink(P, (int)blockIdx.x * LM_CPW + wave, 1, L.pst), L.s_ne, t_schur);
 }
 
 // One LM step inside ba_lm_kernel (LMOP_ITERATE): pass B, [the decision,] pass A, this workgroup's slice of level 2.
@@ -1765,7 +1793,9 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
       if (!accept) linearize_prefix(P, W.R, cur_poses_, pre, unused0);  // rejected: the radius-free part again, at the current point
       suffix_math(P, accept ? Rc : W.R, pre, sh.sDec[1], 0, L.rec, &W.c, o);
     }
-    lm_owner_phases(P, W, my_wave_works, o, tabs, L);
+    stamp(10);  // the lanes' own arithmetic behind the decision
+    if (tp && tid == 0) tp[12] -= tmark;
+    lm_owner_phases(P, W, my_wave_works, o, tabs, L, tp ? tp + 12 : nullptr);  // slot 12: Schur owners alone; slot 3 (below): all owner phases
   }
   stamp(3);
   if (!with_pay1) return true;
@@ -1871,6 +1901,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
       if (a.dbg && tid == 0) {  // SVO_BA_TRACE: this workgroup's own split (ticks), for the spread over the workgroups of a solve
         unsigned* g = a.dbg + 16 * blockIdx.x;
         for (int i = 0; i < 6; ++i) g[8 + i] = (unsigned)cs.tp[i];
+        g[8 + 3] = (unsigned)(cs.tp[3] + cs.tp[10]);  // rest of pass A = the lanes' arithmetic + the owner phases
         g[14] = (unsigned)cs.tp[6];
       }
       // everybody's results are out; the last workgroup to arrive publishes the host's completion word
@@ -2276,7 +2307,7 @@ struct svo_ba {
   bool mfma_ok = false;   // bulk problem eligible for ba_linearize_mfma_kernel (n <= 128, one observation per (landmark, pose))
   svo_lm_stats stats{};
   // SVO_TIMING accumulators
-  double lm_tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double lm_tp[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   double lm_wg_min[7] = {0, 0, 0, 0, 0, 0, 0}, lm_wg_mean[7] = {0, 0, 0, 0, 0, 0, 0}, lm_wg_max[7] = {0, 0, 0, 0, 0, 0, 0};  // SVO_BA_TRACE: spread of the per-workgroup split
   double lm_t_wait = 0, lm_t_ctl = 0, lm_t_body = 0, lm_t_total = 0; long lm_n = 0, lm_iters = 0, lm_same = 0, lm_used = 0, lm_steps = 0, lm_lins = 0;
   double t_lin = 0, t_step = 0, t_upload = 0, t_total = 0, t_prep = 0, t_read = 0; long n_lin = 0, n_step = 0, n_solves = 0, n_spec = 0, n_hit = 0;
@@ -2415,8 +2446,11 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
   if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg)
     fprintf(stderr, "[svo ba]   per LM iteration (workgroup 0, us): pass B %.2f, radius-free part of pass A %.2f, collecting payload2 + decision %.2f, rest of pass A %.2f, "
                     "own slice of level 2 %.2f (of which waiting for everybody's partials %.2f) | collecting the totals + assembly %.2f, system build %.2f, Cholesky %.2f, step tail %.2f\n", 1e-2 * ba->lm_tp[0] / ba->lm_iters, 1e-2 * ba->lm_tp[1] / ba->lm_iters,
-            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * ba->lm_tp[3] / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters, 1e-2 * ba->lm_tp[5] / ba->lm_iters,
+            1e-2 * ba->lm_tp[2] / ba->lm_iters, 1e-2 * (ba->lm_tp[3] + ba->lm_tp[10]) / ba->lm_iters, 1e-2 * ba->lm_tp[4] / ba->lm_iters, 1e-2 * ba->lm_tp[5] / ba->lm_iters,
             1e-2 * ba->lm_tp[6] / ba->lm_iters, 1e-2 * ba->lm_tp[7] / ba->lm_iters, 1e-2 * ba->lm_tp[8] / ba->lm_iters, 1e-2 * ba->lm_tp[9] / ba->lm_iters);
+  if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg)
+    fprintf(stderr, "[svo ba]   rest of pass A, chained steps (workgroup 0's first wavefront, us per LM iteration): lanes' arithmetic behind the decision %.2f, Schur owners %.2f, "
+                    "per-pose owners + posting the partials %.2f\n", 1e-2 * ba->lm_tp[10] / ba->lm_iters, 1e-2 * ba->lm_tp[12] / ba->lm_iters, 1e-2 * (ba->lm_tp[3] - ba->lm_tp[12]) / ba->lm_iters);
   if (getenv("SVO_TIMING") && ba->lm_n && ba->d_lmdbg) {
     static const char* nm[7] = {"pass B", "radius-free part of pass A", "collecting payload2", "rest of pass A", "own slice of level 2", "waiting for the partials", "collecting the totals"};
     for (int sl = 0; sl < 7; ++sl)
@@ -3099,7 +3133,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   ba->stats.speculation_hits = (int)r[LMR_NEXT_USED];
   ba->stats.single_exchange = (int)r[LMR_SAME_SWEEP];
   ba->lm_same += (long)r[LMR_SAME_SWEEP]; ba->lm_used += (long)r[LMR_NEXT_USED]; ba->lm_steps += (long)r[LMR_STEP_CALLS]; ba->lm_lins += (long)r[LMR_LINEARIZE_CALLS];
-  for (int i = 0; i < 12; ++i) ba->lm_tp[i] += r[LMR_TP0 + i];
+  for (int i = 0; i < 14; ++i) ba->lm_tp[i] += r[LMR_TP0 + i];
   if (ba->d_lmdbg && getenv("SVO_TIMING")) {
     const int nb = (d.C + LM_CPW - 1) / LM_CPW;
     std::vector<unsigned> g(16 * (size_t)nb);
@@ -3108,6 +3142,20 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
         double mn = 1e300, mx = 0, sum = 0;
         for (int b = 0; b < nb; ++b) { const double v = g[16 * (size_t)b + 8 + sl]; mn = std::min(mn, v); mx = std::max(mx, v); sum += v; }
         ba->lm_wg_min[sl] += mn; ba->lm_wg_max[sl] += mx; ba->lm_wg_mean[sl] += sum / nb;
+      }
+      static int traced = 0;
+      if (getenv("SVO_BA_TRACE_WG") && traced < 2 && r[LMR_ITERATIONS] >= 4) {  // which chunks are the slow ones: rest of pass A of a workgroup's first wavefront against its chunk's shape
+        ++traced;
+        const int nU = (d.K - 1) * d.K / 2, F = d.K - 1;
+        for (int b = 0; b < nb; ++b) {
+          const int c = b * LM_CPW;
+          const uint16_t* w = ba->u_tab.data() + ba->u_tab_off[(size_t)c];
+          int ne = 0, longest = 0, plong = 0;
+          for (int q = 0; q < nU; ++q) { const int len = w[q + 1] - w[q]; ne += len > 0; longest = std::max(longest, len); }
+          for (int k = 0; k < F; ++k) plong = std::max(plong, (int)w[nU + 1 + k + 1] - (int)w[nU + 1 + k]);
+          fprintf(stderr, "[svo ba wg] %2d: rest of pass A %.2f us/iteration, pass B %.2f | chunk %d: %d entries in %d blocks (longest list %d), longest pose list %d\n", b,
+                  1e-2 * g[16 * (size_t)b + 8 + 3] / r[LMR_ITERATIONS], 1e-2 * g[16 * (size_t)b + 8 + 0] / r[LMR_ITERATIONS], c, (int)w[nU], ne, longest, plong);
+        }
       }
     }
   }
@@ -3125,12 +3173,13 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
 inline size_t wave_lds_bytes(const BaDev& d) { return sizeof(double) * (size_t)wg_lds_doubles(d.E); }
 // workgroup width of the host-driven deterministic kernels (experiment knob)
 inline int det_threads() {
-  static const int v = [] { const char* e = getenv("SVO_BA_DET_THREADS"); return e && atoi(e) == 64 ? 64 : 128; }();
+  static const int v = [] { const char* e = getenv("SVO_BA_DET_THREADS"); const int t = e ? atoi(e) : 0; return t == 64 || t == 256 ? t : 128; }();
   return v;
 }
 #define SVO_DET_LAUNCH(kernel, grid, lds, st, ...)                                                        \
   do {                                                                                                    \
     if (det_threads() == 64) hipLaunchKernelGGL(kernel<64>, grid, dim3(64), lds, st, __VA_ARGS__);        \
+    else if (det_threads() == 256) hipLaunchKernelGGL(kernel<256>, grid, dim3(256), lds, st, __VA_ARGS__); \
     else hipLaunchKernelGGL(kernel<128>, grid, dim3(128), lds, st, __VA_ARGS__);                          \
   } while (0)
 

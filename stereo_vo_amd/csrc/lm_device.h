@@ -2,7 +2,8 @@
 // executed inside the solve kernel so that a whole ceres::Solve (reference src/bundle_adjuster.cpp:140) is a single
 // launch with no host round trip per iteration.  Every function applies the host's operations to every element in the
 // host's order (declared arithmetic of host/linalg.cpp: each element receives  a_ij - l_i0 l_j0 - l_i1 l_j1 - ...  one
-// product at a time in ascending k; forward substitution ascending, back substitution descending), so the bits are
+// product at a time in ascending k; forward substitution ascending, back substitution descending, rows scaled by the
+// pivots' reciprocals r_i = 1 / l_ii), so the bits are
 // the host's — checked by tests/test_ba.py::test_hip_device_cholesky_matches_host and by every pipeline parity test.
 #ifndef SVO_LM_DEVICE_H_
 #define SVO_LM_DEVICE_H_
@@ -46,23 +47,23 @@ __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, doubl
     // wait for the running solution
     const bool in = tid < n;
     double bi = in ? b[tid] : 0.0;
-    const double di = in ? A[tid * n + tid] : 1.0;
+    const double ri = 1.0 / (in ? A[tid * n + tid] : 1.0);  // the pivots' reciprocals, all lanes side by side: the 2 n divisions of the plain form were the chain
     for (int k = 0; k < n; ++k) {  // forward: b[i] -= L[i][k] x[k], ascending k
       const double lik = (in && tid > k) ? A[tid * n + k] : 0.0;
-      const double xk = svo_readlane_f64(bi, k) / svo_readlane_f64(di, k);
+      const double xk = svo_readlane_f64(bi, k) * svo_readlane_f64(ri, k);
       if (tid == k) bi = xk;
       else if (in && tid > k) bi -= lik * xk;
     }
     for (int k = n - 1; k >= 0; --k) {  // backward: b[i] -= L[k][i] x[k], descending k
       const double lki = tid < k ? A[k * n + tid] : 0.0;
-      const double xk = svo_readlane_f64(bi, k) / svo_readlane_f64(di, k);
+      const double xk = svo_readlane_f64(bi, k) * svo_readlane_f64(ri, k);
       if (tid == k) bi = xk;
       else if (tid < k) bi -= lki * xk;
     }
     if (in) b[tid] = bi;
   } else if (tid < 64) {
     for (int k = 0; k < n; ++k) {
-      if (tid == 0) b[k] = b[k] / A[k * n + k];
+      if (tid == 0) b[k] = b[k] * (1.0 / A[k * n + k]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -73,7 +74,7 @@ __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, doubl
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     for (int k = n - 1; k >= 0; --k) {
-      if (tid == 0) b[k] = b[k] / A[k * n + k];
+      if (tid == 0) b[k] = b[k] * (1.0 / A[k * n + k]);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");

@@ -406,8 +406,9 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     {
       // ids advance by at most max_features per keyframe: room for 256 keyframes of survival, power of two; an entry found
       // under another id is reported by the PnP launch (never used silently)
-      size_t cap = 1;
-      while (cap < 256 * mf) cap <<= 1;
+      size_t cap = 1, keyframes = 256;
+      if (const char* e = getenv("SVO_GROUP_STORE_KEYFRAMES")) keyframes = (size_t)std::max(1, atoi(e));  // test hook: a store too small must fail loudly (tests/test_group.py)
+      while (cap < keyframes * mf) cap <<= 1;
       l->store_mask = (unsigned)(cap - 1);
       if (!rc) rc = dev_alloc(g, &l->d_store, cap);
       if (!rc) chk(hipMemset(l->d_store, 0xFF, sizeof(float4) * cap), "hipMemset");

@@ -2,7 +2,9 @@
 //
 // Declared arithmetic (shared with oracle/ora_ba.cpp's cholesky_solve, which is the plain left-looking
 // loop): every element receives  a_ij - l_i0 l_j0 - l_i1 l_j1 - ...  with the products subtracted one at a
-// time in ascending k, each multiply and subtract rounded separately (-ffp-contract=off, no FMA target).
+// time in ascending k, each multiply and subtract rounded separately (-ffp-contract=off, no FMA target); the two
+// substitutions scale a row by the pivot's reciprocal r_i = 1 / l_ii, formed once (round 4: on the device the 2 n divisions
+// of the plain form were a dependent chain).
 // This file applies those same operations in right-looking order — after column j is final, it is
 // subtracted from the trailing rows as contiguous axpy updates — so the compiler can vectorise without
 // reassociating anything: the results are bit-identical to the left-looking loop, about 4x faster with AVX2 (n = 54 on an
@@ -64,15 +66,18 @@ SVO_CLONES bool chol_factor_solve(double* __restrict A, double* __restrict b, in
       }
     }
   }
+  // substitutions scale by the pivots' reciprocals, formed once (declared arithmetic, round 4: see oracle/ora_ba.cpp)
+  double* __restrict rd = col;  // the panel copies are idle now
+  for (int i = 0; i < n; ++i) rd[i] = 1.0 / A[(size_t)i * n + i];
   for (int i = 0; i < n; ++i) {
     double v = b[i];
     for (int k = 0; k < i; ++k) v -= A[(size_t)i * n + k] * b[k];
-    b[i] = v / A[(size_t)i * n + i];
+    b[i] = v * rd[i];
   }
   for (int i = n - 1; i >= 0; --i) {  // inner index DESCENDING: the order the device column sweep produces
     double v = b[i];
     for (int k = n - 1; k > i; --k) v -= A[(size_t)k * n + i] * b[k];
-    b[i] = v / A[(size_t)i * n + i];
+    b[i] = v * rd[i];
   }
   return true;
 }

@@ -86,16 +86,17 @@ def test_host_cholesky_follows_declared_order():
                 for k in range(j):
                     v -= A[i][k] * A[j][k]
                 A[i][j] = v / l
+        r = [1.0 / A[i][i] for i in range(n)]  # the substitutions scale by the pivots' reciprocals, formed once (declared)
         for i in range(n):
             v = b[i]
             for k in range(i):
                 v -= A[i][k] * b[k]
-            b[i] = v / A[i][i]
+            b[i] = v * r[i]
         for i in range(n - 1, -1, -1):
             v = b[i]
             for k in range(n - 1, i, -1):
                 v -= A[k][i] * b[k]
-            b[i] = v / A[i][i]
+            b[i] = v * r[i]
         return np.array(b)
 
     rng = np.random.default_rng(5)

@@ -316,3 +316,29 @@ def test_hip_group_streaming_entry_equals_the_device_pointer_entry():
         assert [KEY(r) for r in got[l]] == [KEY(r) for r in want3[l]], l
     g.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_group_landmark_store_too_small_fails_loudly():
+    """The PnP launch reads world points from the lane's device-resident landmark store, keyed by feature id modulo the
+    capacity.  A capacity below the span of live ids (forced here through the test hook SVO_GROUP_STORE_KEYFRAMES=1: room for
+    ONE keyframe's ids) lets a new landmark overwrite a live one's entry; the launch must report the entry found under a foreign
+    id — an error, never a silently wrong pose."""
+    import os
+    import torch
+    import stereo_vo_amd as S
+    n = 40
+    p0, L, R = _seq(n, seed=0x5EED0901)[:3]
+    ctx = S.Context(p0.width, p0.height, max_batch=8, max_corners=300, max_candidates=1 << 16, max_features=400)
+    os.environ["SVO_GROUP_STORE_KEYFRAMES"] = "1"
+    try:
+        g = _group(S, ctx, p0, 300, 12.0, 400, 1)
+    finally:
+        del os.environ["SVO_GROUP_STORE_KEYFRAMES"]
+    with pytest.raises(S.api.SvoError, match="landmark store"):
+        for b0 in range(0, n, 8):
+            dl, dr = torch.from_numpy(L[None, b0:b0 + 8].copy()).cuda(), torch.from_numpy(R[None, b0:b0 + 8].copy()).cuda()
+            g.process_batch_dev(dl.data_ptr(), dr.data_ptr(), 8 * p0.width * p0.height, 8)
+            torch.cuda.synchronize()
+    g.close()
+    ctx.close()

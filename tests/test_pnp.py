@@ -86,3 +86,28 @@ def test_hip_pnp_too_few_points(ctx):
     X, uv, *_ = _scene(2, 4)
     r, t, inl = ctx.pnp_ransac(X, uv, F, CX, CY, np.ones(3) * 0.01, np.ones(3))
     assert len(inl) == 0 and np.allclose(r, 0.01) and np.allclose(t, 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("iterations", [1, 3, 4, 5, 37, 100, 101])
+def test_hip_pnp_hypothesis_counts_that_do_not_fill_the_last_workgroup(ctx, iterations):
+    """The launch runs four hypotheses per workgroup: counts that are not a multiple of four (and a single workgroup) leave
+    wavefronts without a hypothesis; bookkeeping and refinement must still be the oracle's."""
+    X, uv, *_ = _scene(9, 400, 0.3)
+    r0, t0 = np.array([0.002, 0.001, -0.003]), np.array([0.01, 0.0, -0.1])
+    rg, tg, ig = ctx.pnp_ransac(X, uv, F, CX, CY, r0, t0, iterations=iterations)
+    ro, to, io = O.pnp_ransac(X, uv, F, CX, CY, r0, t0, iterations=iterations)
+    assert np.array_equal(ig, io)
+    assert np.allclose(rg, ro, rtol=0, atol=1e-12) and np.allclose(tg, to, rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_hip_pnp_without_a_model_leaves_the_pose_alone(ctx):
+    """No hypothesis reaches five inliers (pure outliers at a 0.05 px threshold): the oracle returns no inliers and the guess
+    unchanged; so must the launch whose last workgroup finds best < 0 and skips the refinement."""
+    X, uv, *_ = _scene(3, 60, outlier_frac=1.0)
+    r0, t0 = np.array([0.3, -0.2, 0.1]), np.array([1.0, 2.0, 3.0])
+    ro, to, io = O.pnp_ransac(X, uv, F, CX, CY, r0, t0, reproj_err=0.05)
+    rg, tg, ig = ctx.pnp_ransac(X, uv, F, CX, CY, r0, t0, reproj_err=0.05)
+    assert len(io) == 0 and len(ig) == 0
+    assert np.array_equal(rg, ro) and np.array_equal(tg, to) and np.array_equal(rg, r0) and np.array_equal(tg, t0)
