@@ -101,6 +101,7 @@ struct BaDev {
   int G = 1, NG = 0, Epad = 0, E = 0;    // chunks per group, groups, granules per group row (E rounded up), wire-format elements
   const uint16_t* tab = nullptr;   // chunk tables back to back (u16 words), see ba_build_tables
   const uint32_t* tab_off = nullptr;  // C + 1 offsets into tab
+  int tab_lds_words = 0;              // host-driven kernels: u16 words of LDS behind the workgroup's staging area for its chunk's table (0: read from global memory)
   const unsigned* lm_key = nullptr;   // per landmark: low 32 bits of its feature id (null: the problem has none — bulk loads); the key of its landmark-store entry
   double* part1 = nullptr;         // granules {value, tag}: element e of group g at part1[2 * (g * Epad + e)] — a wavefront's partials are one contiguous run
   double* part2 = nullptr;         // granules: pass B's four sums of group g at part2[2 * ((parity * NG + g) * 4 + i)]
@@ -480,13 +481,14 @@ constexpr int PST_MAX = 2048;         // wire elements a wavefront stages in LDS
 // not stage, keeps its four scalars per landmark in the rows themselves) | the E partials of the chunk on their way out
 // (consecutive threads then post consecutive granules: whole lines) | 4 ints
 __host__ __device__ static inline int wg_lds_doubles(int E) { return 64 * REC_STRIDE + (E <= PST_MAX ? ((E + 1) & ~1) : 0) + 2; }
-struct WgLds { double* rec; double* pst; int* s_ne; };
+struct WgLds { double* rec; double* pst; int* s_ne; uint16_t* tab; };  // tab: the host-driven kernels' LDS copy of the chunk table (behind wg_lds_doubles(E))
 __device__ __forceinline__ WgLds wg_lds(double* base, int E) {
   WgLds L;
   const int pst_doubles = E <= PST_MAX ? ((E + 1) & ~1) : 0;
   L.rec = base;
   L.pst = pst_doubles ? base + 64 * REC_STRIDE : nullptr;
   L.s_ne = reinterpret_cast<int*>(base + 64 * REC_STRIDE + pst_doubles);
+  L.tab = reinterpret_cast<uint16_t*>(base + 64 * REC_STRIDE + pst_doubles + 2);
   return L;
 }
 constexpr int TAB_LDS_WORDS = 1024;   // u16 words of a chunk table ba_lm_kernel keeps in LDS (larger tables: host-driven path)
@@ -787,6 +789,7 @@ __device__ __forceinline__ void linearize_chunk_wg1(const BaDev& P, const ObsRec
     linearize_prefix(P, R, poses_, q, unused);
     suffix_math(P, R, q, radius, first_pass, L.rec, nullptr, o);
   }
+  if (NT > 64) __syncthreads(); else wave_lds_fence();  // the LDS copy of the chunk's table (stage_chunk_tab) is complete
   chunk_owner_phases<(NT > 64)>(R, T, o, L.rec, sink, L.s_ne);
 }
 
@@ -1118,6 +1121,19 @@ __device__ __forceinline__ PartSink make_sink(const BaDev& P, int g, int first, 
   return PartSink{P.part1, P.part2, pst, P.Epad, P.E, P.NG, g, first, P.pay_parity, P.pay_tag};
 }
 __device__ __forceinline__ ChunkTab global_tab(const BaDev& P, int chunk) { return ChunkTab{P.tab + P.tab_off[chunk], (P.K - 1) * P.K / 2, P.K - 1}; }
+// The chunk's table for the owner phases of a host-driven kernel: copied into the workgroup's LDS first when the host made room
+// (P.tab_lds_words) — the owners' walk is a chain of dependent reads (entry -> rows), ~100 cycles per link from LDS against
+// ~500+ from L2 (the single-stream pass A of round 4's first version: 20.7 us against 12.9 in round 3).  Called by the whole
+// workgroup; the copy is visible after the next workgroup barrier.
+__device__ __forceinline__ ChunkTab stage_chunk_tab(const BaDev& P, int chunk, const WgLds& L) {
+  if (!P.tab_lds_words) return global_tab(P, chunk);
+  const uint32_t o0 = P.tab_off[chunk], o1 = P.tab_off[chunk + 1];
+  const int words32 = (int)((o1 - o0 + 1) >> 1);  // tables start on even u16 offsets
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tab + o0);
+  uint32_t* d32 = reinterpret_cast<uint32_t*>(L.tab);
+  for (int i = threadIdx.x; i < words32; i += blockDim.x) d32[i] = src[i];
+  return ChunkTab{L.tab, (P.K - 1) * P.K / 2, P.K - 1};
+}
 
 template <int NT>
 __global__ __launch_bounds__(NT) void ba_linearize_det_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
@@ -1130,7 +1146,9 @@ __global__ __launch_bounds__(NT) void ba_linearize_det_kernel(BaDev P, double ra
   for (int chunk = c0; chunk < c1; ++chunk) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
     if (threadIdx.x < 64) R = load_obs(P, chunk, lane, P.points);
-    linearize_chunk_wg1<NT>(P, R, P.poses, radius, first_pass, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
+    if (chunk != c0) __syncthreads();  // the previous chunk's owners are done with the table
+    const ChunkTab T = stage_chunk_tab(P, chunk, L);  // visible behind the barrier in front of the owner phases
+    linearize_chunk_wg1<NT>(P, R, P.poses, radius, first_pass, T, L, make_sink(P, g, chunk == c0, L.pst));
     stores_acknowledged();  // the group's running sums are read back by the next chunk
   }
 }
@@ -1152,6 +1170,7 @@ __global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl 
   ObsRec Rc = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   D3 pc = Rc.p;
   if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
+  ChunkTab T = stage_chunk_tab(P, c0 < P.C ? c0 : 0, L);  // on its way to LDS while the sums are collected
   (void)sum_pay2(P, P.pay_parity, P.pay_tag, rec, sOut, &sFlag);  // pass B's launch is complete: the tags are there
   const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
   if (blockIdx.x == 0 && threadIdx.x < 6)
@@ -1160,8 +1179,8 @@ __global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl 
   const double* poses_ = dec.accept ? P.cand_poses : P.poses;
   if (dec.accept) Rc.p = pc;
   for (int chunk = c0; chunk < c1; ++chunk) {
-    if (chunk != c0) Rc = load_obs(P, chunk, lane, points_);
-    linearize_chunk_wg1<NT>(P, Rc, poses_, dec.next_radius, 0, global_tab(P, chunk), L, make_sink(P, g, chunk == c0, L.pst));
+    if (chunk != c0) { Rc = load_obs(P, chunk, lane, points_); __syncthreads(); T = stage_chunk_tab(P, chunk, L); }
+    linearize_chunk_wg1<NT>(P, Rc, poses_, dec.next_radius, 0, T, L, make_sink(P, g, chunk == c0, L.pst));
     stores_acknowledged();
   }
 }
@@ -1215,10 +1234,12 @@ __global__ __launch_bounds__(NT) void ba_step_kernel(BaDev P, double radius, dou
     const PartSink sink = make_sink(P, g, chunk == c0, L.pst);
     D3 cand = R.p;
     if (threadIdx.x < 64) backsub_chunk(P, R, P.poses, cand_poses_, dc_, P.cand_points, radius, cand, unused0, unused1, unused2, unused3, nullptr, lms, &sink);
+    ChunkTab T = global_tab(P, chunk);
     if (spec_radius > 0) {
-      __syncthreads();  // pass B kept its landmark scalars in the staging rows
+      __syncthreads();  // pass B kept its landmark scalars in the staging rows (and the previous chunk's owners are done with the table)
+      T = stage_chunk_tab(P, chunk, L);
       R.p = cand;
-      linearize_chunk_wg1<NT>(P, R, cand_poses_, spec_radius, 0, global_tab(P, chunk), L, sink);
+      linearize_chunk_wg1<NT>(P, R, cand_poses_, spec_radius, 0, T, L, sink);
     }
     stores_acknowledged();
   }
@@ -2708,6 +2729,7 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
   ba->cur_poses = (double*)(D + o_p0); ba->cand_poses = (double*)(D + o_p1);
   d.rec = (const int4*)(D + o_rec); d.obs_uv = (const double*)(D + o_uv);
   d.tab = (const uint16_t*)(D + o_tab); d.tab_off = (const uint32_t*)(D + o_toff);
+  d.tab_lds_words = (d.det && ba->tab_max_words > 0 && ba->tab_max_words <= 4096) ? ((ba->tab_max_words + 3) & ~3) : 0;  // host-driven kernels: the chunk's table in LDS (8 KB at most)
   d.lm_key = with_keys ? (const unsigned*)(D + o_key) : nullptr;
   memcpy(h + o_p0, poses7, sizeof(double) * 7 * (size_t)K);
   memcpy(h + o_p1, poses7, sizeof(double) * 7 * (size_t)K);
@@ -3170,7 +3192,7 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   return SVO_OK;
 }
 
-inline size_t wave_lds_bytes(const BaDev& d) { return sizeof(double) * (size_t)wg_lds_doubles(d.E); }
+inline size_t wave_lds_bytes(const BaDev& d) { return sizeof(double) * (size_t)wg_lds_doubles(d.E) + sizeof(uint16_t) * (size_t)d.tab_lds_words; }
 // workgroup width of the host-driven deterministic kernels (experiment knob)
 inline int det_threads() {
   static const int v = [] { const char* e = getenv("SVO_BA_DET_THREADS"); const int t = e ? atoi(e) : 0; return t == 64 || t == 256 ? t : 128; }();
