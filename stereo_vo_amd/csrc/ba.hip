@@ -2572,6 +2572,7 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
     has_empty_landmark |= lm_start[j + 1] == 0;
     lm_start[j + 1] += lm_start[j];
   }
+  // chunks (declared with the summation order, oracle/ora_ba.cpp): whole landmarks, greedily, at most 64 observations each
   chunks.push_back(0);
   int cur = 0;
   for (int j = 0; j < npts; ++j) {
