@@ -1008,7 +1008,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         if (error) break;
         if (!cand.empty()) {
           unsigned long long mask = 0;
-          const int launched = svo_ba_solve_launch(bas, (int)cand.size(), g->st_ba[free_line], &mask);
+          static const bool host_solves = [] { const char* e = getenv("SVO_GROUP_HOST_SOLVES"); return e && *e && atoi(e) != 0; }();  // test hook: every window down the host-driven path (the landmark store is then filled by the scatter launch)
+          const int launched = host_solves ? 0 : svo_ba_solve_launch(bas, (int)cand.size(), g->st_ba[free_line], &mask);
           if (launched > 0) { g->launches[4]++; g->lanes_carried[4] += launched; progressed = true; }
           ++g->ba_launch_id;
           int not_taken = -1;  // the first lane the launch skipped: not eligible, or not admitted right now

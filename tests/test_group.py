@@ -342,3 +342,48 @@ def test_hip_group_landmark_store_too_small_fails_loudly():
             torch.cuda.synchronize()
     g.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_group_host_driven_solves_fill_the_landmark_store_too():
+    """A window that is not eligible (or not admitted) for the device-resident solve is solved by the host-driven loop on a
+    worker; its landmarks then reach the lane's landmark store through one scatter launch.  Forced for every window through the
+    test hook SVO_GROUP_HOST_SOLVES=1 (read when the library first launches solves, hence a child process): every lane must
+    still be its oracle, bit for bit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+import stereo_vo_amd as S
+from test_pipeline import _seq, _ora_pipe
+from test_group import _group, KEY
+n, lanes, batch = 16, 3, 8
+seqs = [_seq(n, seed=0x5EED0A00 + 11 * i) for i in range(lanes)]
+p0 = seqs[0][0]
+Ls = np.stack([s[1] for s in seqs]); Rs = np.stack([s[2] for s in seqs])
+ctx = S.Context(p0.width, p0.height, max_batch=lanes * batch, max_corners=300, max_candidates=1 << 16, max_features=400)
+g = _group(S, ctx, p0, 300, 12.0, 400, lanes)
+got = [[] for _ in range(lanes)]
+for b0 in range(0, n, batch):
+    dl, dr = torch.from_numpy(Ls[:, b0:b0 + batch].copy()).cuda(), torch.from_numpy(Rs[:, b0:b0 + batch].copy()).cuda()
+    res = g.process_batch_dev(dl.data_ptr(), dr.data_ptr(), batch * p0.width * p0.height, batch)
+    torch.cuda.synchronize()
+    for l in range(lanes):
+        got[l] += res[l]
+for l in range(lanes):
+    p, Lh, Rh = seqs[l]
+    o = _ora_pipe(p, min_feature_distance=12.0, max_corners=300, max_features=400)
+    ref = [o.process(Lh[k], Rh[k]) for k in range(n)]
+    for k in range(n):
+        assert KEY(got[l][k]) == KEY(ref[k]), (l, k, KEY(got[l][k]), KEY(ref[k]))
+assert sum(q.is_keyframe for q in got[0]) >= 3
+print("host-driven solves ok", sum(q.is_keyframe for q in got[0]))
+''' % (root, os.path.join(root, "tests"))
+    e = dict(os.environ)
+    e["SVO_GROUP_HOST_SOLVES"] = "1"
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "host-driven solves ok" in out.stdout, out.stderr[-3000:]
