@@ -36,6 +36,7 @@ int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_la
 struct SvoPnpLane {
   const long long* ids; const float4* store; unsigned store_mask;  // tracked features' ids (device) -> store entries
   const float* xy; int n; double f, cx, cy; double q0[4], t0[3]; double thr2, confidence; int iterations;
+  int launched;  // hypotheses 0 .. launched-1 are computed by this launch (<= iterations); host_best = -2: the bookkeeping needs more of them
   double* hyp_pose; int* hyp_count; unsigned long long* hyp_mask; int mask_words;   // per-hypothesis scratch (device)
   double* out_pose; int* inliers; int* n_inliers; float* inlier_xy;                // device results (inlier_xy: the dedup stage's input)
   double* host_pose; int* host_inliers; int* host_nin; int* host_best; int* host_bad;  // pinned mirrors; host_best < 0: no model, host_bad != 0: a store entry under a foreign id
@@ -43,8 +44,9 @@ struct SvoPnpLane {
   int* word; int seq;                                                               // pinned completion word
 };
 struct SvoPnpLanes { SvoPnpLane lane[SVO_MAX_LANES]; };
-int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes, int iterations);
-int svo_kg_pnp_workgroups(int iterations);  // workgroups per lane of that launch (what arrive_target counts)
+int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes);  // grid from the lanes' `launched`
+int svo_kg_pnp_workgroups(int launched);  // workgroups of a lane that computes `launched` hypotheses (what its arrive_target counts)
+int svo_kg_pnp_first(int iterations);     // hypotheses of a lane's FIRST launch (the rest only if the bookkeeping asks for them)
 int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters);  // OpenCV's RANSACUpdateNumIters (host/pnp_iters.h)
 int svo_pnp_model_points();
 

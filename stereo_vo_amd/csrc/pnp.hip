@@ -414,7 +414,8 @@ __device__ __forceinline__ void pnp_fused_body(const SvoPnpLane& a, const Src& s
   static_assert(4 * sizeof(HypLds) <= sizeof(double) * 256 * 28, "the hypotheses' LDS must fit the refinement's");
   const int tid = threadIdx.x, wave = tid >> 6;
   const int h = blockIdx.x * 4 + wave;
-  if (h < a.iterations) {
+  if ((int)blockIdx.x * 4 >= a.launched) return;  // (a launch carries lanes with different hypothesis counts: not this lane's workgroup)
+  if (h < a.launched) {
     PnpPose P0;
     for (int k = 0; k < 4; ++k) P0.q[k] = a.q0[k];
     for (int k = 0; k < 3; ++k) P0.t[k] = a.t0[k];
@@ -423,14 +424,18 @@ __device__ __forceinline__ void pnp_fused_body(const SvoPnpLane& a, const Src& s
   }
   if (!svo_last_arrival(a.arrive, a.arrive_target, &sLast)) return;
   if (tid == 0) {
+    // OpenCV consumes the hypotheses in order and stops at the adaptive cap: with mostly inliers the cap falls to a handful after
+    // the first good model, so a lane's FIRST launch computes only the first few (svo_kg_pnp_first) and the rest — never looked
+    // at in that case — only when the cap stays above what was computed (host_best = -2: launch again with all of them)
     int best = -1, best_cnt = 0, niters = a.iterations;
-    for (int hh = 0; hh < niters; ++hh) {
+    for (int hh = 0; hh < niters && hh < a.launched; ++hh) {
       const int c = svo_coherent_load(&a.hyp_count[hh]);
       if (c > (best_cnt > MODEL - 1 ? best_cnt : MODEL - 1)) {
         best = hh; best_cnt = c;
         niters = svo_pnp_update_num_iters_det(a.confidence, (double)(a.n - best_cnt) / a.n, MODEL, niters);
       }
     }
+    if (niters > a.launched) best = -2;  // hypotheses launched .. niters-1 are still to be consumed
     sBest = best;
     *a.host_best = best;
     if (best < 0) *a.host_nin = 0;
@@ -488,9 +493,6 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   double* h_out = (double*)((char*)ctx->h_pinned + 4096);
   int* h_nin = (int*)((char*)ctx->h_pinned + 4096 + 64);
   int* h_best = (int*)((char*)ctx->h_pinned + 4096 + 128);
-  const int wgs = svo_div_up(iterations, 4);
-  const SvoPublish pub = svo_publish_next(ctx, SVO_W_PNP_REF);   // the word the last workgroup publishes
-  const SvoPublish arr = svo_arrive_next(ctx, wgs);               // the arrival counter the workgroups meet at
   SvoPnpLane a;
   memset(&a, 0, sizeof(a));
   a.xy = d_xy; a.n = n; a.f = (double)focal; a.cx = (double)cxf; a.cy = (double)cyf;
@@ -500,14 +502,21 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   a.hyp_pose = d_pose; a.hyp_count = d_count; a.hyp_mask = d_mask; a.mask_words = words;
   a.out_pose = d_out; a.inliers = d_inliers; a.n_inliers = d_nin; a.inlier_xy = d_inlier_xy;
   a.host_pose = h_out; a.host_inliers = h_inliers; a.host_nin = h_nin; a.host_best = h_best; a.host_bad = nullptr;
-  a.arrive = arr.arrive; a.arrive_target = arr.target; a.word = pub.word; a.seq = pub.seq;
-  {
-  SvoProfScope prof(ctx, SVO_PROF_PNP_HYP);
-  hipLaunchKernelGGL(pnp_ransac_kernel, dim3(wgs), dim3(256), 0, st, a, d_xyz);
+  // first the leading hypotheses only; all of them when the bookkeeping's cap stays above what was computed (h_best = -2)
+  for (a.launched = svo_kg_pnp_first(iterations);; a.launched = iterations) {
+    const int wgs = svo_div_up(a.launched, 4);
+    const SvoPublish pub = svo_publish_next(ctx, SVO_W_PNP_REF);   // the word the last workgroup publishes
+    const SvoPublish arr = svo_arrive_next(ctx, wgs);               // the arrival counter the workgroups meet at
+    a.arrive = arr.arrive; a.arrive_target = arr.target; a.word = pub.word; a.seq = pub.seq;
+    {
+    SvoProfScope prof(ctx, SVO_PROF_PNP_HYP);
+    hipLaunchKernelGGL(pnp_ransac_kernel, dim3(wgs), dim3(256), 0, st, a, d_xyz);
+    }
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+    const int rc = svo_wait_word(ctx, pub);
+    if (rc) return rc;
+    if (*h_best != -2 || a.launched >= iterations) break;
   }
-  SVO_HIP_CHECK(ctx, hipGetLastError());
-  int rc = svo_wait_word(ctx, pub);
-  if (rc) return rc;
   if (*h_best < 0) return SVO_OK;
   double q[4] = {h_out[0], h_out[1], h_out[2], h_out[3]};
   if (q[0] < 0) for (double& v : q) v = -v;
@@ -551,10 +560,15 @@ extern "C" int svo_pnp_ransac(svo_ctx* ctx, const float* xyz, const float* xy, i
 int svo_pnp_update_num_iters(double p, double ep, int model_points, int max_iters) { return update_num_iters(p, ep, model_points, max_iters); }
 int svo_pnp_model_points() { return MODEL; }
 
-int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes, int iterations) {
+int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes) {
+  int most = 1;
+  for (int i = 0; i < n_lanes; ++i) most = std::max(most, lanes.lane[i].launched);
   SvoProfScope prof(ctx, SVO_PROF_PNP_HYP, st);
-  hipLaunchKernelGGL(pnp_group_kernel, dim3(svo_div_up(iterations, 4), n_lanes), dim3(256), 0, st, lanes);
+  hipLaunchKernelGGL(pnp_group_kernel, dim3(svo_div_up(most, 4), n_lanes), dim3(256), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }
-int svo_kg_pnp_workgroups(int iterations) { return svo_div_up(iterations, 4); }
+int svo_kg_pnp_workgroups(int launched) { return svo_div_up(launched, 4); }
+// 12 hypotheses = three workgroups: enough whenever the best of them has >= 80 % inliers (the cap is log 0.01 / log(1 - w^5):
+// 5 at w = 0.9, 12 at w = 0.8, 25 at w = 0.7)
+int svo_kg_pnp_first(int iterations) { return std::min(iterations, 12); }

@@ -94,6 +94,7 @@ struct Lane {
   float4* d_store = nullptr; unsigned store_mask = 0;  // device-resident landmark store of the lane, keyed by feature id (get_world_points, src/bundle_adjuster.cpp:159-163)
   double* d_hyp_pose = nullptr; int* d_hyp_count = nullptr; unsigned long long* d_hyp_mask = nullptr;
   double* d_out = nullptr; int* d_nin = nullptr; int* d_inl = nullptr; float* d_trk_xy = nullptr;
+  bool pnp_all = false;  // the lane's next PnP launch computes every hypothesis (the first few did not settle the adaptive cap)
   int* h_best = nullptr; int* h_bad = nullptr; double* h_out = nullptr; int* h_nin = nullptr; int* h_inl = nullptr;
   // ---- dedup / sparse stereo / triangulation
   float* d_disp = nullptr;
@@ -772,7 +773,12 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
                 error = SVO_ERR_CAPACITY;
                 break;
               }
-              l->best = *l->h_best;  // the launch's own RANSAC bookkeeping (csrc/pnp.hip pnp_group_kernel); < 0: no model
+              l->best = *l->h_best;  // the launch's own RANSAC bookkeeping (csrc/pnp.hip pnp_group_kernel); -1: no model
+              if (l->best == -2) {     // the adaptive cap stayed above the hypotheses of the first launch: all of them now
+                l->pnp_all = true;
+                q_pnp.push_back(li); l->queued = true;
+                break;
+              }
               if (l->best >= 0) {
                 double q[4] = {l->h_out[0], l->h_out[1], l->h_out[2], l->h_out[3]};
                 if (q[0] < 0) for (double& v : q) v = -v;
@@ -889,7 +895,6 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       for (int li : t_now) g->lanes[li]->chain_line = line;
     if (!h_now.empty()) {
       SvoPnpLanes a;
-      const int wgs = svo_kg_pnp_workgroups(g->pnp_iterations);
       int k = 0;
       for (int li : h_now) {
         Lane* l = g->lanes[li];
@@ -909,6 +914,9 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         for (int c = 0; c < 3; ++c) x.t0[c] = (double)l->tvec[c];
         x.thr2 = (double)svo_ref::PNP_REPROJ_ERROR * (double)svo_ref::PNP_REPROJ_ERROR;
         x.confidence = svo_ref::PNP_CONFIDENCE; x.iterations = g->pnp_iterations;
+        x.launched = l->pnp_all ? g->pnp_iterations : svo_kg_pnp_first(g->pnp_iterations);
+        l->pnp_all = false;
+        const int wgs = svo_kg_pnp_workgroups(x.launched);
         x.hyp_pose = l->d_hyp_pose; x.hyp_count = l->d_hyp_count; x.hyp_mask = l->d_hyp_mask; x.mask_words = svo_div_up(m, 64);
         x.out_pose = l->d_out; x.inliers = l->d_inl; x.n_inliers = l->d_nin; x.inlier_xy = l->d_trk_xy;
         x.host_pose = l->h_out; x.host_inliers = l->h_inl; x.host_nin = l->h_nin; x.host_best = l->h_best; x.host_bad = l->h_bad;
@@ -916,7 +924,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         x.arrive = pb.arrive; x.arrive_target = pb.target; x.word = pb.word; x.seq = pb.seq;
         l->queued = false;
       }
-      if ((error = svo_kg_pnp(ctx, stc, a, k, g->pnp_iterations))) break;
+      if ((error = svo_kg_pnp(ctx, stc, a, k))) break;
       for (int li : h_now) EV(li, "pnp_launch", k);
       g->launches[1]++; g->lanes_carried[1] += k;
       progressed = true;
