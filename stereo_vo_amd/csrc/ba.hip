@@ -3194,17 +3194,9 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
 }
 
 inline size_t wave_lds_bytes(const BaDev& d) { return sizeof(double) * (size_t)wg_lds_doubles(d.E) + sizeof(uint16_t) * (size_t)d.tab_lds_words; }
-// workgroup width of the host-driven deterministic kernels (experiment knob)
-inline int det_threads() {
-  static const int v = [] { const char* e = getenv("SVO_BA_DET_THREADS"); const int t = e ? atoi(e) : 0; return t == 64 || t == 256 ? t : 128; }();
-  return v;
-}
-#define SVO_DET_LAUNCH(kernel, grid, lds, st, ...)                                                        \
-  do {                                                                                                    \
-    if (det_threads() == 64) hipLaunchKernelGGL(kernel<64>, grid, dim3(64), lds, st, __VA_ARGS__);        \
-    else if (det_threads() == 256) hipLaunchKernelGGL(kernel<256>, grid, dim3(256), lds, st, __VA_ARGS__); \
-    else hipLaunchKernelGGL(kernel<128>, grid, dim3(128), lds, st, __VA_ARGS__);                          \
-  } while (0)
+// workgroup width of the host-driven deterministic kernels: 128 (64, one wavefront doing everything: 1,553 against 1,620
+// frames/s single stream; 256: the same as 128 — measured in round 4, the kernels stay templates on it)
+#define SVO_DET_LAUNCH(kernel, grid, lds, st, ...) hipLaunchKernelGGL(kernel<128>, grid, dim3(128), lds, st, __VA_ARGS__)
 
 int op_linearize(void* user, double radius, int first, double* pay1_out) {
   svo_ba* ba = static_cast<svo_ba*>(user);
