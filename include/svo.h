@@ -211,8 +211,8 @@ typedef struct svo_ba_options {
   int accumulation;        /* how J^T J / the Schur products are summed: SVO_BA_ACC_* (default AUTO) */
 } svo_ba_options;
 
-/* AUTO: DETERMINISTIC (contribution slots + declared summation order: bit-identical to the oracle) while the
- * pair blocks fit, else MFMA when eligible (<= 22 poses, one observation per (landmark, pose)), else ATOMICS. */
+/* AUTO: DETERMINISTIC (per-chunk partial sums in the declared summation order: bit-identical to the oracle) while the
+ * partial store (wire elements x chunk groups x 16 bytes) fits 512 MB, else MFMA when eligible (<= 22 poses, one observation per (landmark, pose)), else ATOMICS. */
 enum { SVO_BA_ACC_AUTO = 0, SVO_BA_ACC_DETERMINISTIC = 1, SVO_BA_ACC_ATOMICS = 2, SVO_BA_ACC_MFMA = 3 };
 
 typedef struct svo_ba_summary {

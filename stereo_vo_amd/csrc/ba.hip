@@ -122,8 +122,8 @@ struct BaDev {
 // Scalars of the running LM iteration that the chained accept / radius decision needs (host/lm_decide.h).
 struct LmCtl { double cost, mcc, radius, decrease_factor; int chain; };
 
-// Pass A's contribution slots (and pass B's per-landmark scalars) cross workgroups — and XCDs, each with its own L2 —
-// inside ONE launch when the whole LM iteration is a single kernel.  Measured on MI355X (tools/exp/l2_invalidate.hip: a
+// A chunk's partial sums (and pass B's four sums) cross workgroups — and XCDs, each with its own L2 — inside ONE launch
+// when the whole solve is a single kernel.  Measured on MI355X (tools/exp/l2_invalidate.hip: a
 // pointer chase through L2-resident data, 88 ns per load alone): with other streams executing agent-scope fences the same
 // chase takes 295 / 830 / 1,480 ns per load (seq_cst = `buffer_wbl2` + `buffer_inv`, 1 / 4 / 8 aggressor streams), 190-390 ns
 // with release fences only (`buffer_wbl2`), 170-480 ns with acquire fences only (`buffer_inv`); kernel boundaries of
@@ -156,8 +156,8 @@ __device__ __forceinline__ void pay_store(double* p, double v) { __hip_atomic_st
 // memory, with release fences in front of the arrivals — and a second read microseconds later returned the new ones: the
 // counter (one memory channel) can be observed before a write-through store to another channel.  Replicated step
 // control turns one such read into workgroups that take different branches; the tag makes the hand-over independent of
-// any ordering between different addresses.  (The contribution slots keep the counter protocol: a late slot would show
-// as a parity failure, which the bit-exact tests have never seen; they are read once per command, by one workgroup.)
+// any ordering between different addresses.  Since round 4 EVERYTHING that crosses workgroups of a launch — the chunks'
+// partials included — travels this way (rounds 2-3 kept per-pair contribution slots under the counter protocol).
 __device__ __forceinline__ void granule_store(double* g, double v, unsigned long long tag) { slot_store2<true>(g, v, __longlong_as_double((long long)tag)); }
 // up to 8 granules per call, all loads in flight together; idx < 0: skipped.  Returns the mask of granules whose tag matched.
 __device__ __forceinline__ unsigned granule_load8(const double* base, const int (&idx)[8], unsigned long long tag, double (&out)[8]) {
