@@ -548,6 +548,21 @@ __device__ __forceinline__ double lds_seq_sum(double acc, const double* x, int c
   }
   return acc;
 }
+// Levels 1 + 2 of the declared order over the C chunk partials x[0], x[stride], ... of one element: groups of G consecutive
+// chunks, Q_g = P_c0 + P_c1 + ... from the group's first, total = Q_0 + Q_1 + ... from the first.  (Rounds 4's first version let
+// ONE workgroup run a group's chunks one after the other and keep the running group sum in the store; every chunk has its own
+// workgroup now — a 10-keyframe window has 200 chunks in groups of two, a 1280x720 window 1,500 in groups of twelve — and
+// the grouping is applied here, where the partials are read anyway.  Same additions in the same order.)
+__device__ __forceinline__ double grouped_seq_sum(const double* x, int C, int G, int stride) {
+  if (G <= 1) return lds_seq_sum(x[0], x + stride, C - 1, stride);
+  double total = 0.0;
+  for (int c0 = 0; c0 < C; c0 += G) {
+    const int m = min(G, C - c0);
+    const double q = lds_seq_sum(x[c0 * stride], x + (c0 + 1) * stride, m - 1, stride);
+    total = c0 == 0 ? q : total + q;
+  }
+  return total;
+}
 // LDS traffic of ONE wavefront is ordered; the fence only keeps the compiler from moving accesses across it
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1064,7 +1079,7 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += (int)blockDim.x) {
       const double* row = sm + el * NG;
-      out(eb + el, lds_seq_sum(row[0], row + 1, NG - 1, 1));
+      out(eb + el, grouped_seq_sum(row, NG, P.G, 1));
     }
     __syncthreads();
   }
@@ -1075,10 +1090,53 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
 // sequentially from the first.  sm: >= 4 * NG doubles of LDS, sOut: 4.  Ends with a barrier; false: a tag never showed up.
 __device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned long long tag, double* sm, double* sOut, int* s_flag) {
   const int NG = P.NG;
-  if (!wait_sentinels(P.part2 + 2 * ((size_t)parity * NG * 4), 3, 4, NG, tag, s_flag)) return false;
-  if (!fetch_granules(sm, P.part2 + 2 * ((size_t)parity * NG * 4), 4 * NG, tag)) *s_flag = 0;
+  const double* base = P.part2 + 2 * ((size_t)parity * NG * 4);
+  if (!wait_sentinels(base, 3, 4, NG, tag, s_flag)) return false;
+  if (P.G <= 1) {
+    if (!fetch_granules(sm, base, 4 * NG, tag)) *s_flag = 0;
+    __syncthreads();
+    if (threadIdx.x < 4) sOut[threadIdx.x] = lds_seq_sum(sm[threadIdx.x], sm + 4 + threadIdx.x, NG - 1, 4);
+    __syncthreads();
+    return *s_flag != 0;
+  }
+  // groups of G chunks (at most 128 of them): item = (group, scalar) forms the group's sum Q_g = P_c0 + P_c1 + ... itself,
+  // eight granules in flight; then the four totals Q_0 + Q_1 + ... — sm: 4 x groups doubles
+  const int G = P.G, ngroups = (NG + G - 1) / G;
+  bool good = true;
+  for (int item = threadIdx.x; item < 4 * ngroups; item += (int)blockDim.x) {
+    const int g = item >> 2, i = item & 3, c0 = g * G, m = min(G, NG - c0);
+    double q = 0.0;
+    for (int b0 = 0; b0 < m; b0 += 8) {
+      int gi[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gi[u] = b0 + u < m ? (c0 + b0 + u) * 4 + i : -1;
+      double v[8];
+      unsigned ok = granule_load8(base, gi, tag, v);
+      long long t0 = 0;
+      for (unsigned spins = 0; ok != 0xFFu; ++spins) {  // (the sentinels were seen: a granule under another tag is a rare late store)
+        __builtin_amdgcn_s_sleep(2);
+        if ((spins & 255u) == 255u) {
+          const long long tn = (long long)wall_clock64();
+          if (!t0) t0 = tn;
+          else if (tn - t0 > LM_WAIT_TICKS) break;
+        }
+        int again[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) again[u] = (ok >> u) & 1u ? -1 : gi[u];
+        double w[8];
+        const unsigned ok2 = granule_load8(base, again, tag, w);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (!((ok >> u) & 1u) && ((ok2 >> u) & 1u)) { v[u] = w[u]; ok |= 1u << u; }
+      }
+      good = good && ok == 0xFFu;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) if (b0 + u < m) q = (b0 + u == 0) ? v[u] : q + v[u];
+    }
+    sm[4 * g + i] = q;
+  }
+  if (!good) *s_flag = 0;
   __syncthreads();
-  if (threadIdx.x < 4) sOut[threadIdx.x] = lds_seq_sum(sm[threadIdx.x], sm + 4 + threadIdx.x, NG - 1, 4);
+  if (threadIdx.x < 4) sOut[threadIdx.x] = lds_seq_sum(sm[threadIdx.x], sm + 4 + threadIdx.x, ngroups - 1, 4);
   __syncthreads();
   return *s_flag != 0;
 }
@@ -1142,7 +1200,7 @@ __global__ __launch_bounds__(NT) void ba_linearize_det_kernel(BaDev P, double ra
   extern __shared__ double lds[];  // wg_lds_doubles(E)
   const WgLds L = wg_lds(lds, P.E);
   const int lane = threadIdx.x & 63, g = blockIdx.x;
-  const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
+  const int c0 = g, c1 = min(P.C, g + 1);  // one chunk per workgroup (the declared groups of G chunks are formed where the partials are summed)
   for (int chunk = c0; chunk < c1; ++chunk) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
     if (threadIdx.x < 64) R = load_obs(P, chunk, lane, P.points);
@@ -1165,7 +1223,7 @@ __global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl 
   const WgLds L = wg_lds(lds, P.E);
   double* rec = L.rec;
   const int lane = threadIdx.x & 63, g = blockIdx.x;
-  const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
+  const int c0 = g, c1 = min(P.C, g + 1);  // one chunk per workgroup (the declared groups of G chunks are formed where the partials are summed)
   // the first chunk's records are requested before the sums (both candidate landing points: the decision is not known yet)
   ObsRec Rc = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   D3 pc = Rc.p;
@@ -1222,7 +1280,7 @@ __global__ __launch_bounds__(NT) void ba_step_kernel(BaDev P, double radius, dou
   const WgLds L = wg_lds(lds, P.E);
   double* lms = L.rec;  // pass B's landmark scalars live in the idle staging rows
   const int lane = threadIdx.x & 63, g = blockIdx.x;
-  const int c0 = g * P.G, c1 = min(P.C, c0 + P.G);
+  const int c0 = g, c1 = min(P.C, g + 1);  // one chunk per workgroup (the declared groups of G chunks are formed where the partials are summed)
   // the observation records are requested BEFORE the step is staged: the HBM round trip and the PCIe round trip overlap
   ObsRec R = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   stage_step(P, sStep);
@@ -1270,8 +1328,10 @@ __device__ __forceinline__ void reduce_publish(const BaDev& P) {
 // Level 2 of the declared order, host-driven form: workgroup b < nb1 sums RED_EPB wire elements -> pay1_out (pinned host
 // memory, or the device buffer an all-reduce follows on); one more workgroup sums payload2 (and, single rank with a chained
 // step, takes the decision for the pass-A launch queued behind).  The last workgroup to arrive publishes the completion word.
-constexpr int RED_EPB = 64, RED_LDS_DOUBLES = 4096;
-__host__ __device__ inline int ba_reduce_blocks(int E) { return (E + RED_EPB - 1) / RED_EPB; }
+constexpr int RED_LDS_DOUBLES = 4096;
+// wire elements per workgroup of the reduce launch: all partials of its elements in LDS at once (64 elements up to 64 chunks, fewer beyond)
+__host__ __device__ inline int ba_reduce_epb(int NG) { const int e = RED_LDS_DOUBLES / (NG > 0 ? NG : 1); return e > 64 ? 64 : (e < 1 ? 1 : e); }
+__host__ __device__ inline int ba_reduce_blocks(int E, int NG) { const int epb = ba_reduce_epb(NG); return (E + epb - 1) / epb; }
 
 __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, int with_pay2, LmCtl ctl) {
   svo_latency_critical();
@@ -1279,10 +1339,10 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
   __shared__ double sOut[4];
   __shared__ int sFlag;
   const int tid = threadIdx.x, b = blockIdx.x;
-  const int nb1 = with_pay1 ? ba_reduce_blocks(P.E) : 0;
+  const int nb1 = with_pay1 ? ba_reduce_blocks(P.E, P.NG) : 0, epb = ba_reduce_epb(P.NG);
   if (b < nb1) {
     double* out = P.pay1_out;
-    (void)reduce_elements(P, b * RED_EPB, min(P.E, (b + 1) * RED_EPB), P.pay_tag, sm, RED_LDS_DOUBLES, &sFlag, [out](int e, double v) { pay_store(&out[e], v); });
+    (void)reduce_elements(P, b * epb, min(P.E, (b + 1) * epb), P.pay_tag, sm, RED_LDS_DOUBLES, &sFlag, [out](int e, double v) { pay_store(&out[e], v); });
   } else if (with_pay2) {
     (void)sum_pay2(P, P.pay_parity, P.pay_tag, sm, sOut, &sFlag);
     if (tid < 4) pay_store(&P.pay2_out[tid], sOut[tid]);
@@ -2614,7 +2674,7 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
     // deterministic mode ("chunk order"): G chunks per group, NG groups, E wire elements; the partial store holds E x NG granules
     const int nU = F * (F + 1) / 2;
     d.G = d.C <= 128 ? 1 : (d.C + 127) / 128;
-    d.NG = d.C > 0 ? (d.C + d.G - 1) / d.G : 0;
+    d.NG = d.C;  // partials in the store: one per chunk (the groups of G are applied by the level-2 sums)
     d.E = 36 * nU + 33 * F + 2;
     d.Epad = (d.E + 7) & ~7;
     d.det = (size_t)d.Epad * (size_t)(d.NG > 0 ? d.NG : 1) * 16 <= ((size_t)512 << 20) ? 1 : 0;
@@ -3214,7 +3274,7 @@ int op_linearize(void* user, double radius, int first, double* pay1_out) {
       SvoProfScope prof(ctx, SVO_PROF_BA_LINEARIZE, st);
       SVO_DET_LAUNCH(ba_linearize_det_kernel, dim3(d.NG), wave_lds_bytes(d), st, d, radius, first, (const double*)nullptr);  // one wave per workgroup: spreads the chunks over the CUs
     }
-    const int nb = d.NG > 0 ? ba_reduce_blocks(d.E) : 0;
+    const int nb = d.NG > 0 ? ba_reduce_blocks(d.E, d.NG) : 0;
     if (nb > 0) {
       ba_aim_reduce(ba, nb, true);
       hipLaunchKernelGGL(ba_reduce_kernel, dim3(nb), dim3(256), 0, st, d, 1, 0, kNoCtl);
@@ -3274,7 +3334,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
   const bool next = same_sweep || chain;
   if (d.det && d.NG > 0) {
     (void)ba_next_tag(ba);
-    const int nb = ba_reduce_blocks(d.E);
+    const int nb = ba_reduce_blocks(d.E, d.NG);
     {
       SvoProfScope prof(ctx, SVO_PROF_BA_STEP, st);
       SVO_DET_LAUNCH(ba_step_kernel, dim3(d.NG), wave_lds_bytes(d), st, d, radius, same_sweep ? spec_radius : 0.0);
