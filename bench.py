@@ -4,8 +4,10 @@
 Default line = "48 concurrent streams as 2 pipeline groups, inputs resident in HBM": a compute rate.  The same 16 frames per
 stream are re-processed every step from a reset pipeline (identical work per step, no upload in the timed region);
 `--workload kitti_stream` is the streaming figure (BASELINE configs[2]: 4541 frames through the host-pointer entry,
-upload included, 10-keyframe window, nothing reset).  The default line also carries `other_workloads` (kitti_stream, ba50k
-sparse and dense, hd_1280x720_10k), each with its own roofline / cpu_baseline / parity record.
+upload included, 10-keyframe window, nothing reset).  The default line also carries `streaming` (the same lanes fed from host
+memory through svo_pipeline_group_staging / _upload / _process_uploaded, upload timed), `single_stream`, `parity_self` (every
+lane of every timed step against the first step) and `parity_vs_cpu` (8 lanes against the CPU oracle), and `other_workloads`
+(kitti_stream, ba50k sparse and dense, hd_1280x720_10k), each with its own roofline / cpu_baseline / parity record.
 
 A "step" = one pass of the whole hot path on every one of `--streams` (default 48) independent stereo streams that share the
 GPU — as `--groups` (default 2) pipeline groups (svo_pipeline_group_*: one host thread per group, one kernel launch per stage
@@ -20,8 +22,8 @@ N GPUs: the frame stream shards across ranks (rank r processes its own sequence 
 data-path collective — SURVEY §8e "front end / frames").  value = frames all ranks processed / max-over-
 ranks time.  The BA all-reduce path (config 4) is benchmarked with --workload ba50k.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, HIP
-events on the library's stream) and `cpu_baseline` (oracle pipeline on the host cores, rank 0, N=1 only).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (the front end's contract figure; the dominant
+kernel = ba_lm_kernel with live HIP-event duration and live algorithmic flops / bytes; the tracker on VALU issue) and `cpu_baseline` (oracle pipeline on the host cores, rank 0, N=1 only).
 """
 import argparse
 import ctypes as C
@@ -31,8 +33,8 @@ import re
 import sys
 import time
 
-# HIP runtime knob, read when the runtime initialises (profiles/r03_group_sweep.txt has 4 / 8 / 12 / 16 / 20 / 24):
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # two pipeline groups use 2 x 7 HIP streams; with 4 hardware queues their long solve launches share queues with the tracking launches and serialise (measured 9.9 k vs 16 k frames/s)
+# HIP runtime knob, read when the runtime initialises (profiles/r04_exp_hw_queues.txt: 4 / 8 / 12 / 16; r03_group_sweep.txt also 20 / 24):
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # two pipeline groups use 2 x 9 HIP streams; with 4 hardware queues their long solve launches share queues with the tracking launches and serialise (measured 11.6 k vs 19.4 k frames/s)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
