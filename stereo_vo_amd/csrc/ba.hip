@@ -98,7 +98,8 @@ struct BaDev {
   double f = 0, cx = 0, cy = 0;
   // deterministic mode (chunk order): per-chunk destination tables + the partial store
   int det = 0;
-  int G = 1, NG = 0, Epad = 0, E = 0;    // chunks per group, groups, granules per group row (E rounded up), wire-format elements
+  int G = 1, NG = 0, Epad = 0, E = 0;    // chunks per declared group, partials in the store, granules per partial (E rounded up), wire-format elements
+  int CPW = 1, GS = 1;                   // chunks per workgroup = per stored partial (1, or G for very large problems: the workgroup then forms its group's sum itself), and stored partials per declared group in the level-2 sums (G / CPW)
   const uint16_t* tab = nullptr;   // chunk tables back to back (u16 words), see ba_build_tables
   const uint32_t* tab_off = nullptr;  // C + 1 offsets into tab
   int tab_lds_words = 0;              // host-driven kernels: u16 words of LDS behind the workgroup's staging area for its chunk's table (0: read from global memory)
@@ -1079,7 +1080,7 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += (int)blockDim.x) {
       const double* row = sm + el * NG;
-      out(eb + el, grouped_seq_sum(row, NG, P.G, 1));
+      out(eb + el, grouped_seq_sum(row, NG, P.GS, 1));
     }
     __syncthreads();
   }
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned lo
   const int NG = P.NG;
   const double* base = P.part2 + 2 * ((size_t)parity * NG * 4);
   if (!wait_sentinels(base, 3, 4, NG, tag, s_flag)) return false;
-  if (P.G <= 1) {
+  if (P.GS <= 1) {
     if (!fetch_granules(sm, base, 4 * NG, tag)) *s_flag = 0;
     __syncthreads();
     if (threadIdx.x < 4) sOut[threadIdx.x] = lds_seq_sum(sm[threadIdx.x], sm + 4 + threadIdx.x, NG - 1, 4);
@@ -1101,7 +1102,7 @@ __device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned lo
   }
   // groups of G chunks (at most 128 of them): item = (group, scalar) forms the group's sum Q_g = P_c0 + P_c1 + ... itself,
   // eight granules in flight; then the four totals Q_0 + Q_1 + ... — sm: 4 x groups doubles
-  const int G = P.G, ngroups = (NG + G - 1) / G;
+  const int G = P.GS, ngroups = (NG + G - 1) / G;
   bool good = true;
   for (int item = threadIdx.x; item < 4 * ngroups; item += (int)blockDim.x) {
     const int g = item >> 2, i = item & 3, c0 = g * G, m = min(G, NG - c0);
@@ -1200,7 +1201,7 @@ __global__ __launch_bounds__(NT) void ba_linearize_det_kernel(BaDev P, double ra
   extern __shared__ double lds[];  // wg_lds_doubles(E)
   const WgLds L = wg_lds(lds, P.E);
   const int lane = threadIdx.x & 63, g = blockIdx.x;
-  const int c0 = g, c1 = min(P.C, g + 1);  // one chunk per workgroup (the declared groups of G chunks are formed where the partials are summed)
+  const int c0 = g * P.CPW, c1 = min(P.C, c0 + P.CPW);  // one chunk per workgroup (the declared groups of G chunks are then formed where the partials are summed) unless the partial store would get too large: then a workgroup runs its group's G chunks one after the other
   for (int chunk = c0; chunk < c1; ++chunk) {
     ObsRec R{false, 0, 0, 0, lane, 0, D3{0, 0, 1}, 0.0, 0.0};
     if (threadIdx.x < 64) R = load_obs(P, chunk, lane, P.points);
@@ -1223,7 +1224,7 @@ __global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl 
   const WgLds L = wg_lds(lds, P.E);
   double* rec = L.rec;
   const int lane = threadIdx.x & 63, g = blockIdx.x;
-  const int c0 = g, c1 = min(P.C, g + 1);  // one chunk per workgroup (the declared groups of G chunks are formed where the partials are summed)
+  const int c0 = g * P.CPW, c1 = min(P.C, c0 + P.CPW);  // one chunk per workgroup (the declared groups of G chunks are then formed where the partials are summed) unless the partial store would get too large: then a workgroup runs its group's G chunks one after the other
   // the first chunk's records are requested before the sums (both candidate landing points: the decision is not known yet)
   ObsRec Rc = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   D3 pc = Rc.p;
@@ -1280,7 +1281,7 @@ __global__ __launch_bounds__(NT) void ba_step_kernel(BaDev P, double radius, dou
   const WgLds L = wg_lds(lds, P.E);
   double* lms = L.rec;  // pass B's landmark scalars live in the idle staging rows
   const int lane = threadIdx.x & 63, g = blockIdx.x;
-  const int c0 = g, c1 = min(P.C, g + 1);  // one chunk per workgroup (the declared groups of G chunks are formed where the partials are summed)
+  const int c0 = g * P.CPW, c1 = min(P.C, c0 + P.CPW);  // one chunk per workgroup (the declared groups of G chunks are then formed where the partials are summed) unless the partial store would get too large: then a workgroup runs its group's G chunks one after the other
   // the observation records are requested BEFORE the step is staged: the HBM round trip and the PCIe round trip overlap
   ObsRec R = load_obs(P, c0 < P.C ? c0 : 0, lane, P.points);
   stage_step(P, sStep);
@@ -2674,7 +2675,11 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
     // deterministic mode ("chunk order"): G chunks per group, NG groups, E wire elements; the partial store holds E x NG granules
     const int nU = F * (F + 1) / 2;
     d.G = d.C <= 128 ? 1 : (d.C + 127) / 128;
-    d.NG = d.C;  // partials in the store: one per chunk (the groups of G are applied by the level-2 sums)
+    // partials in the store: one per chunk (the groups of G are applied by the level-2 sums) while that stays below 64 MB —
+    // a 1280x720 window: 1,500 chunks x 1,920 elements = 46 MB; config 4 (6,900 chunks x 7,472 elements) keeps one partial per GROUP
+    d.CPW = (size_t)((36 * nU + 33 * F + 2 + 7) & ~7) * (size_t)d.C * 16 <= ((size_t)64 << 20) ? 1 : d.G;
+    d.GS = d.G / d.CPW;
+    d.NG = d.C > 0 ? (d.C + d.CPW - 1) / d.CPW : 0;
     d.E = 36 * nU + 33 * F + 2;
     d.Epad = (d.E + 7) & ~7;
     d.det = (size_t)d.Epad * (size_t)(d.NG > 0 ? d.NG : 1) * 16 <= ((size_t)512 << 20) ? 1 : 0;
