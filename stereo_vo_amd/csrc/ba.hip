@@ -1031,7 +1031,9 @@ __device__ __forceinline__ bool fetch_granules(double* dst, const double* src, i
 // Level 2 for the wire elements [e0, e1): the NG group sums of every element (granules under `tag`) added sequentially,
 // starting from the first.  sm: >= sm_doubles doubles of LDS; out(e, total).  Any workgroup size, block-uniform arguments;
 // ends with a barrier.  false (block-uniform): a tag never showed up.
-template <typename Out>
+// GROUPED: the stored partials are summed in declared groups of P.GS (large windows of the host-driven path); ba_lm_kernel's
+// problems have one chunk per group and instantiate the plain form only (its code is larger than the instruction cache as it is)
+template <bool GROUPED, typename Out>
 __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, unsigned long long tag, double* sm, int sm_doubles, int* s_flag, Out out, long long* t_waited = nullptr) {
   const int NG = P.NG, Epad = P.Epad;
   const int per_round = max(1, sm_doubles / NG);
@@ -1080,7 +1082,7 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
     __syncthreads();
     for (int el = threadIdx.x; el < ne; el += (int)blockDim.x) {
       const double* row = sm + el * NG;
-      out(eb + el, grouped_seq_sum(row, NG, P.GS, 1));
+      out(eb + el, GROUPED ? grouped_seq_sum(row, NG, P.GS, 1) : lds_seq_sum(row[0], row + 1, NG - 1, 1));
     }
     __syncthreads();
   }
@@ -1089,11 +1091,12 @@ __device__ __forceinline__ bool reduce_elements(const BaDev& P, int e0, int e1, 
 
 // payload2: the NG group sums of pass B's four scalars (granules under `tag`, half `parity` of the store) added
 // sequentially from the first.  sm: >= 4 * NG doubles of LDS, sOut: 4.  Ends with a barrier; false: a tag never showed up.
+template <bool GROUPED>
 __device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned long long tag, double* sm, double* sOut, int* s_flag) {
   const int NG = P.NG;
   const double* base = P.part2 + 2 * ((size_t)parity * NG * 4);
   if (!wait_sentinels(base, 3, 4, NG, tag, s_flag)) return false;
-  if (P.GS <= 1) {
+  if (!GROUPED || P.GS <= 1) {
     if (!fetch_granules(sm, base, 4 * NG, tag)) *s_flag = 0;
     __syncthreads();
     if (threadIdx.x < 4) sOut[threadIdx.x] = lds_seq_sum(sm[threadIdx.x], sm + 4 + threadIdx.x, NG - 1, 4);
@@ -1230,7 +1233,7 @@ __global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl 
   D3 pc = Rc.p;
   if (Rc.active) pc = D3{P.cand_points[3 * Rc.j], P.cand_points[3 * Rc.j + 1], P.cand_points[3 * Rc.j + 2]};
   ChunkTab T = stage_chunk_tab(P, c0 < P.C ? c0 : 0, L);  // on its way to LDS while the sums are collected
-  (void)sum_pay2(P, P.pay_parity, P.pay_tag, rec, sOut, &sFlag);  // pass B's launch is complete: the tags are there
+  (void)sum_pay2<true>(P, P.pay_parity, P.pay_tag, rec, sOut, &sFlag);  // pass B's launch is complete: the tags are there
   const SvoLmDecision dec = svo_lm_decide(ctl.cost, ctl.mcc, ctl.radius, ctl.decrease_factor, sOut[0], sOut[1]);
   if (blockIdx.x == 0 && threadIdx.x < 6)
     pay_store(&P.pay2_out[threadIdx.x], threadIdx.x < 4 ? sOut[threadIdx.x] : (threadIdx.x == 4 ? (double)dec.accept : dec.next_radius));
@@ -1343,9 +1346,9 @@ __global__ __launch_bounds__(256) void ba_reduce_kernel(BaDev P, int with_pay1, 
   const int nb1 = with_pay1 ? ba_reduce_blocks(P.E, P.NG) : 0, epb = ba_reduce_epb(P.NG);
   if (b < nb1) {
     double* out = P.pay1_out;
-    (void)reduce_elements(P, b * epb, min(P.E, (b + 1) * epb), P.pay_tag, sm, RED_LDS_DOUBLES, &sFlag, [out](int e, double v) { pay_store(&out[e], v); });
+    (void)reduce_elements<true>(P, b * epb, min(P.E, (b + 1) * epb), P.pay_tag, sm, RED_LDS_DOUBLES, &sFlag, [out](int e, double v) { pay_store(&out[e], v); });
   } else if (with_pay2) {
-    (void)sum_pay2(P, P.pay_parity, P.pay_tag, sm, sOut, &sFlag);
+    (void)sum_pay2<true>(P, P.pay_parity, P.pay_tag, sm, sOut, &sFlag);
     if (tid < 4) pay_store(&P.pay2_out[tid], sOut[tid]);
     if (ctl.chain) {  // single rank: these ARE the global sums; decide here, pass A is queued right behind this launch
       if (tid == 0) decide_device(ctl, sOut[0], sOut[1], P.ctl_dev, P.pay2_out);
@@ -1581,7 +1584,7 @@ __device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs,
   if (st == LMS_STEP) {
     // payload2: a chained step formed it (and the decision) inside the pass; otherwise collect the group sums now
     if (!cs.chain) {
-      if (!sum_pay2(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+      if (!sum_pay2<false>(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
       if (tid < 4) cs.pay2[tid] = sOut4[tid];
       __syncthreads();
     }
@@ -1860,7 +1863,7 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
     stamp(1);
     // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits (the staging
     // rows are idle between the passes: they are the scratch of the collection)
-    const bool ok = sum_pay2(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
+    const bool ok = sum_pay2<false>(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
     if (!ok) return false;
     if (tid == 0) {
       const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, sh.sOut[0], sh.sOut[1]);
@@ -1890,7 +1893,7 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
   double* res = a.dev_res;
   const unsigned long long tag = P.pay_tag;
   bool ok = true;
-  if (e0 < e1) ok = reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); }, tp ? tp + 5 : nullptr);
+  if (e0 < e1) ok = reduce_elements<false>(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); }, tp ? tp + 5 : nullptr);
   if (blockIdx.x == 0 && tid == 0)  // the clock every controller tests (see the kernel's header): seconds since this workgroup's first pass
     granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
   stamp(4);
@@ -2016,7 +2019,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
       const int e0 = min(P.E, (int)blockIdx.x * per), e1 = min(P.E, e0 + per);
       double* res = a.dev_res;
       const unsigned long long tag = P.pay_tag;
-      if (e0 < e1 && !reduce_elements(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); })) return;
+      if (e0 < e1 && !reduce_elements<false>(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); })) return;
       if (blockIdx.x == 0 && tid == 0) granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
     }
     __syncthreads();
