@@ -1521,7 +1521,7 @@ __device__ __forceinline__ bool lm_fetch_totals(double* cP, double* cU, const do
 // Controller turn (every thread of every workgroup; identical inputs -> identical state everywhere): consume the
 // finished pass, run host/lm.cpp's step control up to the next pass.  Leaves the next pass' step block
 // [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
-__device__ int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* cSc, double* sStep, double* sOut4) {
+__device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* cSc, double* sStep, double* sOut4) {
   const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
   const int grid = (P.C + LM_CPW - 1) / LM_CPW;  // workgroups of THIS solve (the launch may hold several solves)
   const int pay1 = n * n + 3 * n + 2;
@@ -1826,18 +1826,23 @@ __device__ __forceinline__ void lm_owner_phases(const BaDev& P, const LmWave& W,
   chunk_owner_phases<false>(W.R, T, o, L.rec, make_sink(P, (int)blockIdx.x * LM_CPW + wave, 1, L.pst), L.s_ne, t_schur);
 }
 
-// One LM step inside ba_lm_kernel (LMOP_ITERATE): pass B, [the decision,] pass A, this workgroup's slice of level 2.
+// One command of ba_lm_kernel's passes: LMOP_ITERATE = pass B, [the decision,] pass A, this workgroup's slice of level 2;
+// LMOP_LINEARIZE = pass A alone at the current point, then level 2.  ONE instance of every stage's code (prefix, suffix,
+// owner phases, level 2) serves all of them: the kernel is larger than the instruction cache, and every inlined copy of a
+// stage that this function used to hold (three of pass A's) cost every pass of every solve misses — measured: 5 KB more code,
+// nowhere near pass A, made pass A 1.8 us slower.
 __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, LmWave& W, bool my_wave_works, const uint16_t* tabs, const WgLds& L,
-                                           double* union_lds, int union_doubles, LmDevState& cs, double* sStep, LmShared& sh, int n_blocks, long long t_first, long long* tp) {
+                                           double* union_lds, int union_doubles, LmDevState& cs, double* sStep, LmShared& sh, int n_blocks, long long t_first, long long* tp,
+                                           bool linearize_only) {
   const int tid = threadIdx.x, wave = tid >> 6;
   long long tmark = tp && tid == 0 ? (long long)wall_clock64() : 0;
   auto stamp = [&](int slot) { if (tp && tid == 0) { const long long tn = (long long)wall_clock64(); tp[slot] += tn - tmark; tmark = tn; } };
   const double* dc_ = sStep;
   const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
   const double* cur_poses_ = cand_poses_ + 7 * P.K;
-  const double radius = cs.radius, spec_radius = cs.spec;
-  const int chain = cs.chain;
-  const int with_pay1 = chain || spec_radius > 0;
+  const double radius = cs.radius, spec_radius = linearize_only ? 0.0 : cs.spec;
+  const int chain = linearize_only ? 0 : cs.chain;
+  const int with_pay1 = linearize_only || chain || spec_radius > 0;
   const int my_chunk = (int)blockIdx.x * LM_CPW + wave;
   double* lms = L.rec;  // this wavefront's own LDS: pass B's landmark scalars live in the idle staging rows
   double unused0 = 0, unused1 = 0, unused2 = 0, unused3 = 0;
@@ -1845,39 +1850,39 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
   LinPre pre;
   SufRegs o;
   o.freep = false;
-  if (my_wave_works) {
+  if (!linearize_only && my_wave_works)
     backsub_chunk(P, W.R, cur_poses_, cand_poses_, dc_, P.cand_points, radius, W.cand, unused0, unused1, unused2, unused3, &W.c, lms, &sink);
-    if (spec_radius > 0) {  // same sweep: pass A at the candidate with the predicted radius
-      ObsRec Rc = W.R;
-      Rc.p = W.cand;
-      linearize_prefix(P, Rc, cand_poses_, pre, unused0);
-      suffix_math(P, Rc, pre, spec_radius, 0, L.rec, &W.c, o);
-    }
-  }
   stamp(0);
-  if (spec_radius > 0) lm_owner_phases(P, W, my_wave_works, o, tabs, L);
-  if (chain) {
-    ObsRec Rc = W.R;
-    Rc.p = W.cand;
-    if (my_wave_works) linearize_prefix(P, Rc, cand_poses_, pre, unused0);  // the other wavefronts' sums are on their way meanwhile
-    stamp(1);
-    // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits (the staging
-    // rows are idle between the passes: they are the scratch of the collection)
-    const bool ok = sum_pay2<false>(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
-    if (!ok) return false;
-    if (tid == 0) {
-      const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, sh.sOut[0], sh.sOut[1]);
-      sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius;
-      cs.pay2[0] = sh.sOut[0]; cs.pay2[1] = sh.sOut[1]; cs.pay2[2] = sh.sOut[2]; cs.pay2[3] = sh.sOut[3];
-      cs.pay2[4] = (double)dec.accept; cs.pay2[5] = dec.next_radius;
+  if (with_pay1) {
+    // what pass A linearises: the current point (a linearisation alone: first one, or after a rejected / mispredicted step), or
+    // the candidate pass B just formed (same sweep: with the predicted radius; chained: with the radius of the decision below)
+    ObsRec Ra = W.R;
+    const double* poses_a = cur_poses_;
+    double radius_a = radius;
+    const int first_a = linearize_only ? cs.first : 0;
+    if (!linearize_only) { Ra.p = W.cand; poses_a = cand_poses_; radius_a = spec_radius; }
+#pragma nounroll
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      if (my_wave_works) linearize_prefix(P, Ra, poses_a, pre, unused0);  // radius-free; in a chained step the other wavefronts' sums are on their way meanwhile
+      if (!chain || attempt == 1) break;
+      stamp(1);
+      // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits (the staging
+      // rows are idle between the passes: they are the scratch of the collection)
+      const bool ok = sum_pay2<false>(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
+      if (!ok) return false;
+      if (tid == 0) {
+        const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, sh.sOut[0], sh.sOut[1]);
+        sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius;
+        cs.pay2[0] = sh.sOut[0]; cs.pay2[1] = sh.sOut[1]; cs.pay2[2] = sh.sOut[2]; cs.pay2[3] = sh.sOut[3];
+        cs.pay2[4] = (double)dec.accept; cs.pay2[5] = dec.next_radius;
+      }
+      __syncthreads();
+      stamp(2);
+      radius_a = sh.sDec[1];
+      if (sh.sDec[0] != 0.0) break;  // accepted: the prefix at the candidate is the one to use
+      Ra = W.R; poses_a = cur_poses_;  // rejected: the radius-free part again, at the current point
     }
-    __syncthreads();
-    stamp(2);
-    if (my_wave_works) {
-      const bool accept = sh.sDec[0] != 0.0;
-      if (!accept) linearize_prefix(P, W.R, cur_poses_, pre, unused0);  // rejected: the radius-free part again, at the current point
-      suffix_math(P, accept ? Rc : W.R, pre, sh.sDec[1], 0, L.rec, &W.c, o);
-    }
+    if (my_wave_works) suffix_math(P, Ra, pre, radius_a, first_a, L.rec, &W.c, o);
     stamp(10);  // the lanes' own arithmetic behind the decision
     if (tp && tid == 0) tp[12] -= tmark;
     lm_owner_phases(P, W, my_wave_works, o, tabs, L, tp ? tp + 12 : nullptr);  // slot 12: Schur owners alone; slot 3 (below): all owner phases
@@ -2000,28 +2005,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
       continue;  // the next controller turn answers "delivered": everybody leaves
     }
     long long* tp = a.dbg ? cs.tp : nullptr;
-    if (op == LMOP_ITERATE) {
-      if (!lm_iterate(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, tp)) return;
-    } else {  // pass A alone at the current point, then level 2
-      const int first = cs.first;
-      const double radius = cs.radius;
-      SufRegs o;
-      o.freep = false;
-      if (my_wave_works) {
-        LinPre pre;
-        double unused = 0.0;
-        linearize_prefix(P, W.R, sStep + nn + 7 * K, pre, unused);
-        suffix_math(P, W.R, pre, radius, first, L.rec, &W.c, o);
-      }
-      lm_owner_phases(P, W, my_wave_works, o, tabs, L);
-      __syncthreads();
-      const int per = (P.E + n_blocks - 1) / n_blocks;
-      const int e0 = min(P.E, (int)blockIdx.x * per), e1 = min(P.E, e0 + per);
-      double* res = a.dev_res;
-      const unsigned long long tag = P.pay_tag;
-      if (e0 < e1 && !reduce_elements<false>(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); })) return;
-      if (blockIdx.x == 0 && tid == 0) granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
-    }
+    if (!lm_iterate(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, op == LMOP_ITERATE ? tp : nullptr, op != LMOP_ITERATE)) return;
     __syncthreads();
   }
 }
