@@ -19,13 +19,66 @@ __device__ __forceinline__ double svo_readlane_f64(double v, int k) {
 }
 
 // Dense SPD solve in LDS by the calling workgroup (128 threads).  A: n x n row-major, lower triangle read, overwritten by
-// L; b: right-hand side, overwritten by the solution; col: n doubles of scratch.  Right-looking: after column j is
+// L; b: right-hand side, overwritten by the solution; col: 4 n + 1 doubles of scratch (n for n > 64).  Right-looking: after column j is
 // final, every trailing element (i, c), j < c <= i, receives  -= l_ij * l_cj  — the same subtraction, in the same
 // ascending-k position of its sequence, as the left-looking loop.  Returns false (in every thread) when a pivot is not
 // positive.  Ends with a barrier.
 __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, double* col) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tr = tid >> 3, tc = tid & 7, rstep = nt >> 3;  // trailing update: 8 columns x (threads / 8) rows per sweep
+  if (n <= 64) {
+    // Panels of PW columns (as host/linalg.cpp): the first wavefront finishes a panel in registers — lane = row, a column's values
+    // cross lanes through v_readlane — and only then the workgroup meets for the trailing update, which applies the panel's columns
+    // to an element one after the other in ascending order.  Two barriers per PANEL instead of two per column; every element still
+    // receives  a_ic - l_i0 l_c0 - l_i1 l_c1 - ...  in ascending k, so the bits are those of the column-by-column form below.
+    // col: PW x n doubles (the panel's columns, col[q * n + i] = L[i][j0 + q]); col[PW * n] carries the verdict.
+    constexpr int PW = 4;
+    for (int j0 = 0; j0 < n; j0 += PW) {
+      const int bw = n - j0 < PW ? n - j0 : PW;
+      if (tid < 64) {
+        const bool in = tid < n && tid >= j0;
+        double pcol[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) pcol[q] = (in && q < bw) ? A[tid * n + j0 + q] : 0.0;
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+          if (q < bw && ok) {  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < q; ++r) pcol[q] -= pcol[r] * svo_readlane_f64(pcol[r], j0 + q);  // rows below the panel's r-th pivot hold l_i,j0+r; ascending r
+            const double s = svo_readlane_f64(pcol[q], j0 + q);
+            ok = s > 0;
+            if (ok) {
+              const double l = sqrt(s);
+              const double v = pcol[q] / l;
+              pcol[q] = tid == j0 + q ? l : (tid > j0 + q ? v : 0.0);  // (rows above the pivot take no part in later columns of the panel)
+            }
+          }
+        }
+        if (ok) {
+#pragma unroll
+          for (int q = 0; q < PW; ++q)
+            if (q < bw && in && tid >= j0 + q) { A[tid * n + j0 + q] = pcol[q]; col[q * n + tid] = pcol[q]; }
+        }
+        if (tid == 0) col[PW * n] = ok ? 1.0 : -1.0;
+      }
+      __syncthreads();
+      if (!(col[PW * n] > 0.0)) { __syncthreads(); return false; }  // uniform
+      const int t0 = j0 + bw;  // first trailing row / column
+      for (int i = t0 + tr; i < n; i += rstep) {
+        double li[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) li[q] = q < bw ? col[q * n + i] : 0.0;
+        for (int c = t0 + tc; c <= i; c += 8) {
+          double v = A[i * n + c];
+#pragma unroll
+          for (int q = 0; q < PW; ++q) if (q < bw) v -= li[q] * col[q * n + c];
+          A[i * n + c] = v;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   for (int j = 0; j < n; ++j) {
     const double s = A[j * n + j];
     if (!(s > 0)) {  // uniform: every thread reads the same word
@@ -41,6 +94,7 @@ __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, doubl
       for (int c = j + 1 + tc; c <= i; c += 8) A[i * n + c] -= li * col[c];
     }
     __syncthreads();
+  }
   }
   if (tid < 64 && n <= 64) {
     // substitutions by the first wavefront, lane = row, x in a register; L is final (barrier above), so its loads do not
