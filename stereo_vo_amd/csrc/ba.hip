@@ -1528,7 +1528,7 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
   double* cP = cl;             // payload image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
   double* cDf = cP + pay1;
   double* cRhs = cDf + nn;
-  double* cCol = cRhs + nn;    // the Cholesky's panel columns: 4 n + 1 doubles, over cTerm and cU (both dead while it runs; 2 n + 35 K - 21 >= 4 n + 1)
+  double* cCol = cRhs + nn;    // the Cholesky's panel columns: 6 n + 1 doubles, over cTerm and cU (both dead while it runs; 2 n + 35 K - 21 >= 6 n + 1 = 36 K - 35)
   double* cTerm = cCol + nn;   // nn + 14 K: per-element terms of the sequential sums
   double* cU = cTerm + nn + 14 * K;  // 21 F: the U triangles on their way into the diagonal blocks
   double* cDc = sStep;         // the step block is built in place

@@ -5,7 +5,7 @@
 #include "lm_device.h"
 
 __global__ __launch_bounds__(128) void cholesky_solve_kernel(double* __restrict__ A, double* __restrict__ b, int n, int* __restrict__ ok_out) {
-  extern __shared__ double lds[];  // A (n x n) | b (n) | col (4 n + 1: the panel columns of svo_dev_cholesky_solve)
+  extern __shared__ double lds[];  // A (n x n) | b (n) | col (6 n + 1: the panel columns of svo_dev_cholesky_solve)
   double* sA = lds;
   double* sb = sA + n * n;
   double* col = sb + n;
@@ -22,7 +22,7 @@ extern "C" int svo_cholesky_solve_dev(svo_ctx* ctx, double* A, double* b, int n)
   if (!ctx || !A || !b || n < 0) return SVO_ERR_INVALID;
   svo_use_device(ctx);
   if (n == 0) return SVO_OK;
-  const size_t lds = sizeof(double) * ((size_t)n * n + 5 * (size_t)n + 1);
+  const size_t lds = sizeof(double) * ((size_t)n * n + 7 * (size_t)n + 1);
   SVO_REQUIRE(ctx, lds <= 150 * 1024, "cholesky_solve_dev: system too large for one workgroup's LDS");
   SvoScratch s(ctx);
   double* dA = s.take<double>((size_t)n * n);

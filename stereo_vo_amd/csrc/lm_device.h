@@ -19,7 +19,7 @@ __device__ __forceinline__ double svo_readlane_f64(double v, int k) {
 }
 
 // Dense SPD solve in LDS by the calling workgroup (128 threads).  A: n x n row-major, lower triangle read, overwritten by
-// L; b: right-hand side, overwritten by the solution; col: 4 n + 1 doubles of scratch (n for n > 64).  Right-looking: after column j is
+// L; b: right-hand side, overwritten by the solution; col: 6 n + 1 doubles of scratch (n for n > 64).  Right-looking: after column j is
 // final, every trailing element (i, c), j < c <= i, receives  -= l_ij * l_cj  — the same subtraction, in the same
 // ascending-k position of its sequence, as the left-looking loop.  Returns false (in every thread) when a pivot is not
 // positive.  Ends with a barrier.
@@ -27,12 +27,13 @@ __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, doubl
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tr = tid >> 3, tc = tid & 7, rstep = nt >> 3;  // trailing update: 8 columns x (threads / 8) rows per sweep
   if (n <= 64) {
-    // Panels of PW columns (as host/linalg.cpp): the first wavefront finishes a panel in registers — lane = row, a column's values
+    // Panels of PW columns (as host/linalg.cpp; 6 = one pose block of the reduced camera system: 7.8 us for n = 24 against 8.3 with
+    // panels of 4 and 9.9 column by column): the first wavefront finishes a panel in registers — lane = row, a column's values
     // cross lanes through v_readlane — and only then the workgroup meets for the trailing update, which applies the panel's columns
     // to an element one after the other in ascending order.  Two barriers per PANEL instead of two per column; every element still
     // receives  a_ic - l_i0 l_c0 - l_i1 l_c1 - ...  in ascending k, so the bits are those of the column-by-column form below.
     // col: PW x n doubles (the panel's columns, col[q * n + i] = L[i][j0 + q]); col[PW * n] carries the verdict.
-    constexpr int PW = 4;
+    constexpr int PW = 6;
     for (int j0 = 0; j0 < n; j0 += PW) {
       const int bw = n - j0 < PW ? n - j0 : PW;
       if (tid < 64) {
