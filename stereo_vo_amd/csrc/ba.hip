@@ -1441,7 +1441,10 @@ constexpr int LM_CPW = 2;
 __host__ __device__ static inline int ba_wire_elements(int K) { const int F = K - 1; return 18 * F * (F + 1) + 33 * F + 2; }
 __host__ __device__ static inline size_t ba_lm_union_doubles(int n, int K) { const size_t a = (size_t)LM_CPW * (size_t)wg_lds_doubles(ba_wire_elements(K)), b = ba_lm_ctl_doubles(n, K); return a > b ? a : b; }
 __host__ __device__ static inline size_t ba_lm_lds_doubles(int n, int K, int tab_words /* per wavefront, a multiple of 4, <= TAB_LDS_WORDS */) {
-  return ba_lm_union_doubles(n, K) + (size_t)LM_CPW * (size_t)tab_words / 4 + 2 * (size_t)(n > 0 ? n : 1) + 14 * (size_t)K;
+  // behind the union and the tables: Jacobi scales (nn) | spare (nn) | step block [dc (nn) | candidate poses (7 K) | current poses (7 K)] — the kernel's
+  // carve-up (cSc, sStep).  (Until the end of round 4 this said 2 nn: the current poses' tail lay nn doubles beyond the allocation, inside the
+  // allocation granule for the 5-keyframe window and outside it from n = 36 on — NaN poses, found when larger windows first took this kernel.)
+  return ba_lm_union_doubles(n, K) + (size_t)LM_CPW * (size_t)tab_words / 4 + 3 * (size_t)(n > 0 ? n : 1) + 14 * (size_t)K;
 }
 
 // The E wire totals (granules under `tag`) -> the payload image [S | g_red | g_c | diag U | cost | sum g_p^2] in LDS, assembled as
@@ -3060,14 +3063,15 @@ int ba_lm_admission_cost(int grid, size_t lds, int device) {
 inline FusedAdmission* ba_resident_admission(svo_ba* ba) { return &ba->res_admission; }
 
 // ---- device-resident solve (ba_lm_kernel): host side -------------------------------------------------------------
-// SVO_BA_DEVICE_LM=0 / 1 forces; default: on for every window-sized single-rank deterministic solve that is admitted.
-// Default for svo_ba_solve / svo_ba_solve_problem: on while more than two pipelines are inside process_batch (a solve that
-// never comes back to the host costs 52 us per LM iteration whatever else runs; the host-driven loop 35 us alone on the GPU,
-// 52-57 with eight streams and a host thread per stream).  A pipeline group always uses it (svo_ba_solve_launch).
+// SVO_BA_DEVICE_LM=0 / 1 forces; default since the end of round 4: ON for every window-sized single-rank deterministic solve that
+// is eligible and admitted — one stream alone on the GPU runs 1,715-1,745 frames/s with it against 1,745-1,750 with the host-driven
+// loop (41 against 40 us per LM iteration), many streams were always faster with it, and no host thread sits in the loop.
+// (Rounds 3-4 kept the host loop for a lone stream: the device loop was 51 / 45 us per iteration then.)  A pipeline group always
+// uses it (svo_ba_solve_launch); larger windows (more than 128 chunks) take the host-driven loop.
 bool ba_device_lm_wanted() {
   static const char* e = getenv("SVO_BA_DEVICE_LM");
   if (e && *e) return atoi(e) != 0;
-  return svo_throughput_mode();
+  return true;
 }
 
 int ba_lm_tab_words(const svo_ba* ba) { return std::max(64, (ba->tab_max_words + 63) & ~63); }

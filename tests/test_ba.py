@@ -149,6 +149,29 @@ def test_hip_ba_matches_oracle(ctx, seed, K, N, dense, device_lm):
 
 
 @pytest.mark.gpu
+def test_hip_device_solve_equals_the_host_driven_loop_for_every_window_size(ctx):
+    """Windows of 2 .. 14 poses, a dozen landmarks (one chunk, one workgroup) and a few hundred (a few dozen chunks): the
+    device-resident solve must take the host-driven loop's trajectory bit for bit.  (Regression: the kernel's LDS size was
+    short by n doubles — inside the allocation granule for the reference's 5-keyframe window, outside it from n = 36 on: NaN
+    poses for some windows of 7 and more keyframes, found when single pipelines started to use the kernel by default.)"""
+    import stereo_vo_amd as S
+    for K in range(2, 15):
+        for N in (12, 300):
+            p = BP.make_problem(K, K, N, dense=False)
+            res = []
+            for dev in (False, True):
+                ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8,
+                              max_observations=len(p["op"]) + 8, max_time_s=0.0, device_lm=dev)
+                ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+                s = ba.solve_problem()
+                poses, pts = ba.read_problem()
+                res.append((s.iterations, s.termination, s.initial_cost, s.final_cost, poses.tobytes(), pts.tobytes()))
+                ba.close()
+            assert res[0][:4] == res[1][:4], (K, N, res[0][:4], res[1][:4])
+            assert res[0][4] == res[1][4] and res[0][5] == res[1][5], (K, N)
+
+
+@pytest.mark.gpu
 def test_hip_device_solve_twice_on_one_load_continues_from_the_solved_state(ctx):
     """The device-resident solve reads the problem image from pinned memory in place (no upload in front of it).  A second
     solve of the SAME load must start from the solved landmarks and poses (the host image is refreshed first), exactly as
