@@ -2667,7 +2667,8 @@ static int ba_upload_checked(svo_ba* ba, int K, const double* poses7, int npts, 
     d.G = d.C <= 128 ? 1 : (d.C + 127) / 128;
     // partials in the store: one per chunk (the groups of G are applied by the level-2 sums) while that stays below 64 MB —
     // a 1280x720 window: 1,500 chunks x 1,920 elements = 46 MB; config 4 (6,900 chunks x 7,472 elements) keeps one partial per GROUP
-    d.CPW = (size_t)((36 * nU + 33 * F + 2 + 7) & ~7) * (size_t)d.C * 16 <= ((size_t)64 << 20) ? 1 : d.G;
+    // (and at most 2,048 partials: the level-2 reducers hold all partials of an element in 4,096 doubles of LDS)
+    d.CPW = ((size_t)((36 * nU + 33 * F + 2 + 7) & ~7) * (size_t)d.C * 16 <= ((size_t)64 << 20) && d.C <= 2048) ? 1 : d.G;
     d.GS = d.G / d.CPW;
     d.NG = d.C > 0 ? (d.C + d.CPW - 1) / d.CPW : 0;
     d.E = 36 * nU + 33 * F + 2;

@@ -421,3 +421,21 @@ def test_declared_orders_agree():
             f.write("poses  landmarks  observations  LM iterations (both)  |final cost difference| / cost  max translation difference (m)\n")
             for r in rows:
                 f.write("%5d  %9d  %12d  %20d  %30.3e  %30.3e\n" % r)
+
+
+@pytest.mark.gpu
+def test_hip_deterministic_solve_with_more_chunks_than_stored_partials(ctx):
+    """Beyond 2,048 chunks (or 64 MB of partials) the store keeps one partial per declared GROUP of chunks and a workgroup runs its
+    group's chunks one after the other; below, every chunk has its own workgroup and the groups are formed by the level-2 sums.
+    Same declared order either way: a 3-pose problem with ~150 k observations (~2,400 chunks, groups of 19) against the oracle."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(21, 3, 70000, dense=False)
+    assert len(p["op"]) > 64 * 2048
+    ba = S.api.BA(ctx, 3, BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0,
+                  max_iterations=6, accumulation="deterministic", device_lm=False)
+    ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+    s = ba.solve_problem()
+    po, pto, so = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=8, max_iterations=6)
+    assert s.iterations == so["iterations"]
+    assert s.initial_cost == so["initial_cost"] and s.final_cost == so["final_cost"]
+    ba.close()
