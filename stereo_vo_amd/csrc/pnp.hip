@@ -362,24 +362,44 @@ __device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __r
         for (int c = r; c < 6; ++c) { v[o] += J[r] * J[c] + J[6 + r] * J[6 + c]; ++o; }
       }
     }
+    // the declared binary tree (partial t += partial t + s for s = 128, 64, .., 1).  The two levels that cross wavefronts go
+    // through LDS (128 rows, then 64 of them again), the six inside the first wavefront through lane shifts: t + s is lane
+    // t + s of the same wavefront for s <= 32 — the same additions, partial t on the left — and the workgroup needs 28 KB of
+    // LDS instead of 57 (a CU that holds three resident solves has 13 KB left: the 57 KB form waited for one of them to end).
+    if (tid >= 128) {
 #pragma unroll
-    for (int e = 0; e < 28; ++e) sPart[tid][e] = v[e];
-    __syncthreads();
-    // the declared binary tree (partial t += partial t + s for s = 128, 64, .., 1), element-parallel: the s x 28
-    // independent additions of a level are spread over all 256 threads instead of 28 sequential ones on s of them
-    for (int s = 128; s > 0; s >>= 1) {
-      double* lo = &sPart[0][0];
-      const double* hi = &sPart[s][0];
-      for (int i = tid; i < s * 28; i += 256) lo[i] += hi[i];
-      __syncthreads();
+      for (int e = 0; e < 28; ++e) sPart[tid - 128][e] = v[e];
     }
+    __syncthreads();
+    if (tid < 128) {
+#pragma unroll
+      for (int e = 0; e < 28; ++e) v[e] += sPart[tid][e];
+    }
+    __syncthreads();
+    if (tid >= 64 && tid < 128) {
+#pragma unroll
+      for (int e = 0; e < 28; ++e) sPart[tid - 64][e] = v[e];
+    }
+    __syncthreads();
+    if (tid < 64) {
+#pragma unroll
+      for (int e = 0; e < 28; ++e) v[e] += sPart[tid][e];
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) {
+#pragma unroll
+        for (int e = 0; e < 28; ++e) v[e] += __shfl_down(v[e], s);  // lanes >= s compute values nobody reads
+      }
+    }
+    __syncthreads();  // every thread is done reading sPart
     if (tid == 0) {
       int o = 0;
       for (int r = 0; r < 6; ++r) {
-        g[r] = sPart[0][21 + r];
-        for (int c = r; c < 6; ++c) H[6 * r + c] = sPart[0][o++];
+        g[r] = v[21 + r];
+        for (int c = r; c < 6; ++c) H[6 * r + c] = v[o++];
       }
+      sPart[0][27] = v[27];
     }
+    __syncthreads();
     const double cost = sPart[0][27];
     __syncthreads();
     return cost;
@@ -408,10 +428,10 @@ __device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __r
 template <typename Src>
 __device__ __forceinline__ void pnp_fused_body(const SvoPnpLane& a, const Src& src) {
   svo_latency_critical();
-  __shared__ double sPart[256][28];  // first the four hypotheses' LDS, then the refinement's partial sums
+  __shared__ double sPart[128][28];  // first the four hypotheses' LDS, then the refinement's partial sums (the tree's two cross-wavefront levels)
   __shared__ LmShared S;
   __shared__ int sBase, sLast, sBest;
-  static_assert(4 * sizeof(HypLds) <= sizeof(double) * 256 * 28, "the hypotheses' LDS must fit the refinement's");
+  static_assert(4 * sizeof(HypLds) <= sizeof(double) * 128 * 28, "the hypotheses' LDS must fit the refinement's");
   const int tid = threadIdx.x, wave = tid >> 6;
   const int h = blockIdx.x * 4 + wave;
   if ((int)blockIdx.x * 4 >= a.launched) return;  // (a launch carries lanes with different hypothesis counts: not this lane's workgroup)
