@@ -642,10 +642,18 @@ __global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
   if (f < n) {
     const Pyr A = make_pyr(a.pyr_prev, g.w, g.h, a.l0_prev), B = make_pyr(a.pyr_next, g.w, g.h, a.l0_next);
     const float x0 = a.xy[2 * f], y0 = a.xy[2 * f + 1];
-    float fx, fy, bx = 0.f, by = 0.f;
-    const uint8_t s1 = lk_point(A, B, x0, y0, &fx, &fy, S);
-    uint8_t s2 = 0;
-    if (s1) s2 = lk_point(B, A, fx, fy, &bx, &by, S);
+    // forward, then backward from the forward result: ONE instance of the tracker's code serves both directions (the two inlined
+    // copies were 31 KB of code next to a 107 KB solve kernel on the same instruction cache)
+    float fx = 0.f, fy = 0.f, bx = 0.f, by = 0.f, px = x0, py = y0;
+    uint8_t s1 = 0, s2 = 0;
+#pragma nounroll
+    for (int dir = 0; dir < 2; ++dir) {
+      const Pyr P0 = dir ? B : A, P1 = dir ? A : B;
+      float ox, oy;
+      const uint8_t st = lk_point(P0, P1, px, py, &ox, &oy, S);
+      if (dir == 0) { s1 = st; fx = ox; fy = oy; px = ox; py = oy; if (!st) break; }
+      else { s2 = st; bx = ox; by = oy; }
+    }
     if (lane == 0) {
       uint8_t k = 0;
       float par = 0.f;
