@@ -203,34 +203,33 @@ __global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* 
 // the surviving corners keep their detection order, as after the separate, order-preserving dedup compaction.
 __global__ __launch_bounds__(256) void stereo_triangulate_group_kernel(SvoStereoTriLanes g) {
   const SvoStereoTriLane& a = g.lane[blockIdx.y];
-  if (!a.trk) {
-    stereo_triangulate_body(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, a.xy, a.n_dev, a.n_max, a.disp, a.M, a.kept_xy, a.xyz,
-                            nullptr, a.n_kept, a.pub);
-    return;
-  }
   svo_latency_critical();
   __shared__ int sWaveT[4];
   __shared__ int sLast, sHit;
-  const int n = a.n_max, f = blockIdx.x;
-  if (f < n) {
+  const int n = a.n_dev ? *a.n_dev : a.n_max, f = blockIdx.x;
+  if (f < n) {  // (one instance of the block matcher for the first keyframe — no tracked features to keep away from — and all later ones)
     const float x = a.xy[2 * f], y = a.xy[2 * f + 1];
-    if (threadIdx.x < 64) {
-      const int lane = threadIdx.x;
-      bool hit = false;
-      for (int j0 = 0; j0 < a.n_trk && !hit; j0 += 64) {
-        const int j = j0 + lane;
-        bool h = false;
-        if (j < a.n_trk) {
-          const float dx = x - a.trk[2 * j], dy = y - a.trk[2 * j + 1];
-          h = sqrtf(dx * dx + dy * dy) < a.min_d;  // src/image_processor.cpp:118-123
+    bool dup = false;
+    if (a.trk) {  // uniform in the workgroup
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        bool hit = false;
+        for (int j0 = 0; j0 < a.n_trk && !hit; j0 += 64) {
+          const int j = j0 + lane;
+          bool h = false;
+          if (j < a.n_trk) {
+            const float dx = x - a.trk[2 * j], dy = y - a.trk[2 * j + 1];
+            h = sqrtf(dx * dx + dy * dy) < a.min_d;  // src/image_processor.cpp:118-123
+          }
+          hit = __any(h);
         }
-        hit = __any(h);
+        if (lane == 0) sHit = hit ? 1 : 0;
       }
-      if (lane == 0) sHit = hit ? 1 : 0;
+      __syncthreads();
+      dup = sHit != 0;  // workgroup-uniform
     }
-    __syncthreads();
-    const bool dup = sHit != 0;  // workgroup-uniform
     float d = 0.f;
+    // at<float>(it->y, it->x): truncation (SURVEY C-13)
     if (!dup) d = stereo_at_block(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, (int)x, (int)y);
     if (threadIdx.x == 0) svo_wt_store(&a.disp[f], d);
   }
