@@ -1584,6 +1584,7 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
   __syncthreads();
   if (a.dbg && tid == 0) cs.tp[11] = (long long)wall_clock64();
 
+  bool fetch = true;  // (a stand-alone pass A has finished)
   if (st == LMS_STEP) {
     // payload2: a chained step formed it (and the decision) inside the pass; otherwise collect the group sums now
     if (!cs.chain) {
@@ -1641,13 +1642,18 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
     if (cs.accepted) for (int i = tid; i < 7 * K; i += nt) cPose[i] = cCand[i];
     // the totals of the pass A that rode along are collected even when they are not used: every slice owner has posted
     // them under this command's tag, and the elapsed time travels with them
-    const bool with_pay1 = cs.chain != 0 || cs.spec > 0;
-    if (with_pay1) {
-      if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
-      if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
-      if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
-    }
-    __syncthreads();
+    fetch = cs.chain != 0 || cs.spec > 0;
+  }
+  // the totals of a pass A: a stand-alone one's are the linearisation in use; one that rode along with a step is collected even
+  // when it is not used (every slice owner has posted it under this command's tag, and the elapsed time travels with it).
+  // ONE call site: the collection is 3 KB of code in a kernel that is larger than the instruction cache.
+  if (fetch) {
+    if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
+    if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+    if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
+  }
+  __syncthreads();
+  if (st == LMS_STEP) {
     act = cs.act;
     const bool relin = act == ACT_ACCEPT_TAIL && cs.relin;
     __syncthreads();  // thread 0 writes cs.act again below
@@ -1656,11 +1662,6 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
       return issue(LMOP_LINEARIZE);
     }
   } else {
-    // a stand-alone pass A has finished: its totals are the linearisation in use
-    if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
-    if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
-    if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
-    __syncthreads();
     if (st == LMS_FIRST) {
       if (tid == 0) { cs.cost = cP[pay1 - 2]; cs.initial_cost = cs.cost; }
       for (int q = tid; q < n; q += nt) cSc[q] = 1.0 / (1.0 + sqrt(cP[n * n + 2 * n + q]));

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
     const Pyr A = make_pyr(a.pyr_prev, g.w, g.h, a.l0_prev), B = make_pyr(a.pyr_next, g.w, g.h, a.l0_next);
     const float x0 = a.xy[2 * f], y0 = a.xy[2 * f + 1];
     // forward, then backward from the forward result: ONE instance of the tracker's code serves both directions (the two inlined
-    // copies were 31 KB of code next to a 107 KB solve kernel on the same instruction cache)
+    // copies were 31 KB of code next to the 71 KB of the solve kernel on the same instruction cache)
     float fx = 0.f, fy = 0.f, bx = 0.f, by = 0.f, px = x0, py = y0;
     uint8_t s1 = 0, s2 = 0;
 #pragma nounroll
