@@ -633,7 +633,8 @@ __global__ __launch_bounds__(LKT * FPB) void lk_fb_kernel(const uint8_t* __restr
 // Register budget: the natural 123 VGPRs.  Measured with 80 (amdgpu_waves_per_eu(6, 6): three tracker wavefronts instead of two
 // fit next to a 256-VGPR wavefront of a resident solve): +1.5 % frames/s, but the 22 spilled values of the per-level set-up
 // cost 9 MB of scratch traffic per stereo pair (3.7 -> 12.8 MB for this kernel, profiles/r03_traffic.json of that build).
-__global__ __launch_bounds__(64) void lk_fb_group_kernel(SvoLkLanes g) {
+// (four wavefronts per SIMD are pinned: the kernel sits at 126 VGPRs, and a build that needed 176 cost 13 % of the frame rate)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lk_fb_group_kernel(SvoLkLanes g) {
   static_assert(LKT == 64 && FPB == 1, "the stream-batched tracker is written for one wavefront per feature");
   __shared__ LkShared S;
   __shared__ int sLast;
