@@ -66,7 +66,8 @@ __device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, 
   constexpr int LC = MAX_BLOCK + 2;              // raw left cols
   constexpr int RC = MAX_BLOCK + 2 + MAX_NDISP;  // raw right cols
   __shared__ uint8_t sLr[PR][LC + 1], sRr[PR][RC + 1];
-  __shared__ uint8_t sLp[MAX_BLOCK][MAX_BLOCK + 3], sRp[MAX_BLOCK][MAX_BLOCK + MAX_NDISP + 3];
+  __shared__ __align__(16) uint8_t sLp[MAX_BLOCK][MAX_BLOCK + 3], sRp[MAX_BLOCK][MAX_BLOCK + MAX_NDISP + 3];  // rows are whole dwords (24 and 88 bytes): the SAD reads them as such
+  static_assert((MAX_BLOCK + 3) % 4 == 0 && (MAX_BLOCK + MAX_NDISP + 3) % 4 == 0 && MAX_BLOCK % 4 == 1, "dword rows; the packed SAD below is written for 21 = 5 dwords + 1 byte");
   __shared__ int sSad[MAX_NDISP + 2];
   __shared__ int sT;
   const int rows = block + 2, lcols = block + 2, rcols = block + 1 + ndisp;
@@ -132,8 +133,30 @@ __device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, 
   const int lane = tid & 63, wave = tid >> 6;
   if (lane < ndisp) {
     int acc = 0;
-    for (int r = wave; r < block; r += 4)
-      for (int c = 0; c < block; ++c) acc += abs((int)sLp[r][c] - (int)sRp[r][c + lane]);  // R col = x-half+c-d
+    if (block == MAX_BLOCK) {
+      // packed: a row of the left patch is 5 dwords + 1 byte, the right row starts `lane` bytes in — seven aligned dwords,
+      // byte-aligned in registers — and v_sad_u8 sums four absolute differences per instruction: 13 LDS reads + 12 ALU
+      // instructions per row instead of 42 + 63 (exact integers: the same sums)
+      constexpr int LW = (MAX_BLOCK + 3) / 4, RW = (MAX_BLOCK + MAX_NDISP + 3) / 4;
+      const uint32_t* Lw = reinterpret_cast<const uint32_t*>(&sLp[0][0]);
+      const uint32_t* Rw = reinterpret_cast<const uint32_t*>(&sRp[0][0]);
+      const int sh = lane & 3, w0 = lane >> 2;
+      unsigned a4 = 0;
+      for (int r = wave; r < MAX_BLOCK; r += 4) {
+        uint32_t l[LW], q[LW + 1];
+#pragma unroll
+        for (int k = 0; k < LW; ++k) l[k] = Lw[LW * r + k];
+#pragma unroll
+        for (int k = 0; k < LW + 1; ++k) q[k] = Rw[RW * r + w0 + k];
+#pragma unroll
+        for (int k = 0; k < LW - 1; ++k) a4 = __builtin_amdgcn_sad_u8(l[k], __builtin_amdgcn_alignbyte(q[k + 1], q[k], sh), a4);
+        a4 = __builtin_amdgcn_sad_u8(l[LW - 1] & 0xFFu, __builtin_amdgcn_alignbyte(q[LW], q[LW - 1], sh) & 0xFFu, a4);
+      }
+      acc = (int)a4;
+    } else {
+      for (int r = wave; r < block; r += 4)
+        for (int c = 0; c < block; ++c) acc += abs((int)sLp[r][c] - (int)sRp[r][c + lane]);  // R col = x-half+c-d
+    }
     atomicAdd(&sSad[lane + 1], acc);
   }
   if (wave == 0) {  // texture sum by one wave
