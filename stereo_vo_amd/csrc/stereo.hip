@@ -57,8 +57,14 @@ __device__ __forceinline__ int bm_select(int* s /* points at index 0, s[-1] and 
 
 // Sparse StereoBM at one feature pixel (x, y) by one 256-thread workgroup; the disparity is returned in thread 0.
 // Control flow is workgroup-uniform (the function contains barriers).
-__device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
-                                                 int stride, int ndisp, int block, int x, int y) {
+// BLOCK_C / NDISP_C: the block size and disparity range as compile-time constants (0: the run-time arguments).  The staging and
+// the prefilter index their patches by  i / columns, i % columns : with run-time column counts every one of those is an integer
+// division sequence (22 of them per thread in the staging alone); the reference's values (21, 48: src/image_processor.cpp:174)
+// get their own instance, in which they are multiplications.
+template <int BLOCK_C, int NDISP_C>
+__device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
+                                                   int stride, int ndisp_rt, int block_rt, int x, int y) {
+  const int ndisp = NDISP_C ? NDISP_C : ndisp_rt, block = BLOCK_C ? BLOCK_C : block_rt;
   const int tid = threadIdx.x;
   const int half = block / 2;
   if (!(x >= ndisp - 1 + half && x < W - half && y >= half && y < H - half)) return -1.0f;  // workgroup-uniform
@@ -169,6 +175,12 @@ __device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, 
   float d = 0.f;
   if (tid == 0) d = (float)bm_select(sSad + 1, ndisp, sT) * svo_ref::STEREO_DISPARITY_SCALE;
   return d;
+}
+__device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
+                                                 int stride, int ndisp, int block, int x, int y) {
+  if (block == svo_ref::STEREO_BLOCK_SIZE && ndisp == svo_ref::STEREO_NUM_DISPARITIES)  // workgroup-uniform
+    return stereo_at_block_t<svo_ref::STEREO_BLOCK_SIZE, svo_ref::STEREO_NUM_DISPARITIES>(L, R, W, H, stride, ndisp, block, x, y);
+  return stereo_at_block_t<0, 0>(L, R, W, H, stride, ndisp, block, x, y);
 }
 
 __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
