@@ -61,7 +61,9 @@ __device__ __forceinline__ int bm_select(int* s /* points at index 0, s[-1] and 
 // the prefilter index their patches by  i / columns, i % columns : with run-time column counts every one of those is an integer
 // division sequence (22 of them per thread in the staging alone); the reference's values (21, 48: src/image_processor.cpp:174)
 // get their own instance, in which they are multiplications.
-template <int BLOCK_C, int NDISP_C>
+// NT: threads that work on the feature together — the 256 of a workgroup, or 64: ONE wavefront per feature (the grouped launch
+// with the reference's sizes: a quarter of the wavefronts, no wavefront parked at a workgroup barrier while another stages).
+template <int BLOCK_C, int NDISP_C, int NT>
 __device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
                                                    int stride, int ndisp_rt, int block_rt, int x, int y) {
   const int ndisp = NDISP_C ? NDISP_C : ndisp_rt, block = BLOCK_C ? BLOCK_C : block_rt;
@@ -82,39 +84,40 @@ __device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L
   // and disparity range) before the first LDS store waits for any of them — a plain copy loop with a run-time trip count
   // is compiled as load, wait, store per iteration: ten dependent trips to L2 / HBM per feature
   {
-    constexpr int NL = (PR * LC + 255) / 256, NR = (PR * RC + 255) / 256;
+    constexpr int RCC = NDISP_C ? MAX_BLOCK + 2 + NDISP_C : RC;  // right columns actually staged when the range is a constant
+    constexpr int NL = (PR * LC + NT - 1) / NT, NR = (PR * RCC + NT - 1) / NT;
     uint8_t vl[NL], vr[NR];
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NT * k;
       const int ic = min(i, rows * lcols - 1);  // unconditional load of a valid address: predication would put a wait behind each load
       const int r = ic / lcols, c = ic % lcols;
       vl[k] = L[(size_t)pf_row(ly0 + r, H) * stride + min(max(lx0 + c, 0), W - 1)];
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NT * k;
       const int ic = min(i, rows * rcols - 1);
       const int r = ic / rcols, c = ic % rcols;
       vr[k] = R[(size_t)pf_row(ly0 + r, H) * stride + min(max(rx0 + c, 0), W - 1)];
     }
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NT * k;
       if (i < rows * lcols) sLr[i / lcols][i % lcols] = vl[k];
     }
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int i = tid + 256 * k;
+      const int i = tid + NT * k;
       if (i < rows * rcols) sRr[i / rcols][i % rcols] = vr[k];
     }
   }
-  if (tid < MAX_NDISP + 2) sSad[tid] = 0;
+  for (int i = tid; i < MAX_NDISP + 2; i += NT) sSad[i] = 0;
   if (tid == 0) sT = 0;
   __syncthreads();
   // prefilter in LDS: the staged rows are already row-reflected, so the vertical taps are r-1, r, r+1
   const int pcols_r = block + ndisp - 1;
-  for (int i = tid; i < block * block; i += 256) {
+  for (int i = tid; i < block * block; i += NT) {
     const int r = i / block, c = i % block;
     const int gx = x - half + c, gy = y - half + r;
     int v = CAP;
@@ -124,7 +127,7 @@ __device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L
     }
     sLp[r][c] = (uint8_t)v;
   }
-  for (int i = tid; i < block * pcols_r; i += 256) {
+  for (int i = tid; i < block * pcols_r; i += NT) {
     const int r = i / pcols_r, c = i % pcols_r;
     const int gx = x - half - (ndisp - 1) + c, gy = y - half + r;
     int v = CAP;
@@ -148,7 +151,7 @@ __device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L
       const uint32_t* Rw = reinterpret_cast<const uint32_t*>(&sRp[0][0]);
       const int sh = lane & 3, w0 = lane >> 2;
       unsigned a4 = 0;
-      for (int r = wave; r < MAX_BLOCK; r += 4) {
+      for (int r = wave; r < MAX_BLOCK; r += NT / 64) {
         uint32_t l[LW], q[LW + 1];
 #pragma unroll
         for (int k = 0; k < LW; ++k) l[k] = Lw[LW * r + k];
@@ -160,7 +163,7 @@ __device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L
       }
       acc = (int)a4;
     } else {
-      for (int r = wave; r < block; r += 4)
+      for (int r = wave; r < block; r += NT / 64)
         for (int c = 0; c < block; ++c) acc += abs((int)sLp[r][c] - (int)sRp[r][c + lane]);  // R col = x-half+c-d
     }
     atomicAdd(&sSad[lane + 1], acc);
@@ -176,11 +179,13 @@ __device__ __forceinline__ float stereo_at_block_t(const uint8_t* __restrict__ L
   if (tid == 0) d = (float)bm_select(sSad + 1, ndisp, sT) * svo_ref::STEREO_DISPARITY_SCALE;
   return d;
 }
+template <int NT>
 __device__ __forceinline__ float stereo_at_block(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R, int W, int H,
                                                  int stride, int ndisp, int block, int x, int y) {
-  if (block == svo_ref::STEREO_BLOCK_SIZE && ndisp == svo_ref::STEREO_NUM_DISPARITIES)  // workgroup-uniform
-    return stereo_at_block_t<svo_ref::STEREO_BLOCK_SIZE, svo_ref::STEREO_NUM_DISPARITIES>(L, R, W, H, stride, ndisp, block, x, y);
-  return stereo_at_block_t<0, 0>(L, R, W, H, stride, ndisp, block, x, y);
+  if (NT == 64 || (block == svo_ref::STEREO_BLOCK_SIZE && ndisp == svo_ref::STEREO_NUM_DISPARITIES))  // workgroup-uniform; the one-wavefront form is launched for these sizes only
+    return stereo_at_block_t<svo_ref::STEREO_BLOCK_SIZE, svo_ref::STEREO_NUM_DISPARITIES, NT>(L, R, W, H, stride, ndisp, block, x, y);
+  if constexpr (NT != 64) return stereo_at_block_t<0, 0, NT>(L, R, W, H, stride, ndisp, block, x, y);
+  return 0.f;
 }
 
 __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restrict__ L, const uint8_t* __restrict__ R,
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(256) void stereo_at_kernel(const uint8_t* __restric
   const int f = blockIdx.x;
   if (f >= n) return;
   // at<float>(it->y, it->x): truncation (SURVEY C-13)
-  const float d = stereo_at_block(L, R, W, H, stride, ndisp, block, (int)xy[2 * f], (int)xy[2 * f + 1]);
+  const float d = stereo_at_block<256>(L, R, W, H, stride, ndisp, block, (int)xy[2 * f], (int)xy[2 * f + 1]);
   if (threadIdx.x == 0) disp[f] = d;
 }
 
@@ -211,7 +216,7 @@ __device__ __forceinline__ void stereo_triangulate_body(const uint8_t* __restric
   const int n = n_dev ? *n_dev : n_host;
   const int f = blockIdx.x;
   if (f < n) {
-    const float d = stereo_at_block(L, R, W, H, stride, ndisp, block, (int)xy[2 * f], (int)xy[2 * f + 1]);
+    const float d = stereo_at_block<256>(L, R, W, H, stride, ndisp, block, (int)xy[2 * f], (int)xy[2 * f + 1]);
     if (threadIdx.x == 0) svo_wt_store(&disp[f], d);
   }
   if (!svo_last_arrival(pub.arrive, pub.target, &sLast)) return;
@@ -236,10 +241,11 @@ __global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* 
 // 15 us of work): wavefront 0 of a corner's workgroup tests it against the tracked inliers exactly as dedup_body does
 // (sqrtf(dx^2 + dy^2) < min_d); a duplicate gets disparity 0, which the triangulation's validity test (d > 0, :194) drops —
 // the surviving corners keep their detection order, as after the separate, order-preserving dedup compaction.
-__global__ __launch_bounds__(256) void stereo_triangulate_group_kernel(SvoStereoTriLanes g) {
+template <int NT>
+__global__ __launch_bounds__(NT) void stereo_triangulate_group_kernel(SvoStereoTriLanes g) {
   const SvoStereoTriLane& a = g.lane[blockIdx.y];
   svo_latency_critical();
-  __shared__ int sWaveT[4];
+  __shared__ int sWaveT[NT / 64];
   __shared__ int sLast, sHit;
   const int n = a.n_dev ? *a.n_dev : a.n_max, f = blockIdx.x;
   if (f < n) {  // (one instance of the block matcher for the first keyframe — no tracked features to keep away from — and all later ones)
@@ -265,11 +271,11 @@ __global__ __launch_bounds__(256) void stereo_triangulate_group_kernel(SvoStereo
     }
     float d = 0.f;
     // at<float>(it->y, it->x): truncation (SURVEY C-13)
-    if (!dup) d = stereo_at_block(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, (int)x, (int)y);
+    if (!dup) d = stereo_at_block<NT>(a.left, a.right, g.w, g.h, g.stride, g.ndisp, g.block, (int)x, (int)y);
     if (threadIdx.x == 0) svo_wt_store(&a.disp[f], d);
   }
   if (!svo_last_arrival(a.pub.arrive, a.pub.target, &sLast)) return;
-  svo_triangulate_block<256, true>(a.xy, a.disp, n, a.M, a.kept_xy, a.xyz, nullptr, a.n_kept, sWaveT);
+  svo_triangulate_block<NT, true>(a.xy, a.disp, n, a.M, a.kept_xy, a.xyz, nullptr, a.n_kept, sWaveT);
   SvoPublish one = a.pub;
   one.arrive = nullptr;  // the arrivals have been counted: this workgroup publishes alone
   svo_publish_block(one);
@@ -277,7 +283,11 @@ __global__ __launch_bounds__(256) void stereo_triangulate_group_kernel(SvoStereo
 
 int svo_kg_stereo_triangulate(svo_ctx* ctx, hipStream_t st, const SvoStereoTriLanes& lanes, int n_lanes, int grid_x) {
   SvoProfScope prof(ctx, SVO_PROF_STEREO_AT, st);
-  hipLaunchKernelGGL(stereo_triangulate_group_kernel, dim3(grid_x, n_lanes), dim3(256), 0, st, lanes);
+  // one wavefront per corner for the reference's block size and range (the instance with compile-time patch sizes), else a workgroup
+  if (lanes.block == svo_ref::STEREO_BLOCK_SIZE && lanes.ndisp == svo_ref::STEREO_NUM_DISPARITIES)
+    hipLaunchKernelGGL(stereo_triangulate_group_kernel<64>, dim3(grid_x, n_lanes), dim3(64), 0, st, lanes);
+  else
+    hipLaunchKernelGGL(stereo_triangulate_group_kernel<256>, dim3(grid_x, n_lanes), dim3(256), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }
