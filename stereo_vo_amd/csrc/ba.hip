@@ -3039,6 +3039,10 @@ int ba_fused_budget(int device) {
   // workgroup the occupancy query promises, so one per CU is left out of the count
   const int usable = per_cu >= 3 ? per_cu - 1 : (per_cu >= 1 ? 1 : 0);
   budget[device] = usable * cus / 8 * 7 * g_ba_cu_share / 32;  // a CU-masked stream holds proportionally fewer workgroups
+  if (const char* e = getenv("SVO_BA_BUDGET_PERCENT")) {  // developer experiments (profiles/r04_exp_admission_budget.txt)
+    const int pct = atoi(e);
+    if (pct >= 10 && pct <= 400) budget[device] = (int)((long long)budget[device] * pct / 100);
+  }
   return budget[device];
 }
 

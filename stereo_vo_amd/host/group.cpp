@@ -110,6 +110,7 @@ struct Lane {
   svo_ba_summary ba_summary{};
   int ba_rc = 0;
   int ba_launch = 0, ba_line = 0;  // which solve launch of the group carries this lane's solve, on which solve line
+  unsigned long long ba_ready_seq = 0;  // when its assembled solve was first seen waiting for a launch (0: none waits); the order of admission
   bool has_keyframe = false;
   double solved_pose[7] = {1, 0, 0, 0, 0, 0, 0};
   int last_iterations = 0;
@@ -190,6 +191,7 @@ struct svo_pipeline_group {
   hipStream_t st_lk[MAX_LINES + 1] = {}, st_chain[MAX_LINES + 1] = {}, st_ba[MAX_LINES] = {};  // [MAX_LINES]: the express lines (see process_batch)
   bool express = false;
   int ba_launch_id = 0;
+  unsigned long long ba_ready_counter = 0;
   // batch-wide front-end outputs
   float* d_corners = nullptr; int* d_ncorners = nullptr; uint8_t* d_pyr[2] = {nullptr, nullptr}; int pyr_cur = 0;
   size_t pyr_stride = 0;
@@ -247,6 +249,7 @@ void fill_pending(Lane* l, svo_frame_result* res, int upto) {
 // join the lane's solve (BundleAdjuster::bundle_adjust's tail, src/bundle_adjuster.cpp:146-155; host/pipeline.cpp run_bundle_adjust)
 int finish_solve(svo_pipeline_group* g, Lane* l) {
   const int st = l->ba_state.load(std::memory_order_acquire);
+  l->ba_ready_seq = 0;  // (no solve of this lane waits for a launch any more)
   if (st == BA_NONE) return SVO_OK;
   int rc = SVO_OK;
   const auto tf0 = std::chrono::steady_clock::now();
@@ -990,8 +993,20 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       for (int li = 0; li < S; ++li) {
         const int bs = g->lanes[li]->ba_state.load(std::memory_order_acquire);
         assembling += bs == BA_ASSEMBLING;
-        if (bs == BA_READY) q_ba.push_back(li);
+        if (bs == BA_READY) {
+          q_ba.push_back(li);
+          if (!g->lanes[li]->ba_ready_seq) g->lanes[li]->ba_ready_seq = ++g->ba_ready_counter;
+        }
       }
+      // who is offered to the admission first (it may run out of budget behind any of them): a lane whose next keyframe already
+      // waits for this solve, then the solve that has waited longest — in lane order the high lanes of a large group starved
+      // and became the stragglers of the call (profiles/r04_group_sweep.txt: 56 and 64 lanes)
+      std::sort(q_ba.begin(), q_ba.end(), [&](int a, int b) {
+        const Lane* la = g->lanes[a]; const Lane* lb = g->lanes[b];
+        const bool wa = la->state == L_NEED_SOLVE, wb = lb->state == L_NEED_SOLVE;
+        if (wa != wb) return wa;
+        return la->ba_ready_seq < lb->ba_ready_seq;
+      });
       bool ba_line_busy[svo_pipeline_group::MAX_LINES] = {};
       for (int li = 0; li < S; ++li) {
         const Lane* l = g->lanes[li];
@@ -1008,7 +1023,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         std::vector<int> cand;
         for (int li : q_ba) {
           Lane* l = g->lanes[li];
-          if (l->ba_rc == 1) { l->ba_state.store(BA_NONE, std::memory_order_release); continue; }  // nothing to solve
+          if (l->ba_rc == 1) { l->ba_ready_seq = 0; l->ba_state.store(BA_NONE, std::memory_order_release); continue; }  // nothing to solve
           if (l->ba_rc) { error = l->ba_rc; break; }
           bas[cand.size()] = l->ba;
           cand.push_back(li);
@@ -1025,7 +1040,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             if (!((mask >> k) & 1ull)) { if (not_taken < 0) not_taken = cand[k]; continue; }
             Lane* l = g->lanes[cand[k]];
             EV(cand[k], "ba_launch", launched);
-            l->ba_launch = g->ba_launch_id; l->ba_line = free_line; l->ba_state.store(BA_INFLIGHT, std::memory_order_release);
+            l->ba_launch = g->ba_launch_id; l->ba_line = free_line; l->ba_ready_seq = 0; l->ba_state.store(BA_INFLIGHT, std::memory_order_release);
           }
           if (not_taken >= 0) {
             // if nothing of this group is in flight that could free the admission budget (or the problem is simply not
@@ -1035,6 +1050,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             for (int li = 0; li < S; ++li) inflight |= g->lanes[li]->ba_state.load(std::memory_order_acquire) == BA_INFLIGHT;
             if (!inflight) {
               Lane* l = g->lanes[not_taken];
+              l->ba_ready_seq = 0;
               l->ba_state.store(BA_HOST_SOLVING, std::memory_order_release);
               g->pool.post(l, 1);
               progressed = true;
@@ -1108,6 +1124,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     if (copied && hipStreamSynchronize(st) != hipSuccess && !error) { error = SVO_ERR_HIP; ctx->err = "pipeline group: pyramid clone failed"; }
   }
   if (trace_on) {
+    static std::mutex trace_mu;  // the groups of a process print their calls one after the other
+    std::lock_guard<std::mutex> lk(trace_mu);
     for (const Ev& e : evs) fprintf(stderr, "[svo group] %10.1f lane %2d %-22s %d\n", e.us, e.lane, e.what, e.arg);
     fprintf(stderr, "[svo group] %10.1f end\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count());
   }
