@@ -25,8 +25,14 @@ struct SvoLkLane {
   unsigned* arrive; unsigned arrive_target;                        // device arrival counter of the lane (monotone)
   int* word; int seq;                                              // pinned completion word
 };
-struct SvoLkLanes { int w, h; SvoLkLane lane[SVO_MAX_LANES]; };
-// grid_x = the largest lane's feature count; every lane's arrive_target counts grid_x workgroups
+// per_chunk > 0: the XCD-aware map (a speed choice only).  The launch's features, lane after lane (a lane without features counts
+// one idle workgroup: somebody has to arrive for it), are cut into SVO_LK_CHUNKS contiguous chunks of per_chunk; workgroup b works
+// on chunk (b % 8) + 8 * ((b / 8) / per_chunk): workgroups b and b + 8 share an XCD (observed dispatch, MI355X_MICROARCH.md), so an
+// XCD's L2 sees the pyramids of the two or three lanes its chunks lie in instead of every lane's.  prefix[j] = first feature slot
+// of lane j, prefix[n_lanes] = total; a lane's arrive_target then counts max(n, 1) workgroups.  per_chunk == 0: blockIdx = (feature, lane).
+constexpr int SVO_LK_CHUNKS = 16;
+struct SvoLkLanes { int w, h; int per_chunk, total, chunks; int prefix[SVO_MAX_LANES + 1]; SvoLkLane lane[SVO_MAX_LANES]; };  // chunks: a multiple of 8
+// per_chunk == 0: grid_x = the largest lane's feature count; every lane's arrive_target counts grid_x workgroups
 int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_lanes, int grid_x);
 
 // a5: the whole cv::solvePnPRansac of a lane (src/image_processor.cpp:72-80) as ONE launch: hypotheses (four per workgroup),
