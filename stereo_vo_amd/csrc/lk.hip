@@ -638,15 +638,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void lk
   static_assert(LKT == 64 && FPB == 1, "the stream-batched tracker is written for one wavefront per feature");
   __shared__ LkShared S;
   __shared__ int sLast;
-  int li = blockIdx.y, f = blockIdx.x;
-  if (g.per_chunk > 0) {  // XCD-aware map (group_kernels.h); everything here is wave-uniform
-    const int slot = (int)(blockIdx.x >> 3), sub = slot / g.per_chunk;
-    const int idx = ((int)(blockIdx.x & 7) + 8 * sub) * g.per_chunk + (slot - sub * g.per_chunk);
-    if (idx >= g.total) return;  // beyond the last chunk's end: nobody counts this workgroup
-    li = 0;
-    while (idx >= g.prefix[li + 1]) ++li;
-    f = idx - g.prefix[li];
-  }
+  int li, f;
+  if (!svo_xcd_map_item(g.map, li, f)) return;
   const SvoLkLane& a = g.lane[li];
   const int n = a.n, lane = threadIdx.x;
   if (f < n) {
@@ -848,7 +841,7 @@ int svo_k_track(svo_ctx* ctx, const uint8_t* pyr_prev, const uint8_t* pyr_next, 
 
 int svo_kg_track(svo_ctx* ctx, hipStream_t st, const SvoLkLanes& lanes, int n_lanes, int grid_x) {
   SvoProfScope prof(ctx, SVO_PROF_LK_FB, st);
-  if (lanes.per_chunk > 0) hipLaunchKernelGGL(lk_fb_group_kernel, dim3(lanes.chunks * lanes.per_chunk), dim3(64), 0, st, lanes);
+  if (lanes.map.per_chunk > 0) hipLaunchKernelGGL(lk_fb_group_kernel, dim3(lanes.map.grid()), dim3(64), 0, st, lanes);
   else hipLaunchKernelGGL(lk_fb_group_kernel, dim3(grid_x, n_lanes), dim3(64), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;

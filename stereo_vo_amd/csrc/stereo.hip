@@ -243,11 +243,13 @@ __global__ __launch_bounds__(256) void stereo_triangulate_kernel(const uint8_t* 
 // the surviving corners keep their detection order, as after the separate, order-preserving dedup compaction.
 template <int NT>
 __global__ __launch_bounds__(NT) void stereo_triangulate_group_kernel(SvoStereoTriLanes g) {
-  const SvoStereoTriLane& a = g.lane[blockIdx.y];
+  int li, f;
+  if (!svo_xcd_map_item(g.map, li, f)) return;
+  const SvoStereoTriLane& a = g.lane[li];
   svo_latency_critical();
   __shared__ int sWaveT[NT / 64];
   __shared__ int sLast, sHit;
-  const int n = a.n_dev ? *a.n_dev : a.n_max, f = blockIdx.x;
+  const int n = a.n_dev ? *a.n_dev : a.n_max;
   if (f < n) {  // (one instance of the block matcher for the first keyframe — no tracked features to keep away from — and all later ones)
     const float x = a.xy[2 * f], y = a.xy[2 * f + 1];
     bool dup = false;
@@ -284,10 +286,11 @@ __global__ __launch_bounds__(NT) void stereo_triangulate_group_kernel(SvoStereoT
 int svo_kg_stereo_triangulate(svo_ctx* ctx, hipStream_t st, const SvoStereoTriLanes& lanes, int n_lanes, int grid_x) {
   SvoProfScope prof(ctx, SVO_PROF_STEREO_AT, st);
   // one wavefront per corner for the reference's block size and range (the instance with compile-time patch sizes), else a workgroup
+  const dim3 grid = lanes.map.per_chunk > 0 ? dim3(lanes.map.grid()) : dim3(grid_x, n_lanes);
   if (lanes.block == svo_ref::STEREO_BLOCK_SIZE && lanes.ndisp == svo_ref::STEREO_NUM_DISPARITIES)
-    hipLaunchKernelGGL(stereo_triangulate_group_kernel<64>, dim3(grid_x, n_lanes), dim3(64), 0, st, lanes);
+    hipLaunchKernelGGL(stereo_triangulate_group_kernel<64>, grid, dim3(64), 0, st, lanes);
   else
-    hipLaunchKernelGGL(stereo_triangulate_group_kernel<256>, dim3(grid_x, n_lanes), dim3(256), 0, st, lanes);
+    hipLaunchKernelGGL(stereo_triangulate_group_kernel<256>, grid, dim3(256), 0, st, lanes);
   SVO_HIP_CHECK(ctx, hipGetLastError());
   return SVO_OK;
 }

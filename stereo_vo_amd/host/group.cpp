@@ -184,8 +184,8 @@ struct svo_pipeline_group {
   // consecutive stages coherent), solves take whichever solve line is free
   static constexpr int MAX_LINES = 8;
   int n_lk = 1, n_chain = 1, n_ba = 2;
-  int lk_chunks = SVO_LK_CHUNKS;
-  bool lk_xcd_map = true;  // the tracker's XCD-aware feature -> workgroup map (group_kernels.h; SVO_GROUP_LK_XCD=0: blockIdx = (feature, lane))
+  int xcd_chunks = SVO_XCD_CHUNKS;
+  bool xcd_map = true, xcd_map_tri = true;  // the XCD-aware item -> workgroup map of the tracking / stereo launches (group_kernels.h; SVO_GROUP_LK_XCD=0, SVO_GROUP_TRI_XCD=0: blockIdx = (item, lane))
   // SVO_TIMING: host time of the group thread inside the per-keyframe graph calls (ns), and keyframes seen
   double t_get_points = 0, t_add_keyframe = 0, t_finish = 0, t_loop = 0; long n_kf = 0; bool timing = false;
   double lk_overlap_us = 0.0;  // > 0: a second tracking line may depart once every launch in flight is at least this old (it is in its tail then)
@@ -353,8 +353,9 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     g->timing = getenv("SVO_TIMING") != nullptr;
     { const char* e = getenv("SVO_GROUP_LK_OVERLAP_US"); g->lk_overlap_us = e && *e ? std::max(0.0, atof(e)) : 0.0; }
     g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 2, svo_pipeline_group::MAX_LINES);
-    { const char* e = getenv("SVO_GROUP_LK_XCD"); g->lk_xcd_map = !(e && *e && atoi(e) == 0); }
-    { const char* e = getenv("SVO_GROUP_LK_CHUNKS"); if (e && *e) g->lk_chunks = std::max(8, std::min(64, atoi(e) / 8 * 8)); }  // developer experiments
+    { const char* e = getenv("SVO_GROUP_LK_XCD"); g->xcd_map = !(e && *e && atoi(e) == 0); }
+    { const char* e = getenv("SVO_GROUP_TRI_XCD"); g->xcd_map_tri = !(e && *e && atoi(e) == 0); }
+    { const char* e = getenv("SVO_GROUP_XCD_CHUNKS"); if (e && *e) g->xcd_chunks = std::max(8, std::min(64, atoi(e) / 8 * 8)); }  // developer experiments
     g->n_ba = knob("SVO_GROUP_BA_LINES", 4, svo_pipeline_group::MAX_LINES);
     g->st_lk[0] = ctx->stream;
     // experiment knob: the tracker's launches on `keep` of every 32 CUs only (the rest stays free for the short kernels of the
@@ -868,12 +869,11 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       a.w = W; a.h = H;
       int gx = 1;
       for (int li : q_now) gx = std::max(gx, g->lanes[li]->n);
-      a.per_chunk = 0; a.total = 0; a.chunks = 0;
-      if (g->lk_xcd_map) {
-        int tot = 0, j = 0;
-        for (int li : q_now) { a.prefix[j++] = tot; tot += std::max(1, g->lanes[li]->n); }
-        a.prefix[j] = tot;
-        a.total = tot; a.chunks = g->lk_chunks; a.per_chunk = (tot + a.chunks - 1) / a.chunks;
+      a.map.per_chunk = 0; a.map.total = 0; a.map.chunks = 0;
+      if (g->xcd_map) {
+        int counts[SVO_MAX_LANES], j = 0;
+        for (int li : q_now) counts[j++] = g->lanes[li]->n;
+        svo_xcd_map_fill(a.map, counts, j, g->xcd_chunks);
       }
       int k = 0;
       for (int li : q_now) {
@@ -889,7 +889,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         x.fwd = l->d_fwd; x.keep = l->d_keep; x.parallax = l->d_par;
         x.kept_xy = l->d_xy[nxt]; x.init_dst = l->d_init[nxt]; x.ids_dst = l->d_ids[nxt];
         x.host_xy = l->h_xy[nxt]; x.host_ids = l->h_ids[nxt]; x.host_n = l->h_n; x.host_av = l->h_av;
-        l->arrive_total[C_LK] += (unsigned)(a.per_chunk > 0 ? std::max(1, l->n) : gx);
+        l->arrive_total[C_LK] += (unsigned)(a.map.per_chunk > 0 ? std::max(1, l->n) : gx);
         x.arrive = l->d_arrive + 16 * C_LK; x.arrive_target = l->arrive_total[C_LK];
         x.word = &l->words[16 * W_TRACK]; x.seq = ++l->seq[W_TRACK];
         l->queued = false;
@@ -948,10 +948,16 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       SvoStereoTriLanes t;
       t.w = W; t.h = H; t.stride = W; t.ndisp = svo_ref::STEREO_NUM_DISPARITIES; t.block = svo_ref::STEREO_BLOCK_SIZE;
       int kt = 0, gxt = 1;
-      for (int li : t_now) {
-        Lane* l = g->lanes[li];
-        const int n_det = hc[li * batch + l->frame];
-        gxt = std::max(gxt, n_det);
+      t.map.per_chunk = 0; t.map.total = 0; t.map.chunks = 0;
+      {
+        int counts[SVO_MAX_LANES], j = 0;
+        for (int li : t_now) {
+          Lane* l = g->lanes[li];
+          const int n_det = hc[li * batch + l->frame];
+          gxt = std::max(gxt, n_det);
+          counts[j++] = n_det;
+        }
+        if (g->xcd_map_tri) svo_xcd_map_fill(t.map, counts, j, g->xcd_chunks);
       }
       for (int li : t_now) {
         Lane* l = g->lanes[li];
@@ -978,7 +984,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         x.n_max = n_det; x.disp = l->d_disp;
         x.M = svo_k_reprojection_matrix(pose, g->K[0], g->K[2], g->K[5], (float)g->prm.cam.baseline);  // :178-189
         x.kept_xy = l->h_tri_xy; x.xyz = l->h_tri_xyz; x.n_kept = l->h_tri_cnt;
-        x.pub = make_pub(l, W_TRI, C_TRI, gxt);
+        x.pub = make_pub(l, W_TRI, C_TRI, t.map.per_chunk > 0 ? std::max(1, n_det) : gxt);
         l->state = L_TRI_WAIT;
         l->queued = false;
       }
