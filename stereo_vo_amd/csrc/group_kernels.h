@@ -1,5 +1,5 @@
 // Stream-batched launches: ONE launch of a stage of the hot path covers several stereo streams ("lanes" of a pipeline
-// group, host/group.cpp), blockIdx.y = lane.  The kernels run the SAME device bodies as the single-stream launches
+// group, host/group.cpp), blockIdx.y = lane or the XCD-aware map below.  The kernels run the SAME device bodies as the single-stream launches
 // (kernels.h) on per-lane argument records that travel in the kernel-argument segment, so a lane's results are bit for
 // bit those of its own svo_pipeline.  Why: with eight stereo streams as eight host threads and 16-24 hardware queues a
 // launch -> completion round trip costs 30-90 us instead of 7-11 and concurrent small kernels run 3-5x their solo time
