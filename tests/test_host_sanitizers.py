@@ -63,3 +63,16 @@ def test_host_code_is_clean_under_asan_and_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
     r = subprocess.run([exe, str(d)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "host sanitize ok" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_xcd_aware_block_map_serves_every_slot_exactly_once(tmp_path):
+    """The item -> workgroup map of the grouped tracking / sparse-stereo launches (csrc/xcd_map.h): the device function's own text
+    compiled for the host walks whole grids — every (lane, item) slot once, max(n, 1) workgroups per lane (what the lanes'
+    arrival targets count), contiguous runs per XCD label — under ASan + UBSan."""
+    exe = str(tmp_path / "xcd_map_test")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-Wall", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-I", os.path.join(ROOT, "stereo_vo_amd", "csrc"), os.path.join(ROOT, "tests", "sanitize", "xcd_map_test.cpp"), "-o", exe]
+    subprocess.run(cmd, check=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "xcd map ok" in r.stdout
