@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void corner_response_nms_kernel(const uint8_t*
     base = __builtin_amdgcn_readfirstlane(base);
     for (int i = lane; i < nbuf; i += 64) {
       if ((size_t)(base + i) < raw_stride) list[base + i] = buf[i];
-      else atomicOr(status, 1);
+      else atomicOr(status, 8);  // the RAW list (timing dependent: filtered against a running maximum), not the candidate list
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -802,6 +802,7 @@ static int corner_status(svo_ctx* ctx) {
     const int s = *h;
     (void)hipMemsetAsync(ctx->d_status, 0, sizeof(int), ctx->stream);
     ctx->err = (s & 1)   ? "corner_detect: more NMS candidates than svo_limits.max_candidates"
+               : (s & 8) ? "corner_detect: more raw local maxima than the streaming pass's list holds (svo_ctx raw_cap: width x height / 4 per image under a 1 GiB budget)"
                : (s & 2) ? "corner_detect: more accepted corners than the select kernel holds (16384)"
                          : "corner_detect: min-distance grid larger than the workspace";
     return SVO_ERR_CAPACITY;

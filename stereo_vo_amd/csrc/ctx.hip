@@ -91,11 +91,17 @@ extern "C" int svo_create(svo_ctx** out, int device, const svo_limits* lim) {
 #define ALLOC(ptr, bytes) \
   if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return fail(#ptr, e)
   ALLOC(c->d_ws, c->ws_bytes);
-  // raw local maxima of the streaming detection pass: at most one 3x3 maximum per 2x2 pixels could exist (px / 4; ties on
-  // plateaus aside), but what counts is what survives "above quality x the running maximum": twice the candidate bound;
-  // an overflow is reported like a candidate overflow (status bit 1).  The f32 response map of rounds 1-2 (4 px bytes per
-  // frame: 717 MB for a 384-frame context) is no longer allocated here, see svo_ensure_eig.
-  c->raw_cap = std::min(px / 2, (size_t)2 * (size_t)c->lim.max_candidates);
+  // raw local maxima of the streaming detection pass: at most one 3x3 maximum per 2x2 pixels can exist (px / 4; ties on
+  // plateaus aside).  How many are RECORDED depends on timing (a candidate is dropped early against the image's running
+  // maximum), so the list is sized by that geometric bound, not by max_candidates (round 4 used 2 x max_candidates: contexts
+  // with a small candidate bound could then overflow on textured frames although the final candidates fit — ADVICE r4),
+  // under a budget of 1 GiB per context and never below twice the candidate bound; an overflow has its own status bit (8)
+  // and message.  8 B per entry: 358 MB for the bench's 384-frame context at 1241x376.
+  // (The f32 response map of rounds 1-2, 4 px bytes per frame, is not allocated here, see svo_ensure_eig.)
+  {
+    const size_t geometric = px / 4 + 4096, budget = ((size_t)1 << 27) / B;  // entries
+    c->raw_cap = std::max(std::min(geometric, std::max(budget, (size_t)4096)), std::min(px / 2, (size_t)2 * (size_t)c->lim.max_candidates));
+  }
   ALLOC(c->d_raw, B * c->raw_cap * sizeof(unsigned long long));
   ALLOC(c->d_maxkey, B * sizeof(unsigned));
   ALLOC(c->d_cand, B * c->lim.max_candidates * sizeof(unsigned long long));

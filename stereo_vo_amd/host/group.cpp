@@ -281,6 +281,7 @@ void quiesce_after_error(svo_pipeline_group* g) {
     (void)hipMemset(l->d_arrive, 0, sizeof(unsigned) * 16 * C_COUNT);
     for (int c = 0; c < C_COUNT; ++c) l->arrive_total[c] = 0;
     for (int w = 0; w < W_COUNT; ++w) { l->seq[w] = 0; l->words[16 * w] = 0; }
+    if (l->h_bad) *l->h_bad = 0;  // a "foreign landmark-store entry" report must not outlive the batch it failed
     l->queued = false;
   }
 }
@@ -490,6 +491,10 @@ extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
     l->state = L_IDLE; l->queued = false; l->pending_from = -1; l->last_iterations = 0;
     const double id7[7] = {1, 0, 0, 0, 0, 0, 0};
     memcpy(l->solved_pose, id7, sizeof(id7));
+    // feature ids restart at 0 (svo_ba_reset): no entry of the landmark store may survive under an old id, and a reported
+    // foreign entry is forgotten with the stream that produced it
+    if (l->h_bad) *l->h_bad = 0;
+    if (l->d_store && hipMemset(l->d_store, 0xFF, sizeof(float4) * ((size_t)l->store_mask + 1)) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP;
   }
   if (rc_join) { quiesce_after_error(g); return rc_join; }  // a solve that was in flight did not come back cleanly
   return SVO_OK;
@@ -582,7 +587,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
   if (hc[S * batch]) {
     (void)hipMemsetAsync(ctx->d_status, 0, sizeof(int), st);
-    ctx->err = "corner detection exceeded a workspace bound (svo_limits.max_candidates)";
+    ctx->err = (hc[S * batch] & 8) ? "corner detection: more raw local maxima than the streaming pass's list holds (raw_cap: width x height / 4 per image under a 1 GiB budget)"
+                         : "corner detection exceeded a workspace bound (svo_limits.max_candidates)";
     return SVO_ERR_CAPACITY;
   }
 
@@ -1159,12 +1165,13 @@ int ensure_staging(svo_pipeline_group* g) {
   svo_ctx* ctx = g->ctx;
   SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const size_t bytes = (size_t)g->n_lanes * (size_t)g->max_batch * (size_t)g->prm.width * (size_t)g->prm.height;
+  // only what is still missing: a call that failed half way (out of pinned memory) leaves st_copy null and comes back here
   for (int sl = 0; sl < 2; ++sl) {
     for (int e = 0; e < 2; ++e) {
-      SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&g->h_stage[sl][e], bytes, hipHostMallocDefault));
-      SVO_HIP_CHECK(ctx, hipMalloc((void**)&g->d_stage[sl][e], bytes));
+      if (!g->h_stage[sl][e]) SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&g->h_stage[sl][e], bytes, hipHostMallocDefault));
+      if (!g->d_stage[sl][e]) SVO_HIP_CHECK(ctx, hipMalloc((void**)&g->d_stage[sl][e], bytes));
     }
-    SVO_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->ev_up[sl], hipEventDisableTiming));
+    if (!g->ev_up[sl]) SVO_HIP_CHECK(ctx, hipEventCreateWithFlags(&g->ev_up[sl], hipEventDisableTiming));
   }
   SVO_HIP_CHECK(ctx, hipStreamCreateWithFlags(&g->st_copy, hipStreamNonBlocking));
   return SVO_OK;

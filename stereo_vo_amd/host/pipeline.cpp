@@ -545,7 +545,8 @@ int ImageProcessor::prepare_batch(const uint8_t* left, int batch, int width, int
   }
   if (h[batch]) {
     (void)hipMemsetAsync(ctx_->d_status, 0, sizeof(int), ctx_->stream);
-    ctx_->err = "corner detection exceeded a workspace bound (svo_limits.max_candidates)";
+    ctx_->err = (h[batch] & 8) ? "corner detection: more raw local maxima than the streaming pass's list holds (raw_cap: width x height / 4 per image under a 1 GiB budget)"
+                         : "corner detection exceeded a workspace bound (svo_limits.max_candidates)";
     return SVO_ERR_CAPACITY;
   }
   for (int i = 0; i < batch; ++i) h_ncorners_[i] = h[i];

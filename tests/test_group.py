@@ -335,11 +335,22 @@ def test_hip_group_landmark_store_too_small_fails_loudly():
         g = _group(S, ctx, p0, 300, 12.0, 400, 1)
     finally:
         del os.environ["SVO_GROUP_STORE_KEYFRAMES"]
+    def run(b0):
+        dl, dr = torch.from_numpy(L[None, b0:b0 + 8].copy()).cuda(), torch.from_numpy(R[None, b0:b0 + 8].copy()).cuda()
+        out = g.process_batch_dev(dl.data_ptr(), dr.data_ptr(), 8 * p0.width * p0.height, 8)
+        torch.cuda.synchronize()
+        return [bytes(r) for r in out[0]]
+    good, failed_at = [], None
     with pytest.raises(S.api.SvoError, match="landmark store"):
         for b0 in range(0, n, 8):
-            dl, dr = torch.from_numpy(L[None, b0:b0 + 8].copy()).cuda(), torch.from_numpy(R[None, b0:b0 + 8].copy()).cuda()
-            g.process_batch_dev(dl.data_ptr(), dr.data_ptr(), 8 * p0.width * p0.height, 8)
-            torch.cuda.synchronize()
+            failed_at = b0
+            good.append(run(b0))
+    assert failed_at is not None and failed_at >= 8, "the first batch fits even one keyframe's ids"
+    # the documented recovery: after the error a reset gives a working group again — the report word is cleared and
+    # the store refilled, so the batches that succeeded before succeed again with the same bits
+    g.reset()
+    for i, b0 in enumerate(range(0, failed_at, 8)):
+        assert run(b0) == good[i], b0
     g.close()
     ctx.close()
 

@@ -20,8 +20,8 @@ for ln in open(sys.argv[1], errors="replace"):
 tot = collections.Counter()
 n_lane_calls = 0
 wall = 0.0
-pairs = {"track_launch": ("track_done", "tracking launch in flight"), "hyp_launch": ("hyp_done", "PnP hypotheses in flight"),
-         "ref_launch": ("ref_done", "PnP refinement in flight"), "tri_launch": ("tri_done", "stereo + triangulation in flight"),
+pairs = {"track_launch": ("track_done", "tracking launch in flight"), "pnp_launch": ("pnp_done", "PnP-RANSAC launch in flight"),
+         "tri_launch": ("tri_done", "stereo + triangulation in flight"),
          "need_solve": ("solve_joined_for_pnp", "keyframe waits for its previous solve")}
 for t_end, lanes in calls:
     for l, evs in lanes.items():

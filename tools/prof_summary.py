@@ -19,7 +19,41 @@ os.makedirs(out, exist_ok=True)
 
 
 def kname(full):
-    return full.replace("(anonymous namespace)::", "").split("(")[0]
+    """Kernel name as it is classified below: no namespace, no return type, no template arguments, no parameter list —
+    `void stereo_triangulate_group_kernel<64>(...)` and `stereo_triangulate_group_kernel(...)` are the same kernel (round 4's
+    summary matched exact names and silently dropped the templated sparse-stereo kernel from the front-end bytes)."""
+    n = full.replace("(anonymous namespace)::", "").split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    return n.split("<")[0].strip()
+
+
+# Every kernel of a trace belongs to exactly one class; a kernel nobody classified stops the summary (a rename can never
+# silently drop bytes or time again).  "wide": streams whole images with 16-byte requests (the guide's x2 on FETCH_SIZE applies).
+FRONT_END = {"corner_response_kernel", "corner_response_nms_kernel", "corner_threshold_kernel", "corner_nms_kernel", "corner_select_kernel",
+             "pyr_copy_kernel", "pyr_down_kernel", "pyr_build_kernel", "lk_fb_kernel", "lk_fb_group_kernel", "track_compact_kernel", "tracker_init_kernel",
+             "tracker_init_group_kernel", "stereo_at_kernel", "stereo_triangulate_kernel", "stereo_triangulate_group_kernel", "stereo_prefilter_kernel",
+             "stereo_dense_kernel", "dedup_group_kernel", "dedup_kernel", "triangulate_kernel", "gather_track_kernel", "lk_kernel", "chain_group_kernel"}
+WIDE = {"corner_response_kernel", "corner_response_nms_kernel", "corner_nms_kernel", "pyr_copy_kernel", "pyr_down_kernel", "pyr_build_kernel"}
+SOLVE = {"ba_lm_kernel", "ba_lm_compact_kernel", "ba_step_kernel", "ba_decide_linearize_kernel", "ba_reduce_kernel", "ba_linearize_det_kernel", "ba_linearize_kernel",
+         "ba_linearize_mfma_kernel", "ba_backsub_kernel", "ba_decide_kernel", "ba_bulk_control_kernel", "ba_store_scatter_kernel", "pnp_ransac_kernel", "pnp_group_kernel"}
+OTHER_PREFIXES = ("__amd_rocclr_", "peak_", "cholesky_solve_kernel", "reproj_", "nccl", "rccl", "msccl", "at::", "void at::", "vectorized_elementwise", "elementwise_kernel")
+
+
+def classify(k):
+    if k in FRONT_END:
+        return "front_end"
+    if k in SOLVE:
+        return "solve"
+    if k.startswith(OTHER_PREFIXES) or "at::native" in k or "Generic_" in k:
+        return "other"
+    return None
+
+
+def check_classified(names, where):
+    unknown = sorted({k for k in names if classify(k) is None})
+    if unknown:
+        raise SystemExit(f"prof_summary: unclassified kernel(s) in {where}: {unknown} — add them to FRONT_END / SOLVE / OTHER_PREFIXES")
 
 
 def stats(path):
@@ -35,6 +69,7 @@ for key, sub in (("default", "s8"), ("1_stream", "s1"), ("ba50k", "ba")):
     if not os.path.exists(f):
         continue
     st = stats(f)
+    check_classified([n for n, c, t, a, p in st], f)
     with open(os.path.join(out, f"{tag}_kernel_stats_{key}.csv"), "w") as w:
         w.write("# " + stamp + "\n")
         w.write("kernel,calls,total_ms,average_us,percent\n")
@@ -82,9 +117,12 @@ if agg:
             summary["lk_fb_waves_per_launch"] = agg[lk]["SQ_WAVES"] / calls[lk]
             summary["lk_fb_valu_instructions_per_wave"] = agg[lk]["SQ_INSTS_VALU"] / max(agg[lk]["SQ_WAVES"], 1.0)
             break
-    if "ba_lm_kernel" in agg:
-        summary["ba_lm_valu_wave_instructions_per_launch"] = agg["ba_lm_kernel"]["SQ_INSTS_VALU"] / calls["ba_lm_kernel"]
-        summary["ba_lm_waves_per_launch"] = agg["ba_lm_kernel"]["SQ_WAVES"] / calls["ba_lm_kernel"]
+    for sk in ("ba_lm_compact_kernel", "ba_lm_kernel"):
+        if sk in agg:
+            pre = "ba_lm" if sk == "ba_lm_kernel" else "ba_lm_compact"
+            summary[pre + "_valu_wave_instructions_per_launch"] = agg[sk]["SQ_INSTS_VALU"] / calls[sk]
+            summary[pre + "_waves_per_launch"] = agg[sk]["SQ_WAVES"] / calls[sk]
+            summary[pre + "_parked_fraction"] = agg[sk]["SQ_WAIT_ANY"] / max(agg[sk]["SQ_WAVE_CYCLES"], 1.0)
 
 traffic = collections.defaultdict(dict)
 launches = {}
@@ -103,22 +141,25 @@ if traffic:
                 frames = (b["steps"] + b["warmup"]) * b["config"]["batch_per_stream"] * b["config"]["streams_per_gpu"]
     except Exception:
         pass
-    front = ("corner_response_kernel", "corner_response_nms_kernel", "corner_threshold_kernel", "corner_nms_kernel", "corner_select_kernel", "pyr_copy_kernel", "pyr_down_kernel", "lk_fb_kernel",
-             "lk_fb_group_kernel", "track_compact_kernel", "stereo_at_kernel", "stereo_triangulate_kernel", "stereo_triangulate_group_kernel",
-             "dedup_group_kernel", "dedup_kernel")
+    check_classified(traffic.keys(), "the FETCH_SIZE / WRITE_SIZE passes")
+    front = sorted(k for k in traffic if classify(k) == "front_end")
     # MI355X_MICROARCH.md HBM section: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950; applied to the kernels
     # that stream whole images with 16-byte requests (response, NMS, pyramid), not to the byte-granular gathers
-    wide = ("corner_response_kernel", "corner_response_nms_kernel", "corner_nms_kernel", "pyr_copy_kernel", "pyr_down_kernel")
+    wide = WIDE
     per_pair_corrected = sum(((2.0 if k in wide else 1.0) * traffic[k].get("fetch_kb_per_launch", 0) + traffic[k].get("write_kb_per_launch", 0)) * 1024.0 * launches[k]
                              for k in front if k in traffic) / frames
     summary["front_end_hbm_bytes_per_pair_pmc_fetch_x2_on_streaming_kernels"] = per_pair_corrected
     per_pair = sum((traffic[k].get("fetch_kb_per_launch", 0) + traffic[k].get("write_kb_per_launch", 0)) * 1024.0 * launches[k]
                    for k in front if k in traffic) / frames
     summary["front_end_hbm_bytes_per_pair_pmc"] = per_pair
+    summary["front_end_kernels_counted"] = front
+    summary["front_end_hbm_bytes_per_pair_by_kernel"] = {k: round((traffic[k].get("fetch_kb_per_launch", 0) + traffic[k].get("write_kb_per_launch", 0)) * 1024.0 * launches[k] / frames) for k in front}
     for k in traffic:
         traffic[k]["launches"] = launches[k]
-    if "ba_lm_kernel" in traffic:  # the solve kernel's own HBM traffic per launch (bench.py sets it against the algorithmic bytes)
-        summary["ba_lm_traffic_bytes_per_launch"] = (traffic["ba_lm_kernel"].get("fetch_kb_per_launch", 0) + traffic["ba_lm_kernel"].get("write_kb_per_launch", 0)) * 1024.0
+    for sk in ("ba_lm_compact_kernel", "ba_lm_kernel"):  # the solve kernel's own HBM traffic per launch (bench.py sets it against the algorithmic bytes)
+        if sk in traffic:
+            pre = "ba_lm" if sk == "ba_lm_kernel" else "ba_lm_compact"
+            summary[pre + "_traffic_bytes_per_launch"] = (traffic[sk].get("fetch_kb_per_launch", 0) + traffic[sk].get("write_kb_per_launch", 0)) * 1024.0
     json.dump(dict(stamp=stamp, unit="KB per launch, raw FETCH_SIZE / WRITE_SIZE (no 2x correction: byte-granular gathers)", frames=frames,
                    front_end_bytes_per_pair=per_pair, kernels=traffic), open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1)
 
