@@ -262,6 +262,10 @@ typedef struct svo_lm_stats {
   int speculations;      /* steps that also produced a linearisation for the next iteration (same sweep or chained) */
   int speculation_hits;  /* ... that the step control could use: the iteration cost exactly one host round trip */
   int single_exchange;   /* steps whose pass A rode in the SAME collective as payload2 (saturated-radius prediction) */
+  int collectives;       /* all-reduce calls the solve issued (sharded runs; what N ranks would issue: also counted on one rank) */
+  int device_control;    /* 1: the step control ran on the device (bulk / sharded path: no host work inside an LM iteration) */
+  int fallbacks;         /* device-resident window solves that gave up and were re-run through the host-driven loop */
+  double host_us;        /* host time spent inside the LM loop of the last solve (launch calls + waits that were not overlapped), us */
 } svo_lm_stats;
 
 void svo_ba_default_options(svo_ba_options* o);
@@ -330,6 +334,12 @@ int svo_rccl_comm_destroy(void* nccl_comm);
  * than two pipelines are inside svo_pipeline_process_batch* (pipeline groups always solve on the device).  Results are
  * bit-identical either way. */
 int svo_ba_set_device_lm(svo_ba* ba, int mode);
+/* Where the step control runs for BULK / SHARDED solves (hardware-order accumulation, svo_ba_load_problem +
+ * svo_ba_solve_problem; the all-reduce of src/bundle_adjuster.cpp:140's normal equations over the ranks): mode 1 / -1 (default):
+ * on the device — per LM iteration the host only enqueues [pass B, all-reduce, pass A, all-reduce, control kernel], a fixed
+ * number of slots ahead of the control kernel's status records (csrc/ba.hip ba_bulk_control_kernel; reduced camera systems up
+ * to n = 128); mode 0: host/lm.cpp drives every iteration (one D2H + host Cholesky + upload per iteration). */
+int svo_ba_set_bulk_control(svo_ba* ba, int mode);
 /* counters of the last svo_ba_solve / svo_ba_solve_problem */
 int svo_ba_last_stats(svo_ba* ba, svo_lm_stats* stats);
 int svo_ba_solve_problem(svo_ba* ba, svo_ba_summary* summary);

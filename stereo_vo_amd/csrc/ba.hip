@@ -79,7 +79,8 @@ struct FusedAdmission {
   void release() { if (blocks) g_fused_blocks[device].fetch_sub(blocks, std::memory_order_acq_rel); blocks = 0; }
   ~FusedAdmission() { release(); }
 };
-constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32;
+constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, LM_MIN_RADIUS_BULK = 1e-32;
+constexpr int BULK_RING = 8;   // status records of the device-side step control (bulk path) the host may lag behind
 constexpr int PAY2_SLOTS = 8;  // payload2 (4 doubles) is padded to 8 so that payload1 starts 64-byte aligned behind it
 
 struct BaDev {
@@ -242,6 +243,38 @@ __device__ __forceinline__ void apply_ctl(BaDev& P, double& radius, const double
   if (acc != 0.0) { P.points = P.cand_points; P.poses = P.cand_poses; }
 }
 
+// ---- bulk / sharded solves with the step control on the device (round 5; ba_bulk_control_kernel below) --------------------
+// The LM state lives in device memory (`bctl`, BC_* doubles).  The host enqueues a FIXED sequence per LM iteration —
+//   ba_backsub_kernel -> [all-reduce of payload2] -> pass A (MFMA / LDS-atomic kernel) -> [all-reduce of payload1] -> ba_bulk_control_kernel
+// — without reading anything back: every kernel takes the point it works at (current / candidate buffers by BC_SEL), the radius
+// and whether it has anything to do from that state, pass A takes Ceres' accept / radius decision itself from the (all-reduced)
+// payload2 (svo_lm_decide: the same closed form in every workgroup and on every rank), and the control kernel does what
+// host/lm.cpp does between two passes: Cholesky of the reduced camera system (n <= 128 in LDS), termination tests, pose update.
+enum { BC_DONE = 0, BC_MODE, BC_SEL, BC_RADIUS, BC_DF, BC_COST, BC_INITIAL_COST, BC_MCC, BC_ITER, BC_SUCC, BC_TERM, BC_NEED_LIN,
+       BC_LIN_CALLS, BC_STEP_CALLS, BC_NEXT_USED, BC_T0, BC_WORDS = 24 };
+enum { BCM_FIRST = 0, BCM_STEP, BCM_RELIN };  // what the sequence slot in flight is: the first linearisation | pass B + chained pass A | pass A alone at the current point
+struct BulkSel { const double* bctl; double* pts[2]; double* pos[2]; };  // bctl == null: the host-driven loop (arguments as passed)
+
+__device__ __forceinline__ void bulk_select(BaDev& P, const BulkSel& bs) {
+  const int sel = (int)bs.bctl[BC_SEL] & 1;
+  P.points = bs.pts[sel]; P.cand_points = bs.pts[sel ^ 1]; P.poses = bs.pos[sel]; P.cand_poses = bs.pos[sel ^ 1];
+}
+// pass A of a sequence slot: false = nothing to do (the solve has terminated).  Block-uniform.
+__device__ __forceinline__ bool bulk_apply(BaDev& P, double& radius, int& first_pass, const BulkSel& bs) {
+  if (!bs.bctl) return true;
+  const double* c = bs.bctl;
+  if (c[BC_DONE] != 0.0) return false;
+  const int mode = (int)c[BC_MODE];
+  bulk_select(P, bs);
+  first_pass = mode == BCM_FIRST;
+  radius = c[BC_RADIUS];
+  if (mode == BCM_STEP) {  // chained: at the candidate with the new radius, or — rejected / invalid step — at the current point with the reduced one
+    const SvoLmDecision d = svo_lm_decide(c[BC_COST], c[BC_MCC], c[BC_RADIUS], c[BC_DF], P.pay2[0], P.pay2[1]);
+    radius = d.next_radius;
+    if (d.accept) { P.points = P.cand_points; P.poses = P.cand_poses; }
+  }
+  return true;
+}
 
 __device__ __forceinline__ bool inv3_sym(const double* V, double* Vi) {
   const double a = V[0], b = V[1], c = V[2], d = V[4], e = V[5], f = V[8];
@@ -1146,9 +1179,10 @@ __device__ __forceinline__ bool sum_pay2(const BaDev& P, int parity, unsigned lo
 }
 
 // ---- pass A alone, bulk modes (first linearisation of a solve, re-linearisation after a rejected step or a missed speculation)
-__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+__global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl, BulkSel bs) {
   svo_latency_critical();
   apply_ctl(P, radius, ctl);
+  if (!bulk_apply(P, radius, first_pass, bs)) return;
   extern __shared__ double lds[];  // payload1 image: S (n*n) | gred (n) | gc (n) | dU (n) | cost | gp2
   const int n = P.n;
   const int pay1 = n * n + 3 * n + 2;
@@ -1248,7 +1282,12 @@ __global__ __launch_bounds__(NT) void ba_decide_linearize_kernel(BaDev P, LmCtl 
 }
 
 // ---- pass B alone (bulk modes; the speculative pass A follows as its own launch on the MFMA / LDS-atomic kernel)
-__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius) {
+__global__ __launch_bounds__(256) void ba_backsub_kernel(BaDev P, double radius, BulkSel bs) {
+  if (bs.bctl) {  // device-side step control: the slot has a step to evaluate, or nothing to do
+    if (bs.bctl[BC_DONE] != 0.0 || (int)bs.bctl[BC_MODE] != BCM_STEP) return;
+    bulk_select(P, bs);
+    radius = bs.bctl[BC_RADIUS];
+  }
   __shared__ double sStep[STEP_LDS_DOUBLES];
   __shared__ double sAcc[4];
   if (threadIdx.x < 4) sAcc[threadIdx.x] = 0.0;
@@ -1310,6 +1349,220 @@ __global__ __launch_bounds__(NT) void ba_step_kernel(BaDev P, double radius, dou
 // sharded runs: the decision is taken from the ALL-REDUCED payload2 (device buffer [payload2 | payload1])
 __global__ __launch_bounds__(64) void ba_decide_kernel(LmCtl ctl, double* paybuf, double* ctl_dev) {
   if (threadIdx.x == 0 && blockIdx.x == 0) decide_device(ctl, paybuf[0], paybuf[1], ctl_dev, paybuf);
+}
+
+// ---- the step control of a bulk / sharded solve on the device: ONE workgroup behind the all-reduce of payload1 -------------
+// What host/lm.cpp does between two passes, on the summed payloads in device memory: consume the step (Ceres' acceptance,
+// radius update, tolerances: the SAME functions — host/lm_decide.h, host/lm_math.h), test the gradient, the iteration / time /
+// radius limits, build the scaled damped reduced camera system, factor it (csrc/lm_device.h: the declared arithmetic of
+// host/linalg.cpp, n <= 128 in LDS), form the pose step and the candidate poses, and leave state + step for the next slot's
+// kernels.  Also clears the payload buffer for the next slot's accumulation and publishes a status record (pinned host memory)
+// that the host reads only to decide how far ahead it may keep enqueuing — never inside an iteration's critical path.
+// Every rank runs it on identical sums, so every rank takes identical decisions (the reason the wall-clock cap is tested on the
+// all-reduced MEAN of the ranks' clocks: the payload's tail carries [elapsed seconds, 1.0] per rank).
+struct LmDevOpt { int max_iterations; double function_tolerance, gradient_tolerance, parameter_tolerance, initial_radius, max_time_s; };
+constexpr int BS_HEAD = 16;                      // status record: [seq | done | iterations | successful | termination | initial cost | cost | sel | stand-alone pass-A slots | steps | next linearisation used | mode | radius | elapsed s | - | -] then 7 K poses
+constexpr int BS_DOUBLES = BS_HEAD + 7 * 64;
+struct BulkCtlArgs {
+  int n, K, slot, ring;
+  double* pay;      // device [payload2 (PAY2_SLOTS) | payload1 (n n + 3 n + 2) | elapsed, ranks]
+  double* bctl;     // device LM state (BC_*)
+  double* sc;       // device: Jacobi scales of the pose columns, fixed by the first linearisation
+  double* step;     // device [dc (max(n, 1)) | candidate poses (7 K)]: what ba_backsub_kernel stages
+  double* pos[2];   // the two pose buffers (current = BC_SEL)
+  double* status;   // pinned ring of BS_DOUBLES records
+  LmDevOpt opt;
+};
+static inline size_t ba_bulk_ctl_lds_doubles(int n, int K) {
+  const size_t nn = n > 0 ? n : 1;
+  return (size_t)n * n + (3 * (size_t)n + 4) + 4 * nn + (nn + 14 * (size_t)K) + (6 * nn + 1) + 14 * (size_t)K;
+}
+
+__global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
+  extern __shared__ double lds[];
+  __shared__ double st[BC_WORDS];
+  __shared__ int sAct;
+  const int tid = threadIdx.x, nt = blockDim.x, n = a.n, K = a.K, nn = n > 0 ? n : 1;
+  const LmDevOpt& opt = a.opt;
+  for (int i = tid; i < BC_WORDS; i += nt) st[i] = a.bctl[i];
+  __syncthreads();
+  double* rec = a.status + (size_t)(a.slot % a.ring) * BS_DOUBLES;
+  double* cS = lds;                         // n x n: S (lower triangle used) -> the scaled damped system -> L
+  double* cV = cS + (size_t)n * n;          // g_red (n) | g_c (n) | diag U (n) | cost | sum g_p^2 | sum of the ranks' elapsed seconds | ranks
+  double* cDf = cV + 3 * n + 4;
+  double* cRhs = cDf + nn;
+  double* cSc = cRhs + nn;
+  double* cDc = cSc + nn;
+  double* cTerm = cDc + nn;                 // nn + 14 K: per-element terms of the sequential sums
+  double* cCol = cTerm + nn + 14 * K;       // 6 nn + 1: the Cholesky's panel columns
+  double* cPose = cCol + 6 * nn + 1;        // 7 K current poses
+  double* cCand = cPose + 7 * K;            // 7 K candidate poses
+  enum { ACT_RETURN = 0, ACT_GRAD, ACT_LOOPTOP, ACT_SOLVE, ACT_FINISH };
+  const bool was_done = st[BC_DONE] != 0.0;
+  double elapsed_now = 0.0;
+  if (!was_done) {
+    const int mode = (int)st[BC_MODE], sel = (int)st[BC_SEL] & 1;
+    const double* P1 = a.pay + PAY2_SLOTS;
+    for (int i = tid; i < 3 * n + 4; i += nt) cV[i] = P1[(size_t)n * n + i];
+    // every unordered pose pair was accumulated once (upper block), diagonal pose blocks in full: the lower triangle as
+    // ba_payload1_out forms it (src[ij] + src[ji] off the diagonal blocks)
+    for (int idx = tid; idx < n * n; idx += nt) {
+      const int r = idx / n, c = idx - r * n;
+      if (c > r) continue;
+      cS[idx] = (r / 6 == c / 6) ? P1[idx] : P1[idx] + P1[(size_t)c * n + r];
+    }
+    for (int i = tid; i < 7 * K; i += nt) { cPose[i] = a.pos[sel][i]; cCand[i] = a.step[nn + i]; }
+    if (mode != BCM_FIRST) for (int q = tid; q < n; q += nt) cSc[q] = a.sc[q];
+    __shared__ double sPay2[4];
+    if (tid < 4) sPay2[tid] = a.pay[tid];
+    __syncthreads();
+    // the payload buffer is consumed: clear it for the next slot's accumulation; its tail takes this rank's clock
+    for (int i = tid; i < PAY2_SLOTS + n * n + 3 * n + 4; i += nt) a.pay[i] = 0.0;
+    if (tid == 0) {
+      const double now = (double)(long long)wall_clock64();
+      if (mode == BCM_FIRST) st[BC_T0] = now;
+      elapsed_now = 1e-8 * (now - st[BC_T0]);
+    }
+    __syncthreads();
+    if (tid == 0) { a.pay[PAY2_SLOTS + (size_t)n * n + 3 * n + 2] = elapsed_now; a.pay[PAY2_SLOTS + (size_t)n * n + 3 * n + 3] = 1.0; }
+    const double ranks = cV[3 * n + 3], mean_elapsed = ranks > 0 ? cV[3 * n + 2] / ranks : 0.0;
+    int act = ACT_RETURN;
+    if (mode == BCM_FIRST) {
+      for (int q = tid; q < n; q += nt) { const double v = 1.0 / (1.0 + sqrt(cV[2 * n + q])); cSc[q] = v; a.sc[q] = v; }
+      if (tid == 0) { st[BC_COST] = cV[3 * n]; st[BC_INITIAL_COST] = cV[3 * n]; st[BC_LIN_CALLS] = 1; }
+      act = ACT_GRAD;
+    } else if (mode == BCM_RELIN) {
+      if (tid == 0) st[BC_NEED_LIN] = 0;
+      act = ACT_SOLVE;
+    } else {  // BCM_STEP: host/lm.cpp behind ops->step; the pass A that followed took svo_lm_decide's outcome (bulk_apply)
+      for (int i = tid; i < 7 * K; i += nt) {
+        const double dd = cCand[i] - cPose[i];
+        cTerm[i] = dd * dd;
+        cTerm[7 * K + i] = cPose[i] * cPose[i];
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const double cost = st[BC_COST], mcc = st[BC_MCC], radius = st[BC_RADIUS], df = st[BC_DF];
+        const double cost_new = sPay2[0], model_change = mcc + sPay2[1];
+        double step2 = sPay2[2], x2 = sPay2[3];
+        for (int i = 7; i < 7 * K; ++i) { step2 += cTerm[i]; x2 += cTerm[7 * K + i]; }
+        const SvoLmDecision dec = svo_lm_decide(cost, mcc, radius, df, cost_new, sPay2[1]);  // what pass A linearised for
+        int a_ = ACT_LOOPTOP, accepted = 0;
+        if (!(model_change > 0)) {  // invalid step: pass A ran at the current point with radius / df — exactly what is needed
+          st[BC_RADIUS] = radius / df; st[BC_DF] = df * 2; st[BC_NEED_LIN] = 0; st[BC_NEXT_USED] += 1;
+        } else if (sqrt(step2) <= opt.parameter_tolerance * (sqrt(x2) + opt.parameter_tolerance)) {
+          st[BC_TERM] = 0; a_ = ACT_FINISH;
+        } else if (fabs(cost - cost_new) <= opt.function_tolerance * cost) {  // Ceres returns before the step is taken
+          st[BC_TERM] = 0; a_ = ACT_FINISH;
+        } else if (dec.accept) {
+          accepted = 1;
+          st[BC_SEL] = (double)(((int)st[BC_SEL] & 1) ^ 1);  // the candidate buffers become the current ones (op_accept)
+          st[BC_COST] = cost_new; st[BC_SUCC] += 1; st[BC_RADIUS] = dec.next_radius; st[BC_DF] = 2.0; st[BC_NEXT_USED] += 1;
+          a_ = ACT_GRAD;
+        } else {
+          st[BC_RADIUS] = dec.next_radius; st[BC_DF] = df * 2; st[BC_NEED_LIN] = 0; st[BC_NEXT_USED] += 1;
+        }
+        sAct = a_ | (accepted << 8);
+      }
+      __syncthreads();
+      act = sAct & 0xFF;
+      if (sAct >> 8) for (int i = tid; i < 7 * K; i += nt) cPose[i] = cCand[i];
+      __syncthreads();
+    }
+    __syncthreads();
+    for (;;) {  // block-uniform: every transition is decided by thread 0 and read between two barriers
+      if (act == ACT_GRAD) {
+        if (tid == 0) {  // sqrt(sum g_p^2 + sum g_c^2), sequentially as host/lm.cpp's gradient_norm
+          double g2 = cV[3 * n + 1];
+          for (int q = 0; q < n; ++q) g2 += cV[n + q] * cV[n + q];
+          if (sqrt(g2) <= opt.gradient_tolerance) { st[BC_TERM] = 0; sAct = ACT_FINISH; } else sAct = ACT_LOOPTOP;
+        }
+        __syncthreads();
+        act = sAct;
+        __syncthreads();
+      }
+      if (act == ACT_LOOPTOP) {
+        if (tid == 0) {
+          int a_ = ACT_SOLVE;
+          if (st[BC_ITER] >= (double)opt.max_iterations) { st[BC_TERM] = 1; a_ = ACT_FINISH; }
+          else if (opt.max_time_s > 0 && mean_elapsed >= opt.max_time_s) { st[BC_TERM] = 1; a_ = ACT_FINISH; }  // src/bundle_adjuster.cpp:11
+          else if (st[BC_RADIUS] <= LM_MIN_RADIUS_BULK) { st[BC_TERM] = 0; a_ = ACT_FINISH; }
+          else {
+            st[BC_ITER] += 1;
+            if (st[BC_NEED_LIN] != 0.0) { st[BC_LIN_CALLS] += 1; st[BC_MODE] = (double)BCM_RELIN; a_ = ACT_RETURN; }
+          }
+          sAct = a_;
+        }
+        __syncthreads();
+        act = sAct;
+        __syncthreads();
+      }
+      if (act == ACT_FINISH) { if (tid == 0) st[BC_DONE] = 1.0; break; }
+      if (act == ACT_RETURN) break;
+      // ACT_SOLVE
+      const double radius = st[BC_RADIUS];
+      for (int q = tid; q < n; q += nt) {
+        const double sq = cSc[q];
+        cDf[q] = fmin(fmax(cV[2 * n + q] * sq * sq, MIN_DIAG), MAX_DIAG) / radius;
+        cRhs[q] = -(cV[q] + cV[n + q]) * sq;
+      }
+      __syncthreads();
+      for (int idx = tid; idx < n * n; idx += nt) {
+        const int r = idx / n, c = idx - r * n;
+        if (c > r) continue;
+        double w = cS[idx] * cSc[r] * cSc[c];
+        if (r == c) w += cDf[r];
+        cS[idx] = w;
+      }
+      __syncthreads();
+      const bool ok = n == 0 || svo_dev_cholesky_solve(cS, cRhs, n, cCol);
+      if (ok) {
+        for (int q = tid; q < n; q += nt) {
+          const double rq = cRhs[q], sq = cSc[q];
+          cDc[q] = rq * sq;
+          cTerm[q] = 0.5 * rq * (cDf[q] * rq - cV[n + q] * sq);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          double mcc = 0.0;
+          for (int q = 0; q < n; ++q) mcc += cTerm[q];
+          st[BC_MCC] = mcc; st[BC_STEP_CALLS] += 1; st[BC_MODE] = (double)BCM_STEP;
+        }
+        if (tid < K) {
+          if (tid == 0) for (int q = 0; q < 7; ++q) cCand[q] = cPose[q];
+          else svo_plus_pose(&cPose[7 * tid], &cDc[6 * (tid - 1)], &cCand[7 * tid]);
+        }
+        __syncthreads();
+        const int nsel = (int)st[BC_SEL] & 1;
+        for (int q = tid; q < nn; q += nt) a.step[q] = q < n ? cDc[q] : 0.0;
+        for (int i = tid; i < 7 * K; i += nt) { a.step[nn + i] = cCand[i]; a.pos[nsel ^ 1][i] = cCand[i]; }
+        break;
+      }
+      // not positive definite: invalid step, linearise again with the reduced radius
+      if (tid == 0) { st[BC_RADIUS] = st[BC_RADIUS] / st[BC_DF]; st[BC_DF] = st[BC_DF] * 2; st[BC_NEED_LIN] = 1; }
+      __syncthreads();
+      act = ACT_LOOPTOP;
+    }
+    __syncthreads();
+    for (int i = tid; i < BC_WORDS; i += nt) a.bctl[i] = st[i];
+    // the accepted poses are the current buffer's content from now on
+    { const int nsel = (int)st[BC_SEL] & 1; for (int i = tid; i < 7 * K; i += nt) a.pos[nsel][i] = cPose[i]; }
+  } else {
+    const int sel = (int)st[BC_SEL] & 1;
+    for (int i = tid; i < 7 * K; i += nt) cPose[i] = a.pos[sel][i];
+    __syncthreads();
+  }
+  // status record: poses and head (written through), acknowledged, then the sequence word
+  if (st[BC_DONE] != 0.0) for (int i = tid; i < 7 * K; i += nt) pay_store(&rec[BS_HEAD + i], cPose[i]);
+  if (tid == 0) {
+    pay_store(&rec[1], st[BC_DONE]); pay_store(&rec[2], st[BC_ITER]); pay_store(&rec[3], st[BC_SUCC]); pay_store(&rec[4], st[BC_TERM]);
+    pay_store(&rec[5], st[BC_INITIAL_COST]); pay_store(&rec[6], st[BC_COST]); pay_store(&rec[7], st[BC_SEL]); pay_store(&rec[8], st[BC_LIN_CALLS]);
+    pay_store(&rec[9], st[BC_STEP_CALLS]); pay_store(&rec[10], st[BC_NEXT_USED]); pay_store(&rec[11], st[BC_MODE]); pay_store(&rec[12], st[BC_RADIUS]);
+    pay_store(&rec[13], elapsed_now);
+  }
+  stores_acknowledged();
+  __syncthreads();
+  if (tid == 0) pay_store(&rec[0], (double)(a.slot + 1));
 }
 
 // Publishing without cache maintenance.  A compiler fence at agent or system scope is `buffer_wbl2` + `buffer_inv`: it
@@ -1391,7 +1644,6 @@ __device__ __forceinline__ bool wait_until(const unsigned* word, unsigned target
 // The wall-clock cap of src/bundle_adjuster.cpp:11: replicated controllers cannot each read a clock and agree, so
 // workgroup 0 posts the time elapsed since its first pass with every reduction it takes part in (one more granule) and
 // every controller tests THAT value at the top of the loop, where host/lm.cpp tests its clock.
-struct LmDevOpt { int max_iterations; double function_tolerance, gradient_tolerance, parameter_tolerance, initial_radius, max_time_s; };
 struct LmDevArgs {
   unsigned* cnt;            // device counter block (LMC_*)
   const void* arena_src;    // pinned problem image to read in place (null: already on the device)
@@ -2041,8 +2293,9 @@ static inline size_t ba_mfma_lds_bytes(int n, int F) {
          sizeof(uint32_t) * MF_WAVES * 64 + sizeof(int) * MF_WAVES;
 }
 
-__global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl) {
+__global__ __launch_bounds__(512) void ba_linearize_mfma_kernel(BaDev P, double radius, int first_pass, const double* __restrict__ ctl, BulkSel bs) {
   apply_ctl(P, radius, ctl);
+  if (!bulk_apply(P, radius, first_pass, bs)) return;
   extern __shared__ double lds[];
   const int n = P.n, F = P.K - 1;
   double* sZ = lds;                                  // [8][64][18]
@@ -2330,6 +2583,9 @@ struct svo_ba {
   hipStream_t stream = nullptr;   // BA has its own stream so a solve can overlap the tracker's kernels
   double* d_pay = nullptr;        // [payload2 (PAY2_SLOTS) | payload1]: one buffer, one all-reduce
   double* d_step = nullptr;       // device copy of [dc | candidate poses] (bulk / sharded runs)
+  double* d_bctl = nullptr;       // bulk path, device-side step control: LM state (BC_*) | Jacobi scales of the pose columns
+  double* h_bstat = nullptr;      // ... pinned: ring of status records (BS_DOUBLES each) | initial state image
+  int bulk_ctl = -1;              // svo_ba_set_bulk_control: -1 automatic (on whenever eligible), 0 host-driven, 1 on
   // pinned block, fixed layout (never depends on the window size): [flag word (64 B) | step: dc + candidate poses |
   // payload2 (PAY2_SLOTS) | payload1]
   uint8_t* h_pin = nullptr;
@@ -2391,12 +2647,15 @@ static int ba_alloc(svo_ba* ba) {
   BaDev& d = ba->d;
   const int Kmax = ba->max_poses, nmax = 6 * (Kmax - 1);
   ba->cap_points = ba->max_landmarks; ba->cap_obs = ba->max_obs;
-  ba->cap_pay1 = std::max((size_t)nmax * nmax + 3 * (size_t)nmax + 2, (size_t)(18 * (Kmax - 1) * Kmax + 33 * (Kmax - 1) + 2));  // payload1, or the wire totals
+  ba->cap_pay1 = std::max((size_t)nmax * nmax + 3 * (size_t)nmax + 2 + 2, (size_t)(18 * (Kmax - 1) * Kmax + 33 * (Kmax - 1) + 2));  // payload1 (+ the [elapsed, ranks] tail of the device-side step control), or the wire totals
   const size_t step_doubles = (size_t)(nmax > 0 ? nmax : 1) + 7 * (size_t)Kmax;
 #define A(ptr, T, cnt) SVO_HIP_CHECK(ctx, hipMalloc((void**)&(ptr), sizeof(T) * (size_t)(cnt)))
   A(d.sp, double, 3 * ba->cap_points);
   A(ba->d_pay, double, PAY2_SLOTS + ba->cap_pay1);
   A(ba->d_step, double, step_doubles);
+  A(ba->d_bctl, double, BC_WORDS + (nmax > 0 ? nmax : 1));
+  SVO_HIP_CHECK(ctx, hipHostMalloc((void**)&ba->h_bstat, sizeof(double) * ((size_t)BULK_RING * BS_DOUBLES + BC_WORDS), hipHostMallocCoherent));
+  memset(ba->h_bstat, 0, sizeof(double) * ((size_t)BULK_RING * BS_DOUBLES + BC_WORDS));
   // The counter block of the device-resident solve: ordinary device memory (fine-grained memory LOST atomic increments
   // when it was tried in round 3: 38 workgroups had added to a counter that read 37).  The granule stores (partials, totals)
   // are sized by the problem: ba_ensure_partials.
@@ -2531,7 +2790,8 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
               1e-2 * ba->lm_wg_mean[sl] / ba->lm_iters, 1e-2 * ba->lm_wg_max[sl] / ba->lm_iters);
   }
   if (ba->stream) (void)hipStreamSynchronize(ba->stream);
-  void* ptrs[] = {ba->d_res, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, d.sp, d.part1, d.part2, ba->d_arena};
+  void* ptrs[] = {ba->d_res, ba->d_lmdbg, ba->d_lmc, ba->d_arrive, ba->d_pay, ba->d_step, ba->d_bctl, d.sp, d.part1, d.part2, ba->d_arena};
+  if (ba->h_bstat) (void)hipHostFree(ba->h_bstat);
   if (ba->h_arena) (void)hipHostFree(ba->h_arena);
   if (ba->h_store_stage) (void)hipHostFree(ba->h_store_stage);
   for (void* p : ptrs)
@@ -2558,6 +2818,12 @@ extern "C" int svo_ba_set_comm(svo_ba* ba, void* nccl_comm) {
 extern "C" int svo_ba_set_device_lm(svo_ba* ba, int mode) {
   if (!ba || mode < -1 || mode > 1) return SVO_ERR_INVALID;
   ba->device_lm = mode;
+  return SVO_OK;
+}
+
+extern "C" int svo_ba_set_bulk_control(svo_ba* ba, int mode) {
+  if (!ba || mode < -1 || mode > 1) return SVO_ERR_INVALID;
+  ba->bulk_ctl = mode;
   return SVO_OK;
 }
 
@@ -2976,7 +3242,8 @@ void ba_payload1_out(svo_ba* ba, const double* src, double* dst) {
 
 // launch pass A in the bulk modes (accumulates into d.pay1, which the caller zeroed).  ctl != null: the point and the
 // radius come from the chained decision on the device.
-int ba_launch_bulk_linearize(svo_ba* ba, double radius, int first, const double* ctl) {
+const BulkSel kNoBulk = {nullptr, {nullptr, nullptr}, {nullptr, nullptr}};
+int ba_launch_bulk_linearize(svo_ba* ba, double radius, int first, const double* ctl, const BulkSel& bs = kNoBulk) {
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   if (d.C <= 0) return SVO_OK;
@@ -2987,13 +3254,13 @@ int ba_launch_bulk_linearize(svo_ba* ba, double radius, int first, const double*
     const size_t mfma_lds = ba_mfma_lds_bytes(n, d.K - 1);
     const int mfma_grid = std::max(1, std::min(svo_div_up(d.C, MF_WAVES), 256));
     SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mfma_lds));
-    hipLaunchKernelGGL(ba_linearize_mfma_kernel, dim3(mfma_grid), dim3(64 * MF_WAVES), mfma_lds, ba->stream, d, radius, first, ctl);
+    hipLaunchKernelGGL(ba_linearize_mfma_kernel, dim3(mfma_grid), dim3(64 * MF_WAVES), mfma_lds, ba->stream, d, radius, first, ctl, bs);
   } else {
     const size_t lds_bytes = pay1 * sizeof(double);
     const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
     if (lds_bytes > 64 * 1024)
       SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_linearize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, ba->stream, d, radius, first, ctl);
+    hipLaunchKernelGGL(ba_linearize_kernel, dim3(grid), dim3(256), lds_bytes, ba->stream, d, radius, first, ctl, bs);
   }
   return SVO_OK;
 }
@@ -3380,7 +3647,7 @@ int op_step(void* user, const double* dc, const double* cand_poses7, double radi
     if (d.C > 0) {
       SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB, st);
       const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
-      hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, radius, kNoBulk);
     }
     if (same_sweep) {  // pass A at the candidate the launch above just wrote
       d.points = ba->cand_points; d.poses = ba->cand_poses;
@@ -3425,6 +3692,149 @@ int op_accept(void* user) {
 }
 }  // namespace
 
+// ---- bulk / sharded solve with the step control on the device ----------------------------------------------------------
+// Eligible: hardware-order accumulation (the deterministic window path has its own device-resident form, ba_lm_kernel), a
+// reduced camera system that fits one workgroup's LDS (n <= 128: up to 22 poses).  SVO_BA_BULK_CONTROL=0 / svo_ba_set_bulk_control
+// restore the host-driven loop (host/lm.cpp).
+static bool ba_bulk_control_wanted(const svo_ba* ba) {
+  if (ba->d.det || ba->d.n > 128 || ba->d.K > 64) return false;
+  if (ba->bulk_ctl >= 0) return ba->bulk_ctl == 1;
+  static const char* e = getenv("SVO_BA_BULK_CONTROL");
+  return !(e && *e) || atoi(e) != 0;
+}
+
+// The host's whole part of a solve: enqueue the fixed sequence slot by slot, staying `ahead` slots in front of the last status
+// record it has seen (SVO_BA_RUNAHEAD, default 2: the GPU never waits for the host; on termination ahead - 1 slots of no-op
+// kernels and two small collectives are wasted once per solve).  Slot s is enqueued iff s < ahead or the record of slot s - ahead
+// says "not done" — a function of the records only, never of timing: every rank of a sharded run enqueues the same
+// number of collectives.
+static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
+  svo_ctx* ctx = ba->ctx;
+  BaDev& d = ba->d;
+  hipStream_t st = ba->stream;
+  const auto t_begin = now();
+  const int n = d.n, K = d.K, nn = n > 0 ? n : 1;
+  const size_t pay1 = (size_t)n * n + 3 * (size_t)n + 2, wire = pay1 + 2;  // + [elapsed seconds, ranks]
+  static const int ahead_env = [] { const char* e = getenv("SVO_BA_RUNAHEAD"); const int v = e ? atoi(e) : 2; return v < 1 ? 1 : (v > BULK_RING - 2 ? BULK_RING - 2 : v); }();
+  const int ahead = ahead_env;
+  {
+    const int rcf = ba_flush_arena(ba);
+    if (rcf) return rcf;
+  }
+  ba->host_points_valid = false;
+  memset(&ba->stats, 0, sizeof(ba->stats));
+  double host_ms = 0.0;
+  // initial state -> device (from pinned memory), payload cleared, status ring forgotten
+  double* init = ba->h_bstat + (size_t)BULK_RING * BS_DOUBLES;
+  for (int i = 0; i < BC_WORDS; ++i) init[i] = 0.0;
+  init[BC_MODE] = (double)BCM_FIRST; init[BC_RADIUS] = ba->opt.initial_radius; init[BC_DF] = 2.0; init[BC_TERM] = 1.0;
+  for (int r = 0; r < BULK_RING; ++r) __atomic_store_n(reinterpret_cast<long long*>(&ba->h_bstat[(size_t)r * BS_DOUBLES]), 0ll, __ATOMIC_RELEASE);
+  SVO_HIP_CHECK(ctx, hipMemcpyAsync(ba->d_bctl, init, sizeof(double) * BC_WORDS, hipMemcpyHostToDevice, st));
+  SVO_HIP_CHECK(ctx, hipMemsetAsync(ba->d_pay, 0, sizeof(double) * (PAY2_SLOTS + wire), st));
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  d.step_in = ba->d_step;
+  d.ctl_dev = nullptr;
+  const BulkSel bs = {ba->d_bctl, {ba->cur_points, ba->cand_points}, {ba->cur_poses, ba->cand_poses}};
+  BulkCtlArgs ca;
+  ca.n = n; ca.K = K; ca.slot = 0; ca.ring = BULK_RING;
+  ca.pay = ba->d_pay; ca.bctl = ba->d_bctl; ca.sc = ba->d_bctl + BC_WORDS; ca.step = ba->d_step;
+  ca.pos[0] = ba->cur_poses; ca.pos[1] = ba->cand_poses;
+  ca.status = ba->h_bstat;
+  ca.opt.max_iterations = ba->opt.max_iterations; ca.opt.function_tolerance = ba->opt.function_tolerance;
+  ca.opt.gradient_tolerance = ba->opt.gradient_tolerance; ca.opt.parameter_tolerance = ba->opt.parameter_tolerance;
+  ca.opt.initial_radius = ba->opt.initial_radius; ca.opt.max_time_s = ba->opt.max_time_s;
+  const size_t ctl_lds = sizeof(double) * ba_bulk_ctl_lds_doubles(n, K);
+  SVO_REQUIRE(ctx, ctl_lds <= 158 * 1024, "ba: reduced camera system too large for the device-side step control");
+  if (ctl_lds > 48 * 1024) SVO_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)ba_bulk_control_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctl_lds));
+  int collectives = 0;
+  auto control = [&](int slot) {
+    ca.slot = slot;
+    hipLaunchKernelGGL(ba_bulk_control_kernel, dim3(1), dim3(512), ctl_lds, st, ca);
+  };
+  const bool sharded = ba->comm || ba->allreduce;
+  auto allreduce = [&](size_t off, size_t cnt) -> int {
+    ++collectives;  // what N ranks issue; a single rank has nothing to sum
+    return sharded ? ba_allreduce(ba, off, cnt) : SVO_OK;
+  };
+  auto record = [&](int slot) { return ba->h_bstat + (size_t)(slot % BULK_RING) * BS_DOUBLES; };
+  auto wait_record = [&](int slot) -> int {  // blocks until the control kernel of `slot` has published
+    const double* r = record(slot);
+    const auto t0 = now();
+    unsigned spins = 0;
+    while (__atomic_load_n(reinterpret_cast<const long long*>(&r[0]), __ATOMIC_ACQUIRE) != (long long)__builtin_bit_cast(long long, (double)(slot + 1))) {
+      __builtin_ia32_pause();
+      if (++spins > 4096u && (spins & 63u) == 0) sched_yield();
+      if ((spins & 0xFFFFu) == 0 && ms_between(t0, now()) > 20000.0) {
+        (void)hipStreamSynchronize(st);
+        if (r[0] != (double)(slot + 1)) { ctx->err = "ba: the device-side step control never published its status record"; return SVO_ERR_HIP; }
+      }
+    }
+    return SVO_OK;
+  };
+  int rc = SVO_OK;
+  // slot 0: the first linearisation
+  {
+    const auto h0 = now();
+    rc = ba_launch_bulk_linearize(ba, ba->opt.initial_radius, 1, nullptr, bs);
+    if (!rc) rc = allreduce(PAY2_SLOTS, wire);
+    if (!rc) control(0);
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+    host_ms += ms_between(h0, now());
+  }
+  if (rc) return rc;
+  const int max_slots = 2 * ba->opt.max_iterations + 8;  // every slot is an LM iteration or follows a failed factorisation
+  int enqueued = 1, last_seen = -1;
+  bool done = false;
+  for (int s = 1; s < max_slots && !done; ++s) {
+    if (s >= ahead) {  // (waiting here overlaps the GPU's work on slots s - ahead + 1 .. s - 1)
+      rc = wait_record(s - ahead);
+      if (rc) return rc;
+      last_seen = s - ahead;
+      if (record(s - ahead)[1] != 0.0) { done = true; break; }
+    }
+    const auto h0 = now();
+    const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
+    if (d.C > 0) {
+      SvoProfScope prof(ctx, SVO_PROF_BA_BACKSUB, st);
+      hipLaunchKernelGGL(ba_backsub_kernel, dim3(grid), dim3(256), 0, st, d, 0.0, bs);
+    }
+    rc = allreduce(0, PAY2_SLOTS);
+    if (!rc) rc = ba_launch_bulk_linearize(ba, 0.0, 0, nullptr, bs);
+    if (!rc) rc = allreduce(PAY2_SLOTS, wire);
+    if (rc) return rc;
+    control(s);
+    SVO_HIP_CHECK(ctx, hipGetLastError());
+    ++enqueued;
+    host_ms += ms_between(h0, now());
+  }
+  // the last enqueued slot's record carries the final state (slots behind the terminating one re-publish it)
+  rc = wait_record(enqueued - 1);
+  if (rc) return rc;
+  (void)last_seen;
+  const double* r = record(enqueued - 1);
+  if (r[1] == 0.0) { ctx->err = "ba: the device-side step control did not terminate within its slot bound"; return SVO_ERR_NUMERIC; }
+  SVO_HIP_CHECK(ctx, hipStreamSynchronize(st));
+  memcpy(ba->h_poses.data(), r + BS_HEAD, sizeof(double) * 7 * (size_t)K);
+  if (((int)r[7] & 1) != 0) { std::swap(ba->cur_points, ba->cand_points); std::swap(ba->cur_poses, ba->cand_poses); }
+  ba->stats.linearize_calls = (int)r[8];
+  ba->stats.step_calls = (int)r[9];
+  ba->stats.speculations = (int)r[9];       // every step carried the next linearisation (chained decision)
+  ba->stats.speculation_hits = (int)r[10];
+  ba->stats.single_exchange = 0;
+  ba->stats.collectives = collectives;
+  ba->stats.device_control = 1;
+  ba->stats.host_us = 1e3 * host_ms;
+  if (sum) {
+    sum->iterations = (int)r[2]; sum->successful_steps = (int)r[3]; sum->termination = (int)r[4];
+    sum->initial_cost = r[5]; sum->final_cost = r[6];
+    sum->solve_ms = ms_between(t_begin, now());
+  }
+  d.flag = nullptr;
+  d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  (void)nn;
+  return SVO_OK;
+}
+
 // ceres::Solve for the loaded problem: host/lm.cpp's step control over the HIP passes.
 static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   svo_ctx* ctx = ba->ctx;
@@ -3440,6 +3850,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
     d.flag = nullptr;
     return rcd;
   }
+  if (ba_bulk_control_wanted(ba)) return ba_lm_bulk_device(ba, sum);  // bulk / sharded: nothing on the host inside an LM iteration
   {
     const int rcf = ba_flush_arena(ba);
     if (rcf) return rcf;

@@ -19,7 +19,7 @@ __device__ __forceinline__ double svo_readlane_f64(double v, int k) {
 }
 
 // Dense SPD solve in LDS by the calling workgroup (128 threads).  A: n x n row-major, lower triangle read, overwritten by
-// L; b: right-hand side, overwritten by the solution; col: 6 n + 1 doubles of scratch (n for n > 64).  Right-looking: after column j is
+// L; b: right-hand side, overwritten by the solution; col: 6 n + 1 doubles of scratch (n for n > 128).  Right-looking: after column j is
 // final, every trailing element (i, c), j < c <= i, receives  -= l_ij * l_cj  — the same subtraction, in the same
 // ascending-k position of its sequence, as the left-looking loop.  Returns false (in every thread) when a pivot is not
 // positive.  Ends with a barrier.
@@ -79,6 +79,87 @@ __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, doubl
       }
       __syncthreads();
     }
+  } else if (n <= 128) {
+    // 64 < n <= 128 (the 20-keyframe reduced camera system of the bulk path, n = 114): the same panels, the first wavefront
+    // holding TWO rows per lane — row `lane` in the low set, row `lane + 64` in the high set; a pivot row's values come from the set
+    // it lives in (wave-uniform choice).  Every element still receives  a_ic - l_i0 l_c0 - l_i1 l_c1 - ...  in ascending k.
+    constexpr int PW = 6;
+    for (int j0 = 0; j0 < n; j0 += PW) {
+      const int bw = n - j0 < PW ? n - j0 : PW;
+      if (tid < 64) {
+        const int r0 = tid, r1 = tid + 64;
+        const bool in0 = r0 < n && r0 >= j0, in1 = r1 < n && r1 >= j0;
+        double p0[PW], p1[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) { p0[q] = (in0 && q < bw) ? A[r0 * n + j0 + q] : 0.0; p1[q] = (in1 && q < bw) ? A[r1 * n + j0 + q] : 0.0; }
+        bool ok = true;
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+          if (q < bw && ok) {  // wave-uniform
+            const int pr = j0 + q;  // the pivot row
+#pragma unroll
+            for (int r = 0; r < q; ++r) {
+              const double lp = pr < 64 ? svo_readlane_f64(p0[r], pr) : svo_readlane_f64(p1[r], pr - 64);  // l_{pr, j0 + r}
+              p0[q] -= p0[r] * lp;
+              p1[q] -= p1[r] * lp;
+            }
+            const double s = pr < 64 ? svo_readlane_f64(p0[q], pr) : svo_readlane_f64(p1[q], pr - 64);
+            ok = s > 0;
+            if (ok) {
+              const double l = sqrt(s);
+              const double v0 = p0[q] / l, v1 = p1[q] / l;
+              p0[q] = r0 == pr ? l : (r0 > pr ? v0 : 0.0);
+              p1[q] = r1 == pr ? l : (r1 > pr ? v1 : 0.0);
+            }
+          }
+        }
+        if (ok) {
+#pragma unroll
+          for (int q = 0; q < PW; ++q) {
+            if (q < bw && in0 && r0 >= j0 + q) { A[r0 * n + j0 + q] = p0[q]; col[q * n + r0] = p0[q]; }
+            if (q < bw && in1 && r1 >= j0 + q) { A[r1 * n + j0 + q] = p1[q]; col[q * n + r1] = p1[q]; }
+          }
+        }
+        if (tid == 0) col[PW * n] = ok ? 1.0 : -1.0;
+      }
+      __syncthreads();
+      if (!(col[PW * n] > 0.0)) { __syncthreads(); return false; }  // uniform
+      const int t0 = j0 + bw;
+      for (int i = t0 + tr; i < n; i += rstep) {
+        double li[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) li[q] = q < bw ? col[q * n + i] : 0.0;
+        for (int c = t0 + tc; c <= i; c += 8) {
+          double v = A[i * n + c];
+#pragma unroll
+          for (int q = 0; q < PW; ++q) if (q < bw) v -= li[q] * col[q * n + c];
+          A[i * n + c] = v;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid < 64) {  // substitutions by the first wavefront, two rows per lane, x in registers (as the n <= 64 form below)
+      const int r0 = tid, r1 = tid + 64;
+      const bool in0 = r0 < n, in1 = r1 < n;
+      double b0 = in0 ? b[r0] : 0.0, b1 = in1 ? b[r1] : 0.0;
+      const double i0 = 1.0 / (in0 ? A[r0 * n + r0] : 1.0), i1 = 1.0 / (in1 ? A[r1 * n + r1] : 1.0);
+      for (int k = 0; k < n; ++k) {  // forward, ascending k
+        const double l0 = (in0 && r0 > k) ? A[r0 * n + k] : 0.0, l1 = (in1 && r1 > k) ? A[r1 * n + k] : 0.0;
+        const double xk = k < 64 ? svo_readlane_f64(b0, k) * svo_readlane_f64(i0, k) : svo_readlane_f64(b1, k - 64) * svo_readlane_f64(i1, k - 64);
+        if (r0 == k) b0 = xk; else if (in0 && r0 > k) b0 -= l0 * xk;
+        if (r1 == k) b1 = xk; else if (in1 && r1 > k) b1 -= l1 * xk;
+      }
+      for (int k = n - 1; k >= 0; --k) {  // backward, descending k
+        const double l0 = r0 < k ? A[k * n + r0] : 0.0, l1 = (in1 && r1 < k) ? A[k * n + r1] : 0.0;
+        const double xk = k < 64 ? svo_readlane_f64(b0, k) * svo_readlane_f64(i0, k) : svo_readlane_f64(b1, k - 64) * svo_readlane_f64(i1, k - 64);
+        if (r0 == k) b0 = xk; else if (r0 < k) b0 -= l0 * xk;
+        if (r1 == k) b1 = xk; else if (in1 && r1 < k) b1 -= l1 * xk;
+      }
+      if (in0) b[r0] = b0;
+      if (in1) b[r1] = b1;
+    }
+    __syncthreads();
+    return true;
   } else {
   for (int j = 0; j < n; ++j) {
     const double s = A[j * n + j];

@@ -82,6 +82,9 @@ extern "C" int svo_lm_solve(int n_poses, double* poses7, const svo_lm_ops* ops, 
       sum->initial_cost = initial_cost; sum->final_cost = cost;
       sum->solve_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     }
+    // all-reduces the loop issued (or would issue on N ranks): a stand-alone pass A = 1, a same-sweep step = 1 (both payloads in one
+    // buffer), a chained step = 2 (payload2, decision, payload1), a plain step = 1
+    st.collectives = st.linearize_calls + st.single_exchange + 2 * (st.speculations - st.single_exchange) + (st.step_calls - st.speculations);
     if (stats) *stats = st;
   };
 

@@ -116,9 +116,14 @@ def test_hip_device_cholesky_matches_host():
     import stereo_vo_amd as S
     ctx = S.Context(64, 64)
     rng = np.random.default_rng(6)
-    for n in (1, 2, 5, 6, 7, 24, 30, 54, 60, 66, 114):
+    # 65..128: the two-rows-per-lane panels of the bulk path's device-side step control (n = 114 for 20 keyframes); 132: column by column
+    for n in (1, 2, 5, 6, 7, 24, 30, 54, 60, 64, 65, 66, 70, 96, 114, 127, 128, 132):
         M = rng.normal(size=(n, n)); A = M @ M.T + n * np.eye(n); b = rng.normal(size=n)
         assert np.array_equal(ctx.cholesky_solve_dev(A, b), S.api.cholesky_solve(A, b)), n
+    # a non-positive pivot in the high row set must be reported, not factored
+    A = np.eye(100); A[80, 80] = -1.0
+    with pytest.raises(S.api.SvoError):
+        ctx.cholesky_solve_dev(A, np.ones(100))
     with pytest.raises(S.api.SvoError):
         ctx.cholesky_solve_dev(-np.eye(3), np.ones(3))
     ctx.close()
@@ -251,6 +256,35 @@ def test_hip_ba_bulk_accumulation_modes(ctx, mode, seed, K, N, dense):
     assert dt < 1e-5 and ang < 1e-5
     assert np.array_equal(poses[0], p["poses0"][0])
     ba.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,K,N,sigma", [(21, 8, 900, (0.05, 0.008)), (22, 12, 1500, (0.6, 0.08)), (23, 3, 200, (1.5, 0.2)), (24, 22, 2000, (0.3, 0.03))])
+def test_hip_ba_bulk_device_step_control_follows_the_host_loop(ctx, seed, K, N, sigma):
+    """The device-side step control of the bulk path against the host-driven loop on full solves, including badly initialised
+    problems (pose noise up to 1.5 m / 0.2 rad: rejected steps, shrinking radii, possibly failed factorisations): the same
+    termination, iteration and step counts (decisions are far from their thresholds) and the same optimum."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(seed, K, N, pose_sigma=sigma, pt_sigma=0.3)
+    kw = dict(max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0, accumulation="mfma", max_iterations=30)
+    out = []
+    for dev in (False, True):
+        ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, bulk_control=dev, **kw)
+        ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+        s = ba.solve_problem()
+        poses, pts = ba.read_problem()
+        st = ba.last_stats()
+        assert st.device_control == int(dev)
+        out.append((s, poses, pts, st))
+        ba.close()
+    (sh, ph, xh, sth), (sd, pd, xd, std) = out
+    assert sd.termination == sh.termination
+    assert abs(sd.iterations - sh.iterations) <= 1 and abs(sd.successful_steps - sh.successful_steps) <= 1  # (a tolerance test may fire one iteration apart)
+    assert abs(sd.initial_cost - sh.initial_cost) <= 1e-11 * sh.initial_cost
+    assert abs(sd.final_cost - sh.final_cost) <= 1e-6 * sh.final_cost
+    dt, ang = BP.pose_error(pd, ph)
+    assert dt < 1e-5 and ang < 1e-5
+    assert np.array_equal(pd[0], p["poses0"][0])
 
 
 @pytest.mark.gpu

@@ -32,11 +32,11 @@ def cfg4_oracle_one_iteration(cfg4):
                       num_threads=min(os.cpu_count() or 1, 16))
 
 
-def _solve(ctx, p, mode, iters, parts=None, allreduce=None):
+def _solve(ctx, p, mode, iters, parts=None, allreduce=None, bulk_control=None):
     import stereo_vo_amd as S
     pts, op, oj, uv = parts if parts else (p["points0"], p["op"], p["oj"], p["uv"])
     ba = S.api.BA(ctx, 20, BP.F, BP.CX, BP.CY, max_landmarks=len(pts) + 8, max_observations=len(op) + 8, max_iterations=iters,
-                  max_time_s=0.0, accumulation=mode)
+                  max_time_s=0.0, accumulation=mode, bulk_control=bulk_control)
     if allreduce is not None:
         ba.set_allreduce(allreduce)
     ba.load_problem(p["poses0"], pts, op, oj, uv)
@@ -75,6 +75,25 @@ def test_hip_config4_cost_is_monotone_and_one_round_trip_per_iteration(ctx, cfg4
     # accepted steps only ever lower the cost (1e-9: separate runs of the hardware-order sums differ in the last digits)
     assert all(b <= a * (1 + 1e-9) for a, b in zip(costs, costs[1:])), costs
     assert costs[-1] < 0.01 * s.initial_cost
+
+
+@pytest.mark.gpu
+def test_hip_config4_device_step_control_equals_the_host_driven_loop(ctx, cfg4):
+    """Round 5: the bulk path's step control on the device (ba_bulk_control_kernel: Cholesky n = 114 in LDS, Ceres' decision,
+    pose update; the host only enqueues) against host/lm.cpp driving the same kernels — the same arithmetic on sums that differ
+    in their last bits (hardware-order accumulation), so: same iteration / step counts, costs to 1e-9, poses to 1e-8."""
+    iters = 8
+    sh, ph, xh, sth = _solve(ctx, cfg4, "mfma", iters, bulk_control=False)
+    sd, pd, xd, std = _solve(ctx, cfg4, "mfma", iters, bulk_control=True)
+    assert sth.device_control == 0 and std.device_control == 1
+    assert sd.iterations == sh.iterations == iters and sd.successful_steps == sh.successful_steps
+    assert abs(sd.initial_cost - sh.initial_cost) <= 1e-11 * sh.initial_cost
+    assert abs(sd.final_cost - sh.final_cost) <= 1e-9 * sh.final_cost
+    assert np.allclose(pd, ph, rtol=0, atol=1e-8)
+    assert np.allclose(xd, xh, rtol=1e-8, atol=1e-7)
+    assert np.array_equal(pd[0], cfg4["poses0"][0])
+    assert std.step_calls == iters and std.linearize_calls == 1 and std.speculation_hits >= iters - 1
+    assert 0 < std.host_us / iters < 200  # enqueueing five operations per iteration; the GPU never waits for it (run-ahead)
 
 
 @pytest.mark.gpu
@@ -128,6 +147,10 @@ def test_hip_config4_landmark_shards_equal_the_unsharded_solve(ctx, cfg4, world)
         assert np.array_equal(poses, res[0][2])  # bit-identical poses on every "rank"
         # collectives per rank: one per stand-alone pass A; per LM iteration ONE when both payloads share it (same sweep) or
         # when no next linearisation is asked for (the last iteration), two when the decision is chained (payload2, payload1)
-        chained = st.speculations - st.single_exchange
-        assert calls[rank] == st.linearize_calls + (st.step_calls - chained) + 2 * chained
+        # With the step control on the device (the default here) every sequence slot is chained and the host stays SVO_BA_RUNAHEAD
+        # (2) slots ahead of the status records: one collective for the first linearisation, two per enqueued slot — the same count on
+        # every rank, because a slot is enqueued as a function of the records alone.
+        assert st.device_control == 1 and st.host_us > 0
+        assert calls[rank] == st.collectives == calls[0]
+        assert st.collectives <= 1 + 2 * (iters + 2)
     [c.close() for c in ctxs]

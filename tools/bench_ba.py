@@ -201,8 +201,12 @@ def run(args, cpu_seconds=12.0):
                                    "payloads_in_one_collective": st.single_exchange},
                       # all-reduces the LM loop issued (or would issue on N ranks): a stand-alone pass A = 1, a same-sweep step = 1
                       # (both payloads in one buffer), a chained step = 2 (payload2, decision, payload1), a plain step = 1
-                      "collectives_per_iteration": (st.linearize_calls + st.single_exchange + 2 * (st.speculations - st.single_exchange) +
-                                                    (st.step_calls - st.speculations)) / n_it}}
+                      "collectives_per_iteration": st.collectives / n_it,
+                      # round 5: where the step control ran (1: ba_bulk_control_kernel on the device, the host only enqueues) and what the
+                      # host spent inside the LM loop per iteration — launch calls; with the device-side control it is overlapped by the
+                      # run-ahead (the GPU never waits for it)
+                      "step_control_on_device": bool(st.device_control),
+                      "host_us_per_iteration": st.host_us / n_it}}
     if k_n:
         # roofline of the dominant kernel.  achieved = SURVEY 8d algorithmic f64 flops of one linearisation / launch time,
         # HIP events on the adjuster's stream.  peak = the f64 MFMA rate MEASURED on this card (svo_measure_peak).
