@@ -334,6 +334,16 @@ int svo_rccl_comm_destroy(void* nccl_comm);
  * than two pipelines are inside svo_pipeline_process_batch* (pipeline groups always solve on the device).  Results are
  * bit-identical either way. */
 int svo_ba_set_device_lm(svo_ba* ba, int mode);
+/* Which form a device-resident window solve takes (both run src/bundle_adjuster.cpp:140's whole ceres::Solve on the device,
+ * bit-identical to each other and to the host-driven loop):
+ *   0 wide     ba_lm_kernel: one workgroup per two chunks of 64 observations (~47 for the reference's 5-keyframe window), replicated
+ *              step control, lowest latency — a lone stereo stream (the reference's vo_node);
+ *   1 compact  ba_lm_compact_kernel: ONE workgroup per solve, its wavefronts take the chunks in turn, step control once, nothing
+ *              waits for another workgroup — 1/16 of the wide form's wavefronts and LDS for ~10x its latency (measured: it does not
+ *              pay at 48-128 streams on one MI355X); the re-run of a wide solve that gave up, the overflow of the
+ *              admission budget (SVO_BA_OVERFLOW=1); takes windows of up to 256 chunks (the wide form: 128);
+ *  -1 default  SVO_BA_FORM=wide|compact if set, else wide. */
+int svo_ba_set_solve_form(svo_ba* ba, int form);
 /* Where the step control runs for BULK / SHARDED solves (hardware-order accumulation, svo_ba_load_problem +
  * svo_ba_solve_problem; the all-reduce of src/bundle_adjuster.cpp:140's normal equations over the ranks): mode 1 / -1 (default):
  * on the device — per LM iteration the host only enqueues [pass B, all-reduce, pass A, all-reduce, control kernel], a fixed

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "ora_constants.h"
+#include "ora_trig.h"
 #include "svo_oracle.h"
 
 namespace {
@@ -38,22 +39,8 @@ struct Keyframe {  // src/bundle_adjuster.hpp:22-46
   std::vector<size_t> new_ids;
 };
 
-// cv::Rodrigues on a CV_32F rvec: computed in double, stored as float.
-void rodrigues_f(const float* rv, float* R9) {
-  const double rx = rv[0], ry = rv[1], rz = rv[2];
-  const double th = std::sqrt(rx * rx + ry * ry + rz * rz);
-  double R[9];
-  if (th < 2.220446049250313e-16) {
-    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
-  } else {
-    const double c = std::cos(th), s = std::sin(th), c1 = 1.0 - c, it = 1.0 / th;
-    const double x = rx * it, y = ry * it, z = rz * it;
-    R[0] = c + c1 * x * x; R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
-    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y; R[5] = c1 * y * z - s * x;
-    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
-  }
-  for (int i = 0; i < 9; ++i) R9[i] = (float)R[i];
-}
+// cv::Rodrigues on a CV_32F rvec with declared arithmetic (ora_trig.h; round 5: the HIP path runs this conversion on the device)
+void rodrigues_f(const float* rv, float* R9) { ora_trig::rodrigues_f(rv, R9); }
 
 // Eigen::Quaternionf(Matrix3f) (src/image_processor.cpp:92), float arithmetic.
 void quat_from_R(const float* m, float* q /*wxyz*/) {

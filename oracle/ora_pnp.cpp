@@ -22,6 +22,7 @@
 #include <cstdint>
 #include <vector>
 
+#include "ora_trig.h"
 #include "svo_oracle.h"
 
 namespace {
@@ -219,6 +220,13 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
 
 extern "C" int ora_pnp_update_num_iters(double p, double ep, int model_points, int max_iters) { return update_num_iters(p, ep, model_points, max_iters); }
 extern "C" double ora_pnp_det_log(double x) { return det_log(x); }
+// the declared trigonometry of the pose conversions (ora_trig.h): taps for tests/test_pnp.py
+extern "C" double ora_det_atan2_q1(double y, double x) { return ora_trig::atan2_q1(y, x); }
+extern "C" void ora_det_sincos(double x, double* sn, double* cs) { ora_trig::sincos_det(x, sn, cs); }
+extern "C" void ora_det_rvec_quat_roundtrip(const double* rvec3, double* quat4, double* rvec3_back) {
+  ora_trig::quat_from_rvec(rvec3, quat4);
+  ora_trig::rvec_from_quat(quat4, rvec3_back);
+}
 
 extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float focal, float cxf,
                               float cyf, double* rvec3, double* tvec3, int iterations,
@@ -226,15 +234,10 @@ extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float fo
   const int kModel = 5;
   if (n < kModel) return 0;
   const double f = focal, cx = cxf, cy = cyf;
-  // Rodrigues(rvec) -> quaternion (host libm)
+  // Rodrigues(rvec) -> quaternion (declared arithmetic, ora_trig.h)
   Pose P0;
   {
-    const double th = std::sqrt(rvec3[0] * rvec3[0] + rvec3[1] * rvec3[1] + rvec3[2] * rvec3[2]);
-    if (th < 1e-12) { P0.q[0] = 1; P0.q[1] = 0.5 * rvec3[0]; P0.q[2] = 0.5 * rvec3[1]; P0.q[3] = 0.5 * rvec3[2]; }
-    else {
-      const double s = std::sin(0.5 * th) / th;
-      P0.q[0] = std::cos(0.5 * th); P0.q[1] = s * rvec3[0]; P0.q[2] = s * rvec3[1]; P0.q[3] = s * rvec3[2];
-    }
+    ora_trig::quat_from_rvec(rvec3, P0.q);
     for (int k = 0; k < 3; ++k) P0.t[k] = tvec3[k];
   }
   const double thr2 = (double)reproj_err * (double)reproj_err;
@@ -294,15 +297,8 @@ extern "C" int ora_pnp_ransac(const float* xyz, const float* xy, int n, float fo
     if (ex * ex + ey * ey <= thr2) inliers[m++] = i;
   }
   const Pose F = lm_solve(B, xyz, xy, inliers, m, f, cx, cy, 20, true);
-  // quaternion -> rvec (host libm)
-  double q[4] = {F.q[0], F.q[1], F.q[2], F.q[3]};
-  if (q[0] < 0) for (double& v : q) v = -v;
-  const double vn = std::sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (vn < 1e-12) { rvec3[0] = 2 * q[1]; rvec3[1] = 2 * q[2]; rvec3[2] = 2 * q[3]; }
-  else {
-    const double th = 2.0 * std::atan2(vn, q[0]);
-    rvec3[0] = q[1] / vn * th; rvec3[1] = q[2] / vn * th; rvec3[2] = q[3] / vn * th;
-  }
+  // quaternion -> rvec (declared arithmetic, ora_trig.h)
+  ora_trig::rvec_from_quat(F.q, rvec3);
   for (int k = 0; k < 3; ++k) tvec3[k] = F.t[k];
   return m;
 }

@@ -160,7 +160,7 @@ SYMBOLS = [
     "svo_pnp_ransac",
     "svo_ba_default_options", "svo_ba_create", "svo_ba_destroy", "svo_ba_reset", "svo_ba_add_keyframe", "svo_ba_solve",
     "svo_ba_get_pose", "svo_ba_window_count", "svo_ba_get_points", "svo_ba_load_problem",
-    "svo_ba_set_allreduce", "svo_ba_set_device_lm", "svo_ba_set_bulk_control", "svo_ba_solve_problem", "svo_ba_read_problem", "svo_ba_set_comm", "svo_ba_last_stats", "svo_lm_solve", "svo_lm_decide_step",
+    "svo_ba_set_allreduce", "svo_ba_set_device_lm", "svo_ba_set_bulk_control", "svo_ba_set_solve_form", "svo_ba_solve_problem", "svo_ba_read_problem", "svo_ba_set_comm", "svo_ba_last_stats", "svo_lm_solve", "svo_lm_decide_step",
     "svo_rccl_unique_id", "svo_rccl_comm_create", "svo_rccl_comm_destroy",
     "svo_pipeline_default_params", "svo_pipeline_create", "svo_pipeline_destroy", "svo_pipeline_reset",
     "svo_pipeline_process_batch_dev", "svo_pipeline_process_batch", "svo_pipeline_get_tracked",
@@ -417,7 +417,7 @@ class BA:
     """svo_ba wrapper: sliding-window graph (add_keyframe / solve) and the bulk-problem interface."""
 
     def __init__(self, ctx, window_size, focal, cx, cy, baseline=0.0, max_landmarks=1 << 16,
-                 max_observations=1 << 18, max_iterations=50, max_time_s=0.0, max_features=400, accumulation="auto", device_lm=None, bulk_control=None):
+                 max_observations=1 << 18, max_iterations=50, max_time_s=0.0, max_features=400, accumulation="auto", device_lm=None, bulk_control=None, solve_form=None):
         self.ctx = ctx
         self.L = ctx.L
         cam = CameraInfo(focal, cx, cy, 0, 0, 0, 0, baseline)
@@ -432,6 +432,8 @@ class BA:
                                       max_landmarks, max_observations), "svo_ba_create")
         if device_lm is not None:
             ctx._chk(self.L.svo_ba_set_device_lm(self.h, 1 if device_lm else 0), "svo_ba_set_device_lm")
+        if solve_form is not None:  # "wide" / "compact": which device-resident form a window solve takes
+            ctx._chk(self.L.svo_ba_set_solve_form(self.h, {"wide": 0, "compact": 1}[solve_form]), "svo_ba_set_solve_form")
         if bulk_control is not None:  # bulk / sharded solves: step control on the device (True) or host-driven (False)
             ctx._chk(self.L.svo_ba_set_bulk_control(self.h, 1 if bulk_control else 0), "svo_ba_set_bulk_control")
         self.L.svo_ba_destroy.argtypes = [C.c_void_p]

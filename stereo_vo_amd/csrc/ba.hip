@@ -545,8 +545,11 @@ struct ChunkTab {
 
 // Where a chunk's partials go: group g of the partial store.  `first`: the group's first chunk (its partial starts the
 // group's sum); otherwise the partial is added to what the group holds so far (same wavefront, acknowledged stores).
-struct PartSink { double* part1; double* part2; double* pst; int Epad, E, NG, g, first, parity; unsigned long long tag; };
+// part1 == null: the compact form (ba_lm_compact_kernel) — the chunk's partials stay in the workgroup's LDS (pst: the E elements of
+// pass A; pst2: pass B's four sums) and are added to the running totals there, nothing crosses workgroups.
+struct PartSink { double* part1; double* part2; double* pst; int Epad, E, NG, g, first, parity; unsigned long long tag; double* pst2; };
 __device__ __forceinline__ void post1(const PartSink& k, int e, double v) {
+  if (!k.part1) { k.pst[e] = v; return; }
   double* slot = k.part1 + 2 * ((size_t)k.g * k.Epad + e);
   if (!k.first) v = slot_load(slot) + v;
   granule_store(slot, v, k.tag);
@@ -555,6 +558,7 @@ __device__ __forceinline__ void emit1(const PartSink& k, int e, double v) {
   if (k.pst) k.pst[e] = v; else post1(k, e, v);
 }
 __device__ __forceinline__ void emit2(const PartSink& k, int i, double v) {
+  if (!k.part1) { k.pst2[i] = v; return; }
   double* slot = k.part2 + 2 * (((size_t)k.parity * k.NG + k.g) * 4 + i);
   if (!k.first) v = slot_load(slot) + v;
   granule_store(slot, v, k.tag);
@@ -817,7 +821,7 @@ __device__ __forceinline__ void chunk_owner_phases(const ObsRec& R, const ChunkT
   }
   // ---- cost, sum g_p^2: landmark order.  LAST: sum g_p^2 is the readers' sentinel.
   sync();
-  if (sink.pst) {  // the chunk's partials leave as one contiguous run
+  if (sink.pst && sink.part1) {  // the chunk's partials leave as one contiguous run
     for (int e = tid; e < sink.E - 2; e += nt) post1(sink, e, sink.pst[e]);
   }
   if (tid < 2) post1(sink, 36 * nU + 33 * F + tid, lds_seq_sum(0.0, rec + LMS_COL + tid, nlm, REC_STRIDE));
@@ -1214,7 +1218,7 @@ __global__ __launch_bounds__(256) void ba_linearize_kernel(BaDev P, double radiu
 
 // ---- deterministic mode, host-driven: one wavefront per workgroup, workgroup = group of chunks (window problems: one chunk)
 __device__ __forceinline__ PartSink make_sink(const BaDev& P, int g, int first, double* pst) {
-  return PartSink{P.part1, P.part2, pst, P.Epad, P.E, P.NG, g, first, P.pay_parity, P.pay_tag};
+  return PartSink{P.part1, P.part2, pst, P.Epad, P.E, P.NG, g, first, P.pay_parity, P.pay_tag, nullptr};
 }
 __device__ __forceinline__ ChunkTab global_tab(const BaDev& P, int chunk) { return ChunkTab{P.tab + P.tab_off[chunk], (P.K - 1) * P.K / 2, P.K - 1}; }
 // The chunk's table for the owner phases of a host-driven kernel: copied into the workgroup's LDS first when the host made room
@@ -1361,7 +1365,7 @@ __global__ __launch_bounds__(64) void ba_decide_kernel(LmCtl ctl, double* paybuf
 // Every rank runs it on identical sums, so every rank takes identical decisions (the reason the wall-clock cap is tested on the
 // all-reduced MEAN of the ranks' clocks: the payload's tail carries [elapsed seconds, 1.0] per rank).
 struct LmDevOpt { int max_iterations; double function_tolerance, gradient_tolerance, parameter_tolerance, initial_radius, max_time_s; };
-constexpr int BS_HEAD = 16;                      // status record: [seq | done | iterations | successful | termination | initial cost | cost | sel | stand-alone pass-A slots | steps | next linearisation used | mode | radius | elapsed s | - | -] then 7 K poses
+constexpr int BS_HEAD = 24;                      // status record: [seq | done | iterations | successful | termination | initial cost | cost | sel | stand-alone pass-A slots | steps | next linearisation used | mode | radius | elapsed s | - | -] then 7 K poses
 constexpr int BS_DOUBLES = BS_HEAD + 7 * 64;
 struct BulkCtlArgs {
   int n, K, slot, ring;
@@ -1375,7 +1379,7 @@ struct BulkCtlArgs {
 };
 static inline size_t ba_bulk_ctl_lds_doubles(int n, int K) {
   const size_t nn = n > 0 ? n : 1;
-  return (size_t)n * n + (3 * (size_t)n + 4) + 4 * nn + (nn + 14 * (size_t)K) + (6 * nn + 1) + 14 * (size_t)K;
+  return (size_t)n * n + (3 * (size_t)n + 4) + 4 * nn + (nn + 14 * (size_t)K) + (7 * nn + 8) + 14 * (size_t)K;
 }
 
 __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
@@ -1394,22 +1398,48 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
   double* cSc = cRhs + nn;
   double* cDc = cSc + nn;
   double* cTerm = cDc + nn;                 // nn + 14 K: per-element terms of the sequential sums
-  double* cCol = cTerm + nn + 14 * K;       // 6 nn + 1: the Cholesky's panel columns
-  double* cPose = cCol + 6 * nn + 1;        // 7 K current poses
+  double* cCol = cTerm + nn + 14 * K;       // 7 nn + 8: the solver's panel columns, reciprocal pivots, panel part of y
+  double* cPose = cCol + 7 * nn + 8;        // 7 K current poses
   double* cCand = cPose + 7 * K;            // 7 K candidate poses
   enum { ACT_RETURN = 0, ACT_GRAD, ACT_LOOPTOP, ACT_SOLVE, ACT_FINISH };
   const bool was_done = st[BC_DONE] != 0.0;
   double elapsed_now = 0.0;
+  // phase stamps of thread 0 (100 MHz ticks since kernel entry): loaded | step consumed | system built | factored + solved | step written
+  long long tk0 = tid == 0 ? (long long)wall_clock64() : 0, tk[5] = {0, 0, 0, 0, 0};
+  auto stamp = [&](int i) { if (tid == 0) tk[i] = (long long)wall_clock64() - tk0; };
   if (!was_done) {
     const int mode = (int)st[BC_MODE], sel = (int)st[BC_SEL] & 1;
     const double* P1 = a.pay + PAY2_SLOTS;
     for (int i = tid; i < 3 * n + 4; i += nt) cV[i] = P1[(size_t)n * n + i];
     // every unordered pose pair was accumulated once (upper block), diagonal pose blocks in full: the lower triangle as
     // ba_payload1_out forms it (src[ij] + src[ji] off the diagonal blocks)
-    for (int idx = tid; idx < n * n; idx += nt) {
-      const int r = idx / n, c = idx - r * n;
-      if (c > r) continue;
-      cS[idx] = (r / 6 == c / 6) ? P1[idx] : P1[idx] + P1[(size_t)c * n + r];
+    // (The lower off-diagonal blocks of the payload are +0.0, so "src[ij] + src[ji]" is the upper element + 0.0.)  Read as the
+    // payload lies in memory — wavefront = row, lanes = consecutive columns, eight rows in flight — and placed transposed.
+    {
+      const int wv = tid >> 6, ln = tid & 63, nwv = nt >> 6;
+      for (int r0 = wv; r0 < n; r0 += 8 * nwv) {
+        double v[8][2];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u * nwv, cb = 6 * (r / 6);  // first column of the row's own pose block
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = cb + ln + 64 * h;
+            v[u][h] = (r < n && c < n) ? P1[(size_t)r * n + c] : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int r = r0 + u * nwv, cb = 6 * (r / 6);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int c = cb + ln + 64 * h;
+            if (r >= n || c >= n) continue;
+            if (c < cb + 6) { if (c <= r) cS[r * n + c] = v[u][h]; }  // the row's diagonal pose block: its own lower element
+            else cS[c * n + r] = v[u][h] + 0.0;                        // an upper block: the mirror's lower element
+          }
+        }
+      }
     }
     for (int i = tid; i < 7 * K; i += nt) { cPose[i] = a.pos[sel][i]; cCand[i] = a.step[nn + i]; }
     if (mode != BCM_FIRST) for (int q = tid; q < n; q += nt) cSc[q] = a.sc[q];
@@ -1426,6 +1456,7 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
     __syncthreads();
     if (tid == 0) { a.pay[PAY2_SLOTS + (size_t)n * n + 3 * n + 2] = elapsed_now; a.pay[PAY2_SLOTS + (size_t)n * n + 3 * n + 3] = 1.0; }
     const double ranks = cV[3 * n + 3], mean_elapsed = ranks > 0 ? cV[3 * n + 2] / ranks : 0.0;
+    stamp(0);
     int act = ACT_RETURN;
     if (mode == BCM_FIRST) {
       for (int q = tid; q < n; q += nt) { const double v = 1.0 / (1.0 + sqrt(cV[2 * n + q])); cSc[q] = v; a.sc[q] = v; }
@@ -1444,8 +1475,7 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
       if (tid == 0) {
         const double cost = st[BC_COST], mcc = st[BC_MCC], radius = st[BC_RADIUS], df = st[BC_DF];
         const double cost_new = sPay2[0], model_change = mcc + sPay2[1];
-        double step2 = sPay2[2], x2 = sPay2[3];
-        for (int i = 7; i < 7 * K; ++i) { step2 += cTerm[i]; x2 += cTerm[7 * K + i]; }
+        const double step2 = lds_seq_sum(sPay2[2], cTerm + 7, 7 * K - 7, 1), x2 = lds_seq_sum(sPay2[3], cTerm + 7 * K + 7, 7 * K - 7, 1);  // host/lm.cpp's order, eight loads in flight
         const SvoLmDecision dec = svo_lm_decide(cost, mcc, radius, df, cost_new, sPay2[1]);  // what pass A linearised for
         int a_ = ACT_LOOPTOP, accepted = 0;
         if (!(model_change > 0)) {  // invalid step: pass A ran at the current point with radius / df — exactly what is needed
@@ -1470,11 +1500,13 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
       __syncthreads();
     }
     __syncthreads();
+    stamp(1);
     for (;;) {  // block-uniform: every transition is decided by thread 0 and read between two barriers
       if (act == ACT_GRAD) {
+        for (int q = tid; q < n; q += nt) cTerm[q] = cV[n + q] * cV[n + q];
+        __syncthreads();
         if (tid == 0) {  // sqrt(sum g_p^2 + sum g_c^2), sequentially as host/lm.cpp's gradient_norm
-          double g2 = cV[3 * n + 1];
-          for (int q = 0; q < n; ++q) g2 += cV[n + q] * cV[n + q];
+          const double g2 = lds_seq_sum(cV[3 * n + 1], cTerm, n, 1);
           if (sqrt(g2) <= opt.gradient_tolerance) { st[BC_TERM] = 0; sAct = ACT_FINISH; } else sAct = ACT_LOOPTOP;
         }
         __syncthreads();
@@ -1507,15 +1539,18 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
         cRhs[q] = -(cV[q] + cV[n + q]) * sq;
       }
       __syncthreads();
-      for (int idx = tid; idx < n * n; idx += nt) {
-        const int r = idx / n, c = idx - r * n;
-        if (c > r) continue;
-        double w = cS[idx] * cSc[r] * cSc[c];
-        if (r == c) w += cDf[r];
-        cS[idx] = w;
+      for (int r = tid >> 6; r < n; r += nt >> 6) {  // wavefront = row, lanes = columns of the lower triangle
+        const double sr = cSc[r];
+        for (int c = tid & 63; c <= r; c += 64) {
+          double w = cS[r * n + c] * sr * cSc[c];
+          if (r == c) w += cDf[r];
+          cS[r * n + c] = w;
+        }
       }
       __syncthreads();
-      const bool ok = n == 0 || svo_dev_cholesky_solve(cS, cRhs, n, cCol);
+      stamp(2);
+      const bool ok = n == 0 || svo_dev_spd_solve_fast(cS, cRhs, n, cCol);  // (deterministic, not the host's bits: see csrc/lm_device.h)
+      stamp(3);
       if (ok) {
         for (int q = tid; q < n; q += nt) {
           const double rq = cRhs[q], sq = cSc[q];
@@ -1524,9 +1559,7 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
         }
         __syncthreads();
         if (tid == 0) {
-          double mcc = 0.0;
-          for (int q = 0; q < n; ++q) mcc += cTerm[q];
-          st[BC_MCC] = mcc; st[BC_STEP_CALLS] += 1; st[BC_MODE] = (double)BCM_STEP;
+          st[BC_MCC] = lds_seq_sum(0.0, cTerm, n, 1); st[BC_STEP_CALLS] += 1; st[BC_MODE] = (double)BCM_STEP;
         }
         if (tid < K) {
           if (tid == 0) for (int q = 0; q < 7; ++q) cCand[q] = cPose[q];
@@ -1559,6 +1592,8 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
     pay_store(&rec[5], st[BC_INITIAL_COST]); pay_store(&rec[6], st[BC_COST]); pay_store(&rec[7], st[BC_SEL]); pay_store(&rec[8], st[BC_LIN_CALLS]);
     pay_store(&rec[9], st[BC_STEP_CALLS]); pay_store(&rec[10], st[BC_NEXT_USED]); pay_store(&rec[11], st[BC_MODE]); pay_store(&rec[12], st[BC_RADIUS]);
     pay_store(&rec[13], elapsed_now);
+    stamp(4);
+    for (int i = 0; i < 5; ++i) pay_store(&rec[14 + i], (double)tk[i]);
   }
   stores_acknowledged();
   __syncthreads();
@@ -1699,6 +1734,37 @@ __host__ __device__ static inline size_t ba_lm_lds_doubles(int n, int K, int tab
   return ba_lm_union_doubles(n, K) + (size_t)LM_CPW * (size_t)tab_words / 4 + 3 * (size_t)(n > 0 ? n : 1) + 14 * (size_t)K;
 }
 
+// wire total e -> its place in the payload image (cP) or the U triangles (cU)
+__device__ __forceinline__ void lm_place_total(int e, double v, double* cP, double* cU, int F, int n) {
+  const int nU = F * (F + 1) / 2;
+  if (e < 36 * nU) {
+    const int d = e / 36, el = e - 36 * d;
+    int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
+    while (rest >= F - ka) { rest -= F - ka; ++ka; }
+    const int kb = ka + rest;
+    cP[(6 * ka + el / 6) * n + 6 * kb + el % 6] = v;
+  } else if (e < 36 * nU + 33 * F) {
+    const int k = (e - 36 * nU) / 33, el = (e - 36 * nU) - 33 * k;
+    if (el < 6) cP[n * n + n + 6 * k + el] = v;            // g_c
+    else if (el < 12) cP[n * n + 6 * k + (el - 6)] = v;    // g_red (the -Y g_p part)
+    else cU[21 * k + (el - 12)] = v;
+  } else {
+    cP[n * n + 3 * n + (e - 36 * nU - 33 * F)] = v;
+  }
+}
+// diagonal pose blocks take U; diag U.  Ends with a barrier.
+__device__ __forceinline__ void lm_fold_u(double* cP, const double* cU, int F, int n) {
+  for (int i = threadIdx.x; i < 36 * F; i += (int)blockDim.x) {
+    const int k = i / 36, a = (i % 36) / 6, b = i % 6;
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    const double uu = cU[21 * k + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
+    double* s = &cP[(6 * k + a) * n + 6 * k + b];
+    *s = uu + *s;
+    if (a == b) cP[n * n + 2 * n + 6 * k + a] = uu;
+  }
+  __syncthreads();
+}
+
 // The E wire totals (granules under `tag`) -> the payload image [S | g_red | g_c | diag U | cost | sum g_p^2] in LDS, assembled as
 // the oracle does: S[(k,a),(k,b)] = U_k[min][max] + Schur_(k,k)[a][b]; upper blocks as summed; the step control reads the
 // lower triangle through the mirror (see the system build).  cU: 21 F doubles of scratch.  false: a tag never showed up.
@@ -1741,44 +1807,25 @@ __device__ __forceinline__ bool lm_fetch_totals(double* cP, double* cU, const do
     for (int u = 0; u < 8; ++u) {
       const int e = gi[u];
       if (e < 0) continue;
-      if (e < 36 * nU) {
-        const int d = e / 36, el = e - 36 * d;
-        int ka = 0, rest = d;  // d = ka F - ka (ka - 1) / 2 + (kb - ka), row-major over ka <= kb
-        while (rest >= F - ka) { rest -= F - ka; ++ka; }
-        const int kb = ka + rest;
-        cP[(6 * ka + el / 6) * n + 6 * kb + el % 6] = v[u];
-      } else if (e < 36 * nU + 33 * F) {
-        const int k = (e - 36 * nU) / 33, el = (e - 36 * nU) - 33 * k;
-        if (el < 6) cP[n * n + n + 6 * k + el] = v[u];            // g_c
-        else if (el < 12) cP[n * n + 6 * k + (el - 6)] = v[u];    // g_red (the -Y g_p part)
-        else cU[21 * k + (el - 12)] = v[u];
-      } else if (e < E) {
-        cP[n * n + 3 * n + (e - 36 * nU - 33 * F)] = v[u];
-      } else {
-        *elapsed = v[u];
-      }
+      if (e < E) lm_place_total(e, v[u], cP, cU, F, n);
+      else *elapsed = v[u];
     }
   }
   __syncthreads();
-  // diagonal pose blocks take U; diag U
-  for (int i = threadIdx.x; i < 36 * F; i += (int)blockDim.x) {
-    const int k = i / 36, a = (i % 36) / 6, b = i % 6;
-    const int lo = a < b ? a : b, hi = a < b ? b : a;
-    const double uu = cU[21 * k + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)];
-    double* s = &cP[(6 * k + a) * n + 6 * k + b];
-    *s = uu + *s;
-    if (a == b) cP[n * n + 2 * n + 6 * k + a] = uu;
-  }
-  __syncthreads();
+  lm_fold_u(cP, cU, F, n);
   return good;
 }
 
 // Controller turn (every thread of every workgroup; identical inputs -> identical state everywhere): consume the
 // finished pass, run host/lm.cpp's step control up to the next pass.  Leaves the next pass' step block
 // [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
-__device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* cSc, double* sStep, double* sOut4) {
+// LOCAL (ba_lm_compact_kernel: ONE workgroup runs the whole solve): the summed payloads are not collected from granules, they sit in
+// the workgroup's LDS — `tot` (E wire totals) and `tot2` (pass B's four sums); cs.elapsed is set by the caller from its own clock.
+template <bool LOCAL>
+__device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* cSc, double* sStep, double* sOut4,
+                                                        const double* tot = nullptr, const double* tot2 = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
-  const int grid = (P.C + LM_CPW - 1) / LM_CPW;  // workgroups of THIS solve (the launch may hold several solves)
+  const int grid = LOCAL ? 1 : (P.C + LM_CPW - 1) / LM_CPW;  // workgroups of THIS solve (the launch may hold several solves)
   const int pay1 = n * n + 3 * n + 2;
   double* cP = cl;             // payload image [S | g_red | g_c | diag U | cost | sum g_p^2]; S becomes the scaled system, then L
   double* cDf = cP + pay1;
@@ -1840,8 +1887,12 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
   if (st == LMS_STEP) {
     // payload2: a chained step formed it (and the decision) inside the pass; otherwise collect the group sums now
     if (!cs.chain) {
-      if (!sum_pay2<false>(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
-      if (tid < 4) cs.pay2[tid] = sOut4[tid];
+      if constexpr (LOCAL) {
+        if (tid < 4) cs.pay2[tid] = tot2[tid];
+      } else {
+        if (!sum_pay2<false>(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+        if (tid < 4) cs.pay2[tid] = sOut4[tid];
+      }
       __syncthreads();
     }
     for (int i = tid; i < 7 * K; i += nt) {  // terms of the pose part of |step|^2 and |x|^2 (host/lm.cpp after ops->step)
@@ -1901,7 +1952,13 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
   // ONE call site: the collection is 3 KB of code in a kernel that is larger than the instruction cache.
   if (fetch) {
     if (tid == 0) { const long long w0 = (long long)wall_clock64(); cs.t_mark = w0; }
-    if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+    if constexpr (LOCAL) {
+      for (int e = tid; e < P.E; e += nt) lm_place_total(e, tot[e], cP, cU, K - 1, n);
+      __syncthreads();
+      lm_fold_u(cP, cU, K - 1, n);
+    } else {
+      if (!lm_fetch_totals(cP, cU, a.dev_res, K - 1, n, cs.tag, &cs.elapsed, grid, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+    }
     if (tid == 0) { const long long w1 = (long long)wall_clock64(); cs.t_wait += w1 - cs.t_mark; cs.t_mark = w1; }
   }
   __syncthreads();
@@ -2213,14 +2270,17 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
   __syncthreads();
   for (;;) {
     const int st_before = cs.state;
-    const int op = lm_controller(P, a, cs, union_lds, cSc, sStep, sh.sOut);
+    const int op = lm_controller<false>(P, a, cs, union_lds, cSc, sStep, sh.sOut);
     if (a.dbg && tid == 0) {
       unsigned* g = a.dbg + 16 * blockIdx.x;
       g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
       g[4] = (unsigned)cs.chain | ((unsigned)cs.bad << 8);  // bit 8: a tagged granule never arrived
       g[5] = cs.arrive_total; g[6] = cs.op_count; g[7] = (unsigned)cs.lin_calls;
     }
-    if (op == LMOP_ABORT || cs.bad) return;
+    if (op == LMOP_ABORT || cs.bad) {  // a bounded wait ran out: tell the host now (it re-runs the solve), the other workgroups follow within their own bound
+      if (tid == 0) __hip_atomic_store(a.host_flag, -a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
     if (op == LMOP_EXIT) break;
     if (st_before == LMS_STEP && cs.accepted) W.R.p = W.cand;  // the step control took the step: the candidate is the current point
     if (!t_first) t_first = (long long)wall_clock64();
@@ -2261,7 +2321,225 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
       continue;  // the next controller turn answers "delivered": everybody leaves
     }
     long long* tp = a.dbg ? cs.tp : nullptr;
-    if (!lm_iterate(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, op == LMOP_ITERATE ? tp : nullptr, op != LMOP_ITERATE)) return;
+    if (!lm_iterate(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, op == LMOP_ITERATE ? tp : nullptr, op != LMOP_ITERATE)) {
+      if (tid == 0) __hip_atomic_store(a.host_flag, -a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return;
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The THROUGHPUT form of the device-resident solve: ba_lm_compact_kernel — ONE workgroup runs a whole solve (round 5).
+// ba_lm_kernel spreads a window over ~47 workgroups of two 256-VGPR wavefronts that spend most of their life parked, waiting for
+// each other's tagged granules: with 48 streams on the GPU ~10 resident solves held 46 % of all register files and the frame
+// rate stopped growing with the number of streams.  Here a solve is NW <= 6 wavefronts in one workgroup:
+//   * wavefront w takes chunks w, w + NW, w + 2 NW, ... IN TURN through its ONE staging area (rows + outgoing partials: the
+//     same device functions as every other form — backsub_chunk, linearize_prefix, suffix_math, chunk_owner_phases);
+//   * after every round of NW chunks the workgroup meets at a barrier and thread e adds the round's partials of wire element e to
+//     the running total IN CHUNK ORDER — the declared order (groups of G chunks first when C > 128), so the bits are those of
+//     every other form and of the oracle;
+//   * the step control (lm_controller<true>: the same code as ba_lm_kernel's) runs ONCE per solve, on totals that never leave
+//     the workgroup's LDS: no tagged granules, no sentinels, no replicated Cholesky, no hand-over latency;
+//   * nothing waits for another workgroup, so there is no co-residency requirement, no admission budget and no way to give
+//     up: the form is also the fallback of a wide solve that could not make progress.
+// Per solve: 1/16 of the wide form's wavefronts and LDS for ~5x its latency — what a GPU shared by dozens of streams wants.
+// The problem image is copied from pinned host memory into the device arena by the kernel itself (16-byte system-scope loads,
+// eight in flight per thread) and read from there by plain loads (one workgroup = one CU = one L2: coherent by construction).
+constexpr int LMC_MAX_WAVES = 6;
+__host__ __device__ static inline int lmc_wave_doubles(int E) { return 64 * REC_STRIDE + ((E + 1) & ~1) + 2 + 4; }  // rows | partials | 4 ints | pass B's four sums
+__host__ __device__ static inline size_t ba_lmc_union_doubles(int n, int K, int NW) {
+  const size_t a = (size_t)NW * (size_t)lmc_wave_doubles(ba_wire_elements(K)), b = ba_lm_ctl_doubles(n, K);
+  return a > b ? a : b;
+}
+// dynamic LDS (doubles): [NW wave areas | controller workspace] (union) | NW chunk tables | running totals (E) | running group sums (E) |
+// pass B's totals and group sums (4 + 4) | Jacobi scales of the pose columns (nn) | spare (nn) | step block [dc (nn) | candidate poses (7 K) | current poses (7 K)]
+__host__ __device__ static inline size_t ba_lmc_lds_doubles(int n, int K, int tab_words, int NW) {
+  const size_t Ep = ((size_t)ba_wire_elements(K) + 1) & ~(size_t)1, nn = n > 0 ? n : 1;
+  return ba_lmc_union_doubles(n, K, NW) + (size_t)NW * (size_t)tab_words / 4 + 2 * Ep + 8 + 3 * nn + 14 * (size_t)K;
+}
+
+// element `idx` of the running sums takes chunk c's partial p: groups of G consecutive chunks are summed from their first, the
+// groups from the first (grouped_seq_sum's additions in its order)
+__device__ __forceinline__ void lmc_acc(double* tot, double* q, int idx, int c, int C, int G, double p) {
+  if (G <= 1) { tot[idx] = c == 0 ? p : tot[idx] + p; return; }
+  const int r = c % G;
+  const double qq = r == 0 ? p : q[idx] + p;
+  if (r == G - 1 || c == C - 1) tot[idx] = c < G ? qq : tot[idx] + qq;
+  else q[idx] = qq;
+}
+
+struct LmcLds { double* wave_area; uint16_t* tab; double *tot, *q, *tot2, *q2; int wave_doubles; };
+
+// One sweep over all chunks of the solve.  do_b: pass B (step dc_ from the current point, candidate landmarks -> P.cand_points);
+// do_a: pass A — at the candidate pass B just formed (a_from_b: same sweep), at the stored candidate (a_at_cand: behind an accepted
+// chained decision) or at the current point.  Leaves the totals in L.tot2 / L.tot.  Block-uniform arguments.
+__device__ __forceinline__ void lmc_sweep(const BaDev& P, const LmcLds& L, const double* sStep, bool do_b, bool do_a, bool a_from_b, bool a_at_cand,
+                                          double radius_b, double radius_a, int first_a) {
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, NW = nt >> 6;
+  const int C = P.C, G = P.G, E = P.E;
+  const double* dc_ = sStep;
+  const double* cand_poses_ = sStep + (P.n > 0 ? P.n : 1);
+  const double* cur_poses_ = cand_poses_ + 7 * P.K;
+  double* area = L.wave_area + (size_t)wave * L.wave_doubles;
+  double* rec = area;
+  double* pst = area + 64 * REC_STRIDE;
+  int* s_ne = reinterpret_cast<int*>(pst + ((E + 1) & ~1));
+  double* pst2 = pst + ((E + 1) & ~1) + 2;
+  const PartSink sink{nullptr, nullptr, pst, P.Epad, E, P.NG, 0, 1, 0, 0ull, pst2};
+  for (int c0 = 0; c0 < C; c0 += NW) {
+    const int chunk = c0 + wave;
+    if (chunk < C) {
+      const ObsRec R = load_obs(P, chunk, lane, P.points);
+      D3 cand = R.p;
+      double u0 = 0, u1 = 0, u2 = 0, u3 = 0;
+      if (do_a) {  // the chunk's table on its way to LDS while pass B / the prefix compute (plain loads: the arena was written by this workgroup)
+        const uint32_t o0 = P.tab_off[chunk], o1 = P.tab_off[chunk + 1];
+        const int words32 = (int)((o1 - o0 + 1) >> 1);
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(P.tab + o0);
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(L.tab);
+        for (int i = lane; i < words32; i += 64) d32[i] = src[i];
+      }
+      if (do_b) backsub_chunk(P, R, cur_poses_, cand_poses_, dc_, P.cand_points, radius_b, cand, u0, u1, u2, u3, nullptr, rec, &sink);
+      if (do_a) {
+        ObsRec Ra = R;
+        const double* poses_a = cur_poses_;
+        if (a_from_b) { Ra.p = cand; poses_a = cand_poses_; }
+        else if (a_at_cand) {
+          if (R.active) Ra.p = D3{P.cand_points[3 * R.j], P.cand_points[3 * R.j + 1], P.cand_points[3 * R.j + 2]};
+          poses_a = cand_poses_;
+        }
+        LinPre pre;
+        linearize_prefix(P, Ra, poses_a, pre, u0);
+        ChunkRegs cr;
+        cr.s[0] = cr.s[1] = cr.s[2] = 1.0;
+        if (!first_a && R.active) { cr.s[0] = P.sp[3 * R.j]; cr.s[1] = P.sp[3 * R.j + 1]; cr.s[2] = P.sp[3 * R.j + 2]; }
+        SufRegs o;
+        o.freep = false;
+        suffix_math(P, Ra, pre, radius_a, first_a, rec, &cr, o);
+        wave_lds_fence();  // the table's LDS copy is complete
+        const ChunkTab T{L.tab, (P.K - 1) * P.K / 2, P.K - 1};
+        chunk_owner_phases<false>(Ra, T, o, rec, sink, s_ne);
+      }
+    }
+    __syncthreads();
+    // the round's partials join the running sums in chunk order
+    const int nw = min(NW, C - c0);
+    if (do_b && tid < 4)
+      for (int w = 0; w < nw; ++w) lmc_acc(L.tot2, L.q2, tid, c0 + w, C, G, (L.wave_area + (size_t)w * L.wave_doubles)[64 * REC_STRIDE + ((E + 1) & ~1) + 2 + tid]);
+    if (do_a)
+      for (int e = tid; e < E; e += nt)
+        for (int w = 0; w < nw; ++w) lmc_acc(L.tot, L.q, e, c0 + w, C, G, (L.wave_area + (size_t)w * L.wave_doubles)[64 * REC_STRIDE + e]);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64 * LMC_MAX_WAVES) void ba_lm_compact_kernel(LmLanePtrs lanes) {
+  extern __shared__ double lds[];  // ba_lmc_lds_doubles(n, K, tab_words, NW)
+  __shared__ LmShared sh;
+  __shared__ LmDevState cs;
+  __shared__ __align__(16) unsigned char sLaneRaw[sizeof(LmLane)];
+  LmLane& sLane = *reinterpret_cast<LmLane*>(sLaneRaw);
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, NW = nt >> 6;
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(lanes.p[blockIdx.y]);
+    unsigned* dst = reinterpret_cast<unsigned*>(&sLane);
+    for (int i = tid; i < (int)(sizeof(LmLane) / 4); i += nt) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  BaDev P = sLane.P;
+  const LmDevArgs& a = sLane.a;
+  const int n = P.n, K = P.K, nn = n > 0 ? n : 1, E = P.E, Ep = (E + 1) & ~1;
+  const int union_doubles = (int)ba_lmc_union_doubles(n, K, NW);
+  LmcLds L;
+  L.wave_area = lds;
+  L.wave_doubles = lmc_wave_doubles(E);
+  L.tab = reinterpret_cast<uint16_t*>(lds + union_doubles) + wave * a.tab_words;
+  L.tot = lds + union_doubles + NW * a.tab_words / 4;
+  L.q = L.tot + Ep;
+  L.tot2 = L.q + Ep;
+  L.q2 = L.tot2 + 4;
+  double* cSc = L.q2 + 4;          // persistent: Jacobi scales of the pose columns
+  double* sStep = cSc + 2 * nn;    // [dc | candidate poses | current poses] (the second nn: spare)
+  // the problem image -> the device arena
+  if (a.arena_src) {
+    const char* src = reinterpret_cast<const char*>(a.arena_src);
+    char* dst = reinterpret_cast<char*>(a.arena_dst);
+    const size_t n16 = a.arena_bytes / 16;
+    for (size_t base = 0; base < n16; base += 8 * (size_t)nt) {
+      uint4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t i = base + (size_t)u * nt + tid;
+        const char* q = src + 16 * (i < n16 ? i : n16 - 1);
+        asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[u]) : "v"(q) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const size_t i = base + (size_t)u * nt + tid;
+        if (i < n16) *reinterpret_cast<uint4*>(dst + 16 * i) = v[u];
+      }
+    }
+  }
+  P.step_in = nullptr; P.flag = nullptr; P.part1 = nullptr; P.part2 = nullptr;
+  __builtin_amdgcn_s_setprio(3);
+  if (tid == 0) { cs.state = LMS_START; cs.bad = 0; cs.accepted = 0; cs.elapsed = 0.0; }
+  __syncthreads();
+  long long t_first = 0;
+  LmDevArgs al = a;
+  al.arena_src = nullptr;  // the controller reads the poses from the device arena now
+  for (;;) {
+    const int st_before = cs.state;
+    if (tid == 0 && t_first) cs.elapsed = 1e-8 * (double)((long long)wall_clock64() - t_first);
+    const int op = lm_controller<true>(P, al, cs, lds, cSc, sStep, sh.sOut, L.tot, L.tot2);
+    if (op == LMOP_ABORT || op == LMOP_EXIT) break;
+    (void)st_before;
+    if (!t_first) t_first = (long long)wall_clock64();
+    const bool sel = cs.sel != 0;
+    P.points = sel ? a.points_b : a.points_a;
+    P.cand_points = sel ? a.points_a : a.points_b;
+    if (op == LMOP_DELIVER) {
+      double* stage = lds + (size_t)wave * L.wave_doubles;  // the staging rows are idle
+      for (int c0 = 0; c0 < P.C; c0 += NW) {
+        const int chunk = c0 + wave;
+        if (chunk >= P.C) break;  // (no barrier below: wave-level only)
+        const ObsRec R = load_obs(P, chunk, lane, P.points);
+        if (a.export_points) deliver_chunk_points(R, a.export_points, stage, 64 * REC_STRIDE);
+        if (a.store && R.active && lane == R.first) {  // get_world_points (src/bundle_adjuster.cpp:159-163: double -> float) for the next keyframe's PnP
+          const unsigned key = P.lm_key[R.j];
+          const unsigned long long lo = ((unsigned long long)__float_as_uint((float)R.p.y) << 32) | __float_as_uint((float)R.p.x);
+          const unsigned long long hi = ((unsigned long long)key << 32) | __float_as_uint((float)R.p.z);
+          slot_store2<true>(reinterpret_cast<double*>(a.store + (key & a.store_mask)), __longlong_as_double((long long)lo), __longlong_as_double((long long)hi));
+        }
+        wave_lds_fence();
+      }
+      stores_acknowledged();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(a.host_flag, a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __syncthreads();
+      continue;  // the next controller turn answers "delivered"
+    }
+    const bool linearize_only = op != LMOP_ITERATE;
+    const double radius = cs.radius, spec = linearize_only ? 0.0 : cs.spec;
+    const int chain = linearize_only ? 0 : cs.chain;
+    if (linearize_only) {
+      lmc_sweep(P, L, sStep, false, true, false, false, 0.0, radius, cs.first);
+    } else if (spec > 0) {
+      lmc_sweep(P, L, sStep, true, true, true, false, radius, spec, 0);
+    } else {
+      lmc_sweep(P, L, sStep, true, false, false, false, radius, 0.0, 0);
+      if (chain) {
+        if (tid == 0) {  // Ceres' decision on the summed payload2 (the same function as everywhere)
+          const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, L.tot2[0], L.tot2[1]);
+          sh.sDec[0] = (double)dec.accept; sh.sDec[1] = dec.next_radius;
+          cs.pay2[0] = L.tot2[0]; cs.pay2[1] = L.tot2[1]; cs.pay2[2] = L.tot2[2]; cs.pay2[3] = L.tot2[3];
+          cs.pay2[4] = (double)dec.accept; cs.pay2[5] = dec.next_radius;
+        }
+        __syncthreads();
+        lmc_sweep(P, L, sStep, false, true, false, sh.sDec[0] != 0.0, 0.0, sh.sDec[1], 0);
+      }
+    }
     __syncthreads();
   }
 }
@@ -2603,6 +2881,10 @@ struct svo_ba {
   unsigned* d_lmdbg = nullptr;   // SVO_BA_TRACE: last command of every workgroup of ba_lm_kernel
   double* h_result = nullptr;    // pinned [LMR_DOUBLES | poses 7 Kmax], inside h_pin
   int device_lm = -1;            // svo_ba_set_device_lm: -1 automatic, 0 never, 1 whenever eligible
+  int lm_form = -1;              // svo_ba_set_solve_form: which device-resident form — 0 wide (ba_lm_kernel: many workgroups, lowest latency), 1 compact (ba_lm_compact_kernel: one workgroup, smallest footprint), -1 automatic (SVO_BA_FORM, else wide)
+  bool lm_compact_inflight = false;  // the launch in flight is the compact form (nothing admitted, no counter)
+  int lm_penalty = 0;            // solves left that avoid the wide form after one of its launches gave up
+  long fallbacks = 0;            // device-resident solves that gave up and were re-run (svo_lm_stats.fallbacks of the last solve: 0 / 1)
   bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
   hipStream_t lm_stream = nullptr;  // ... on this stream
   LmLane* h_lane = nullptr;      // pinned launch record of this adjuster's solve
@@ -2818,6 +3100,12 @@ extern "C" int svo_ba_set_comm(svo_ba* ba, void* nccl_comm) {
 extern "C" int svo_ba_set_device_lm(svo_ba* ba, int mode) {
   if (!ba || mode < -1 || mode > 1) return SVO_ERR_INVALID;
   ba->device_lm = mode;
+  return SVO_OK;
+}
+
+extern "C" int svo_ba_set_solve_form(svo_ba* ba, int form) {
+  if (!ba || form < -1 || form > 1) return SVO_ERR_INVALID;
+  ba->lm_form = form;
   return SVO_OK;
 }
 
@@ -3153,7 +3441,10 @@ int ba_wait_flag(svo_ba* ba, int seq) {
   svo_ctx* ctx = ba->ctx;
   const auto t0 = now();
   unsigned spins = 0;
-  while (__atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE) != seq) {
+  for (;;) {
+    const int v = __atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE);
+    if (v == seq) break;
+    if (v == -seq && seq != 0) { ctx->err = "ba: the device-resident solve gave up (a workgroup waited 3 s for another one's partial sums)"; return SVO_ERR_HIP; }
     __builtin_ia32_pause();
     if (++spins > 4096u && (spins & 63u) == 0) sched_yield();  // long wait: stay polite when threads outnumber cores
     if ((spins & 0xFFFFu) == 0 && ms_between(t0, now()) > 10000.0) {  // never expected: fall back to the stream wait
@@ -3351,12 +3642,41 @@ int ba_lm_tab_words(const svo_ba* ba) { return std::max(64, (ba->tab_max_words +
 size_t ba_lm_lds_bytes(const svo_ba* ba) { return sizeof(double) * ba_lm_lds_doubles(ba->d.n, ba->d.K, ba_lm_tab_words(ba)); }
 
 // Fills the adjuster's launch record for the loaded problem; false: not eligible (use the host-driven path).
-bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
+// compact form: the waves per workgroup that fit 156 KB of dynamic LDS (the kernel keeps ~1.5 KB of static LDS), at most
+// SVO_BA_COMPACT_WAVES (default 6) and not more than the problem has chunks; 0: not eligible
+constexpr size_t LMC_LDS_BUDGET = 156 * 1024;
+constexpr int LMC_MAX_CHUNKS = 256;   // beyond, a single workgroup's rounds take longer than the host-driven loop's launches
+int ba_lmc_tab_words(const svo_ba* ba) { return std::max(64, (ba->tab_max_words + 63) & ~63); }
+int ba_lmc_waves(const svo_ba* ba) {
+  static const int cap = [] { const char* e = getenv("SVO_BA_COMPACT_WAVES"); const int v = e ? atoi(e) : LMC_MAX_WAVES; return v < 1 ? 1 : (v > LMC_MAX_WAVES ? LMC_MAX_WAVES : v); }();
+  const BaDev& d = ba->d;
+  int nw = std::min(cap, std::max(1, d.C));
+  while (nw >= 1 && sizeof(double) * ba_lmc_lds_doubles(d.n, d.K, ba_lmc_tab_words(ba), nw) > LMC_LDS_BUDGET) --nw;
+  return nw;
+}
+// which device-resident form a solve of this adjuster takes (see svo_ba_set_solve_form)
+bool ba_wants_compact(const svo_ba* ba) {
+  if (ba->lm_penalty > 0) return true;
+  if (ba->lm_form >= 0) return ba->lm_form == 1;
+  static const int env = [] { const char* e = getenv("SVO_BA_FORM"); return !e || !*e ? -1 : (e[0] == 'c' ? 1 : (e[0] == 'w' ? 0 : -1)); }();
+  return env == 1;
+}
+
+bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced, bool compact = false, int* waves_out = nullptr) {
   BaDev& d = ba->d;
   if (!d.det || d.C <= 0 || !ba_zero_copy(ba) || !(forced || ba->device_lm == 1 || (ba->device_lm < 0 && ba_device_lm_wanted())) || !ba->h_lane) return false;
+  size_t lds = 0;
+  int nw = 0;
+  if (compact) {
+    if (d.C > LMC_MAX_CHUNKS || ba->tab_max_words > 4096) return false;
+    nw = ba_lmc_waves(ba);
+    if (nw < 1) return false;
+    lds = sizeof(double) * ba_lmc_lds_doubles(d.n, d.K, ba_lmc_tab_words(ba), nw);
+  } else {
   if (d.C > 128 || ba->tab_max_words > TAB_LDS_WORDS) return false;  // one group per chunk, every chunk table in LDS: window-sized problems
-  const size_t lds = ba_lm_lds_bytes(ba);
+  lds = ba_lm_lds_bytes(ba);
   if (lds > 120 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
+  }
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   d.flag = nullptr;
   if (ba->arena_partial && ba_refresh_arena_image(ba)) return false;  // a re-solve after a zero-copy solve: the host image takes the solved state first
@@ -3376,14 +3696,15 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
   // unless the last one did not leave cleanly
   const bool fresh = ba->lm_counters_dirty || !ba->lm_have_base;
   a.base_arrive = fresh ? 0 : ba->lm_base;
-  a.tab_words = ba_lm_tab_words(ba);
+  a.tab_words = compact ? ba_lmc_tab_words(ba) : ba_lm_tab_words(ba);
   a.opt.max_iterations = ba->opt.max_iterations;
   a.opt.function_tolerance = ba->opt.function_tolerance; a.opt.gradient_tolerance = ba->opt.gradient_tolerance;
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
   a.opt.max_time_s = ba->opt.max_time_s;  // src/bundle_adjuster.cpp:11, tested on workgroup 0's posted clock
   a.dbg = d.C <= 8192 ? ba->d_lmdbg : nullptr;
-  *cost = ba_lm_admission_cost((d.C + LM_CPW - 1) / LM_CPW, lds, ba->ctx->device);
+  *cost = compact ? 0 : ba_lm_admission_cost((d.C + LM_CPW - 1) / LM_CPW, lds, ba->ctx->device);
   *lds_out = lds;
+  if (waves_out) *waves_out = nw;
   return true;
 }
 
@@ -3392,19 +3713,25 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced) {
 // or not admitted adjuster is skipped, not a barrier for those behind it).  The others keep their loaded problem and can be
 // offered again later, or solved by the host-driven path.
 int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsigned long long* launched_mask) {
+  if (launched_mask) *launched_mask = 0;
+  // SVO_BA_OVERFLOW=1: a solve the admission budget refuses takes the compact form at once instead of waiting for the budget
+  static const bool overflow = [] { const char* e = getenv("SVO_BA_OVERFLOW"); return e && *e && atoi(e) != 0; }();
+  bool to_compact[SVO_MAX_LANES] = {};
+  // ---- the wide form (ba_lm_kernel): admitted against the budget of co-resident waiting workgroups
   LmLanePtrs ptrs;
   int launched = 0, max_c = 0;
   size_t max_lds = 0;
   svo_ba* took[SVO_MAX_LANES];
-  if (launched_mask) *launched_mask = 0;
+  int tidx[SVO_MAX_LANES];
   for (int i = 0; i < n && i < SVO_MAX_LANES; ++i) {
     svo_ba* ba = bas[i];
     int cost = 0;
     size_t lds = 0;
     ba->lm_inflight = false;
+    if (ba_wants_compact(ba)) { to_compact[i] = true; continue; }
     if (!ba_device_lm_fill(ba, &cost, &lds, forced)) continue;
     if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) continue;
-    if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) continue;
+    if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) { to_compact[i] = overflow; continue; }
     // the counter starts from zero: cleared in front of the launch (the adjuster's previous solve no longer touches it
     // once its completion word is out)
     if (ba->lm_counters_dirty || !ba->lm_have_base) {
@@ -3413,33 +3740,79 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsign
     ba->lm_counters_dirty = false;
     ptrs.p[launched] = ba->h_lane;
     took[launched] = ba;
-    if (launched_mask) *launched_mask |= 1ull << i;
+    tidx[launched] = i;
     max_c = std::max(max_c, (ba->d.C + LM_CPW - 1) / LM_CPW);
     max_lds = std::max(max_lds, lds);
     ++launched;
   }
-  if (!launched) return 0;
-  const auto t0 = now();
+  if (launched) {
+    const auto t0 = now();
+    {
+      SvoProfScope prof(took[0]->ctx, SVO_PROF_BA_STEP, st);
+      hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
+    }
+    if (hipGetLastError() != hipSuccess) {
+      for (int i = 0; i < launched; ++i) ba_resident_admission(took[i])->release();
+      launched = 0;
+    }
+    for (int i = 0; i < launched; ++i) {
+      svo_ba* ba = took[i];
+      ++ba->seq;  // = a.host_seq
+      ba->lm_t0 = t0;
+      if (ba->arena_dirty) ba->arena_partial = true;  // the kernel reads the host image in place: the device arena holds the landmark buffers only
+      ba->arena_dirty = false;
+      ba->lm_inflight = true; ba->lm_compact_inflight = false;
+      ba->lm_stream = st;
+      ba->res_export = ba->h_lane->a.export_points != nullptr;
+      if (launched_mask) *launched_mask |= 1ull << tidx[i];
+    }
+  }
+  // ---- the compact form (ba_lm_compact_kernel: one workgroup per solve; nothing to admit, nothing to clear)
+  int n_compact = 0;
   {
-    SvoProfScope prof(took[0]->ctx, SVO_PROF_BA_STEP, st);
-    hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
+    LmLanePtrs cptrs;
+    svo_ba* ctook[SVO_MAX_LANES];
+    int cidx[SVO_MAX_LANES];
+    int nw = LMC_MAX_WAVES;
+    for (int i = 0; i < n && i < SVO_MAX_LANES; ++i) {
+      svo_ba* ba = bas[i];
+      if (!to_compact[i]) continue;
+      int cost = 0, waves = 0;
+      size_t lds = 0;
+      if (!ba_device_lm_fill(ba, &cost, &lds, forced, true, &waves)) continue;
+      cptrs.p[n_compact] = ba->h_lane; ctook[n_compact] = ba; cidx[n_compact] = i;
+      nw = std::min(nw, waves);
+      ++n_compact;
+    }
+    if (n_compact) {
+      // one launch = one workgroup shape: the smallest wave count of its solves (fewer waves need less LDS), LDS of the largest
+      size_t clds = 0;
+      for (int k = 0; k < n_compact; ++k)
+        clds = std::max(clds, sizeof(double) * ba_lmc_lds_doubles(ctook[k]->d.n, ctook[k]->d.K, ctook[k]->h_lane->a.tab_words, nw));
+      static bool attr_set = false;
+      if (!attr_set) attr_set = hipFuncSetAttribute((const void*)ba_lm_compact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LMC_LDS_BUDGET) == hipSuccess;
+      const auto t0 = now();
+      bool ok = attr_set;
+      if (ok) {
+        SvoProfScope prof(ctook[0]->ctx, SVO_PROF_BA_STEP, st);
+        hipLaunchKernelGGL(ba_lm_compact_kernel, dim3(1, n_compact), dim3(64 * nw), clds, st, cptrs);
+        ok = hipGetLastError() == hipSuccess;
+      }
+      if (!ok) n_compact = 0;
+      for (int k = 0; k < n_compact; ++k) {
+        svo_ba* ba = ctook[k];
+        ++ba->seq;  // = a.host_seq
+        ba->lm_t0 = t0;
+        if (ba->arena_dirty) ba->arena_partial = true;  // the host image keeps the INITIAL state (see ba_refresh_arena_image)
+        ba->arena_dirty = false;
+        ba->lm_inflight = true; ba->lm_compact_inflight = true;
+        ba->lm_stream = st;
+        ba->res_export = ba->h_lane->a.export_points != nullptr;
+        if (launched_mask) *launched_mask |= 1ull << cidx[k];
+      }
+    }
   }
-  if (hipGetLastError() != hipSuccess) {
-    for (int i = 0; i < launched; ++i) ba_resident_admission(took[i])->release();
-    if (launched_mask) *launched_mask = 0;
-    return 0;
-  }
-  for (int i = 0; i < launched; ++i) {
-    svo_ba* ba = took[i];
-    ++ba->seq;  // = a.host_seq
-    ba->lm_t0 = t0;
-    if (ba->arena_dirty) ba->arena_partial = true;  // the kernel reads the host image in place: the device arena holds the landmark buffers only
-    ba->arena_dirty = false;
-    ba->lm_inflight = true;
-    ba->lm_stream = st;
-    ba->res_export = ba->h_lane->a.export_points != nullptr;
-  }
-  return launched;
+  return launched + n_compact;
 }
 
 // Joins the launch: completion word, then poses / summary / counters out of the pinned result block.
@@ -3448,6 +3821,8 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
   svo_ctx* ctx = ba->ctx;
   BaDev& d = ba->d;
   ba->lm_inflight = false;
+  const bool was_compact = ba->lm_compact_inflight;
+  ba->lm_compact_inflight = false;
   const int rc = ba_wait_flag(ba, ba->seq);
   ba_resident_admission(ba)->release();
   if (rc) {
@@ -3468,13 +3843,12 @@ int ba_device_lm_end(svo_ba* ba, svo_ba_summary* sum) {
         }
       }
     }
-    ba->lm_counters_dirty = true;
+    if (!was_compact) ba->lm_counters_dirty = true;
     ba->host_points_valid = false;
     return rc;
   }
   const double* r = ba->h_result;
-  ba->lm_base = (unsigned)r[LMR_C_ARRIVE];
-  ba->lm_have_base = true;
+  if (!was_compact) { ba->lm_base = (unsigned)r[LMR_C_ARRIVE]; ba->lm_have_base = true; }
   memcpy(ba->h_poses.data(), r + LMR_DOUBLES, sizeof(double) * 7 * (size_t)d.K);
   if (r[LMR_SEL] != 0.0) { std::swap(ba->cur_points, ba->cand_points); std::swap(ba->cur_poses, ba->cand_poses); }
   ba->host_points_valid = ba->res_export;
@@ -3785,12 +4159,16 @@ static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
   const int max_slots = 2 * ba->opt.max_iterations + 8;  // every slot is an LM iteration or follows a failed factorisation
   int enqueued = 1, last_seen = -1;
   bool done = false;
+  double tk_sum[5] = {0, 0, 0, 0, 0};
+  int tk_n = 0;
   for (int s = 1; s < max_slots && !done; ++s) {
     if (s >= ahead) {  // (waiting here overlaps the GPU's work on slots s - ahead + 1 .. s - 1)
       rc = wait_record(s - ahead);
       if (rc) return rc;
       last_seen = s - ahead;
       if (record(s - ahead)[1] != 0.0) { done = true; break; }
+      for (int i = 0; i < 5; ++i) tk_sum[i] += record(s - ahead)[14 + i];
+      ++tk_n;
     }
     const auto h0 = now();
     const int grid = std::max(1, std::min(svo_div_up(d.C, 4), 512));
@@ -3824,6 +4202,9 @@ static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
   ba->stats.collectives = collectives;
   ba->stats.device_control = 1;
   ba->stats.host_us = 1e3 * host_ms;
+  if (getenv("SVO_TIMING") && tk_n)
+    fprintf(stderr, "[svo ba] device-side step control, %d slots, thread 0 per slot (us since kernel entry): payloads loaded %.1f, step consumed %.1f, system built %.1f, "
+                    "factored + solved %.1f, status written %.1f\n", tk_n, 1e-2 * tk_sum[0] / tk_n, 1e-2 * tk_sum[1] / tk_n, 1e-2 * tk_sum[2] / tk_n, 1e-2 * tk_sum[3] / tk_n, 1e-2 * tk_sum[4] / tk_n);
   if (sum) {
     sum->iterations = (int)r[2]; sum->successful_steps = (int)r[3]; sum->termination = (int)r[4];
     sum->initial_cost = r[5]; sum->final_cost = r[6];
@@ -3833,6 +4214,23 @@ static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
   (void)nn;
   return SVO_OK;
+}
+
+// A device-resident solve gave up (ba_lm_kernel's workgroups wait for each other; on a GPU that another process fills, or with
+// LDS handed out in pieces, a launch may not become co-resident within its 3 s bound).  Nothing is lost: the pinned problem
+// image was only read, so the adjuster goes back to "loaded, not uploaded" and the caller solves it again — compact form or
+// host-driven loop, the same bits.  The wide form is avoided for the next 64 solves of this adjuster.
+static void ba_after_giveup(svo_ba* ba) {
+  uint8_t* D = ba->d_arena;
+  ba->cur_points = (double*)(D + ba->arena_pts_off); ba->cand_points = (double*)(D + ba->arena_cpts_off);
+  ba->cur_poses = (double*)(D + ba->arena_p0_off); ba->cand_poses = (double*)(D + ba->arena_p1_off);
+  ba->d.points = ba->cur_points; ba->d.cand_points = ba->cand_points; ba->d.poses = ba->cur_poses; ba->d.cand_poses = ba->cand_poses;
+  ba->arena_partial = false;
+  ba->arena_dirty = true;
+  ba->host_points_valid = false;
+  ba->upload_pending = false;
+  ba->lm_penalty = 64;
+  ++ba->fallbacks;
 }
 
 // ceres::Solve for the loaded problem: host/lm.cpp's step control over the HIP passes.
@@ -3845,10 +4243,19 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   ops.step = op_step;
   ops.accept = op_accept;
   memset(&ba->stats, 0, sizeof(ba->stats));
+  int fell_back = 0;
   if (ba_device_lm_launch(&ba, 1, ba->stream, false, nullptr) == 1) {  // the whole solve is one launch: nothing for the host to do until the completion word
     const int rcd = ba_device_lm_end(ba, sum);
     d.flag = nullptr;
-    return rcd;
+    if (rcd == SVO_OK) { if (ba->lm_penalty > 0) --ba->lm_penalty; return rcd; }
+    ba_after_giveup(ba);  // the problem is still loaded (pinned image untouched): solve it again below, never lose the keyframe
+    fell_back = 1;
+    if (ba_device_lm_launch(&ba, 1, ba->stream, true, nullptr) == 1) {  // (the compact form: one workgroup, nothing it could wait for)
+      const int rc2 = ba_device_lm_end(ba, sum);
+      d.flag = nullptr;
+      if (rc2 == SVO_OK) { ba->stats.fallbacks = 1; ctx->err.clear(); return rc2; }
+      ba_after_giveup(ba);
+    }
   }
   if (ba_bulk_control_wanted(ba)) return ba_lm_bulk_device(ba, sum);  // bulk / sharded: nothing on the host inside an LM iteration
   {
@@ -3864,6 +4271,7 @@ static int ba_lm(svo_ba* ba, svo_ba_summary* sum) {
   d.flag = nullptr;
   // leave the result in d.points / d.poses
   d.points = ba->cur_points; d.cand_points = ba->cand_points; d.poses = ba->cur_poses; d.cand_poses = ba->cand_poses;
+  if (fell_back && rc == SVO_OK) { ba->stats.fallbacks = 1; ctx->err.clear(); }
   return rc;
 }
 
@@ -4104,8 +4512,17 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   std::vector<int64_t>& lm_ids = ba->solve_lm_ids;
   int rc;
   const bool on_device = ba->lm_inflight;
-  if (ba->lm_inflight) { rc = ba_device_lm_end(ba, summary); ba->d.flag = nullptr; }
-  else rc = ba_lm(ba, summary);
+  bool on_device_ok = on_device;
+  if (ba->lm_inflight) {
+    rc = ba_device_lm_end(ba, summary); ba->d.flag = nullptr;
+    if (rc == SVO_OK) { if (ba->lm_penalty > 0) --ba->lm_penalty; }
+    else {  // gave up: never lose the keyframe — the problem is still loaded, solve it again (compact form, else host-driven)
+      ba_after_giveup(ba);
+      rc = ba_lm(ba, summary);
+      if (rc == SVO_OK) { ba->stats.fallbacks = 1; ba->ctx->err.clear(); }
+      on_device_ok = false;  // (the landmark store is written by the scatter below unless the re-run was device-resident — harmless twice)
+    }
+  } else rc = ba_lm(ba, summary);
   if (!rc) ba->upload_pending = false;
   ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   ba->n_solves++;
@@ -4123,7 +4540,7 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   for (size_t l = 0; l < lm_ids.size(); ++l)
     for (int a = 0; a < 3; ++a) ba->feat_pos[3 * lm_ids[l] + a] = out_pts[3 * l + a];
   ba->new_frame_added = false;  // :155
-  if (ba->store && !on_device && !lm_ids.empty()) {  // the device-resident solve wrote the landmark store itself
+  if (ba->store && !on_device_ok && !lm_ids.empty()) {  // the device-resident solve wrote the landmark store itself
     rc = ba_store_scatter(ba, lm_ids, out_pts);
     if (rc) return rc;
   }

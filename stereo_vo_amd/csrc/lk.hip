@@ -579,6 +579,116 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(uint8_t* __restrict__ pyr
   pyr[(size_t)blockIdx.z * pyr_stride + dst_off + (size_t)y * dw + x] = (uint8_t)((s + 128) >> 8);
 }
 
+// ---- levels 1..3 from ONE read of level 0 (round 5) ---------------------------------------------------------------------------
+// pyr_down_kernel runs once per level and reads its source with 25 byte loads per output pixel from workgroups that land on all
+// eight XCDs: 1.8 A of level-0 fetches per pair plus the re-read of levels 1 and 2 (profiles/r04_traffic.json: 1.05 MB per pair
+// raw for 0.62 MB = 1.33 A of compulsory traffic).  Here a workgroup owns a 128 x 64 tile of level 1 (64 x 32 of level 2,
+// 32 x 16 of level 3): it stages the 277 x 149 region of level 0 that its level-3 pixels depend on in LDS (dword loads), forms
+// the 137 x 73 region of level 1 and the 67 x 35 region of level 2 there — the halo of the next level is recomputed, never read
+// back — and writes its own tiles of the three levels.  Workgroups are dealt XCD-aware: an image's 15 tiles are consecutive
+// workgroups of ONE XCD, so the halo rows a neighbour re-reads come from that XCD's L2.  Integer arithmetic ((s + 128) >> 8 of
+// the [1 4 6 4 1]^2 sums, REFLECT_101 at every level): the same bytes as pyr_down_kernel whatever the tiling.
+constexpr int PB_T1W = 128, PB_T1H = 64;                  // a workgroup's own tile of level 1
+constexpr int PB_R0W = 2 * PB_T1W + 21, PB_R0H = 2 * PB_T1H + 21;   // level-0 region: 277 x 149
+constexpr int PB_R1W = PB_T1W + 9, PB_R1H = PB_T1H + 9;             // level-1 region: 137 x 73
+constexpr int PB_R2W = PB_T1W / 2 + 3, PB_R2H = PB_T1H / 2 + 3;     // level-2 region: 67 x 35
+constexpr int PB_P0 = 280, PB_P1 = 140, PB_P2 = 68;                 // LDS pitches (bytes)
+__global__ __launch_bounds__(256) void pyr_build_kernel(const uint8_t* __restrict__ imgs, size_t image_stride, int row_stride, int w0, int h0,
+                                                        uint8_t* __restrict__ pyr, size_t pyr_stride, int tiles_x, int tiles_y, int n_images) {
+  __shared__ __align__(16) uint8_t s0[PB_R0H * PB_P0];
+  __shared__ __align__(16) uint8_t s1[PB_R1H * PB_P1];
+  __shared__ __align__(16) uint8_t s2[PB_R2H * PB_P2];
+  const int per_img = tiles_x * tiles_y, total = per_img * n_images;
+  // the hardware deals workgroup L to XCD L % 8: workgroups 8 k + x, k = 0, 1, ... (one XCD's share) take consecutive tiles
+  const int per_xcd = (total + 7) >> 3, v = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+  if (v >= total) return;
+  const int img = v / per_img, t = v - img * per_img, ty = t / tiles_x, tx = t - ty * tiles_x;
+  const int w1 = (w0 + 1) >> 1, h1 = (h0 + 1) >> 1, w2 = (w1 + 1) >> 1, h2 = (h1 + 1) >> 1, w3 = (w2 + 1) >> 1, h3 = (h2 + 1) >> 1;
+  const int x0lo = max(0, 2 * PB_T1W * tx - 14), x0hi = min(w0 - 1, 2 * PB_T1W * tx + 2 * PB_T1W + 6);
+  const int y0lo = max(0, 2 * PB_T1H * ty - 14), y0hi = min(h0 - 1, 2 * PB_T1H * ty + 2 * PB_T1H + 6);
+  const int x1lo = max(0, PB_T1W * tx - 6), x1hi = min(w1 - 1, PB_T1W * tx + PB_T1W + 2);
+  const int y1lo = max(0, PB_T1H * ty - 6), y1hi = min(h1 - 1, PB_T1H * ty + PB_T1H + 2);
+  const int x2lo = max(0, PB_T1W / 2 * tx - 2), x2hi = min(w2 - 1, PB_T1W / 2 * tx + PB_T1W / 2);
+  const int y2lo = max(0, PB_T1H / 2 * ty - 2), y2hi = min(h2 - 1, PB_T1H / 2 * ty + PB_T1H / 2);
+  const uint8_t* src = imgs + (size_t)img * image_stride;
+  uint8_t* dst = pyr + (size_t)img * pyr_stride;
+  const size_t off1 = (size_t)w0 * h0, off2 = off1 + (size_t)w1 * h1, off3 = off2 + (size_t)w2 * h2;
+  // ---- level 0 -> LDS: dwords (unaligned: rows are w0 bytes apart), the last few bytes of a row one by one
+  {
+    const int rw = x0hi - x0lo + 1, rh = y0hi - y0lo + 1, dw = rw >> 2;
+    for (int i = threadIdx.x; i < rh * dw; i += 256) {
+      const int r = i / dw, c = i - r * dw;
+      uint32_t val;
+      __builtin_memcpy(&val, src + (size_t)(y0lo + r) * row_stride + x0lo + 4 * c, 4);
+      *reinterpret_cast<uint32_t*>(&s0[r * PB_P0 + 4 * c]) = val;
+    }
+    const int tail = rw - 4 * dw;
+    for (int i = threadIdx.x; i < rh * tail; i += 256) {
+      const int r = i / tail, c = 4 * dw + (i - r * tail);
+      s0[r * PB_P0 + c] = src[(size_t)(y0lo + r) * row_stride + x0lo + c];
+    }
+  }
+  __syncthreads();
+  const int k5[5] = {1, 4, 6, 4, 1};
+  // ---- level 1 region (own tile to HBM as it is formed)
+  {
+    const int rw = x1hi - x1lo + 1, rh = y1hi - y1lo + 1;
+    for (int i = threadIdx.x; i < rw * rh; i += 256) {
+      const int ry = i / rw, rx = i - ry * rw, x = x1lo + rx, y = y1lo + ry;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = &s0[(reflect101(2 * y + j - 2, h0) - y0lo) * PB_P0];
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r += k5[q] * row[reflect101(2 * x + q - 2, w0) - x0lo];
+        sum += k5[j] * r;
+      }
+      const uint8_t o = (uint8_t)((sum + 128) >> 8);
+      s1[ry * PB_P1 + rx] = o;
+      if (x >= PB_T1W * tx && x < PB_T1W * tx + PB_T1W && y >= PB_T1H * ty && y < PB_T1H * ty + PB_T1H) dst[off1 + (size_t)y * w1 + x] = o;
+    }
+  }
+  __syncthreads();
+  // ---- level 2 region
+  {
+    const int rw = x2hi - x2lo + 1, rh = y2hi - y2lo + 1;
+    for (int i = threadIdx.x; i < rw * rh; i += 256) {
+      const int ry = i / rw, rx = i - ry * rw, x = x2lo + rx, y = y2lo + ry;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = &s1[(reflect101(2 * y + j - 2, h1) - y1lo) * PB_P1];
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r += k5[q] * row[reflect101(2 * x + q - 2, w1) - x1lo];
+        sum += k5[j] * r;
+      }
+      const uint8_t o = (uint8_t)((sum + 128) >> 8);
+      s2[ry * PB_P2 + rx] = o;
+      if (x >= PB_T1W / 2 * tx && x < PB_T1W / 2 * tx + PB_T1W / 2 && y >= PB_T1H / 2 * ty && y < PB_T1H / 2 * ty + PB_T1H / 2) dst[off2 + (size_t)y * w2 + x] = o;
+    }
+  }
+  __syncthreads();
+  // ---- level 3: own tile only
+  {
+    const int x3lo = PB_T1W / 4 * tx, y3lo = PB_T1H / 4 * ty, rw = min(w3, x3lo + PB_T1W / 4) - x3lo, rh = min(h3, y3lo + PB_T1H / 4) - y3lo;
+    for (int i = threadIdx.x; i < rw * rh; i += 256) {
+      const int ry = i / rw, rx = i - ry * rw, x = x3lo + rx, y = y3lo + ry;
+      int sum = 0;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const uint8_t* row = &s2[(reflect101(2 * y + j - 2, h2) - y2lo) * PB_P2];
+        int r = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) r += k5[q] * row[reflect101(2 * x + q - 2, w2) - x2lo];
+        sum += k5[j] * r;
+      }
+      dst[off3 + (size_t)y * w3 + x] = (uint8_t)((sum + 128) >> 8);
+    }
+  }
+}
+
 __global__ __launch_bounds__(LKT * FPB) void lk_kernel(const uint8_t* __restrict__ pyrA, const uint8_t* __restrict__ pyrB, int w,
                                                       int h, const float* __restrict__ xy, int n, float* __restrict__ out,
                                                       uint8_t* __restrict__ status) {
@@ -793,6 +903,20 @@ int svo_k_build_pyramid(svo_ctx* ctx, const uint8_t* imgs, int batch, int w, int
   if (!level0_in_place)
     hipLaunchKernelGGL(pyr_copy_kernel, dim3(svo_div_up(w, 64), svo_div_up(h, 4), batch), dim3(256), 0, st, imgs, w, h,
                        row_stride, image_stride, pyr, pyr_stride);
+  // levels 1..3 from one read of level 0 (pyr_build_kernel); the per-level launches stay for images too small for its tiling to make
+  // sense, for other level counts, and behind SVO_PYR_PER_LEVEL=1 (A/B, tests)
+  static const bool per_level = [] { const char* e = getenv("SVO_PYR_PER_LEVEL"); return e && *e && atoi(e) != 0; }();
+  if (LEVELS == 4 && !per_level && w >= 64 && h >= 64) {
+    const int w1 = (w + 1) / 2, h1 = (h + 1) / 2, tiles_x = svo_div_up(w1, PB_T1W), tiles_y = svo_div_up(h1, PB_T1H);
+    const long long total = (long long)tiles_x * tiles_y * batch;
+    if (total > 0 && total < (1ll << 30)) {
+      SvoProfScope prof(ctx, SVO_PROF_PYR_DOWN);
+      hipLaunchKernelGGL(pyr_build_kernel, dim3((unsigned)(8 * ((total + 7) / 8))), dim3(256), 0, st, imgs, image_stride, row_stride, w, h, pyr, pyr_stride,
+                         tiles_x, tiles_y, batch);
+      SVO_HIP_CHECK(ctx, hipGetLastError());
+      return SVO_OK;
+    }
+  }
   size_t src_off = 0;
   int sw = w, sh = h;
   for (int l = 1; l < LEVELS; ++l) {

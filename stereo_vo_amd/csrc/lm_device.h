@@ -224,5 +224,123 @@ __device__ inline bool svo_dev_cholesky_solve(double* A, double* b, int n, doubl
   __syncthreads();
   return true;
 }
+
+// ---- the throughput form of the dense SPD solve (bulk path's device-side step control, n <= 128: ba_bulk_control_kernel) -------
+// svo_dev_cholesky_solve above reproduces host/linalg.cpp's bits: correctly rounded sqrt and divisions on a dependent chain —
+// 140 us for n = 114 (measured, round 5), of which the in-panel chain of sqrt / divide sequences is 57, the LDS-bound trailing
+// update 35, the two substitutions 14.  The bulk path sums in hardware order (tolerance-level parity), so its
+// step control does not need the host's bits — it needs every rank to compute the SAME bits, which any deterministic sequence
+// does.  This form therefore uses
+//   * pivots by reciprocal square root: rs = rsq(s) + two Newton steps (relative error < 2e-16), l_jj = s rs, column scaled by rs;
+//   * the right-hand side as one more row of the matrix: the forward substitution happens inside the factorisation (y = L^-1 b
+//     is the row's panel solve), no separate chain;
+//   * the backward substitution with the stored reciprocals.
+// A: n x n row-major, lower triangle read, overwritten by L; b: right-hand side -> solution; col: 7 n + 8 doubles of scratch.
+// Any workgroup size that is a multiple of 64 (written for 512).  Returns false (in every thread) on a non-positive pivot.
+__device__ __forceinline__ double svo_rsqrt_newton(double s) {
+  double r = __builtin_amdgcn_rsq(s);
+  r = r * (1.5 - 0.5 * s * r * r);
+  r = r * (1.5 - 0.5 * s * r * r);
+  return r;
+}
+__device__ inline bool svo_dev_spd_solve_fast(double* A, double* b, int n, double* col) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  constexpr int PW = 6;
+  double* inv = col + PW * n;       // n: reciprocals of the diagonal of L
+  double* yp = inv + n;             // PW: the panel's part of y = L^-1 b
+  double* verdict = yp + PW;        // 1
+  for (int j0 = 0; j0 < n; j0 += PW) {
+    const int bw = n - j0 < PW ? n - j0 : PW;
+    if (tid < 64) {
+      const int r0 = tid, r1 = tid + 64;
+      const bool in0 = r0 < n && r0 >= j0, in1 = r1 < n && r1 >= j0;
+      double p0[PW], p1[PW], pb[PW];  // rows r0, r1 of the panel; the right-hand side's "row" (the same value in every lane)
+#pragma unroll
+      for (int q = 0; q < PW; ++q) {
+        p0[q] = (in0 && q < bw) ? A[r0 * n + j0 + q] : 0.0;
+        p1[q] = (in1 && q < bw) ? A[r1 * n + j0 + q] : 0.0;
+        pb[q] = q < bw ? b[j0 + q] : 0.0;
+      }
+      bool ok = true;
+#pragma unroll
+      for (int q = 0; q < PW; ++q) {
+        if (q < bw && ok) {  // wave-uniform
+          const int pr = j0 + q;
+#pragma unroll
+          for (int r = 0; r < q; ++r) {
+            const double lp = pr < 64 ? svo_readlane_f64(p0[r], pr) : svo_readlane_f64(p1[r], pr - 64);  // l_{pr, j0 + r}
+            p0[q] -= p0[r] * lp;
+            p1[q] -= p1[r] * lp;
+            pb[q] -= pb[r] * lp;
+          }
+          const double s = pr < 64 ? svo_readlane_f64(p0[q], pr) : svo_readlane_f64(p1[q], pr - 64);
+          ok = s > 0;
+          if (ok) {
+            const double rs = svo_rsqrt_newton(s), l = s * rs;
+            p0[q] = r0 == pr ? l : (r0 > pr ? p0[q] * rs : 0.0);
+            p1[q] = r1 == pr ? l : (r1 > pr ? p1[q] * rs : 0.0);
+            pb[q] = pb[q] * rs;
+            if (tid == 0) inv[pr] = rs;
+          }
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int q = 0; q < PW; ++q) {
+          if (q < bw && in0 && r0 >= j0 + q) { A[r0 * n + j0 + q] = p0[q]; col[q * n + r0] = p0[q]; }
+          if (q < bw && in1 && r1 >= j0 + q) { A[r1 * n + j0 + q] = p1[q]; col[q * n + r1] = p1[q]; }
+          if (q < bw && tid == 0) { b[j0 + q] = pb[q]; yp[q] = pb[q]; }
+        }
+      }
+      if (tid == 0) *verdict = ok ? 1.0 : -1.0;
+    }
+    __syncthreads();
+    if (!(*verdict > 0.0)) { __syncthreads(); return false; }  // uniform
+    const int t0 = j0 + bw;  // first trailing row / column
+    // trailing update, rows paired (t0 + m, n - 1 - m) so that every group of eight threads walks the same number of columns
+    const int rows = n - t0, pairs = (rows + 1) >> 1;
+    for (int m = tid >> 3; m < pairs; m += nt >> 3) {
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int i = half == 0 ? t0 + m : n - 1 - m;
+        if (half == 1 && i == t0 + m) continue;  // the middle row of an odd count
+        double li[PW];
+#pragma unroll
+        for (int q = 0; q < PW; ++q) li[q] = q < bw ? col[q * n + i] : 0.0;
+        for (int c = t0 + (tid & 7); c <= i; c += 8) {
+          double v = A[i * n + c];
+#pragma unroll
+          for (int q = 0; q < PW; ++q) if (q < bw) v -= li[q] * col[q * n + c];
+          A[i * n + c] = v;
+        }
+      }
+    }
+    // ... and the right-hand side's row: b_c -= sum_q y_q l_cq
+    for (int c = t0 + tid; c < n; c += nt) {
+      double v = b[c];
+#pragma unroll
+      for (int q = 0; q < PW; ++q) if (q < bw) v -= yp[q] * col[q * n + c];
+      b[c] = v;
+    }
+    __syncthreads();
+  }
+  // b holds y = L^-1 b; backward substitution by the first wavefront, two rows per lane, x in registers
+  if (tid < 64) {
+    const int r0 = tid, r1 = tid + 64;
+    const bool in0 = r0 < n, in1 = r1 < n;
+    double b0 = in0 ? b[r0] : 0.0, b1 = in1 ? b[r1] : 0.0;
+    const double i0 = in0 ? inv[r0] : 1.0, i1 = in1 ? inv[r1] : 1.0;
+    for (int k = n - 1; k >= 0; --k) {
+      const double l0 = r0 < k ? A[k * n + r0] : 0.0, l1 = (in1 && r1 < k) ? A[k * n + r1] : 0.0;
+      const double xk = k < 64 ? svo_readlane_f64(b0, k) * svo_readlane_f64(i0, k) : svo_readlane_f64(b1, k - 64) * svo_readlane_f64(i1, k - 64);
+      if (r0 == k) b0 = xk; else if (r0 < k) b0 -= l0 * xk;
+      if (r1 == k) b1 = xk; else if (in1 && r1 < k) b1 -= l1 * xk;
+    }
+    if (in0) b[r0] = b0;
+    if (in1) b[r1] = b1;
+  }
+  __syncthreads();
+  return true;
+}
 #endif
 #endif  // SVO_LM_DEVICE_H_

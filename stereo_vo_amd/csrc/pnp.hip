@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cfloat>
 
+#include "det_trig.h"
 #include "kernels.h"
 #include "group_kernels.h"
 #include "pnp_iters.h"
@@ -492,12 +493,7 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   if (n < MODEL || iterations < 1) return SVO_OK;
   PnpPose P0;
   {
-    const double th = sqrt(rvec3[0] * rvec3[0] + rvec3[1] * rvec3[1] + rvec3[2] * rvec3[2]);
-    if (th < 1e-12) { P0.q[0] = 1; P0.q[1] = 0.5 * rvec3[0]; P0.q[2] = 0.5 * rvec3[1]; P0.q[3] = 0.5 * rvec3[2]; }
-    else {
-      const double sn = sin(0.5 * th) / th;
-      P0.q[0] = cos(0.5 * th); P0.q[1] = sn * rvec3[0]; P0.q[2] = sn * rvec3[1]; P0.q[3] = sn * rvec3[2];
-    }
+    svo_det_quat_from_rvec(rvec3, P0.q);  // declared arithmetic (host/det_trig.h)
     for (int k = 0; k < 3; ++k) P0.t[k] = tvec3[k];
   }
   const int words = svo_div_up(n, 64);
@@ -538,14 +534,7 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
     if (*h_best != -2 || a.launched >= iterations) break;
   }
   if (*h_best < 0) return SVO_OK;
-  double q[4] = {h_out[0], h_out[1], h_out[2], h_out[3]};
-  if (q[0] < 0) for (double& v : q) v = -v;
-  const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  if (vn < 1e-12) { rvec3[0] = 2 * q[1]; rvec3[1] = 2 * q[2]; rvec3[2] = 2 * q[3]; }
-  else {
-    const double th = 2.0 * atan2(vn, q[0]);
-    rvec3[0] = q[1] / vn * th; rvec3[1] = q[2] / vn * th; rvec3[2] = q[3] / vn * th;
-  }
+  svo_det_rvec_from_quat(h_out, rvec3);  // declared arithmetic (host/det_trig.h)
   for (int k = 0; k < 3; ++k) tvec3[k] = h_out[4 + k];
   *n_inliers = *h_nin;
   return SVO_OK;

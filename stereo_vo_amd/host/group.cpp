@@ -27,28 +27,15 @@
 #include <thread>
 #include <vector>
 
+#include "det_trig.h"
 #include "group_kernels.h"
 #include "ref_constants.h"
 #include "svo.h"
 
 namespace {
 
-// cv::Rodrigues on a CV_32F rvec: evaluated in double, stored as float (host/pipeline.cpp).
-void rodrigues_f(const float* rv, float* R9) {
-  const double rx = rv[0], ry = rv[1], rz = rv[2];
-  const double th = sqrt(rx * rx + ry * ry + rz * rz);
-  double R[9];
-  if (th < 2.220446049250313e-16) {
-    R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
-  } else {
-    const double c = cos(th), s = sin(th), c1 = 1.0 - c, it = 1.0 / th;
-    const double x = rx * it, y = ry * it, z = rz * it;
-    R[0] = c + c1 * x * x; R[1] = c1 * x * y - s * z; R[2] = c1 * x * z + s * y;
-    R[3] = c1 * x * y + s * z; R[4] = c + c1 * y * y; R[5] = c1 * y * z - s * x;
-    R[6] = c1 * x * z - s * y; R[7] = c1 * y * z + s * x; R[8] = c + c1 * z * z;
-  }
-  for (int i = 0; i < 9; ++i) R9[i] = (float)R[i];
-}
+// cv::Rodrigues on a CV_32F rvec with declared arithmetic (host/det_trig.h): the same bits on the host, on the device and in the oracle
+inline void rodrigues_f(const float* rv, float* R9) { svo_det_rodrigues_f(rv, R9); }
 
 // Eigen::Quaternionf(Matrix3f) (src/image_processor.cpp:92), float arithmetic, row-major m.
 void quat_from_R(const float* m, float* q /*wxyz*/) {
@@ -463,6 +450,9 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     const int max_obs = (p->window_size + 1) * p->max_features + 64;
     rc = svo_ba_create(ctx, &l->ba, p->window_size, &p->cam, &opt, max_obs, max_obs);
     if (!rc) rc = svo_ba_attach_store(l->ba, l->d_store, l->store_mask);
+    // (the window solves keep the wide form unless SVO_BA_FORM=compact: measured in round 5, one workgroup per solve costs a lane
+    // ~10x the solve latency and halves the frame rate at 48 lanes — profiles/r05_exp_compact_lanes.txt; the compact form serves as
+    // the overflow of the admission budget, SVO_BA_OVERFLOW, and as the re-run of a solve that gave up)
   }
   if (rc) { svo_pipeline_group_destroy(g); return rc; }
   {
@@ -794,15 +784,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
                 break;
               }
               if (l->best >= 0) {
-                double q[4] = {l->h_out[0], l->h_out[1], l->h_out[2], l->h_out[3]};
-                if (q[0] < 0) for (double& v : q) v = -v;
-                const double vn = sqrt(q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
                 double rv[3];
-                if (vn < 1e-12) { rv[0] = 2 * q[1]; rv[1] = 2 * q[2]; rv[2] = 2 * q[3]; }
-                else {
-                  const double th = 2.0 * atan2(vn, q[0]);
-                  rv[0] = q[1] / vn * th; rv[1] = q[2] / vn * th; rv[2] = q[3] / vn * th;
-                }
+                svo_det_rvec_from_quat(l->h_out, rv);  // declared arithmetic (host/det_trig.h)
                 for (int k = 0; k < 3; ++k) { l->rvec[k] = (float)rv[k]; l->tvec[k] = (float)l->h_out[4 + k]; }
                 l->num_inliers = *l->h_nin;
               }
@@ -925,12 +908,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         x.f = (double)g->K[0]; x.cx = (double)g->K[2]; x.cy = (double)g->K[5];
         // rvec/tvec are CV_32F in/out, the solver works in double (host/pipeline.cpp; csrc/pnp.hip svo_k_pnp)
         const double rv[3] = {l->rvec[0], l->rvec[1], l->rvec[2]};
-        const double th = sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
-        if (th < 1e-12) { x.q0[0] = 1; x.q0[1] = 0.5 * rv[0]; x.q0[2] = 0.5 * rv[1]; x.q0[3] = 0.5 * rv[2]; }
-        else {
-          const double sn = sin(0.5 * th) / th;
-          x.q0[0] = cos(0.5 * th); x.q0[1] = sn * rv[0]; x.q0[2] = sn * rv[1]; x.q0[3] = sn * rv[2];
-        }
+        svo_det_quat_from_rvec(rv, x.q0);  // declared arithmetic (host/det_trig.h)
         for (int c = 0; c < 3; ++c) x.t0[c] = (double)l->tvec[c];
         x.thr2 = (double)svo_ref::PNP_REPROJ_ERROR * (double)svo_ref::PNP_REPROJ_ERROR;
         x.confidence = svo_ref::PNP_CONFIDENCE; x.iterations = g->pnp_iterations;

@@ -186,6 +186,24 @@ def pnp_ransac(xyz, xy, focal, cx, cy, rvec, tvec, iterations=100, reproj_err=8.
     return rv, tv, inl[:m].copy()
 
 
+def det_atan2_q1(y, x):
+    oracle().ora_det_atan2_q1.restype = C.c_double
+    return float(oracle().ora_det_atan2_q1(C.c_double(y), C.c_double(x)))
+
+
+def det_sincos(x):
+    s, c = C.c_double(0), C.c_double(0)
+    oracle().ora_det_sincos(C.c_double(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def det_rvec_quat_roundtrip(rvec):
+    rv = _f64(rvec).copy()
+    q, back = np.zeros(4), np.zeros(3)
+    oracle().ora_det_rvec_quat_roundtrip(_p(rv), _p(q), _p(back))
+    return q, back
+
+
 def pnp_update_num_iters(p, ep, model_points, max_iters):
     return int(oracle().ora_pnp_update_num_iters(C.c_double(p), C.c_double(ep), int(model_points), int(max_iters)))
 

@@ -164,16 +164,42 @@ def test_hip_device_solve_equals_the_host_driven_loop_for_every_window_size(ctx)
         for N in (12, 300):
             p = BP.make_problem(K, K, N, dense=False)
             res = []
-            for dev in (False, True):
+            # host-driven | wide device form (ba_lm_kernel) | compact device form (ba_lm_compact_kernel: one workgroup per solve, round 5)
+            for dev, form in ((False, None), (True, "wide"), (True, "compact")):
                 ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8,
-                              max_observations=len(p["op"]) + 8, max_time_s=0.0, device_lm=dev)
+                              max_observations=len(p["op"]) + 8, max_time_s=0.0, device_lm=dev, solve_form=form)
                 ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
                 s = ba.solve_problem()
                 poses, pts = ba.read_problem()
                 res.append((s.iterations, s.termination, s.initial_cost, s.final_cost, poses.tobytes(), pts.tobytes()))
                 ba.close()
-            assert res[0][:4] == res[1][:4], (K, N, res[0][:4], res[1][:4])
-            assert res[0][4] == res[1][4] and res[0][5] == res[1][5], (K, N)
+            for other in (1, 2):
+                assert res[0][:4] == res[other][:4], (K, N, other, res[0][:4], res[other][:4])
+                assert res[0][4] == res[other][4] and res[0][5] == res[other][5], (K, N, other)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,K,N", [(41, 5, 1500), (42, 8, 2600), (43, 11, 2300), (44, 3, 40)])
+def test_hip_compact_solve_equals_the_host_driven_loop_beyond_128_chunks(ctx, seed, K, N):
+    """The compact form takes any number of chunks up to 256: beyond 128 the declared order sums groups of G = ceil(C / 128)
+    consecutive chunks first (oracle/ora_ba.cpp), which the workgroup's running sums reproduce (lmc_acc) — the wide form stops at
+    128.  Bit for bit against the host-driven loop and against the oracle; fewer wavefronts per workgroup (what larger windows
+    leave room for in LDS) must not change a bit either."""
+    import stereo_vo_amd as S
+    p = BP.make_problem(seed, K, N)
+    res = []
+    for dev, form in ((False, None), (True, "compact")):
+        ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8,
+                      max_time_s=0.0, device_lm=dev, solve_form=form, accumulation="deterministic")
+        ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+        s = ba.solve_problem()
+        poses, pts = ba.read_problem()
+        res.append((s.iterations, s.termination, s.initial_cost, s.final_cost, poses.tobytes(), pts.tobytes()))
+        ba.close()
+    assert res[0] == res[1], (res[0][:4], res[1][:4])
+    po, pto, so = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=4)
+    assert res[1][0] == so["iterations"] and res[1][3] == so["final_cost"]
+    assert res[1][4] == np.ascontiguousarray(po).tobytes()
 
 
 @pytest.mark.gpu
@@ -184,9 +210,9 @@ def test_hip_device_solve_twice_on_one_load_continues_from_the_solved_state(ctx)
     import stereo_vo_amd as S
     p = BP.make_problem(31, 5, 600)
     out = {}
-    for name, modes in (("host", (False, False)), ("device", (True, True)), ("mixed", (True, False))):
+    for name, modes in (("host", (False, False)), ("device", (True, True)), ("mixed", (True, False)), ("compact", (True, True)), ("compact_mixed", (True, False))):
         ba = S.api.BA(ctx, 6, BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0,
-                      max_iterations=4, device_lm=modes[0])
+                      max_iterations=4, device_lm=modes[0], solve_form="compact" if name.startswith("compact") else None)
         ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
         s1 = ba.solve_problem()
         ba.L.svo_ba_set_device_lm(ba.h, 1 if modes[1] else 0)
@@ -195,7 +221,7 @@ def test_hip_device_solve_twice_on_one_load_continues_from_the_solved_state(ctx)
         out[name] = (s1.iterations, s1.final_cost, s2.iterations, s2.initial_cost, s2.final_cost, poses.copy(), pts.copy())
         assert s2.initial_cost == s1.final_cost, name  # the second solve starts where the first ended
         ba.close()
-    for name in ("device", "mixed"):
+    for name in ("device", "mixed", "compact", "compact_mixed"):
         assert out[name][:5] == out["host"][:5], name
         assert np.array_equal(out[name][5], out["host"][5]) and np.array_equal(out[name][6], out["host"][6]), name
 

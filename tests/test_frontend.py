@@ -136,6 +136,23 @@ def test_hip_pyramid_bit_exact(ctx, frames):
 
 
 @pytest.mark.gpu
+def test_hip_fused_pyramid_levels_1_to_3_from_one_read_of_level_0():
+    """Round 5: pyr_build_kernel forms levels 1-3 of an image from ONE staged read of level 0 (a workgroup = a 128 x 64 tile of level 1,
+    the halo of every next level recomputed in LDS, REFLECT_101 at every level's own border).  Bit-exact against the oracle at the
+    sizes the configs use (1241 x 376, 1280 x 720) and at sizes that put image borders, odd halves and one-pixel-wide remainders at
+    every position relative to the tiling."""
+    import stereo_vo_amd as S
+    rng = np.random.default_rng(17)
+    ctx2 = S.Context(1280, 720, max_batch=2, max_corners=256, max_candidates=1 << 12, max_features=256)
+    for (h, w) in ((376, 1241), (720, 1280), (64, 64), (65, 257), (129, 259), (130, 513), (255, 1025), (257, 771), (131, 77), (200, 253), (127, 255)):
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        img[::7, ::5] = 255; img[3::11, 1::9] = 0
+        for lvl, (a, b) in enumerate(zip(ctx2.build_pyramid(img), O.build_pyramid(img))):
+            assert np.array_equal(a, b), (h, w, lvl, np.argwhere(a != b)[:4])
+    ctx2.close()
+
+
+@pytest.mark.gpu
 def test_hip_lk_and_track_bit_exact(ctx, frames):
     p, fr = frames
     for i in range(3):

@@ -111,3 +111,26 @@ def test_hip_pnp_without_a_model_leaves_the_pose_alone(ctx):
     rg, tg, ig = ctx.pnp_ransac(X, uv, F, CX, CY, r0, t0, reproj_err=0.05)
     assert len(io) == 0 and len(ig) == 0
     assert np.array_equal(rg, ro) and np.array_equal(tg, to) and np.array_equal(rg, r0) and np.array_equal(tg, t0)
+
+
+def test_declared_trigonometry_of_the_pose_conversions_is_within_a_few_ulp_of_libm():
+    """Round 5: cv::Rodrigues and its inverse around solvePnPRansac (src/image_processor.cpp:84-92,130-134) use declared
+    arithmetic (host/det_trig.h, restated in oracle/ora_trig.h) so that they can run on the device with the host's bits.  Bound
+    against libm: atan2 in the first quadrant and sin / cos on [0, pi] within 4 ulp of the result's scale; rvec -> quaternion ->
+    rvec reproduces rvec to 1e-15 (every caller stores these as float)."""
+    import math
+    rng = np.random.default_rng(11)
+    pts = [(1.0, 1.0), (0.0, 1.0), (1.0, 0.0), (1e-12, 1.0), (1.0, 1e-12), (0.41421356237309503, 1.0), (0.4142135623730951, 1.0), (1e-300, 1e-300)]
+    pts += [tuple(v) for v in rng.uniform(0, 1, (3000, 2))] + [(float(a), float(b)) for a, b in zip(10.0 ** rng.uniform(-12, 0, 500), 10.0 ** rng.uniform(-12, 0, 500))]
+    for y, x in pts:
+        d = O.det_atan2_q1(y, x)
+        assert abs(d - math.atan2(y, x)) <= 4 * np.spacing(max(abs(d), 1e-300)), (y, x, d, math.atan2(y, x))
+    for x in list(rng.uniform(0, math.pi, 3000)) + [0.0, 1e-9, 0.5, 0.5000000001, 1.0, math.pi / 2, math.pi]:
+        s, c = O.det_sincos(float(x))
+        assert abs(s - math.sin(x)) <= 8 * np.spacing(1.0) and abs(c - math.cos(x)) <= 8 * np.spacing(1.0), (x, s, c)
+    for _ in range(500):
+        rv = rng.normal(size=3) * rng.choice([1e-14, 1e-3, 0.3, 1.0])
+        if np.linalg.norm(rv) > 3.0:
+            continue
+        q, back = O.det_rvec_quat_roundtrip(rv)
+        assert abs(np.linalg.norm(q) - 1.0) < 1e-14 and np.allclose(back, rv, rtol=0, atol=1e-15 + 4e-16 * np.linalg.norm(rv))
