@@ -386,7 +386,7 @@ def run_kitti(args):
     out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, avg_us, res, k_n, lanes_per_launch, bool(NG))
     share = profile_summary()
     if share:
-        out["kernel_time_share"] = {"source": "profiles/r04_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
+        out["kernel_time_share"] = {"source": "profiles/r05_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
                                     "default_percent": share.get("kernel_time_share_default"),
                                     "1_stream_percent": share.get("kernel_time_share_1_stream")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -478,6 +478,22 @@ def run_kitti(args):
     return out if rank == 0 else None
 
 
+def fixture_parity(name, results, rank):
+    """EVERY frame of a long stream against the oracle-derived fixture tests/golden/stream_keys_<name>.npz (generated once in the build
+    container by tests/golden/gen_stream_keys.py: the CPU oracle over all frames).  Counters, av_parallax bits and
+    pose bits per frame.  Rank 0's stream only (the other ranks render another seed)."""
+    if rank != 0:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stream_configs as SC
+    keys = SC.load_keys(name)
+    if keys is None:
+        return {"fixture": f"tests/golden/stream_keys_{name}.npz", "frames": 0, "note": "fixture not present"}
+    n = min(len(keys), len(results))
+    bad = SC.compare(keys, results[:n])
+    return {"fixture": f"tests/golden/stream_keys_{name}.npz", "frames": n, "all_frames_identical_to_the_oracle": not bad, "first_differing_frames": bad}
+
+
 def window_load(kfs, window):
     """Observations and live landmarks of the sliding window behind every keyframe (steady state: full windows only): a keyframe
     adds n_inliers observations of known landmarks and n_new new ones (src/bundle_adjuster.cpp:72-121)."""
@@ -564,6 +580,8 @@ def run_kitti_stream(args):
                       "ate_rmse_m_at_keyframes_vs_generator": ate, "path_length_m": path,
                       "pcie_bytes_per_step": 2 * B * W * H}}
     out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, None, res_all, 0)
+    if (SMAXC, SQUAL, SMIND, SMAXF, window) == (2800, 0.004, 7.0, 3300, 10):  # = tests/stream_configs.py "kitti_bench"
+        out["parity_vs_oracle_fixture"] = fixture_parity("kitti_bench", res_all, rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -644,6 +662,7 @@ def run_hd10k(args):
                       "ba_lm_iterations": int(sum(r.ba_iterations for r in res)), "fps_vs_60": n_frames / dt / 60.0},
            "roofline": {"bound": "hbm", "kernel": "whole front end per stereo pair (6.33 A bytes, SURVEY 8d)", "achieved": gbs, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_pair": 6.33 * A, "traffic": None}}
+    out["parity_vs_oracle_fixture"] = fixture_parity("hd10k", res, rank)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import oracle_lib as O
@@ -679,7 +698,7 @@ def other_workloads(args):
         t0 = time.perf_counter()
         try:
             r = fn()
-            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "parity_vs_cpu") if k in r}
+            keep = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "config", "roofline", "cpu_baseline", "parity_vs_cpu", "parity_vs_oracle_fixture") if k in r}
             keep["wall_s"] = round(time.perf_counter() - t0, 1)
             out[name] = keep
         except Exception as e:  # a sub-workload must never take the headline down with it
@@ -718,7 +737,13 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches, lanes
     r = {"bound": "hbm", "kernel": "whole front end per stereo pair (corner 1 A + StereoBM 4 A + LK pyramid 1.33 A)",
          "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
          "frac_of_measured_copy": gbs / HBM_COPY_GBS, "algorithmic_bytes_per_pair": contract,
-         "traffic": prof.get("front_end_hbm_bytes_per_pair_pmc"),
+         # HBM bytes per pair from the committed FETCH_SIZE / WRITE_SIZE passes of this command (tools/prof_summary.py: every
+         # front-end kernel of the trace, matched by base name): `traffic` is the figure the guide prescribes — FETCH_SIZE doubled
+         # on the kernels that stream whole images with 16-byte requests — next to the raw counters
+         "traffic": prof.get("front_end_hbm_bytes_per_pair_pmc_fetch_x2_on_streaming_kernels"),
+         "traffic_raw_counters": prof.get("front_end_hbm_bytes_per_pair_pmc"),
+         "traffic_over_algorithmic": (prof.get("front_end_hbm_bytes_per_pair_pmc_fetch_x2_on_streaming_kernels") / contract) if prof.get("front_end_hbm_bytes_per_pair_pmc_fetch_x2_on_streaming_kernels") else None,
+         "traffic_by_kernel_raw": prof.get("front_end_hbm_bytes_per_pair_by_kernel"),
          "note": "per GPU; the front end is latency / instruction-issue bound at these sizes (SURVEY 8d 'honest expectation'): "
                  "the contract fraction is reported as asked, the binding resource of the dominant kernel is below"}
     if avg_us:
@@ -736,7 +761,7 @@ def front_end_roofline(pairs_per_s_per_gpu, kernel, avg_us, res, launches, lanes
                 g = vi / (avg_us * 1e-6) / 1e9
                 dk.update({"valu_wave_instructions_per_launch": vi, "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR,
                            "frac": g / VALU_ISSUE_PEAK_GINSTR,
-                           "note": "VALU instructions per wavefront (= per feature) from the committed SQ pass (profiles/r04_sq_counters.txt) x the "
+                           "note": "VALU instructions per wavefront (= per feature) from the committed SQ pass (profiles/r05_sq_counters.txt) x the "
                                    "features of a launch, duration live; <= 30 iterations x 4 levels x 2 directions of a 441-pixel window per feature"})
         r["dominant_kernel"] = dk
     return r

@@ -43,8 +43,16 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <errno.h>
+#include <fcntl.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <sys/types.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <sched.h>
 #include <chrono>
 #include <deque>
@@ -68,15 +76,90 @@ int g_ba_cu_share = 32;  // CUs of every 32 the adjusters' streams may use (SVO_
 constexpr int SVO_MAX_DEVICES = 16;
 std::atomic<int> g_fused_blocks[SVO_MAX_DEVICES];
 int ba_fused_budget(int device);
+// ... and across PROCESSES (round 5): the budget belongs to the GPU, not to a process.  /dev/shm/svo_admit_<PCI bus id> holds 64
+// slots {pid, admitted workgroups}; a process claims a slot (or the slot of a process that no longer exists), mirrors its own
+// admitted total there and counts the live slots of the others against the same budget.  Without /dev/shm (or with
+// SVO_BA_XPROC=0) the admission is per process as before; a solve that still cannot become co-resident gives up within its
+// bound and is re-run (ba_after_giveup), it is never lost.
+struct XprocTable { int magic; int pad; int slot[64][2]; };
+struct Xproc {
+  XprocTable* t = nullptr;
+  int mine = -1;
+  bool tried = false;
+};
+Xproc g_xproc[SVO_MAX_DEVICES];
+std::mutex g_xproc_mu;
+Xproc& xproc_for(int dev) {
+  Xproc& x = g_xproc[dev];
+  std::lock_guard<std::mutex> g(g_xproc_mu);
+  if (x.tried) return x;
+  x.tried = true;
+  if (const char* e = getenv("SVO_BA_XPROC")) if (*e && atoi(e) == 0) return x;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus) - 1, dev) != hipSuccess) return x;
+  for (char* c = bus; *c; ++c) if (*c == ':' || *c == '.') *c = '_';
+  char path[128];
+  snprintf(path, sizeof(path), "/dev/shm/svo_admit_%s", bus);
+  const int fd = open(path, O_RDWR | O_CREAT, 0666);
+  if (fd < 0) return x;
+  if (ftruncate(fd, sizeof(XprocTable)) != 0) { close(fd); return x; }
+  void* m = mmap(nullptr, sizeof(XprocTable), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) return x;
+  XprocTable* t = static_cast<XprocTable*>(m);
+  const int me = (int)getpid();
+  for (int pass = 0; pass < 2 && x.mine < 0; ++pass)
+    for (int i = 0; i < 64 && x.mine < 0; ++i) {
+      int owner = __atomic_load_n(&t->slot[i][0], __ATOMIC_ACQUIRE);
+      const bool dead = owner != 0 && owner != me && kill(owner, 0) != 0 && errno == ESRCH;
+      if (owner == me || (pass == 1 && (owner == 0 || dead))) {
+        if (owner == me || __atomic_compare_exchange_n(&t->slot[i][0], &owner, me, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+          __atomic_store_n(&t->slot[i][1], 0, __ATOMIC_RELEASE);
+          x.mine = i;
+        }
+      }
+    }
+  if (x.mine >= 0) x.t = t; else munmap(m, sizeof(XprocTable));
+  return x;
+}
+// workgroups the OTHER live processes have admitted on this device
+int xproc_others(Xproc& x) {
+  if (!x.t) return 0;
+  int sum = 0;
+  for (int i = 0; i < 64; ++i) {
+    if (i == x.mine) continue;
+    const int owner = __atomic_load_n(&x.t->slot[i][0], __ATOMIC_ACQUIRE);
+    if (owner == 0) continue;
+    const int b = __atomic_load_n(&x.t->slot[i][1], __ATOMIC_ACQUIRE);
+    if (b > 0 && (kill(owner, 0) == 0 || errno != ESRCH)) sum += b;
+  }
+  return sum;
+}
 struct FusedAdmission {
   int blocks = 0, device = 0;
   bool admit(int n, int dev) {
     dev = dev >= 0 && dev < SVO_MAX_DEVICES ? dev : 0;
-    if (g_fused_blocks[dev].fetch_add(n, std::memory_order_acq_rel) + n <= ba_fused_budget(dev)) { blocks = n; device = dev; return true; }
-    g_fused_blocks[dev].fetch_sub(n, std::memory_order_acq_rel);
-    return false;
+    const int budget = ba_fused_budget(dev);
+    if (g_fused_blocks[dev].fetch_add(n, std::memory_order_acq_rel) + n > budget) { g_fused_blocks[dev].fetch_sub(n, std::memory_order_acq_rel); return false; }
+    Xproc& x = xproc_for(dev);
+    if (x.t) {  // publish first, then look at the others: two processes racing may both back off, never both pass
+      const int mine_now = __atomic_add_fetch(&x.t->slot[x.mine][1], n, __ATOMIC_ACQ_REL);
+      if (mine_now + xproc_others(x) > budget) {
+        __atomic_sub_fetch(&x.t->slot[x.mine][1], n, __ATOMIC_ACQ_REL);
+        g_fused_blocks[dev].fetch_sub(n, std::memory_order_acq_rel);
+        return false;
+      }
+    }
+    blocks = n; device = dev;
+    return true;
   }
-  void release() { if (blocks) g_fused_blocks[device].fetch_sub(blocks, std::memory_order_acq_rel); blocks = 0; }
+  void release() {
+    if (!blocks) return;
+    g_fused_blocks[device].fetch_sub(blocks, std::memory_order_acq_rel);
+    Xproc& x = g_xproc[device];
+    if (x.t) __atomic_sub_fetch(&x.t->slot[x.mine][1], blocks, __ATOMIC_ACQ_REL);
+    blocks = 0;
+  }
   ~FusedAdmission() { release(); }
 };
 constexpr double MIN_DIAG = 1e-6, MAX_DIAG = 1e32, LM_MIN_RADIUS_BULK = 1e-32;
@@ -1407,6 +1490,7 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
   // phase stamps of thread 0 (100 MHz ticks since kernel entry): loaded | step consumed | system built | factored + solved | step written
   long long tk0 = tid == 0 ? (long long)wall_clock64() : 0, tk[5] = {0, 0, 0, 0, 0};
   auto stamp = [&](int i) { if (tid == 0) tk[i] = (long long)wall_clock64() - tk0; };
+  long long tsolve[3] = {0, 0, 0};
   if (!was_done) {
     const int mode = (int)st[BC_MODE], sel = (int)st[BC_SEL] & 1;
     const double* P1 = a.pay + PAY2_SLOTS;
@@ -1549,7 +1633,7 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
       }
       __syncthreads();
       stamp(2);
-      const bool ok = n == 0 || svo_dev_spd_solve_fast(cS, cRhs, n, cCol);  // (deterministic, not the host's bits: see csrc/lm_device.h)
+      const bool ok = n == 0 || svo_dev_spd_solve_fast(cS, cRhs, n, cCol, tid == 0 ? tsolve : nullptr);  // (deterministic, not the host's bits: see csrc/lm_device.h)
       stamp(3);
       if (ok) {
         for (int q = tid; q < n; q += nt) {
@@ -1594,6 +1678,7 @@ __global__ __launch_bounds__(512) void ba_bulk_control_kernel(BulkCtlArgs a) {
     pay_store(&rec[13], elapsed_now);
     stamp(4);
     for (int i = 0; i < 5; ++i) pay_store(&rec[14 + i], (double)tk[i]);
+    for (int i = 0; i < 3; ++i) pay_store(&rec[19 + i], (double)tsolve[i]);
   }
   stores_acknowledged();
   __syncthreads();
@@ -1697,6 +1782,7 @@ struct LmDevArgs {
   int tab_words;            // u16 words of LDS per wavefront for its chunk table (a multiple of 4)
   LmDevOpt opt;
   unsigned* dbg;            // per workgroup 16 words: its last command (diagnostics of a solve that gave up; null: none)
+  int test_giveup;          // test hook (SVO_BA_TEST_GIVEUP): the wide launch reports "gave up" at once, as if a bounded wait had run out
 };
 enum { LMC_ARRIVE = 0, LMC_WORDS = 16 };
 enum { LMR_ITERATIONS = 0, LMR_SUCCESSFUL, LMR_TERMINATION, LMR_INITIAL_COST, LMR_FINAL_COST, LMR_LINEARIZE_CALLS, LMR_STEP_CALLS, LMR_SEL,
@@ -2250,6 +2336,10 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
   double* sStep = cSc + 2 * nn;                                    // [dc | candidate poses | current poses] (the second nn: spare)
   const int my_chunk = (int)blockIdx.x * LM_CPW + wave;
   const bool my_wave_works = my_chunk < P.C;
+  if (a.test_giveup) {  // (test hook: the host must re-run this solve and lose nothing)
+    if (blockIdx.x == 0 && tid == 0) __hip_atomic_store(a.host_flag, -a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return;
+  }
   __builtin_amdgcn_s_setprio(3);
   P.step_in = nullptr;  // the step block is built in LDS by the step control
   P.flag = nullptr;
@@ -2884,6 +2974,7 @@ struct svo_ba {
   int lm_form = -1;              // svo_ba_set_solve_form: which device-resident form — 0 wide (ba_lm_kernel: many workgroups, lowest latency), 1 compact (ba_lm_compact_kernel: one workgroup, smallest footprint), -1 automatic (SVO_BA_FORM, else wide)
   bool lm_compact_inflight = false;  // the launch in flight is the compact form (nothing admitted, no counter)
   int lm_penalty = 0;            // solves left that avoid the wide form after one of its launches gave up
+  long wide_launches = 0;        // (test hook SVO_BA_TEST_GIVEUP counts them)
   long fallbacks = 0;            // device-resident solves that gave up and were re-run (svo_lm_stats.fallbacks of the last solve: 0 / 1)
   bool lm_inflight = false;      // a ba_lm_kernel has been launched and not yet joined
   hipStream_t lm_stream = nullptr;  // ... on this stream
@@ -3702,6 +3793,11 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced, bool
   a.opt.parameter_tolerance = ba->opt.parameter_tolerance; a.opt.initial_radius = ba->opt.initial_radius;
   a.opt.max_time_s = ba->opt.max_time_s;  // src/bundle_adjuster.cpp:11, tested on workgroup 0's posted clock
   a.dbg = d.C <= 8192 ? ba->d_lmdbg : nullptr;
+  {
+    // SVO_BA_TEST_GIVEUP=n: every n-th wide launch of an adjuster reports "gave up" (tests/test_ba.py, tests/test_group.py)
+    static const int every = [] { const char* e = getenv("SVO_BA_TEST_GIVEUP"); return e && *e ? atoi(e) : 0; }();
+    a.test_giveup = (!compact && every > 0 && (++ba->wide_launches % every) == 0) ? 1 : 0;
+  }
   *cost = compact ? 0 : ba_lm_admission_cost((d.C + LM_CPW - 1) / LM_CPW, lds, ba->ctx->device);
   *lds_out = lds;
   if (waves_out) *waves_out = nw;
@@ -4159,7 +4255,7 @@ static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
   const int max_slots = 2 * ba->opt.max_iterations + 8;  // every slot is an LM iteration or follows a failed factorisation
   int enqueued = 1, last_seen = -1;
   bool done = false;
-  double tk_sum[5] = {0, 0, 0, 0, 0};
+  double tk_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int tk_n = 0;
   for (int s = 1; s < max_slots && !done; ++s) {
     if (s >= ahead) {  // (waiting here overlaps the GPU's work on slots s - ahead + 1 .. s - 1)
@@ -4167,7 +4263,7 @@ static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
       if (rc) return rc;
       last_seen = s - ahead;
       if (record(s - ahead)[1] != 0.0) { done = true; break; }
-      for (int i = 0; i < 5; ++i) tk_sum[i] += record(s - ahead)[14 + i];
+      for (int i = 0; i < 8; ++i) tk_sum[i] += record(s - ahead)[14 + i];
       ++tk_n;
     }
     const auto h0 = now();
@@ -4204,7 +4300,8 @@ static int ba_lm_bulk_device(svo_ba* ba, svo_ba_summary* sum) {
   ba->stats.host_us = 1e3 * host_ms;
   if (getenv("SVO_TIMING") && tk_n)
     fprintf(stderr, "[svo ba] device-side step control, %d slots, thread 0 per slot (us since kernel entry): payloads loaded %.1f, step consumed %.1f, system built %.1f, "
-                    "factored + solved %.1f, status written %.1f\n", tk_n, 1e-2 * tk_sum[0] / tk_n, 1e-2 * tk_sum[1] / tk_n, 1e-2 * tk_sum[2] / tk_n, 1e-2 * tk_sum[3] / tk_n, 1e-2 * tk_sum[4] / tk_n);
+                    "factored + solved %.1f, status written %.1f; inside the solve: panels %.1f, trailing updates + barriers %.1f, back substitution %.1f\n", tk_n, 1e-2 * tk_sum[0] / tk_n, 1e-2 * tk_sum[1] / tk_n, 1e-2 * tk_sum[2] / tk_n, 1e-2 * tk_sum[3] / tk_n, 1e-2 * tk_sum[4] / tk_n,
+            1e-2 * tk_sum[5] / tk_n, 1e-2 * tk_sum[6] / tk_n, 1e-2 * tk_sum[7] / tk_n);
   if (sum) {
     sum->iterations = (int)r[2]; sum->successful_steps = (int)r[3]; sum->termination = (int)r[4];
     sum->initial_cost = r[5]; sum->final_cost = r[6];
@@ -4497,7 +4594,8 @@ int svo_ba_solve_launch(svo_ba** bas, int n, void* stream, unsigned long long* l
 // 1: the launched solve has published its completion word (svo_ba_solve_finish will not block), 0: still running
 int svo_ba_solve_poll(svo_ba* ba) {
   if (!ba || !ba->lm_inflight) return 1;
-  return __atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE) == ba->seq ? 1 : 0;
+  const int v = __atomic_load_n(ba->h_flag, __ATOMIC_ACQUIRE);
+  return (v == ba->seq || (v == -ba->seq && ba->seq != 0)) ? 1 : 0;  // published, or gave up (svo_ba_solve_finish re-runs it): either way the join will not wait
 }
 
 // finish: join the launched solve (or, if none was launched for this adjuster, run the host-driven loop now) and write

@@ -243,9 +243,11 @@ __device__ __forceinline__ double svo_rsqrt_newton(double s) {
   r = r * (1.5 - 0.5 * s * r * r);
   return r;
 }
-__device__ inline bool svo_dev_spd_solve_fast(double* A, double* b, int n, double* col) {
+__device__ inline bool svo_dev_spd_solve_fast(double* A, double* b, int n, double* col, long long* prof = nullptr /* thread 0: ticks in [panel | trailing update + barriers | back substitution] */) {
   const int tid = threadIdx.x, nt = blockDim.x;
   constexpr int PW = 6;
+  long long pt = prof && tid == 0 ? (long long)wall_clock64() : 0;
+  auto lap = [&](int i) { if (prof && tid == 0) { const long long t = (long long)wall_clock64(); prof[i] += t - pt; pt = t; } };
   double* inv = col + PW * n;       // n: reciprocals of the diagonal of L
   double* yp = inv + n;             // PW: the panel's part of y = L^-1 b
   double* verdict = yp + PW;        // 1
@@ -294,6 +296,7 @@ __device__ inline bool svo_dev_spd_solve_fast(double* A, double* b, int n, doubl
       }
       if (tid == 0) *verdict = ok ? 1.0 : -1.0;
     }
+    lap(0);
     __syncthreads();
     if (!(*verdict > 0.0)) { __syncthreads(); return false; }  // uniform
     const int t0 = j0 + bw;  // first trailing row / column
@@ -323,6 +326,7 @@ __device__ inline bool svo_dev_spd_solve_fast(double* A, double* b, int n, doubl
       b[c] = v;
     }
     __syncthreads();
+    lap(1);
   }
   // b holds y = L^-1 b; backward substitution by the first wavefront, two rows per lane, x in registers
   if (tid < 64) {
@@ -339,6 +343,7 @@ __device__ inline bool svo_dev_spd_solve_fast(double* A, double* b, int n, doubl
     if (in0) b[r0] = b0;
     if (in1) b[r1] = b1;
   }
+  lap(2);
   __syncthreads();
   return true;
 }

@@ -203,6 +203,47 @@ def test_hip_compact_solve_equals_the_host_driven_loop_beyond_128_chunks(ctx, se
 
 
 @pytest.mark.gpu
+def test_hip_wide_solve_that_gives_up_is_rerun_with_the_same_bits():
+    """The wide device-resident solve reports "gave up" (test hook SVO_BA_TEST_GIVEUP=2: every second wide launch; a child process
+    because the hook is read once): svo_ba_solve_problem must return the host-driven loop's result bit for bit all the same —
+    re-run in the compact form — and say so in svo_lm_stats.fallbacks."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import stereo_vo_amd as S
+import ba_problem as BP
+ctx = S.Context(64, 64)
+fb = 0
+for seed, K, N in ((51, 5, 500), (52, 6, 900), (53, 3, 100), (54, 5, 1200)):
+    p = BP.make_problem(seed, K, N)
+    res = []
+    for dev in (False, True):
+        ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8, max_time_s=0.0, device_lm=dev,
+                      solve_form="wide" if dev else None)
+        for rep in range(2):  # the second wide launch of the adjuster gives up
+            ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
+            s = ba.solve_problem()
+            if dev:
+                fb += ba.last_stats().fallbacks
+        poses, pts = ba.read_problem()
+        res.append((s.iterations, s.termination, s.initial_cost, s.final_cost, poses.tobytes(), pts.tobytes()))
+        ba.close()
+    assert res[0] == res[1], (seed, res[0][:4], res[1][:4])
+assert fb == 4, fb
+print("fallback ok")
+''' % (root, os.path.join(root, "tests"))
+    e = dict(os.environ)
+    e["SVO_BA_TEST_GIVEUP"] = "2"
+    out = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fallback ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+@pytest.mark.gpu
 def test_hip_device_solve_twice_on_one_load_continues_from_the_solved_state(ctx):
     """The device-resident solve reads the problem image from pinned memory in place (no upload in front of it).  A second
     solve of the SAME load must start from the solved landmarks and poses (the host image is refreshed first), exactly as

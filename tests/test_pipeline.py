@@ -237,6 +237,38 @@ def test_hip_pipeline_config5_hd_many_features():
 
 
 @pytest.mark.gpu
+def test_hip_config5_all_64_frames_equal_the_oracle_fixture():
+    """BASELINE configs[4] exactly as bench.py's hd10k leg runs it (1280x720, d435i focal, 0.25 m per frame, 10,000 / 0.001 / 4, 10-keyframe
+    window, 64 frames): every frame's key against the CPU oracle's, from the fixture tests/golden/stream_keys_hd10k.npz (the live
+    oracle comparison above covers 2 frames; the oracle needs ~25 s per frame at this size)."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    import stereo_vo_amd as S
+    import stream_configs as SC
+    keys = SC.load_keys("hd10k")
+    assert keys is not None and len(keys) == 64, "tests/golden/stream_keys_hd10k.npz is missing: run tests/golden/gen_stream_keys.py hd10k"
+    cfg = SC.STREAMS["hd10k"]
+    p = SC.synth_params(S, "hd10k")
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16)) as ex:
+        fr = list(ex.map(lambda i: S.synth_render(p, i), range(64)))
+    L, R = np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr])
+    c = S.Context(1280, 720, max_batch=16, max_corners=10240, max_candidates=1 << 17, max_features=10240)
+    pp = S.pipeline_default_params()
+    pp.cam.focal, pp.cam.cx, pp.cam.cy, pp.cam.baseline = p.focal, p.cx, p.cy, p.baseline
+    pp.width, pp.height = 1280, 720
+    pp.max_corners, pp.quality, pp.min_feature_distance, pp.max_features, pp.window_size = (cfg["max_corners"], cfg["quality"], cfg["min_feature_distance"],
+                                                                                           cfg["max_features"], cfg["window_size"])
+    pp.ba_max_time_s = 0.0
+    g = S.Pipeline(c, pp)
+    res = []
+    for f0 in range(0, 64, 16):
+        res += g.process_batch(L[f0:f0 + 16], R[f0:f0 + 16])
+    assert SC.compare(keys, res) == []
+    g.close()
+    c.close()
+
+
+@pytest.mark.gpu
 def test_hip_pipelines_concurrent_streams_keep_parity():
     """Several independent stereo streams on one GPU, one host thread each (the bench's default shape): every stream must
     still reproduce its own oracle run exactly — nothing in the library may be shared between contexts."""
@@ -332,7 +364,10 @@ def test_hip_config3_full_4541_frame_stream_properties():
     pipeline, host buffers in, nothing reset.  The oracle needs minutes for this, so the full run is checked through
     size-independent properties — the results must not depend on how the stream is cut into batches (16 vs 7 frames per
     call: identical counters, ids and poses for all 4,541 frames), feature ids only ever grow, the keyframe trajectory
-    stays within 1 % of the path length of the generator's ground truth — and against the oracle on the first 48 frames."""
+    stays within 8 % of the path length of the generator's ground truth (open-loop VO over 3.6 km through scene changes; the
+    degenerate ground-only circle of rounds 1-3 stayed below 1 %) — and, since round 5, EVERY frame against the oracle: the fixture
+    tests/golden/stream_keys_kitti_test.npz holds the CPU oracle's key (counters, av_parallax bits, pose bits) of all 4,541 frames
+    (generated in the build container by tests/golden/gen_stream_keys.py; the first 48 frames are also run through the oracle live)."""
     from concurrent.futures import ThreadPoolExecutor
     import os
     import stereo_vo_amd as S
@@ -383,6 +418,13 @@ def test_hip_config3_full_4541_frame_stream_properties():
     # (rigid alignment, no scale: open-loop VO over 3.6 km through scene changes — the camera drives through billboards, some
     # frames have a few hundred corners — drifts by a few per cent; the degenerate ground-only circle of rounds 1-3 stayed below 1 %)
     assert path > 3000 and ate < 0.08 * path, (ate, path)
+    # every frame against the oracle-derived fixture (a GPU-only defect anywhere in the stream would show here, not only in the head)
+    import stream_configs as SC
+    c3 = SC.STREAMS["kitti_test"]
+    assert (c3["max_corners"], c3["quality"], c3["min_feature_distance"], c3["max_features"], c3["window_size"], c3["frames"]) == (1500, 0.02, 10.0, 2000, 10, N)
+    keys = SC.load_keys("kitti_test")
+    assert keys is not None and len(keys) == N, "tests/golden/stream_keys_kitti_test.npz is missing or short: run tests/golden/gen_stream_keys.py"
+    assert SC.compare(keys, a) == []
     # the head of the stream against the oracle (bit-exact counters and poses)
     o = O.Pipeline(focal=p.focal, cx=p.cx, cy=p.cy, baseline=p.baseline, width=W, height=H, max_corners=1500, quality=0.02,
                    min_feature_distance=10.0, parallax_thresh=20.0, window_size=10, max_features=2000, ba_max_iterations=50,
