@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
     ap.add_argument("--streams", type=int, default=48, help="independent stereo streams processed concurrently per GPU")
     ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
+    ap.add_argument("--stagger-ms", type=float, default=0.0, help="group i starts its steps i x this many milliseconds after group 0 (inside the timed region)")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k", "hd10k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
     ap.add_argument("--profile-kernel", default="lk_fb", help="kernel timed with HIP events for the roofline object")
@@ -304,10 +305,12 @@ def run_kitti(args):
             for _ in range(k):
                 streams[0].step()
             return
-        def work(st):
+        def work(st, delay):
+            if delay > 0:
+                time.sleep(delay)  # inside the timed region: the groups' steps start out of phase (a group's step is a dense detection burst followed by a latency-bound tail)
             for _ in range(k):
                 st.step()
-        th = [threading.Thread(target=work, args=(st,)) for st in streams]
+        th = [threading.Thread(target=work, args=(st, 1e-3 * args.stagger_ms * i)) for i, st in enumerate(streams)]
         [t.start() for t in th]
         [t.join() for t in th]
 

@@ -401,7 +401,7 @@ int svo_pipeline_get_tracked(svo_pipeline* p, int64_t* ids, float* xy, int capac
  * tracker, graph and poses exactly as an svo_pipeline does, every stage that several lanes reach together is ONE kernel
  * launch (blockIdx.y = lane) and their bundle adjustments are ONE device-resident solve launch; lanes never wait for
  * each other.  Lane results are bit-identical to n_lanes separate svo_pipeline objects.  The context's
- * svo_limits.max_batch bounds n_lanes x frames per call; 1 <= n_lanes <= 32.  (No reference counterpart: the reference is one stream in one
+ * svo_limits.max_batch bounds n_lanes x frames per call; 1 <= n_lanes <= 64.  (No reference counterpart: the reference is one stream in one
  * process; this is how one GPU serves many of them — and what a rank of the multi-GPU bench runs.) */
 typedef struct svo_pipeline_group svo_pipeline_group;
 int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out, const svo_pipeline_params* p, int n_lanes);

@@ -3,7 +3,7 @@
 #ifndef SVO_XCD_MAP_H_
 #define SVO_XCD_MAP_H_
 
-constexpr int SVO_MAX_LANES = 32;
+constexpr int SVO_MAX_LANES = 64;  // lanes of one pipeline group (round 5: 32 -> 64; the launches' lane records travel in the kernel-argument segment, masks are 64-bit)
 
 // XCD-aware item -> workgroup map of a stream-batched launch (a speed choice only; per_chunk == 0: blockIdx = (item, lane)).  The
 // launch's items (features, corners), lane after lane — a lane without items counts one idle workgroup: somebody has to arrive for

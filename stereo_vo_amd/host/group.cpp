@@ -306,7 +306,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
   if (!ctx || !out || !p) return SVO_ERR_INVALID;
   *out = nullptr;
   SVO_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-  SVO_REQUIRE(ctx, n_lanes >= 1 && n_lanes <= SVO_MAX_LANES, "pipeline_group_create: 1..32 lanes");
+  SVO_REQUIRE(ctx, n_lanes >= 1 && n_lanes <= SVO_MAX_LANES, "pipeline_group_create: 1..64 lanes");
   SVO_REQUIRE(ctx, p->width >= 32 && p->height >= 32 && p->width <= ctx->lim.max_width && p->height <= ctx->lim.max_height,
               "pipeline_group_create: image size outside the context limits");
   SVO_REQUIRE(ctx, p->max_corners >= 4 && p->max_corners <= ctx->lim.max_corners && p->max_features >= 4 &&

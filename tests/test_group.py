@@ -23,7 +23,7 @@ def _group(S, ctx, p, maxc, md, mf, lanes, window=5):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("lanes,batch,md,maxc", [(1, 4, 30.0, 300), (4, 6, 10.0, 600), (7, 12, 12.0, 300), (20, 6, 14.0, 300)])
+@pytest.mark.parametrize("lanes,batch,md,maxc", [(1, 4, 30.0, 300), (4, 6, 10.0, 600), (7, 12, 12.0, 300), (20, 6, 14.0, 300), (44, 4, 14.0, 300), (64, 3, 16.0, 300)])  # (round 5: up to 64 lanes per group)
 def test_hip_group_lanes_match_their_oracles(lanes, batch, md, maxc):
     """Lanes with DIFFERENT scenes (their keyframes fall on different frames: lanes sit in different stages of the chain at
     the same time and are batched in changing combinations); frames handed over in batches that cut the sequence."""
