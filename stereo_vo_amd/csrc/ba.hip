@@ -2949,6 +2949,7 @@ struct svo_ba {
   uint8_t* h_arena = nullptr;     // pinned staging image of the arena
   size_t arena_cap = 0;
   hipStream_t stream = nullptr;   // BA has its own stream so a solve can overlap the tracker's kernels
+  bool stream_owned = true;       // false: adopted from the caller (svo_ba_use_stream: the lanes of a pipeline group share the group's lines)
   double* d_pay = nullptr;        // [payload2 (PAY2_SLOTS) | payload1]: one buffer, one all-reduce
   double* d_step = nullptr;       // device copy of [dc | candidate poses] (bulk / sharded runs)
   double* d_bctl = nullptr;       // bulk path, device-side step control: LM state (BC_*) | Jacobi scales of the pose columns
@@ -3171,7 +3172,7 @@ extern "C" void svo_ba_destroy(svo_ba* ba) {
     if (p) (void)hipFree(p);
   if (ba->h_pin) (void)hipHostFree(ba->h_pin);
   if (ba->h_lane) (void)hipHostFree(ba->h_lane);
-  if (ba->stream) (void)hipStreamDestroy(ba->stream);
+  if (ba->stream && ba->stream_owned) (void)hipStreamDestroy(ba->stream);
   delete ba;
 }
 
@@ -3191,6 +3192,21 @@ extern "C" int svo_ba_set_comm(svo_ba* ba, void* nccl_comm) {
 extern "C" int svo_ba_set_device_lm(svo_ba* ba, int mode) {
   if (!ba || mode < -1 || mode > 1) return SVO_ERR_INVALID;
   ba->device_lm = mode;
+  return SVO_OK;
+}
+
+// The adjuster's own HIP stream (uploads, host-driven solves, the landmark-store scatter) replaced by one of the caller's: a process
+// with many adjusters then keeps few streams, and the runtime's stream -> hardware-queue binding (GPU_MAX_HW_QUEUES) stays one to one
+// for the streams that carry the work (host/group.cpp).  Not while a solve is in flight.
+int svo_ba_use_stream(svo_ba* ba, void* stream) {
+  if (!ba || !stream || ba->lm_inflight) return SVO_ERR_INVALID;
+  svo_use_device(ba->ctx);
+  if (ba->stream) {
+    (void)hipStreamSynchronize(ba->stream);
+    if (ba->stream_owned) (void)hipStreamDestroy(ba->stream);
+  }
+  ba->stream = (hipStream_t)stream;
+  ba->stream_owned = false;
   return SVO_OK;
 }
 

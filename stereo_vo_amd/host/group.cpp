@@ -286,6 +286,7 @@ extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
     fprintf(stderr, "[svo group] %d lanes, %ld keyframes; group thread per keyframe (us): get_world_points %.1f, add_keyframe %.1f, join + write-back of the solve %.1f\n",
             g->n_lanes, g->n_kf, 1e-3 * g->t_get_points / g->n_kf, 1e-3 * g->t_add_keyframe / g->n_kf, 1e-3 * g->t_finish / g->n_kf);
   (void)hipStreamSynchronize(g->ctx->stream);
+  for (Lane* l : g->lanes) { if (l->ba) { svo_ba_destroy(l->ba); l->ba = nullptr; } }  // before the lines they work on (svo_ba_use_stream) go
   for (int i = 0; i <= svo_pipeline_group::MAX_LINES; ++i) {
     if (g->st_lk[i] && g->st_lk[i] != g->ctx->stream) { (void)hipStreamSynchronize(g->st_lk[i]); (void)hipStreamDestroy(g->st_lk[i]); }
     if (g->st_chain[i]) { (void)hipStreamSynchronize(g->st_chain[i]); (void)hipStreamDestroy(g->st_chain[i]); }
@@ -372,7 +373,16 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
       if (chain_hi) chk(hipStreamCreateWithPriority(&g->st_chain[i], hipStreamNonBlocking, prio_hi), "stream");
       else chk(hipStreamCreateWithFlags(&g->st_chain[i], hipStreamNonBlocking), "stream");
     }
-    for (int i = 0; i < g->n_ba; ++i) chk(hipStreamCreateWithFlags(&g->st_ba[i], hipStreamNonBlocking), "stream");
+    {
+      // SVO_GROUP_BA_PRIORITY=low|high: the solve lines as streams of another priority class — the runtime keeps one pool of hardware
+      // queues per class, so they can never share a queue with (and block) a tracking or keyframe-chain launch
+      const char* be = getenv("SVO_GROUP_BA_PRIORITY");
+      const int ba_prio = (be && be[0] == 'l') ? prio_lo : ((be && be[0] == 'h') ? prio_hi : 0);
+      for (int i = 0; i < g->n_ba; ++i) {
+        if (ba_prio != 0 && prio_hi != prio_lo) chk(hipStreamCreateWithPriority(&g->st_ba[i], hipStreamNonBlocking, ba_prio), "stream");
+        else chk(hipStreamCreateWithFlags(&g->st_ba[i], hipStreamNonBlocking), "stream");
+      }
+    }
     { const char* e = getenv("SVO_GROUP_EXPRESS"); g->express = e && *e && atoi(e) != 0; }  // off by default: measured 17.1 k against 18.3 k frames/s on the bench
     if (g->express) {
       chk(hipStreamCreateWithFlags(&g->st_lk[svo_pipeline_group::MAX_LINES], hipStreamNonBlocking), "stream");
@@ -381,6 +391,31 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
   }
   g->pyr_stride = svo_k_pyramid_bytes(p->width, p->height);
   if (!rc) rc = dev_alloc(g, &g->d_corners, 2 * mc * S * B);
+  if (!rc) {
+    // The runtime binds a HIP stream to one of its GPU_MAX_HW_QUEUES hardware queues when the stream is first USED (the least
+    // referenced queue at that moment); streams that share a hardware queue serialise.  With several groups warming up on their
+    // own threads the order of first use — and with it which streams end up sharing a queue — differed from run to run (the same
+    // command gave 22 k or 41 k frames/s at 128 lanes in 4 groups, profiles/r05_exp_lanes_groups.txt).  Touch every line once, here,
+    // on the creating thread, in a fixed order: the binding becomes a function of the creation order alone.  SVO_GROUP_TOUCH=0: off.
+    const char* e = getenv("SVO_GROUP_TOUCH");
+    if (!(e && *e && atoi(e) == 0)) {
+      hipStream_t order[3 * (svo_pipeline_group::MAX_LINES + 1)];
+      int no = 0;
+      if (e && atoi(e) == 2) {  // (experiment: tracking and chain lines first)
+        for (int i = 0; i < g->n_lk; ++i) order[no++] = g->st_lk[i];
+        for (int i = 0; i < g->n_chain; ++i) order[no++] = g->st_chain[i];
+        for (int i = 0; i < g->n_ba; ++i) order[no++] = g->st_ba[i];
+      } else {
+        for (int i = 0; i < g->n_ba; ++i) order[no++] = g->st_ba[i];
+        for (int i = 0; i < g->n_chain; ++i) order[no++] = g->st_chain[i];
+        for (int i = 0; i < g->n_lk; ++i) order[no++] = g->st_lk[i];
+      }
+      for (int i = 0; i < no && !rc; ++i) {
+        chk(hipMemsetAsync(g->d_corners, 0, 16, order[i]), "hipMemsetAsync");
+        chk(hipStreamSynchronize(order[i]), "hipStreamSynchronize");
+      }
+    }
+  }
   if (!rc) rc = dev_alloc(g, &g->d_ncorners, S * B);
   if (!rc) rc = dev_alloc(g, &g->d_pyr[0], g->pyr_stride * S * B);
   if (!rc) rc = dev_alloc(g, &g->d_pyr[1], g->pyr_stride * S * B);
@@ -450,6 +485,8 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     const int max_obs = (p->window_size + 1) * p->max_features + 64;
     rc = svo_ba_create(ctx, &l->ba, p->window_size, &p->cam, &opt, max_obs, max_obs);
     if (!rc) rc = svo_ba_attach_store(l->ba, l->d_store, l->store_mask);
+    // the lane's adjuster works on the group's solve lines (no stream of its own: see the hardware-queue note above)
+    { const char* e = getenv("SVO_GROUP_OWN_BA_STREAMS"); if (!rc && !(e && *e && atoi(e) != 0)) rc = svo_ba_use_stream(l->ba, g->st_ba[li % g->n_ba]); }
     // (the window solves keep the wide form unless SVO_BA_FORM=compact: measured in round 5, one workgroup per solve costs a lane
     // ~10x the solve latency and halves the frame rate at 48 lanes — profiles/r05_exp_compact_lanes.txt; the compact form serves as
     // the overflow of the admission budget, SVO_BA_OVERFLOW, and as the re-run of a solve that gave up)
