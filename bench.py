@@ -34,7 +34,7 @@ import sys
 import time
 
 # HIP runtime knob, read when the runtime initialises (profiles/r04_exp_hw_queues.txt: 4 / 8 / 12 / 16; r03_group_sweep.txt also 20 / 24):
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # two pipeline groups use 2 x 9 HIP streams; with 4 hardware queues their long solve launches share queues with the tracking launches and serialise (measured 11.6 k vs 19.4 k frames/s)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # HIP streams that share a hardware queue serialise (a 3 ms solve in front of a tracking launch), and more hardware queues than the GPU has slots for slow EVERY stream of the process down (round 5, profiles/r05_exp_lanes_groups.txt: 32 queues gave the headline 27-33 k frames/s but halved the single-stream workloads that follow in the same process).  So: 16 queues, and at most 16 streams — see group_lines() below
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the copy bandwidth that guide measured
 VALU_ISSUE_PEAK_GINSTR = 1228.8  # 256 CUs x 4 SIMDs x 2.4 GHz / 2 (one wave64 VALU instruction per 2 cycles per SIMD)
 FP64_VEC_PEAK_TFLOPS = 78.6  # public MI355X FP64 vector spec (not in the local guide)
-PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r04_summary.json")  # written by tools/prof_round.sh + prof_summary.py
+PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r05_summary.json")  # written by tools/prof_round.sh + prof_summary.py
 
 
 def parse():
@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
-    ap.add_argument("--streams", type=int, default=48, help="independent stereo streams processed concurrently per GPU")
-    ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
+    ap.add_argument("--streams", type=int, default=128, help="independent stereo streams processed concurrently per GPU (round 4's default: 48 in 2 groups)")
+    ap.add_argument("--groups", type=int, default=4, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="group i starts its steps i x this many milliseconds after group 0 (inside the timed region)")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k", "hd10k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
@@ -224,7 +224,9 @@ class _Group:
     def __init__(self, S, torch, local, seeds, B):
         n = len(seeds)
         self.ctx = S.Context(W, H, device=local, max_batch=n * B, max_corners=MAXC, max_candidates=1 << 16, max_features=MAX_FEAT)
-        data = [render_batch(S, sd, B) for sd in seeds]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 1, 16)) as ex:  # (the renderer is host C++ behind ctypes: the GIL is released)
+            data = list(ex.map(lambda sd: render_batch(S, sd, B), seeds))
         self.p, self.L, self.R = data[0]
         dev = torch.device("cuda", local)
         self.dL = torch.from_numpy(np.stack([d[1] for d in data])).to(dev)  # (lanes, B, H, W)
@@ -281,13 +283,25 @@ class _Group:
         self.ctx.close()
 
 
+def group_lines(n_groups):
+    """HIP streams ("lines") per pipeline group so that the process stays within its 16 hardware queues: a group drives 1 tracking
+    line + chain lines + solve lines; 2 groups take the library's defaults (1 + 2 + 4 = 7 each, round 4's sweep), 3 or more groups
+    1 + 1 + 2 = 4 each (round 5: 128 lanes in 4 groups, 16 streams on 16 queues — 28-31 k frames/s and nothing else in the process
+    slows down; with 7 lines per group on 16 queues the same command gave 19-41 k from run to run, profiles/r05_exp_lanes_groups.txt).
+    Environment variables set by the caller win."""
+    if n_groups >= 3:
+        os.environ.setdefault("SVO_GROUP_CHAIN_LINES", "1")
+        os.environ.setdefault("SVO_GROUP_BA_LINES", "2")
+
+
 def run_kitti(args):
     import threading
     import stereo_vo_amd as S
     torch, dist, rank, local, world = dist_setup(args.gpus)
     B, NS = args.batch, max(1, args.streams)
-    seeds = [0x5EED0001 + rank * 64 + i for i in range(NS)]
+    seeds = [0x5EED0001 + rank * 1024 + i for i in range(NS)]
     NG = max(0, min(args.groups, NS))
+    group_lines(NG)
     single_pipe = None
     if NG > 0:  # pipeline groups: NG host threads, the streams dealt round-robin
         streams = [_Group(S, torch, local, seeds[gi::NG], B) for gi in range(NG)]
@@ -460,14 +474,15 @@ def run_kitti(args):
             us = 1e3 * ba_ms / ba_n
             tf = fl / (ba_ms * 1e-3) / 1e12
             prof = profile_summary() or {}
-            tr = (prof.get("ba_lm_traffic_bytes_per_launch") or None)
-            dk = {"kernel": "ba_lm_kernel", "bound": "latency (tagged hand-overs between the workgroups of a solve; FP64 VALU inside a pass)",
+            tr = (prof.get("ba_lm_traffic_bytes_per_launch") or None)  # the wide kernel's own FETCH_SIZE + WRITE_SIZE per launch (committed counter pass)
+            dk = {"kernel": "ba_lm_kernel (+ ba_lm_compact_kernel for the solves the admission budget refuses)", "bound": "latency (tagged hand-overs between the workgroups of a solve; FP64 VALU inside a pass)",
                   "avg_launch_us": us, "launches": ba_n, "solves": n_solves, "lm_iterations": n_its,
                   "algorithmic_flops_per_launch": fl / ba_n, "algorithmic_bytes_per_launch": by / ba_n,
                   "achieved": tf, "peak": FP64_VEC_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VEC_PEAK_TFLOPS,
                   "hbm_frac_algorithmic": by / (ba_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
                   "traffic_over_algorithmic": (tr / (by / ba_n)) if tr else None,
-                  "time_share_percent": (prof.get("kernel_time_share_default") or {}).get("ba_lm_kernel"),
+                  "time_share_percent": {k: v for k, v in (prof.get("kernel_time_share_default") or {}).items() if k.startswith("ba_lm")},
+                  "workload_definition": "r05: 128 lanes in 4 groups, device-resident solves only in the work count",
                   "measured": "HIP events on the solve lines of the second pipeline group over the timed region; per launch = per "
                               "%.1f solves of %.1f LM iterations" % (n_solves / ba_n, n_its / max(n_solves, 1))}
             out["roofline"]["tracker_kernel"] = out["roofline"].pop("dominant_kernel", None)

@@ -70,6 +70,7 @@ int svo_rccl_allreduce_f64(void* buf, size_t count, void* comm, hipStream_t stre
 bool svo_throughput_mode();  // host/pipeline.cpp: more than two pipelines share the process
 
 namespace {
+std::atomic<int> g_group_lanes{0};  // lanes of the live pipeline groups of this process (svo_ba_note_group_lanes)
 int g_ba_cu_share = 32;  // CUs of every 32 the adjusters' streams may use (SVO_BA_CU_SHARE; 32 = unmasked)
 // Workgroups of admitted kernels whose workgroups wait for each other (see ba_fused_budget), per device: a process that drives
 // several GPUs (one svo_ctx each) must not let one device's adjusters draw from another device's budget.
@@ -1907,7 +1908,7 @@ __device__ __forceinline__ bool lm_fetch_totals(double* cP, double* cU, const do
 // [dc | candidate poses | current poses] in sStep and its parameters in cs; returns an LMOP_* code.
 // LOCAL (ba_lm_compact_kernel: ONE workgroup runs the whole solve): the summed payloads are not collected from granules, they sit in
 // the workgroup's LDS — `tot` (E wire totals) and `tot2` (pass B's four sums); cs.elapsed is set by the caller from its own clock.
-template <bool LOCAL>
+template <bool LOCAL, bool GROUPED = false>
 __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmDevArgs& a, LmDevState& cs, double* cl, double* cSc, double* sStep, double* sOut4,
                                                         const double* tot = nullptr, const double* tot2 = nullptr) {
   const int tid = threadIdx.x, nt = blockDim.x, n = P.n, K = P.K, nn = n > 0 ? n : 1;
@@ -1976,7 +1977,7 @@ __device__ __attribute__((noinline)) int lm_controller(const BaDev& P, const LmD
       if constexpr (LOCAL) {
         if (tid < 4) cs.pay2[tid] = tot2[tid];
       } else {
-        if (!sum_pay2<false>(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
+        if (!sum_pay2<GROUPED>(P, (int)(cs.op_count & 1u), cs.tag, cP, sOut4, &cs.flag)) { if (tid == 0) cs.bad = 1; }
         if (tid < 4) cs.pay2[tid] = sOut4[tid];
       }
       __syncthreads();
@@ -2230,6 +2231,7 @@ __device__ __forceinline__ void lm_owner_phases(const BaDev& P, const LmWave& W,
 // owner phases, level 2) serves all of them: the kernel is larger than the instruction cache, and every inlined copy of a
 // stage that this function used to hold (three of pass A's) cost every pass of every solve misses — measured: 5 KB more code,
 // nowhere near pass A, made pass A 1.8 us slower.
+template <bool GROUPED>
 __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, LmWave& W, bool my_wave_works, const uint16_t* tabs, const WgLds& L,
                                            double* union_lds, int union_doubles, LmDevState& cs, double* sStep, LmShared& sh, int n_blocks, long long t_first, long long* tp,
                                            bool linearize_only) {
@@ -2267,7 +2269,7 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
       stamp(1);
       // every workgroup collects pass B's sums itself and takes the decision: identical inputs, identical bits (the staging
       // rows are idle between the passes: they are the scratch of the collection)
-      const bool ok = sum_pay2<false>(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
+      const bool ok = sum_pay2<GROUPED>(P, P.pay_parity, P.pay_tag, union_lds, sh.sOut, &sh.sGo);
       if (!ok) return false;
       if (tid == 0) {
         const SvoLmDecision dec = svo_lm_decide(cs.cost, cs.mcc, radius, cs.df, sh.sOut[0], sh.sOut[1]);
@@ -2297,7 +2299,7 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
   double* res = a.dev_res;
   const unsigned long long tag = P.pay_tag;
   bool ok = true;
-  if (e0 < e1) ok = reduce_elements<false>(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); }, tp ? tp + 5 : nullptr);
+  if (e0 < e1) ok = reduce_elements<GROUPED>(P, e0, e1, tag, union_lds, union_doubles, &sh.sGo, [res, tag](int e, double v) { granule_store(&res[2 * e], v, tag); }, tp ? tp + 5 : nullptr);
   if (blockIdx.x == 0 && tid == 0)  // the clock every controller tests (see the kernel's header): seconds since this workgroup's first pass
     granule_store(&res[2 * P.E], 1e-8 * (double)((long long)wall_clock64() - t_first), tag);
   stamp(4);
@@ -2307,7 +2309,11 @@ __device__ __forceinline__ bool lm_iterate(const BaDev& P, const LmDevArgs& a, L
 #ifndef SVO_LM_WAVES_PER_EU  // developer experiments only (SVO_EXTRA_HIPFLAGS): the register budget of the solve kernel's wavefronts
 #define SVO_LM_WAVES_PER_EU 2
 #endif
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVES_PER_EU, SVO_LM_WAVES_PER_EU))) void ba_lm_kernel(LmLanePtrs lanes) {
+// GROUPED: windows of 129..LM_MAX_CHUNKS_GROUPED chunks (the 10-keyframe windows of configs[2]): levels 1-2 of the declared order sum
+// groups of G = ceil(C / 128) consecutive chunks first (reduce_elements<true>, sum_pay2<true>: the forms the host-driven kernels use).
+// A kernel of its own (ba_lm_grouped_kernel) so that the plain one — every pipeline group's solve — keeps its code size.
+template <bool GROUPED>
+__device__ __forceinline__ void ba_lm_body(const LmLanePtrs& lanes) {
   extern __shared__ double lds[];  // ba_lm_lds_doubles(n, K)
   __shared__ LmShared sh;
   __shared__ LmDevState cs;
@@ -2360,7 +2366,7 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
   __syncthreads();
   for (;;) {
     const int st_before = cs.state;
-    const int op = lm_controller<false>(P, a, cs, union_lds, cSc, sStep, sh.sOut);
+    const int op = lm_controller<false, GROUPED>(P, a, cs, union_lds, cSc, sStep, sh.sOut);
     if (a.dbg && tid == 0) {
       unsigned* g = a.dbg + 16 * blockIdx.x;
       g[0] = (unsigned)op; g[1] = (unsigned)cs.state; g[2] = (unsigned)cs.iterations; g[3] = (unsigned)cs.need_linearize;
@@ -2411,13 +2417,15 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVE
       continue;  // the next controller turn answers "delivered": everybody leaves
     }
     long long* tp = a.dbg ? cs.tp : nullptr;
-    if (!lm_iterate(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, op == LMOP_ITERATE ? tp : nullptr, op != LMOP_ITERATE)) {
+    if (!lm_iterate<GROUPED>(P, a, W, my_wave_works, tabs, L, union_lds, union_doubles, cs, sStep, sh, n_blocks, t_first, op == LMOP_ITERATE ? tp : nullptr, op != LMOP_ITERATE)) {
       if (tid == 0) __hip_atomic_store(a.host_flag, -a.host_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return;
     }
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVES_PER_EU, SVO_LM_WAVES_PER_EU))) void ba_lm_kernel(LmLanePtrs lanes) { ba_lm_body<false>(lanes); }
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(SVO_LM_WAVES_PER_EU, SVO_LM_WAVES_PER_EU))) void ba_lm_grouped_kernel(LmLanePtrs lanes) { ba_lm_body<true>(lanes); }
 
 // ---------------------------------------------------------------------------------------------------
 // The THROUGHPUT form of the device-resident solve: ba_lm_compact_kernel — ONE workgroup runs a whole solve (round 5).
@@ -3210,6 +3218,9 @@ int svo_ba_use_stream(svo_ba* ba, void* stream) {
   return SVO_OK;
 }
 
+// host/group.cpp: a pipeline group of `delta` lanes was created (> 0) or destroyed (< 0)
+void svo_ba_note_group_lanes(int delta) { g_group_lanes.fetch_add(delta, std::memory_order_relaxed); }
+
 extern "C" int svo_ba_set_solve_form(svo_ba* ba, int form) {
   if (!ba || form < -1 || form > 1) return SVO_ERR_INVALID;
   ba->lm_form = form;
@@ -3739,10 +3750,13 @@ inline FusedAdmission* ba_resident_admission(svo_ba* ba) { return &ba->res_admis
 // loop (41 against 40 us per LM iteration), many streams were always faster with it, and no host thread sits in the loop.
 // (Rounds 3-4 kept the host loop for a lone stream: the device loop was 51 / 45 us per iteration then.)  A pipeline group always
 // uses it (svo_ba_solve_launch); larger windows (more than 128 chunks) take the host-driven loop.
+// Round 5: measured again with both loops in the tree — one stream alone: 1,803 frames/s host-driven against 1,700 device-resident
+// (profiles/r05_exp_single_stream_paths.txt) — so a single pipeline takes the device-resident solve only while more than two
+// pipelines are inside svo_pipeline_process_batch* (then the host thread per stream is what hurts); pipeline groups always do.
 bool ba_device_lm_wanted() {
   static const char* e = getenv("SVO_BA_DEVICE_LM");
   if (e && *e) return atoi(e) != 0;
-  return true;
+  return svo_throughput_mode();
 }
 
 int ba_lm_tab_words(const svo_ba* ba) { return std::max(64, (ba->tab_max_words + 63) & ~63); }
@@ -3752,6 +3766,7 @@ size_t ba_lm_lds_bytes(const svo_ba* ba) { return sizeof(double) * ba_lm_lds_dou
 // compact form: the waves per workgroup that fit 156 KB of dynamic LDS (the kernel keeps ~1.5 KB of static LDS), at most
 // SVO_BA_COMPACT_WAVES (default 6) and not more than the problem has chunks; 0: not eligible
 constexpr size_t LMC_LDS_BUDGET = 156 * 1024;
+constexpr int LM_MAX_CHUNKS_GROUPED = 288;   // wide form: 129..288 chunks go to ba_lm_grouped_kernel (144 workgroups at one per CU fit the admission budget)
 constexpr int LMC_MAX_CHUNKS = 256;   // beyond, a single workgroup's rounds take longer than the host-driven loop's launches
 int ba_lmc_tab_words(const svo_ba* ba) { return std::max(64, (ba->tab_max_words + 63) & ~63); }
 int ba_lmc_waves(const svo_ba* ba) {
@@ -3780,7 +3795,12 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced, bool
     if (nw < 1) return false;
     lds = sizeof(double) * ba_lmc_lds_doubles(d.n, d.K, ba_lmc_tab_words(ba), nw);
   } else {
-  if (d.C > 128 || ba->tab_max_words > TAB_LDS_WORDS) return false;  // one group per chunk, every chunk table in LDS: window-sized problems
+  // every chunk table in LDS, every chunk its own partial (beyond 128 chunks the grouped kernel sums groups of G chunks first), and
+  // the launch must fit the admission budget at all (workgroups that wait for each other): window-sized problems
+  if (d.C > LM_MAX_CHUNKS_GROUPED || d.CPW != 1 || ba->tab_max_words > TAB_LDS_WORDS) return false;
+  // beyond 128 chunks (ba_lm_grouped_kernel) only on request: measured on configs[2]'s 10-keyframe windows (~210 chunks, E = 2,312 wire
+  // elements) the host-driven loop is faster — 780 against 590 frames/s (profiles/r05_exp_single_stream_paths.txt)
+  if (d.G > 1 && ba->device_lm != 1) return false;
   lds = ba_lm_lds_bytes(ba);
   if (lds > 120 * 1024) return false;  // n <= 100 or so; window problems are n <= 60
   }
@@ -3826,10 +3846,16 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced, bool
 // offered again later, or solved by the host-driven path.
 int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsigned long long* launched_mask) {
   if (launched_mask) *launched_mask = 0;
-  // SVO_BA_OVERFLOW=1: a solve the admission budget refuses takes the compact form at once instead of waiting for the budget
-  static const bool overflow = [] { const char* e = getenv("SVO_BA_OVERFLOW"); return e && *e && atoi(e) != 0; }();
+  // A solve the admission budget refuses takes the compact form at once instead of waiting for the budget: SVO_BA_OVERFLOW=0 / 1, else
+  // on while the process drives many streams (svo_ba_note_group_lanes: >= 96 lanes in live pipeline groups — measured, round 5: at 48
+  // lanes the overflow costs 15 % of the frame rate, at 128 it is worth 30-50 %, profiles/r05_exp_lanes_groups.txt)
+  static const int overflow_env = [] { const char* e = getenv("SVO_BA_OVERFLOW"); return e && *e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool overflow = overflow_env >= 0 ? overflow_env == 1 : g_group_lanes.load(std::memory_order_relaxed) >= 96;
   bool to_compact[SVO_MAX_LANES] = {};
   // ---- the wide form (ba_lm_kernel): admitted against the budget of co-resident waiting workgroups
+  int launched_total = 0;
+  for (int i = 0; i < n && i < SVO_MAX_LANES; ++i) bas[i]->lm_inflight = false;
+  for (int grouped = 0; grouped < 2; ++grouped) {  // windows of up to 128 chunks: ba_lm_kernel; beyond: ba_lm_grouped_kernel
   LmLanePtrs ptrs;
   int launched = 0, max_c = 0;
   size_t max_lds = 0;
@@ -3839,10 +3865,10 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsign
     svo_ba* ba = bas[i];
     int cost = 0;
     size_t lds = 0;
-    ba->lm_inflight = false;
+    if ((ba->d.G > 1) != (grouped != 0)) continue;
     if (ba_wants_compact(ba)) { to_compact[i] = true; continue; }
     if (!ba_device_lm_fill(ba, &cost, &lds, forced)) continue;
-    if (lds > 32 * 1024 && hipFuncSetAttribute((const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) continue;
+    if (lds > 32 * 1024 && hipFuncSetAttribute(grouped ? (const void*)ba_lm_grouped_kernel : (const void*)ba_lm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024) != hipSuccess) continue;
     if (!ba_resident_admission(ba)->admit(cost, ba->ctx->device)) { to_compact[i] = overflow; continue; }
     // the counter starts from zero: cleared in front of the launch (the adjuster's previous solve no longer touches it
     // once its completion word is out)
@@ -3861,7 +3887,8 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsign
     const auto t0 = now();
     {
       SvoProfScope prof(took[0]->ctx, SVO_PROF_BA_STEP, st);
-      hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
+      if (grouped) hipLaunchKernelGGL(ba_lm_grouped_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
+      else hipLaunchKernelGGL(ba_lm_kernel, dim3(max_c, launched), dim3(128), max_lds, st, ptrs);
     }
     if (hipGetLastError() != hipSuccess) {
       for (int i = 0; i < launched; ++i) ba_resident_admission(took[i])->release();
@@ -3879,6 +3906,9 @@ int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsign
       if (launched_mask) *launched_mask |= 1ull << tidx[i];
     }
   }
+  launched_total += launched;
+  }
+  const int launched = launched_total;
   // ---- the compact form (ba_lm_compact_kernel: one workgroup per solve; nothing to admit, nothing to clear)
   int n_compact = 0;
   {
@@ -4186,7 +4216,7 @@ static bool ba_bulk_control_wanted(const svo_ba* ba) {
   if (ba->d.det || ba->d.n > 128 || ba->d.K > 64) return false;
   if (ba->bulk_ctl >= 0) return ba->bulk_ctl == 1;
   static const char* e = getenv("SVO_BA_BULK_CONTROL");
-  return !(e && *e) || atoi(e) != 0;
+  return e && *e && atoi(e) != 0;  // opt-in: one workgroup factors n = 114 in 125 us where a host core takes 35
 }
 
 // The host's whole part of a solve: enqueue the fixed sequence slot by slot, staying `ahead` slots in front of the last status
@@ -4641,7 +4671,7 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary) {
   ba->t_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tu0).count();
   ba->n_solves++;
   if (rc) return rc;
-  if (summary) {
+  if (summary && on_device) {  // device-resident solves only: the launches bench.py times with HIP events carry exactly these
     const double its = summary->iterations + 1;  // + the first linearisation
     ba->acc_flops += its * ba->flops_iter; ba->acc_bytes += its * ba->bytes_iter; ba->acc_solves += 1; ba->acc_iters += summary->iterations;
   }

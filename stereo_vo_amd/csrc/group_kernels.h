@@ -70,6 +70,7 @@ int svo_ba_solve_finish(svo_ba* ba, svo_ba_summary* summary);  // join (or solve
 void svo_ba_work(svo_ba* ba, double* out4, int reset);
 // device-resident landmark store of the adjuster's stream (capacity = mask + 1 entries, a power of two): every solve writes the
 // landmarks it optimised into it — ba_lm_kernel with its delivery, a host-driven solve through one scatter launch at its finish
+void svo_ba_note_group_lanes(int delta);           // lanes of live pipeline groups (decides the admission overflow, csrc/ba.hip)
 int svo_ba_use_stream(svo_ba* ba, void* stream);   // the adjuster's own stream replaced by one of the group's lines
 int svo_ba_attach_store(svo_ba* ba, float4* store, unsigned mask);          // algorithmic [flops, bytes, solves, LM iterations] of the finished solves
 

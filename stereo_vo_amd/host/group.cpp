@@ -164,6 +164,7 @@ struct svo_pipeline_group {
   svo_ctx* ctx = nullptr;
   svo_pipeline_params prm{};
   int n_lanes = 0, max_batch = 0;
+  int counted_lanes = 0;  // what this group added to the process-wide lane count (svo_ba_note_group_lanes)
   float K[9];
   std::vector<Lane*> lanes;
   std::vector<void*> dev_allocs, pin_allocs;
@@ -287,6 +288,7 @@ extern "C" void svo_pipeline_group_destroy(svo_pipeline_group* g) {
             g->n_lanes, g->n_kf, 1e-3 * g->t_get_points / g->n_kf, 1e-3 * g->t_add_keyframe / g->n_kf, 1e-3 * g->t_finish / g->n_kf);
   (void)hipStreamSynchronize(g->ctx->stream);
   for (Lane* l : g->lanes) { if (l->ba) { svo_ba_destroy(l->ba); l->ba = nullptr; } }  // before the lines they work on (svo_ba_use_stream) go
+  if (g->counted_lanes) svo_ba_note_group_lanes(-g->counted_lanes);
   for (int i = 0; i <= svo_pipeline_group::MAX_LINES; ++i) {
     if (g->st_lk[i] && g->st_lk[i] != g->ctx->stream) { (void)hipStreamSynchronize(g->st_lk[i]); (void)hipStreamDestroy(g->st_lk[i]); }
     if (g->st_chain[i]) { (void)hipStreamSynchronize(g->st_chain[i]); (void)hipStreamDestroy(g->st_chain[i]); }
@@ -501,6 +503,8 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     if (nw > 8) nw = 8;
     g->pool.start(nw, ctx->device);
   }
+  g->counted_lanes = n_lanes;
+  svo_ba_note_group_lanes(n_lanes);
   *out = g;
   return SVO_OK;
 }

@@ -188,7 +188,8 @@ def test_hip_compact_solve_equals_the_host_driven_loop_beyond_128_chunks(ctx, se
     import stereo_vo_amd as S
     p = BP.make_problem(seed, K, N)
     res = []
-    for dev, form in ((False, None), (True, "compact")):
+    # host-driven | compact | wide (round 5: ba_lm_grouped_kernel takes windows of 129..288 chunks — the 10-keyframe windows of configs[2])
+    for dev, form in ((False, None), (True, "compact"), (True, "wide")):
         ba = S.api.BA(ctx, max(K, 2), BP.F, BP.CX, BP.CY, max_landmarks=len(p["points0"]) + 8, max_observations=len(p["op"]) + 8,
                       max_time_s=0.0, device_lm=dev, solve_form=form, accumulation="deterministic")
         ba.load_problem(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"])
@@ -197,6 +198,7 @@ def test_hip_compact_solve_equals_the_host_driven_loop_beyond_128_chunks(ctx, se
         res.append((s.iterations, s.termination, s.initial_cost, s.final_cost, poses.tobytes(), pts.tobytes()))
         ba.close()
     assert res[0] == res[1], (res[0][:4], res[1][:4])
+    assert res[0] == res[2], (res[0][:4], res[2][:4])
     po, pto, so = O.ba_solve(p["poses0"], p["points0"], p["op"], p["oj"], p["uv"], BP.F, BP.CX, BP.CY, num_threads=4)
     assert res[1][0] == so["iterations"] and res[1][3] == so["final_cost"]
     assert res[1][4] == np.ascontiguousarray(po).tobytes()

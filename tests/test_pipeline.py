@@ -103,13 +103,17 @@ def test_hip_pipeline_degenerate_frames(ctx):
 @pytest.mark.parametrize("env", [{"SVO_BA_CU_SHARE": "8"}, {"SVO_BA_NO_POLL": "1"}, {"SVO_LM_NO_SPECULATION": "1"},
                                  {"SVO_BA_DEVICE_LM": "0"}, {"SVO_BA_DEVICE_LM": "0", "SVO_SPIN": "50"},
                                  {"SVO_BA_DEVICE_LM": "1"}, {"SVO_BA_DEVICE_LM": "1", "SVO_BA_CU_SHARE": "4"},
-                                 {"SVO_BA_DEVICE_LM": "1", "SVO_BA_CU_SHARE": "24"}, {"SVO_CORNER_TWO_PASS": "1"}])
+                                 {"SVO_BA_DEVICE_LM": "1", "SVO_BA_CU_SHARE": "24"}, {"SVO_CORNER_TWO_PASS": "1"},
+                                 {"SVO_BA_DEVICE_LM": "1", "SVO_BA_FORM": "compact"}, {"SVO_PYR_PER_LEVEL": "1"},
+                                 {"SVO_BA_DEVICE_LM": "1", "SVO_BA_TEST_GIVEUP": "2"}, {"SVO_BA_XPROC": "0", "SVO_BA_DEVICE_LM": "1"}])
 def test_hip_pipeline_optional_paths_keep_parity(env):
     """Deployment knobs must not change results: CU-partitioned streams, the stream-wait (non-polling) host loop, the
     LM loop without chained / same-sweep linearisation (two host round trips per iteration), the host-driven loop forced,
     sleeping host waits, the device-resident solve (one launch per solve, LM step control on the device; also on CU masks,
     one of them too small to hold its waiting workgroups: admission must send the solve down the host-driven path)
-    and corner detection through the f32 response map (two passes) instead of the fused response + non-maximum pass all
+    and corner detection through the f32 response map (two passes) instead of the fused response + non-maximum pass, and (round 5)
+    the compact form of the device-resident solve, the per-level pyramid launches instead of the fused pyramid kernel, wide
+    solves that give up (every second one, test hook) and are re-run, and the per-process admission all
     have to reproduce the oracle's index sets and poses exactly.  The knobs are read from the environment, hence one child process each."""
     import os
     import subprocess

@@ -132,8 +132,8 @@ for c, key in (("FETCH_SIZE", "fetch_kb_per_launch"), ("WRITE_SIZE", "write_kb_p
         traffic[k][key] = a[k][c] / n[k]
         launches[k] = n[k]
 if traffic:
-    # the counter passes ran `bench.py --steps 3 --warmup 1 --streams 24 --groups 1 --no-single`: frames = (steps + warmup) x batch x lanes, from the run's own line
-    frames = 4 * 16 * 24
+    # the counter passes ran `bench.py --steps 3 --warmup 1 --streams 32 --groups 1 --no-single`: frames = (steps + warmup) x batch x lanes, from the run's own line
+    frames = 4 * 16 * 32
     try:
         for ln in open(os.path.join(src, "bench_FETCH_SIZE.log")):
             if ln.startswith('{"metric"'):
