@@ -3846,11 +3846,12 @@ bool ba_device_lm_fill(svo_ba* ba, int* cost, size_t* lds_out, bool forced, bool
 // offered again later, or solved by the host-driven path.
 int ba_device_lm_launch(svo_ba** bas, int n, hipStream_t st, bool forced, unsigned long long* launched_mask) {
   if (launched_mask) *launched_mask = 0;
-  // A solve the admission budget refuses takes the compact form at once instead of waiting for the budget: SVO_BA_OVERFLOW=0 / 1, else
-  // on while the process drives many streams (svo_ba_note_group_lanes: >= 96 lanes in live pipeline groups — measured, round 5: at 48
-  // lanes the overflow costs 15 % of the frame rate, at 128 it is worth 30-50 %, profiles/r05_exp_lanes_groups.txt)
-  static const int overflow_env = [] { const char* e = getenv("SVO_BA_OVERFLOW"); return e && *e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-  const bool overflow = overflow_env >= 0 ? overflow_env == 1 : g_group_lanes.load(std::memory_order_relaxed) >= 96;
+  // SVO_BA_OVERFLOW=1: a solve the admission budget refuses takes the compact form at once instead of waiting for the budget.  Off by
+  // default: measured in round 5 (profiles/r05_exp_lanes_groups.txt) it helps only while streams share hardware queues (7 lines per group
+  // on 16 queues: 30 k against 25 k frames/s at 128 lanes); with one hardware queue per stream the wide form alone is faster (37-51 k
+  // against 27-36 k) — a 3 ms compact solve holds its line for 3 ms.
+  static const bool overflow = [] { const char* e = getenv("SVO_BA_OVERFLOW"); return e && *e && atoi(e) != 0; }();
+  (void)g_group_lanes;
   bool to_compact[SVO_MAX_LANES] = {};
   // ---- the wide form (ba_lm_kernel): admitted against the budget of co-resident waiting workgroups
   int launched_total = 0;

@@ -1093,8 +1093,26 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             if (!inflight) {
               Lane* l = g->lanes[not_taken];
               l->ba_ready_seq = 0;
-              l->ba_state.store(BA_HOST_SOLVING, std::memory_order_release);
-              g->pool.post(l, 1);
+              // SVO_GROUP_STALLED_COMPACT=1 (experiment, round 5): the compact device-resident form instead of the host-driven loop on a
+              // worker.  Measured slower — 29 k against 41 k frames/s at 128 lanes (profiles/r05_exp_lanes_groups.txt): a compact solve
+              // holds its solve line for ~3 ms, the worker's host-driven solve holds none.
+              static const bool stalled_compact = [] { const char* e = getenv("SVO_GROUP_STALLED_COMPACT"); return e && *e && atoi(e) != 0; }();
+              bool went = false;
+              if (stalled_compact && !host_solves) {
+                svo_ba* one = l->ba;
+                (void)svo_ba_set_solve_form(one, 1);
+                went = svo_ba_solve_launch(&one, 1, g->st_ba[free_line], nullptr) == 1;
+                (void)svo_ba_set_solve_form(one, -1);
+                if (went) {
+                  EV(not_taken, "ba_launch_compact", 1);
+                  l->ba_launch = ++g->ba_launch_id; l->ba_line = free_line; l->ba_state.store(BA_INFLIGHT, std::memory_order_release);
+                  g->launches[4]++; g->lanes_carried[4]++;
+                }
+              }
+              if (!went) {
+                l->ba_state.store(BA_HOST_SOLVING, std::memory_order_release);
+                g->pool.post(l, 1);
+              }
               progressed = true;
             }
           }
