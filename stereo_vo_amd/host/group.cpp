@@ -272,6 +272,7 @@ void quiesce_after_error(svo_pipeline_group* g) {
     if (l->h_bad) *l->h_bad = 0;  // a "foreign landmark-store entry" report must not outlive the batch it failed
     l->queued = false;
   }
+  (void)hipDeviceSynchronize();  // (the fills ran on the null stream)
 }
 
 }  // namespace
@@ -503,6 +504,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     if (nw > 8) nw = 8;
     g->pool.start(nw, ctx->device);
   }
+  (void)hipDeviceSynchronize();  // the fills above ran on the null stream, the group's lines are non-blocking streams: nothing may still be in flight
   g->counted_lanes = n_lanes;
   svo_ba_note_group_lanes(n_lanes);
   *out = g;
@@ -525,8 +527,11 @@ extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
     // feature ids restart at 0 (svo_ba_reset): no entry of the landmark store may survive under an old id, and a reported
     // foreign entry is forgotten with the stream that produced it
     if (l->h_bad) *l->h_bad = 0;
-    if (l->d_store && hipMemset(l->d_store, 0xFF, sizeof(float4) * ((size_t)l->store_mask + 1)) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP;
+    // (on the context's stream and waited for below: hipMemset on device memory may return before the fill has run, and the group's
+    // lines are non-blocking streams — a fill that landed behind the first solve of the next batch wiped its entries; seen under rocprofv3)
+    if (l->d_store && hipMemsetAsync(l->d_store, 0xFF, sizeof(float4) * ((size_t)l->store_mask + 1), g->ctx->stream) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP;
   }
+  if (hipStreamSynchronize(g->ctx->stream) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP;
   if (rc_join) { quiesce_after_error(g); return rc_join; }  // a solve that was in flight did not come back cleanly
   return SVO_OK;
 }
