@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
-    ap.add_argument("--streams", type=int, default=128, help="independent stereo streams processed concurrently per GPU (round 4's default: 48 in 2 groups)")
-    ap.add_argument("--groups", type=int, default=4, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
+    ap.add_argument("--streams", type=int, default=48, help="independent stereo streams processed concurrently per GPU")
+    ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="group i starts its steps i x this many milliseconds after group 0 (inside the timed region)")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k", "hd10k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
@@ -164,6 +164,9 @@ def group_self_parity(groups, B):
                 if raw[l * B * rec:(l + 1) * B * rec] != ref[l * B * rec:(l + 1) * B * rec]:
                     bad += 1
                     first_bad = first_bad or {"group": gi, "lane": l, "step": si}
+    short = [gi for gi, g in enumerate(groups) if len(g.raws) != steps]
+    if short:
+        raise RuntimeError(f"groups {short} recorded fewer steps than the others: {[len(g.raws) for g in groups]}")
     return {"lanes_checked": lanes, "steps_checked": steps, "lane_steps_that_differ_from_step_0": bad, "first": first_bad,
             "what": "raw svo_frame_result records of every lane, every timed step against the first timed step"}
 
@@ -286,8 +289,9 @@ class _Group:
 def group_lines(n_groups):
     """HIP streams ("lines") per pipeline group so that the process stays within its 16 hardware queues: a group drives 1 tracking
     line + chain lines + solve lines; 2 groups take the library's defaults (1 + 2 + 4 = 7 each, round 4's sweep), 3 or more groups
-    1 + 1 + 2 = 4 each (round 5: 128 lanes in 4 groups, 16 streams on 16 queues — 28-31 k frames/s and nothing else in the process
-    slows down; with 7 lines per group on 16 queues the same command gave 19-41 k from run to run, profiles/r05_exp_lanes_groups.txt).
+    1 + 1 + 2 = 4 each (16 streams on 16 queues for 4 groups; every stream its own queue).  Lanes x groups x lines measured in round 5:
+    profiles/r05_exp_lanes_groups_honest.txt — a plateau at ~20 k frames/s from 48 lanes in 2 groups to 96 in 3; the figures of
+    profiles/r05_exp_lanes_groups.txt above that are retracted (threads of dead groups were counted, see its header).
     Environment variables set by the caller win."""
     if n_groups >= 3:
         os.environ.setdefault("SVO_GROUP_CHAIN_LINES", "1")
@@ -319,14 +323,20 @@ def run_kitti(args):
             for _ in range(k):
                 streams[0].step()
             return
+        errs = []
         def work(st, delay):
-            if delay > 0:
-                time.sleep(delay)  # inside the timed region: the groups' steps start out of phase (a group's step is a dense detection burst followed by a latency-bound tail)
-            for _ in range(k):
-                st.step()
+            try:
+                if delay > 0:
+                    time.sleep(delay)  # inside the timed region: the groups' steps start out of phase (a group's step is a dense detection burst followed by a latency-bound tail)
+                for _ in range(k):
+                    st.step()
+            except BaseException as e:  # noqa: BLE001 — a thread that dies must fail the run, not shorten it
+                errs.append(e)
         th = [threading.Thread(target=work, args=(st, 1e-3 * args.stagger_ms * i)) for i, st in enumerate(streams)]
         [t.start() for t in th]
         [t.join() for t in th]
+        if errs:
+            raise errs[0]
 
     run_steps(args.warmup)
     # single-stream rate (latency-bound: one sequential VO chain) measured first, in the same run
@@ -439,13 +449,19 @@ def run_kitti(args):
             g.fill_staging()
             g.clear_counters()
 
+        serrs = []
         def swork(st, k):
-            for _ in range(k):
-                st.step_streaming()
+            try:
+                for _ in range(k):
+                    st.step_streaming()
+            except BaseException as e:  # noqa: BLE001
+                serrs.append(e)
         def run_streaming(k):
             th = [threading.Thread(target=swork, args=(st, k)) for st in streams]
             [t.start() for t in th]
             [t.join() for t in th]
+            if serrs:
+                raise serrs[0]
         run_streaming(max(1, args.warmup))
         for g in streams:
             g.clear_counters()
@@ -482,7 +498,7 @@ def run_kitti(args):
                   "hbm_frac_algorithmic": by / (ba_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
                   "traffic_over_algorithmic": (tr / (by / ba_n)) if tr else None,
                   "time_share_percent": {k: v for k, v in (prof.get("kernel_time_share_default") or {}).items() if k.startswith("ba_lm")},
-                  "workload_definition": "r05: 128 lanes in 4 groups, device-resident solves only in the work count",
+                  "workload_definition": "r05: device-resident solves only in the work count (round 4 counted host-driven ones too)",
                   "measured": "HIP events on the solve lines of the second pipeline group over the timed region; per launch = per "
                               "%.1f solves of %.1f LM iterations" % (n_solves / ba_n, n_its / max(n_solves, 1))}
             out["roofline"]["tracker_kernel"] = out["roofline"].pop("dominant_kernel", None)

@@ -10,6 +10,7 @@
 #define SVO_GROUP_KERNELS_H_
 #include "kernels.h"
 
+#include "chain_math.h"  // SvoChainRec
 #include "xcd_map.h"  // SVO_MAX_LANES, SvoXcdMap
 
 // a3 + the survivor filter of FeatureTracker::track_features, forward/backward LK and the stable compaction in ONE launch:
@@ -42,6 +43,10 @@ struct SvoPnpLane {
   double* host_pose; int* host_inliers; int* host_nin; int* host_best; int* host_bad;  // pinned mirrors; host_best < 0: no model, host_bad != 0: a store entry under a foreign id
   unsigned* arrive; unsigned arrive_target;                                         // device arrival counter of the lane (monotone)
   int* word; int seq;                                                               // pinned completion word
+  // round 5: the keyframe chain without a host turn — the launch's last workgroup also leaves the reprojection matrix of the refined
+  // pose (or of the previous one: prev_rvec / prev_tvec, when no model was found) and the inlier count for the stereo +
+  // triangulation launch queued right behind it (host/chain_math.h); chain == null: not asked for
+  SvoChainRec* chain; float prev_rvec[3], prev_tvec[3]; float cam_f, cam_cx, cam_cy, cam_b;
 };
 struct SvoPnpLanes { SvoPnpLane lane[SVO_MAX_LANES]; };
 int svo_kg_pnp(svo_ctx* ctx, hipStream_t st, const SvoPnpLanes& lanes, int n_lanes);  // grid from the lanes' `launched`
@@ -57,6 +62,7 @@ struct SvoStereoTriLane {
   const uint8_t* left; const uint8_t* right; const float* xy; const int* n_dev; int n_max; float* disp; SvoMat4 M;
   const float* trk; int n_trk; float min_d;  // a6 folded in: the tracked inliers a detected corner must keep min_d away from (null: no dedup, frame 0)
   float* kept_xy; float* xyz; int* n_kept; SvoPublish pub;
+  const SvoChainRec* chain;  // non-null: M, the number of tracked inliers and "nothing to do" (best == -2) come from the PnP launch in front of this one
 };
 struct SvoStereoTriLanes { int w, h, stride, ndisp, block; SvoXcdMap map; SvoStereoTriLane lane[SVO_MAX_LANES]; };
 // map.per_chunk == 0: grid_x = the largest lane's n_max; every lane's pub.target counts grid_x workgroups (pub.arrive must be set); with the map (lanes' n_dev must be null) max(n_max, 1)

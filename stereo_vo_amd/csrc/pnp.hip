@@ -314,6 +314,24 @@ __device__ __forceinline__ void pnp_hypothesis_wave(const Xyz& src, const float*
 
 // Refinement over the inliers of hypothesis `best` by the calling workgroup (256 threads).  COHERENT: mask and pose of the
 // hypothesis were written by other workgroups of this very launch (read at the coherence point).
+// What the stereo + triangulation launch queued behind this one needs (SvoChainRec): rvec / tvec exactly as the host stores them
+// (float, from the refined pose by the declared conversion; the previous ones when no model was found), then hmat and M by the
+// function the host calls for lanes without PnP (host/chain_math.h).  One thread.
+__device__ __forceinline__ void pnp_write_chain(const SvoPnpLane& a, int best, int n_inl, const double* q, const double* t) {
+  float rvec[3], tvec[3];
+  if (best >= 0) {
+    double rv[3];
+    svo_det_rvec_from_quat(q, rv);
+    for (int k = 0; k < 3; ++k) { rvec[k] = (float)rv[k]; tvec[k] = (float)t[k]; }
+  } else {
+    for (int k = 0; k < 3; ++k) { rvec[k] = a.prev_rvec[k]; tvec[k] = a.prev_tvec[k]; }
+  }
+  SvoChainRec* c = a.chain;
+  svo_chain_matrix(rvec, tvec, a.cam_f, a.cam_cx, a.cam_cy, a.cam_b, c->M);
+  c->n_inl = best >= 0 ? n_inl : 0;
+  c->best = best;
+}
+
 template <typename Xyz, bool COHERENT>
 __device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __restrict__ xy, int n,
                                                 double f, double cx, double cy, const double* hyp_pose,
@@ -321,7 +339,8 @@ __device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __r
                                                 int best, double* __restrict__ out_pose, int* __restrict__ inliers,
                                                 int* __restrict__ n_inliers, double* __restrict__ host_pose,
                                                 int* __restrict__ host_inliers, int* __restrict__ host_nin,
-                                                float* __restrict__ inlier_xy, SvoPublish pub, LmShared& S, double (*sPart)[28], int* sBase) {
+                                                float* __restrict__ inlier_xy, SvoPublish pub, LmShared& S, double (*sPart)[28], int* sBase,
+                                                const SvoPnpLane* chain_lane = nullptr) {
   svo_latency_critical();
   const int tid = threadIdx.x;
   // inlier list of the best hypothesis, ascending (one wave builds it)
@@ -416,6 +435,7 @@ __device__ __forceinline__ void pnp_refine_body(const Xyz& src, const float* __r
       for (int k = 0; k < 3; ++k) host_pose[4 + k] = S.cur.t[k];
       *host_nin = m;
     }
+    if (chain_lane && chain_lane->chain) pnp_write_chain(*chain_lane, best, m, S.cur.q, S.cur.t);
   }
   svo_publish_block(pub);
 }
@@ -465,9 +485,13 @@ __device__ __forceinline__ void pnp_fused_body(const SvoPnpLane& a, const Src& s
   const int best = sBest;
   SvoPublish pub;
   pub.word = a.word; pub.seq = a.seq;
-  if (best < 0) { svo_publish_block(pub); return; }
+  if (best < 0) {
+    if (tid == 0 && a.chain) pnp_write_chain(a, best, 0, a.q0, a.t0);
+    svo_publish_block(pub);
+    return;
+  }
   pnp_refine_body<Src, true>(src, a.xy, a.n, a.f, a.cx, a.cy, a.hyp_pose, a.hyp_mask, a.mask_words, best, a.out_pose, a.inliers, a.n_inliers,
-                             a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, pub, S, sPart, &sBase);
+                             a.host_pose, a.host_inliers, a.host_nin, a.inlier_xy, pub, S, sPart, &sBase, &a);
 }
 
 // single stream: the world points as a float3 array in feature order (gathered by the host: get_world_points)
@@ -518,6 +542,7 @@ int svo_k_pnp(svo_ctx* ctx, SvoScratch& s, const float* d_xyz, const float* d_xy
   a.hyp_pose = d_pose; a.hyp_count = d_count; a.hyp_mask = d_mask; a.mask_words = words;
   a.out_pose = d_out; a.inliers = d_inliers; a.n_inliers = d_nin; a.inlier_xy = d_inlier_xy;
   a.host_pose = h_out; a.host_inliers = h_inliers; a.host_nin = h_nin; a.host_best = h_best; a.host_bad = nullptr;
+  a.chain = nullptr;
   // first the leading hypotheses only; all of them when the bookkeeping's cap stays above what was computed (h_best = -2)
   for (a.launched = svo_kg_pnp_first(iterations);; a.launched = iterations) {
     const int wgs = svo_div_up(a.launched, 4);

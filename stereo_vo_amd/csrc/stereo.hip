@@ -249,19 +249,25 @@ __global__ __launch_bounds__(NT) void stereo_triangulate_group_kernel(SvoStereoT
   svo_latency_critical();
   __shared__ int sWaveT[NT / 64];
   __shared__ int sLast, sHit;
-  const int n = a.n_dev ? *a.n_dev : a.n_max;
+  // behind a PnP launch of the same line (round 5: no host turn in between) the matrix, the number of tracked inliers and "nothing to
+  // do — the RANSAC bookkeeping wants more hypotheses first" come from the record that launch left (host/chain_math.h)
+  const SvoChainRec* ch = a.chain;
+  const bool idle = ch && ch->best == -2;
+  const int n = idle ? 0 : (a.n_dev ? *a.n_dev : a.n_max);
+  const int n_trk = ch ? ch->n_inl : a.n_trk;
+  const float* trk = (ch && n_trk <= 0) ? nullptr : a.trk;
   if (f < n) {  // (one instance of the block matcher for the first keyframe — no tracked features to keep away from — and all later ones)
     const float x = a.xy[2 * f], y = a.xy[2 * f + 1];
     bool dup = false;
-    if (a.trk) {  // uniform in the workgroup
+    if (trk) {  // uniform in the workgroup
       if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         bool hit = false;
-        for (int j0 = 0; j0 < a.n_trk && !hit; j0 += 64) {
+        for (int j0 = 0; j0 < n_trk && !hit; j0 += 64) {
           const int j = j0 + lane;
           bool h = false;
-          if (j < a.n_trk) {
-            const float dx = x - a.trk[2 * j], dy = y - a.trk[2 * j + 1];
+          if (j < n_trk) {
+            const float dx = x - trk[2 * j], dy = y - trk[2 * j + 1];
             h = sqrtf(dx * dx + dy * dy) < a.min_d;  // src/image_processor.cpp:118-123
           }
           hit = __any(h);
@@ -277,7 +283,9 @@ __global__ __launch_bounds__(NT) void stereo_triangulate_group_kernel(SvoStereoT
     if (threadIdx.x == 0) svo_wt_store(&a.disp[f], d);
   }
   if (!svo_last_arrival(a.pub.arrive, a.pub.target, &sLast)) return;
-  svo_triangulate_block<NT, true>(a.xy, a.disp, n, a.M, a.kept_xy, a.xyz, nullptr, a.n_kept, sWaveT);
+  SvoMat4 Mc = a.M;
+  if (ch) for (int i = 0; i < 16; ++i) Mc.m[i] = ch->M[i];
+  svo_triangulate_block<NT, true>(a.xy, a.disp, n, Mc, a.kept_xy, a.xyz, nullptr, a.n_kept, sWaveT);
   SvoPublish one = a.pub;
   one.arrive = nullptr;  // the arrivals have been counted: this workgroup publishes alone
   svo_publish_block(one);

@@ -27,6 +27,7 @@
 #include <thread>
 #include <vector>
 
+#include "chain_math.h"
 #include "det_trig.h"
 #include "group_kernels.h"
 #include "ref_constants.h"
@@ -109,6 +110,9 @@ struct Lane {
   int frame = 0;                    // index into the batch
   int pending_from = -1;            // first frame of the batch whose pose waits for the running solve
   bool first_keyframe = false;      // the triangulation in flight is frame 0's (src/image_processor.cpp:30-58)
+  SvoChainRec* d_chain = nullptr;   // what the lane's PnP launch leaves for the stereo + triangulation launch queued behind it (host/chain_math.h)
+  double t_q = 0.0;                 // when the lane entered the queue of its next stage (microseconds of this call): the gather policy
+  bool fused = false;               // the triangulation in flight rides behind a PnP launch: its results are consumed together with PnP's
   int m_tracked = 0, num_inliers = 0, best = -1;
   float rmat[9], quat[4];
   std::vector<long long> kf_tracked_ids; std::vector<float> kf_tracked_xy;  // the keyframe under construction
@@ -172,10 +176,12 @@ struct svo_pipeline_group {
   // consecutive stages coherent), solves take whichever solve line is free
   static constexpr int MAX_LINES = 8;
   int n_lk = 1, n_chain = 1, n_ba = 2;
+  int n_cmp = 0;  // compact lines: st_ba[n_ba ..): solves the admission budget refuses leave at once in the one-workgroup form, on lines of their own
   int xcd_chunks = SVO_XCD_CHUNKS;
   bool xcd_map = true, xcd_map_tri = true;  // the XCD-aware item -> workgroup map of the tracking / stereo launches (group_kernels.h; SVO_GROUP_LK_XCD=0, SVO_GROUP_TRI_XCD=0: blockIdx = (item, lane))
   // SVO_TIMING: host time of the group thread inside the per-keyframe graph calls (ns), and keyframes seen
   double t_get_points = 0, t_add_keyframe = 0, t_finish = 0, t_loop = 0; long n_kf = 0; bool timing = false;
+  double gather_us = 0.0;      // > 0: a stage's launch waits up to this long for the other lanes of its line that are still on their way
   double lk_overlap_us = 0.0;  // > 0: a second tracking line may depart once every launch in flight is at least this old (it is in its tail then)
   double lk_t0[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // departure time of the launch in flight on each tracking line (us since the call began)
   hipStream_t st_lk[MAX_LINES + 1] = {}, st_chain[MAX_LINES + 1] = {}, st_ba[MAX_LINES] = {};  // [MAX_LINES]: the express lines (see process_batch)
@@ -270,6 +276,7 @@ void quiesce_after_error(svo_pipeline_group* g) {
     for (int c = 0; c < C_COUNT; ++c) l->arrive_total[c] = 0;
     for (int w = 0; w < W_COUNT; ++w) { l->seq[w] = 0; l->words[16 * w] = 0; }
     if (l->h_bad) *l->h_bad = 0;  // a "foreign landmark-store entry" report must not outlive the batch it failed
+    l->fused = false; l->pnp_all = false;
     l->queued = false;
   }
   (void)hipDeviceSynchronize();  // (the fills ran on the null stream)
@@ -343,12 +350,14 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     auto knob = [](const char* name, int dflt, int hi) { const char* e = getenv(name); int v = e && *e ? atoi(e) : dflt; return v < 1 ? 1 : (v > hi ? hi : v); };
     g->n_lk = knob("SVO_GROUP_LK_LINES", 1, svo_pipeline_group::MAX_LINES);
     g->timing = getenv("SVO_TIMING") != nullptr;
+    { const char* e = getenv("SVO_GROUP_GATHER_US"); g->gather_us = e && *e ? std::max(0.0, atof(e)) : 0.0; }
     { const char* e = getenv("SVO_GROUP_LK_OVERLAP_US"); g->lk_overlap_us = e && *e ? std::max(0.0, atof(e)) : 0.0; }
     g->n_chain = knob("SVO_GROUP_CHAIN_LINES", 2, svo_pipeline_group::MAX_LINES);
     { const char* e = getenv("SVO_GROUP_LK_XCD"); g->xcd_map = !(e && *e && atoi(e) == 0); }
     { const char* e = getenv("SVO_GROUP_TRI_XCD"); g->xcd_map_tri = !(e && *e && atoi(e) == 0); }
     { const char* e = getenv("SVO_GROUP_XCD_CHUNKS"); if (e && *e) g->xcd_chunks = std::max(8, std::min(64, atoi(e) / 8 * 8)); }  // developer experiments
     g->n_ba = knob("SVO_GROUP_BA_LINES", 4, svo_pipeline_group::MAX_LINES);
+    { const char* e = getenv("SVO_GROUP_COMPACT_LINES"); g->n_cmp = e && *e ? std::max(0, std::min(atoi(e), svo_pipeline_group::MAX_LINES - g->n_ba)) : 0; }
     g->st_lk[0] = ctx->stream;
     // experiment knob: the tracker's launches on `keep` of every 32 CUs only (the rest stays free for the short kernels of the
     // keyframe chains and the solves)
@@ -381,7 +390,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
       // queues per class, so they can never share a queue with (and block) a tracking or keyframe-chain launch
       const char* be = getenv("SVO_GROUP_BA_PRIORITY");
       const int ba_prio = (be && be[0] == 'l') ? prio_lo : ((be && be[0] == 'h') ? prio_hi : 0);
-      for (int i = 0; i < g->n_ba; ++i) {
+      for (int i = 0; i < g->n_ba + g->n_cmp; ++i) {
         if (ba_prio != 0 && prio_hi != prio_lo) chk(hipStreamCreateWithPriority(&g->st_ba[i], hipStreamNonBlocking, ba_prio), "stream");
         else chk(hipStreamCreateWithFlags(&g->st_ba[i], hipStreamNonBlocking), "stream");
       }
@@ -407,9 +416,9 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
       if (e && atoi(e) == 2) {  // (experiment: tracking and chain lines first)
         for (int i = 0; i < g->n_lk; ++i) order[no++] = g->st_lk[i];
         for (int i = 0; i < g->n_chain; ++i) order[no++] = g->st_chain[i];
-        for (int i = 0; i < g->n_ba; ++i) order[no++] = g->st_ba[i];
+        for (int i = 0; i < g->n_ba + g->n_cmp; ++i) order[no++] = g->st_ba[i];
       } else {
-        for (int i = 0; i < g->n_ba; ++i) order[no++] = g->st_ba[i];
+        for (int i = 0; i < g->n_ba + g->n_cmp; ++i) order[no++] = g->st_ba[i];
         for (int i = 0; i < g->n_chain; ++i) order[no++] = g->st_chain[i];
         for (int i = 0; i < g->n_lk; ++i) order[no++] = g->st_lk[i];
       }
@@ -455,6 +464,7 @@ extern "C" int svo_pipeline_group_create(svo_ctx* ctx, svo_pipeline_group** out,
     if (!rc) rc = dev_alloc(g, &l->d_nin, 16);
     if (!rc) rc = dev_alloc(g, &l->d_inl, mf);
     if (!rc) rc = dev_alloc(g, &l->d_trk_xy, 2 * mf);
+    if (!rc) rc = dev_alloc(g, &l->d_chain, 1);
     if (!rc) rc = dev_alloc(g, &l->d_disp, mc);
     if (!rc) rc = dev_alloc(g, &l->d_own_pyr, g->pyr_stride);
     if (!rc) rc = dev_alloc(g, &l->d_arrive, 16 * C_COUNT);
@@ -527,8 +537,12 @@ extern "C" int svo_pipeline_group_reset(svo_pipeline_group* g) {
     // feature ids restart at 0 (svo_ba_reset): no entry of the landmark store may survive under an old id, and a reported
     // foreign entry is forgotten with the stream that produced it
     if (l->h_bad) *l->h_bad = 0;
+    l->fused = false; l->pnp_all = false;
     // (on the context's stream and waited for below: hipMemset on device memory may return before the fill has run, and the group's
     // lines are non-blocking streams — a fill that landed behind the first solve of the next batch wiped its entries; seen under rocprofv3)
+    static const int fill_mode = [] { const char* e = getenv("SVO_GROUP_RESET_FILL"); return e ? atoi(e) : 0; }();  // experiment: 1 = null stream, not waited for (before 954d023); 2 = no fill
+    if (fill_mode == 1) { if (l->d_store && hipMemset(l->d_store, 0xFF, sizeof(float4) * ((size_t)l->store_mask + 1)) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP; }
+    else if (fill_mode == 0)
     if (l->d_store && hipMemsetAsync(l->d_store, 0xFF, sizeof(float4) * ((size_t)l->store_mask + 1), g->ctx->stream) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP;
   }
   if (hipStreamSynchronize(g->ctx->stream) != hipSuccess && !rc_join) rc_join = SVO_ERR_HIP;
@@ -646,6 +660,9 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   const int MODEL = svo_pnp_model_points();
   // SVO_GROUP_TRACE=1: (microseconds, lane, event) of this call on stderr — where a lane's time goes
   static const bool trace_on = getenv("SVO_GROUP_TRACE") != nullptr;
+  // the keyframe chain without a host turn between PnP and stereo + triangulation (round 5); SVO_GROUP_CHAIN_FUSED=0: one launch,
+  // one host turn each, as before — same results either way (tests/test_group.py)
+  static const bool chain_fused = [] { const char* e = getenv("SVO_GROUP_CHAIN_FUSED"); return !(e && *e && atoi(e) == 0); }();
   struct Ev { double us; int lane; const char* what; int arg; };
   std::vector<Ev> evs;
   const auto t_begin = std::chrono::steady_clock::now();
@@ -653,6 +670,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     if (trace_on) evs.push_back({std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(), lane, what, arg});
   };
 
+  auto now_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count(); };
   // frame finished (is_keyframe etc. already in the result): move on
   auto frame_done = [&](int li) {
     Lane* l = g->lanes[li];
@@ -710,7 +728,30 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
   };
 
   // after PnP (:84-134): keyframe pose, inlier copy; then dedup + sparse stereo + triangulation go out
-  auto after_pnp = [&](int li) {
+  // PnP's verdict and pose out of the pinned mirrors: 0 = go on, -1 = error (set) or "launch again with all hypotheses" (queued)
+  auto consume_pnp = [&](int li) -> int {
+    Lane* l = g->lanes[li];
+    if (*l->h_bad) {
+      ctx->err = "pipeline group: a tracked feature's entry of the landmark store belongs to another id (store capacity exceeded?)";
+      error = SVO_ERR_CAPACITY;
+      return -1;
+    }
+    l->best = *l->h_best;  // the launch's own RANSAC bookkeeping (csrc/pnp.hip pnp_group_kernel); -1: no model
+    if (l->best == -2) {     // the adaptive cap stayed above the hypotheses of the first launch: all of them now
+      l->pnp_all = true;
+      l->state = L_PNP_WAIT;
+      q_pnp.push_back(li); l->queued = true; l->t_q = now_us();
+      return -1;
+    }
+    if (l->best >= 0) {
+      double rv[3];
+      svo_det_rvec_from_quat(l->h_out, rv);  // declared arithmetic (host/det_trig.h)
+      for (int k = 0; k < 3; ++k) { l->rvec[k] = (float)rv[k]; l->tvec[k] = (float)l->h_out[4 + k]; }
+      l->num_inliers = *l->h_nin;
+    }
+    return 0;
+  };
+  auto after_pnp = [&](int li, bool queue_tri = true) {
     Lane* l = g->lanes[li];
     svo_frame_result* res = &RES(li, 0);
     res[l->frame].n_inliers = l->num_inliers;
@@ -725,8 +766,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       l->kf_tracked_xy[2 * k] = txy[2 * idx]; l->kf_tracked_xy[2 * k + 1] = txy[2 * idx + 1];
     }
     l->first_keyframe = false;
-    q_tri.push_back(li); l->queued = true;
-    l->state = L_TRI_WAIT;
+    if (queue_tri) { q_tri.push_back(li); l->queued = true; l->t_q = now_us(); l->state = L_TRI_WAIT; }
   };
 
   // the keyframe path once the previous solve is joined (:71-82)
@@ -737,7 +777,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     l->num_inliers = 0; l->best = -1;
     // :72 get_world_points: nothing to do on the host — the PnP launch reads the tracked features' world points from the lane's
     // device-resident landmark store, which the (joined) solve of the previous keyframe has written
-    if (m >= MODEL) { q_pnp.push_back(li); l->queued = true; l->state = L_PNP_WAIT; }
+    if (m >= MODEL) { q_pnp.push_back(li); l->queued = true; l->t_q = now_us(); l->state = L_PNP_WAIT; }
     else after_pnp(li);
     return SVO_OK;
   };
@@ -764,7 +804,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     if (!l->has_keyframe) {  // :30-58
       l->first_keyframe = true;
       l->num_inliers = 0;
-      q_tri.push_back(li); l->queued = true;
+      q_tri.push_back(li); l->queued = true; l->t_q = now_us();
       l->state = L_TRI_WAIT;
       return SVO_OK;
     }
@@ -772,7 +812,7 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       l->n = 0; *l->h_av = 0.f;
       return after_track(li);
     }
-    q_track.push_back(li); l->queued = true;
+    q_track.push_back(li); l->queued = true; l->t_q = now_us();
     l->state = L_TRACK_WAIT;
     return SVO_OK;
   };
@@ -818,31 +858,23 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             if (!l->queued && word_ready(l, W_PNP)) {
               EV(li, "pnp_done", l->frame);
               progressed = true;
-              if (*l->h_bad) {
-                ctx->err = "pipeline group: a tracked feature's entry of the landmark store belongs to another id (store capacity exceeded?)";
-                error = SVO_ERR_CAPACITY;
-                break;
-              }
-              l->best = *l->h_best;  // the launch's own RANSAC bookkeeping (csrc/pnp.hip pnp_group_kernel); -1: no model
-              if (l->best == -2) {     // the adaptive cap stayed above the hypotheses of the first launch: all of them now
-                l->pnp_all = true;
-                q_pnp.push_back(li); l->queued = true;
-                break;
-              }
-              if (l->best >= 0) {
-                double rv[3];
-                svo_det_rvec_from_quat(l->h_out, rv);  // declared arithmetic (host/det_trig.h)
-                for (int k = 0; k < 3; ++k) { l->rvec[k] = (float)rv[k]; l->tvec[k] = (float)l->h_out[4 + k]; }
-                l->num_inliers = *l->h_nin;
-              }
-              after_pnp(li);
+              const int verdict = consume_pnp(li);
+              if (verdict < 0) break;        // error, or all hypotheses are needed: queued again
+              after_pnp(li, true);
             }
             break;
           case L_TRI_WAIT:
             if (!l->queued && word_ready(l, W_TRI)) {
               EV(li, "tri_done", l->frame);
+              progressed = true;
+              if (l->fused) {  // the launch rode behind the lane's PnP launch: PnP's results first (they are complete: same stream, earlier)
+                l->fused = false;
+                const int verdict = consume_pnp(li);
+                if (verdict < 0) break;      // (all hypotheses needed: the triangulation did nothing; both go out again)
+                after_pnp(li, false);
+              }
               error = keyframe_tail(li);
-              progressed = true; again = l->state == L_IDLE;
+              again = l->state == L_IDLE;
             }
             break;
           default: break;
@@ -885,6 +917,18 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       return mine;
     };
     const double t_now_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    // GATHER (SVO_GROUP_GATHER_US > 0): a launch lasts as long as its slowest item whatever it carries, so a bus that leaves with
+    // four of the line's lanes while others are a hundred microseconds away costs a whole launch more.  A stage's launch therefore
+    // waits while a lane of its line is NEAR (in the launch in flight of the stage before it), at most gather_us per waiting lane.
+    auto ripe = [&](const std::vector<int>& q, int line, int n_lines, int near_state) {
+      if (g->gather_us <= 0.0 || line == XL) return true;
+      int mine = 0, near = 0;
+      bool waited = false;
+      for (int li : q) if (n_lines <= 1 || li % n_lines == line) { ++mine; waited = waited || t_now_us - g->lanes[li]->t_q >= g->gather_us; }
+      if (!mine || waited) return true;
+      for (int li = 0; li < S; ++li) if ((n_lines <= 1 || li % n_lines == line) && g->lanes[li]->state == near_state && !g->lanes[li]->queued) ++near;
+      return near == 0;
+    };
     bool tails_only = true;  // every tracking launch in flight is old enough to be in its tail (a few straggling wavefronts)
     for (int line = 0; line < g->n_lk; ++line) tails_only = tails_only && (!lk_busy[line] || t_now_us - g->lk_t0[line] >= g->lk_overlap_us);
     for (int pass = g->express ? -1 : 0; pass < g->n_lk && !error; ++pass) {
@@ -893,8 +937,10 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       std::vector<int> q_now;
       if (g->lk_overlap_us > 0 && line != XL) {  // dynamic lines: the whole queue departs on a free line, but only next to tails
         if (!tails_only) break;
+        if (!ripe(q_track, 0, 1, L_TRI_WAIT)) break;
         q_now.swap(q_track);
       } else {
+        if (!ripe(q_track, line, g->n_lk, L_TRI_WAIT)) continue;
         q_now = take_line(q_track, line, g->n_lk);
       }
       if (q_now.empty()) continue;
@@ -939,7 +985,8 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
       const int line = pass < 0 ? XL : pass;
       if (chain_busy[line]) continue;
       hipStream_t stc = g->st_chain[line];
-      const std::vector<int> h_now = take_line(q_pnp, line, g->n_chain), t_now = take_line(q_tri, line, g->n_chain);
+      const std::vector<int> h_now = ripe(q_pnp, line, g->n_chain, L_TRACK_WAIT) ? take_line(q_pnp, line, g->n_chain) : std::vector<int>();
+      std::vector<int> t_now = take_line(q_tri, line, g->n_chain);
       for (int li : h_now) g->lanes[li]->chain_line = line;
       for (int li : t_now) g->lanes[li]->chain_line = line;
     if (!h_now.empty()) {
@@ -966,12 +1013,17 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         x.host_pose = l->h_out; x.host_inliers = l->h_inl; x.host_nin = l->h_nin; x.host_best = l->h_best; x.host_bad = l->h_bad;
         const SvoPublish pb = make_pub(l, W_PNP, C_PNP, wgs);
         x.arrive = pb.arrive; x.arrive_target = pb.target; x.word = pb.word; x.seq = pb.seq;
+        // fused chain: the launch leaves M / the inlier count / "more hypotheses first" for the stereo launch right behind it
+        x.chain = chain_fused ? l->d_chain : nullptr;
+        for (int c = 0; c < 3; ++c) { x.prev_rvec[c] = l->rvec[c]; x.prev_tvec[c] = l->tvec[c]; }
+        x.cam_f = g->K[0]; x.cam_cx = g->K[2]; x.cam_cy = g->K[5]; x.cam_b = (float)g->prm.cam.baseline;
         l->queued = false;
       }
       if ((error = svo_kg_pnp(ctx, stc, a, k))) break;
       for (int li : h_now) EV(li, "pnp_launch", k);
       g->launches[1]++; g->lanes_carried[1] += k;
       progressed = true;
+      if (chain_fused) for (int li : h_now) { g->lanes[li]->fused = true; t_now.push_back(li); }
     }
     if (!t_now.empty()) {
       // dedup (:113-128) for the lanes that tracked, then sparse StereoBM + triangulation (:137-142, :34-39 for frame 0)
@@ -996,7 +1048,10 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
         SvoStereoTriLane& x = t.lane[kt++];
         x.xy = DET(li, i); x.n_dev = nullptr;
         x.trk = nullptr; x.n_trk = 0; x.min_d = 0.f;
-        if (!l->first_keyframe) {
+        x.chain = nullptr;
+        if (l->fused) {  // behind the lane's PnP launch: M and the inlier count are read from its record on the device
+          x.chain = l->d_chain; x.trk = l->d_trk_xy; x.min_d = g->prm.min_feature_distance;
+        } else if (!l->first_keyframe) {
           // dedup (:113-128) inside the same launch: every corner's workgroup tests it against the tracked inliers first
           x.trk = l->d_trk_xy; x.n_trk = l->num_inliers; x.min_d = g->prm.min_feature_distance;
           if (x.n_trk <= 0) x.trk = nullptr;  // no inliers (C-9): nothing to keep away from
@@ -1088,6 +1143,32 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
             Lane* l = g->lanes[cand[k]];
             EV(cand[k], "ba_launch", launched);
             l->ba_launch = g->ba_launch_id; l->ba_line = free_line; l->ba_ready_seq = 0; l->ba_state.store(BA_INFLIGHT, std::memory_order_release);
+          }
+          if (not_taken >= 0 && g->n_cmp > 0 && !host_solves) {
+            // compact lines (SVO_GROUP_COMPACT_LINES, round 5): what the admission budget refused leaves at once in the one-workgroup
+            // form — no budget, 3-4x the latency — on a line of its own, so that the wide launches' lines stay free
+            int cline = -1;
+            for (int i = g->n_ba; i < g->n_ba + g->n_cmp; ++i) if (!ba_line_busy[i]) { cline = i; break; }
+            if (cline >= 0) {
+              svo_ba* cb[SVO_MAX_LANES];
+              int cl[SVO_MAX_LANES], nc = 0;
+              for (int k = 0; k < (int)cand.size(); ++k) if (!((mask >> k) & 1ull)) { cb[nc] = bas[k]; cl[nc++] = cand[k]; (void)svo_ba_set_solve_form(bas[k], 1); }
+              unsigned long long cmask = 0;
+              const int went = svo_ba_solve_launch(cb, nc, g->st_ba[cline], &cmask);
+              for (int k = 0; k < nc; ++k) (void)svo_ba_set_solve_form(cb[k], -1);
+              if (went > 0) {
+                ++g->ba_launch_id;
+                g->launches[4]++; g->lanes_carried[4] += went; progressed = true;
+                for (int k = 0; k < nc; ++k) {
+                  if (!((cmask >> k) & 1ull)) continue;
+                  Lane* l = g->lanes[cl[k]];
+                  EV(cl[k], "ba_launch_compact", went);
+                  l->ba_launch = g->ba_launch_id; l->ba_line = cline; l->ba_ready_seq = 0; l->ba_state.store(BA_INFLIGHT, std::memory_order_release);
+                }
+                not_taken = -1;
+                for (int k = 0; k < nc; ++k) if (!((cmask >> k) & 1ull)) { not_taken = cl[k]; break; }
+              }
+            }
           }
           if (not_taken >= 0) {
             // if nothing of this group is in flight that could free the admission budget (or the problem is simply not

@@ -97,8 +97,8 @@ def test_hip_config4_device_step_control_equals_the_host_driven_loop(ctx, cfg4):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_hip_config4_landmark_shards_equal_the_unsharded_solve(ctx, cfg4, world):
+@pytest.mark.parametrize("world,control", [(2, "host"), (4, "host"), (8, "host"), (2, "device"), (4, "device")])
+def test_hip_config4_landmark_shards_equal_the_unsharded_solve(ctx, cfg4, world, control):
     """`world` landmark shards (j mod world) solved in lock-step inside one process, the callback summing their device
     payloads (what the RCCL all-reduce does across ranks): every shard must take the same decisions and end at the
     unsharded poses; its own landmarks must match the unsharded ones."""
@@ -129,7 +129,7 @@ def test_hip_config4_landmark_shards_equal_the_unsharded_solve(ctx, cfg4, world)
                 bar.wait()
                 return 0
             parts = sharding.shard_problem(cfg4["points0"], cfg4["op"], cfg4["oj"], cfg4["uv"], rank, world)
-            s, poses, pts, st = _solve(ctxs[rank], cfg4, "mfma", iters, parts=parts[:4], allreduce=cb)
+            s, poses, pts, st = _solve(ctxs[rank], cfg4, "mfma", iters, parts=parts[:4], allreduce=cb, bulk_control=control == "device")
             res[rank] = (parts[4], s, poses, pts, st)
         except Exception as e:  # noqa: BLE001
             errs.append((rank, repr(e)))
@@ -147,10 +147,10 @@ def test_hip_config4_landmark_shards_equal_the_unsharded_solve(ctx, cfg4, world)
         assert np.array_equal(poses, res[0][2])  # bit-identical poses on every "rank"
         # collectives per rank: one per stand-alone pass A; per LM iteration ONE when both payloads share it (same sweep) or
         # when no next linearisation is asked for (the last iteration), two when the decision is chained (payload2, payload1)
-        # With the step control on the device (the default here) every sequence slot is chained and the host stays SVO_BA_RUNAHEAD
-        # (2) slots ahead of the status records: one collective for the first linearisation, two per enqueued slot — the same count on
-        # every rank, because a slot is enqueued as a function of the records alone.
-        assert st.device_control == 1 and st.host_us > 0
+        # With the step control on the device (opt-in) every sequence slot is chained and the host stays SVO_BA_RUNAHEAD (2) slots
+        # ahead of the status records: one collective for the first linearisation, two per enqueued slot — the same count on every
+        # rank, because a slot is enqueued as a function of the records alone.
+        assert st.device_control == int(control == "device") and (st.host_us > 0) == (control == "device")
         assert calls[rank] == st.collectives == calls[0]
         assert st.collectives <= 1 + 2 * (iters + 2)
     [c.close() for c in ctxs]
