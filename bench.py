@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — stereo frames/s of the MI355X-native stereo-VO hot path (BASELINE.json metric).
 
-Default line = "48 concurrent streams as 2 pipeline groups, inputs resident in HBM": a compute rate.  The same 16 frames per
+Default line = "96 concurrent streams as 3 pipeline groups, inputs resident in HBM": a compute rate.  The same 16 frames per
 stream are re-processed every step from a reset pipeline (identical work per step, no upload in the timed region);
 `--workload kitti_stream` is the streaming figure (BASELINE configs[2]: 4541 frames through the host-pointer entry,
 upload included, 10-keyframe window, nothing reset).  The default line also carries `streaming` (the same lanes fed from host
@@ -9,8 +9,8 @@ memory through svo_pipeline_group_staging / _upload / _process_uploaded, upload 
 lane of every timed step against the first step) and `parity_vs_cpu` (8 lanes against the CPU oracle), and `other_workloads`
 (kitti_stream, ba50k sparse and dense, hd_1280x720_10k), each with its own roofline / cpu_baseline / parity record.
 
-A "step" = one pass of the whole hot path on every one of `--streams` (default 48) independent stereo streams that share the
-GPU — as `--groups` (default 2) pipeline groups (svo_pipeline_group_*: one host thread per group, one kernel launch per stage
+A "step" = one pass of the whole hot path on every one of `--streams` (default 96) independent stereo streams that share the
+GPU — as `--groups` (default 3) pipeline groups (svo_pipeline_group_*: one host thread per group, one kernel launch per stage
 for the lanes that are ready, their bundle adjustments one device-resident launch), or with `--groups 0` as one svo_pipeline
 and one host thread per stream (round 2's form) — i.e. one pass (ImageProcessor::process + BundleAdjuster::bundle_adjust per
 frame: corner detection, pyramids, forward/backward LK + survivor filter, PnP-RANSAC, dedup, stereo disparity at the features,
@@ -56,8 +56,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="stereo pairs per step (per stream)")
-    ap.add_argument("--streams", type=int, default=48, help="independent stereo streams processed concurrently per GPU")
-    ap.add_argument("--groups", type=int, default=2, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
+    ap.add_argument("--streams", type=int, default=96, help="independent stereo streams processed concurrently per GPU (rounds 3-4: 48 in 2 groups)")
+    ap.add_argument("--groups", type=int, default=3, help="pipeline groups (= host driver threads) the streams are split over; 0: one host thread and one svo_pipeline per stream (round 2's shape)")
     ap.add_argument("--stagger-ms", type=float, default=0.0, help="group i starts its steps i x this many milliseconds after group 0 (inside the timed region)")
     ap.add_argument("--workload", default="kitti_cfg1", choices=["kitti_cfg1", "kitti_stream", "ba50k", "hd10k"])
     ap.add_argument("--frames", type=int, default=4541, help="kitti_stream: length of the stream (KITTI 00 has 4541 frames)")
@@ -287,15 +287,18 @@ class _Group:
 
 
 def group_lines(n_groups):
-    """HIP streams ("lines") per pipeline group so that the process stays within its 16 hardware queues: a group drives 1 tracking
-    line + chain lines + solve lines; 2 groups take the library's defaults (1 + 2 + 4 = 7 each, round 4's sweep), 3 or more groups
-    1 + 1 + 2 = 4 each (16 streams on 16 queues for 4 groups; every stream its own queue).  Lanes x groups x lines measured in round 5:
-    profiles/r05_exp_lanes_groups_honest.txt — a plateau at ~20 k frames/s from 48 lanes in 2 groups to 96 in 3; the figures of
+    """HIP streams ("lines") per pipeline group so that the process stays within its 16 hardware queues (streams that share a queue
+    serialise: 96 lanes in 3 groups gave 20.6-21.7 k frames/s with 5 lines per group and 15.7-18.2 k with 6): 2 groups take the library's
+    defaults (1 tracking + 2 chain + 4 solve lines each, round 4's sweep), 3 or more groups 1 + 1 + 2 and ONE compact line — solves the
+    admission budget of the wide form refuses leave at once in the one-workgroup form on a line of their own (round 5; without it 96 lanes
+    in 3 groups gave 19.8 k, 128 in 4 17.8 k: their lanes wait for admission).  Lanes x groups x lines measured in round 5:
+    profiles/r05_exp_lanes_groups_honest.txt — a plateau at 20-22 k frames/s from 48 lanes in 2 groups to 120 in 3; the figures of
     profiles/r05_exp_lanes_groups.txt above that are retracted (threads of dead groups were counted, see its header).
     Environment variables set by the caller win."""
     if n_groups >= 3:
         os.environ.setdefault("SVO_GROUP_CHAIN_LINES", "1")
         os.environ.setdefault("SVO_GROUP_BA_LINES", "2")
+        os.environ.setdefault("SVO_GROUP_COMPACT_LINES", "1")
 
 
 def run_kitti(args):
@@ -412,6 +415,15 @@ def run_kitti(args):
         lanes_per_launch = g0_stats["track"][1] / g0_stats["track"][0]
     out["roofline"] = front_end_roofline(frames / dt / world, args.profile_kernel, avg_us, res, k_n, lanes_per_launch, bool(NG))
     share = profile_summary()
+    if share and share.get("valu_wave_instructions_per_frame"):
+        # the resource the whole path comes closest to: wave-level VALU instructions of every kernel per stereo frame (committed
+        # SQ_INSTS_VALU pass of this workload, profiles/r05_sq_counters.txt) x this run's frames/s against the chip's VALU issue rate
+        vpf = float(share["valu_wave_instructions_per_frame"])
+        g = vpf * (frames / dt / world) / 1e9
+        out["roofline"]["chip_valu_issue"] = {
+            "bound": "valu_issue", "valu_wave_instructions_per_frame": vpf, "by_kernel_per_frame": share.get("valu_wave_instructions_per_frame_by_kernel"),
+            "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": g / VALU_ISSUE_PEAK_GINSTR,
+            "note": "per GPU; every kernel of the path together (the tracker is ~70 % of it); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
     if share:
         out["kernel_time_share"] = {"source": "profiles/r05_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
                                     "default_percent": share.get("kernel_time_share_default"),

@@ -606,7 +606,7 @@ class Pipeline:
 class PipelineGroup:
     """svo_pipeline_group wrapper: n_lanes independent stereo streams behind one caller thread (stream-batched launches)."""
 
-    STAGES = ("track", "pnp_ransac", "unused", "dedup_stereo_triangulate", "bundle_adjust", "corners_pyramids")
+    STAGES = ("track", "pnp_ransac", "host_thread_busy_us_of_call_us", "dedup_stereo_triangulate", "bundle_adjust", "corners_pyramids")
 
     def __init__(self, ctx, params, n_lanes):
         self.ctx, self.L, self.prm, self.n_lanes = ctx, ctx.L, params, n_lanes
@@ -685,7 +685,8 @@ class PipelineGroup:
         return list(out)
 
     def last_stats(self):
-        """{stage: (launches, lane-stages carried)} of the last process_batch_dev call."""
+        """{stage: (launches, lane-stages carried)} of the last process_batch_dev call; "host_thread_busy_us_of_call_us": (microseconds of the
+        driving thread's loop passes that did something, microseconds of the call's main loop)."""
         a, b = (C.c_long * 6)(), (C.c_long * 6)()
         self.ctx._chk(self.L.svo_pipeline_group_last_stats(self.h, a, b), "svo_pipeline_group_last_stats")
         return {s: (a[i], b[i]) for i, s in enumerate(self.STAGES) if s != "unused"}

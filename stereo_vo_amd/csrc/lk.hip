@@ -447,7 +447,8 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
         const int ixv = descale(__mul24(gx[0][p], iw00) + __mul24(gx[0][p + 1], iw01) + __mul24(gx[1][p], iw10) + __mul24(gx[1][p + 1], iw11), 14);
         const int iyv = descale(__mul24(gy[0][p], iw00) + __mul24(gy[0][p + 1], iw01) + __mul24(gy[1][p], iw10) + __mul24(gy[1][p + 1], iw11), 14);
         // the patches are int16 in the reference arithmetic (oracle: (short) stores)
-        tI[p] = (int)(short)ival; tX[p] = (int)(short)ixv; tY[p] = (int)(short)iyv;
+        // (what an iteration subtracts from the target's bilinear value, folded into its rounding: ((v + 256) >> 9) - t == (v + 256 - 512 t) >> 9)
+        tI[p] = (1 << 8) - ((int)(short)ival << 9); tX[p] = (int)(short)ixv; tY[p] = (int)(short)iyv;
         if (act) {
           pA[0] += __mul24(tX[p], tX[p]);
           pA[1] += __mul24(tX[p], tY[p]);
@@ -517,7 +518,7 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
       for (int p = 0; p < 7; ++p) {
         const uint32_t sel = 0x0c000c00u | ((uint32_t)(p + 1) << 16) | (uint32_t)p;  // (byte p, 0, byte p + 1, 0) of the 8-byte row
         const lk_s2 tp = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(th, tl, sel)), bp = __builtin_bit_cast(lk_s2, __builtin_amdgcn_perm(bh, bl, sel));
-        diff[p] = descale(__builtin_amdgcn_sdot2(tp, wtop, __builtin_amdgcn_sdot2(bp, wbot, 0, false), false), 9) - tI[p];
+        diff[p] = __builtin_amdgcn_sdot2(tp, wtop, __builtin_amdgcn_sdot2(bp, wbot, tI[p], false), false) >> 9;  // descale(., 9) - template, see tI
       }
       diff[7] = 0;
       int pb[2] = {0, 0};
@@ -527,6 +528,9 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
         pb[0] = __builtin_amdgcn_sdot2(d, tXp[q], pb[0], false);   // the template pairs of the idle 64th lane are zero
         pb[1] = __builtin_amdgcn_sdot2(d, tYp[q], pb[1], false);
       }
+      // (round 5 also measured the two sums finished in LDS — three DPP steps, then two ds_add_u64 of eight lanes: 119 instead of 132 VALU
+      // instructions per iteration, bit-identical, and no change in launch duration or frames/s (profiles/r05_exp_lanes_groups_honest.txt,
+      // sweep v): an iteration is a dependency chain, not an issue-bound stream.  Not kept.)
       const float b1 = wave_sum_f32(pb[0]) * FLT_SCALE;
       const float b2 = wave_sum_f32(pb[1]) * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;

@@ -819,8 +819,10 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
 
   unsigned idle_spins = 0;
   auto last_progress = std::chrono::steady_clock::now();
+  double busy_us = 0.0;  // wall time of the loop passes that did something: how much of the call the driving thread was occupied
   for (;;) {
     bool all_done = true, progressed = false;
+    const auto t_pass = std::chrono::steady_clock::now();
     // ---- advance every lane as far as the host alone can
     for (int li = 0; li < S && !error; ++li) {
       Lane* l = g->lanes[li];
@@ -1226,8 +1228,11 @@ extern "C" int svo_pipeline_group_process_batch_dev(svo_pipeline_group* g, const
     } else {
       idle_spins = 0;
       last_progress = std::chrono::steady_clock::now();
+      busy_us += std::chrono::duration<double, std::micro>(last_progress - t_pass).count();
     }
   }
+  g->launches[2] += (long)busy_us;
+  g->lanes_carried[2] += (long)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
 
   // ---- end of the batch: join every solve, fill the poses that waited for it
   for (int li = 0; li < S; ++li) {

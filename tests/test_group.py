@@ -455,6 +455,24 @@ def test_hip_group_solves_that_give_up_are_rerun_and_lose_no_frame():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"SVO_GROUP_CHAIN_FUSED": "0"}, {"SVO_GROUP_GATHER_US": "200"},
+                                 {"SVO_GROUP_COMPACT_LINES": "1", "SVO_BA_BUDGET_PERCENT": "25"},
+                                 {"SVO_GROUP_COMPACT_LINES": "2", "SVO_GROUP_BA_LINES": "1", "SVO_BA_BUDGET_PERCENT": "12"},
+                                 ])
+def test_hip_group_optional_paths_keep_parity(env):
+    """Round 5's scheduling knobs of a pipeline group must not change a bit: the keyframe chain with a host turn between the PnP and the
+    stereo launch again (default: the stereo launch rides right behind PnP and reads the reprojection matrix from the device record,
+    host/chain_math.h), the gather policy, compact lines (the admission budget cut so far that most solves take them).  Read once per process: one child each; 6 lanes x 16 frames against the oracle."""
+    import os
+    import subprocess
+    import sys
+    e = dict(os.environ)
+    e.update(env)
+    out = subprocess.run([sys.executable, "-c", _child_code(n=16, lanes=6, batch=8, seed=0x5EED0D00, reps=2)], env=e, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "child ok" in out.stdout, out.stderr[-3000:]
+
+
+@pytest.mark.gpu
 def test_hip_two_processes_share_one_gpu_without_losing_a_solve():
     """Two PROCESSES drive pipeline groups on the same GPU at once.  The admission of the wide solves counts the workgroups of every live
     process on the device (/dev/shm/svo_admit_<PCI bus id>, csrc/ba.hip), here with 150 % of the budget to make refusals and

@@ -117,6 +117,18 @@ if agg:
             summary["lk_fb_waves_per_launch"] = agg[lk]["SQ_WAVES"] / calls[lk]
             summary["lk_fb_valu_instructions_per_wave"] = agg[lk]["SQ_INSTS_VALU"] / max(agg[lk]["SQ_WAVES"], 1.0)
             break
+    # chip-wide VALU issue: wave-level VALU instructions of EVERY kernel of the pass per stereo frame (the pass ran
+    # `bench.py --steps 3 --warmup 1 --streams 32 --groups 1`: frames from its own line) — bench.py multiplies by its frames/s
+    sq_frames = 4 * 16 * 32
+    try:
+        for ln in open(os.path.join(src, "bench_sq.log")):
+            if ln.startswith('{"metric"'):
+                b = json.loads(ln)
+                sq_frames = (b["steps"] + b["warmup"]) * b["config"]["batch_per_stream"] * b["config"]["streams_per_gpu"]
+    except Exception:
+        pass
+    summary["valu_wave_instructions_per_frame"] = sum(agg[k]["SQ_INSTS_VALU"] for k in agg) / sq_frames
+    summary["valu_wave_instructions_per_frame_by_kernel"] = {k: round(agg[k]["SQ_INSTS_VALU"] / sq_frames) for k in sorted(agg, key=lambda k: -agg[k]["SQ_INSTS_VALU"])[:8]}
     for sk in ("ba_lm_compact_kernel", "ba_lm_kernel"):
         if sk in agg:
             pre = "ba_lm" if sk == "ba_lm_kernel" else "ba_lm_compact"
