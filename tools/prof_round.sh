@@ -12,7 +12,7 @@ cd "$GRAFT_REPO_ROOT"
 # every file of this round comes from ONE tree: its identity goes into the output directory (the GPU box has no .git: the
 # caller passes the commit, tools/prof_round.sh <tag> <commit>), together with the library's own build stamp
 echo "commit ${2:-unknown}; libsvo_hip.so sha256 $(sha256sum stereo_vo_amd/libsvo_hip.so | cut -c1-16); $(date -u +%Y-%m-%dT%H:%MZ)" > "$OUT/STAMP.txt"
-echo "[1/5] kernel trace, default bench (128 streams in 4 pipeline groups)"
+echo "[1/5] kernel trace, default bench"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/s8" -o p -- python3 bench.py --no-cpu-baseline --no-other-workloads --no-single --no-streaming > "$OUT/bench_s8.log" 2>&1
 grep '^{"metric"' "$OUT/bench_s8.log" | tail -1 > "$OUT/bench_s8.json"
 python3 tools/gpu_busy.py "$OUT/s8/p_kernel_trace.csv" 100 > "$OUT/gpu_busy_s8.txt" || true
