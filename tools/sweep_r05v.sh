@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: tracker iteration with its two sums finished in LDS (119 VALU instructions per iteration instead of 132 / 146): parity
+# NOTE: the LDS form of the sums lived in the working tree of the experiment only (described in csrc/lk.hip at the iteration sums); result in profiles/r05_exp_lanes_groups_honest.txt
 # tests, then the new default (96 lanes / 3 groups / 1 compact line) and round 4's shape
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r5_sweep_v.txt

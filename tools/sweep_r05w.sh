@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 5: what is the chip full OF?  (a) the pause between two polls of a waiting solve workgroup (SVO_LM_POLL_SLEEPS x 128 cycles),
+# NOTE: SVO_LM_POLL_SLEEPS lived in the working tree of the experiment only; the result is in profiles/r05_exp_lanes_groups_honest.txt
 # (b) how busy a group's driving host thread is ("host_thread_busy_us_of_call_us" in launches_per_step_of_group_0)
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/r5_sweep_w.txt
