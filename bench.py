@@ -145,6 +145,25 @@ def cpu_baseline(p, L, R, frames):
 RES_KEY = lambda r: (r.n_detected, r.n_tracked, r.n_inliers, r.n_new, r.is_keyframe, r.ba_iterations, list(r.pose7))
 
 
+def run_threads(fns):
+    """One thread per callable; returns when all have ended and RAISES the first exception any of them died of.  (Until the middle of
+    round 5 the bench joined its group threads without looking: a group that died on an error shortened the run instead of failing
+    it, and the frames it never processed were counted — profiles/r05_exp_reset_fill.txt.)"""
+    import threading
+    errs = []
+
+    def guarded(fn):
+        try:
+            fn()
+        except BaseException as e:  # noqa: BLE001 — a thread that dies must fail the run, not shorten it
+            errs.append(e)
+    th = [threading.Thread(target=guarded, args=(fn,)) for fn in fns]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    if errs:
+        raise errs[0]
+
+
 def group_self_parity(groups, B):
     """Every lane of every group, every timed step: the SAME frames from a reset group must give the SAME result records, bit for
     bit (a stale or late hand-over inside a solve would show here on whatever lane and step it hits)."""
@@ -326,20 +345,12 @@ def run_kitti(args):
             for _ in range(k):
                 streams[0].step()
             return
-        errs = []
         def work(st, delay):
-            try:
-                if delay > 0:
-                    time.sleep(delay)  # inside the timed region: the groups' steps start out of phase (a group's step is a dense detection burst followed by a latency-bound tail)
-                for _ in range(k):
-                    st.step()
-            except BaseException as e:  # noqa: BLE001 — a thread that dies must fail the run, not shorten it
-                errs.append(e)
-        th = [threading.Thread(target=work, args=(st, 1e-3 * args.stagger_ms * i)) for i, st in enumerate(streams)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        if errs:
-            raise errs[0]
+            if delay > 0:
+                time.sleep(delay)  # inside the timed region: the groups' steps start out of phase (a group's step is a dense detection burst followed by a latency-bound tail)
+            for _ in range(k):
+                st.step()
+        run_threads([lambda st=st, d=1e-3 * args.stagger_ms * i: work(st, d) for i, st in enumerate(streams)])
 
     run_steps(args.warmup)
     # single-stream rate (latency-bound: one sequential VO chain) measured first, in the same run
@@ -461,19 +472,11 @@ def run_kitti(args):
             g.fill_staging()
             g.clear_counters()
 
-        serrs = []
         def swork(st, k):
-            try:
-                for _ in range(k):
-                    st.step_streaming()
-            except BaseException as e:  # noqa: BLE001
-                serrs.append(e)
+            for _ in range(k):
+                st.step_streaming()
         def run_streaming(k):
-            th = [threading.Thread(target=swork, args=(st, k)) for st in streams]
-            [t.start() for t in th]
-            [t.join() for t in th]
-            if serrs:
-                raise serrs[0]
+            run_threads([lambda st=st: swork(st, k) for st in streams])
         run_streaming(max(1, args.warmup))
         for g in streams:
             g.clear_counters()

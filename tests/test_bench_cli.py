@@ -61,3 +61,27 @@ def test_bench_gpu_count_reads_the_environment_not_the_runtime():
             os.environ.pop(k, None)
             if v is not None:
                 os.environ[k] = v
+
+
+def test_bench_fails_when_a_group_thread_dies_and_when_groups_ran_different_step_counts():
+    """Round 5: a pipeline group's thread that raised used to end silently while the bench went on and divided the frames of ALL groups
+    by the elapsed time (figures up to 2.5x too high, retracted in profiles/).  run_threads must re-raise; group_self_parity must refuse
+    groups whose recorded step counts differ."""
+    sys.path.insert(0, ROOT)
+    import importlib
+    import pytest
+    bench = importlib.import_module("bench")
+    done = []
+    with pytest.raises(RuntimeError, match="store"):
+        bench.run_threads([lambda: done.append(1), lambda: (_ for _ in ()).throw(RuntimeError("landmark store belongs to another id")), lambda: done.append(2)])
+    assert sorted(done) == [1, 2]  # the others ran to their end first
+    bench.run_threads([lambda: done.append(3)])
+
+    class G:
+        def __init__(self, n, raws):
+            self.n, self.raws = n, raws
+    rec = bytes(range(16))
+    ok = bench.group_self_parity([G(2, [rec * 2 * 4] * 3), G(2, [rec * 2 * 4] * 3)], 4)
+    assert ok["lanes_checked"] == 4 and ok["steps_checked"] == 3 and ok["lane_steps_that_differ_from_step_0"] == 0
+    with pytest.raises(RuntimeError, match="fewer steps"):
+        bench.group_self_parity([G(2, [rec * 2 * 4] * 3), G(2, [rec * 2 * 4] * 1)], 4)
