@@ -46,6 +46,8 @@ MAXC, QUALITY, MIN_DIST, MAX_FEAT, WINDOW = 1500, 0.02, 10.0, 2000, 5
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0        # ... and the copy bandwidth that guide measured
 VALU_ISSUE_PEAK_GINSTR = 1228.8  # 256 CUs x 4 SIMDs x 2.4 GHz / 2 (one wave64 VALU instruction per 2 cycles per SIMD)
+VALU_CYCLES_TRACKER_MIX = 3.6     # SIMD cycles per VALU instruction of the tracker's iteration (81 half-rate + 51 full-rate, measured rates)
+VALU_CYCLES_OTHER_KERNELS = 3.4   # assumed for the other kernels (between the measured 2.5 and 4.3)
 FP64_VEC_PEAK_TFLOPS = 78.6  # public MI355X FP64 vector spec (not in the local guide)
 PROFILE_SUMMARY = os.path.join(ROOT, "profiles", "r05_summary.json")  # written by tools/prof_round.sh + prof_summary.py
 
@@ -431,10 +433,19 @@ def run_kitti(args):
         # SQ_INSTS_VALU pass of this workload, profiles/r05_sq_counters.txt) x this run's frames/s against the chip's VALU issue rate
         vpf = float(share["valu_wave_instructions_per_frame"])
         g = vpf * (frames / dt / world) / 1e9
+        byk = share.get("valu_wave_instructions_per_frame_by_kernel") or {}
+        lk = float(sum(v for k, v in byk.items() if k.startswith("lk_fb")))
+        # SIMD cycles: the tracker's iteration is 81 half-rate (4.3 cycles) + 51 full-rate (2.5) instructions = 3.6 cycles per instruction
+        # (tools/exp/issue_rate.hip on this GPU, profiles/r05_exp_issue_rate.txt, and the kernel's ISA); the other kernels at the mid-point 3.4
+        simd_cycles_per_frame = lk * VALU_CYCLES_TRACKER_MIX + (vpf - lk) * VALU_CYCLES_OTHER_KERNELS
+        ceiling = 256 * 4 * 2.4e9 / simd_cycles_per_frame
         out["roofline"]["chip_valu_issue"] = {
-            "bound": "valu_issue", "valu_wave_instructions_per_frame": vpf, "by_kernel_per_frame": share.get("valu_wave_instructions_per_frame_by_kernel"),
-            "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac": g / VALU_ISSUE_PEAK_GINSTR,
-            "note": "per GPU; every kernel of the path together (the tracker is ~70 % of it); peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction"}
+            "bound": "valu_issue", "valu_wave_instructions_per_frame": vpf, "by_kernel_per_frame": byk,
+            "achieved_ginstr_s": g, "peak_ginstr_s": VALU_ISSUE_PEAK_GINSTR, "frac_of_full_rate_issue": g / VALU_ISSUE_PEAK_GINSTR,
+            "simd_cycles_per_frame": simd_cycles_per_frame, "frames_per_s_if_every_simd_computed_all_the_time": ceiling,
+            "frac": (frames / dt / world) / ceiling,
+            "note": "per GPU; every kernel of the path together (the tracker ~70 %); full-rate peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 "
+                    "instruction, but 60 % of the tracker's instructions are half-rate on gfx950: frac prices them at their measured cost"}
     if share:
         out["kernel_time_share"] = {"source": "profiles/r05_kernel_stats_*.csv (rocprofv3 --kernel-trace --stats of this command)",
                                     "default_percent": share.get("kernel_time_share_default"),

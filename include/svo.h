@@ -431,8 +431,9 @@ int svo_pipeline_group_process_batch(svo_pipeline_group* g, const uint8_t* left,
                                      int batch, svo_frame_result* results);
 int svo_pipeline_group_get_tracked(svo_pipeline_group* g, int lane, int64_t* ids, float* xy, int capacity, int* n);
 /* Launch statistics of the last process_batch call, by stage: 0 track (LK + compaction), 1 PnP-RANSAC (hypotheses, bookkeeping and
- * refinement in one launch), 2 unused (round 3: PnP refinement), 3 dedup / stereo + triangulation, 4 bundle-adjustment solves, 5 corner detection + pyramids;
- * launches6[i] launches carried lanes6[i] lane-stages in total. */
+ * refinement in one launch), 3 dedup / stereo + triangulation, 4 bundle-adjustment solves, 5 corner detection + pyramids;
+ * launches6[i] launches carried lanes6[i] lane-stages in total.  Slot 2 (round 5) is the driving thread instead: launches6[2] = microseconds of
+ * its loop passes that did something, lanes6[2] = microseconds of the call's main loop. */
 int svo_pipeline_group_last_stats(const svo_pipeline_group* g, long* launches6, long* lanes6);
 /* Algorithmic work (SURVEY 8(d) per-iteration figures: 466 flops per observation + 50 + 144 L + 216 L (L + 1) / 2 per landmark;
  * 24 B per observation + 48 B per landmark + 56 B per pose) of the bundle adjustments all lanes have finished since the last
