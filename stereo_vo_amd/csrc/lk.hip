@@ -528,9 +528,14 @@ __device__ uint8_t lk_point_wave(const Pyr& A, const Pyr& B, float px0, float py
         pb[0] = __builtin_amdgcn_sdot2(d, tXp[q], pb[0], false);   // the template pairs of the idle 64th lane are zero
         pb[1] = __builtin_amdgcn_sdot2(d, tYp[q], pb[1], false);
       }
-      // (round 5 also measured the two sums finished in LDS — three DPP steps, then two ds_add_u64 of eight lanes: 119 instead of 132 VALU
-      // instructions per iteration, bit-identical, and no change in launch duration or frames/s (profiles/r05_exp_lanes_groups_honest.txt,
-      // sweep v): an iteration is a dependency chain, not an issue-bound stream.  Not kept.)
+      // (round 5 also measured, both bit-identical and both WITHOUT any change in launch duration or frames/s, hence not kept
+      // (profiles/r05_exp_lanes_groups_honest.txt, sweeps v and ab): the two sums finished in LDS — three DPP steps, then two ds_add_u64
+      // of eight lanes, 119 instead of 132 VALU instructions per iteration; and the bilinear values above by full-rate f32 FMAs on an
+      // f32 copy of the staged region (every value a multiple of 2^-9 below 2^14: exact) — 7 v_pk_fma_f32 + 14 v_fmac_f32 +
+      // 7 v_cvt_flr_i32_f32 for the 14 permutes, 14 dot products, 4 byte alignments and 7 shifts: 464 instead of 549 SIMD cycles per
+      // iteration at the measured issue rates (tools/exp/issue_rate.hip) — once the copy's row pitch was odd; at pitch 32 the 21 rows
+      // of a column met in two LDS banks and the form ran 20 % slower.  A tracking launch lasts as long as its slowest feature
+      // (~650 us against ~80 us for the average wavefront): cheaper instructions shorten the average, not the launch.)
       const float b1 = wave_sum_f32(pb[0]) * FLT_SCALE;
       const float b2 = wave_sum_f32(pb[1]) * FLT_SCALE;
       const float dx = (A12 * b2 - A22 * b1) * D;
