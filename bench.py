@@ -6,7 +6,7 @@ stream are re-processed every step from a reset pipeline (identical work per ste
 `--workload kitti_stream` is the streaming figure (BASELINE configs[2]: 4541 frames through the host-pointer entry,
 upload included, 10-keyframe window, nothing reset).  The default line also carries `streaming` (the same lanes fed from host
 memory through svo_pipeline_group_staging / _upload / _process_uploaded, upload timed), `single_stream`, `parity_self` (every
-lane of every timed step against the first step) and `parity_vs_cpu` (8 lanes against the CPU oracle), and `other_workloads`
+lane of every timed step against the first step) and `parity_vs_cpu` (4 lanes of every group against the CPU oracle), and `other_workloads`
 (kitti_stream, ba50k sparse and dense, hd_1280x720_10k), each with its own roofline / cpu_baseline / parity record.
 
 A "step" = one pass of the whole hot path on every one of `--streams` (default 96) independent stereo streams that share the
